@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""paths/sec (train+score) of the KPRN hot path on MI355X -- BASELINE.json's metric.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic paths already resident in
+HBM: ONE MyOptimizer:trainBatch (zeroPad, zeroGrad, forward, BCE, backward, Adam, zeroPad;
+release/songPathRnn/model/optimizer/MyOptimizer.lua:177-221) followed by ONE scoring forward
+(release/songPathRnn/eval/test_from_checkpoint.lua:109) over the same batch, i.e. the
+"combined = N_paths / (t_train + t_score)" of SURVEY.md section 8d.  value = paths processed by
+all ranks / max-over-ranks wall time of the K timed steps.
+
+Workload = BASELINE.json configs[1] ("C2", reading A of "d=64"): path_len T=6, D=H=64
+(d_type 16 | d_entity 32 | d_relation 16), 2-layer FastLSTM, fp32, KKBox vocabulary
+(2 851 220 entities / 6 types / 9 relations, run_scripts/config.sh:24-26), 46 labels, LogSumExp
+pool, Adam lr 1e-3.  Batches are bucketed by #paths-per-pair like the reference's files
+(movie_data_format.py:301-314) and sized to ~--paths-per-step paths.
+
+N>1: one process per GPU (torchrun), pairs sharded across ranks, dense-gradient all-reduce +
+sparse entity-row all-gather over RCCL (kprn_amd/dp.py); weak scaling.
+
+Extra objects on the JSON line: "roofline" (dominant kernel family, HIP events on the engine's
+stream inside the timed region) and "cpu_baseline" (the float64 oracle with OpenMP on the host
+cores, bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS_F32_MFMA = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--paths-per-step", type=int, default=32768, help="paths per rank per step")
+    ap.add_argument("--dims", default="A", choices=["A", "B"], help="A: D=H=64 (16/32/16); B: 64/64/64 -> D=H=192")
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--T", type=int, default=6)
+    ap.add_argument("--entities", type=int, default=2851220)
+    ap.add_argument("--impl", default="auto", choices=["auto", "generic"])
+    ap.add_argument("--entity-update", type=int, default=0, help="0 lazy-exact, 1 dense (as the reference)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--train-only", action="store_true")
+    ap.add_argument("--score-only", action="store_true")
+    return ap.parse_args()
+
+
+def dims_of(a):
+    if a.dims == "A":
+        return 16, 32, 16, 64
+    return 64, 64, 64, 192
+
+
+def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr):
+    """(bound, algorithmic work per launch) for a kernel family of the engine; None if unknown."""
+    g = 4 * H
+    if name == "lstm_fused_fwd":
+        fl = 0
+        for l in range(L):
+            din = D if l == 0 else H
+            fl += T * 2 * g * (din + H)
+        return "mfma", N * (fl + 2 * H * C)
+    if name == "lstm_fused_bwd":
+        fl = 0
+        for l in range(L):
+            din = D if l == 0 else H
+            fl += T * 2 * g * (din + H)
+        return "mfma", 2 * N * fl
+    tbl = {
+        "gemm_i2g_fwd": 2 * T * N * g * D, "gemm_o2g_fwd": 2 * N * g * H, "gemm_head_fwd": 2 * N * C * H,
+        "gemm_o2g_bwd_dh": 2 * N * g * H, "gemm_o2g_bwd_dw": 2 * (T - 1) * N * g * H,
+        "gemm_i2g_bwd_dw": 2 * T * N * g * D, "gemm_i2g_bwd_dx": 2 * T * N * g * D,
+    }
+    if name in tbl:
+        return "mfma", tbl[name]
+    if name == "embed_gather":
+        return "hbm", N * T * ((nT * dt + de + dr) * 4 + F * 4)
+    if name == "embed_scatter":
+        return "hbm", N * T * (D * 4 + F * 4)
+    return None
+
+
+def cpu_baseline(a, T, dt, de, dr, H, L, seconds):
+    """float64 oracle (CPU restatement of the reference, kind "port") on the host cores:
+    model-only train pass (forward + BCE + backward, no dense optimiser sweep) + scoring pass over
+    the same bounded sample, like the GPU step.  A reported baseline, not the target."""
+    from oracle.oracle import Oracle, make_cfg
+    from kprn_amd import synth
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    Ve = 100000  # the entity table size does not affect the model-only flavour; keep RAM small
+    cfg = make_cfg(Vt=6, Ve=Ve, Vr=9, dt=dt, de=de, dr=dr, H=H, L=L)
+    orc = Oracle(cfg, np.float64)
+    theta = orc.init_params(1, 0.1)
+    P = 2
+    pairs = 256
+    idx, labels = synth.make_paths(pairs, P, T, Ve=Ve, seed=9)
+    t0 = time.perf_counter()
+    orc.forward_backward(theta, idx, labels)
+    orc.forward(theta, idx)
+    dt0 = time.perf_counter() - t0
+    rate = pairs * P / max(dt0, 1e-6)
+    pairs = int(max(256, min(200000, rate * seconds / P)))
+    idx, labels = synth.make_paths(pairs, P, T, Ve=Ve, seed=10)
+    t0 = time.perf_counter()
+    orc.forward_backward(theta, idx, labels)
+    t1 = time.perf_counter()
+    orc.forward(theta, idx)
+    t2 = time.perf_counter()
+    n = pairs * P
+    return {"value": n / (t2 - t0), "unit": "paths/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic paths (P={P}, T={T}, D=H={H}, L={L}): float64 oracle forward+BCE+backward then scoring "
+                      f"forward, OpenMP over pairs; model-only flavour (no dense Adam sweep over the entity table)",
+            "train_paths_per_s": n / (t1 - t0), "score_paths_per_s": n / (t2 - t1)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: kprn_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from kprn_amd import _ffi, synth, dp
+    dt_, de_, dr_, H = dims_of(a)
+    D, L, T, C, F, nT = dt_ + de_ + dr_, a.layers, a.T, 46, 3, 1
+    Vt, Ve, Vr = 6, a.entities, 9
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = _ffi.Engine(Vt, Ve, Vr, dt_, de_, dr_, H, L, F=F, num_types=nT, C_=C, reducer=2, device_id=local_rank,
+                      rank=rank, world=world, param_init=0.1, seed=12345, stream=stream)
+    eng.set_option("impl", a.impl)
+    opt = _ffi.make_opt(method=1, lr=1e-3, entity_update=a.entity_update)
+
+    # bucketed batches (constant P per batch, like the reference's train.txt.<P>.torch files)
+    Ps = [1, 2, 3, 4, 5, 8]
+    batches = []
+    for i, P in enumerate(Ps):
+        pairs = max(1, a.paths_per_step // P)
+        idx, labels = synth.make_paths(pairs, P, T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, num_types=nT, seed=12345 + 97 * i + 7919 * rank)
+        batches.append(eng.batch(idx, labels))
+    paths_of = [b.n_paths for b in batches]
+
+    dpx = None
+    if world > 1:
+        dpx = dp.DataParallel(dp.GpuAdapter(eng, dev))
+        dpx.set_capacity(max(int(b.B) * b.P * b.T for b in batches))  # safe upper bound; tightened below
+        # tight capacity: largest distinct-row count of any batch on any rank
+        # (n_uniq is not exposed through ctypes; one dry backward per batch reads it back)
+        mx = 0
+        for b in batches:
+            eng.backward(b, 1, False, 0.0, want_loss=False)
+            mx = max(mx, eng.sparse_grad_capacity())
+        dpx.set_capacity(mx)
+
+    def step(i):
+        b = batches[i % len(batches)]
+        if not a.score_only:
+            if dpx is not None:
+                dpx.train_step(b, opt, 1)
+            else:
+                eng.train_step(b, opt, 1, want_loss=False)
+        if not a.train_only:
+            eng.forward_async(b, 1)
+        return paths_of[i % len(batches)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    eng.sync()
+    prof = not a.no_kernel_events
+    eng.profile_reset()
+    eng.profile(prof)
+    barrier()
+    t0 = time.perf_counter()
+    npaths = 0
+    for i in range(a.steps):
+        npaths += step(a.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tn = torch.tensor([npaths], dtype=torch.float64, device=dev)
+        dist.all_reduce(tn, op=dist.ReduceOp.SUM)
+        npaths_total = float(tn.item())
+    else:
+        npaths_total = float(npaths)
+
+    loss = eng.read_loss()
+    assert np.isfinite(loss), "training diverged"
+
+    # ---- roofline of the dominant kernel family (HIP events recorded inside the timed region)
+    roofline = None
+    fams = eng.profile_get() if prof else {}
+    kernels = {}
+    if fams:
+        # algorithmic work per family over the timed steps
+        for name, (ms, launches) in fams.items():
+            kernels[name] = {"ms": round(ms, 4), "launches": launches}
+        dom = max(fams.items(), key=lambda kv: kv[1][0])
+        name, (ms, launches) = dom
+        # launches of a family all see the same N within a step; average work per launch over steps
+        work = 0.0
+        known = True
+        for i in range(a.steps):
+            N = paths_of[(a.warmup + i) % len(batches)]
+            fw = family_work(name, N, T, D, H, L, C, F, nT, dt_, de_, dr_)
+            if fw is None:
+                known = False
+                break
+            work += fw[1]
+        if known and launches > 0 and ms > 0:
+            bound = family_work(name, 1, T, D, H, L, C, F, nT, dt_, de_, dr_)[0]
+            # every launch of a family inside one step sees that step's N; launches per step is constant
+            total_work = work * (launches / a.steps)
+            if bound == "mfma":
+                achieved = total_work / (ms * 1e-3) / 1e12
+                peak, unit = PEAK_TFLOPS_F32_MFMA, "TFLOP/s"
+            else:
+                achieved = total_work / (ms * 1e-3) / 1e9
+                peak, unit = PEAK_HBM_GBS, "GB/s"
+            roofline = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                        "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(ms / launches, 5),
+                        "launches": launches}
+        else:
+            roofline = {"kernel": name, "bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
+                        "traffic": None, "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": launches}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a, T, dt_, de_, dr_, H, L, a.cpu_seconds)
+
+    if rank == 0:
+        value = npaths_total / elapsed
+        fwd_flops = sum(T * 2 * 4 * H * ((D if l == 0 else H) + H) for l in range(L)) + 2 * H * C
+        step_flops = (0 if a.score_only else 3 * fwd_flops) + (0 if a.train_only else fwd_flops)
+        out = {
+            "metric": "paths/sec (train+score) at path_len=6 d=64", "value": round(value, 1), "unit": "paths/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2 KKBOX-MI synthetic: T={T}, D=H={H} ({dt_}/{de_}/{dr_}), L={L} FastLSTM, fp32, Ve={Ve}, "
+                                   f"C=46, LSE pool, Adam; train step + scoring pass per batch",
+                       "paths_per_step_per_gpu": a.paths_per_step, "paths_per_pair_buckets": Ps, "impl": a.impl,
+                       "entity_update": "lazy-exact" if a.entity_update == 0 else "dense",
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "model_tflops": round(value * step_flops / 1e12, 3),
+            "mfma_frac_end_to_end": round(value * step_flops / 1e12 / (PEAK_TFLOPS_F32_MFMA * world), 4),
+            "final_loss": round(loss, 6),
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+/*
+ * kprn.h -- C ABI of libkprn.so: the MI355X (gfx950) path-scoring engine behind the
+ * songPathRnn training / scoring surface of eBay/KPRN.
+ *
+ * The reference has NO native boundary; the operator API this library replaces is the
+ * Torch7 nn.Module protocol as consumed by exactly two callers:
+ *   release/songPathRnn/model/optimizer/MyOptimizer.lua:177-221  (trainBatch: zeroGrad,
+ *       forward, BCE, backward, clip/L2, optim step, zeroPadTokens)
+ *   release/songPathRnn/eval/test_from_checkpoint.lua:98-118     (model:forward -> preds[i])
+ * Each entry point below cites the reference lines it stands in for.  The binding a
+ * maintainer adds on the reference side (LuaJIT ffi.cdef) is in INTEGRATION.md and
+ * bindings/kprn.lua.
+ *
+ * Conventions
+ *  - plain C, no torch types; every function returns 0 on success or a negative
+ *    kprn_status; the message is available from kprn_last_error(h) (h may be NULL for
+ *    a failed kprn_create).  Nothing throws or aborts across the ABI.
+ *  - the caller owns every host buffer it passes; the library owns all device memory.
+ *  - indices are int32, 1-BASED, row-major [B,P,T,F] exactly like the reference's
+ *    data tensor (release/songPathRnn/model/batcher/Batcher.lua:51): F columns per step =
+ *    numEntityTypes type ids, then entity id, then relation id
+ *    (model/net/FeatureEmbedding.lua:51,88,31).  Out-of-range ids are an error
+ *    (KPRN_E_INDEX), never undefined behaviour.
+ *  - one handle <-> one GPU <-> one host thread at a time.  Work is queued on one HIP
+ *    stream; functions that return results to host memory synchronise that stream,
+ *    functions documented "async" do not.
+ *  - parameters are named and ordered as nn.Module:getParameters() flattens them
+ *    (MyOptimizer.lua:42):  type_emb[Vt,dt] | entity_emb[Ve,de] | relation_emb[Vr,dr] |
+ *    lstm{l}.i2g.weight[4H,D_l] lstm{l}.i2g.bias[4H] lstm{l}.o2g.weight[4H,H] (l=1..L) |
+ *    out.weight[C,H] | out.bias[C]          (host side: row-major fp32)
+ *    FastLSTM gate order inside the 4H rows: input, candidate(tanh), forget, output.
+ */
+#ifndef KPRN_H
+#define KPRN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kprn_handle kprn_handle;
+typedef struct kprn_batch kprn_batch;
+
+typedef enum {
+  KPRN_OK = 0,
+  KPRN_E_ARG = -1,          /* bad argument / shape / name                        */
+  KPRN_E_INDEX = -2,        /* an id outside 1..V                                 */
+  KPRN_E_DEVICE = -3,       /* HIP error (message has the HIP string)             */
+  KPRN_E_UNSUPPORTED = -4,  /* valid reference option not built yet               */
+  KPRN_E_IO = -5,
+  KPRN_E_NOMEM = -6
+} kprn_status;
+
+/* mirrors the torch.CmdLine flags of model/OneModel.lua:27-87 that shape the graph */
+typedef struct {
+  int32_t Vt, Ve, Vr;        /* -entityTypeVocabSize -entityVocabSize -relationVocabSize        */
+  int32_t dt, de, dr;        /* -entityTypeEmbeddingDim -entityEmbeddingDim -relationEmbeddingDim */
+  int32_t F;                 /* -numFeatureTemplates                                             */
+  int32_t num_types;         /* -numEntityTypes                                                  */
+  int32_t H;                 /* -rnnHidSize                                                      */
+  int32_t L;                 /* -numLayers  (L>1 requires dt+de+dr == H, OneModel.lua:236,270)   */
+  int32_t C;                 /* labelDimension, 46 in the reference (OneModel.lua:119)           */
+  int32_t rnn_type;          /* 0 = lstm (nn.FastLSTM).  1 = rnn, 2 = gru -> KPRN_E_UNSUPPORTED  */
+  int32_t reducer;           /* -topK: 0 = Max, 1 = TopK+Mean, 2 = LogSumExp (OneModel.lua:284-293) */
+  int32_t K;                 /* -K                                                               */
+  int32_t device_id;         /* HIP device ordinal                                               */
+  int32_t rank, world;       /* data-parallel position; loss is scaled by the GLOBAL batch       */
+  float param_init;          /* -paramInit: uniform(-a, a) over every parameter (OneModel.lua:306-309) */
+  uint64_t seed;             /* init RNG seed (the reference leaves it unseeded, OneModel.lua:123) */
+  void* stream;              /* optional caller hipStream_t to queue on; NULL = library-owned    */
+} kprn_config;
+
+/* mirrors optInfo / optConfig (OneModel.lua:340-384) */
+typedef struct {
+  int32_t method;            /* -useAdam: 1 = optim.adam, 0 = optim.adagrad                      */
+  float lr;                  /* -learningRate                                                    */
+  float beta1, beta2, eps;   /* 0.9, 0.999, -epsilon                                             */
+  float lr_decay;            /* -learningRateDecay (adagrad)                                     */
+  int32_t regularize;        /* -regularize: gates BOTH clip and L2 (MyOptimizer.lua:196)        */
+  int32_t use_grad_clip;     /* -useGradClip                                                     */
+  float grad_clip_norm;      /* -gradClipNorm                                                    */
+  float l2;                  /* -l2                                                              */
+  int32_t bce_literal;       /* 1 = nn.BCECriterion backward then nn.Sigmoid backward, eps 1e-12;
+                                0 = fused (p - t)/B (identical away from fp32 saturation)         */
+  int32_t entity_update;     /* 0 = lazy-exact: rows of entity_emb are brought up to date when
+                                    touched; bit-identical to the dense update of optim.adam
+                                1 = dense: every row every step, as the reference does          */
+} kprn_opt;
+
+/* ---- lifetime -------------------------------------------------------------------- */
+/* OneModel.lua:204-309: build predictor_net + reducer, init uniform(-paramInit,paramInit) */
+int kprn_create(const kprn_config* cfg, kprn_handle** out);
+void kprn_destroy(kprn_handle* h);
+const char* kprn_last_error(const kprn_handle* h);
+/* library / kernel build id, e.g. "kprn-amd 0.1 gfx950" */
+const char* kprn_version(void);
+
+/* ---- parameters (nn.Module:parameters()/getParameters(), MyOptimizer.lua:42) -------- */
+int kprn_num_params(kprn_handle* h, int64_t* n);
+/* n = element count of dst/src, must match the tensor */
+int kprn_get_param(kprn_handle* h, const char* name, float* dst, int64_t n);
+int kprn_set_param(kprn_handle* h, const char* name, const float* src, int64_t n);
+int kprn_get_grad(kprn_handle* h, const char* name, float* dst, int64_t n);
+/* whole flat vector in getParameters() order */
+int kprn_get_flat_params(kprn_handle* h, float* dst, int64_t n);
+int kprn_set_flat_params(kprn_handle* h, const float* src, int64_t n);
+int kprn_get_flat_grads(kprn_handle* h, float* dst, int64_t n);
+/* optimiser state (optState: adam m,v / adagrad paramVariance) -- slot 0 or 1 */
+int kprn_get_flat_opt_state(kprn_handle* h, int32_t slot, float* dst, int64_t n);
+/* MyOptimizer:zeroPadTokens (MyOptimizer.lua:74-93): zero row V (1-based) of each table */
+int kprn_zero_pad_tokens(kprn_handle* h);
+
+/* ---- batches resident in HBM (BatcherFileList:populateGPUTensor, BatcherFileList.lua:78-96) */
+/* validates every id against its vocabulary; labels may be NULL for scoring            */
+int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels,
+                      int32_t B, int32_t P, int32_t T, int32_t F, kprn_batch** out);
+void kprn_batch_destroy(kprn_handle* h, kprn_batch* b);
+
+/* ---- scoring: model:forward(inputs) (test_from_checkpoint.lua:81-82,109) ------------
+ * probs[B]      = Sigmoid(reduce_p(mapper))[:, classId]       (Select(2,classId))
+ * all_probs     = optional [B,C] (before Select)
+ * pooled        = optional [B,C] reducer output before Sigmoid
+ * path_scores   = optional [B*P,C] mapper output (nn.Linear(H,46), OneModel.lua:275)      */
+int kprn_forward(kprn_handle* h, const int32_t* idx, int32_t B, int32_t P, int32_t T, int32_t F,
+                 int32_t class_id, float* probs, float* all_probs);
+int kprn_forward_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id,
+                       float* probs, float* all_probs, float* pooled, float* path_scores);
+/* async variant for throughput loops: results stay on the device until kprn_read_probs  */
+int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id);
+int kprn_read_probs(kprn_handle* h, float* probs, int32_t B);
+/* embedding sub-net output x[N,T,D] (FeatureEmbedding.lua:112-121), for bit-exact checks */
+int kprn_embed(kprn_handle* h, const int32_t* idx, int64_t N, int32_t T, int32_t F, float* x);
+
+/* ---- training ---------------------------------------------------------------------- */
+/* fEval of MyOptimizer.lua:184-195: zeroGradParameters; forward; BCE; backward.
+ * inv_batch = 0 -> 1/B; data-parallel callers pass 1/B_global.  loss may be NULL (async). */
+int kprn_backward_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, int32_t bce_literal,
+                        float inv_batch, float* loss);
+/* MyOptimizer.lua:196-219 on the gradients now in the handle: clip/L2 iff regularize==1,
+ * optim step, zeroPadTokens.  Async.                                                     */
+int kprn_apply_update(kprn_handle* h, const kprn_opt* opt);
+/* MyOptimizer:trainBatch = zeroPadTokens + kprn_backward_batch + kprn_apply_update        */
+int kprn_train_step(kprn_handle* h, const int32_t* idx, int32_t B, int32_t P, int32_t T, int32_t F,
+                    const float* labels, int32_t class_id, const kprn_opt* opt, float* loss);
+int kprn_train_step_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, const kprn_opt* opt,
+                          float* loss /* NULL = async */);
+/* loss of the most recent backward, once the stream has drained */
+int kprn_read_loss(kprn_handle* h, float* loss);
+int kprn_sync(kprn_handle* h);
+
+/* ---- data-parallel hooks (new design; the reference is single-device) -----
+ * The dense gradients (type_emb, relation_emb, LSTM, head) live in ONE contiguous device
+ * buffer that the caller all-reduces (RCCL).  entity_emb gradients are row-sparse: pack
+ * -> all-gather -> unpack(add) on every rank.  All pointers are DEVICE pointers.        */
+int kprn_dense_grad_buffer(kprn_handle* h, void** dev_ptr, int64_t* n_floats);
+/* copies the touched rows' ids and gradient rows to the packing buffers (capacity rows);
+ * clears them from the local accumulator; count written to *dev_count (device int32)    */
+int kprn_sparse_grad_capacity(kprn_handle* h, int32_t* max_rows_per_step);
+int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_ids, void** dev_rows, void** dev_count);
+/* adds `count` packed rows (device pointers, possibly another rank's) into the accumulator */
+int kprn_sparse_grad_unpack_add(kprn_handle* h, const void* dev_ids, const void* dev_rows,
+                                const void* dev_count, int32_t capacity);
+/* the stream everything is queued on (hipStream_t), so the caller can order collectives  */
+int kprn_stream(kprn_handle* h, void** stream);
+
+/* ---- checkpoints (OneModel.lua:392-408 torch.save{embeddingLayer,predictor_net}) ------
+ * native format: header + flat fp32 vector in getParameters() order (optimizer state is
+ * NOT saved, like the reference).                                                        */
+int kprn_save(kprn_handle* h, const char* path);
+int kprn_load(kprn_handle* h, const char* path);
+
+/* ---- measurement ------------------------------------------------------------------- */
+/* when enabled, every kernel family is bracketed by HIP events on the handle's stream   */
+int kprn_profile_enable(kprn_handle* h, int32_t on);
+int kprn_profile_reset(kprn_handle* h);
+/* fills up to cap entries; returns the number of kernel families seen in *n             */
+typedef struct { char name[48]; double total_ms; int64_t launches; } kprn_prof_entry;
+int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t* n);
+/* selects the implementation: "auto" (fused where the shape allows), "generic"           */
+int kprn_set_option(kprn_handle* h, const char* key, const char* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KPRN_H */

@@ -1,0 +1,325 @@
+"""ctypes binding of libkprn.so (include/kprn.h).  There is NO CPU path: if the HIP library
+is missing or no GPU is visible, everything here fails loudly.
+
+The LuaJIT twin of this file is bindings/kprn.lua.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkprn.so")
+HEADER = os.path.join(_HERE, "..", "include", "kprn.h")
+
+
+class KprnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"kprn error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+E_ARG, E_INDEX, E_DEVICE, E_UNSUPPORTED, E_IO, E_NOMEM = -1, -2, -3, -4, -5, -6
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("Vt", "Ve", "Vr", "dt", "de", "dr", "F", "num_types", "H", "L", "C",
+                                          "rnn_type", "reducer", "K", "device_id", "rank", "world")] + \
+               [("param_init", C.c_float), ("seed", C.c_uint64), ("stream", C.c_void_p)]
+
+
+class Opt(C.Structure):
+    _fields_ = [("method", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("lr_decay", C.c_float), ("regularize", C.c_int32), ("use_grad_clip", C.c_int32),
+                ("grad_clip_norm", C.c_float), ("l2", C.c_float), ("bce_literal", C.c_int32), ("entity_update", C.c_int32)]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("total_ms", C.c_double), ("launches", C.c_int64)]
+
+
+def declared_symbols():
+    """every function include/kprn.h declares (used by the CPU test that the library exports them all)."""
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"\b(kprn_[a-z_0-9]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def lib():
+    """Loads libkprn.so.  torch (if importable) is imported first so that both share ONE HIP runtime
+    (torch bundles libamdhip64.so.7; the loader de-duplicates by SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m kprn_amd.build` "
+                          "(hipcc --offload-arch=gfx950). kprn_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    L = C.CDLL(LIB_PATH)
+    L.kprn_last_error.restype = C.c_char_p
+    L.kprn_last_error.argtypes = [C.c_void_p]
+    L.kprn_version.restype = C.c_char_p
+    L.kprn_destroy.restype = None
+    L.kprn_destroy.argtypes = [C.c_void_p]
+    L.kprn_batch_destroy.restype = None
+    L.kprn_batch_destroy.argtypes = [C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_opt(method=1, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, lr_decay=0.0, regularize=0, use_grad_clip=1,
+             grad_clip_norm=5.0, l2=1e-3, bce_literal=0, entity_update=0):
+    return Opt(method, lr, beta1, beta2, eps, lr_decay, regularize, use_grad_clip, grad_clip_norm, l2, bce_literal, entity_update)
+
+
+class Batch:
+    """A minibatch resident in HBM (BatcherFileList:populateGPUTensor, BatcherFileList.lua:78-96)."""
+
+    def __init__(self, engine, idx, labels=None):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if idx.ndim != 4:
+            raise KprnError(E_ARG, "idx must be [B,P,T,F]")
+        self.engine = engine
+        self.B, self.P, self.T, self.F = (int(x) for x in idx.shape)
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.float32)
+        if lab is not None and lab.shape != (self.B,):
+            raise KprnError(E_ARG, "labels must be [B]")
+        self.ptr = C.c_void_p()
+        engine._ck(engine.L.kprn_batch_create(engine.h, _fp(idx), _fp(lab), self.B, self.P, self.T, self.F, C.byref(self.ptr)))
+        self.has_labels = lab is not None
+
+    @property
+    def n_paths(self):
+        return self.B * self.P
+
+    def free(self):
+        if self.ptr:
+            self.engine.L.kprn_batch_destroy(self.engine.h, self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.engine.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """Thin object wrapper over one kprn_handle."""
+
+    def __init__(self, Vt, Ve, Vr, dt, de, dr, H, L=1, F=3, num_types=1, C_=46, reducer=2, K=5, rnn_type=0, device_id=0,
+                 rank=0, world=1, param_init=0.1, seed=12345, stream=None):
+        self.L = lib()
+        self.cfg = Config(Vt, Ve, Vr, dt, de, dr, F, num_types, H, L, C_, rnn_type, reducer, K, device_id, rank, world,
+                          param_init, seed, stream)
+        self.h = C.c_void_p()
+        rc = self.L.kprn_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            self.h = C.c_void_p()
+            raise KprnError(rc, (self.L.kprn_last_error(None) or b"").decode())
+        n = C.c_int64()
+        self._ck(self.L.kprn_num_params(self.h, C.byref(n)))
+        self.n_params = int(n.value)
+        self.D = dt + de + dr
+
+    # -- plumbing ------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            raise KprnError(rc, (self.L.kprn_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.L.kprn_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def layout(self):
+        """name -> (flat offset, shape) in nn.Module:getParameters() order."""
+        c = self.cfg
+        out, off = {}, 0
+        items = [("type_emb", (c.Vt, c.dt)), ("entity_emb", (c.Ve, c.de)), ("relation_emb", (c.Vr, c.dr))]
+        for i in range(c.L):
+            din = self.D if i == 0 else c.H
+            items += [(f"lstm{i + 1}.i2g.weight", (4 * c.H, din)), (f"lstm{i + 1}.i2g.bias", (4 * c.H,)),
+                      (f"lstm{i + 1}.o2g.weight", (4 * c.H, c.H))]
+        items += [("out.weight", (c.C, c.H)), ("out.bias", (c.C,))]
+        for nm, shp in items:
+            out[nm] = (off, shp)
+            off += int(np.prod(shp))
+        assert off == self.n_params
+        return out
+
+    # -- parameters ----------------------------------------------------------------------
+    def get_param(self, name):
+        off, shp = self.layout()[name]
+        a = np.empty(shp, np.float32)
+        self._ck(self.L.kprn_get_param(self.h, name.encode(), _fp(a), C.c_int64(a.size)))
+        return a
+
+    def set_param(self, name, value):
+        a = np.ascontiguousarray(value, np.float32)
+        self._ck(self.L.kprn_set_param(self.h, name.encode(), _fp(a), C.c_int64(a.size)))
+
+    def get_grad(self, name):
+        off, shp = self.layout()[name]
+        a = np.empty(shp, np.float32)
+        self._ck(self.L.kprn_get_grad(self.h, name.encode(), _fp(a), C.c_int64(a.size)))
+        return a
+
+    def get_flat_params(self):
+        a = np.empty(self.n_params, np.float32)
+        self._ck(self.L.kprn_get_flat_params(self.h, _fp(a), C.c_int64(a.size)))
+        return a
+
+    def set_flat_params(self, theta):
+        a = np.ascontiguousarray(theta, np.float32)
+        self._ck(self.L.kprn_set_flat_params(self.h, _fp(a), C.c_int64(a.size)))
+
+    def get_flat_grads(self):
+        a = np.empty(self.n_params, np.float32)
+        self._ck(self.L.kprn_get_flat_grads(self.h, _fp(a), C.c_int64(a.size)))
+        return a
+
+    def get_flat_opt_state(self, slot):
+        a = np.empty(self.n_params, np.float32)
+        self._ck(self.L.kprn_get_flat_opt_state(self.h, int(slot), _fp(a), C.c_int64(a.size)))
+        return a
+
+    def zero_pad_tokens(self):
+        self._ck(self.L.kprn_zero_pad_tokens(self.h))
+
+    # -- scoring -------------------------------------------------------------------------
+    def batch(self, idx, labels=None):
+        return Batch(self, idx, labels)
+
+    def forward(self, batch, class_id=1, want=("probs",)):
+        """want: any of probs [B], all_probs [B,C], pooled [B,C], path_scores [B*P,C]."""
+        if not isinstance(batch, Batch):
+            batch = Batch(self, batch)
+        c = self.cfg
+        bufs = {"probs": np.empty(batch.B, np.float32) if "probs" in want else None,
+                "all_probs": np.empty((batch.B, c.C), np.float32) if "all_probs" in want else None,
+                "pooled": np.empty((batch.B, c.C), np.float32) if "pooled" in want else None,
+                "path_scores": np.empty((batch.n_paths, c.C), np.float32) if "path_scores" in want else None}
+        self._ck(self.L.kprn_forward_batch(self.h, batch.ptr, int(class_id), _fp(bufs["probs"]), _fp(bufs["all_probs"]),
+                                           _fp(bufs["pooled"]), _fp(bufs["path_scores"])))
+        return {k: v for k, v in bufs.items() if v is not None}
+
+    def forward_host(self, idx, class_id=1):
+        """the host-pointer entry point kprn_forward (one H2D copy per call)."""
+        idx = np.ascontiguousarray(idx, np.int32)
+        B, P, T, F = idx.shape
+        probs = np.empty(B, np.float32)
+        allp = np.empty((B, self.cfg.C), np.float32)
+        self._ck(self.L.kprn_forward(self.h, _fp(idx), B, P, T, F, int(class_id), _fp(probs), _fp(allp)))
+        return probs, allp
+
+    def forward_async(self, batch, class_id=1):
+        self._ck(self.L.kprn_forward_batch_async(self.h, batch.ptr, int(class_id)))
+
+    def read_probs(self, B):
+        a = np.empty(B, np.float32)
+        self._ck(self.L.kprn_read_probs(self.h, _fp(a), int(B)))
+        return a
+
+    def embed(self, idx):
+        idx = np.ascontiguousarray(idx, np.int32)
+        T, F = idx.shape[-2], idx.shape[-1]
+        N = idx.size // (T * F)
+        x = np.empty((N, T, self.D), np.float32)
+        self._ck(self.L.kprn_embed(self.h, _fp(idx), C.c_int64(N), T, F, _fp(x)))
+        return x
+
+    # -- training ------------------------------------------------------------------------
+    def backward(self, batch, class_id=1, bce_literal=False, inv_batch=0.0, want_loss=True):
+        loss = C.c_float()
+        self._ck(self.L.kprn_backward_batch(self.h, batch.ptr, int(class_id), int(bool(bce_literal)), C.c_float(inv_batch),
+                                            C.byref(loss) if want_loss else None))
+        return float(loss.value) if want_loss else None
+
+    def apply_update(self, opt):
+        self._ck(self.L.kprn_apply_update(self.h, C.byref(opt)))
+
+    def train_step(self, batch, opt, class_id=1, want_loss=True):
+        loss = C.c_float()
+        self._ck(self.L.kprn_train_step_batch(self.h, batch.ptr, int(class_id), C.byref(opt), C.byref(loss) if want_loss else None))
+        return float(loss.value) if want_loss else None
+
+    def train_step_host(self, idx, labels, opt, class_id=1):
+        idx = np.ascontiguousarray(idx, np.int32)
+        labels = np.ascontiguousarray(labels, np.float32)
+        B, P, T, F = idx.shape
+        loss = C.c_float()
+        self._ck(self.L.kprn_train_step(self.h, _fp(idx), B, P, T, F, _fp(labels), int(class_id), C.byref(opt), C.byref(loss)))
+        return float(loss.value)
+
+    def read_loss(self):
+        loss = C.c_float()
+        self._ck(self.L.kprn_read_loss(self.h, C.byref(loss)))
+        return float(loss.value)
+
+    def sync(self):
+        self._ck(self.L.kprn_sync(self.h))
+
+    # -- data parallel -------------------------------------------------------------------
+    def dense_grad_buffer(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._ck(self.L.kprn_dense_grad_buffer(self.h, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def sparse_grad_capacity(self):
+        n = C.c_int32()
+        self._ck(self.L.kprn_sparse_grad_capacity(self.h, C.byref(n)))
+        return int(n.value)
+
+    def sparse_grad_pack(self, capacity):
+        ids, rows, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(self.L.kprn_sparse_grad_pack(self.h, int(capacity), C.byref(ids), C.byref(rows), C.byref(cnt)))
+        return int(ids.value), int(rows.value), int(cnt.value)
+
+    def sparse_grad_unpack_add(self, ids_ptr, rows_ptr, count_ptr, capacity):
+        self._ck(self.L.kprn_sparse_grad_unpack_add(self.h, C.c_void_p(ids_ptr), C.c_void_p(rows_ptr), C.c_void_p(count_ptr), int(capacity)))
+
+    def stream(self):
+        p = C.c_void_p()
+        self._ck(self.L.kprn_stream(self.h, C.byref(p)))
+        return p.value or 0
+
+    # -- checkpoints / measurement ---------------------------------------------------------
+    def save(self, path):
+        self._ck(self.L.kprn_save(self.h, os.fsencode(path)))
+
+    def load(self, path):
+        self._ck(self.L.kprn_load(self.h, os.fsencode(path)))
+
+    def profile(self, on=True):
+        self._ck(self.L.kprn_profile_enable(self.h, int(bool(on))))
+
+    def profile_reset(self):
+        self._ck(self.L.kprn_profile_reset(self.h))
+
+    def profile_get(self):
+        n = C.c_int32()
+        arr = (ProfEntry * 128)()
+        self._ck(self.L.kprn_profile_get(self.h, arr, 128, C.byref(n)))
+        return {arr[i].name.decode(): (arr[i].total_ms, int(arr[i].launches)) for i in range(min(n.value, 128))}
+
+    def set_option(self, key, value):
+        self._ck(self.L.kprn_set_option(self.h, key.encode(), value.encode()))

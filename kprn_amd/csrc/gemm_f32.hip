@@ -1,0 +1,133 @@
+// Generic fp32 GEMM on the gfx950 f32 MFMA (v_mfma_f32_16x16x4_f32, exact f32, 157 TF peak).
+//
+// This is the shape-agnostic fallback of the engine: any M, N, K, any operand strides
+// (so A*B^T, A*B and A^T*B are one kernel), boundary-checked, optional split-K.  The
+// fused LSTM kernels (lstm_fused_*.hip) replace it on the shapes they cover; it stays the
+// reference GPU path for odd sizes (e.g. the shipped config's H=250, D=200,
+// release/songPathRnn/run_scripts/config.sh:20-23).
+//
+// Replaces the TH/THC BLAS calls under nn.Linear / FastLSTM's i2g,o2g
+// (release/songPathRnn/model/OneModel.lua:236,275).
+#include "kprn_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, BN = 64, BK = 16, LDT = 80;  // LDT: k-major tile row stride (conflict-free frag reads)
+
+template <bool A_KCONTIG, bool B_NCONTIG>
+__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int64_t sAm, int64_t sAk,
+                                                   const float* __restrict__ B, int64_t sBk, int64_t sBn,
+                                                   float* __restrict__ C, int64_t ldc, int64_t M, int N, int64_t K,
+                                                   int accumulate, const float* __restrict__ bias, int64_t kchunk,
+                                                   int use_atomic) {
+  __shared__ float As[BK][LDT];
+  __shared__ float Bs[BK][LDT];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m_base = (int64_t)blockIdx.x * BM;
+  const int n_base = blockIdx.y * BN;
+  const int64_t k_beg = (int64_t)blockIdx.z * kchunk;
+  const int64_t k_end = (k_beg + kchunk < K) ? k_beg + kchunk : K;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t k0 = k_beg; k0 < k_end; k0 += BK) {
+    // ---- stage A tile [BM x BK] and B tile [BK x BN], zero-filled outside the problem
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m, k;
+      if (A_KCONTIG) { k = tid & 15; m = (tid >> 4) + i * 16; }
+      else           { m = tid & 63; k = (tid >> 6) + i * 4; }
+      const int64_t gm = m_base + m, gk = k0 + k;
+      float v = 0.f;
+      if (gm < M && gk < k_end) v = A[gm * sAm + gk * sAk];
+      As[k][m] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int n, k;
+      if (B_NCONTIG) { n = tid & 63; k = (tid >> 6) + i * 4; }
+      else           { k = tid & 15; n = (tid >> 4) + i * 16; }
+      const int gn = n_base + n;
+      const int64_t gk = k0 + k;
+      float v = 0.f;
+      if (gn < N && gk < k_end) v = B[gk * sBk + (int64_t)gn * sBn];
+      Bs[k][n] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      float a[2], b[2];
+      const int kr = kk + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[kr][wm * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n_base + wn * 32 + j * 16 + (lane & 15);
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m_base + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+        if (row >= M) continue;
+        float v = acc[i][j][r];
+        float* dst = C + row * ldc + col;
+        if (use_atomic) {
+          unsafeAtomicAdd(dst, v);
+        } else if (accumulate) {
+          *dst += v;
+        } else {
+          if (bias) v += bias[col];
+          *dst = v;
+        }
+      }
+    }
+}
+
+}  // namespace
+
+namespace gemm {
+
+void run(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C,
+         int64_t ldc, int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k) {
+  if (M <= 0 || N <= 0) return;
+  if (split_k < 1) split_k = 1;
+  int64_t kchunk = (K + split_k - 1) / split_k;
+  kchunk = ((kchunk + BK - 1) / BK) * BK;
+  if (kchunk <= 0) kchunk = BK;
+  split_k = (int)((K + kchunk - 1) / kchunk);
+  if (split_k < 1) split_k = 1;
+  KPRN_REQUIRE(!(split_k > 1 && !accumulate), KPRN_E_ARG, "gemm: split-K needs accumulate mode");
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN), (unsigned)split_k);
+  const int use_atomic = split_k > 1 ? 1 : 0;
+  const bool akc = (sAk == 1), bnc = (sBn == 1);
+#define LAUNCH(AK, BNC)                                                                                            \
+  hipLaunchKernelGGL((gemm_kernel<AK, BNC>), grid, dim3(256), 0, s, A, sAm, sAk, B, sBk, sBn, C, ldc, M, N, K,     \
+                     accumulate ? 1 : 0, bias, kchunk, use_atomic)
+  if (akc && bnc) LAUNCH(true, true);
+  else if (akc && !bnc) LAUNCH(true, false);
+  else if (!akc && bnc) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  HIP_TRY(hipGetLastError());
+}
+
+}  // namespace gemm

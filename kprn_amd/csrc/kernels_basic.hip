@@ -1,0 +1,698 @@
+// HBM-bound and element-wise kernels of the path-scoring engine (gfx950).
+// Each kernel cites the reference module it stands in for (paths under
+// /root/reference/release/songPathRnn/).
+#include "kprn_internal.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline unsigned nblocks(int64_t n, int per = TPB) { return (unsigned)((n + per - 1) / per); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// index validation: ids must be in 1..V (int2torch.lua:60-63 makes them 1-based)
+__global__ void k_validate(const int32_t* __restrict__ idx, int64_t nsteps, int F, int nT, int Vt, int Ve, int Vr, int32_t* flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsteps) return;
+  const int32_t* f = idx + i * F;
+  bool bad = false;
+  for (int k = 0; k < nT; ++k) { int32_t v = f[F - nT - 2 + k]; bad |= (v < 1 || v > Vt); }
+  { int32_t v = f[F - 2]; bad |= (v < 1 || v > Ve); }
+  { int32_t v = f[F - 1]; bad |= (v < 1 || v > Vr); }
+  if (bad) atomicOr(flag, 1);
+}
+
+// distinct entity rows of a batch (0-based), via a tag array
+__global__ void k_unique(const int32_t* __restrict__ idx, int64_t nsteps, int F, int32_t* stamp, int32_t tag, int32_t* list, int32_t* count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsteps) return;
+  int32_t r = idx[i * F + F - 2] - 1;
+  if (atomicExch(&stamp[r], tag) != tag) {
+    int32_t pos = atomicAdd(count, 1);
+    list[pos] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// FeatureEmbedding:getEmbeddingNetworkBothEntitiesAndTypes (net/FeatureEmbedding.lua:112-121):
+// x[n,t,:] = [ sum_k Wt[type_k] | We[ent] | Wr[rel] ]; one float4 (or scalar) per thread.
+template <int VEC>
+__global__ void k_embed(const int32_t* __restrict__ idx, int64_t N, int T, int F, int nT, const float* __restrict__ Wt,
+                        const float* __restrict__ We, const float* __restrict__ Wr, int dt, int de, int dr, float* __restrict__ X,
+                        int time_major) {
+  const int D = dt + de + dr;
+  const int DV = D / VEC;
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = N * T * DV;
+  if (gid >= total) return;
+  int j = (int)(gid % DV) * VEC;
+  int64_t nt = gid / DV;  // = n*T + t  (input order)
+  int t = (int)(nt % T);
+  int64_t n = nt / T;
+  const int32_t* f = idx + nt * F;
+  float out[VEC];
+  if (j < dt) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) out[q] = 0.f;
+    for (int k = 0; k < nT; ++k) {
+      const float* row = Wt + (int64_t)(f[F - nT - 2 + k] - 1) * dt + j;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) out[q] = (k == 0) ? row[q] : out[q] + row[q];
+    }
+  } else if (j < dt + de) {
+    const float* row = We + (int64_t)(f[F - 2] - 1) * de + (j - dt);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) out[q] = row[q];
+  } else {
+    const float* row = Wr + (int64_t)(f[F - 1] - 1) * dr + (j - dt - de);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) out[q] = row[q];
+  }
+  float* dst = time_major ? X + ((int64_t)t * N + n) * D + j : X + nt * D + j;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) dst[q] = out[q];
+}
+
+// ---------------------------------------------------------------------------------------
+// nn.FastLSTM gate math (Element-Research rnn): chunks [i, g, f, o]
+__global__ void k_gates_fwd(float* __restrict__ act, const float* __restrict__ c_prev, float* __restrict__ c, float* __restrict__ h,
+                            int64_t N, int H) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= N * H) return;
+  int j = (int)(gid % H);
+  int64_t n = gid / H;
+  float* a = act + n * 4 * H;
+  float ig = sigmoidf_(a[j]);
+  float gg = tanhf(a[H + j]);
+  float fg = sigmoidf_(a[2 * H + j]);
+  float og = sigmoidf_(a[3 * H + j]);
+  float cp = c_prev ? c_prev[gid] : 0.f;
+  float cc = fg * cp + ig * gg;
+  float hh = og * tanhf(cc);
+  a[j] = ig; a[H + j] = gg; a[2 * H + j] = fg; a[3 * H + j] = og;
+  c[gid] = cc;
+  h[gid] = hh;
+}
+
+__global__ void k_gates_bwd(const float* __restrict__ act, const float* __restrict__ c, const float* __restrict__ c_prev,
+                            const float* __restrict__ dH_up, float* __restrict__ dH, float* __restrict__ dC, float* __restrict__ dA,
+                            int64_t N, int H) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= N * H) return;
+  int j = (int)(gid % H);
+  int64_t n = gid / H;
+  const float* a = act + n * 4 * H;
+  float ig = a[j], gg = a[H + j], fg = a[2 * H + j], og = a[3 * H + j];
+  float tc = tanhf(c[gid]);
+  float dh = dH[gid] + (dH_up ? dH_up[gid] : 0.f);
+  float dO = dh * tc;
+  float dc = dC[gid] + dh * og * (1.f - tc * tc);
+  float cp = c_prev ? c_prev[gid] : 0.f;
+  float* d = dA + n * 4 * H;
+  d[j] = dc * gg * ig * (1.f - ig);
+  d[H + j] = dc * ig * (1.f - gg * gg);
+  d[2 * H + j] = dc * cp * fg * (1.f - fg);
+  d[3 * H + j] = dO * og * (1.f - og);
+  dC[gid] = dc * fg;
+  dH[gid] = 0.f;  // refilled with the recurrent gradient dA * Wo by the caller (t > 0)
+}
+
+__global__ void k_add_bias(float* __restrict__ Y, const float* __restrict__ b, int64_t total, int cols) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  Y[gid] += b[gid % cols];
+}
+
+// out[c] += sum_r A[r][c]; block = 256 threads handles 256 rows x 64-col strip with LDS-free partials
+__global__ void k_colsum(const float* __restrict__ A, int64_t rows, int cols, float* __restrict__ out, int rows_per_block) {
+  int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  int sub = threadIdx.x >> 6;  // 4 row-subgroups
+  int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float acc = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + sub; r < r1; r += 4) acc += A[r * cols + c];
+  __shared__ float red[4][64];
+  red[sub][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sub == 0 && c < cols) {
+    float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    unsafeAtomicAdd(out + c, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// reducer over the P paths of a pair + nn.Sigmoid (OneModel.lua:284-294):
+//   2: module/LogSumExp.lua:13-27   0: nn.Max(2)   1: module/TopK.lua:17-24 + nn.Mean(2)
+__device__ float reduce_col(const float* s, int P, int C, int reducer, int K) {
+  if (reducer == 2) {
+    float m = s[0];
+    for (int p = 1; p < P; ++p) m = fmaxf(m, s[(int64_t)p * C]);
+    float sum = 0.f;
+    for (int p = 0; p < P; ++p) sum += expf(s[(int64_t)p * C] - m);
+    return logf(sum) + m;
+  } else if (reducer == 0) {
+    float m = s[0];
+    for (int p = 1; p < P; ++p) m = fmaxf(m, s[(int64_t)p * C]);
+    return m;
+  } else {
+    int kk = K < P ? K : P;
+    // k largest by repeated selection with an exclusion bound (value, index) -- P is small (<= 28)
+    float acc = 0.f;
+    float last_v = INFINITY; int last_i = -1;
+    for (int q = 0; q < kk; ++q) {
+      float best = -INFINITY; int bi = -1;
+      for (int p = 0; p < P; ++p) {
+        float v = s[(int64_t)p * C];
+        bool after = (v < last_v) || (v == last_v && p > last_i);
+        if (after && (bi < 0 || v > best)) { best = v; bi = p; }
+      }
+      acc += best; last_v = best; last_i = bi;
+    }
+    return acc / (float)kk;
+  }
+}
+
+__global__ void k_pool(const float* __restrict__ S, int B, int P, int C, int reducer, int K, float* __restrict__ pooled, float* __restrict__ probs) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * C) return;
+  int c = (int)(gid % C);
+  int64_t b = gid / C;
+  float y = reduce_col(S + b * P * C + c, P, C, reducer, K);
+  pooled[gid] = y;
+  probs[gid] = sigmoidf_(y);
+}
+
+__global__ void k_select(const float* __restrict__ probs, int B, int C, int cid, float* __restrict__ sel) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) sel[b] = probs[(int64_t)b * C + cid];
+}
+
+// nn.BCECriterion forward/backward + nn.Sigmoid backward + reducer backward, column classId only
+// (MyOptimizer.lua:193-195,126; LogSumExp.lua:30-36; TopK.lua:34-38).  lossb[b] = per-pair loss term.
+__global__ void k_bce_dscore(const float* __restrict__ S, const float* __restrict__ pooled, const float* __restrict__ probs,
+                             const float* __restrict__ labels, int B, int P, int C, int cid, int reducer, int K, int literal, float invB,
+                             float* __restrict__ lossb, float* __restrict__ dS) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float eps = 1e-12f;
+  float p = probs[(int64_t)b * C + cid];
+  float t = labels[b];
+  lossb[b] = -(t * logf(p + eps) + (1.f - t) * logf(1.f - p + eps)) * invB;
+  float dy;
+  if (literal) {
+    float dp = -(t - p) / ((1.f - p + eps) * (p + eps)) * invB;
+    dy = dp * p * (1.f - p);
+  } else {
+    dy = (p - t) * invB;
+  }
+  const float* s = S + (int64_t)b * P * C + cid;
+  float* d = dS + (int64_t)b * P;
+  if (reducer == 2) {
+    float y = pooled[(int64_t)b * C + cid];
+    // exp(s - m)/sum == exp(s - y)
+    float m = s[0];
+    for (int q = 1; q < P; ++q) m = fmaxf(m, s[(int64_t)q * C]);
+    float sum = 0.f;
+    for (int q = 0; q < P; ++q) sum += expf(s[(int64_t)q * C] - m);
+    (void)y;
+    for (int q = 0; q < P; ++q) d[q] = expf(s[(int64_t)q * C] - m) / sum * dy;
+  } else if (reducer == 0) {
+    int arg = 0;
+    for (int q = 1; q < P; ++q) if (s[(int64_t)q * C] > s[(int64_t)arg * C]) arg = q;
+    for (int q = 0; q < P; ++q) d[q] = (q == arg) ? dy : 0.f;
+  } else {
+    int kk = K < P ? K : P;
+    for (int q = 0; q < P; ++q) d[q] = 0.f;
+    float last_v = INFINITY; int last_i = -1;
+    for (int r = 0; r < kk; ++r) {
+      float best = -INFINITY; int bi = -1;
+      for (int q = 0; q < P; ++q) {
+        float v = s[(int64_t)q * C];
+        bool after = (v < last_v) || (v == last_v && q > last_i);
+        if (after && (bi < 0 || v > best)) { best = v; bi = q; }
+      }
+      d[bi] = dy / (float)kk; last_v = best; last_i = bi;
+    }
+  }
+}
+
+// deterministic single-block sum
+__global__ void k_sum_det(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[1024];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += x[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+
+// nn.Linear(H,46) backward restricted to the selected column (OneModel.lua:275; Select at MyOptimizer.lua:126)
+__global__ void k_head_bwd(const float* __restrict__ dS, const float* __restrict__ hT, const float* __restrict__ Wout, int64_t N, int H,
+                           int cid, float* __restrict__ dH, float* __restrict__ gWout, float* __restrict__ gbout, int rows_per_block) {
+  int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+  for (int j = threadIdx.x; j < H; j += blockDim.x) {
+    float w = Wout[(int64_t)cid * H + j];
+    float acc = 0.f;
+    for (int64_t n = r0; n < r1; ++n) {
+      float d = dS[n];
+      acc += d * hT[n * H + j];
+      dH[n * H + j] = d * w;
+    }
+    unsafeAtomicAdd(gWout + (int64_t)cid * H + j, acc);
+  }
+  if (threadIdx.x == 0) {
+    float acc = 0.f;
+    for (int64_t n = r0; n < r1; ++n) acc += dS[n];
+    unsafeAtomicAdd(gbout + cid, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// nn.LookupTable backward = scatter-add (duplicates accumulate).  The two tiny tables (types,
+// relations) are reduced in LDS per block first; entity rows go straight to L2 atomics.
+__global__ void k_embed_scatter(const int32_t* __restrict__ idx, int64_t N, int T, int F, int nT, const float* __restrict__ dX, int dt, int de,
+                                int dr, int Vt, int Vr, float* __restrict__ gWt, float* __restrict__ gWe, float* __restrict__ gWr,
+                                int use_lds, int steps_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int D = dt + de + dr;
+  const int nt_small = Vt * dt, nr_small = Vr * dr;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < nt_small + nr_small; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+  }
+  int64_t s0 = (int64_t)blockIdx.x * steps_per_block;
+  int64_t total = N * T;
+  int64_t s1 = s0 + steps_per_block < total ? s0 + steps_per_block : total;
+  int64_t nelem = (s1 - s0) * D;
+  for (int64_t e = threadIdx.x; e < nelem; e += blockDim.x) {
+    int64_t step = s0 + e / D;  // time-major linear index = t*N + n
+    int j = (int)(e % D);
+    int t = (int)(step / N);
+    int64_t n = step % N;
+    const int32_t* f = idx + (n * T + t) * F;
+    float v = dX[step * D + j];
+    if (j < dt) {
+      for (int k = 0; k < nT; ++k) {
+        int row = f[F - nT - 2 + k] - 1;
+        if (use_lds) atomicAdd(&lds[row * dt + j], v);
+        else unsafeAtomicAdd(gWt + (int64_t)row * dt + j, v);
+      }
+    } else if (j < dt + de) {
+      unsafeAtomicAdd(gWe + (int64_t)(f[F - 2] - 1) * de + (j - dt), v);
+    } else {
+      int row = f[F - 1] - 1;
+      if (use_lds) atomicAdd(&lds[nt_small + row * dr + (j - dt - de)], v);
+      else unsafeAtomicAdd(gWr + (int64_t)row * dr + (j - dt - de), v);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt_small; i += blockDim.x) { float v = lds[i]; if (v != 0.f) unsafeAtomicAdd(gWt + i, v); }
+    for (int i = threadIdx.x; i < nr_small; i += blockDim.x) { float v = lds[nt_small + i]; if (v != 0.f) unsafeAtomicAdd(gWr + i, v); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ void k_sumsq(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += x[i] * x[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, acc);
+}
+
+__global__ void k_sumsq_rows(const float* __restrict__ G, const int32_t* __restrict__ rows, const int32_t* __restrict__ count, int d,
+                             float* __restrict__ out) {
+  int nrows = *count;
+  float acc = 0.f;
+  int64_t total = (int64_t)nrows * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = G[(int64_t)rows[i / d] * d + (i % d)];
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, acc);
+}
+
+// ---- optimisers (optim.adam / optim.adagrad, OneModel.lua:347-361; MyOptimizer.lua:196-218) ----
+#pragma clang fp contract(off)
+__device__ __forceinline__ float clip_factor(const float* norm2, float clip) {
+  if (!norm2) return 1.f;
+  float nrm = sqrtf(*norm2);
+  return (nrm > clip) ? clip / nrm : 1.f;
+}
+
+__device__ __forceinline__ void adam_elem(float& x, float& m, float& v, float g, float step, float b1, float b2, float eps) {
+  m = m * b1 + (1.f - b1) * g;
+  v = v * b2 + (1.f - b2) * g * g;
+  float denom = sqrtf(v) + eps;
+  x = x - step * (m / denom);
+}
+
+__global__ void k_adam_dense(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                             float step, float b1, float b2, float eps, const float* __restrict__ norm2, float clip, float l2, int reg) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  float xi = x[i];
+  if (reg) { gi = gi * clip_factor(norm2, clip); gi = gi + l2 * xi; }
+  float mi = m[i], vi = v[i];
+  adam_elem(xi, mi, vi, gi, step, b1, b2, eps);
+  x[i] = xi; m[i] = mi; v[i] = vi;
+}
+
+__global__ void k_adagrad_dense(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ G, int64_t n, float clr,
+                                const float* __restrict__ norm2, float clip, float l2, int reg) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  float xi = x[i];
+  if (reg) { gi = gi * clip_factor(norm2, clip); gi = gi + l2 * xi; }
+  float Gi = G[i] + gi * gi;
+  G[i] = Gi;
+  x[i] = xi - clr * gi / (sqrtf(Gi) + 1e-10f);
+}
+
+// lazy-exact Adam over a list of rows: one wave per row.  Replays the steps the row missed
+// (gradient 0) with the same arithmetic as k_adam_dense, then (apply_step) applies step t_now
+// with the accumulated gradient and clears it.  Result is bit-identical to updating every
+// row at every step, which is what optim.adam does to the flat vector.
+__global__ void k_adam_rows(float* __restrict__ W, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int32_t* __restrict__ last, const int32_t* __restrict__ rows, const int32_t* __restrict__ count, int d,
+                            int32_t t_now, int apply_step, const float* __restrict__ step_tab, float b1, float b2, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= *count) return;
+  const int64_t r = rows[wave];
+  const int32_t l = last[r];
+  const int32_t upto = apply_step ? t_now - 1 : t_now;  // replay (l, upto] with g = 0
+  for (int e = lane; e < d; e += 64) {
+    const int64_t o = r * d + e;
+    float x = W[o], mm = m[o], vv = v[o];
+    if (l > 0)
+      for (int32_t k = l + 1; k <= upto; ++k) adam_elem(x, mm, vv, 0.f, step_tab[k], b1, b2, eps);
+    if (apply_step) {
+      adam_elem(x, mm, vv, g[o], step_tab[t_now], b1, b2, eps);
+      g[o] = 0.f;
+    }
+    W[o] = x; m[o] = mm; v[o] = vv;
+  }
+  if (lane == 0) last[r] = t_now;
+}
+
+__global__ void k_adam_flush_all(float* __restrict__ W, float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ last, int64_t V,
+                                 int d, int32_t t_now, const float* __restrict__ step_tab, float b1, float b2, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= V) return;
+  const int32_t l = last[r];
+  if (l <= 0 || l >= t_now) return;
+  for (int e = lane; e < d; e += 64) {
+    const int64_t o = r * d + e;
+    float x = W[o], mm = m[o], vv = v[o];
+    for (int32_t k = l + 1; k <= t_now; ++k) adam_elem(x, mm, vv, 0.f, step_tab[k], b1, b2, eps);
+    W[o] = x; m[o] = mm; v[o] = vv;
+  }
+  if (lane == 0) last[r] = t_now;
+}
+
+__global__ void k_adagrad_rows(float* __restrict__ W, float* __restrict__ g, float* __restrict__ G, const int32_t* __restrict__ rows,
+                               const int32_t* __restrict__ count, int d, float clr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= *count) return;
+  const int64_t r = rows[wave];
+  for (int e = lane; e < d; e += 64) {
+    const int64_t o = r * d + e;
+    float gi = g[o];
+    float Gi = G[o] + gi * gi;
+    G[o] = Gi;
+    W[o] = W[o] - clr * gi / (sqrtf(Gi) + 1e-10f);
+    g[o] = 0.f;
+  }
+}
+#pragma clang fp contract(fast)
+
+__global__ void k_zero_row(float* __restrict__ W, int64_t row, int d) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < d) W[row * d + j] = 0.f;
+}
+
+__global__ void k_fill_i32(int32_t* __restrict__ x, int64_t n, int32_t v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+
+// data-parallel exchange helpers -------------------------------------------------------------
+__global__ void k_pack_rows(float* __restrict__ G, const int32_t* __restrict__ rows, const int32_t* __restrict__ count, int d,
+                            int32_t* __restrict__ ids_out, float* __restrict__ rows_out, int32_t* __restrict__ count_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int32_t n = *count;
+  if (wave == 0 && lane == 0) *count_out = n;
+  if (wave >= n) return;
+  const int64_t r = rows[wave];
+  if (lane == 0) ids_out[wave] = (int32_t)r;
+  for (int e = lane; e < d; e += 64) {
+    rows_out[wave * d + e] = G[r * d + e];
+    G[r * d + e] = 0.f;
+  }
+}
+
+__global__ void k_unpack_add(float* __restrict__ G, const int32_t* __restrict__ ids, const float* __restrict__ rows,
+                             const int32_t* __restrict__ count, int d, int32_t* __restrict__ stamp, int32_t tag, int32_t* __restrict__ list,
+                             int32_t* __restrict__ list_count) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= *count) return;
+  const int64_t r = ids[wave];
+  if (lane == 0) {
+    if (atomicExch(&stamp[r], tag) != tag) { int32_t pos = atomicAdd(list_count, 1); list[pos] = (int32_t)r; }
+  }
+  // ids within one packed buffer are distinct, and buffers are applied one launch at a time in
+  // rank order, so each element sees a fixed addition order on every rank.
+  for (int e = lane; e < d; e += 64) G[r * d + e] += rows[wave * d + e];
+}
+
+__global__ void k_clear_rows(float* __restrict__ G, const int32_t* __restrict__ rows, const int32_t* __restrict__ count, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= *count) return;
+  const int64_t r = rows[wave];
+  for (int e = lane; e < d; e += 64) G[r * d + e] = 0.f;
+}
+
+// uniform(-a, a) init (OneModel.lua:306-309); counter-based splitmix64
+__global__ void k_fill_uniform(float* __restrict__ x, int64_t n, float a, uint64_t seed, uint64_t offset) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + offset + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  float u = (float)(z >> 40) * (1.0f / 16777216.0f);  // [0,1)
+  x[i] = (2.f * u - 1.f) * a;
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH() HIP_TRY(hipGetLastError())
+
+namespace kk {
+
+void validate_indices(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int nT, int Vt, int Ve, int Vr, int32_t* flag) {
+  if (nsteps <= 0) return;
+  hipLaunchKernelGGL(k_validate, dim3(nblocks(nsteps)), dim3(TPB), 0, s, idx, nsteps, F, nT, Vt, Ve, Vr, flag);
+  CHECK_LAUNCH();
+}
+
+void unique_rows(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int32_t* stamp, int32_t tag, int32_t* list, int32_t* count) {
+  if (nsteps <= 0) return;
+  hipLaunchKernelGGL(k_unique, dim3(nblocks(nsteps)), dim3(TPB), 0, s, idx, nsteps, F, stamp, tag, list, count);
+  CHECK_LAUNCH();
+}
+
+void embed_gather(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* Wt, const float* We, const float* Wr,
+                  int dt, int de, int dr, float* X, bool time_major) {
+  if (N <= 0) return;
+  const int D = dt + de + dr;
+  if ((dt % 4 == 0) && (de % 4 == 0) && (dr % 4 == 0)) {
+    int64_t total = N * T * (D / 4);
+    hipLaunchKernelGGL((k_embed<4>), dim3(nblocks(total)), dim3(TPB), 0, s, idx, N, T, F, nT, Wt, We, Wr, dt, de, dr, X, time_major ? 1 : 0);
+  } else {
+    int64_t total = N * T * D;
+    hipLaunchKernelGGL((k_embed<1>), dim3(nblocks(total)), dim3(TPB), 0, s, idx, N, T, F, nT, Wt, We, Wr, dt, de, dr, X, time_major ? 1 : 0);
+  }
+  CHECK_LAUNCH();
+}
+
+void lstm_gates_fwd(hipStream_t s, float* act, const float* c_prev, float* c, float* h, int64_t N, int H) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_gates_fwd, dim3(nblocks(N * H)), dim3(TPB), 0, s, act, c_prev, c, h, N, H);
+  CHECK_LAUNCH();
+}
+
+void lstm_gates_bwd(hipStream_t s, const float* act, const float* c, const float* c_prev, const float* dH_up, float* dH, float* dC, float* dA,
+                    int64_t N, int H) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_gates_bwd, dim3(nblocks(N * H)), dim3(TPB), 0, s, act, c, c_prev, dH_up, dH, dC, dA, N, H);
+  CHECK_LAUNCH();
+}
+
+void add_bias_rows(hipStream_t s, float* Y, const float* b, int64_t rows, int cols) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(k_add_bias, dim3(nblocks(rows * cols)), dim3(TPB), 0, s, Y, b, rows * cols, cols);
+  CHECK_LAUNCH();
+}
+
+void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out) {
+  if (rows <= 0) return;
+  const int rpb = 512;
+  dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 63) / 64));
+  hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, A, rows, cols, out, rpb);
+  CHECK_LAUNCH();
+}
+
+void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_pool, dim3(nblocks((int64_t)B * C)), dim3(TPB), 0, s, S, B, P, C, reducer, K, pooled, probs);
+  CHECK_LAUNCH();
+}
+
+void select_col(hipStream_t s, const float* probs, int B, int C, int cid, float* sel) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_select, dim3(nblocks(B)), dim3(TPB), 0, s, probs, B, C, cid, sel);
+  CHECK_LAUNCH();
+}
+
+void bce_and_dscore(hipStream_t s, const float* S, const float* pooled, const float* probs, const float* labels, int B, int P, int C, int cid,
+                    int reducer, int K, int literal, float invB, float* loss, float* dS) {
+  if (B <= 0) return;
+  // dS doubles as scratch owner: per-pair loss terms live in the tail of dS ([N] .. [N+B))
+  float* lossb = dS + (int64_t)B * P;
+  hipLaunchKernelGGL(k_bce_dscore, dim3(nblocks(B)), dim3(TPB), 0, s, S, pooled, probs, labels, B, P, C, cid, reducer, K, literal, invB, lossb, dS);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_sum_det, dim3(1), dim3(1024), 0, s, lossb, (int64_t)B, loss);
+  CHECK_LAUNCH();
+}
+
+void head_bwd(hipStream_t s, const float* dS, const float* hT, const float* Wout, int64_t N, int H, int cid, float* dH, float* gWout, float* gbout) {
+  if (N <= 0) return;
+  const int rpb = 64;
+  hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((N + rpb - 1) / rpb)), dim3(H >= 256 ? 256 : (H > 64 ? 128 : 64)), 0, s, dS, hT, Wout, N, H, cid,
+                     dH, gWout, gbout, rpb);
+  CHECK_LAUNCH();
+}
+
+void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* dX, int dt, int de, int dr, int Vt, int Vr,
+                   float* gWt, float* gWe, float* gWr) {
+  if (N <= 0) return;
+  size_t small = (size_t)((int64_t)Vt * dt + (int64_t)Vr * dr) * sizeof(float);
+  int use_lds = small <= 96 * 1024 ? 1 : 0;
+  const int spb = 256;  // steps per block
+  int64_t total = N * T;
+  if (use_lds && small > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)k_embed_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small));
+  hipLaunchKernelGGL(k_embed_scatter, dim3((unsigned)((total + spb - 1) / spb)), dim3(TPB), use_lds ? small : 0, s, idx, N, T, F, nT, dX, dt, de,
+                     dr, Vt, Vr, gWt, gWe, gWr, use_lds, spb);
+  CHECK_LAUNCH();
+}
+
+void sumsq(hipStream_t s, const float* x, int64_t n, float* out) {
+  if (n <= 0) return;
+  unsigned g = nblocks(n);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_sumsq, dim3(g), dim3(TPB), 0, s, x, n, out);
+  CHECK_LAUNCH();
+}
+
+void sumsq_rows(hipStream_t s, const float* G, const int32_t* rows, const int32_t* count, int d, float* out) {
+  hipLaunchKernelGGL(k_sumsq_rows, dim3(1024), dim3(TPB), 0, s, G, rows, count, d, out);
+  CHECK_LAUNCH();
+}
+
+void adam_dense(hipStream_t s, float* x, const float* g, float* m, float* v, int64_t n, float step, float b1, float b2, float eps,
+                const float* norm2, float clip, float l2) {
+  if (n <= 0) return;
+  int reg = (norm2 != nullptr || l2 != 0.f) ? 1 : 0;
+  hipLaunchKernelGGL(k_adam_dense, dim3(nblocks(n)), dim3(TPB), 0, s, x, g, m, v, n, step, b1, b2, eps, norm2, clip, l2, reg);
+  CHECK_LAUNCH();
+}
+
+void adagrad_dense(hipStream_t s, float* x, const float* g, float* G, int64_t n, float clr, const float* norm2, float clip, float l2) {
+  if (n <= 0) return;
+  int reg = (norm2 != nullptr || l2 != 0.f) ? 1 : 0;
+  hipLaunchKernelGGL(k_adagrad_dense, dim3(nblocks(n)), dim3(TPB), 0, s, x, g, G, n, clr, norm2, clip, l2, reg);
+  CHECK_LAUNCH();
+}
+
+void adam_rows(hipStream_t s, float* W, float* g, float* m, float* v, int32_t* last, const int32_t* rows, const int32_t* count, int64_t max_rows,
+               int d, int32_t t_now, int apply_step, const float* step_tab, float b1, float b2, float eps) {
+  if (max_rows <= 0) return;
+  hipLaunchKernelGGL(k_adam_rows, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, d, t_now, apply_step, step_tab, b1,
+                     b2, eps);
+  CHECK_LAUNCH();
+}
+
+void adam_flush_all(hipStream_t s, float* W, float* m, float* v, int32_t* last, int64_t V, int d, int32_t t_now, const float* step_tab, float b1,
+                    float b2, float eps) {
+  hipLaunchKernelGGL(k_adam_flush_all, dim3(nblocks(V * 64)), dim3(TPB), 0, s, W, m, v, last, V, d, t_now, step_tab, b1, b2, eps);
+  CHECK_LAUNCH();
+}
+
+void adagrad_rows(hipStream_t s, float* W, float* g, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, float clr) {
+  if (max_rows <= 0) return;
+  hipLaunchKernelGGL(k_adagrad_rows, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, W, g, G, rows, count, d, clr);
+  CHECK_LAUNCH();
+}
+
+void zero_rows(hipStream_t s, float* W, int64_t row, int d) {
+  hipLaunchKernelGGL(k_zero_row, dim3(nblocks(d)), dim3(TPB), 0, s, W, row, d);
+  CHECK_LAUNCH();
+}
+
+void pack_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, int32_t* ids_out, float* rows_out,
+               int32_t* count_out) {
+  int64_t waves = max_rows > 0 ? max_rows : 1;
+  hipLaunchKernelGGL(k_pack_rows, dim3(nblocks(waves * 64)), dim3(TPB), 0, s, G, rows, count, d, ids_out, rows_out, count_out);
+  CHECK_LAUNCH();
+}
+
+void unpack_add_rows(hipStream_t s, float* G, const int32_t* ids, const float* rows, const int32_t* count, int64_t max_rows, int d, int32_t* stamp,
+                     int32_t tag, int32_t* list, int32_t* list_count) {
+  if (max_rows <= 0) return;
+  hipLaunchKernelGGL(k_unpack_add, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, G, ids, rows, count, d, stamp, tag, list, list_count);
+  CHECK_LAUNCH();
+}
+
+void fill_uniform(hipStream_t s, float* x, int64_t n, float a, uint64_t seed, uint64_t offset) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_fill_uniform, dim3(nblocks(n)), dim3(TPB), 0, s, x, n, a, seed, offset);
+  CHECK_LAUNCH();
+}
+
+void clear_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d) {
+  if (max_rows <= 0) return;
+  hipLaunchKernelGGL(k_clear_rows, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, G, rows, count, d);
+  CHECK_LAUNCH();
+}
+
+void fill_i32(hipStream_t s, int32_t* x, int64_t n, int32_t v) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_fill_i32, dim3(nblocks(n)), dim3(TPB), 0, s, x, n, v);
+  CHECK_LAUNCH();
+}
+
+}  // namespace kk

@@ -1,0 +1,940 @@
+// libkprn.so -- C ABI (include/kprn.h) and step orchestration.
+//
+// One handle = the reference's training_net (MapReduce(predictor_net, reducer) + Sigmoid,
+// release/songPathRnn/model/OneModel.lua:204-294) plus MyOptimizer's state
+// (model/optimizer/MyOptimizer.lua:13-72), resident in HBM.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <exception>
+
+#include "kprn_internal.h"
+
+namespace fused {
+bool fwd_supported(const kprn_handle* h, int T);
+void forward(kprn_handle* h, const kprn_batch* b, bool save);
+bool bwd_supported(const kprn_handle* h, int T);
+void backward(kprn_handle* h, const kprn_batch* b, int cid);
+void params_changed(kprn_handle* h);
+void release(kprn_handle* h);
+}  // namespace fused
+
+static thread_local std::string g_create_error;
+
+// ---------------------------------------------------------------------------------------
+// profiling scopes
+ProfScope::ProfScope(kprn_handle* h_, const char* n) : h(h_), name(n) {
+  if (!h->prof_on) return;
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+    return e;
+  };
+  a = get(); b = get();
+  if (a) hipEventRecord(a, h->stream);
+}
+ProfScope::~ProfScope() {
+  if (!h->prof_on || !a || !b) return;
+  hipEventRecord(b, h->stream);
+  h->prof_pending.push_back({name, a, b});
+  if (h->prof_pending.size() > 4096) prof_drain(h);
+}
+void prof_drain(kprn_handle* h) {
+  if (h->prof_pending.empty()) return;
+  hipStreamSynchronize(h->stream);
+  for (auto& p : h->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      auto& e = h->prof[p.name];
+      e.total_ms += ms;
+      e.launches += 1;
+    }
+    h->event_pool.push_back(p.a);
+    h->event_pool.push_back(p.b);
+  }
+  h->prof_pending.clear();
+}
+
+// ---------------------------------------------------------------------------------------
+template <typename T>
+static T* dalloc(int64_t n) {
+  void* p = nullptr;
+  if (n <= 0) n = 1;
+  hipError_t e = hipMalloc(&p, (size_t)n * sizeof(T));
+  if (e != hipSuccess) throw KprnError{KPRN_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e)};
+  return (T*)p;
+}
+template <typename T>
+static void dfree(T*& p) { if (p) { hipFree(p); p = nullptr; } }
+
+static void build_layout(kprn_handle* h) {
+  const kprn_config& c = h->cfg;
+  h->D = c.dt + c.de + c.dr;
+  int64_t flat = 0, dn = 0;
+  auto add = [&](const std::string& nm, int64_t rows, int64_t cols, int where, int64_t dev_off) {
+    h->params.push_back({nm, flat, rows, cols, where, dev_off});
+    flat += rows * cols;
+  };
+  h->off_Wt = dn; add("type_emb", c.Vt, c.dt, 0, dn); dn += (int64_t)c.Vt * c.dt;
+  add("entity_emb", c.Ve, c.de, 1, 0);
+  h->off_Wr = dn; add("relation_emb", c.Vr, c.dr, 0, dn); dn += (int64_t)c.Vr * c.dr;
+  for (int l = 0; l < c.L; ++l) {
+    const int Din = (l == 0) ? h->D : c.H;
+    h->layer[l].Din = Din;
+    h->layer[l].Wi = dn; add("lstm" + std::to_string(l + 1) + ".i2g.weight", 4 * c.H, Din, 0, dn); dn += (int64_t)4 * c.H * Din;
+    h->layer[l].bi = dn; add("lstm" + std::to_string(l + 1) + ".i2g.bias", 4 * c.H, 1, 0, dn); dn += (int64_t)4 * c.H;
+    h->layer[l].Wo = dn; add("lstm" + std::to_string(l + 1) + ".o2g.weight", 4 * c.H, c.H, 0, dn); dn += (int64_t)4 * c.H * c.H;
+  }
+  h->off_outW = dn; add("out.weight", c.C, c.H, 0, dn); dn += (int64_t)c.C * c.H;
+  h->off_outb = dn; add("out.bias", c.C, 1, 0, dn); dn += c.C;
+  h->n_dense = dn;
+  h->n_ent = (int64_t)c.Ve * c.de;
+  h->n_params = flat;
+}
+
+static const ParamInfo* find_param(kprn_handle* h, const char* name) {
+  if (!name) return nullptr;
+  for (auto& p : h->params) if (p.name == name) return &p;
+  return nullptr;
+}
+
+static void step_tab_reserve(kprn_handle* h, int64_t need) {
+  if (need < h->step_tab_cap) return;
+  int64_t cap = std::max<int64_t>(4096, h->step_tab_cap * 2);
+  while (cap <= need) cap *= 2;
+  float* nd = dalloc<float>(cap);
+  float* nh = nullptr;
+  HIP_TRY(hipHostMalloc((void**)&nh, (size_t)cap * sizeof(float)));
+  memset(nh, 0, (size_t)cap * sizeof(float));
+  if (h->step_tab) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    memcpy(nh, h->step_tab_host, (size_t)h->step_tab_cap * sizeof(float));
+    HIP_TRY(hipMemcpy(nd, nh, (size_t)h->step_tab_cap * sizeof(float), hipMemcpyHostToDevice));
+    hipFree(h->step_tab);
+    hipHostFree(h->step_tab_host);
+  }
+  h->step_tab = nd; h->step_tab_host = nh; h->step_tab_cap = cap;
+}
+
+// bring every entity row up to opt_step (needed before anything reads the whole table)
+static void flush_lazy(kprn_handle* h) {
+  if (!h->lazy_pending) return;
+  ProfScope ps(h, "adam_flush_all");
+  kk::adam_flush_all(h->stream, h->We, h->s1_We, h->s2_We, h->We_last, h->cfg.Ve, h->cfg.de, (int32_t)h->opt_step, h->step_tab,
+                     h->last_b1, h->last_b2, h->last_eps);
+  h->lazy_pending = false;
+}
+
+static void zero_pad_tokens(kprn_handle* h) {
+  const kprn_config& c = h->cfg;
+  kk::zero_rows(h->stream, h->dense + h->off_Wt, c.Vt - 1, c.dt);
+  kk::zero_rows(h->stream, h->dense + h->off_Wr, c.Vr - 1, c.dr);
+  kk::zero_rows(h->stream, h->We, c.Ve - 1, c.de);
+}
+
+static void ensure_ws_common(kprn_handle* h, int64_t N, int64_t B) {
+  Workspace& w = h->ws;
+  const kprn_config& c = h->cfg;
+  if (N > w.cap_Nc) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dfree(w.S); dfree(w.dS);
+    w.S = dalloc<float>(N * c.C);
+    w.dS = dalloc<float>(N * 2 + 16);  // [N] grads + [B<=N] per-pair loss terms
+    w.cap_Nc = N;
+  }
+  if (B > w.cap_B) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dfree(w.pooled); dfree(w.probs); dfree(w.sel); dfree(w.dy);
+    w.pooled = dalloc<float>(B * c.C);
+    w.probs = dalloc<float>(B * c.C);
+    w.sel = dalloc<float>(B);
+    w.dy = dalloc<float>(B);
+    w.cap_B = B;
+  }
+  h->score_buf = w.S;
+}
+
+static void ensure_ws_generic(kprn_handle* h, int64_t N, int T) {
+  Workspace& w = h->ws;
+  const kprn_config& c = h->cfg;
+  const int H = c.H, L = c.L, D = h->D;
+  if (N > w.cap_N || T > w.cap_T) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int64_t cn = std::max<int64_t>(N, w.cap_N);
+    int ct = std::max(T, w.cap_T);
+    dfree(w.X); dfree(w.Hs); dfree(w.Cs); dfree(w.ACT); dfree(w.dA); dfree(w.dIn); dfree(w.dH); dfree(w.dC);
+    w.X = dalloc<float>(cn * ct * D);
+    w.Hs = dalloc<float>((int64_t)L * ct * cn * H);
+    w.Cs = dalloc<float>((int64_t)L * ct * cn * H);
+    w.ACT = dalloc<float>((int64_t)L * ct * cn * 4 * H);
+    w.dA = dalloc<float>((int64_t)ct * cn * 4 * H);
+    w.dIn = dalloc<float>((int64_t)ct * cn * std::max(D, H));
+    w.dH = dalloc<float>(cn * H);
+    w.dC = dalloc<float>(cn * H);
+    w.cap_N = cn; w.cap_T = ct;
+  }
+}
+
+// rows of this batch that are behind opt_step are replayed before the forward reads them
+static void catch_up(kprn_handle* h, const kprn_batch* b) {
+  if (!h->lazy_pending || b->n_uniq == 0) return;
+  ProfScope ps(h, "adam_rows_catchup");
+  // count lives at the tail of the list buffer
+  kk::adam_rows(h->stream, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, b->uniq, b->uniq + b->uniq_cap, b->n_uniq, h->cfg.de,
+                (int32_t)h->opt_step, 0, h->step_tab, h->last_b1, h->last_b2, h->last_eps);
+}
+
+// ---------------------------------------------------------------------------------------
+// generic (unfused) forward: gather -> per layer {input GEMM, per step recurrent GEMM + gates} -> head
+static void forward_generic(kprn_handle* h, const kprn_batch* b) {
+  const kprn_config& c = h->cfg;
+  Workspace& w = h->ws;
+  const int H = c.H, L = c.L, D = h->D, T = b->T;
+  const int64_t N = (int64_t)b->B * b->P;
+  hipStream_t s = h->stream;
+  {
+    ProfScope ps(h, "embed_gather");
+    kk::embed_gather(s, b->idx, N, T, b->F, c.num_types, h->dense + h->off_Wt, h->We, h->dense + h->off_Wr, c.dt, c.de, c.dr, w.X, true);
+  }
+  for (int l = 0; l < L; ++l) {
+    const int Din = h->layer[l].Din;
+    const float* in = (l == 0) ? w.X : w.Hs + (int64_t)(l - 1) * T * N * H;
+    float* act = w.ACT + (int64_t)l * T * N * 4 * H;
+    float* hs = w.Hs + (int64_t)l * T * N * H;
+    float* cs = w.Cs + (int64_t)l * T * N * H;
+    const float* Wi = h->dense + h->layer[l].Wi;
+    const float* bi = h->dense + h->layer[l].bi;
+    const float* Wo = h->dense + h->layer[l].Wo;
+    {
+      ProfScope ps(h, "gemm_i2g_fwd");
+      gemm::run(s, in, Din, 1, Wi, 1, Din, act, 4 * H, (int64_t)T * N, 4 * H, Din, false, bi, 1);
+    }
+    for (int t = 0; t < T; ++t) {
+      float* act_t = act + (int64_t)t * N * 4 * H;
+      if (t > 0) {
+        ProfScope ps(h, "gemm_o2g_fwd");
+        gemm::run(s, hs + (int64_t)(t - 1) * N * H, H, 1, Wo, 1, H, act_t, 4 * H, N, 4 * H, H, true, nullptr, 1);
+      }
+      ProfScope ps(h, "lstm_gates_fwd");
+      kk::lstm_gates_fwd(s, act_t, t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr, cs + (int64_t)t * N * H, hs + (int64_t)t * N * H, N, H);
+    }
+  }
+  {
+    ProfScope ps(h, "gemm_head_fwd");
+    const float* hT = w.Hs + ((int64_t)(L - 1) * T + (T - 1)) * N * H;
+    gemm::run(s, hT, H, 1, h->dense + h->off_outW, 1, H, w.S, c.C, N, c.C, H, false, h->dense + h->off_outb, 1);
+  }
+}
+
+static void pool_stage(kprn_handle* h, const kprn_batch* b, int cid) {
+  const kprn_config& c = h->cfg;
+  Workspace& w = h->ws;
+  ProfScope ps(h, "pool_sigmoid");
+  kk::pool_sigmoid(h->stream, w.S, b->B, b->P, c.C, c.reducer, c.K, w.pooled, w.probs);
+  kk::select_col(h->stream, w.probs, b->B, c.C, cid, w.sel);
+}
+
+static void check_batch(kprn_handle* h, const kprn_batch* b, int class_id) {
+  KPRN_REQUIRE(b != nullptr, KPRN_E_ARG, "batch is NULL");
+  KPRN_REQUIRE(class_id >= 1 && class_id <= h->cfg.C, KPRN_E_ARG, "classId must be in 1..C (nn.Select(2,classId), MyOptimizer.lua:126)");
+}
+
+static bool use_fused(kprn_handle* h, const kprn_batch* b, bool save_for_backward) {
+  if (h->impl != 0 || !fused::fwd_supported(h, b->T)) return false;
+  return !save_for_backward || fused::bwd_supported(h, b->T);
+}
+
+static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool save_for_backward) {
+  check_batch(h, b, class_id);
+  const int64_t N = (int64_t)b->B * b->P;
+  catch_up(h, b);
+  ensure_ws_common(h, N, b->B);
+  if (use_fused(h, b, save_for_backward)) {
+    fused::forward(h, b, save_for_backward);
+  } else {
+    ensure_ws_generic(h, N, b->T);
+    forward_generic(h, b);
+  }
+  pool_stage(h, b, class_id - 1);
+  h->last_B = b->B;
+}
+
+// zeroGradParameters (MyOptimizer.lua:186): dense arena memset; entity rows cleared by list
+static void zero_grads(kprn_handle* h) {
+  HIP_TRY(hipMemsetAsync(h->g_dense, 0, (size_t)h->n_dense * sizeof(float), h->stream));
+  if (h->ent_grads_dirty && h->step_rows_ub > 0) {
+    // reuse pack-style clear: adagrad_rows with zero lr would touch state; use a dedicated tiny path
+    kk::clear_rows(h->stream, h->g_We, h->step_rows, h->step_count, h->step_rows_ub, h->cfg.de);
+  }
+  h->ent_grads_dirty = false;
+}
+
+static void set_step_rows_from_batch(kprn_handle* h, const kprn_batch* b) {
+  int64_t need = std::max<int64_t>(b->n_uniq, 1);
+  if (need > h->step_rows_cap) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dfree(h->step_rows);
+    h->step_rows_cap = need * 2;
+    h->step_rows = dalloc<int32_t>(h->step_rows_cap);
+  }
+  if (b->n_uniq > 0)
+    HIP_TRY(hipMemcpyAsync(h->step_rows, b->uniq, (size_t)b->n_uniq * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->step_count, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  h->step_rows_ub = b->n_uniq;
+}
+
+static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
+  const kprn_config& c = h->cfg;
+  Workspace& w = h->ws;
+  const int H = c.H, L = c.L, D = h->D, T = b->T;
+  const int64_t N = (int64_t)b->B * b->P;
+  hipStream_t s = h->stream;
+  float* gd = h->g_dense;
+  {
+    ProfScope ps(h, "head_bwd");
+    const float* hT = w.Hs + ((int64_t)(L - 1) * T + (T - 1)) * N * H;
+    kk::head_bwd(s, w.dS, hT, h->dense + h->off_outW, N, H, cid, w.dH, gd + h->off_outW, gd + h->off_outb);
+  }
+  HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), s));
+  const int split = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (T * N) / 2048));
+  for (int l = L - 1; l >= 0; --l) {
+    const int Din = h->layer[l].Din;
+    const float* in = (l == 0) ? w.X : w.Hs + (int64_t)(l - 1) * T * N * H;
+    const float* act = w.ACT + (int64_t)l * T * N * 4 * H;
+    const float* hs = w.Hs + (int64_t)l * T * N * H;
+    const float* cs = w.Cs + (int64_t)l * T * N * H;
+    const float* Wi = h->dense + h->layer[l].Wi;
+    const float* Wo = h->dense + h->layer[l].Wo;
+    const bool has_up = (l < L - 1);
+    if (has_up) {
+      HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
+      HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), s));
+    }
+    for (int t = T - 1; t >= 0; --t) {
+      float* dA_t = w.dA + (int64_t)t * N * 4 * H;
+      {
+        ProfScope ps(h, "lstm_gates_bwd");
+        kk::lstm_gates_bwd(s, act + (int64_t)t * N * 4 * H, cs + (int64_t)t * N * H, t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr,
+                           has_up ? w.dIn + (int64_t)t * N * H : nullptr, w.dH, w.dC, dA_t, N, H);
+      }
+      if (t > 0) {
+        ProfScope ps(h, "gemm_o2g_bwd_dh");
+        gemm::run(s, dA_t, 4 * H, 1, Wo, H, 1, w.dH, H, N, H, 4 * H, false, nullptr, 1);
+      }
+    }
+    if (T > 1) {
+      ProfScope ps(h, "gemm_o2g_bwd_dw");
+      // gWo[4H,H] += dA[1..T-1]^T * h[0..T-2]
+      gemm::run(s, w.dA + (int64_t)N * 4 * H, 1, 4 * H, hs, H, 1, gd + h->layer[l].Wo, H, 4 * H, H, (int64_t)(T - 1) * N, true, nullptr, split);
+    }
+    {
+      ProfScope ps(h, "gemm_i2g_bwd_dw");
+      gemm::run(s, w.dA, 1, 4 * H, in, Din, 1, gd + h->layer[l].Wi, Din, 4 * H, Din, (int64_t)T * N, true, nullptr, split);
+    }
+    {
+      ProfScope ps(h, "bias_colsum");
+      kk::col_sum_add(s, w.dA, (int64_t)T * N, 4 * H, gd + h->layer[l].bi);
+    }
+    {
+      ProfScope ps(h, "gemm_i2g_bwd_dx");
+      gemm::run(s, w.dA, 4 * H, 1, Wi, Din, 1, w.dIn, Din, (int64_t)T * N, Din, 4 * H, false, nullptr, 1);
+    }
+  }
+  {
+    ProfScope ps(h, "embed_scatter");
+    kk::embed_scatter(s, b->idx, N, T, b->F, c.num_types, w.dIn, c.dt, c.de, c.dr, c.Vt, c.Vr, gd + h->off_Wt, h->g_We, gd + h->off_Wr);
+  }
+  (void)D;
+}
+
+static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int literal, float inv_batch) {
+  check_batch(h, b, class_id);
+  KPRN_REQUIRE(b->labels != nullptr, KPRN_E_ARG, "batch has no labels (targets are required, MyOptimizer.lua:179)");
+  const kprn_config& c = h->cfg;
+  zero_grads(h);
+  forward_impl(h, b, class_id, true);
+  Workspace& w = h->ws;
+  const int cid = class_id - 1;
+  float invB = inv_batch > 0.f ? inv_batch : 1.0f / (float)b->B;
+  if (inv_batch <= 0.f && c.world > 1) invB = 1.0f / ((float)b->B * (float)c.world);
+  {
+    ProfScope ps(h, "bce_dscore");
+    kk::bce_and_dscore(h->stream, h->score_buf, w.pooled, w.probs, b->labels, b->B, b->P, c.C, cid, c.reducer, c.K, literal,
+                       invB, h->d_loss, w.dS);
+  }
+  set_step_rows_from_batch(h, b);
+  if (use_fused(h, b, true)) fused::backward(h, b, cid);
+  else backward_generic(h, b, cid);
+  h->ent_grads_dirty = true;
+}
+
+static void apply_update_impl(kprn_handle* h, const kprn_opt* o) {
+  KPRN_REQUIRE(o != nullptr, KPRN_E_ARG, "opt is NULL");
+  KPRN_REQUIRE(o->method == 0 || o->method == 1, KPRN_E_ARG, "opt.method must be 0 (adagrad) or 1 (adam)");
+  const kprn_config& c = h->cfg;
+  hipStream_t s = h->stream;
+  const bool reg = (o->regularize == 1);
+  const bool dense_ent = reg || o->entity_update == 1;
+  const float* norm2 = nullptr;
+  if (reg && o->use_grad_clip) {
+    ProfScope ps(h, "grad_norm");
+    HIP_TRY(hipMemsetAsync(h->d_norm2, 0, sizeof(float), s));
+    kk::sumsq(s, h->g_dense, h->n_dense, h->d_norm2);
+    if (h->step_rows_ub > 0) kk::sumsq_rows(s, h->g_We, h->step_rows, h->step_count, c.de, h->d_norm2);
+    norm2 = h->d_norm2;
+  }
+  const float l2 = reg ? o->l2 : 0.f;
+  if (o->method == 1) {
+    h->last_b1 = o->beta1; h->last_b2 = o->beta2; h->last_eps = o->eps;
+    if (dense_ent && !h->ent_dense_mode) { flush_lazy(h); h->ent_dense_mode = true; }
+    if (!dense_ent && h->ent_dense_mode) {
+      kk::fill_i32(s, h->We_last, c.Ve, (int32_t)h->opt_step);
+      h->ent_dense_mode = false;
+    }
+    h->opt_step += 1;
+    const int64_t t = h->opt_step;
+    step_tab_reserve(h, t + 1);
+    const double bc1 = 1.0 - pow((double)o->beta1, (double)t), bc2 = 1.0 - pow((double)o->beta2, (double)t);
+    const float step = (float)((double)o->lr * sqrt(bc2) / bc1);
+    h->step_tab_host[t] = step;
+    HIP_TRY(hipMemcpyAsync(h->step_tab + t, h->step_tab_host + t, sizeof(float), hipMemcpyHostToDevice, s));
+    {
+      ProfScope ps(h, "adam_dense");
+      kk::adam_dense(s, h->dense, h->g_dense, h->s1_dense, h->s2_dense, h->n_dense, step, o->beta1, o->beta2, o->eps, norm2, o->grad_clip_norm, l2);
+    }
+    if (dense_ent) {
+      ProfScope ps(h, "adam_entity_dense");
+      kk::adam_dense(s, h->We, h->g_We, h->s1_We, h->s2_We, h->n_ent, step, o->beta1, o->beta2, o->eps, norm2, o->grad_clip_norm, l2);
+      if (h->step_rows_ub > 0) kk::clear_rows(s, h->g_We, h->step_rows, h->step_count, h->step_rows_ub, c.de);
+    } else {
+      ProfScope ps(h, "adam_entity_rows");
+      kk::adam_rows(s, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, h->step_rows, h->step_count, h->step_rows_ub, c.de, (int32_t)t, 1,
+                    h->step_tab, o->beta1, o->beta2, o->eps);
+      h->lazy_pending = true;
+    }
+  } else {
+    const float clr = (float)((double)o->lr / (1.0 + (double)h->opt_step * (double)o->lr_decay));
+    {
+      ProfScope ps(h, "adagrad_dense");
+      kk::adagrad_dense(s, h->dense, h->g_dense, h->s1_dense, h->n_dense, clr, norm2, o->grad_clip_norm, l2);
+    }
+    if (reg) {
+      ProfScope ps(h, "adagrad_entity_dense");
+      kk::adagrad_dense(s, h->We, h->g_We, h->s1_We, h->n_ent, clr, norm2, o->grad_clip_norm, l2);
+      if (h->step_rows_ub > 0) kk::clear_rows(s, h->g_We, h->step_rows, h->step_count, h->step_rows_ub, c.de);
+    } else {
+      ProfScope ps(h, "adagrad_entity_rows");
+      kk::adagrad_rows(s, h->We, h->g_We, h->s1_We, h->step_rows, h->step_count, h->step_rows_ub, c.de, clr);
+    }
+    h->opt_step += 1;
+  }
+  h->ent_grads_dirty = false;
+  h->opt_method = o->method;
+  zero_pad_tokens(h);   // MyOptimizer.lua:219
+  fused::params_changed(h);
+}
+
+// ---------------------------------------------------------------------------------------
+#define API_BEGIN(h)                                   \
+  if (!(h)) return KPRN_E_ARG;                         \
+  try {                                                \
+    HIP_TRY(hipSetDevice((h)->cfg.device_id));
+#define API_END(h)                                                                        \
+  }                                                                                       \
+  catch (const KprnError& e) { (h)->err = e.msg; return e.code; }                         \
+  catch (const std::exception& e) { (h)->err = e.what(); return KPRN_E_DEVICE; }          \
+  catch (...) { (h)->err = "unknown error"; return KPRN_E_DEVICE; }                       \
+  return KPRN_OK;
+
+extern "C" {
+
+const char* kprn_version(void) { return "kprn-amd 0.1 gfx950 f32-mfma"; }
+
+const char* kprn_last_error(const kprn_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int kprn_create(const kprn_config* cfg, kprn_handle** out) {
+  if (!cfg || !out) { g_create_error = "kprn_create: NULL argument"; return KPRN_E_ARG; }
+  *out = nullptr;
+  kprn_handle* h = nullptr;
+  try {
+    const kprn_config& c = *cfg;
+    KPRN_REQUIRE(c.Vt > 0 && c.Ve > 0 && c.Vr > 0, KPRN_E_ARG, "vocab sizes must be positive");
+    KPRN_REQUIRE(c.dt > 0 && c.de > 0 && c.dr > 0, KPRN_E_ARG, "embedding dims must be positive");
+    KPRN_REQUIRE(c.num_types >= 1, KPRN_E_ARG, "numEntityTypes must be >= 1");
+    KPRN_REQUIRE(c.num_types <= c.F, KPRN_E_ARG, "assert(numEntityTypes <= numFeatureTemplates) (OneModel.lua:107)");
+    KPRN_REQUIRE(c.F >= c.num_types + 2, KPRN_E_ARG, "numFeatureTemplates must cover types + entity + relation (FeatureEmbedding.lua:51)");
+    KPRN_REQUIRE(c.H > 0 && c.C > 0, KPRN_E_ARG, "rnnHidSize and labelDimension must be positive");
+    KPRN_REQUIRE(c.L >= 1 && c.L <= KPRN_MAX_LAYERS, KPRN_E_ARG, "numLayers must be in 1..8");
+    KPRN_REQUIRE(c.rnn_type == 0, KPRN_E_UNSUPPORTED, "only rnnType=lstm (nn.FastLSTM) is built; rnn/gru are on the roadmap (SURVEY 8f N4)");
+    KPRN_REQUIRE(c.reducer >= 0 && c.reducer <= 2, KPRN_E_ARG, "topK must be 0 (max), 1 (topK) or 2 (LogSumExp)");
+    KPRN_REQUIRE(c.reducer != 1 || c.K >= 1, KPRN_E_ARG, "K must be >= 1 for the topK reducer");
+    KPRN_REQUIRE(c.L == 1 || (c.dt + c.de + c.dr) == c.H, KPRN_E_ARG,
+                 "numLayers > 1 needs totalInputEmbeddingDim == rnnHidSize: every layer is FastLSTM(D,H) (OneModel.lua:236,270-273)");
+    KPRN_REQUIRE(c.world >= 1 && c.rank >= 0 && c.rank < c.world, KPRN_E_ARG, "bad rank/world");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    KPRN_REQUIRE(ndev > 0, KPRN_E_DEVICE, "no HIP device visible: libkprn has no CPU path");
+    KPRN_REQUIRE(c.device_id >= 0 && c.device_id < ndev, KPRN_E_ARG, "device_id out of range");
+    HIP_TRY(hipSetDevice(c.device_id));
+    h = new kprn_handle();
+    h->cfg = c;
+    if (c.stream) { h->stream = (hipStream_t)c.stream; h->own_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    build_layout(h);
+    h->dense = dalloc<float>(h->n_dense); h->g_dense = dalloc<float>(h->n_dense);
+    h->s1_dense = dalloc<float>(h->n_dense); h->s2_dense = dalloc<float>(h->n_dense);
+    h->We = dalloc<float>(h->n_ent); h->g_We = dalloc<float>(h->n_ent);
+    h->s1_We = dalloc<float>(h->n_ent); h->s2_We = dalloc<float>(h->n_ent);
+    h->We_last = dalloc<int32_t>(c.Ve); h->We_stamp = dalloc<int32_t>(c.Ve);
+    h->d_loss = dalloc<float>(4); h->d_norm2 = dalloc<float>(4); h->d_flag = dalloc<int32_t>(4);
+    h->step_count = dalloc<int32_t>(4);
+    HIP_TRY(hipHostMalloc((void**)&h->h_pinned, 64 * sizeof(float)));
+    hipStream_t s = h->stream;
+    for (float* p : {h->g_dense, h->s1_dense, h->s2_dense}) HIP_TRY(hipMemsetAsync(p, 0, (size_t)h->n_dense * sizeof(float), s));
+    for (float* p : {h->g_We, h->s1_We, h->s2_We}) HIP_TRY(hipMemsetAsync(p, 0, (size_t)h->n_ent * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(h->We_last, 0, (size_t)c.Ve * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(h->We_stamp, 0, (size_t)c.Ve * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(h->d_loss, 0, 4 * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(h->step_count, 0, 4 * sizeof(int32_t), s));
+    // param:uniform(-paramInit, paramInit) over training_net:parameters() (OneModel.lua:306-309)
+    for (auto& p : h->params) {
+      float* dst = (p.where == 1 ? h->We : h->dense) + p.dev_off;
+      kk::fill_uniform(s, dst, p.rows * p.cols, c.param_init, c.seed, (uint64_t)p.flat_off);
+    }
+    step_tab_reserve(h, 1);
+    HIP_TRY(hipStreamSynchronize(s));
+    *out = h;
+    return KPRN_OK;
+  } catch (const KprnError& e) {
+    g_create_error = e.msg;
+    if (h) kprn_destroy(h);
+    return e.code;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    if (h) kprn_destroy(h);
+    return KPRN_E_DEVICE;
+  }
+}
+
+void kprn_destroy(kprn_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device_id);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  prof_drain(h);
+  fused::release(h);
+  for (auto e : h->event_pool) hipEventDestroy(e);
+  Workspace& w = h->ws;
+  for (float** p : {&w.X, &w.Hs, &w.Cs, &w.ACT, &w.dA, &w.dIn, &w.dH, &w.dC, &w.S, &w.dS, &w.pooled, &w.probs, &w.sel, &w.dy}) dfree(*p);
+  for (float** p : {&h->dense, &h->g_dense, &h->s1_dense, &h->s2_dense, &h->We, &h->g_We, &h->s1_We, &h->s2_We, &h->d_loss, &h->d_norm2,
+                    &h->step_tab, &h->pack_rows})
+    dfree(*p);
+  for (int32_t** p : {&h->We_last, &h->We_stamp, &h->d_flag, &h->step_rows, &h->step_count, &h->pack_ids, &h->pack_count}) dfree(*p);
+  if (h->step_tab_host) hipHostFree(h->step_tab_host);
+  if (h->h_pinned) hipHostFree(h->h_pinned);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int kprn_num_params(kprn_handle* h, int64_t* n) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(n, KPRN_E_ARG, "n is NULL");
+  *n = h->n_params;
+  API_END(h)
+}
+
+static int copy_named(kprn_handle* h, const char* name, float* dst, const float* src, int64_t n, int which /*0 param,1 grad*/) {
+  API_BEGIN(h)
+  const ParamInfo* p = find_param(h, name);
+  KPRN_REQUIRE(p, KPRN_E_ARG, std::string("unknown parameter name: ") + (name ? name : "(null)"));
+  KPRN_REQUIRE(n == p->rows * p->cols, KPRN_E_ARG, "element count does not match the tensor");
+  KPRN_REQUIRE(dst || src, KPRN_E_ARG, "NULL buffer");
+  if (p->where == 1 && which == 0) flush_lazy(h);
+  float* base;
+  if (which == 0) base = (p->where == 1 ? h->We : h->dense);
+  else base = (p->where == 1 ? h->g_We : h->g_dense);
+  base += p->dev_off;
+  if (dst) {
+    HIP_TRY(hipMemcpyAsync(dst, base, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(base, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    fused::params_changed(h);
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  API_END(h)
+}
+
+int kprn_get_param(kprn_handle* h, const char* name, float* dst, int64_t n) { return copy_named(h, name, dst, nullptr, n, 0); }
+int kprn_set_param(kprn_handle* h, const char* name, const float* src, int64_t n) { return copy_named(h, name, nullptr, src, n, 0); }
+int kprn_get_grad(kprn_handle* h, const char* name, float* dst, int64_t n) { return copy_named(h, name, dst, nullptr, n, 1); }
+
+static int copy_flat(kprn_handle* h, float* dst, const float* src, int64_t n, int which /*0 param,1 grad,2 s1,3 s2*/) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(n == h->n_params, KPRN_E_ARG, "n must equal kprn_num_params");
+  KPRN_REQUIRE(dst || src, KPRN_E_ARG, "NULL buffer");
+  if (which != 1) flush_lazy(h);
+  for (auto& p : h->params) {
+    float* base;
+    switch (which) {
+      case 0: base = (p.where == 1 ? h->We : h->dense); break;
+      case 1: base = (p.where == 1 ? h->g_We : h->g_dense); break;
+      case 2: base = (p.where == 1 ? h->s1_We : h->s1_dense); break;
+      default: base = (p.where == 1 ? h->s2_We : h->s2_dense); break;
+    }
+    base += p.dev_off;
+    const size_t bytes = (size_t)(p.rows * p.cols) * sizeof(float);
+    if (dst) HIP_TRY(hipMemcpyAsync(dst + p.flat_off, base, bytes, hipMemcpyDeviceToHost, h->stream));
+    else HIP_TRY(hipMemcpyAsync(base, src + p.flat_off, bytes, hipMemcpyHostToDevice, h->stream));
+  }
+  if (!dst) fused::params_changed(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  API_END(h)
+}
+int kprn_get_flat_params(kprn_handle* h, float* dst, int64_t n) { return copy_flat(h, dst, nullptr, n, 0); }
+int kprn_set_flat_params(kprn_handle* h, const float* src, int64_t n) { return copy_flat(h, nullptr, src, n, 0); }
+int kprn_get_flat_grads(kprn_handle* h, float* dst, int64_t n) { return copy_flat(h, dst, nullptr, n, 1); }
+int kprn_get_flat_opt_state(kprn_handle* h, int32_t slot, float* dst, int64_t n) {
+  if (slot != 0 && slot != 1) { if (h) h->err = "slot must be 0 or 1"; return KPRN_E_ARG; }
+  return copy_flat(h, dst, nullptr, n, 2 + slot);
+}
+
+int kprn_zero_pad_tokens(kprn_handle* h) {
+  API_BEGIN(h)
+  zero_pad_tokens(h);
+  fused::params_changed(h);
+  API_END(h)
+}
+
+int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, int32_t B, int32_t P, int32_t T, int32_t F, kprn_batch** out) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(out, KPRN_E_ARG, "out is NULL");
+  *out = nullptr;
+  KPRN_REQUIRE(idx, KPRN_E_ARG, "idx is NULL");
+  KPRN_REQUIRE(B > 0 && P > 0 && T > 0, KPRN_E_ARG, "B, P, T must be positive");
+  KPRN_REQUIRE(F == h->cfg.F, KPRN_E_ARG, "F does not match numFeatureTemplates");
+  kprn_batch* b = new kprn_batch();
+  try {
+    b->B = B; b->P = P; b->T = T; b->F = F;
+    const int64_t nsteps = (int64_t)B * P * T;
+    b->idx = dalloc<int32_t>(nsteps * F);
+    HIP_TRY(hipMemcpyAsync(b->idx, idx, (size_t)nsteps * F * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if (labels) {
+      b->labels = dalloc<float>(B);
+      HIP_TRY(hipMemcpyAsync(b->labels, labels, (size_t)B * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t), h->stream));
+    kk::validate_indices(h->stream, b->idx, nsteps, F, h->cfg.num_types, h->cfg.Vt, h->cfg.Ve, h->cfg.Vr, h->d_flag);
+    int32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, h->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    KPRN_REQUIRE(flag == 0, KPRN_E_INDEX, "an index is outside 1..vocabSize (ids are 1-based, int2torch.lua:60-63)");
+    b->uniq_cap = nsteps;
+    b->uniq = dalloc<int32_t>(nsteps + 4);
+    HIP_TRY(hipMemsetAsync(b->uniq + b->uniq_cap, 0, sizeof(int32_t), h->stream));
+    const int32_t tag = h->next_tag++;
+    kk::unique_rows(h->stream, b->idx, nsteps, F, h->We_stamp, tag, b->uniq, b->uniq + b->uniq_cap);
+    HIP_TRY(hipMemcpyAsync(&b->n_uniq, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  } catch (...) {
+    dfree(b->idx); dfree(b->labels); dfree(b->uniq);
+    delete b;
+    throw;
+  }
+  *out = b;
+  API_END(h)
+}
+
+void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
+  if (!b) return;
+  if (h) { hipSetDevice(h->cfg.device_id); hipStreamSynchronize(h->stream); }
+  dfree(b->idx); dfree(b->labels); dfree(b->uniq);
+  delete b;
+}
+
+int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id) {
+  API_BEGIN(h)
+  forward_impl(h, b, class_id, false);
+  API_END(h)
+}
+
+int kprn_read_probs(kprn_handle* h, float* probs, int32_t B) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(probs && B > 0 && B <= h->last_B, KPRN_E_ARG, "bad probs buffer / B");
+  HIP_TRY(hipMemcpyAsync(probs, h->ws.sel, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  prof_drain(h);
+  API_END(h)
+}
+
+int kprn_forward_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, float* probs, float* all_probs, float* pooled, float* path_scores) {
+  API_BEGIN(h)
+  forward_impl(h, b, class_id, false);
+  const int C = h->cfg.C;
+  hipStream_t s = h->stream;
+  if (probs) HIP_TRY(hipMemcpyAsync(probs, h->ws.sel, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (all_probs) HIP_TRY(hipMemcpyAsync(all_probs, h->ws.probs, (size_t)b->B * C * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (pooled) HIP_TRY(hipMemcpyAsync(pooled, h->ws.pooled, (size_t)b->B * C * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (path_scores)
+    HIP_TRY(hipMemcpyAsync(path_scores, h->score_buf, (size_t)b->B * b->P * C * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  prof_drain(h);
+  API_END(h)
+}
+
+int kprn_forward(kprn_handle* h, const int32_t* idx, int32_t B, int32_t P, int32_t T, int32_t F, int32_t class_id, float* probs, float* all_probs) {
+  if (!h) return KPRN_E_ARG;
+  kprn_batch* b = nullptr;
+  int rc = kprn_batch_create(h, idx, nullptr, B, P, T, F, &b);
+  if (rc != KPRN_OK) return rc;
+  rc = kprn_forward_batch(h, b, class_id, probs, all_probs, nullptr, nullptr);
+  kprn_batch_destroy(h, b);
+  return rc;
+}
+
+int kprn_embed(kprn_handle* h, const int32_t* idx, int64_t N, int32_t T, int32_t F, float* x) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(idx && x && N > 0 && T > 0 && F == h->cfg.F, KPRN_E_ARG, "bad arguments");
+  KPRN_REQUIRE(N < (1ll << 31), KPRN_E_ARG, "N too large");
+  kprn_batch* b = nullptr;
+  {
+    int rc = kprn_batch_create(h, idx, nullptr, (int32_t)N, 1, T, F, &b);
+    if (rc != KPRN_OK) return rc;
+  }
+  float* dx = nullptr;
+  try {
+    catch_up(h, b);
+    const kprn_config& c = h->cfg;
+    dx = dalloc<float>(N * T * h->D);
+    kk::embed_gather(h->stream, b->idx, N, T, F, c.num_types, h->dense + h->off_Wt, h->We, h->dense + h->off_Wr, c.dt, c.de, c.dr, dx, false);
+    HIP_TRY(hipMemcpyAsync(x, dx, (size_t)N * T * h->D * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  } catch (...) { dfree(dx); kprn_batch_destroy(h, b); throw; }
+  dfree(dx);
+  kprn_batch_destroy(h, b);
+  API_END(h)
+}
+
+int kprn_backward_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, int32_t bce_literal, float inv_batch, float* loss) {
+  API_BEGIN(h)
+  backward_impl(h, b, class_id, bce_literal, inv_batch);
+  if (loss) {
+    HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    prof_drain(h);
+  }
+  API_END(h)
+}
+
+int kprn_apply_update(kprn_handle* h, const kprn_opt* opt) {
+  API_BEGIN(h)
+  apply_update_impl(h, opt);
+  API_END(h)
+}
+
+int kprn_train_step_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, const kprn_opt* opt, float* loss) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(opt, KPRN_E_ARG, "opt is NULL");
+  check_batch(h, b, class_id);
+  catch_up(h, b);
+  zero_pad_tokens(h);  // MyOptimizer.lua:181
+  fused::params_changed(h);
+  backward_impl(h, b, class_id, opt->bce_literal, 0.f);
+  apply_update_impl(h, opt);
+  if (loss) {
+    HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    prof_drain(h);
+  }
+  API_END(h)
+}
+
+int kprn_train_step(kprn_handle* h, const int32_t* idx, int32_t B, int32_t P, int32_t T, int32_t F, const float* labels, int32_t class_id,
+                    const kprn_opt* opt, float* loss) {
+  if (!h) return KPRN_E_ARG;
+  if (!labels) { h->err = "assert(targets) (MyOptimizer.lua:179)"; return KPRN_E_ARG; }
+  kprn_batch* b = nullptr;
+  int rc = kprn_batch_create(h, idx, labels, B, P, T, F, &b);
+  if (rc != KPRN_OK) return rc;
+  float l = 0.f;
+  rc = kprn_train_step_batch(h, b, class_id, opt, &l);
+  if (loss) *loss = l;
+  kprn_batch_destroy(h, b);
+  return rc;
+}
+
+int kprn_read_loss(kprn_handle* h, float* loss) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(loss, KPRN_E_ARG, "loss is NULL");
+  HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  prof_drain(h);
+  API_END(h)
+}
+
+int kprn_sync(kprn_handle* h) {
+  API_BEGIN(h)
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  prof_drain(h);
+  API_END(h)
+}
+
+// ---- data-parallel hooks ------------------------------------------------------------------
+int kprn_dense_grad_buffer(kprn_handle* h, void** dev_ptr, int64_t* n_floats) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(dev_ptr && n_floats, KPRN_E_ARG, "NULL argument");
+  *dev_ptr = h->g_dense;
+  *n_floats = h->n_dense;
+  API_END(h)
+}
+
+int kprn_sparse_grad_capacity(kprn_handle* h, int32_t* max_rows) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(max_rows, KPRN_E_ARG, "NULL argument");
+  *max_rows = (int32_t)std::min<int64_t>(h->step_rows_ub, h->cfg.Ve);
+  API_END(h)
+}
+
+int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_ids, void** dev_rows, void** dev_count) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(dev_ids && dev_rows && dev_count, KPRN_E_ARG, "NULL argument");
+  KPRN_REQUIRE(capacity >= h->step_rows_ub && capacity > 0, KPRN_E_ARG, "capacity smaller than this step's touched-row count");
+  if (capacity > h->pack_cap) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dfree(h->pack_ids); dfree(h->pack_rows); dfree(h->pack_count);
+    h->pack_ids = dalloc<int32_t>(capacity);
+    h->pack_rows = dalloc<float>((int64_t)capacity * h->cfg.de);
+    h->pack_count = dalloc<int32_t>(4);
+    h->pack_cap = capacity;
+  }
+  {
+    ProfScope ps(h, "dp_pack_rows");
+    kk::pack_rows(h->stream, h->g_We, h->step_rows, h->step_count, h->step_rows_ub, h->cfg.de, h->pack_ids, h->pack_rows, h->pack_count);
+  }
+  // the per-step list is rebuilt as the union over ranks by kprn_sparse_grad_unpack_add
+  HIP_TRY(hipMemsetAsync(h->step_count, 0, sizeof(int32_t), h->stream));
+  h->step_rows_ub = 0;
+  h->step_tag = h->next_tag++;
+  *dev_ids = h->pack_ids; *dev_rows = h->pack_rows; *dev_count = h->pack_count;
+  API_END(h)
+}
+
+int kprn_sparse_grad_unpack_add(kprn_handle* h, const void* dev_ids, const void* dev_rows, const void* dev_count, int32_t capacity) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(dev_ids && dev_rows && dev_count && capacity > 0, KPRN_E_ARG, "bad argument");
+  KPRN_REQUIRE(h->step_tag != 0, KPRN_E_ARG, "kprn_sparse_grad_pack must be called first");
+  int64_t need = std::min<int64_t>(h->step_rows_ub + capacity, h->cfg.Ve);
+  if (need > h->step_rows_cap) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int32_t* nl = dalloc<int32_t>(need * 2);
+    if (h->step_rows && h->step_rows_ub > 0)
+      HIP_TRY(hipMemcpy(nl, h->step_rows, (size_t)h->step_rows_ub * sizeof(int32_t), hipMemcpyDeviceToDevice));
+    dfree(h->step_rows);
+    h->step_rows = nl; h->step_rows_cap = need * 2;
+  }
+  {
+    ProfScope ps(h, "dp_unpack_add");
+    kk::unpack_add_rows(h->stream, h->g_We, (const int32_t*)dev_ids, (const float*)dev_rows, (const int32_t*)dev_count, capacity, h->cfg.de,
+                        h->We_stamp, h->step_tag, h->step_rows, h->step_count);
+  }
+  h->step_rows_ub = need;
+  h->ent_grads_dirty = true;
+  API_END(h)
+}
+
+int kprn_stream(kprn_handle* h, void** stream) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(stream, KPRN_E_ARG, "NULL argument");
+  *stream = (void*)h->stream;
+  API_END(h)
+}
+
+// ---- checkpoints ------------------------------------------------------------------------
+static const char kMagic[8] = {'K', 'P', 'R', 'N', 'A', 'M', 'D', '1'};
+
+int kprn_save(kprn_handle* h, const char* path) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(path, KPRN_E_ARG, "path is NULL");
+  std::vector<float> flat((size_t)h->n_params);
+  {
+    int rc = kprn_get_flat_params(h, flat.data(), h->n_params);
+    if (rc != KPRN_OK) return rc;
+  }
+  FILE* f = fopen(path, "wb");
+  KPRN_REQUIRE(f, KPRN_E_IO, std::string("cannot open for writing: ") + path);
+  const kprn_config& c = h->cfg;
+  int32_t hdr[16] = {c.Vt, c.Ve, c.Vr, c.dt, c.de, c.dr, c.F, c.num_types, c.H, c.L, c.C, c.rnn_type, c.reducer, c.K, 0, 0};
+  bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, sizeof(int32_t), 16, f) == 16 && fwrite(&h->n_params, sizeof(int64_t), 1, f) == 1 &&
+            fwrite(flat.data(), sizeof(float), flat.size(), f) == flat.size();
+  ok = (fclose(f) == 0) && ok;
+  KPRN_REQUIRE(ok, KPRN_E_IO, "short write");
+  API_END(h)
+}
+
+int kprn_load(kprn_handle* h, const char* path) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(path, KPRN_E_ARG, "path is NULL");
+  FILE* f = fopen(path, "rb");
+  KPRN_REQUIRE(f, KPRN_E_IO, std::string("cannot open: ") + path);
+  char magic[8];
+  int32_t hdr[16];
+  int64_t n = 0;
+  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kMagic, 8) == 0 && fread(hdr, sizeof(int32_t), 16, f) == 16 &&
+            fread(&n, sizeof(int64_t), 1, f) == 1;
+  const kprn_config& c = h->cfg;
+  const int32_t want[11] = {c.Vt, c.Ve, c.Vr, c.dt, c.de, c.dr, c.F, c.num_types, c.H, c.L, c.C};
+  if (ok) ok = memcmp(hdr, want, sizeof(want)) == 0 && n == h->n_params;
+  std::vector<float> flat;
+  if (ok) { flat.resize((size_t)n); ok = fread(flat.data(), sizeof(float), flat.size(), f) == flat.size(); }
+  fclose(f);
+  KPRN_REQUIRE(ok, KPRN_E_IO, "not a kprn checkpoint for this configuration");
+  return kprn_set_flat_params(h, flat.data(), n);
+  API_END(h)
+}
+
+// ---- measurement ------------------------------------------------------------------------
+int kprn_profile_enable(kprn_handle* h, int32_t on) {
+  API_BEGIN(h)
+  prof_drain(h);
+  h->prof_on = on != 0;
+  API_END(h)
+}
+int kprn_profile_reset(kprn_handle* h) {
+  API_BEGIN(h)
+  prof_drain(h);
+  h->prof.clear();
+  API_END(h)
+}
+int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t* n) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(n, KPRN_E_ARG, "n is NULL");
+  prof_drain(h);
+  int k = 0;
+  for (auto& kv : h->prof) {
+    if (out && k < cap) {
+      memset(&out[k], 0, sizeof(kprn_prof_entry));
+      strncpy(out[k].name, kv.first.c_str(), sizeof(out[k].name) - 1);
+      out[k].total_ms = kv.second.total_ms;
+      out[k].launches = kv.second.launches;
+    }
+    ++k;
+  }
+  *n = k;
+  API_END(h)
+}
+
+int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(key && value, KPRN_E_ARG, "NULL argument");
+  if (strcmp(key, "impl") == 0) {
+    if (strcmp(value, "auto") == 0) h->impl = 0;
+    else if (strcmp(value, "generic") == 0) h->impl = 1;
+    else throw KprnError{KPRN_E_ARG, "impl must be auto or generic"};
+  } else {
+    throw KprnError{KPRN_E_ARG, std::string("unknown option: ") + key};
+  }
+  API_END(h)
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+// Internal declarations of libkprn.so (gfx950 only).  Public boundary: include/kprn.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/kprn.h"
+
+#define KPRN_MAX_LAYERS 8
+
+// ---- error plumbing ---------------------------------------------------------------
+struct KprnError { int code; std::string msg; };
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      throw KprnError{KPRN_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)}; \
+  } while (0)
+#define KPRN_REQUIRE(cond, code, text) \
+  do { if (!(cond)) throw KprnError{(code), std::string(text)}; } while (0)
+
+// ---- parameter table ----------------------------------------------------------------
+struct ParamInfo {
+  std::string name;
+  int64_t flat_off;   // offset in the reference getParameters() order
+  int64_t rows, cols; // cols == 1 for biases
+  int where;          // 0 = dense arena, 1 = entity table
+  int64_t dev_off;    // offset inside that device buffer
+};
+
+struct LayerOff {     // offsets into the dense arena
+  int64_t Wi, bi, Wo;
+  int Din;
+};
+
+// ---- workspace for the generic (unfused) pipeline -------------------------------------
+struct Workspace {
+  int64_t cap_N = 0;   // paths (generic-pipeline buffers)
+  int cap_T = 0;
+  int64_t cap_Nc = 0;  // paths (common buffers S, dS)
+  float* X = nullptr;      // [T][N][D]      gathered step inputs (time-major)
+  float* Hs = nullptr;     // [L][T][N][H]
+  float* Cs = nullptr;     // [L][T][N][H]
+  float* ACT = nullptr;    // [L][T][N][4H]  pre-activations overwritten by gate values i,g,f,o
+  float* dA = nullptr;     // [T][N][4H]     pre-activation grads of the layer being processed
+  float* dIn = nullptr;    // [T][N][max(D,H)]
+  float* dH = nullptr;     // [N][H]
+  float* dC = nullptr;     // [N][H]
+  float* S = nullptr;      // [N][C]   mapper output
+  float* dS = nullptr;     // [N]      grad wrt S[:, classId]
+  int64_t cap_B = 0;
+  float* pooled = nullptr; // [B][C]
+  float* probs = nullptr;  // [B][C]
+  float* sel = nullptr;    // [B] probs[:, classId]
+  float* dy = nullptr;     // [B]
+};
+
+struct ProfEntry { double total_ms = 0; int64_t launches = 0; };
+
+struct kprn_batch {
+  int32_t B, P, T, F;
+  int32_t* idx = nullptr;     // device [B,P,T,F]
+  float* labels = nullptr;    // device [B] or null
+  int32_t* uniq = nullptr;    // device: distinct entity rows of this batch (0-based); count at uniq[uniq_cap]
+  int64_t uniq_cap = 0;
+  int32_t n_uniq = 0;
+};
+
+struct kprn_handle {
+  kprn_config cfg;
+  int D = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // parameters
+  std::vector<ParamInfo> params;
+  int64_t n_params = 0, n_dense = 0, n_ent = 0;
+  int64_t off_Wt = 0, off_Wr = 0, off_outW = 0, off_outb = 0;
+  LayerOff layer[KPRN_MAX_LAYERS];
+  float *dense = nullptr, *g_dense = nullptr, *s1_dense = nullptr, *s2_dense = nullptr;
+  float *We = nullptr, *g_We = nullptr, *s1_We = nullptr, *s2_We = nullptr;
+
+  // lazy-exact entity update bookkeeping
+  int32_t* We_last = nullptr;   // [Ve] optimiser step each row is current to
+  int32_t* We_stamp = nullptr;  // [Ve] membership tags for the per-batch / per-step row lists
+  int32_t next_tag = 1;
+  int64_t opt_step = 0;         // optState.t / evalCounter
+  int opt_method = -1;
+  float* step_tab = nullptr;    // device: adam step size of every step so far (index = step)
+  float* step_tab_host = nullptr; // pinned mirror
+  int64_t step_tab_cap = 0;
+  bool lazy_pending = false;    // some entity rows are behind opt_step
+  bool ent_dense_mode = false;  // entity table currently updated densely (We_last not maintained)
+  bool ent_grads_dirty = false; // g_We holds this step's rows (cleared by the optimiser / zero_grads)
+  float last_b1 = 0.9f, last_b2 = 0.999f, last_eps = 1e-8f;
+
+  // per-step touched-row list (union over ranks in data-parallel runs)
+  int32_t* step_rows = nullptr;
+  int32_t* step_count = nullptr; // device scalar
+  int64_t step_rows_cap = 0;
+  int64_t step_rows_ub = 0;      // host-side upper bound of *step_count
+  int32_t step_tag = 0;
+  // packing buffers for the data-parallel exchange
+  int32_t* pack_ids = nullptr; float* pack_rows = nullptr; int32_t* pack_count = nullptr; int64_t pack_cap = 0;
+
+  // scalars on device
+  float* d_loss = nullptr;      // [1]
+  float* d_norm2 = nullptr;     // [1] sum g^2
+  int32_t* d_flag = nullptr;    // [1] index-validation flag
+  float* h_pinned = nullptr;    // pinned host scratch [>= 16]
+
+  Workspace ws;
+  float* score_buf = nullptr;   // where the mapper output [N][C] of the last forward lives (ws.S)
+  void* fused_state = nullptr;  // owned by lstm_fused.hip
+  int impl = 0;                 // 0 auto, 1 generic
+  int32_t last_B = 0;
+
+  bool prof_on = false;
+  std::map<std::string, ProfEntry> prof;
+  struct Pending { std::string name; hipEvent_t a, b; };
+  std::vector<Pending> prof_pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+// ---- profiling scope: HIP events on the handle's stream ------------------------------------
+struct ProfScope {
+  kprn_handle* h; const char* name; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(kprn_handle* h_, const char* n);
+  ~ProfScope();
+};
+void prof_drain(kprn_handle* h);
+
+// ---- kernels (kernels_basic.hip) -----------------------------------------------------------
+namespace kk {
+void validate_indices(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int nT, int Vt, int Ve, int Vr, int32_t* flag);
+void unique_rows(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int32_t* stamp, int32_t tag, int32_t* list, int32_t* count);
+void embed_gather(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* Wt, const float* We,
+                  const float* Wr, int dt, int de, int dr, float* X, bool time_major);
+void lstm_gates_fwd(hipStream_t s, float* act /*[N][4H] in: pre-act, out: gates*/, const float* c_prev, float* c, float* h, int64_t N, int H);
+void lstm_gates_bwd(hipStream_t s, const float* act, const float* c, const float* c_prev, const float* dH_up /*nullable*/,
+                    float* dH, float* dC, float* dA, int64_t N, int H);
+void add_bias_rows(hipStream_t s, float* Y, const float* b, int64_t rows, int cols);
+void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out);
+void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs);
+void select_col(hipStream_t s, const float* probs, int B, int C, int cid, float* sel);
+void bce_and_dscore(hipStream_t s, const float* S, const float* pooled, const float* probs, const float* labels, int B, int P, int C,
+                    int cid, int reducer, int K, int literal, float invB, float* loss, float* dS /*[N]*/);
+void head_bwd(hipStream_t s, const float* dS, const float* hT, const float* Wout, int64_t N, int H, int cid, float* dH, float* gWout, float* gbout);
+void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* dX /*[T][N][D]*/, int dt, int de, int dr,
+                   int Vt, int Vr, float* gWt, float* gWe, float* gWr);
+void sumsq(hipStream_t s, const float* x, int64_t n, float* out);
+void sumsq_rows(hipStream_t s, const float* G, const int32_t* rows, const int32_t* count, int d, float* out);
+// dense optimiser over a contiguous span; scale_src: device float norm2 -> clip factor computed in-kernel
+void adam_dense(hipStream_t s, float* x, const float* g, float* m, float* v, int64_t n, float step, float b1, float b2, float eps,
+                const float* norm2, float clip, float l2);
+void adagrad_dense(hipStream_t s, float* x, const float* g, float* G, int64_t n, float clr, const float* norm2, float clip, float l2);
+// lazy-exact row update of the entity table
+void adam_rows(hipStream_t s, float* W, float* g, float* m, float* v, int32_t* last, const int32_t* rows, const int32_t* count, int64_t max_rows,
+               int d, int32_t t_now, int apply_step, const float* step_tab, float b1, float b2, float eps);
+void adam_flush_all(hipStream_t s, float* W, float* m, float* v, int32_t* last, int64_t V, int d, int32_t t_now, const float* step_tab, float b1, float b2, float eps);
+void adagrad_rows(hipStream_t s, float* W, float* g, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, float clr);
+void zero_rows(hipStream_t s, float* W, int64_t row, int d);
+void pack_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, int32_t* ids_out, float* rows_out, int32_t* count_out);
+void unpack_add_rows(hipStream_t s, float* G, const int32_t* ids, const float* rows, const int32_t* count, int64_t max_rows, int d,
+                     int32_t* stamp, int32_t tag, int32_t* list, int32_t* list_count);
+void fill_uniform(hipStream_t s, float* x, int64_t n, float a, uint64_t seed, uint64_t offset);
+void fill_i32(hipStream_t s, int32_t* x, int64_t n, int32_t v);
+void clear_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d);
+}  // namespace kk
+
+// ---- GEMM (gemm_f32.hip): C[M,N] (+)= A(M,K) * B(K,N), arbitrary strides, fp32 MFMA -----------
+namespace gemm {
+// element (m,k) of A at A[m*sAm + k*sAk]; (k,n) of B at B[k*sBk + n*sBn]; C row-major ldc.
+// accumulate: C += (atomic when split_k > 1); else C = A*B (+ bias[n]).
+void run(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C, int64_t ldc,
+         int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k);
+}
