@@ -167,8 +167,15 @@ class Engine:
         return out
 
     # -- parameters ----------------------------------------------------------------------
+    def _shape(self, name):
+        lay = self.layout()
+        if name not in lay:  # let the library produce its own error code / message
+            self._ck(self.L.kprn_get_param(self.h, str(name).encode(), None, C.c_int64(0)))
+            raise KprnError(E_ARG, f"unknown parameter name: {name}")
+        return lay[name][1]
+
     def get_param(self, name):
-        off, shp = self.layout()[name]
+        shp = self._shape(name)
         a = np.empty(shp, np.float32)
         self._ck(self.L.kprn_get_param(self.h, name.encode(), _fp(a), C.c_int64(a.size)))
         return a
@@ -178,7 +185,7 @@ class Engine:
         self._ck(self.L.kprn_set_param(self.h, name.encode(), _fp(a), C.c_int64(a.size)))
 
     def get_grad(self, name):
-        off, shp = self.layout()[name]
+        shp = self._shape(name)
         a = np.empty(shp, np.float32)
         self._ck(self.L.kprn_get_grad(self.h, name.encode(), _fp(a), C.c_int64(a.size)))
         return a
