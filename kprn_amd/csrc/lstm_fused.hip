@@ -270,6 +270,284 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   }
 }
 
+// ============================================================================================
+// Fused backward (BPTT) -- one launch per layer, top layer first.
+//
+// Stands in for the backward of nn.Sequencer(nn.FastLSTM) x L + FeatureEmbedding
+// (model/OneModel.lua:223-274 via MyOptimizer.lua:195 model:backward): exact BPTT over all T
+// steps, weight gradients accumulated over steps, LookupTable scatter-add for layer 1.
+//
+// Per 64-path tile, t = T-1 .. 0:
+//   A. stage the step's input tile (x_t re-gathered, or h^{l-1}_t) and h^l_{t-1} row-major in LDS
+//   C. per 16-row m-tile: cell backward, lane-local on the saved gate fragments (same wave <-> hidden
+//      tile ownership as the forward) -> dA (pre-activation grads) in the MFMA C layout.  Those
+//      registers ARE the A operand of dW = dA^T [x | h]  (k-slot = lane>>4 <-> row 4*(lane>>4)+r), so
+//      dW += is issued straight away with B fragments read from the LDS tiles; dW (128 VGPRs) and db
+//      stay in registers for the WHOLE launch and are flushed with atomics once per workgroup.
+//      dA is also written row-major to LDS.
+//   E. [dx | dh_{t-1}] = dA [W_i2g | W_o2g]: A from LDS (ds_read_b128), B = one 16-byte load of the
+//      TRANSPOSED weights (WT[n][k], rebuilt when parameters change) streamed from L2.  dh_{t-1} goes
+//      to an LDS tile for the next (earlier) step; dx goes to HBM for the layer below, or -- bottom
+//      layer -- is scattered to the embedding gradients directly from the accumulators (types /
+//      relations via LDS partial sums, entities via L2 atomics).
+struct BwdArgs {
+  const int32_t* idx; int64_t N; int T, F, nT;
+  const float *Wt, *We, *Wr; int dt, de, dr; int Vt, Vr;
+  int L, layer;
+  const float* WiT;        // [64][256]  = W_i2g^T of this layer
+  const float* WoT;        // [64][256]
+  const float* save_frag;  // forward's fragment-order gates
+  const float* save_h;     // [T][L][N][64]
+  const float* dHhead;     // [N][64] (top layer) or null
+  float* DX;               // [T][N][64]: in = dx of the layer above (not top), out = dx of this layer (not bottom)
+  float* gWi; float* gbi; float* gWo;   // [256][64], [256], [256][64]
+  float* gWt; float* gWe; float* gWr;   // bottom layer only
+  int64_t n_tiles;
+};
+
+constexpr int LDD = 4 * DH + 4;  // dA tile row stride
+
+template <bool BOTTOM, bool TOP>
+__global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* in_t = lds;                     // [64][LDA]  x_t or h^{l-1}_t
+  float* hp_t = lds + MT * LDA;          // [64][LDA]  h^l_{t-1}
+  float* dhr = lds + 2 * MT * LDA;       // [64][LDA]  recurrent dh for the step being processed
+  float* dA_t = lds + 3 * MT * LDA;      // [64][LDD]
+  int32_t* idx_base = (int32_t*)(dA_t + MT * LDD);  // 2 x [64][4]: type(first), entity, relation (0-based), valid
+  float* small_g = (float*)(idx_base + 2 * MT * 4);  // [Vt*dt + Vr*dr] bottom layer partial sums (if they fit)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int arow = lane & 15, ag = lane >> 4;
+  const int T = a.T, L = a.L, ly = a.layer;
+  const int n_small = BOTTOM ? (a.Vt * a.dt + a.Vr * a.dr) : 0;
+  const bool small_in_lds = BOTTOM && n_small <= 4096;
+  if (small_in_lds) for (int i = tid; i < n_small; i += 256) small_g[i] = 0.f;
+
+  // launch-persistent accumulators: dW_i2g / dW_o2g rows (q*64 + 16j + 4ag + r), cols 16nt + arow
+  f32x4 dwi[4][4], dwo[4][4];
+  float dbias[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    dbias[q] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { dwi[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dwo[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+
+  const int64_t frag_mt_stride = (int64_t)T * L * 4 * 5 * 256;
+
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * MT;
+    float dc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dc[m][r] = 0.f;
+    __syncthreads();  // previous tile fully consumed before its LDS tiles are overwritten
+    // recurrent dh starts at 0 (or at the head gradient for the top layer)
+    for (int c = tid; c < MT * 16; c += 256) {
+      const int row = c >> 4, ch = c & 15;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (TOP && n0 + row < a.N) v = *(const f32x4*)(a.dHhead + (n0 + row) * DH + ch * 4);
+      *(f32x4*)(dhr + row * LDA + ch * 4) = v;
+    }
+
+    for (int t = T - 1; t >= 0; --t) {
+      // idx tile is double-buffered: step t's scatter (stage E) may still be running in a slow wave
+      // while a fast wave already stages step t-1
+      int32_t* idx_t = idx_base + (t & 1) * (MT * 4);
+      // ---- A. stage tiles ----------------------------------------------------------------
+      {
+        const int c_t = a.dt >> 2, c_e = (a.dt + a.de) >> 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = tid + k * 256;
+          const int row = c >> 4, ch = c & 15;
+          const int64_t n = n0 + row;
+          const bool valid = n < a.N;
+          f32x4 vin = f32x4{0.f, 0.f, 0.f, 0.f}, vhp = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (valid) {
+            if (BOTTOM) {
+              const int32_t* f = a.idx + (n * T + t) * a.F;
+              if (ch < c_t) {
+                vin = *(const f32x4*)(a.Wt + (int64_t)(f[a.F - a.nT - 2] - 1) * a.dt + ch * 4);
+                for (int q = 1; q < a.nT; ++q) vin += *(const f32x4*)(a.Wt + (int64_t)(f[a.F - a.nT - 2 + q] - 1) * a.dt + ch * 4);
+              } else if (ch < c_e) {
+                vin = *(const f32x4*)(a.We + (int64_t)(f[a.F - 2] - 1) * a.de + (ch - c_t) * 4);
+              } else {
+                vin = *(const f32x4*)(a.Wr + (int64_t)(f[a.F - 1] - 1) * a.dr + (ch - c_e) * 4);
+              }
+            } else {
+              vin = *(const f32x4*)(a.save_h + (((int64_t)t * L + (ly - 1)) * a.N + n) * DH + ch * 4);
+            }
+            if (t > 0) vhp = *(const f32x4*)(a.save_h + (((int64_t)(t - 1) * L + ly) * a.N + n) * DH + ch * 4);
+          }
+          *(f32x4*)(in_t + row * LDA + ch * 4) = vin;
+          *(f32x4*)(hp_t + row * LDA + ch * 4) = vhp;
+        }
+        if (BOTTOM && tid < MT) {
+          const int64_t n = n0 + tid;
+          const bool valid = n < a.N;
+          const int32_t* f = a.idx + ((valid ? n : 0) * T + t) * a.F;
+          idx_t[tid * 4 + 0] = f[a.F - a.nT - 2] - 1;
+          idx_t[tid * 4 + 1] = f[a.F - 2] - 1;
+          idx_t[tid * 4 + 2] = f[a.F - 1] - 1;
+          idx_t[tid * 4 + 3] = valid ? 1 : 0;
+        }
+      }
+      __syncthreads();
+
+      // ---- C. cell backward + dW, one m-tile at a time --------------------------------------
+      const float* fr_base = a.save_frag + (((tile * 4) * T + t) * L + ly) * (4 * 5 * 256) + (int64_t)j * (5 * 256) + lane * 4;
+      const float* frp_base = (t > 0) ? a.save_frag + (((tile * 4) * T + (t - 1)) * L + ly) * (4 * 5 * 256) + (int64_t)j * (5 * 256) + lane * 4 : nullptr;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const float* fb = fr_base + (int64_t)mt * frag_mt_stride;
+        const f32x4 vi = *(const f32x4*)(fb + 0 * 256);
+        const f32x4 vg = *(const f32x4*)(fb + 1 * 256);
+        const f32x4 vf = *(const f32x4*)(fb + 2 * 256);
+        const f32x4 vo = *(const f32x4*)(fb + 3 * 256);
+        const f32x4 vc = *(const f32x4*)(fb + 4 * 256);
+        f32x4 vcp = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t > 0) vcp = *(const f32x4*)(frp_base + (int64_t)mt * frag_mt_stride + 4 * 256);
+        f32x4 dA[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = mt * 16 + ag * 4 + r;
+          float dh = dhr[row * LDA + j * 16 + arow];
+          if (!TOP) { if (n0 + row < a.N) dh += a.DX[((int64_t)t * a.N + n0 + row) * DH + j * 16 + arow]; }
+          const float tc = fast_tanh(vc[r]);
+          const float dO = dh * tc;
+          const float dC = dc[mt][r] + dh * vo[r] * (1.f - tc * tc);
+          dA[0][r] = dC * vg[r] * vi[r] * (1.f - vi[r]);
+          dA[1][r] = dC * vi[r] * (1.f - vg[r] * vg[r]);
+          dA[2][r] = dC * vcp[r] * vf[r] * (1.f - vf[r]);
+          dA[3][r] = dO * vo[r] * (1.f - vo[r]);
+          dc[mt][r] = dC * vf[r];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dA_t[row * LDD + q * DH + j * 16 + arow] = dA[q][r];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dbias[q] += (dA[q][0] + dA[q][1]) + (dA[q][2] + dA[q][3]);
+        // dW += dA^T [in | h_prev]: MFMA #r uses k-slot ag <-> row mt*16 + 4ag + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = mt * 16 + ag * 4 + r;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float b = in_t[row * LDA + nt * 16 + arow];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dwi[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[q][r], b, dwi[q][nt], 0, 0, 0);
+          }
+          if (t > 0) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              const float b = hp_t[row * LDA + nt * 16 + arow];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) dwo[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[q][r], b, dwo[q][nt], 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+
+      // ---- E. [dx | dh_prev] = dA * [W_i2g | W_o2g]; this wave: columns 16j..16j+15 of each ----------
+      {
+        f32x4 ax[4], ah[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { ax[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; ah[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const float* wi_row = a.WiT + (int64_t)(j * 16 + arow) * (4 * DH) + ag * 4;
+        const float* wo_row = a.WoT + (int64_t)(j * 16 + arow) * (4 * DH) + ag * 4;
+#pragma unroll 4
+        for (int S = 0; S < 16; ++S) {
+          const f32x4 bi4 = *(const f32x4*)(wi_row + S * 16);
+          f32x4 bo4 = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (t > 0) bo4 = *(const f32x4*)(wo_row + S * 16);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 a4 = *(const f32x4*)(dA_t + (mt * 16 + arow) * LDD + S * 16 + ag * 4);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              ax[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], bi4[jj], ax[mt], 0, 0, 0);
+              if (t > 0) ah[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], bo4[jj], ah[mt], 0, 0, 0);
+            }
+          }
+        }
+        const int col = j * 16 + arow;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + ag * 4 + r;
+            dhr[row * LDA + col] = ah[mt][r];  // read by step t-1 after the next barrier (zero at t == 0, unused)
+            if (BOTTOM) {
+              // nn.LookupTable backward: scatter-add, duplicates accumulate (FeatureEmbedding.lua:29,41-49,86)
+              if (idx_t[row * 4 + 3]) {
+                const float v = ax[mt][r];
+                if (col < a.dt) {
+                  const int32_t* f = a.idx + ((n0 + row) * T + t) * a.F;
+                  for (int k = 0; k < a.nT; ++k) {
+                    const int rr = (k == 0) ? idx_t[row * 4 + 0] : f[a.F - a.nT - 2 + k] - 1;
+                    if (small_in_lds) atomicAdd(&small_g[rr * a.dt + col], v);
+                    else unsafeAtomicAdd(a.gWt + (int64_t)rr * a.dt + col, v);
+                  }
+                } else if (col < a.dt + a.de) {
+                  unsafeAtomicAdd(a.gWe + (int64_t)idx_t[row * 4 + 1] * a.de + (col - a.dt), v);
+                } else {
+                  const int rr = idx_t[row * 4 + 2];
+                  if (small_in_lds) atomicAdd(&small_g[a.Vt * a.dt + rr * a.dr + (col - a.dt - a.de)], v);
+                  else unsafeAtomicAdd(a.gWr + (int64_t)rr * a.dr + (col - a.dt - a.de), v);
+                }
+              }
+            } else {
+              if (n0 + row < a.N) a.DX[((int64_t)t * a.N + n0 + row) * DH + col] = ax[mt][r];
+            }
+          }
+        }
+      }
+      // the barrier at the top of the next step (after staging) orders dhr / dA_t / tile reuse:
+      // staging only writes in_t / hp_t / idx_t, which were last read before the barrier above.
+    }
+  }
+
+  // ---- flush the launch-persistent accumulators -----------------------------------------------
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t grow = (int64_t)q * DH + j * 16 + ag * 4 + r;
+        unsafeAtomicAdd(a.gWi + grow * DH + nt * 16 + arow, dwi[q][nt][r]);
+        unsafeAtomicAdd(a.gWo + grow * DH + nt * 16 + arow, dwo[q][nt][r]);
+      }
+    }
+    float v = dbias[q];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (ag == 0) unsafeAtomicAdd(a.gbi + q * DH + j * 16 + arow, v);
+  }
+  if (small_in_lds) {
+    __syncthreads();
+    const int nt_small = a.Vt * a.dt;
+    for (int i = tid; i < n_small; i += 256) {
+      const float v = small_g[i];
+      if (v != 0.f) { if (i < nt_small) unsafeAtomicAdd(a.gWt + i, v); else unsafeAtomicAdd(a.gWr + (i - nt_small), v); }
+    }
+  }
+}
+
+// WT[n][k] = W[k][n] for a [256][64] weight
+__global__ void k_transpose_256x64(const float* __restrict__ W, float* __restrict__ WT) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 64*256 outputs
+  if (i >= 64 * 256) return;
+  const int n = i >> 8, k = i & 255;
+  WT[i] = W[k * 64 + n];
+}
+
 // ---- host side ----------------------------------------------------------------------------
 struct State {
   float* save_frag = nullptr;
@@ -277,7 +555,11 @@ struct State {
   int64_t cap_N = 0;
   int cap_T = 0;
   int num_cu = 0;
-  bool attr_set = false;
+  float* WT = nullptr;      // [L][2][64][256]
+  bool wt_dirty = true;
+  float* dHhead = nullptr;  // [N][64]
+  float* DX = nullptr;      // [T][N][64]
+  int64_t cap_Nb = 0; int cap_Tb = 0;
 };
 
 static State* st(kprn_handle* h) {
@@ -296,7 +578,7 @@ bool fwd_supported(const kprn_handle* h, int T) {
   return (h->D == DH && c.H == DH && c.L >= 1 && c.L <= 2 && (c.dt % 4) == 0 && (c.de % 4) == 0 && (c.dr % 4) == 0 && T >= 1);
 }
 
-bool bwd_supported(const kprn_handle*, int) { return false; }
+bool bwd_supported(const kprn_handle* h, int T) { return fwd_supported(h, T); }
 
 template <int L, bool SAVE>
 static void launch_fwd(kprn_handle* h, const FwdArgs& a, int grid) {
@@ -340,20 +622,82 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
     }
     a.save_frag = s->save_frag; a.save_h = s->save_h;
   }
-  const int per_cu = 1;
-  const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)s->num_cu * per_cu);
+  const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)s->num_cu);
   ProfScope ps(h, "lstm_fused_fwd");
   if (c.L == 1) { if (save) launch_fwd<1, true>(h, a, grid); else launch_fwd<1, false>(h, a, grid); }
   else { if (save) launch_fwd<2, true>(h, a, grid); else launch_fwd<2, false>(h, a, grid); }
 }
 
-void backward(kprn_handle*, const kprn_batch*, int) { throw KprnError{KPRN_E_UNSUPPORTED, "fused backward not built"}; }
-void params_changed(kprn_handle*) {}
+template <bool BOTTOM, bool TOP>
+static void launch_bwd(kprn_handle* h, const BwdArgs& a, int grid) {
+  const int n_small = BOTTOM ? (a.Vt * a.dt + a.Vr * a.dr) : 0;
+  const size_t lds_bytes = (size_t)(3 * MT * LDA + MT * LDD) * sizeof(float) + 2 * MT * 4 * sizeof(int32_t) + (size_t)(n_small <= 4096 ? n_small : 0) * sizeof(float);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
+  HIP_TRY(hipGetLastError());
+}
+
+// needs: forward(save=true) of the same batch just ran; ws.dS holds d loss / d S[:, cid]
+void backward(kprn_handle* h, const kprn_batch* b, int cid) {
+  const kprn_config& c = h->cfg;
+  State* s = st(h);
+  const int64_t N = (int64_t)b->B * b->P;
+  const int T = b->T, L = c.L;
+  hipStream_t strm = h->stream;
+  if (N > s->cap_Nb || T > s->cap_Tb) {
+    HIP_TRY(hipStreamSynchronize(strm));
+    if (s->dHhead) hipFree(s->dHhead);
+    if (s->DX) hipFree(s->DX);
+    const int64_t cn = std::max<int64_t>(N, s->cap_Nb);
+    const int ct = std::max(T, s->cap_Tb);
+    HIP_TRY(hipMalloc((void**)&s->dHhead, (size_t)(cn + 64) * DH * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&s->DX, (size_t)ct * (cn + 64) * DH * sizeof(float)));
+    s->cap_Nb = cn; s->cap_Tb = ct;
+  }
+  if (!s->WT) HIP_TRY(hipMalloc((void**)&s->WT, (size_t)2 * 2 * 64 * 256 * sizeof(float)));
+  if (s->wt_dirty) {
+    ProfScope ps(h, "weight_transpose");
+    for (int l = 0; l < L; ++l) {
+      hipLaunchKernelGGL(k_transpose_256x64, dim3(64), dim3(256), 0, strm, h->dense + h->layer[l].Wi, s->WT + (size_t)(l * 2 + 0) * 64 * 256);
+      hipLaunchKernelGGL(k_transpose_256x64, dim3(64), dim3(256), 0, strm, h->dense + h->layer[l].Wo, s->WT + (size_t)(l * 2 + 1) * 64 * 256);
+    }
+    HIP_TRY(hipGetLastError());
+    s->wt_dirty = false;
+  }
+  float* gd = h->g_dense;
+  {
+    ProfScope ps(h, "head_bwd");
+    const float* hT = s->save_h + ((int64_t)(T - 1) * L + (L - 1)) * N * DH;
+    kk::head_bwd(strm, h->ws.dS, hT, h->dense + h->off_outW, N, DH, cid, s->dHhead, gd + h->off_outW, gd + h->off_outb);
+  }
+  const int64_t n_tiles = (N + MT - 1) / MT;
+  const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)s->num_cu);
+  for (int l = L - 1; l >= 0; --l) {
+    BwdArgs a;
+    a.idx = b->idx; a.N = N; a.T = T; a.F = b->F; a.nT = c.num_types;
+    a.Wt = h->dense + h->off_Wt; a.We = h->We; a.Wr = h->dense + h->off_Wr;
+    a.dt = c.dt; a.de = c.de; a.dr = c.dr; a.Vt = c.Vt; a.Vr = c.Vr;
+    a.L = L; a.layer = l;
+    a.WiT = s->WT + (size_t)(l * 2 + 0) * 64 * 256; a.WoT = s->WT + (size_t)(l * 2 + 1) * 64 * 256;
+    a.save_frag = s->save_frag; a.save_h = s->save_h; a.dHhead = s->dHhead; a.DX = s->DX;
+    a.gWi = gd + h->layer[l].Wi; a.gbi = gd + h->layer[l].bi; a.gWo = gd + h->layer[l].Wo;
+    a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
+    a.n_tiles = n_tiles;
+    const bool bottom = (l == 0), top = (l == L - 1);
+    ProfScope ps(h, "lstm_fused_bwd");
+    if (bottom && top) launch_bwd<true, true>(h, a, grid);
+    else if (bottom) launch_bwd<true, false>(h, a, grid);
+    else if (top) launch_bwd<false, true>(h, a, grid);
+    else launch_bwd<false, false>(h, a, grid);
+  }
+}
+
+void params_changed(kprn_handle* h) { if (h->fused_state) ((State*)h->fused_state)->wt_dirty = true; }
+
 void release(kprn_handle* h) {
   State* s = (State*)h->fused_state;
   if (!s) return;
-  if (s->save_frag) hipFree(s->save_frag);
-  if (s->save_h) hipFree(s->save_h);
+  for (float* p : {s->save_frag, s->save_h, s->WT, s->dHhead, s->DX}) if (p) hipFree(p);
   delete s;
   h->fused_state = nullptr;
 }
