@@ -78,7 +78,7 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr):
         for l in range(L):
             din = D if l == 0 else H
             fl += T * 2 * g * (din + H)
-        return "mfma", 2 * N * fl
+        return "mfma", 2 * N * fl / L   # one launch per layer
     tbl = {
         "gemm_i2g_fwd": 2 * T * N * g * D, "gemm_o2g_fwd": 2 * N * g * H, "gemm_head_fwd": 2 * N * C * H,
         "gemm_o2g_bwd_dh": 2 * N * g * H, "gemm_o2g_bwd_dw": 2 * (T - 1) * N * g * H,

@@ -10,6 +10,11 @@ inline unsigned nblocks(int64_t n, int per = TPB) { return (unsigned)((n + per -
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+__device__ __forceinline__ void lds_atomic_add(float* p, float v) {  // ds_add_f32 (not the flat aperture path)
+  typedef __attribute__((address_space(3))) float lds_float;
+  __hip_atomic_fetch_add((lds_float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -307,14 +312,14 @@ __global__ void k_embed_scatter(const int32_t* __restrict__ idx, int64_t N, int 
     if (j < dt) {
       for (int k = 0; k < nT; ++k) {
         int row = f[F - nT - 2 + k] - 1;
-        if (use_lds) atomicAdd(&lds[row * dt + j], v);
+        if (use_lds) lds_atomic_add(&lds[row * dt + j], v);
         else unsafeAtomicAdd(gWt + (int64_t)row * dt + j, v);
       }
     } else if (j < dt + de) {
       unsafeAtomicAdd(gWe + (int64_t)(f[F - 2] - 1) * de + (j - dt), v);
     } else {
       int row = f[F - 1] - 1;
-      if (use_lds) atomicAdd(&lds[nt_small + row * dr + (j - dt - de)], v);
+      if (use_lds) lds_atomic_add(&lds[nt_small + row * dr + (j - dt - de)], v);
       else unsafeAtomicAdd(gWr + (int64_t)row * dr + (j - dt - de), v);
     }
   }

@@ -23,6 +23,12 @@
 //  * k-order trick: one ds_read_b128 of A[row][16S+4g..+3] feeds 4 consecutive MFMAs (slot g of
 //    MFMA jj <-> k = 16S+4g+jj); the matching B fragment is one 16-byte load of the ROW-MAJOR
 //    weight row, so no packed weight copy is needed.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
 #include "kprn_internal.h"
 
 namespace fused {
@@ -52,29 +58,64 @@ struct FwdArgs {
 };
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): ~1e-7 absolute error on the gate values, far inside the 1e-4 score bar
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for
+// every global store / atomic / prefetch load in flight (the activation saves of the training forward,
+// the embedding-gradient atomics, the next step's gather) -- none of which the other waves depend on.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// float add on an LDS address as ds_add_f32.  (atomicAdd() through a generic pointer was emitted as
+// flat_atomic_add_f32, the slow aperture path.)
+__device__ __forceinline__ void lds_atomic_add(float* p, float v) {
+  typedef __attribute__((address_space(3))) float lds_float;
+  __hip_atomic_fetch_add((lds_float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
-// gather this thread's share of one step's x rows for `tile` into registers
+constexpr int MAXT_LDS = 16;  // steps whose ids are staged in LDS per tile
+
+// all the tile's ids -> LDS: ids[(row*T + t)*4 + {0: first type, 1: entity, 2: relation}] (0-based).
+// Rows past N repeat row N-1 (their results are never stored).  Removes the dependent id -> row load
+// chain from every step's gather.
 template <int NTHREADS>
-__device__ __forceinline__ void gather_load(const FwdArgs& a, int64_t tile, int t, f32x4 (&v)[1024 / NTHREADS]) {
+__device__ __forceinline__ void ids_stage(const int32_t* idx, int64_t N, int T, int F, int nT, int64_t tile, int32_t* ids) {
+  for (int c = threadIdx.x; c < MT * T; c += NTHREADS) {
+    const int row = c / T, t = c - row * T;
+    int64_t n = tile * MT + row;
+    if (n >= N) n = N - 1;
+    const int32_t* f = idx + (n * T + t) * F;
+    ids[c * 4 + 0] = f[F - nT - 2] - 1;
+    ids[c * 4 + 1] = f[F - 2] - 1;
+    ids[c * 4 + 2] = f[F - 1] - 1;
+  }
+}
+
+// gather this thread's share of one step's x rows for `tile` into registers (ids from the LDS id tile)
+template <int NTHREADS>
+__device__ __forceinline__ void gather_load(const FwdArgs& a, int64_t tile, int t, const int32_t* ids, f32x4 (&v)[1024 / NTHREADS]) {
   constexpr int PER = 1024 / NTHREADS;  // 64 rows x 16 float4 chunks
   const int c_t = a.dt >> 2, c_e = (a.dt + a.de) >> 2;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int c = threadIdx.x + k * NTHREADS;
     const int row = c >> 4, ch = c & 15;
-    int64_t n = tile * MT + row;
-    if (n >= a.N) n = a.N - 1;
-    const int32_t* f = a.idx + (n * a.T + t) * a.F;
+    const int32_t* id = ids + (row * a.T + t) * 4;
     f32x4 out;
     if (ch < c_t) {
-      out = *(const f32x4*)(a.Wt + (int64_t)(f[a.F - a.nT - 2] - 1) * a.dt + ch * 4);
-      for (int q = 1; q < a.nT; ++q) out += *(const f32x4*)(a.Wt + (int64_t)(f[a.F - a.nT - 2 + q] - 1) * a.dt + ch * 4);
+      out = *(const f32x4*)(a.Wt + (int64_t)id[0] * a.dt + ch * 4);
+      if (a.nT > 1) {
+        int64_t n = tile * MT + row;
+        if (n >= a.N) n = a.N - 1;
+        const int32_t* f = a.idx + (n * a.T + t) * a.F;
+        for (int q = 1; q < a.nT; ++q) out += *(const f32x4*)(a.Wt + (int64_t)(f[a.F - a.nT - 2 + q] - 1) * a.dt + ch * 4);
+      }
     } else if (ch < c_e) {
-      out = *(const f32x4*)(a.We + (int64_t)(f[a.F - 2] - 1) * a.de + (ch - c_t) * 4);
+      out = *(const f32x4*)(a.We + (int64_t)id[1] * a.de + (ch - c_t) * 4);
     } else {
-      out = *(const f32x4*)(a.Wr + (int64_t)(f[a.F - 1] - 1) * a.dr + (ch - c_e) * 4);
+      out = *(const f32x4*)(a.Wr + (int64_t)id[2] * a.dr + (ch - c_e) * 4);
     }
     v[k] = out;
   }
@@ -195,6 +236,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   // LDS carve (floats): x double buffer | h(layer l) double buffer, l = 0..L-1
   auto xbuf = [&](int i) -> float* { return lds + i * (MT * LDA); };
   auto hbuf = [&](int g, int i) -> float* { return lds + (2 + 2 * g + i) * (MT * LDA); };
+  // id tiles (double-buffered by tile parity): [64][T][4] ints each
+  auto idbuf = [&](int i) -> int32_t* { return (int32_t*)(lds + (2 + 2 * L) * (MT * LDA)) + i * (MT * MAXT_LDS * 4); };
 
   const int lane = threadIdx.x & 63;
   const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // hidden tile owned by this wave
@@ -230,20 +273,26 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   if (my_tiles == 0) return;
 
   f32x4 gv[1024 / NT];
-  gather_load<NT>(a, blockIdx.x, 0, gv);
+  ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, blockIdx.x, idbuf(0));
+  lds_barrier();
+  gather_load<NT>(a, blockIdx.x, 0, idbuf(0), gv);
   gather_store<NT>(xbuf(0), gv);
-  __syncthreads();
+  lds_barrier();
 
   int64_t tile = blockIdx.x;
   int t = 0;
+  int tpar = 0;  // parity of the tile's id buffer
   for (int64_t s = 0; s < total_slots; ++s) {
     const int par = (int)(s & 1);
     // (1) issue the gather for the NEXT slot (latency hidden under this slot's MFMAs)
     int tn = t + 1;
     int64_t tile_n = tile;
-    if (tn == T) { tn = 0; tile_n += gridDim.x; }
+    int tpar_n = tpar;
+    if (tn == T) { tn = 0; tile_n += gridDim.x; tpar_n ^= 1; }
     const bool have_next = (s + 1) < total_slots;
-    if (have_next) gather_load<NT>(a, tile_n, tn, gv);
+    // the next tile's ids are staged while this tile's first step computes (visible after >= 1 barrier)
+    if (t == 0 && tile + gridDim.x < a.n_tiles) ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
+    if (have_next) gather_load<NT>(a, tile_n, tn, idbuf(tpar_n), gv);
 
     // (2) the layers of this step, bottom-up; h tiles hand over through LDS
     const int64_t rows_valid = a.N - tile * MT;
@@ -259,14 +308,14 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
         sh = a.save_h + (((int64_t)t * L + l) * a.N + tile * MT) * DH;
       }
       lstm_step<SAVE>(in_buf, hp_buf, out_buf, wi[l], wo[l], bias[l], c[l], t == 0, j, lane, sf, stride_mt, sh, rows_valid);
-      if (l + 1 < L) __syncthreads();  // h_l tile complete before layer l+1 reads it
+      if (l + 1 < L) lds_barrier();  // h_l tile complete before layer l+1 reads it
     }
     // (3) land the gathered rows of the next slot (xbuf[par^1] was last read one slot ago)
     if (have_next) gather_store<NT>(xbuf(par ^ 1), gv);
-    __syncthreads();
+    lds_barrier();
     // (4) nn.Linear head on the finished tile: reads hbuf(L-1, par); the next slot writes par^1
     if (t == T - 1) head_tile(a, hbuf(L - 1, par), tile, j, lane);
-    t = tn; tile = tile_n;
+    t = tn; tile = tile_n; tpar = tpar_n;
   }
 }
 
@@ -302,20 +351,90 @@ struct BwdArgs {
   float* DX;               // [T][N][64]: in = dx of the layer above (not top), out = dx of this layer (not bottom)
   float* gWi; float* gbi; float* gWo;   // [256][64], [256], [256][64]
   float* gWt; float* gWe; float* gWr;   // bottom layer only
+  float* part;             // [grid][2*256*64 + 256] per-workgroup partial dW_i2g | dW_o2g | db
+  unsigned long long* timing;  // optional [grid][8] cycle counters (KPRN_TIMING=1)
   int64_t n_tiles;
 };
 
+constexpr int PART = 2 * 256 * 64 + 256;  // floats per workgroup partial slab
 constexpr int LDD = 4 * DH + 4;  // dA tile row stride
+
+// stage-A helper: this thread's 4 float4 chunks of the step's input tile and h_{t-1} tile
+template <bool BOTTOM>
+__device__ __forceinline__ void bwd_tile_load(const BwdArgs& a, int64_t n0, int t, int tid, const int32_t* ids, f32x4 (&vin)[4], f32x4 (&vhp)[4]) {
+  const int c_t = a.dt >> 2, c_e = (a.dt + a.de) >> 2;
+  const int T = a.T, L = a.L, ly = a.layer;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = tid + k * 256;
+    const int row = c >> 4, ch = c & 15;
+    const int64_t n = n0 + row;
+    vin[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    vhp[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n < a.N) {
+      if (BOTTOM) {
+        const int32_t* id = ids + (row * T + t) * 4;
+        if (ch < c_t) {
+          vin[k] = *(const f32x4*)(a.Wt + (int64_t)id[0] * a.dt + ch * 4);
+          if (a.nT > 1) {
+            const int32_t* f = a.idx + (n * T + t) * a.F;
+            for (int q = 1; q < a.nT; ++q) vin[k] += *(const f32x4*)(a.Wt + (int64_t)(f[a.F - a.nT - 2 + q] - 1) * a.dt + ch * 4);
+          }
+        } else if (ch < c_e) {
+          vin[k] = *(const f32x4*)(a.We + (int64_t)id[1] * a.de + (ch - c_t) * 4);
+        } else {
+          vin[k] = *(const f32x4*)(a.Wr + (int64_t)id[2] * a.dr + (ch - c_e) * 4);
+        }
+      } else {
+        vin[k] = *(const f32x4*)(a.save_h + (((int64_t)t * L + (ly - 1)) * a.N + n) * DH + ch * 4);
+      }
+      if (t > 0) vhp[k] = *(const f32x4*)(a.save_h + (((int64_t)(t - 1) * L + ly) * a.N + n) * DH + ch * 4);
+    }
+  }
+}
+
+__device__ __forceinline__ void bwd_tile_store(float* in_t, float* hp_t, int tid, const f32x4 (&vin)[4], const f32x4 (&vhp)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = tid + k * 256;
+    const int row = c >> 4, ch = c & 15;
+    *(f32x4*)(in_t + row * LDA + ch * 4) = vin[k];
+    *(f32x4*)(hp_t + row * LDA + ch * 4) = vhp[k];
+  }
+}
+
+struct Frag6 { f32x4 i, g, f, o, c, cp, up; };
+template <bool REC>
+__device__ __forceinline__ void frag_load(Frag6& fr, const float* fb, const float* fbp) {
+  fr.i = *(const f32x4*)(fb + 0 * 256);
+  fr.g = *(const f32x4*)(fb + 1 * 256);
+  fr.f = *(const f32x4*)(fb + 2 * 256);
+  fr.o = *(const f32x4*)(fb + 3 * 256);
+  fr.c = *(const f32x4*)(fb + 4 * 256);
+  if (REC) fr.cp = *(const f32x4*)(fbp + 4 * 256);
+  else fr.cp = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+#define TPROBE(slot)                                                                 \
+  if (a.timing) {                                                                     \
+    const unsigned long long now__ = __builtin_amdgcn_s_memtime();                    \
+    tacc[slot] += now__ - tlast;                                                      \
+    tlast = now__;                                                                    \
+  }
 
 template <bool BOTTOM, bool TOP>
 __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = a.timing ? __builtin_amdgcn_s_memtime() : 0ull;
   float* in_t = lds;                     // [64][LDA]  x_t or h^{l-1}_t
   float* hp_t = lds + MT * LDA;          // [64][LDA]  h^l_{t-1}
   float* dhr = lds + 2 * MT * LDA;       // [64][LDA]  recurrent dh for the step being processed
   float* dA_t = lds + 3 * MT * LDA;      // [64][LDD]
-  int32_t* idx_base = (int32_t*)(dA_t + MT * LDD);  // 2 x [64][4]: type(first), entity, relation (0-based), valid
-  float* small_g = (float*)(idx_base + 2 * MT * 4);  // [Vt*dt + Vr*dr] bottom layer partial sums (if they fit)
+  int32_t* ids = (int32_t*)(dA_t + MT * LDD);        // [64][T][4] the tile's ids (bottom layer), 0-based
+  int32_t* lead = ids + MT * MAXT_LDS * 4;           // [64] leader row of each row's entity id inside the tile
+  float* dxt = (float*)(lead + MT);                  // [64][LDA] bottom layer: dx tile staged for the combine + scatter
+  float* small_g = dxt + (BOTTOM ? MT * LDA : 0);    // [Vt*dt + Vr*dr] bottom layer partial sums (if they fit)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -345,7 +464,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dc[m][r] = 0.f;
-    __syncthreads();  // previous tile fully consumed before its LDS tiles are overwritten
+    lds_barrier();  // previous tile fully consumed before its LDS tiles are overwritten
+    if (BOTTOM) { ids_stage<256>(a.idx, a.N, T, a.F, a.nT, tile, ids); lds_barrier(); }
     // recurrent dh starts at 0 (or at the head gradient for the top layer)
     for (int c = tid; c < MT * 16; c += 256) {
       const int row = c >> 4, ch = c & 15;
@@ -353,79 +473,62 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       if (TOP && n0 + row < a.N) v = *(const f32x4*)(a.dHhead + (n0 + row) * DH + ch * 4);
       *(f32x4*)(dhr + row * LDA + ch * 4) = v;
     }
+    {
+      f32x4 vin[4], vhp[4];
+      bwd_tile_load<BOTTOM>(a, n0, T - 1, tid, ids, vin, vhp);
+      bwd_tile_store(in_t, hp_t, tid, vin, vhp);
+    }
+    lds_barrier();
+    TPROBE(0)  // tile prologue
 
-    for (int t = T - 1; t >= 0; --t) {
-      // idx tile is double-buffered: step t's scatter (stage E) may still be running in a slow wave
-      // while a fast wave already stages step t-1
-      int32_t* idx_t = idx_base + (t & 1) * (MT * 4);
-      // ---- A. stage tiles ----------------------------------------------------------------
-      {
-        const int c_t = a.dt >> 2, c_e = (a.dt + a.de) >> 2;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = tid + k * 256;
-          const int row = c >> 4, ch = c & 15;
-          const int64_t n = n0 + row;
-          const bool valid = n < a.N;
-          f32x4 vin = f32x4{0.f, 0.f, 0.f, 0.f}, vhp = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (valid) {
-            if (BOTTOM) {
-              const int32_t* f = a.idx + (n * T + t) * a.F;
-              if (ch < c_t) {
-                vin = *(const f32x4*)(a.Wt + (int64_t)(f[a.F - a.nT - 2] - 1) * a.dt + ch * 4);
-                for (int q = 1; q < a.nT; ++q) vin += *(const f32x4*)(a.Wt + (int64_t)(f[a.F - a.nT - 2 + q] - 1) * a.dt + ch * 4);
-              } else if (ch < c_e) {
-                vin = *(const f32x4*)(a.We + (int64_t)(f[a.F - 2] - 1) * a.de + (ch - c_t) * 4);
-              } else {
-                vin = *(const f32x4*)(a.Wr + (int64_t)(f[a.F - 1] - 1) * a.dr + (ch - c_e) * 4);
-              }
-            } else {
-              vin = *(const f32x4*)(a.save_h + (((int64_t)t * L + (ly - 1)) * a.N + n) * DH + ch * 4);
-            }
-            if (t > 0) vhp = *(const f32x4*)(a.save_h + (((int64_t)(t - 1) * L + ly) * a.N + n) * DH + ch * 4);
-          }
-          *(f32x4*)(in_t + row * LDA + ch * 4) = vin;
-          *(f32x4*)(hp_t + row * LDA + ch * 4) = vhp;
-        }
-        if (BOTTOM && tid < MT) {
-          const int64_t n = n0 + tid;
-          const bool valid = n < a.N;
-          const int32_t* f = a.idx + ((valid ? n : 0) * T + t) * a.F;
-          idx_t[tid * 4 + 0] = f[a.F - a.nT - 2] - 1;
-          idx_t[tid * 4 + 1] = f[a.F - 2] - 1;
-          idx_t[tid * 4 + 2] = f[a.F - 1] - 1;
-          idx_t[tid * 4 + 3] = valid ? 1 : 0;
-        }
-      }
-      __syncthreads();
+    // the step body is compiled twice (REC: t > 0, there is an h_{t-1} / c_{t-1}) so that no MFMA sits
+    // under a run-time condition: a branch inside the MFMA loops made hipcc emit a jump plus dozens of
+    // accumulator copies around every MFMA (stage E measured 4x over its MFMA time)
+    auto step = [&](auto rec_tag, const int t) {
+      constexpr bool REC = decltype(rec_tag)::value;
+      // ---- prefetch: the NEXT step's tiles go to registers now and to LDS after the mid barrier ----
+      f32x4 nin[4], nhp[4];
+      if (REC) bwd_tile_load<BOTTOM>(a, n0, t - 1, tid, ids, nin, nhp);
+      TPROBE(1)  // prefetch issue
 
-      // ---- C. cell backward + dW, one m-tile at a time --------------------------------------
+      // ---- C. cell backward + dW, one m-tile at a time; saved gate fragments one m-tile ahead --------
       const float* fr_base = a.save_frag + (((tile * 4) * T + t) * L + ly) * (4 * 5 * 256) + (int64_t)j * (5 * 256) + lane * 4;
-      const float* frp_base = (t > 0) ? a.save_frag + (((tile * 4) * T + (t - 1)) * L + ly) * (4 * 5 * 256) + (int64_t)j * (5 * 256) + lane * 4 : nullptr;
+      const float* frp_base = REC ? a.save_frag + (((tile * 4) * T + (t - 1)) * L + ly) * (4 * 5 * 256) + (int64_t)j * (5 * 256) + lane * 4 : nullptr;
+      // dx of the layer above for this wave's rows / columns (C layout) rides along with the fragments
+      auto up_load = [&](Frag6& f6, int mt) {
+        if (TOP) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int64_t n = n0 + mt * 16 + ag * 4 + r;
+          const float m = (n < a.N) ? 1.f : 0.f;
+          if (n >= a.N) n = a.N - 1;
+          f6.up[r] = m * a.DX[((int64_t)t * a.N + n) * DH + j * 16 + arow];
+        }
+      };
+      Frag6 fr[2];
+      frag_load<REC>(fr[0], fr_base, frp_base);
+      up_load(fr[0], 0);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const float* fb = fr_base + (int64_t)mt * frag_mt_stride;
-        const f32x4 vi = *(const f32x4*)(fb + 0 * 256);
-        const f32x4 vg = *(const f32x4*)(fb + 1 * 256);
-        const f32x4 vf = *(const f32x4*)(fb + 2 * 256);
-        const f32x4 vo = *(const f32x4*)(fb + 3 * 256);
-        const f32x4 vc = *(const f32x4*)(fb + 4 * 256);
-        f32x4 vcp = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t > 0) vcp = *(const f32x4*)(frp_base + (int64_t)mt * frag_mt_stride + 4 * 256);
+        if (mt < 3) {
+          frag_load<REC>(fr[(mt + 1) & 1], fr_base + (int64_t)(mt + 1) * frag_mt_stride, frp_base + (int64_t)(mt + 1) * frag_mt_stride);
+          up_load(fr[(mt + 1) & 1], mt + 1);
+        }
+        const Frag6& F = fr[mt & 1];
         f32x4 dA[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = mt * 16 + ag * 4 + r;
           float dh = dhr[row * LDA + j * 16 + arow];
-          if (!TOP) { if (n0 + row < a.N) dh += a.DX[((int64_t)t * a.N + n0 + row) * DH + j * 16 + arow]; }
-          const float tc = fast_tanh(vc[r]);
+          if (!TOP) dh += F.up[r];
+          const float tc = fast_tanh(F.c[r]);
           const float dO = dh * tc;
-          const float dC = dc[mt][r] + dh * vo[r] * (1.f - tc * tc);
-          dA[0][r] = dC * vg[r] * vi[r] * (1.f - vi[r]);
-          dA[1][r] = dC * vi[r] * (1.f - vg[r] * vg[r]);
-          dA[2][r] = dC * vcp[r] * vf[r] * (1.f - vf[r]);
-          dA[3][r] = dO * vo[r] * (1.f - vo[r]);
-          dc[mt][r] = dC * vf[r];
+          const float dC = dc[mt][r] + dh * F.o[r] * (1.f - tc * tc);
+          dA[0][r] = dC * F.g[r] * F.i[r] * (1.f - F.i[r]);
+          dA[1][r] = dC * F.i[r] * (1.f - F.g[r] * F.g[r]);
+          dA[2][r] = dC * F.cp[r] * F.f[r] * (1.f - F.f[r]);
+          dA[3][r] = dO * F.o[r] * (1.f - F.o[r]);
+          dc[mt][r] = dC * F.f[r];
 #pragma unroll
           for (int q = 0; q < 4; ++q) dA_t[row * LDD + q * DH + j * 16 + arow] = dA[q][r];
         }
@@ -441,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) dwi[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[q][r], b, dwi[q][nt], 0, 0, 0);
           }
-          if (t > 0) {
+          if constexpr (REC) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
               const float b = hp_t[row * LDA + nt * 16 + arow];
@@ -450,9 +553,12 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
             }
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();
+      TPROBE(2)  // stage C (cell backward + dW MFMAs)
+      lds_barrier();
+      TPROBE(3)  // mid barrier wait
+      // tiles of step t are dead now (stage C is the only reader): land the prefetched ones
+      if (REC) bwd_tile_store(in_t, hp_t, tid, nin, nhp);
 
       // ---- E. [dx | dh_prev] = dA * [W_i2g | W_o2g]; this wave: columns 16j..16j+15 of each ----------
       {
@@ -465,14 +571,14 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         for (int S = 0; S < 16; ++S) {
           const f32x4 bi4 = *(const f32x4*)(wi_row + S * 16);
           f32x4 bo4 = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (t > 0) bo4 = *(const f32x4*)(wo_row + S * 16);
+          if constexpr (REC) bo4 = *(const f32x4*)(wo_row + S * 16);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
             const f32x4 a4 = *(const f32x4*)(dA_t + (mt * 16 + arow) * LDD + S * 16 + ag * 4);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
               ax[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], bi4[jj], ax[mt], 0, 0, 0);
-              if (t > 0) ah[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], bo4[jj], ah[mt], 0, 0, 0);
+              if constexpr (REC) ah[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], bo4[jj], ah[mt], 0, 0, 0);
             }
           }
         }
@@ -482,62 +588,123 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = mt * 16 + ag * 4 + r;
-            dhr[row * LDA + col] = ah[mt][r];  // read by step t-1 after the next barrier (zero at t == 0, unused)
-            if (BOTTOM) {
-              // nn.LookupTable backward: scatter-add, duplicates accumulate (FeatureEmbedding.lua:29,41-49,86)
-              if (idx_t[row * 4 + 3]) {
-                const float v = ax[mt][r];
-                if (col < a.dt) {
-                  const int32_t* f = a.idx + ((n0 + row) * T + t) * a.F;
-                  for (int k = 0; k < a.nT; ++k) {
-                    const int rr = (k == 0) ? idx_t[row * 4 + 0] : f[a.F - a.nT - 2 + k] - 1;
-                    if (small_in_lds) atomicAdd(&small_g[rr * a.dt + col], v);
-                    else unsafeAtomicAdd(a.gWt + (int64_t)rr * a.dt + col, v);
-                  }
-                } else if (col < a.dt + a.de) {
-                  unsafeAtomicAdd(a.gWe + (int64_t)idx_t[row * 4 + 1] * a.de + (col - a.dt), v);
-                } else {
-                  const int rr = idx_t[row * 4 + 2];
-                  if (small_in_lds) atomicAdd(&small_g[a.Vt * a.dt + rr * a.dr + (col - a.dt - a.de)], v);
-                  else unsafeAtomicAdd(a.gWr + (int64_t)rr * a.dr + (col - a.dt - a.de), v);
-                }
-              }
-            } else {
-              if (n0 + row < a.N) a.DX[((int64_t)t * a.N + n0 + row) * DH + col] = ax[mt][r];
-            }
+            dhr[row * LDA + col] = ah[mt][r];  // read by step t-1 after the end-of-step barrier
+            if (BOTTOM) dxt[row * LDA + col] = ax[mt][r];
+            else if (n0 + row < a.N) a.DX[((int64_t)t * a.N + n0 + row) * DH + col] = ax[mt][r];
           }
         }
       }
-      // the barrier at the top of the next step (after staging) orders dhr / dA_t / tile reuse:
-      // staging only writes in_t / hp_t / idx_t, which were last read before the barrier above.
-    }
+      TPROBE(4)  // landing + stage E (dX MFMAs)
+      if (BOTTOM) {
+        // nn.LookupTable backward = scatter-add with duplicates accumulating (FeatureEmbedding.lua:29,41-49,86).
+        // Pad steps all hit ONE entity row and a pair's user / item repeat across its paths, so rows
+        // with the same entity id are first summed inside the tile (LDS); one L2 atomic row per distinct id.
+        {
+          // leader = first row of the tile with the same entity id; 4 threads per row scan 16 candidates each
+          const int row = tid >> 2, part = tid & 3;
+          const bool valid = n0 + row < a.N;
+          const int e = ids[(row * T + t) * 4 + 1];
+          int ld = row;
+          const int lo = part * 16, hi = (lo + 16 < row) ? lo + 16 : row;
+          for (int r2 = lo; r2 < hi; ++r2)
+            if (ids[(r2 * T + t) * 4 + 1] == e) { ld = r2; break; }
+          ld = min(ld, __shfl_xor(ld, 1, 64));
+          ld = min(ld, __shfl_xor(ld, 2, 64));
+          if (part == 0) lead[row] = valid ? ld : -1;
+        }
+        lds_barrier();
+        const int e0 = a.dt, e1 = a.dt + a.de;
+        // (1) fold follower rows into their leader (entity slice), types / relations into the small tables
+#pragma unroll 4
+        for (int c = tid; c < MT * DH; c += 256) {
+          const int row = c >> 6, col = c & 63;
+          const int ld = lead[row];
+          if (ld < 0) continue;
+          const float v = dxt[row * LDA + col];
+          const int32_t* id = ids + (row * T + t) * 4;
+          if (col < e0) {
+            if (small_in_lds) lds_atomic_add(&small_g[id[0] * a.dt + col], v);
+            else unsafeAtomicAdd(a.gWt + (int64_t)id[0] * a.dt + col, v);
+            if (a.nT > 1) {
+              const int32_t* f = a.idx + ((n0 + row) * T + t) * a.F;
+              for (int k = 1; k < a.nT; ++k) {
+                const int rr = f[a.F - a.nT - 2 + k] - 1;
+                if (small_in_lds) lds_atomic_add(&small_g[rr * a.dt + col], v);
+                else unsafeAtomicAdd(a.gWt + (int64_t)rr * a.dt + col, v);
+              }
+            }
+          } else if (col < e1) {
+            if (ld != row) lds_atomic_add(&dxt[ld * LDA + col], v);
+          } else {
+            if (small_in_lds) lds_atomic_add(&small_g[a.Vt * a.dt + id[2] * a.dr + (col - e1)], v);
+            else unsafeAtomicAdd(a.gWr + (int64_t)id[2] * a.dr + (col - e1), v);
+          }
+        }
+        lds_barrier();
+        // (2) leaders add their (combined) entity slice to the gradient table (fire-and-forget atomics:
+        //     the LDS-only barriers do not wait for them)
+        for (int c = tid; c < MT * DH; c += 256) {
+          const int row = c >> 6, col = c & 63;
+          if (col >= e0 && col < e1 && lead[row] == row)
+            unsafeAtomicAdd(a.gWe + (int64_t)ids[(row * T + t) * 4 + 1] * a.de + (col - e0), dxt[row * LDA + col]);
+        }
+      }
+      lds_barrier();  // dhr / staged tiles visible to step t-1; dA_t, dxt, lead free for reuse
+      TPROBE(5)  // scatter + end barrier
+    };
+    for (int t = T - 1; t > 0; --t) step(std::true_type{}, t);
+    step(std::false_type{}, 0);
   }
 
-  // ---- flush the launch-persistent accumulators -----------------------------------------------
+  // ---- flush the launch-persistent accumulators: plain coalesced stores into this workgroup's slab;
+  // k_reduce_partials sums the slabs (device-scope atomics from 256 workgroups onto the same 128 KB
+  // were measured slower: they execute at the memory side, the per-XCD L2s are not coherent)
+  {
+    float* pw = a.part + (int64_t)blockIdx.x * PART;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t grow = (int64_t)q * DH + j * 16 + ag * 4 + r;
-        unsafeAtomicAdd(a.gWi + grow * DH + nt * 16 + arow, dwi[q][nt][r]);
-        unsafeAtomicAdd(a.gWo + grow * DH + nt * 16 + arow, dwo[q][nt][r]);
+        for (int r = 0; r < 4; ++r) {
+          const int64_t grow = (int64_t)q * DH + j * 16 + ag * 4 + r;
+          pw[grow * DH + nt * 16 + arow] = dwi[q][nt][r];
+          pw[256 * 64 + grow * DH + nt * 16 + arow] = dwo[q][nt][r];
+        }
       }
+      float v = dbias[q];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (ag == 0) pw[2 * 256 * 64 + q * DH + j * 16 + arow] = v;
     }
-    float v = dbias[q];
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (ag == 0) unsafeAtomicAdd(a.gbi + q * DH + j * 16 + arow, v);
   }
   if (small_in_lds) {
-    __syncthreads();
+    lds_barrier();
     const int nt_small = a.Vt * a.dt;
     for (int i = tid; i < n_small; i += 256) {
       const float v = small_g[i];
       if (v != 0.f) { if (i < nt_small) unsafeAtomicAdd(a.gWt + i, v); else unsafeAtomicAdd(a.gWr + (i - nt_small), v); }
     }
   }
+  TPROBE(6)  // flush
+  if (a.timing && tid == 0) {
+    for (int k = 0; k < 8; ++k) a.timing[(int64_t)blockIdx.x * 8 + k] = tacc[k];
+  }
+}
+
+// gW_i2g / gW_o2g / gb += sum over workgroup slabs
+__global__ void k_reduce_partials(const float* __restrict__ part, int nslab, float* __restrict__ gWi, float* __restrict__ gWo, float* __restrict__ gbi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PART) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = blockIdx.y * 4; s < nslab; s += gridDim.y * 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (s + u < nslab) acc[u] += part[(int64_t)(s + u) * PART + i];
+  }
+  const float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  if (i < 256 * 64) unsafeAtomicAdd(gWi + i, v);
+  else if (i < 2 * 256 * 64) unsafeAtomicAdd(gWo + (i - 256 * 64), v);
+  else unsafeAtomicAdd(gbi + (i - 2 * 256 * 64), v);
 }
 
 // WT[n][k] = W[k][n] for a [256][64] weight
@@ -559,6 +726,8 @@ struct State {
   bool wt_dirty = true;
   float* dHhead = nullptr;  // [N][64]
   float* DX = nullptr;      // [T][N][64]
+  float* part = nullptr;    // [num_cu][PART]
+  unsigned long long* timing = nullptr;  // [num_cu][8] when KPRN_TIMING=1
   int64_t cap_Nb = 0; int cap_Tb = 0;
 };
 
@@ -575,14 +744,14 @@ static State* st(kprn_handle* h) {
 
 bool fwd_supported(const kprn_handle* h, int T) {
   const kprn_config& c = h->cfg;
-  return (h->D == DH && c.H == DH && c.L >= 1 && c.L <= 2 && (c.dt % 4) == 0 && (c.de % 4) == 0 && (c.dr % 4) == 0 && T >= 1);
+  return (h->D == DH && c.H == DH && c.L >= 1 && c.L <= 2 && (c.dt % 4) == 0 && (c.de % 4) == 0 && (c.dr % 4) == 0 && T >= 2 && T <= MAXT_LDS);
 }
 
 bool bwd_supported(const kprn_handle* h, int T) { return fwd_supported(h, T); }
 
 template <int L, bool SAVE>
 static void launch_fwd(kprn_handle* h, const FwdArgs& a, int grid) {
-  const size_t lds_bytes = (size_t)(2 + 2 * L) * MT * LDA * sizeof(float);
+  const size_t lds_bytes = (size_t)(2 + 2 * L) * MT * LDA * sizeof(float) + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t);
   static bool attr_done = false;  // one per template instantiation
   if (!attr_done) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd<L, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -631,7 +800,8 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
 template <bool BOTTOM, bool TOP>
 static void launch_bwd(kprn_handle* h, const BwdArgs& a, int grid) {
   const int n_small = BOTTOM ? (a.Vt * a.dt + a.Vr * a.dr) : 0;
-  const size_t lds_bytes = (size_t)(3 * MT * LDA + MT * LDD) * sizeof(float) + 2 * MT * 4 * sizeof(int32_t) + (size_t)(n_small <= 4096 ? n_small : 0) * sizeof(float);
+  const size_t lds_bytes = (size_t)(3 * MT * LDA + MT * LDD) * sizeof(float) + (MT * MAXT_LDS * 4 + MT) * sizeof(int32_t) +
+                           (size_t)(BOTTOM ? MT * LDA : 0) * sizeof(float) + (size_t)(n_small <= 4096 ? n_small : 0) * sizeof(float);
   HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());
@@ -655,6 +825,9 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     s->cap_Nb = cn; s->cap_Tb = ct;
   }
   if (!s->WT) HIP_TRY(hipMalloc((void**)&s->WT, (size_t)2 * 2 * 64 * 256 * sizeof(float)));
+  if (!s->part) HIP_TRY(hipMalloc((void**)&s->part, (size_t)s->num_cu * PART * sizeof(float)));
+  static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
+  if (want_timing && !s->timing) HIP_TRY(hipMalloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
   if (s->wt_dirty) {
     ProfScope ps(h, "weight_transpose");
     for (int l = 0; l < L; ++l) {
@@ -683,12 +856,29 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     a.gWi = gd + h->layer[l].Wi; a.gbi = gd + h->layer[l].bi; a.gWo = gd + h->layer[l].Wo;
     a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
     a.n_tiles = n_tiles;
+    a.part = s->part; a.timing = s->timing;
     const bool bottom = (l == 0), top = (l == L - 1);
-    ProfScope ps(h, "lstm_fused_bwd");
-    if (bottom && top) launch_bwd<true, true>(h, a, grid);
-    else if (bottom) launch_bwd<true, false>(h, a, grid);
-    else if (top) launch_bwd<false, true>(h, a, grid);
-    else launch_bwd<false, false>(h, a, grid);
+    {
+      ProfScope ps(h, "lstm_fused_bwd");
+      if (bottom && top) launch_bwd<true, true>(h, a, grid);
+      else if (bottom) launch_bwd<true, false>(h, a, grid);
+      else if (top) launch_bwd<false, true>(h, a, grid);
+      else launch_bwd<false, false>(h, a, grid);
+    }
+    {
+      ProfScope ps(h, "dw_reduce");
+      hipLaunchKernelGGL(k_reduce_partials, dim3((PART + 255) / 256, 16), dim3(256), 0, strm, s->part, grid, a.gWi, a.gWo, a.gbi);
+      HIP_TRY(hipGetLastError());
+    }
+    if (s->timing) {
+      HIP_TRY(hipStreamSynchronize(strm));
+      std::vector<unsigned long long> tb((size_t)grid * 8);
+      HIP_TRY(hipMemcpy(tb.data(), s->timing, tb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      double sum[8] = {0};
+      for (int g = 0; g < grid; ++g) for (int k = 0; k < 8; ++k) sum[k] += (double)tb[(size_t)g * 8 + k];
+      fprintf(stderr, "[kprn timing] bwd layer %d N=%lld grid=%d avg cycles/WG: prologue %.0f prefetch %.0f stageC %.0f midbar %.0f stageE %.0f scatter+bar %.0f flush %.0f\n",
+              l, (long long)N, grid, sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid);
+    }
   }
 }
 
@@ -697,7 +887,8 @@ void params_changed(kprn_handle* h) { if (h->fused_state) ((State*)h->fused_stat
 void release(kprn_handle* h) {
   State* s = (State*)h->fused_state;
   if (!s) return;
-  for (float* p : {s->save_frag, s->save_h, s->WT, s->dHhead, s->DX}) if (p) hipFree(p);
+  for (float* p : {s->save_frag, s->save_h, s->WT, s->dHhead, s->DX, s->part}) if (p) hipFree(p);
+  if (s->timing) hipFree(s->timing);
   delete s;
   h->fused_state = nullptr;
 }
