@@ -1,0 +1,253 @@
+"""On-disk formats either side of the hot path.
+
+1. ``.int`` text files written by release/songPathRnn/data/movie_data_format.py and parsed by
+   release/songPathRnn/data/int2torch.lua:27-56:
+       <label> TAB <path>;<path>;...      path = <step> <step> ...      step = f1,f2,...,fF
+   (0-based ids; int2torch -addOne 1 shifts the DATA, not the labels, to 1-based: lines 60-63.)
+
+2. Torch7 binary serialisation of ``{labels=DoubleTensor[N], data=DoubleTensor[N,P,T,F],
+   classId=number}`` (int2torch.lua:65-70, insertClassLabels.lua:12-17; consumed by
+   model/batcher/Batcher.lua:11-28).  The reference tree ships NO .torch file, so this
+   reader/writer follows the published Torch7 File format [restated from torch7/File.lua +
+   generic/Tensor.c, unpinned -- SURVEY.md 8f N2] and is verified by round trips only:
+     object   := int32 type ; type 0 nil | 1 number(f64) | 2 string(int32 len, bytes) |
+                 3 table | 4 torch object | 5 boolean(int32)
+     table    := int32 ref-index ; (first time) int32 n ; n x (key object, value object)
+     torch    := int32 ref-index ; (first time) string "V 1" ; string class name ; payload
+     Tensor   := int32 nDim ; int64 size[nDim] ; int64 stride[nDim] ; int64 storageOffset(1-based) ;
+                 storage object (torch.<T>Storage: int64 n ; raw elements)
+
+3. ``.npz`` -- the native container of this engine (same three fields, data already int32).
+"""
+import struct
+
+import numpy as np
+
+# ------------------------------------------------------------------------------------------
+# .int text
+
+
+def read_int_file(path, add_one=True):
+    """-> (labels float64 [N], data int32 [N,P,T,F]); mirrors int2torch.lua -tokenFeatures 1."""
+    labels, rows = [], []
+    with open(path, "r") as f:
+        for ln, line in enumerate(f, 1):
+            line = line.rstrip("\n")
+            if not line:
+                continue
+            fields = line.split("\t")
+            if len(fields) < 2:
+                raise ValueError(f"{path}:{ln}: expected '<label>\\t<paths>'")
+            labels.append(float(fields[0]))
+            paths = []
+            for p in fields[1].split(";"):
+                paths.append([[int(x) for x in tok.split(",")] for tok in p.split(" ") if tok != ""])
+            rows.append(paths)
+    if not rows:
+        raise ValueError(f"{path}: empty file")
+    P, T, F = len(rows[0]), len(rows[0][0]), len(rows[0][0][0])
+    for i, r in enumerate(rows):
+        # Util:table2tensor asserts regular sizes (util/Util.lua:121-140)
+        if len(r) != P or any(len(p) != T for p in r) or any(len(s) != F for p in r for s in p):
+            raise ValueError(f"{path}: row {i + 1} is not {P}x{T}x{F}: input tensor is expected to have the same "
+                             "number of elements in each dim")
+    data = np.asarray(rows, dtype=np.int64)
+    if add_one:
+        data = data + 1
+    if data.min() < 0 or data.max() >= 2 ** 31:
+        raise ValueError(f"{path}: id out of int32 range")
+    return np.asarray(labels, dtype=np.float64), data.astype(np.int32)
+
+
+def write_int_file(path, labels, data, sub_one=True):
+    data = np.asarray(data)
+    if sub_one:
+        data = data - 1
+    with open(path, "w") as f:
+        for lab, pairs in zip(labels, data):
+            lab_s = str(int(lab)) if float(lab).is_integer() else repr(float(lab))
+            f.write(lab_s + "\t" + ";".join(" ".join(",".join(str(int(v)) for v in step) for step in p) for p in pairs) + "\n")
+
+
+# ------------------------------------------------------------------------------------------
+# Torch7 binary
+
+_T_NIL, _T_NUMBER, _T_STRING, _T_TABLE, _T_TORCH, _T_BOOL = 0, 1, 2, 3, 4, 5
+_STORAGE_DTYPES = {
+    "torch.DoubleStorage": np.float64, "torch.FloatStorage": np.float32, "torch.LongStorage": np.int64,
+    "torch.IntStorage": np.int32, "torch.ShortStorage": np.int16, "torch.ByteStorage": np.uint8, "torch.CharStorage": np.int8,
+}
+_TENSOR_OF = {np.dtype(np.float64): "Double", np.dtype(np.float32): "Float", np.dtype(np.int64): "Long", np.dtype(np.int32): "Int"}
+
+
+class _T7Reader:
+    def __init__(self, buf):
+        self.b, self.o, self.objs = buf, 0, {}
+
+    def _rd(self, fmt):
+        v = struct.unpack_from("<" + fmt, self.b, self.o)
+        self.o += struct.calcsize("<" + fmt)
+        return v[0] if len(v) == 1 else v
+
+    def _string(self):
+        n = self._rd("i")
+        s = bytes(self.b[self.o:self.o + n]).decode("latin-1")
+        self.o += n
+        return s
+
+    def obj(self):
+        t = self._rd("i")
+        if t == _T_NIL:
+            return None
+        if t == _T_NUMBER:
+            return self._rd("d")
+        if t == _T_STRING:
+            return self._string()
+        if t == _T_BOOL:
+            return self._rd("i") != 0
+        if t == _T_TABLE:
+            ref = self._rd("i")
+            if ref in self.objs:
+                return self.objs[ref]
+            out = {}
+            self.objs[ref] = out
+            for _ in range(self._rd("i")):
+                k = self.obj()
+                out[k] = self.obj()
+            return out
+        if t == _T_TORCH:
+            ref = self._rd("i")
+            if ref in self.objs:
+                return self.objs[ref]
+            version = self._string()
+            cls = self._string() if version.startswith("V ") else version
+            if cls in _STORAGE_DTYPES:
+                n = self._rd("q")
+                dt = np.dtype(_STORAGE_DTYPES[cls])
+                arr = np.frombuffer(self.b, dtype=dt, count=n, offset=self.o).copy()
+                self.o += n * dt.itemsize
+                self.objs[ref] = arr
+                return arr
+            if cls.endswith("Tensor"):
+                nd = self._rd("i")
+                size = [self._rd("q") for _ in range(nd)]
+                stride = [self._rd("q") for _ in range(nd)]
+                off = self._rd("q") - 1
+                storage = self.obj()
+                if storage is None or nd == 0:
+                    ten = np.zeros(size, dtype=np.float64)
+                else:
+                    ten = np.lib.stride_tricks.as_strided(storage[off:], shape=size, strides=[s * storage.itemsize for s in stride]).copy()
+                self.objs[ref] = ten
+                return ten
+            raise ValueError(f"unsupported torch class in .torch file: {cls}")
+        raise ValueError(f"unsupported Torch7 type tag {t}")
+
+
+def t7_load(path):
+    with open(path, "rb") as f:
+        buf = memoryview(f.read())
+    return _T7Reader(buf).obj()
+
+
+class _T7Writer:
+    def __init__(self):
+        self.parts, self.n = [], 0
+
+    def _w(self, fmt, *v):
+        self.parts.append(struct.pack("<" + fmt, *v))
+
+    def _string(self, s):
+        b = s.encode("latin-1")
+        self._w("i", len(b))
+        self.parts.append(b)
+
+    def obj(self, v):
+        if v is None:
+            self._w("i", _T_NIL)
+        elif isinstance(v, bool):
+            self._w("ii", _T_BOOL, int(v))
+        elif isinstance(v, (int, float, np.integer, np.floating)):
+            self._w("id", _T_NUMBER, float(v))
+        elif isinstance(v, str):
+            self._w("i", _T_STRING)
+            self._string(v)
+        elif isinstance(v, dict):
+            self.n += 1
+            self._w("iii", _T_TABLE, self.n, len(v))
+            for k, x in v.items():
+                self.obj(k)
+                self.obj(x)
+        elif isinstance(v, np.ndarray):
+            a = np.ascontiguousarray(v)
+            name = _TENSOR_OF[a.dtype]
+            self.n += 1
+            self._w("ii", _T_TORCH, self.n)
+            self._string("V 1")
+            self._string(f"torch.{name}Tensor")
+            self._w("i", a.ndim)
+            for s in a.shape:
+                self._w("q", s)
+            st = [x // a.itemsize for x in a.strides]
+            for s in st:
+                self._w("q", s)
+            self._w("q", 1)
+            self.n += 1
+            self._w("ii", _T_TORCH, self.n)
+            self._string("V 1")
+            self._string(f"torch.{name}Storage")
+            self._w("q", a.size)
+            self.parts.append(a.tobytes())
+        else:
+            raise TypeError(type(v))
+
+
+def t7_save(path, obj):
+    w = _T7Writer()
+    w.obj(obj)
+    with open(path, "wb") as f:
+        for p in w.parts:
+            f.write(p)
+
+
+# ------------------------------------------------------------------------------------------
+# path-set files ({labels, data, classId}) in any of the three containers
+
+
+def load_path_file(path):
+    """-> (labels float32 [N], data int32 [N,P,T,F] 1-based, classId int)."""
+    if path.endswith(".npz"):
+        z = np.load(path)
+        labels, data, cid = z["labels"], z["data"], int(z["classId"]) if "classId" in z else 1
+    elif path.endswith(".int"):
+        labels, data = read_int_file(path, add_one=True)
+        cid = 1  # movie_data_format.sh:39  insertClassLabels -classLabel 1
+    else:
+        t = t7_load(path)
+        if not isinstance(t, dict) or "labels" not in t or "data" not in t:
+            raise ValueError(f"{path}: not a {{labels, data, classId}} table")
+        labels, data = t["labels"], t["data"]
+        cid = int(t.get("classId", 1))
+    data = np.asarray(data)
+    if data.ndim != 4:
+        raise ValueError(f"{path}: data must be [N,P,T,F], got {data.shape}")
+    if not np.issubdtype(data.dtype, np.integer):
+        # .torch files hold float64 ids (util/Util.lua:129); 20M-entity vocabularies exceed 2^24, so go
+        # through int64, never float32
+        if np.any(data != np.rint(data)):
+            raise ValueError(f"{path}: non-integer id")
+        data = data.astype(np.int64)
+    if data.size and (data.min() < 1 or data.max() >= 2 ** 31):
+        raise ValueError(f"{path}: id outside 1..2^31-1")
+    return np.asarray(labels, dtype=np.float32).reshape(-1), np.ascontiguousarray(data, dtype=np.int32), cid
+
+
+def save_path_file(path, labels, data, class_id=1):
+    labels = np.asarray(labels)
+    data = np.asarray(data)
+    if path.endswith(".npz"):
+        np.savez(path, labels=labels.astype(np.float32), data=data.astype(np.int32), classId=np.int32(class_id))
+    elif path.endswith(".int"):
+        write_int_file(path, labels, data, sub_one=True)
+    else:
+        t7_save(path, {"labels": labels.astype(np.float64), "data": data.astype(np.float64), "classId": float(class_id)})

@@ -1,0 +1,144 @@
+"""-m gpu: the host-side mirror (batch feed -> MyOptimizer -> checkpoint -> scoring writer) end to end
+on the GPU against an oracle replay, and the committed golden vectors through the C ABI."""
+import io
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from kprn_amd import _ffi, batcher, formats, model, optimizer, scoring, synth
+from oracle.oracle import Oracle, make_cfg, make_opt
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["c1_small.npz", "c2_small.npz"])
+def test_golden_vectors_through_the_c_abi(name):
+    z = np.load(os.path.join(GOLD, name))
+    c = [int(x) for x in z["cfg"]]
+    eng = _ffi.Engine(c[0], c[1], c[2], c[3], c[4], c[5], c[8], c[9], F=c[6], num_types=c[7], C_=c[10], reducer=c[11], K=c[12])
+    eng.set_flat_params(z["theta"])
+    b = eng.batch(z["idx"], z["labels"])
+    out = eng.forward(b, 1, want=("probs", "pooled", "path_scores"))
+    assert np.max(np.abs(out["path_scores"] - z["path_scores"])) / np.max(np.abs(z["path_scores"])) < 2e-5
+    np.testing.assert_allclose(out["probs"], z["probs"][:, 0], rtol=1e-4)
+    loss = eng.backward(b, 1)
+    assert abs(loss - float(z["loss"])) < 1e-5
+    g = eng.get_flat_grads()
+    assert np.max(np.abs(g - z["grad"])) / np.max(np.abs(z["grad"])) < 2e-4
+    opt = _ffi.make_opt(method=1, lr=1e-2)
+    losses = [eng.train_step(b, opt) for _ in range(3)]
+    np.testing.assert_allclose(losses, z["losses3"], rtol=2e-4)
+    assert np.max(np.abs(eng.get_flat_params() - z["theta_after3"])) < 1e-4
+
+
+def _write_dataset(root, ext):
+    os.makedirs(os.path.join(root, "train"), exist_ok=True)
+    os.makedirs(os.path.join(root, "test"), exist_ok=True)
+    tr, te = [], []
+    for i, (n, P) in enumerate([(40, 1), (24, 3), (9, 5)]):
+        idx, labels = synth.make_paths(n, P, 6, Ve=500, seed=50 + i)
+        name = f"train/train.txt.{P}{ext}"
+        formats.save_path_file(os.path.join(root, name), labels, idx, 1)
+        tr.append(name)
+    for i, (n, P) in enumerate([(30, 2), (11, 4)]):
+        idx, labels = synth.make_paths(n, P, 6, Ve=500, seed=70 + i)
+        name = f"test/test.txt.{P}{ext}"
+        formats.save_path_file(os.path.join(root, name), labels, idx, 1)
+        te.append(name)
+    open(os.path.join(root, "train.list"), "w").write("\n".join(tr) + "\n")
+    open(os.path.join(root, "test.list"), "w").write("\n".join(te) + "\n")
+
+
+FLAGS = ("-entityTypeVocabSize 6 -entityVocabSize 500 -relationVocabSize 9 -entityTypeEmbeddingDim 16 -entityEmbeddingDim 32 "
+         "-relationEmbeddingDim 16 -numFeatureTemplates 3 -numEntityTypes 1 -rnnType lstm -rnnHidSize 64 -numLayers 2 -topK 2 "
+         "-useAdam 1 -learningRate 0.01 -regularize 0 -includeEntity 1 -minibatch 16 -numEpochs 2 -gradientStepCounter 100000")
+
+
+@pytest.mark.parametrize("ext", [".torch", ".npz"])
+def test_train_loop_checkpoint_and_scoring_match_an_oracle_replay(tmp_path, ext):
+    root = str(tmp_path)
+    _write_dataset(root, ext)
+    params = model.parse_flags(FLAGS.split() + ["-dataDir", root])
+    eng = model.build_engine(params)
+    ocfg = make_cfg(Vt=6, Ve=500, Vr=9, dt=16, de=32, dr=16, H=64, L=2)
+    o64 = Oracle(ocfg, np.float64)
+    theta = eng.get_flat_params().astype(np.float64)  # the engine's own uniform(-paramInit, paramInit) init
+    assert np.all(np.abs(theta) <= 0.1 + 1e-7) and abs(theta.mean()) < 1e-3
+    log = io.StringIO()
+    fl = batcher.BatcherFileList(root, params.minibatch, False, 100, True, "train.list")
+    opt = optimizer.MyOptimizer(eng, {"numEpochs": 2, "epochHooks": [], "minibatchsize": 16}, model.opt_from_flags(params), out=log)
+    hist = opt.train(fl)
+    # oracle replay in the same order
+    fl2 = batcher.BatcherFileList(root, params.minibatch, False, 100, False, "train.list")
+    st = o64.new_state()
+    oo = make_opt(method=1, lr=0.01, regularize=0)
+    ohist = []
+    for _ in range(2):
+        tot, nb = 0.0, 0
+        while True:
+            got = fl2.getBatch()
+            if got is None:
+                break
+            labels, data, n, cid = got
+            l, _ = o64.train_step(theta, st, oo, data, labels, cid)
+            tot += l
+            nb += 1
+        ohist.append(tot / nb)
+        fl2.reset()
+    np.testing.assert_allclose(hist, ohist, rtol=2e-4)
+    assert "Total num batches 6" in log.getvalue() and "examples/sec" in log.getvalue() and "Iter: 2" in log.getvalue()
+    assert np.max(np.abs(eng.get_flat_params() - theta)) < 2e-4
+    # checkpoint -> fresh engine -> test_from_checkpoint writer
+    ck = os.path.join(root, "model-latest")
+    eng.save(ck)
+    params2 = model.parse_flags(FLAGS.split() + ["-initModel", ck])
+    eng2 = model.build_engine(params2)
+    out_file = os.path.join(root, "test.res")
+    n = scoring.test_from_checkpoint(eng2, root, "test.list", out_file)
+    lines = open(out_file).read().splitlines()
+    assert n == len(lines) == 41
+    k = 0
+    for name in open(os.path.join(root, "test.list")).read().split():
+        labels, data, _ = formats.load_path_file(os.path.join(root, name))
+        _, _, probs = o64.forward(theta, data)
+        for i in range(len(labels)):
+            c, s, lab = lines[k].split("\t")
+            assert int(c) == k and lab == ("1" if labels[i] == 1 else "0")
+            assert len(s.split(".")[1]) == 5 and abs(float(s) - probs[i, 0]) < 2e-5
+            k += 1
+
+
+def test_cli_train_and_score(tmp_path):
+    root = str(tmp_path)
+    _write_dataset(root, ".int")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    ck = os.path.join(root, "m")
+    r = subprocess.run([sys.executable, "-m", "kprn_amd.train"] + FLAGS.split() +
+                       ["-dataDir", root, "-model", ck, "-exptDir", os.path.join(root, "expt"), "-saveFrequency", "1", "-gpuid", "0"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Reducer is LogSumExp" in r.stdout and "Using Adam!" in r.stdout and "saving to " + ck + "-latest" in r.stdout
+    assert os.path.exists(os.path.join(root, "expt", "config.txt"))
+    out_file = os.path.join(root, "test.res")
+    r = subprocess.run([sys.executable, "-m", "kprn_amd.score", "-input_dir", root, "-test_list", "test.list", "-model_path", ck + "-latest",
+                        "-out_file", out_file, "-top_k", "2", "-gpu_id", "0"] + FLAGS.split(),
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = open(out_file).read().splitlines()
+    assert len(lines) == 41 and lines[0].startswith("0\t") and lines[-1].startswith("40\t")
+
+
+def test_unsupported_reference_options_fail_loudly():
+    p = model.parse_flags(FLAGS.replace("-rnnType lstm", "-rnnType rnn").split())
+    with pytest.raises(_ffi.KprnError) as e:
+        model.build_engine(p)
+    assert e.value.code == _ffi.E_UNSUPPORTED
+    p = model.parse_flags(FLAGS.replace("-includeEntity 1", "-includeEntity 0").split())
+    with pytest.raises(_ffi.KprnError) as e:
+        model.build_engine(p)
+    assert e.value.code == _ffi.E_UNSUPPORTED
