@@ -1,0 +1,105 @@
+--[[ kprn.lua -- LuaJIT FFI binding of libkprn.so (include/kprn.h).
+
+This is the stub a maintainer of release/songPathRnn adds so that MyOptimizer.lua and
+eval/test_from_checkpoint.lua call the MI355X engine instead of the Torch7 nn graph.  LuaJIT is not
+in the build image, so this file is exercised only through its Python twin (kprn_amd/_ffi.py binds the
+same symbols with the same struct layouts; tests/test_abi.py checks both against the header).
+
+  local kprn = require 'kprn'
+  local net  = kprn.create{Vt=6, Ve=2851220, Vr=9, dt=16, de=32, dr=16, F=3, num_types=1, H=64, L=2, reducer=2}
+  -- MyOptimizer:trainBatch(inputs, targets)          (model/optimizer/MyOptimizer.lua:177-221)
+  local err = net:trainBatch(inputs, targets, classId, optConfig)
+  -- test_from_checkpoint.lua:109   local preds = model:forward(inputs)
+  local preds = net:forward(inputs, 1)
+]]
+local ffi = require 'ffi'
+
+ffi.cdef[[
+typedef struct kprn_handle kprn_handle;
+typedef struct kprn_batch kprn_batch;
+typedef struct {
+  int32_t Vt, Ve, Vr, dt, de, dr, F, num_types, H, L, C, rnn_type, reducer, K, device_id, rank, world;
+  float param_init; uint64_t seed; void* stream;
+} kprn_config;
+typedef struct {
+  int32_t method; float lr, beta1, beta2, eps, lr_decay; int32_t regularize, use_grad_clip;
+  float grad_clip_norm, l2; int32_t bce_literal, entity_update;
+} kprn_opt;
+int kprn_create(const kprn_config*, kprn_handle**);
+void kprn_destroy(kprn_handle*);
+const char* kprn_last_error(const kprn_handle*);
+int kprn_num_params(kprn_handle*, int64_t*);
+int kprn_get_param(kprn_handle*, const char*, float*, int64_t);
+int kprn_set_param(kprn_handle*, const char*, const float*, int64_t);
+int kprn_get_flat_params(kprn_handle*, float*, int64_t);
+int kprn_set_flat_params(kprn_handle*, const float*, int64_t);
+int kprn_zero_pad_tokens(kprn_handle*);
+int kprn_forward(kprn_handle*, const int32_t*, int32_t, int32_t, int32_t, int32_t, int32_t, float*, float*);
+int kprn_train_step(kprn_handle*, const int32_t*, int32_t, int32_t, int32_t, int32_t, const float*, int32_t, const kprn_opt*, float*);
+int kprn_save(kprn_handle*, const char*);
+int kprn_load(kprn_handle*, const char*);
+]]
+
+local C = ffi.load('kprn')
+local M = {}
+local Net = {}
+Net.__index = Net
+
+local function check(h, rc)
+  if rc ~= 0 then error(('kprn error %d: %s'):format(rc, ffi.string(C.kprn_last_error(h)))) end
+end
+
+function M.create(o)
+  local cfg = ffi.new('kprn_config')
+  cfg.Vt, cfg.Ve, cfg.Vr = o.Vt, o.Ve, o.Vr
+  cfg.dt, cfg.de, cfg.dr = o.dt, o.de, o.dr
+  cfg.F, cfg.num_types = o.F or 3, o.num_types or 1
+  cfg.H, cfg.L, cfg.C = o.H, o.L or 1, o.C or 46
+  cfg.rnn_type, cfg.reducer, cfg.K = 0, o.reducer or 2, o.K or 5
+  cfg.device_id, cfg.rank, cfg.world = o.device_id or 0, 0, 1
+  cfg.param_init, cfg.seed = o.paramInit or 0.1, o.seed or 12345
+  local ph = ffi.new('kprn_handle*[1]')
+  local rc = C.kprn_create(cfg, ph)
+  if rc ~= 0 then error(('kprn_create failed (%d): %s'):format(rc, ffi.string(C.kprn_last_error(nil)))) end
+  return setmetatable({h = ffi.gc(ph[0], C.kprn_destroy), C = cfg.C}, Net)
+end
+
+-- DoubleTensor[B,P,T,F] of 1-based ids (model/batcher/Batcher.lua:51) -> int32 host buffer, once per batch
+local function to_int32(t)
+  local n = t:nElement()
+  local src = t:contiguous():data()
+  local dst = ffi.new('int32_t[?]', n)
+  for i = 0, n - 1 do dst[i] = src[i] end
+  return dst
+end
+
+function Net:forward(inputs, classId)  -- == nn.Sequential():add(training_net):add(nn.Select(2,classId)):forward(inputs)
+  local B, P, T, F = inputs:size(1), inputs:size(2), inputs:size(3), inputs:size(4)
+  local probs = ffi.new('float[?]', B)
+  check(self.h, C.kprn_forward(self.h, to_int32(inputs), B, P, T, F, classId or 1, probs, nil))
+  local out = torch.DoubleTensor(B)
+  for i = 1, B do out[i] = probs[i - 1] end
+  return out
+end
+
+function Net:trainBatch(inputs, targets, classId, optConfig, optInfo)
+  local B, P, T, F = inputs:size(1), inputs:size(2), inputs:size(3), inputs:size(4)
+  local opt = ffi.new('kprn_opt')
+  opt.method = optInfo.useAdam and 1 or 0
+  opt.lr, opt.beta1, opt.beta2, opt.eps = optConfig.learningRate, optConfig.beta1 or 0.9, optConfig.beta2 or 0.999, optConfig.epsilon or 1e-8
+  opt.lr_decay = optConfig.learningRateDecay or 0
+  opt.regularize, opt.use_grad_clip = optInfo.regularize, optInfo.useGradClip and 1 or 0
+  opt.grad_clip_norm, opt.l2 = optInfo.gradClipNorm, optInfo.l2
+  local lab = ffi.new('float[?]', B)
+  local td = targets:contiguous():data()
+  for i = 0, B - 1 do lab[i] = td[i] end
+  local loss = ffi.new('float[1]')
+  check(self.h, C.kprn_train_step(self.h, to_int32(inputs), B, P, T, F, lab, classId or 1, opt, loss))
+  return loss[0]
+end
+
+function Net:zeroPadTokens() check(self.h, C.kprn_zero_pad_tokens(self.h)) end
+function Net:save(path) check(self.h, C.kprn_save(self.h, path)) end
+function Net:load(path) check(self.h, C.kprn_load(self.h, path)) end
+
+return M
