@@ -499,6 +499,23 @@ __global__ void k_clear_rows(float* __restrict__ G, const int32_t* __restrict__ 
   for (int e = lane; e < d; e += 64) G[r * d + e] = 0.f;
 }
 
+// per (64-row tile, step): leader[row] = first row of the tile with the same entity id (-1 past N).
+// Used by the fused backward to fold duplicate rows before the embedding-gradient atomics.
+__global__ void k_tile_leaders(const int32_t* __restrict__ idx, int64_t N, int T, int F, int32_t* __restrict__ lead) {
+  __shared__ int32_t e[64];
+  const int64_t tile = blockIdx.x / T;
+  const int t = blockIdx.x % T;
+  const int r = threadIdx.x;
+  const int64_t n = tile * 64 + r;
+  const bool valid = n < N;
+  e[r] = valid ? idx[(n * T + t) * F + F - 2] : -1 - r;
+  __syncthreads();
+  int ld = r;
+  for (int r2 = 0; r2 < r; ++r2)
+    if (e[r2] == e[r]) { ld = r2; break; }
+  lead[n * T + t] = valid ? ld : -1;
+}
+
 // uniform(-a, a) init (OneModel.lua:306-309); counter-based splitmix64
 __global__ void k_fill_uniform(float* __restrict__ x, int64_t n, float a, uint64_t seed, uint64_t offset) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -691,6 +708,13 @@ void fill_uniform(hipStream_t s, float* x, int64_t n, float a, uint64_t seed, ui
 void clear_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d) {
   if (max_rows <= 0) return;
   hipLaunchKernelGGL(k_clear_rows, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, G, rows, count, d);
+  CHECK_LAUNCH();
+}
+
+void tile_leaders(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int32_t* lead) {
+  if (N <= 0) return;
+  const int64_t tiles = (N + 63) / 64;
+  hipLaunchKernelGGL(k_tile_leaders, dim3((unsigned)(tiles * T)), dim3(64), 0, s, idx, N, T, F, lead);
   CHECK_LAUNCH();
 }
 

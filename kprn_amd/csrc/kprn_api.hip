@@ -636,9 +636,14 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
     const int32_t tag = h->next_tag++;
     kk::unique_rows(h->stream, b->idx, nsteps, F, h->We_stamp, tag, b->uniq, b->uniq + b->uniq_cap);
     HIP_TRY(hipMemcpyAsync(&b->n_uniq, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (labels) {  // training batches: duplicate-row leaders per 64-row tile for the fused backward
+      const int64_t N = (int64_t)B * P;
+      b->lead = dalloc<int32_t>(((N + 63) / 64) * 64 * T);
+      kk::tile_leaders(h->stream, b->idx, N, T, F, b->lead);
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
   } catch (...) {
-    dfree(b->idx); dfree(b->labels); dfree(b->uniq);
+    dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->lead);
     delete b;
     throw;
   }
@@ -649,7 +654,7 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
 void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
   if (!b) return;
   if (h) { hipSetDevice(h->cfg.device_id); hipStreamSynchronize(h->stream); }
-  dfree(b->idx); dfree(b->labels); dfree(b->uniq);
+  dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->lead);
   delete b;
 }
 

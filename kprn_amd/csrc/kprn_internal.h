@@ -66,6 +66,7 @@ struct kprn_batch {
   int32_t* uniq = nullptr;    // device: distinct entity rows of this batch (0-based); count at uniq[uniq_cap]
   int64_t uniq_cap = 0;
   int32_t n_uniq = 0;
+  int32_t* lead = nullptr;    // device [ceil(N/64)*64][T]: first row of the 64-row tile with the same entity id at step t, -1 past N
 };
 
 struct kprn_handle {
@@ -168,6 +169,7 @@ void unpack_add_rows(hipStream_t s, float* G, const int32_t* ids, const float* r
                      int32_t* stamp, int32_t tag, int32_t* list, int32_t* list_count);
 void fill_uniform(hipStream_t s, float* x, int64_t n, float a, uint64_t seed, uint64_t offset);
 void fill_i32(hipStream_t s, int32_t* x, int64_t n, int32_t v);
+void tile_leaders(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int32_t* lead);
 void clear_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d);
 }  // namespace kk
 

@@ -93,6 +93,11 @@ __device__ __forceinline__ void ids_stage(const int32_t* idx, int64_t N, int T, 
   }
 }
 
+// slot 3 of the id tile <- precomputed tile leader (fused backward, bottom layer)
+__device__ __forceinline__ void lead_stage(const int32_t* lead, int T, int64_t tile, int32_t* ids) {
+  for (int c = threadIdx.x; c < MT * T; c += 256) ids[c * 4 + 3] = lead[tile * MT * T + c];
+}
+
 // gather this thread's share of one step's x rows for `tile` into registers (ids from the LDS id tile)
 template <int NTHREADS>
 __device__ __forceinline__ void gather_load(const FwdArgs& a, int64_t tile, int t, const int32_t* ids, f32x4 (&v)[1024 / NTHREADS]) {
@@ -348,11 +353,15 @@ struct BwdArgs {
   const float* save_frag;  // forward's fragment-order gates
   const float* save_h;     // [T][L][N][64]
   const float* dHhead;     // [N][64] (top layer) or null
-  float* DX;               // [T][N][64]: in = dx of the layer above (not top), out = dx of this layer (not bottom)
+  float* DX;               // [T][Npad][64]: in = dx of the layer above (not top), out = dx of this layer (not bottom)
+  int64_t Npad;            // N rounded up to the 64-row tile
   float* gWi; float* gbi; float* gWo;   // [256][64], [256], [256][64]
   float* gWt; float* gWe; float* gWr;   // bottom layer only
   float* part;             // [grid][2*256*64 + 256] per-workgroup partial dW_i2g | dW_o2g | db
   unsigned long long* timing;  // optional [grid][8] cycle counters (KPRN_TIMING=1)
+  int dbg;                 // KPRN_DBG bit 0: skip the embedding scatter (measurement only)
+  const int32_t* lead;     // [Npad][T] tile leaders (bottom layer)
+  int mfma_scatter;        // 1: one-hot MFMA scatter (dims multiples of 16, one type slot, tables <= 16 rows)
   int64_t n_tiles;
 };
 
@@ -422,7 +431,7 @@ __device__ __forceinline__ void frag_load(Frag6& fr, const float* fb, const floa
     tlast = now__;                                                                    \
   }
 
-template <bool BOTTOM, bool TOP>
+template <bool BOTTOM, bool TOP, bool MSCAT>
 __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   const int arow = lane & 15, ag = lane >> 4;
   const int T = a.T, L = a.L, ly = a.layer;
   const int n_small = BOTTOM ? (a.Vt * a.dt + a.Vr * a.dr) : 0;
-  const bool small_in_lds = BOTTOM && n_small <= 4096;
+  const bool small_in_lds = BOTTOM && !MSCAT && n_small <= 4096;
   if (small_in_lds) for (int i = tid; i < n_small; i += 256) small_g[i] = 0.f;
 
   // launch-persistent accumulators: dW_i2g / dW_o2g rows (q*64 + 16j + 4ag + r), cols 16nt + arow
@@ -456,6 +465,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   }
 
   const int64_t frag_mt_stride = (int64_t)T * L * 4 * 5 * 256;
+  // one-hot MFMA scatter: class of this wave's 16 columns (0 type, 1 entity, 2 relation) and the launch-
+  // persistent accumulator of its small table: acc_s[r] <-> table row 4ag + r, column 16j + arow
+  constexpr bool mscat = BOTTOM && MSCAT;  // compile-time: the two scatter forms never share a register allocation
+  const int wcls = (j * 16 < a.dt) ? 0 : ((j * 16 < a.dt + a.de) ? 1 : 2);
+  f32x4 acc_s = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * MT;
@@ -465,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) dc[m][r] = 0.f;
     lds_barrier();  // previous tile fully consumed before its LDS tiles are overwritten
-    if (BOTTOM) { ids_stage<256>(a.idx, a.N, T, a.F, a.nT, tile, ids); lds_barrier(); }
+    if (BOTTOM) { ids_stage<256>(a.idx, a.N, T, a.F, a.nT, tile, ids); if (mscat) lead_stage(a.lead, T, tile, ids); lds_barrier(); }
     // recurrent dh starts at 0 (or at the head gradient for the top layer)
     for (int c = tid; c < MT * 16; c += 256) {
       const int row = c >> 4, ch = c & 15;
@@ -486,28 +500,34 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     // accumulator copies around every MFMA (stage E measured 4x over its MFMA time)
     auto step = [&](auto rec_tag, const int t) {
       constexpr bool REC = decltype(rec_tag)::value;
-      // ---- prefetch: the NEXT step's tiles go to registers now and to LDS after the mid barrier ----
-      f32x4 nin[4], nhp[4];
-      if (REC) bwd_tile_load<BOTTOM>(a, n0, t - 1, tid, ids, nin, nhp);
-      TPROBE(1)  // prefetch issue
+      TPROBE(1)
 
       // ---- C. cell backward + dW, one m-tile at a time; saved gate fragments one m-tile ahead --------
       const float* fr_base = a.save_frag + (((tile * 4) * T + t) * L + ly) * (4 * 5 * 256) + (int64_t)j * (5 * 256) + lane * 4;
       const float* frp_base = REC ? a.save_frag + (((tile * 4) * T + (t - 1)) * L + ly) * (4 * 5 * 256) + (int64_t)j * (5 * 256) + lane * 4 : nullptr;
       // dx of the layer above for this wave's rows / columns (C layout) rides along with the fragments
+      // (DX rows past N are written as exact zeros by the layer above, so no tail handling here)
+      const float* dxp = TOP ? nullptr : a.DX + ((int64_t)t * a.Npad + n0 + ag * 4) * DH + j * 16 + arow;
       auto up_load = [&](Frag6& f6, int mt) {
         if (TOP) return;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int64_t n = n0 + mt * 16 + ag * 4 + r;
-          const float m = (n < a.N) ? 1.f : 0.f;
-          if (n >= a.N) n = a.N - 1;
-          f6.up[r] = m * a.DX[((int64_t)t * a.N + n) * DH + j * 16 + arow];
-        }
+        for (int r = 0; r < 4; ++r) f6.up[r] = dxp[(mt * 16 + r) * DH];
       };
       Frag6 fr[2];
       frag_load<REC>(fr[0], fr_base, frp_base);
       up_load(fr[0], 0);
+      // B operands of the dW product: [in | h_prev][row = mt*16 + 4ag + r][16nt + arow], one group ahead
+      float bq[8];
+      auto load_b = [&](float (&b)[8], int mt2, int r2) {
+        const int row = mt2 * 16 + ag * 4 + r2;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          b[nt] = in_t[row * LDA + nt * 16 + arow];
+          if constexpr (REC) b[4 + nt] = hp_t[row * LDA + nt * 16 + arow];
+          else b[4 + nt] = 0.f;
+        }
+      };
+      load_b(bq, 0, 0);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         if (mt < 3) {
@@ -534,22 +554,30 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) dbias[q] += (dA[q][0] + dA[q][1]) + (dA[q][2] + dA[q][3]);
-        // dW += dA^T [in | h_prev]: MFMA #r uses k-slot ag <-> row mt*16 + 4ag + r
+        // dW += dA^T [in | h_prev]: MFMA #r uses k-slot ag <-> row mt*16 + 4ag + r.
+        // The B values of group (mt, r) were read from LDS one group earlier (bq); the reads for the
+        // next group are issued before this group's 32 MFMAs.  (Left to itself hipcc emitted
+        // read -> s_waitcnt -> 8 MFMAs, exposing the LDS latency on every group.)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = mt * 16 + ag * 4 + r;
+          float bc[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) bc[u] = bq[u];
+          {
+            const int g2 = mt * 4 + r + 1;  // next group (static after unrolling)
+            if (g2 < 16) load_b(bq, g2 >> 2, g2 & 3);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the next group's LDS reads ahead of this group's MFMAs
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
-            const float b = in_t[row * LDA + nt * 16 + arow];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dwi[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[q][r], b, dwi[q][nt], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) dwi[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[q][r], bc[nt], dwi[q][nt], 0, 0, 0);
           }
           if constexpr (REC) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-              const float b = hp_t[row * LDA + nt * 16 + arow];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) dwo[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[q][r], b, dwo[q][nt], 0, 0, 0);
+              for (int q = 0; q < 4; ++q) dwo[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[q][r], bc[4 + nt], dwo[q][nt], 0, 0, 0);
             }
           }
         }
@@ -557,8 +585,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       TPROBE(2)  // stage C (cell backward + dW MFMAs)
       lds_barrier();
       TPROBE(3)  // mid barrier wait
-      // tiles of step t are dead now (stage C is the only reader): land the prefetched ones
-      if (REC) bwd_tile_store(in_t, hp_t, tid, nin, nhp);
+      // tiles of step t are dead now (stage C is the only reader): fetch the NEXT step's tiles into
+      // registers here (their latency hides under stage E's MFMAs) and land them after those MFMAs --
+      // keeping them out of stage C, which is the register-pressure peak of the kernel
+      f32x4 nin[4], nhp[4];
+      if (REC) bwd_tile_load<BOTTOM>(a, n0, t - 1, tid, ids, nin, nhp);
 
       // ---- E. [dx | dh_prev] = dA * [W_i2g | W_o2g]; this wave: columns 16j..16j+15 of each ----------
       {
@@ -582,6 +613,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
             }
           }
         }
+        if (REC) bwd_tile_store(in_t, hp_t, tid, nin, nhp);
         const int col = j * 16 + arow;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -589,64 +621,140 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
           for (int r = 0; r < 4; ++r) {
             const int row = mt * 16 + ag * 4 + r;
             dhr[row * LDA + col] = ah[mt][r];  // read by step t-1 after the end-of-step barrier
-            if (BOTTOM) dxt[row * LDA + col] = ax[mt][r];
-            else if (n0 + row < a.N) a.DX[((int64_t)t * a.N + n0 + row) * DH + col] = ax[mt][r];
+            if (BOTTOM) { if (!mscat) dxt[row * LDA + col] = ax[mt][r]; }
+            else a.DX[((int64_t)t * a.Npad + n0 + row) * DH + col] = ax[mt][r];  // rows past N are exact zeros (dA = 0 there)
+          }
+        }
+        if constexpr (mscat) if (!(a.dbg & 1)) {
+          // nn.LookupTable backward as a matrix product: grad_table[v][:] += sum_rows onehot(id[row] == v) dx[row][:].
+          // The dx accumulators ax[mt][r] already sit in the MFMA B layout (k-slot ag <-> row mt*16+4ag+r),
+          // the one-hot A operand is built from the LDS id tile; exact (products by 1.0 / 0.0).
+          if (wcls != 1) {
+            const int which = (wcls == 0) ? 0 : 2;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int32_t* id = ids + ((mt * 16 + ag * 4 + r) * T + t) * 4;
+                const float oh = (id[which] == arow && id[3] >= 0) ? 1.f : 0.f;
+                acc_s = __builtin_amdgcn_mfma_f32_16x16x4f32(oh, ax[mt][r], acc_s, 0, 0, 0);
+              }
+          } else {
+            // entity rows: fold the tile's duplicate ids onto their leader row (every pad step hits ONE row,
+            // a pair's user / item repeat across its paths), then one L2 atomic per distinct id
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {  // one 16-leader block at a time: 4 live accumulator registers
+              f32x4 comb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int ld = ids[((mt * 16 + ag * 4 + r) * T + t) * 4 + 3];
+                  comb = __builtin_amdgcn_mfma_f32_16x16x4f32((ld == m * 16 + arow) ? 1.f : 0.f, ax[mt][r], comb, 0, 0, 0);
+                }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = m * 16 + ag * 4 + r;
+                const int32_t* id = ids + (row * T + t) * 4;
+                if (id[3] == row) unsafeAtomicAdd(a.gWe + (int64_t)id[1] * a.de + (col - a.dt), comb[r]);
+              }
+            }
           }
         }
       }
       TPROBE(4)  // landing + stage E (dX MFMAs)
-      if (BOTTOM) {
+      if constexpr (BOTTOM && !mscat) if (!(a.dbg & 1)) {
         // nn.LookupTable backward = scatter-add with duplicates accumulating (FeatureEmbedding.lua:29,41-49,86).
         // Pad steps all hit ONE entity row and a pair's user / item repeat across its paths, so rows
         // with the same entity id are first summed inside the tile (LDS); one L2 atomic row per distinct id.
         {
-          // leader = first row of the tile with the same entity id; 4 threads per row scan 16 candidates each
+          // leader = first row of the tile with the same entity id; 4 threads per row, 16 candidates each,
+          // all 16 id reads issued together (branch-free: one wave per SIMD hides no LDS latency for us)
           const int row = tid >> 2, part = tid & 3;
-          const bool valid = n0 + row < a.N;
           const int e = ids[(row * T + t) * 4 + 1];
+          int cand[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) cand[u] = ids[((part * 16 + u) * T + t) * 4 + 1];
           int ld = row;
-          const int lo = part * 16, hi = (lo + 16 < row) ? lo + 16 : row;
-          for (int r2 = lo; r2 < hi; ++r2)
-            if (ids[(r2 * T + t) * 4 + 1] == e) { ld = r2; break; }
+#pragma unroll
+          for (int u = 15; u >= 0; --u) {
+            const int r2 = part * 16 + u;
+            ld = (r2 < row && cand[u] == e) ? r2 : ld;
+          }
           ld = min(ld, __shfl_xor(ld, 1, 64));
           ld = min(ld, __shfl_xor(ld, 2, 64));
-          if (part == 0) lead[row] = valid ? ld : -1;
+          if (part == 0) lead[row] = (n0 + row < a.N) ? ld : -1;
         }
         lds_barrier();
         const int e0 = a.dt, e1 = a.dt + a.de;
-        // (1) fold follower rows into their leader (entity slice), types / relations into the small tables
-#pragma unroll 4
-        for (int c = tid; c < MT * DH; c += 256) {
-          const int row = c >> 6, col = c & 63;
-          const int ld = lead[row];
-          if (ld < 0) continue;
-          const float v = dxt[row * LDA + col];
-          const int32_t* id = ids + (row * T + t) * 4;
-          if (col < e0) {
-            if (small_in_lds) lds_atomic_add(&small_g[id[0] * a.dt + col], v);
-            else unsafeAtomicAdd(a.gWt + (int64_t)id[0] * a.dt + col, v);
-            if (a.nT > 1) {
+        const int col = tid & 63, rg = tid >> 6;  // this thread: one column, rows rg, rg+4, ...
+        const bool is_ent = col >= e0 && col < e1;
+        int ldk[16];
+        if (a.dbg & 4) {
+        } else if (small_in_lds && a.nT == 1) {
+          // (1) fold follower rows into their leader (entity slice); types / relations into the LDS small tables.
+          //     One predicated ds_add_f32 per element, all operand reads batched up front.
+          float vk[16];
+          int idk[16];
+          const int which = (col < e0) ? 0 : 2;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int row = rg + 4 * k;
+            vk[k] = dxt[row * LDA + col];
+            ldk[k] = lead[row];
+            idk[k] = ids[(row * T + t) * 4 + which];
+          }
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int row = rg + 4 * k;
+            float* p;
+            bool go = ldk[k] >= 0;
+            if (is_ent) { p = dxt + ldk[k] * LDA + col; go = go && (ldk[k] != row); }
+            else if (col < e0) p = small_g + idk[k] * a.dt + col;
+            else p = small_g + a.Vt * a.dt + idk[k] * a.dr + (col - e1);
+            if (go) lds_atomic_add(p, vk[k]);
+          }
+        } else {
+          // general form: several type slots per step and / or small tables too big for LDS
+          for (int k = 0; k < 16; ++k) {
+            const int row = rg + 4 * k;
+            const int ld = lead[row];
+            ldk[k] = ld;
+            if (ld < 0) continue;
+            const float v = dxt[row * LDA + col];
+            const int32_t* id = ids + (row * T + t) * 4;
+            if (col < e0) {
               const int32_t* f = a.idx + ((n0 + row) * T + t) * a.F;
-              for (int k = 1; k < a.nT; ++k) {
-                const int rr = f[a.F - a.nT - 2 + k] - 1;
+              for (int kk = 0; kk < a.nT; ++kk) {
+                const int rr = (kk == 0) ? id[0] : f[a.F - a.nT - 2 + kk] - 1;
                 if (small_in_lds) lds_atomic_add(&small_g[rr * a.dt + col], v);
                 else unsafeAtomicAdd(a.gWt + (int64_t)rr * a.dt + col, v);
               }
+            } else if (col < e1) {
+              if (ld != row) lds_atomic_add(&dxt[ld * LDA + col], v);
+            } else {
+              if (small_in_lds) lds_atomic_add(&small_g[a.Vt * a.dt + id[2] * a.dr + (col - e1)], v);
+              else unsafeAtomicAdd(a.gWr + (int64_t)id[2] * a.dr + (col - e1), v);
             }
-          } else if (col < e1) {
-            if (ld != row) lds_atomic_add(&dxt[ld * LDA + col], v);
-          } else {
-            if (small_in_lds) lds_atomic_add(&small_g[a.Vt * a.dt + id[2] * a.dr + (col - e1)], v);
-            else unsafeAtomicAdd(a.gWr + (int64_t)id[2] * a.dr + (col - e1), v);
           }
         }
         lds_barrier();
         // (2) leaders add their (combined) entity slice to the gradient table (fire-and-forget atomics:
         //     the LDS-only barriers do not wait for them)
-        for (int c = tid; c < MT * DH; c += 256) {
-          const int row = c >> 6, col = c & 63;
-          if (col >= e0 && col < e1 && lead[row] == row)
-            unsafeAtomicAdd(a.gWe + (int64_t)ids[(row * T + t) * 4 + 1] * a.de + (col - e0), dxt[row * LDA + col]);
+        if (is_ent && !(a.dbg & 2)) {
+          float vk[16];
+          int ek[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int row = rg + 4 * k;
+            vk[k] = dxt[row * LDA + col];
+            ek[k] = ids[(row * T + t) * 4 + 1];
+          }
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int row = rg + 4 * k;
+            if (ldk[k] == row) unsafeAtomicAdd(a.gWe + (int64_t)ek[k] * a.de + (col - e0), vk[k]);
+          }
         }
       }
       lds_barrier();  // dhr / staged tiles visible to step t-1; dA_t, dxt, lead free for reuse
@@ -678,7 +786,17 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       if (ag == 0) pw[2 * 256 * 64 + q * DH + j * 16 + arow] = v;
     }
   }
-  if (small_in_lds) {
+  if constexpr (mscat) if (wcls != 1) {
+    // acc_s[r] <-> table row 4ag + r, column 16j + arow of the type (wcls 0) / relation (wcls 2) gradient
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int v = ag * 4 + r;
+      const int col = j * 16 + arow;
+      if (wcls == 0) { if (v < a.Vt) unsafeAtomicAdd(a.gWt + (int64_t)v * a.dt + col, acc_s[r]); }
+      else { if (v < a.Vr) unsafeAtomicAdd(a.gWr + (int64_t)v * a.dr + (col - a.dt - a.de), acc_s[r]); }
+    }
+  }
+  if constexpr (!mscat) if (small_in_lds) {
     lds_barrier();
     const int nt_small = a.Vt * a.dt;
     for (int i = tid; i < n_small; i += 256) {
@@ -797,13 +915,13 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   else { if (save) launch_fwd<2, true>(h, a, grid); else launch_fwd<2, false>(h, a, grid); }
 }
 
-template <bool BOTTOM, bool TOP>
+template <bool BOTTOM, bool TOP, bool MSCAT>
 static void launch_bwd(kprn_handle* h, const BwdArgs& a, int grid) {
   const int n_small = BOTTOM ? (a.Vt * a.dt + a.Vr * a.dr) : 0;
   const size_t lds_bytes = (size_t)(3 * MT * LDA + MT * LDD) * sizeof(float) + (MT * MAXT_LDS * 4 + MT) * sizeof(int32_t) +
                            (size_t)(BOTTOM ? MT * LDA : 0) * sizeof(float) + (size_t)(n_small <= 4096 ? n_small : 0) * sizeof(float);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP, MSCAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP, MSCAT>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());
 }
 
@@ -821,7 +939,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     const int64_t cn = std::max<int64_t>(N, s->cap_Nb);
     const int ct = std::max(T, s->cap_Tb);
     HIP_TRY(hipMalloc((void**)&s->dHhead, (size_t)(cn + 64) * DH * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&s->DX, (size_t)ct * (cn + 64) * DH * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&s->DX, (size_t)ct * (cn + 2 * MT) * DH * sizeof(float)));
     s->cap_Nb = cn; s->cap_Tb = ct;
   }
   if (!s->WT) HIP_TRY(hipMalloc((void**)&s->WT, (size_t)2 * 2 * 64 * 256 * sizeof(float)));
@@ -852,18 +970,22 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     a.dt = c.dt; a.de = c.de; a.dr = c.dr; a.Vt = c.Vt; a.Vr = c.Vr;
     a.L = L; a.layer = l;
     a.WiT = s->WT + (size_t)(l * 2 + 0) * 64 * 256; a.WoT = s->WT + (size_t)(l * 2 + 1) * 64 * 256;
-    a.save_frag = s->save_frag; a.save_h = s->save_h; a.dHhead = s->dHhead; a.DX = s->DX;
+    a.save_frag = s->save_frag; a.save_h = s->save_h; a.dHhead = s->dHhead; a.DX = s->DX; a.Npad = n_tiles * MT;
     a.gWi = gd + h->layer[l].Wi; a.gbi = gd + h->layer[l].bi; a.gWo = gd + h->layer[l].Wo;
     a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
     a.n_tiles = n_tiles;
     a.part = s->part; a.timing = s->timing;
+    { static const char* d = getenv("KPRN_DBG"); a.dbg = d ? atoi(d) : 0; }
+    a.lead = b->lead;
+    a.mfma_scatter = (b->lead && c.num_types == 1 && (c.dt % 16) == 0 && (c.de % 16) == 0 && (c.dr % 16) == 0 && c.Vt <= 16 && c.Vr <= 16 &&
+                      !(a.dbg & 8)) ? 1 : 0;
     const bool bottom = (l == 0), top = (l == L - 1);
     {
       ProfScope ps(h, "lstm_fused_bwd");
-      if (bottom && top) launch_bwd<true, true>(h, a, grid);
-      else if (bottom) launch_bwd<true, false>(h, a, grid);
-      else if (top) launch_bwd<false, true>(h, a, grid);
-      else launch_bwd<false, false>(h, a, grid);
+      if (bottom && top) { if (a.mfma_scatter) launch_bwd<true, true, true>(h, a, grid); else launch_bwd<true, true, false>(h, a, grid); }
+      else if (bottom) { if (a.mfma_scatter) launch_bwd<true, false, true>(h, a, grid); else launch_bwd<true, false, false>(h, a, grid); }
+      else if (top) launch_bwd<false, true, false>(h, a, grid);
+      else launch_bwd<false, false, false>(h, a, grid);
     }
     {
       ProfScope ps(h, "dw_reduce");
