@@ -67,7 +67,7 @@ def dims_of(a):
 def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr):
     """(bound, algorithmic work per launch) for a kernel family of the engine; None if unknown."""
     g = 4 * H
-    if name == "lstm_fused_fwd":
+    if name in ("lstm_fused_fwd", "lstm_fused_fwd_train"):
         fl = 0
         for l in range(L):
             din = D if l == 0 else H

@@ -137,70 +137,62 @@ __device__ __forceinline__ void gather_store(float* xbuf, const f32x4 (&v)[1024 
   }
 }
 
-// One LSTM step of one layer for the 64-row tile, executed by the 4 waves of a group.
-//  in_buf / hp_buf / out_buf: LDS tiles [64][LDA]; hp_buf == nullptr at t == 0 (h0 = 0).
-//  wi/wo: this wave's register-stationary B fragments [gate][S]; bias[gate]; c[mt][r] state.
-template <bool SAVE>
-__device__ __forceinline__ void lstm_step(const float* in_buf, const float* hp_buf, float* out_buf, const f32x4 (&wi)[4][4],
-                                          const f32x4 (&wo)[4][4], const float (&bias)[4], float (&c)[4][4], bool first, int j, int lane,
-                                          float* save_frag_t /* base for (gmt = tile*4, t, ly, j) or null */, int64_t frag_mt_stride,
-                                          float* save_h_t /* &save_h[t][ly][tile*64][0] or null */, int64_t rows_valid) {
-  const int arow = lane & 15, ag = lane >> 4;
+constexpr int NPL = 6;  // saved planes per (16-row m-tile, t, layer, wave): i, g, f, o, c, h -- 1 KiB each, MFMA C-fragment order
+
+// One quarter (accumulator register r) of the LSTM cell of one 16-row m-tile, lane-local on the MFMA
+// accumulators: acc[q][r] <-> row 4*ag + r of the m-tile, hidden col 16j + arow.
+template <bool SAVE, int R>
+__device__ __forceinline__ void cell_q(const f32x4 (&acc)[4], float (&cst)[4], bool first, float* out_row, f32x4 (&sv)[NPL]) {
+  const float ig = fast_sigmoid(acc[0][R]);
+  const float gg = fast_tanh(acc[1][R]);
+  const float fg = fast_sigmoid(acc[2][R]);
+  const float og = fast_sigmoid(acc[3][R]);
+  const float cp = first ? 0.f : cst[R];
+  const float cc = fg * cp + ig * gg;
+  const float hh = og * fast_tanh(cc);
+  cst[R] = cc;
+  out_row[R * LDA] = hh;
+  if (SAVE) { sv[0][R] = ig; sv[1][R] = gg; sv[2][R] = fg; sv[3][R] = og; sv[4][R] = cc; sv[5][R] = hh; }
+}
+
+// Half of a unit's 4-gate GEMM: 4 k-groups (S) of 16 MFMAs over one LDS tile (the recurrent h_{t-1} tile or
+// the step-input tile).  The A fragment of the NEXT group is always in flight (apre) while a group's MFMAs
+// issue; with CELL the LSTM cell of the PREVIOUS unit (pacc) is interleaved under the MFMAs, one accumulator
+// register per group, so the transcendental / VALU work hides in the MFMA shadow instead of following it.
+template <bool SAVE, bool CELL, bool PF>
+__device__ __forceinline__ void half_unit(const float* abase, const f32x4 (&w)[4][4], f32x4 (&acc)[4], f32x4& apre, const float* next_abase,
+                                          const f32x4 (&pacc)[4], float (&pc)[4], bool pfirst, float* pout_row, f32x4 (&sv)[NPL]) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    // one 16-row m-tile at a time: 4 independent accumulators (one per gate) cover the 40-cycle
-    // dependent-MFMA latency; keeping m-tiles apart keeps the live register set small.
-    f32x4 acc[4];
+  for (int S = 0; S < 4; ++S) {
+    const f32x4 a4 = apre;
+    if (S < 3) apre = *(const f32x4*)(abase + (S + 1) * 16);
+    else if (PF) apre = *(const f32x4*)(next_abase);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = f32x4{bias[q], bias[q], bias[q], bias[q]};
+    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-    for (int S = 0; S < 4; ++S) {
-      const f32x4 a4 = *(const f32x4*)(in_buf + (mt * 16 + arow) * LDA + S * 16 + ag * 4);
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], w[q][S][jj], acc[q], 0, 0, 0);
+    if (CELL) {
+      if (S == 0) cell_q<SAVE, 0>(pacc, pc, pfirst, pout_row, sv);
+      if (S == 1) cell_q<SAVE, 1>(pacc, pc, pfirst, pout_row, sv);
+      if (S == 2) cell_q<SAVE, 2>(pacc, pc, pfirst, pout_row, sv);
+      if (S == 3) cell_q<SAVE, 3>(pacc, pc, pfirst, pout_row, sv);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // the A-fragment prefetch first
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], wi[q][S][jj], acc[q], 0, 0, 0);
-    }
-    if (!first) {
-#pragma unroll
-      for (int S = 0; S < 4; ++S) {
-        const f32x4 a4 = *(const f32x4*)(hp_buf + (mt * 16 + arow) * LDA + S * 16 + ag * 4);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], wo[q][S][jj], acc[q], 0, 0, 0);
-      }
-    }
-    // ---- cell math, lane-local: acc[q][r] <-> row mt*16 + 4*ag + r, hidden col 16j + arow
-    f32x4 vi, vg, vf, vo, vc, vh;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float ig = fast_sigmoid(acc[0][r]);
-      const float gg = fast_tanh(acc[1][r]);
-      const float fg = fast_sigmoid(acc[2][r]);
-      const float og = fast_sigmoid(acc[3][r]);
-      const float cp = first ? 0.f : c[mt][r];
-      const float cc = fg * cp + ig * gg;
-      const float hh = og * fast_tanh(cc);
-      c[mt][r] = cc;
-      vi[r] = ig; vg[r] = gg; vf[r] = fg; vo[r] = og; vc[r] = cc; vh[r] = hh;
-      out_buf[(mt * 16 + ag * 4 + r) * LDA + j * 16 + arow] = hh;
-    }
-    if (SAVE) {
-      float* fb = save_frag_t + (int64_t)mt * frag_mt_stride + lane * 4;
-      *(f32x4*)(fb + 0 * 256) = vi;
-      *(f32x4*)(fb + 1 * 256) = vg;
-      *(f32x4*)(fb + 2 * 256) = vf;
-      *(f32x4*)(fb + 3 * 256) = vo;
-      *(f32x4*)(fb + 4 * 256) = vc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + ag * 4 + r;
-        if (row < rows_valid) save_h_t[(int64_t)row * DH + j * 16 + arow] = vh[r];
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);  // 2 VALU / transcendental of the cell
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+template <bool SAVE>
+__device__ __forceinline__ void cell_all(const f32x4 (&pacc)[4], float (&pc)[4], bool pfirst, float* pout_row, f32x4 (&sv)[NPL]) {
+  cell_q<SAVE, 0>(pacc, pc, pfirst, pout_row, sv);
+  cell_q<SAVE, 1>(pacc, pc, pfirst, pout_row, sv);
+  cell_q<SAVE, 2>(pacc, pc, pfirst, pout_row, sv);
+  cell_q<SAVE, 3>(pacc, pc, pfirst, pout_row, sv);
 }
 
 // nn.Linear(H, C) on the tile's h_T (LDS) -> S[n][0..C)
@@ -282,11 +274,101 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   lds_barrier();
   gather_load<NT>(a, blockIdx.x, 0, idbuf(0), gv);
   gather_store<NT>(xbuf(0), gv);
-  lds_barrier();
+
+  // The work of a slot (one step t of one tile) is a chain of units u = (layer l, 16-row m-tile mt).  Unit u:
+  //   [recurrent half: 64 MFMAs over h^l_{t-1}, with the CELL of unit u-1 interleaved]  (skipped at t == 0)
+  //   [mt == 0: LDS barrier -- the tile this unit's input half reads is complete]
+  //   [input half: 64 MFMAs over x_t / h^{l-1}_t]                                        (cell of u-1 here at t == 0)
+  // so the cell math (40 transcendentals per lane per m-tile) and the barrier skew sit under MFMAs of the
+  // next unit; accumulators ping-pong between two register sets.
+  f32x4 accs[2][4];
+  f32x4 apre = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 sv[NPL];
+  const int64_t frag_unit = (int64_t)NPL * 256;           // floats per (m-tile, t, layer, wave)
+  const int64_t frag_mt_stride = (int64_t)T * L * 4 * frag_unit;
+  const int a_off = arow * LDA + ag * 4;                   // this lane's A-fragment offset inside a 16-row block
+  const int o_off = (ag * 4) * LDA + j * 16 + arow;        // this lane's cell-output offset inside a 16-row block
+
+  auto save_unit = [&](int64_t p_tile, int p_t, int pl, int pm) {
+    if (!SAVE) return;
+    float* fb = a.save_frag + (p_tile * 4 + pm) * frag_mt_stride + ((int64_t)(p_t * L + pl) * 4 + j) * frag_unit + lane * 4;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) *(f32x4*)(fb + k * 256) = sv[k];
+  };
+  // training: the complete h tile of (tile, t, layer l) -> save_h[t][l][n][:] row-major, coalesced 16-byte stores
+  auto copy_h = [&](int64_t f_tile, int f_t, int l, const float* hb) {
+    if (!SAVE) return;
+    float* dst = a.save_h + (((int64_t)f_t * L + l) * a.N + f_tile * MT) * DH;
+    const int64_t rows_valid = a.N - f_tile * MT;
+#pragma unroll
+    for (int k = 0; k < 1024 / NT; ++k) {
+      const int cch = threadIdx.x + k * NT;
+      const int row = cch >> 4, ch = cch & 15;
+      if (row < rows_valid) *(f32x4*)(dst + row * DH + ch * 4) = *(const f32x4*)(hb + row * LDA + ch * 4);
+    }
+  };
+
+  auto slot = [&](auto first_tag, const int64_t tile, const int t, const int par, const bool has_prev, const int64_t p_tile, const int p_t,
+                  const bool p_first) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float* in_buf = (l == 0) ? xbuf(par) : hbuf(l - 1, par);
+      const float* hp_buf = hbuf(l, par ^ 1);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        // the unit whose cell is still outstanding
+        const int pl = (mt > 0) ? l : ((l > 0) ? l - 1 : L - 1);
+        const int pm = (mt > 0) ? mt - 1 : 3;
+        const bool cross = (l == 0 && mt == 0);             // it belongs to the previous slot
+        const int64_t q_tile = cross ? p_tile : tile;
+        const int q_t = cross ? p_t : t;
+        const int q_par = cross ? (par ^ 1) : par;
+        const bool q_first = cross ? p_first : FIRST;
+        float* pout = hbuf(pl, q_par) + pm * 16 * LDA + o_off;
+        f32x4(&acc)[4] = accs[mt & 1];
+        f32x4(&pacc)[4] = accs[(mt & 1) ^ 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{bias[l][q], bias[l][q], bias[l][q], bias[l][q]};
+        const float* in_base = in_buf + mt * 16 * LDA + a_off;
+        // first A fragment of the unit that follows this one (always a readable LDS address; unused when that
+        // unit starts behind a barrier)
+        const float* nxt;
+        if (mt < 3) nxt = (FIRST ? in_buf : hp_buf) + (mt + 1) * 16 * LDA + a_off;
+        else if (l + 1 < L) nxt = hbuf(l + 1, par ^ 1) + a_off;
+        else nxt = hbuf(0, par) + a_off;
+        if (!FIRST) {
+          half_unit<SAVE, true, true>(hp_buf + mt * 16 * LDA + a_off, wo[l], acc, apre, in_base, pacc, c[pl][pm], q_first, pout, sv);
+          save_unit(q_tile, q_t, pl, pm);
+          if (mt == 0) {
+            lds_barrier();
+            copy_h(q_tile, q_t, pl, hbuf(pl, q_par));
+            apre = *(const f32x4*)(in_base);
+          }
+          half_unit<SAVE, false, true>(in_base, wi[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
+        } else if (mt == 0) {
+          if (!cross || has_prev) {
+            cell_all<SAVE>(pacc, c[pl][pm], q_first, pout, sv);
+            save_unit(q_tile, q_t, pl, pm);
+          }
+          lds_barrier();
+          if (!cross || has_prev) copy_h(q_tile, q_t, pl, hbuf(pl, q_par));
+          if (cross && has_prev) head_tile(a, hbuf(L - 1, q_par), p_tile, j, lane);
+          apre = *(const f32x4*)(in_base);
+          half_unit<SAVE, false, true>(in_base, wi[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
+        } else {
+          half_unit<SAVE, true, true>(in_base, wi[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
+          save_unit(q_tile, q_t, pl, pm);
+        }
+      }
+    }
+  };
 
   int64_t tile = blockIdx.x;
   int t = 0;
   int tpar = 0;  // parity of the tile's id buffer
+  int64_t p_tile = tile;
+  int p_t = 0;
   for (int64_t s = 0; s < total_slots; ++s) {
     const int par = (int)(s & 1);
     // (1) issue the gather for the NEXT slot (latency hidden under this slot's MFMAs)
@@ -298,29 +380,23 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
     // the next tile's ids are staged while this tile's first step computes (visible after >= 1 barrier)
     if (t == 0 && tile + gridDim.x < a.n_tiles) ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
     if (have_next) gather_load<NT>(a, tile_n, tn, idbuf(tpar_n), gv);
-
-    // (2) the layers of this step, bottom-up; h tiles hand over through LDS
-    const int64_t rows_valid = a.N - tile * MT;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const float* in_buf = (l == 0) ? xbuf(par) : hbuf(l - 1, par);
-      const float* hp_buf = hbuf(l, par ^ 1);
-      float* out_buf = hbuf(l, par);
-      float* sf = nullptr; float* sh = nullptr; int64_t stride_mt = 0;
-      if (SAVE) {
-        stride_mt = (int64_t)T * L * 4 * 5 * 256;  // floats per global m-tile
-        sf = a.save_frag + (((tile * 4) * T + t) * L + l) * (4 * 5 * 256) + (int64_t)j * (5 * 256);
-        sh = a.save_h + (((int64_t)t * L + l) * a.N + tile * MT) * DH;
-      }
-      lstm_step<SAVE>(in_buf, hp_buf, out_buf, wi[l], wo[l], bias[l], c[l], t == 0, j, lane, sf, stride_mt, sh, rows_valid);
-      if (l + 1 < L) lds_barrier();  // h_l tile complete before layer l+1 reads it
-    }
-    // (3) land the gathered rows of the next slot (xbuf[par^1] was last read one slot ago)
+    // (2) the units of this slot
+    if (t == 0) slot(std::true_type{}, tile, t, par, s > 0, p_tile, p_t, p_t == 0);
+    else slot(std::false_type{}, tile, t, par, true, p_tile, p_t, p_t == 0);
+    // (3) land the gathered rows of the next slot (xbuf[par^1] was last read one slot ago); visible to the
+    //     other waves after the next slot's first barrier
     if (have_next) gather_store<NT>(xbuf(par ^ 1), gv);
-    lds_barrier();
-    // (4) nn.Linear head on the finished tile: reads hbuf(L-1, par); the next slot writes par^1
-    if (t == T - 1) head_tile(a, hbuf(L - 1, par), tile, j, lane);
+    p_tile = tile; p_t = t;
     t = tn; tile = tile_n; tpar = tpar_n;
+  }
+  // drain: the cell of the very last unit, then the last tile's head
+  {
+    const int par = (int)((total_slots - 1) & 1);
+    cell_all<SAVE>(accs[1], c[L - 1][3], p_t == 0, hbuf(L - 1, par) + 3 * 16 * LDA + o_off, sv);
+    save_unit(p_tile, p_t, L - 1, 3);
+    lds_barrier();
+    copy_h(p_tile, p_t, L - 1, hbuf(L - 1, par));
+    head_tile(a, hbuf(L - 1, par), p_tile, j, lane);
   }
 }
 
@@ -464,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     for (int nt = 0; nt < 4; ++nt) { dwi[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dwo[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
 
-  const int64_t frag_mt_stride = (int64_t)T * L * 4 * 5 * 256;
+  const int64_t frag_mt_stride = (int64_t)T * L * 4 * NPL * 256;
   // one-hot MFMA scatter: class of this wave's 16 columns (0 type, 1 entity, 2 relation) and the launch-
   // persistent accumulator of its small table: acc_s[r] <-> table row 4ag + r, column 16j + arow
   constexpr bool mscat = BOTTOM && MSCAT;  // compile-time: the two scatter forms never share a register allocation
@@ -503,8 +579,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       TPROBE(1)
 
       // ---- C. cell backward + dW, one m-tile at a time; saved gate fragments one m-tile ahead --------
-      const float* fr_base = a.save_frag + (((tile * 4) * T + t) * L + ly) * (4 * 5 * 256) + (int64_t)j * (5 * 256) + lane * 4;
-      const float* frp_base = REC ? a.save_frag + (((tile * 4) * T + (t - 1)) * L + ly) * (4 * 5 * 256) + (int64_t)j * (5 * 256) + lane * 4 : nullptr;
+      const float* fr_base = a.save_frag + (((tile * 4) * T + t) * L + ly) * (4 * NPL * 256) + (int64_t)j * (NPL * 256) + lane * 4;
+      const float* frp_base = REC ? a.save_frag + (((tile * 4) * T + (t - 1)) * L + ly) * (4 * NPL * 256) + (int64_t)j * (NPL * 256) + lane * 4 : nullptr;
       // dx of the layer above for this wave's rows / columns (C layout) rides along with the fragments
       // (DX rows past N are written as exact zeros by the layer above, so no tail handling here)
       const float* dxp = TOP ? nullptr : a.DX + ((int64_t)t * a.Npad + n0 + ag * 4) * DH + j * 16 + arow;
@@ -833,7 +909,7 @@ __global__ void k_transpose_256x64(const float* __restrict__ W, float* __restric
   WT[i] = W[k * 64 + n];
 }
 
-// ---- host side ----------------------------------------------------------------------------
+// ---- host side ----
 struct State {
   float* save_frag = nullptr;
   float* save_h = nullptr;
@@ -903,14 +979,14 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
       const int64_t cn = std::max<int64_t>(N, s->cap_N);
       const int ct = std::max(b->T, s->cap_T);
       const int64_t mts = (cn + 15) / 16 + 4;
-      HIP_TRY(hipMalloc((void**)&s->save_frag, (size_t)mts * ct * c.L * 4 * 5 * 256 * sizeof(float)));
+      HIP_TRY(hipMalloc((void**)&s->save_frag, (size_t)mts * ct * c.L * 4 * NPL * 256 * sizeof(float)));
       HIP_TRY(hipMalloc((void**)&s->save_h, (size_t)ct * c.L * (cn + 64) * DH * sizeof(float)));
       s->cap_N = cn; s->cap_T = ct;
     }
     a.save_frag = s->save_frag; a.save_h = s->save_h;
   }
   const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)s->num_cu);
-  ProfScope ps(h, "lstm_fused_fwd");
+  ProfScope ps(h, save ? "lstm_fused_fwd_train" : "lstm_fused_fwd");
   if (c.L == 1) { if (save) launch_fwd<1, true>(h, a, grid); else launch_fwd<1, false>(h, a, grid); }
   else { if (save) launch_fwd<2, true>(h, a, grid); else launch_fwd<2, false>(h, a, grid); }
 }

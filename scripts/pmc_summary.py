@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-kernel averages of the rocprofv3 PMC passes written by scripts/gpu_pmc.sh.
+
+Units / gfx950 corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
+FETCH_SIZE and WRITE_SIZE are reported in KiB-like units of the TCC_EA request counters; on gfx950
+FETCH_SIZE tallies 128-B requests at 64 B, so wide coalesced reads are DOUBLED here
+("fetch_bytes_corrected"); WRITE_SIZE is uncalibrated and reported as-is (x1024).
+"""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def load(path):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    if not os.path.exists(path):
+        return acc
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            k = row.get("Kernel_Name", "?")
+            c = row.get("Counter_Name", "?")
+            v = float(row.get("Counter_Value", "0") or 0)
+            a = acc[k][c]
+            a[0] += v
+            a[1] += 1
+    return acc
+
+
+def short(name):
+    for key in ("k_lstm_fwd<2, true>", "k_lstm_fwd<2, false>", "k_lstm_bwd<true, false", "k_lstm_bwd<false, true",
+                "k_lstm_fwd<1, true>", "k_lstm_fwd<1, false>"):
+        if key in name:
+            return key.replace(" ", "") + (">" if not key.endswith(">") else "")
+    n = name.split("(")[0]
+    return n.split("::")[-1]
+
+
+def main(d):
+    out = {}
+    for fname in ("fetch", "write", "sq"):
+        acc = load(os.path.join(d, fname + ".csv"))
+        for k, cs in acc.items():
+            o = out.setdefault(short(k), {})
+            for c, (s, n) in cs.items():
+                o[c + "_avg"] = s / max(n, 1)
+                o["dispatches"] = n
+    for k, o in out.items():
+        if "FETCH_SIZE_avg" in o:
+            o["fetch_bytes_raw"] = o["FETCH_SIZE_avg"] * 1024.0
+            o["fetch_bytes_corrected"] = o["FETCH_SIZE_avg"] * 1024.0 * 2.0
+        if "WRITE_SIZE_avg" in o:
+            o["write_bytes_raw"] = o["WRITE_SIZE_avg"] * 1024.0
+        if "SQ_VALU_MFMA_BUSY_CYCLES_avg" in o and o.get("SQ_BUSY_CU_CYCLES_avg"):
+            o["mfma_busy_over_cu_busy"] = o["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / o["SQ_BUSY_CU_CYCLES_avg"]
+    keep = {k: v for k, v in out.items() if "lstm" in k or "unique" in k or "adam" in k}
+    print(json.dumps(keep, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
