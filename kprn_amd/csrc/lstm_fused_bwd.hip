@@ -1,0 +1,570 @@
+// Fused BPTT kernels of the KPRN path scorer for gfx950 (forward: lstm_fused_fwd.hip; design: DESIGN.md).
+#include "lstm_fused_common.h"
+
+namespace fused {
+
+// ============================================================================================
+// Fused backward (BPTT) -- one launch per layer, top layer first.
+//
+// Stands in for the backward of nn.Sequencer(nn.FastLSTM) x L + FeatureEmbedding
+// (model/OneModel.lua:223-274 via MyOptimizer.lua:195 model:backward): exact BPTT over all T
+// steps, weight gradients accumulated over steps, LookupTable scatter-add for layer 1.
+//
+// Same tile / wave ownership as the forward: 64-path tiles, wave j owns hidden units [16j,16j+16) of all four
+// gates, MFMA C layout (lane (ag, arow), register r <-> row 4 ag + r, col 16 j + arow).  Per tile, t = T-1 .. 0:
+//   C. per 16-row m-tile: cell backward = 7 VALU ops per element on the factors the forward saved (NPL in
+//      lstm_fused_common.h) -> dA (pre-activation grads) in C layout.  Those registers ARE the A operand of
+//      dW += dA^T [in | h_prev] (k-slot = ag <-> row 4 ag + r); the B operands are the saved h fragments of
+//      the four waves (plane 6: already in B-operand layout, loaded 1 KiB per instruction) or, bottom layer,
+//      the re-gathered x_t tile in LDS.  dW (128 registers) lives in AGPRs for the whole launch.  dA also goes
+//      row-major to an LDS tile.
+//   E. [dx | dh_{t-1}] = dA [W_i2g | W_o2g]: A from the LDS dA tile (ds_read_b128, next fragment always in
+//      flight), B = this wave's 128-register slice of the transposed weights, AGPR-stationary.  dh_{t-1} comes
+//      out in exactly the layout stage C of step t-1 wants, so it never leaves registers; dx goes to HBM in
+//      fragment order for the layer below (1 KiB stores, and the layer below reloads it the same way), or --
+//      bottom layer -- is scattered to the embedding gradients straight from the accumulators.
+// fp32 MFMA and VALU share the SIMD's FP32 lanes on gfx950 (scripts/ubench/mfma_rate.hip: their times add, also
+// across waves), so the VALU work above is the part of the step the matrix pipe cannot hide; it is kept minimal.
+struct BwdArgs {
+  const int32_t* idx; int64_t N; int T, F, nT;
+  const float *Wt, *We, *Wr; int dt, de, dr; int Vt, Vr;
+  int L, layer;
+  const float* WiT;        // [64][256]  = W_i2g^T of this layer
+  const float* WoT;        // [64][256]
+  const float* save_frag;  // forward's fragment-order saves: [(N/16)][T][L][4 waves][NPL][64 lanes][4]
+  const float* dHhead;     // [N][64] (top layer) or null
+  float* DX;               // [(Npad/16)][T][4 waves][64 lanes][4] fragment order: in = dx of the layer above (not top), out = dx of this layer (not bottom)
+  int64_t Npad;            // N rounded up to the 64-row tile
+  float* gWi; float* gbi; float* gWo;   // [256][64], [256], [256][64]
+  float* gWt; float* gWe; float* gWr;   // bottom layer only
+  float* part;             // [grid][2*256*64 + 256] per-workgroup partial dW_i2g | dW_o2g | db
+  unsigned long long* timing;  // optional [grid][8] cycle counters (KPRN_TIMING=1)
+  int dbg;                 // KPRN_DBG bit 0: skip the embedding scatter (measurement only)
+  const int32_t* lead;     // [Npad][T] tile leaders (bottom layer)
+  int mfma_scatter;        // 1: one-hot MFMA scatter (dims multiples of 16, one type slot, tables <= 16 rows)
+  int64_t n_tiles;
+};
+
+constexpr int PART = 2 * 256 * 64 + 256;  // floats per workgroup partial slab
+constexpr int LDD = 4 * DH + 4;  // dA tile row stride
+
+#define TPROBE(slot)                                                                 \
+  if (a.timing) {                                                                     \
+    const unsigned long long now__ = __builtin_amdgcn_s_memtime();                    \
+    tacc[slot] += now__ - tlast;                                                      \
+    tlast = now__;                                                                    \
+  }
+
+// what stage C needs for one 16-row m-tile, requested one m-tile ahead
+struct Pre {
+  f32x4 P[6];    // this wave's backward factors
+  f32x4 up;      // dx of the layer above (not top)
+  f32x4 bin[4];  // B operands of dW_i2g: [in][row 4 ag + r][16 nt + arow] for nt = 0..3
+  f32x4 bhp[4];  // B operands of dW_o2g: h^l_{t-1}, same layout
+};
+
+template <bool BOTTOM, bool TOP, bool MSCAT>
+__global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = a.timing ? __builtin_amdgcn_s_memtime() : 0ull;
+  constexpr bool mscat = BOTTOM && MSCAT;  // compile-time: the two scatter forms never share a register allocation
+  float* dA_t = lds;                                        // [64][LDD]
+  float* in_t = dA_t + MT * LDD;                            // bottom: [64][LDA] x_t
+  int32_t* ids = (int32_t*)(in_t + (BOTTOM ? MT * LDA : 0));  // bottom: [64][T][4] the tile's ids, 0-based (slot 3: tile leader)
+  int32_t* lead = ids + (BOTTOM ? MT * MAXT_LDS * 4 : 0);     // bottom, general scatter: [64] leader row of each row's entity id
+  float* dxt = (float*)(lead + (BOTTOM ? MT : 0));            // bottom, general scatter: [64][LDA] dx tile
+  float* small_g = dxt + ((BOTTOM && !mscat) ? MT * LDA : 0); // bottom, general scatter: [Vt*dt + Vr*dr] partial sums (if they fit)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int arow = lane & 15, ag = lane >> 4;
+  const int T = a.T, L = a.L, ly = a.layer;
+  const int n_small = BOTTOM ? (a.Vt * a.dt + a.Vr * a.dr) : 0;
+  const bool small_in_lds = BOTTOM && !mscat && n_small <= 4096;
+  if (small_in_lds) for (int i = tid; i < n_small; i += 256) small_g[i] = 0.f;
+
+  // ---- AGPR residents: this wave's slice of [W_i2g^T | W_o2g^T] (stage E's B operand) and the dW accumulators
+  //      dwi/dwo[q][nt][r] <-> dW row q*64 + 16j + 4ag + r, col 16nt + arow
+  f32x4 wiT[16], woT[16];
+  {
+    const float* wi_row = a.WiT + (int64_t)(j * 16 + arow) * (4 * DH) + ag * 4;
+    const float* wo_row = a.WoT + (int64_t)(j * 16 + arow) * (4 * DH) + ag * 4;
+#pragma unroll
+    for (int S = 0; S < 16; ++S) { wiT[S] = *(const f32x4*)(wi_row + S * 16); woT[S] = *(const f32x4*)(wo_row + S * 16); }
+#pragma unroll
+    for (int S = 0; S < 16; ++S) { asm volatile("" : "+a"(wiT[S])); asm volatile("" : "+a"(woT[S])); }
+  }
+  f32x4 dwi[4][4], dwo[4][4];
+  float dbias[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    dbias[q] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      dwi[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dwo[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "+a"(dwi[q][nt])); asm volatile("" : "+a"(dwo[q][nt]));
+    }
+  }
+
+  const int64_t frag_unit = (int64_t)NPL * 256;                // floats per (m-tile, t, layer, wave)
+  const int64_t frag_mt_stride = (int64_t)T * L * 4 * frag_unit;  // floats per m-tile
+  // one-hot MFMA scatter: class of this wave's 16 columns (0 type, 1 entity, 2 relation) and the launch-
+  // persistent accumulator of its small table: acc_s[r] <-> table row 4ag + r, column 16j + arow
+  const int wcls = (j * 16 < a.dt) ? 0 : ((j * 16 < a.dt + a.de) ? 1 : 2);
+  f32x4 acc_s = f32x4{0.f, 0.f, 0.f, 0.f}, acc_s2 = f32x4{0.f, 0.f, 0.f, 0.f};  // two chains: an asm MFMA never reads the result of the MFMA right before it
+  GatherSrc gsrc;
+  if (BOTTOM) gsrc = gather_src(a);
+  TPROBE(0)
+
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * MT;
+    const float* frag_tile = a.save_frag + tile * 4 * frag_mt_stride + lane * 4;
+    auto frag_ptr = [&](int mt, int t, int l, int w, int plane) -> const float* {
+      return frag_tile + mt * frag_mt_stride + ((int64_t)(t * L + l) * 4 + w) * frag_unit + plane * 256;
+    };
+    f32x4 dc[4], dh[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      dc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dh[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (TOP) {  // recurrent dh starts at the head gradient
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = n0 + m * 16 + ag * 4 + r;
+          if (n < a.N) dh[m][r] = a.dHhead[n * DH + j * 16 + arow];
+        }
+      }
+    }
+    if (BOTTOM) {
+      lds_barrier();  // previous tile's id tile / x tile fully consumed
+      ids_stage<256>(a.idx, a.N, T, a.F, a.nT, tile, ids);
+      if (mscat) lead_stage(a.lead, T, tile, ids);
+      lds_barrier();
+      f32x4 nin[4];
+      gather_load<256>(a, gsrc, tile, T - 1, ids, nin);
+      gather_store<256>(in_t, nin);
+      lds_barrier();
+    }
+    TPROBE(1)  // tile prologue
+
+    // Stage C operands, single-buffered: each register set is re-requested for the NEXT m-tile as soon as its
+    // last consumer has issued (the factors after the VALU block, each B fragment after its 32 MFMAs), so the
+    // loads have ~3k cycles of MFMA issue to land in.
+    f32x4 P[6], up, bin[4], bhp[4];
+    auto load_P = [&](int mt, int t) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) P[k] = *(const f32x4*)frag_ptr(mt, t, ly, j, k);
+      if (!TOP) up = *(const f32x4*)(a.DX + (((tile * 4 + mt) * T + t) * 4 + j) * 256 + lane * 4);
+    };
+    auto load_B = [&](int nt, int mt, int t, bool has_hp) {
+      if (!BOTTOM) bin[nt] = *(const f32x4*)frag_ptr(mt, t, ly - 1, nt, 6);
+      if (has_hp) bhp[nt] = *(const f32x4*)frag_ptr(mt, t - 1, ly, nt, 6);
+    };
+    // bottom layer: the dW_i2g B operands come from the x_t tile in LDS
+    auto load_bin_lds = [&](int nt, int mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bin[nt][r] = in_t[(mt * 16 + ag * 4 + r) * LDA + nt * 16 + arow];
+    };
+    load_P(0, T - 1);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) load_B(nt, 0, T - 1, T > 1);
+
+    // the step body is compiled twice (REC: t > 0, there is an h_{t-1} / c_{t-1}): no MFMA sits under a run-time condition
+    auto step = [&](auto rec_tag, const int t) {
+      constexpr bool REC = decltype(rec_tag)::value;
+      // ---- C. cell backward + dW, one m-tile at a time ------------------------------------------------
+      if (BOTTOM) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) load_bin_lds(nt, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        // cell backward on the saved factors (elementwise on float4: register r <-> row 4 ag + r)
+        f32x4 dhv = dh[mt];
+        if (!TOP) dhv += up;
+        const f32x4 dC = dc[mt] + dhv * P[4];
+        f32x4 dA[4];
+        dA[0] = dC * P[0];
+        dA[1] = dC * P[1];
+        dA[2] = dC * P[2];
+        dA[3] = dhv * P[3];
+        dc[mt] = dC * P[5];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dA_t[(mt * 16 + ag * 4 + r) * LDD + q * DH + j * 16 + arow] = dA[q][r];
+          dbias[q] += (dA[q][0] + dA[q][1]) + (dA[q][2] + dA[q][3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the factors are dead: request the next m-tile's (first m-tile of step t-1 after the last one)
+        if (mt < 3) load_P(mt + 1, t);
+        else if (REC) load_P(0, t - 1);
+        // dW += dA^T [in | h_prev]: MFMA (nt, r, q) uses k-slot ag <-> row mt*16 + 4ag + r
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              KPRN_MFMA_ACC_A(dwi[q][nt], dA[q][r], bin[nt][r]);
+              if (REC) KPRN_MFMA_ACC_A(dwo[q][nt], dA[q][r], bhp[nt][r]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          if (mt < 3) { load_B(nt, mt + 1, t, REC); if (BOTTOM) load_bin_lds(nt, mt + 1); }
+          else if (REC) load_B(nt, 0, t - 1, t > 1);
+        }
+      }
+      TPROBE(2)  // stage C (cell backward + dW MFMAs)
+      lds_barrier();
+      TPROBE(3)  // mid barrier wait
+      // bottom layer: x_{t-1} is requested here (latency hides under stage E) and lands after it
+      f32x4 nin[4];
+      if (BOTTOM && REC) gather_load<256>(a, gsrc, tile, t - 1, ids, nin);
+
+      // ---- E. [dx | dh_prev] = dA * [W_i2g | W_o2g]; this wave: columns 16j..16j+15 of each ----------
+      f32x4 ax[4], ah[4];
+      {
+        const float* abase = dA_t + arow * LDD + ag * 4;
+        if (REC) {
+          // groups (S, mt): one A fragment feeds 8 MFMAs (4 k-slots x {dx, dh}); the next fragment is requested mid-group
+          f32x4 apre = *(const f32x4*)(abase);
+#pragma unroll
+          for (int S = 0; S < 16; ++S) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+              const f32x4 a4 = apre;
+              const int gn = S * 4 + mt + 1;  // next group
+              if (S == 0) { KPRN_MFMA_Z(ax[mt], a4[0], wiT[S][0]); KPRN_MFMA_Z(ah[mt], a4[0], woT[S][0]); }
+              else { KPRN_MFMA(ax[mt], a4[0], wiT[S][0]); KPRN_MFMA(ah[mt], a4[0], woT[S][0]); }
+              KPRN_MFMA(ax[mt], a4[1], wiT[S][1]); KPRN_MFMA(ah[mt], a4[1], woT[S][1]);
+              if (gn < 64) apre = *(const f32x4*)(abase + (gn & 3) * 16 * LDD + (gn >> 2) * 16);
+              KPRN_MFMA(ax[mt], a4[2], wiT[S][2]); KPRN_MFMA(ah[mt], a4[2], woT[S][2]);
+              KPRN_MFMA(ax[mt], a4[3], wiT[S][3]); KPRN_MFMA(ah[mt], a4[3], woT[S][3]);
+            }
+          }
+        } else {
+          // t = 0: no dh; two m-tiles share a group so that consecutive MFMAs never chain on one accumulator
+          f32x4 ap0 = *(const f32x4*)(abase), ap1 = *(const f32x4*)(abase + 16 * LDD);
+#pragma unroll
+          for (int S = 0; S < 16; ++S) {
+#pragma unroll
+            for (int mp = 0; mp < 2; ++mp) {
+              const f32x4 a0 = ap0, a1 = ap1;
+              const int gn = S * 2 + mp + 1;
+              if (S == 0) { KPRN_MFMA_Z(ax[2 * mp], a0[0], wiT[S][0]); KPRN_MFMA_Z(ax[2 * mp + 1], a1[0], wiT[S][0]); }
+              else { KPRN_MFMA(ax[2 * mp], a0[0], wiT[S][0]); KPRN_MFMA(ax[2 * mp + 1], a1[0], wiT[S][0]); }
+              KPRN_MFMA(ax[2 * mp], a0[1], wiT[S][1]); KPRN_MFMA(ax[2 * mp + 1], a1[1], wiT[S][1]);
+              if (gn < 32) {
+                ap0 = *(const f32x4*)(abase + ((gn & 1) * 2) * 16 * LDD + (gn >> 1) * 16);
+                ap1 = *(const f32x4*)(abase + ((gn & 1) * 2 + 1) * 16 * LDD + (gn >> 1) * 16);
+              }
+              KPRN_MFMA(ax[2 * mp], a0[2], wiT[S][2]); KPRN_MFMA(ax[2 * mp + 1], a1[2], wiT[S][2]);
+              KPRN_MFMA(ax[2 * mp], a0[3], wiT[S][3]); KPRN_MFMA(ax[2 * mp + 1], a1[3], wiT[S][3]);
+            }
+          }
+        }
+      }
+      KPRN_MFMA_DRAIN();  // ax / ah are read by VALU, stores and (as B operand) the scatter MFMAs below
+      if (BOTTOM && REC) gather_store<256>(in_t, nin);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        if (REC) dh[mt] = ah[mt];  // already in the layout stage C of step t-1 reads
+        if (!BOTTOM) *(f32x4*)(a.DX + (((tile * 4 + mt) * T + t) * 4 + j) * 256 + lane * 4) = ax[mt];  // rows past N: exact zeros (dA = 0 there)
+      }
+      const int col = j * 16 + arow;
+      if constexpr (mscat) if (!(a.dbg & 1)) {
+        // nn.LookupTable backward as a matrix product: grad_table[v][:] += sum_rows onehot(id[row] == v) dx[row][:].
+        // The dx accumulators ax[mt][r] already sit in the MFMA B layout (k-slot ag <-> row mt*16+4ag+r),
+        // the one-hot A operand is built from the LDS id tile; exact (products by 1.0 / 0.0).
+        if (wcls != 1) {
+          const int which = (wcls == 0) ? 0 : 2;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int32_t* id = ids + ((mt * 16 + ag * 4 + r) * T + t) * 4;
+              // branch-free on purpose (both ids are read unconditionally): a short-circuit here became a divergent
+              // branch whose EXEC restore sat right in front of the asm MFMA
+              const int iv = id[which], il = id[3];
+              const float oh = (((int)(iv == arow)) & ((int)(il >= 0))) ? 1.f : 0.f;
+              if (r & 1) KPRN_MFMA_VV(acc_s2, oh, ax[mt][r]); else KPRN_MFMA_VV(acc_s, oh, ax[mt][r]);
+            }
+          // acc_s lives across the rest of the launch: if hipcc parks it (spill store / register copy) right behind
+          // the last MFMA it would read a result that has not landed -- seen as intermittently wrong type /
+          // relation gradients.  Nothing may touch it for the MFMA latency.
+          KPRN_MFMA_DRAIN();
+        } else {
+          // entity rows: fold the tile's duplicate ids onto their leader row (every pad step hits ONE row,
+          // a pair's user / item repeat across its paths), then one L2 atomic per distinct id
+          f32x4 comb[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ld = ids[((mt * 16 + ag * 4 + r) * T + t) * 4 + 3];
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {  // four independent accumulation chains (one per 16-leader block)
+                const float oh = (ld == m * 16 + arow) ? 1.f : 0.f;
+                if (mt == 0 && r == 0) KPRN_MFMA_VVZ(comb[m], oh, ax[mt][r]);
+                else KPRN_MFMA_VV(comb[m], oh, ax[mt][r]);
+              }
+            }
+          KPRN_MFMA_DRAIN();
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = m * 16 + ag * 4 + r;
+              const int32_t* id = ids + (row * T + t) * 4;
+              if (id[3] == row) unsafeAtomicAdd(a.gWe + (int64_t)id[1] * a.de + (col - a.dt), comb[m][r]);
+            }
+        }
+      }
+      if constexpr (BOTTOM && !mscat) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dxt[(mt * 16 + ag * 4 + r) * LDA + col] = ax[mt][r];
+      }
+      TPROBE(4)  // stage E (dX MFMAs) + outputs
+      if constexpr (BOTTOM && !mscat) if (!(a.dbg & 1)) {
+        // nn.LookupTable backward = scatter-add with duplicates accumulating (FeatureEmbedding.lua:29,41-49,86).
+        // Pad steps all hit ONE entity row and a pair's user / item repeat across its paths, so rows
+        // with the same entity id are first summed inside the tile (LDS); one L2 atomic row per distinct id.
+        {
+          // leader = first row of the tile with the same entity id; 4 threads per row, 16 candidates each
+          const int row = tid >> 2, part = tid & 3;
+          const int e = ids[(row * T + t) * 4 + 1];
+          int cand[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) cand[u] = ids[((part * 16 + u) * T + t) * 4 + 1];
+          int ld = row;
+#pragma unroll
+          for (int u = 15; u >= 0; --u) {
+            const int r2 = part * 16 + u;
+            ld = (r2 < row && cand[u] == e) ? r2 : ld;
+          }
+          ld = min(ld, __shfl_xor(ld, 1, 64));
+          ld = min(ld, __shfl_xor(ld, 2, 64));
+          if (part == 0) lead[row] = (n0 + row < a.N) ? ld : -1;
+        }
+        lds_barrier();
+        const int e0 = a.dt, e1 = a.dt + a.de;
+        const int colx = tid & 63, rg = tid >> 6;  // this thread: one column, rows rg, rg+4, ...
+        const bool is_ent = colx >= e0 && colx < e1;
+        int ldk[16];
+        for (int k = 0; k < 16; ++k) {
+          const int row = rg + 4 * k;
+          const int ld = lead[row];
+          ldk[k] = ld;
+          if (ld < 0) continue;
+          const float v = dxt[row * LDA + colx];
+          const int32_t* id = ids + (row * T + t) * 4;
+          if (colx < e0) {
+            const int32_t* f = a.idx + ((n0 + row) * T + t) * a.F;
+            for (int kk = 0; kk < a.nT; ++kk) {
+              const int rr = (kk == 0) ? id[0] : f[a.F - a.nT - 2 + kk] - 1;
+              if (small_in_lds) lds_atomic_add(&small_g[rr * a.dt + colx], v);
+              else unsafeAtomicAdd(a.gWt + (int64_t)rr * a.dt + colx, v);
+            }
+          } else if (colx < e1) {
+            if (ld != row) lds_atomic_add(&dxt[ld * LDA + colx], v);
+          } else {
+            if (small_in_lds) lds_atomic_add(&small_g[a.Vt * a.dt + id[2] * a.dr + (colx - e1)], v);
+            else unsafeAtomicAdd(a.gWr + (int64_t)id[2] * a.dr + (colx - e1), v);
+          }
+        }
+        lds_barrier();
+        // leaders add their (combined) entity slice to the gradient table (fire-and-forget atomics)
+        if (is_ent) {
+          for (int k = 0; k < 16; ++k) {
+            const int row = rg + 4 * k;
+            if (ldk[k] == row) unsafeAtomicAdd(a.gWe + (int64_t)ids[(row * T + t) * 4 + 1] * a.de + (colx - e0), dxt[row * LDA + colx]);
+          }
+        }
+      }
+      lds_barrier();  // dA_t / dxt / lead free for reuse, x_{t-1} tile visible
+      TPROBE(5)  // scatter + end barrier
+    };
+    for (int t = T - 1; t > 0; --t) step(std::true_type{}, t);
+    step(std::false_type{}, 0);
+  }
+
+  // ---- flush the launch-persistent accumulators: plain coalesced stores into this workgroup's slab;
+  // k_reduce_partials sums the slabs (device-scope atomics from 256 workgroups onto the same 128 KB
+  // were measured slower: they execute at the memory side, the per-XCD L2s are not coherent)
+  KPRN_MFMA_DRAIN();
+  {
+    float* pw = a.part + (int64_t)blockIdx.x * PART;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t grow = (int64_t)q * DH + j * 16 + ag * 4 + r;
+          pw[grow * DH + nt * 16 + arow] = dwi[q][nt][r];
+          pw[256 * 64 + grow * DH + nt * 16 + arow] = dwo[q][nt][r];
+        }
+      }
+      float v = dbias[q];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (ag == 0) pw[2 * 256 * 64 + q * DH + j * 16 + arow] = v;
+    }
+  }
+  if constexpr (mscat) if (wcls != 1) {
+    acc_s += acc_s2;
+    // acc_s[r] <-> table row 4ag + r, column 16j + arow of the type (wcls 0) / relation (wcls 2) gradient
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int v = ag * 4 + r;
+      const int col = j * 16 + arow;
+      if (wcls == 0) { if (v < a.Vt) unsafeAtomicAdd(a.gWt + (int64_t)v * a.dt + col, acc_s[r]); }
+      else { if (v < a.Vr) unsafeAtomicAdd(a.gWr + (int64_t)v * a.dr + (col - a.dt - a.de), acc_s[r]); }
+    }
+  }
+  if constexpr (!mscat) if (small_in_lds) {
+    lds_barrier();
+    const int nt_small = a.Vt * a.dt;
+    for (int i = tid; i < n_small; i += 256) {
+      const float v = small_g[i];
+      if (v != 0.f) { if (i < nt_small) unsafeAtomicAdd(a.gWt + i, v); else unsafeAtomicAdd(a.gWr + (i - nt_small), v); }
+    }
+  }
+  TPROBE(6)  // flush
+  if (a.timing && tid == 0) {
+    for (int k = 0; k < 8; ++k) a.timing[(int64_t)blockIdx.x * 8 + k] = tacc[k];
+  }
+}
+
+// gW_i2g / gW_o2g / gb += sum over workgroup slabs
+__global__ void k_reduce_partials(const float* __restrict__ part, int nslab, float* __restrict__ gWi, float* __restrict__ gWo, float* __restrict__ gbi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PART) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = blockIdx.y * 4; s < nslab; s += gridDim.y * 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (s + u < nslab) acc[u] += part[(int64_t)(s + u) * PART + i];
+  }
+  const float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  if (i < 256 * 64) unsafeAtomicAdd(gWi + i, v);
+  else if (i < 2 * 256 * 64) unsafeAtomicAdd(gWo + (i - 256 * 64), v);
+  else unsafeAtomicAdd(gbi + (i - 2 * 256 * 64), v);
+}
+
+// WT[n][k] = W[k][n] for a [256][64] weight
+__global__ void k_transpose_256x64(const float* __restrict__ W, float* __restrict__ WT) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 64*256 outputs
+  if (i >= 64 * 256) return;
+  const int n = i >> 8, k = i & 255;
+  WT[i] = W[k * 64 + n];
+}
+
+// ---- host side ----
+bool bwd_supported(const kprn_handle* h, int T) { return fwd_supported(h, T); }
+
+template <bool BOTTOM, bool TOP, bool MSCAT>
+static void launch_bwd(kprn_handle* h, const BwdArgs& a, int grid) {
+  const int n_small = BOTTOM ? (a.Vt * a.dt + a.Vr * a.dr) : 0;
+  size_t lds_bytes = (size_t)MT * LDD * sizeof(float);
+  if (BOTTOM) lds_bytes += (size_t)MT * LDA * sizeof(float) + (MT * MAXT_LDS * 4 + MT) * sizeof(int32_t);
+  if (BOTTOM && !MSCAT) lds_bytes += (size_t)MT * LDA * sizeof(float) + (size_t)(n_small <= 4096 ? n_small : 0) * sizeof(float);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP, MSCAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP, MSCAT>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
+  HIP_TRY(hipGetLastError());
+}
+
+// needs: forward(save=true) of the same batch just ran; ws.dS holds d loss / d S[:, cid]
+void backward(kprn_handle* h, const kprn_batch* b, int cid) {
+  const kprn_config& c = h->cfg;
+  State* s = st(h);
+  const int64_t N = (int64_t)b->B * b->P;
+  const int T = b->T, L = c.L;
+  hipStream_t strm = h->stream;
+  if (N > s->cap_Nb || T > s->cap_Tb) {
+    HIP_TRY(hipStreamSynchronize(strm));
+    if (s->dHhead) hipFree(s->dHhead);
+    if (s->DX) hipFree(s->DX);
+    const int64_t cn = std::max<int64_t>(N, s->cap_Nb);
+    const int ct = std::max(T, s->cap_Tb);
+    HIP_TRY(hipMalloc((void**)&s->dHhead, (size_t)(cn + 64) * DH * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&s->DX, (size_t)ct * (cn + 2 * MT) * DH * sizeof(float)));
+    s->cap_Nb = cn; s->cap_Tb = ct;
+  }
+  if (!s->WT) HIP_TRY(hipMalloc((void**)&s->WT, (size_t)2 * 2 * 64 * 256 * sizeof(float)));
+  if (!s->part) HIP_TRY(hipMalloc((void**)&s->part, (size_t)s->num_cu * PART * sizeof(float)));
+  static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
+  if (want_timing && !s->timing) HIP_TRY(hipMalloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
+  if (s->wt_dirty) {
+    ProfScope ps(h, "weight_transpose");
+    for (int l = 0; l < L; ++l) {
+      hipLaunchKernelGGL(k_transpose_256x64, dim3(64), dim3(256), 0, strm, h->dense + h->layer[l].Wi, s->WT + (size_t)(l * 2 + 0) * 64 * 256);
+      hipLaunchKernelGGL(k_transpose_256x64, dim3(64), dim3(256), 0, strm, h->dense + h->layer[l].Wo, s->WT + (size_t)(l * 2 + 1) * 64 * 256);
+    }
+    HIP_TRY(hipGetLastError());
+    s->wt_dirty = false;
+  }
+  float* gd = h->g_dense;
+  {
+    ProfScope ps(h, "head_bwd");
+    const float* hT = s->save_h;  // h_T of the top layer, [N][64]
+    kk::head_bwd(strm, h->ws.dS, hT, h->dense + h->off_outW, N, DH, cid, s->dHhead, gd + h->off_outW, gd + h->off_outb);
+  }
+  const int64_t n_tiles = (N + MT - 1) / MT;
+  const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)s->num_cu);
+  for (int l = L - 1; l >= 0; --l) {
+    BwdArgs a;
+    a.idx = b->idx; a.N = N; a.T = T; a.F = b->F; a.nT = c.num_types;
+    a.Wt = h->dense + h->off_Wt; a.We = h->We; a.Wr = h->dense + h->off_Wr;
+    a.dt = c.dt; a.de = c.de; a.dr = c.dr; a.Vt = c.Vt; a.Vr = c.Vr;
+    a.L = L; a.layer = l;
+    a.WiT = s->WT + (size_t)(l * 2 + 0) * 64 * 256; a.WoT = s->WT + (size_t)(l * 2 + 1) * 64 * 256;
+    a.save_frag = s->save_frag; a.dHhead = s->dHhead; a.DX = s->DX; a.Npad = n_tiles * MT;
+    a.gWi = gd + h->layer[l].Wi; a.gbi = gd + h->layer[l].bi; a.gWo = gd + h->layer[l].Wo;
+    a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
+    a.n_tiles = n_tiles;
+    a.part = s->part; a.timing = s->timing;
+    { static const char* d = getenv("KPRN_DBG"); a.dbg = d ? atoi(d) : 0; }
+    a.lead = b->lead;
+    a.mfma_scatter = (b->lead && c.num_types == 1 && (c.dt % 16) == 0 && (c.de % 16) == 0 && (c.dr % 16) == 0 && c.Vt <= 16 && c.Vr <= 16 &&
+                      !(a.dbg & 8)) ? 1 : 0;
+    const bool bottom = (l == 0), top = (l == L - 1);
+    {
+      ProfScope ps(h, "lstm_fused_bwd");
+      if (bottom && top) { if (a.mfma_scatter) launch_bwd<true, true, true>(h, a, grid); else launch_bwd<true, true, false>(h, a, grid); }
+      else if (bottom) { if (a.mfma_scatter) launch_bwd<true, false, true>(h, a, grid); else launch_bwd<true, false, false>(h, a, grid); }
+      else if (top) launch_bwd<false, true, false>(h, a, grid);
+      else launch_bwd<false, false, false>(h, a, grid);
+    }
+    {
+      ProfScope ps(h, "dw_reduce");
+      hipLaunchKernelGGL(k_reduce_partials, dim3((PART + 255) / 256, 16), dim3(256), 0, strm, s->part, grid, a.gWi, a.gWo, a.gbi);
+      HIP_TRY(hipGetLastError());
+    }
+    if (s->timing) {
+      HIP_TRY(hipStreamSynchronize(strm));
+      std::vector<unsigned long long> tb((size_t)grid * 8);
+      HIP_TRY(hipMemcpy(tb.data(), s->timing, tb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      double sum[8] = {0};
+      for (int g = 0; g < grid; ++g) for (int k = 0; k < 8; ++k) sum[k] += (double)tb[(size_t)g * 8 + k];
+      fprintf(stderr, "[kprn timing] bwd layer %d N=%lld grid=%d avg cycles/WG: prologue %.0f tile-prologue %.0f stageC %.0f midbar %.0f stageE %.0f scatter+bar %.0f flush %.0f\n",
+              l, (long long)N, grid, sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid);
+    }
+  }
+}
+
+void params_changed(kprn_handle* h) { if (h->fused_state) ((State*)h->fused_state)->wt_dirty = true; }
+
+void release(kprn_handle* h) {
+  State* s = (State*)h->fused_state;
+  if (!s) return;
+  for (float* p : {s->save_frag, s->save_h, s->WT, s->dHhead, s->DX, s->part}) if (p) hipFree(p);
+  if (s->timing) hipFree(s->timing);
+  delete s;
+  h->fused_state = nullptr;
+}
+
+}  // namespace fused

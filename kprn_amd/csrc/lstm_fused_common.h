@@ -1,0 +1,191 @@
+// Shared device helpers + host-side state of the fused LSTM path kernels (gfx950, D = H = 64, L <= 2).
+// Forward: lstm_fused_fwd.hip, backward: lstm_fused_bwd.hip.
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "kprn_internal.h"
+
+namespace fused {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DH = 64;        // D == H == 64 in this variant
+constexpr int MT = 64;        // paths per tile
+constexpr int LDA = DH + 4;   // LDS row stride (floats): 16-byte aligned, spreads ds_read_b128 slots
+
+struct FwdArgs {
+  const int32_t* idx;  // [N][T][F] 1-based
+  int64_t N;
+  int T, F, nT;
+  const float *Wt, *We, *Wr;
+  int dt, de, dr;
+  const float* Wi[2];
+  const float* bi[2];
+  const float* Wo[2];
+  const float* Wout;
+  const float* bout;
+  int C;
+  float* S;          // [N][C]
+  float* save_frag;  // training: [(N/16)][T][L][4 waves][NPL][64 lanes][4]   (nullable)
+  float* save_h;     // training: h_T of the top layer, [N][H] row-major (head backward)   (nullable)
+  int64_t n_tiles;
+  unsigned long long* timing;  // optional [grid][8] cycle counters (KPRN_TIMING=1)
+};
+
+// v_exp_f32 + v_rcp_f32 (1 ulp each): ~1e-7 absolute error on the gate values, far inside the 1e-4 score bar
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for
+// every global store / atomic / prefetch load in flight (the activation saves of the training forward,
+// the embedding-gradient atomics, the next step's gather) -- none of which the other waves depend on.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// float add on an LDS address as ds_add_f32.  (atomicAdd() through a generic pointer was emitted as
+// flat_atomic_add_f32, the slow aperture path.)
+__device__ __forceinline__ void lds_atomic_add(float* p, float v) {
+  typedef __attribute__((address_space(3))) float lds_float;
+  __hip_atomic_fetch_add((lds_float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+constexpr int MAXT_LDS = 16;  // steps whose ids are staged in LDS per tile
+
+// all the tile's ids -> LDS: ids[(row*T + t)*4 + {0: first type, 1: entity, 2: relation}] (0-based).
+// Rows past N repeat row N-1 (their results are never stored).  Removes the dependent id -> row load
+// chain from every step's gather.
+template <int NTHREADS>
+__device__ __forceinline__ void ids_stage(const int32_t* idx, int64_t N, int T, int F, int nT, int64_t tile, int32_t* ids) {
+  for (int c = threadIdx.x; c < MT * T; c += NTHREADS) {
+    const int row = c / T, t = c - row * T;
+    int64_t n = tile * MT + row;
+    if (n >= N) n = N - 1;
+    const int32_t* f = idx + (n * T + t) * F;
+    ids[c * 4 + 0] = f[F - nT - 2] - 1;
+    ids[c * 4 + 1] = f[F - 2] - 1;
+    ids[c * 4 + 2] = f[F - 1] - 1;
+  }
+}
+
+// slot 3 of the id tile <- precomputed tile leader (fused backward, bottom layer)
+__device__ __forceinline__ void lead_stage(const int32_t* lead, int T, int64_t tile, int32_t* ids) {
+  for (int c = threadIdx.x; c < MT * T; c += 256) ids[c * 4 + 3] = lead[tile * MT * T + c];
+}
+
+// Per-thread source of the x-row gather.  A thread always serves the same 16-byte chunk column (ch = tid & 15)
+// of rows (tid >> 4) + 16k, so the table it reads from is fixed for the whole launch: no branches per load.
+struct GatherSrc {
+  const float* base;  // table + chunk offset inside the row
+  int width;          // table row stride (floats)
+  int slot;           // which id of the LDS id tile: 0 type, 1 entity, 2 relation
+};
+template <class Args>
+__device__ __forceinline__ GatherSrc gather_src(const Args& a) {
+  const int ch = threadIdx.x & 15;
+  const int c_t = a.dt >> 2, c_e = (a.dt + a.de) >> 2;
+  GatherSrc g;
+  if (ch < c_t) { g.base = a.Wt + ch * 4; g.width = a.dt; g.slot = 0; }
+  else if (ch < c_e) { g.base = a.We + (ch - c_t) * 4; g.width = a.de; g.slot = 1; }
+  else { g.base = a.Wr + (ch - c_e) * 4; g.width = a.dr; g.slot = 2; }
+  return g;
+}
+
+// gather this thread's share of one step's x rows for `tile` into registers (ids from the LDS id tile)
+template <int NTHREADS, class Args>
+__device__ __forceinline__ void gather_load(const Args& a, const GatherSrc& g, int64_t tile, int t, const int32_t* ids, f32x4 (&v)[1024 / NTHREADS]) {
+  constexpr int PER = 1024 / NTHREADS;  // 64 rows x 16 float4 chunks
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int row = (threadIdx.x >> 4) + k * (NTHREADS >> 4);
+    const int id = ids[(row * a.T + t) * 4 + g.slot];
+    v[k] = *(const f32x4*)(g.base + (int64_t)id * g.width);
+  }
+  if (a.nT > 1 && g.slot == 0) {  // several type slots per step: CAddTable over them (FeatureEmbedding.lua:55)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int row = (threadIdx.x >> 4) + k * (NTHREADS >> 4);
+      int64_t n = tile * MT + row;
+      if (n >= a.N) n = a.N - 1;
+      const int32_t* f = a.idx + (n * a.T + t) * a.F;
+      for (int q = 1; q < a.nT; ++q) v[k] += *(const f32x4*)(g.base + (int64_t)(f[a.F - a.nT - 2 + q] - 1) * g.width);
+    }
+  }
+}
+
+template <int NTHREADS>
+__device__ __forceinline__ void gather_store(float* xbuf, const f32x4 (&v)[1024 / NTHREADS]) {
+  constexpr int PER = 1024 / NTHREADS;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int c = threadIdx.x + k * NTHREADS;
+    const int row = c >> 4, ch = c & 15;
+    *(f32x4*)(xbuf + row * LDA + ch * 4) = v[k];
+  }
+}
+
+// Training saves, per (16-row m-tile, t, layer, wave): NPL planes of 1 KiB in MFMA C-fragment order (lane-major
+// float4: lane (ag, arow), register r <-> row 4 ag + r, hidden col 16 wave + arow).  The forward stores the
+// factors the backward multiplies by, not the raw gates, so the cell backward is 7 VALU ops per element:
+//   P1 = g i (1-i)   P2 = i (1-g^2)   P3 = c_{t-1} f (1-f)   P4 = tanh(c) o (1-o)   P5 = o (1-tanh(c)^2)   P6 = f
+//   dC = dc + dh P5;  dA_i = dC P1;  dA_g = dC P2;  dA_f = dC P3;  dA_o = dh P4;  dc' = dC P6
+// plane 6 = h: the B operand of dW = dA^T [x | h] in exactly the register layout the MFMA wants.
+constexpr int NPL = 7;
+
+// ---- MFMA issue, hand-placed ---------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 as inline asm with the register FILES chosen here.  Values that only ever feed the
+// matrix pipe (register-stationary weights as B operand, the launch-persistent dW accumulators) live in the
+// accumulation half of the unified register file ("a"); everything the VALU touches lives in architectural
+// VGPRs ("v").  Left to hipcc, such values were parked in AGPRs but staged through v_accvgpr_read/write around
+// most MFMAs; a staging copy that feeds the very next MFMA costs +16 cycles per 32-cycle MFMA
+// (scripts/ubench/mfma_rate.hip: 48.0 vs 32.07 ticks/MFMA).
+// The asm MFMAs are opaque to hipcc's hazard recogniser: every place where an MFMA RESULT is consumed by a
+// non-MFMA instruction (or as an A/B operand) less than ~20 issue slots later carries an explicit KPRN_MFMA_DRAIN.
+#define KPRN_MFMA(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "a"(B_))
+// first MFMA of an accumulation chain, srcC = another register (bias vector)
+#define KPRN_MFMA_C(ACC, A_, B_, C_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=&v"(ACC) : "v"(A_), "a"(B_), "v"(C_))
+// first MFMA of an accumulation chain, srcC = 0
+#define KPRN_MFMA_Z(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A_), "a"(B_))
+// accumulator in AGPRs, both operands in VGPRs (dW += dA^T [x | h])
+#define KPRN_MFMA_ACC_A(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(A_), "v"(B_))
+// everything in VGPRs; the A operand is a VALU result of the instruction right before (one-hot scatter): a VALU
+// write needs 2 wait states before an MFMA may read it, which hipcc inserts for its own MFMAs only
+#define KPRN_MFMA_VV(ACC, A_, B_) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "v"(B_))
+#define KPRN_MFMA_VVZ(ACC, A_, B_) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A_), "v"(B_))
+#define KPRN_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+
+// ---- host-side state shared by forward() and backward() ----
+struct State {
+  float* save_frag = nullptr;
+  float* save_h = nullptr;
+  int64_t cap_N = 0;
+  int cap_T = 0;
+  int num_cu = 0;
+  float* WT = nullptr;      // [L][2][64][256]
+  bool wt_dirty = true;
+  float* dHhead = nullptr;  // [N][64]
+  float* DX = nullptr;      // [T][N][64]
+  float* part = nullptr;    // [num_cu][PART]
+  unsigned long long* timing = nullptr;  // [num_cu][8] when KPRN_TIMING=1
+  int64_t cap_Nb = 0; int cap_Tb = 0;
+};
+
+static inline State* st(kprn_handle* h) {
+  if (!h->fused_state) {
+    State* s = new State();
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, h->cfg.device_id) == hipSuccess) s->num_cu = p.multiProcessorCount;
+    if (s->num_cu <= 0) s->num_cu = 256;
+    h->fused_state = s;
+  }
+  return (State*)h->fused_state;
+}
+
+bool fwd_supported(const kprn_handle* h, int T);
+bool bwd_supported(const kprn_handle* h, int T);
+
+}  // namespace fused

@@ -1,0 +1,445 @@
+// Fused persistent LSTM path kernels for gfx950 (D = H = 64, L <= 2: BASELINE config C2-A).
+//
+// Replaces, in one launch, the reference's
+//   nn.SplitTable(3) -> FeatureEmbedding (3 LookupTables + CAddTable + JoinTable)    net/FeatureEmbedding.lua:112-121
+//   -> nn.SplitTable(2) -> nn.Sequencer(nn.FastLSTM(D,H)) x L -> nn.SelectTable(-1)   model/OneModel.lua:223,236,268-274
+//   -> nn.Linear(H,46)                                                                model/OneModel.lua:275
+//
+// Design (MI355X-first, see DESIGN.md "fused forward"):
+//  * persistent workgroups, one per CU, each walks 64-path tiles; no [N,T,D] embedding tensor,
+//    no per-step activation tensors in HBM (scoring); x_t rows are gathered straight from the
+//    three tables into LDS one step ahead of use (loads issued before the MFMA block, LDS
+//    write after it).
+//  * 4 waves per workgroup; wave j owns hidden units [16j,16j+16) for ALL four
+//    gates, so the LSTM cell math is lane-local on the MFMA accumulators (C/D layout
+//    col = lane&15, row = 4*(lane>>4)+reg) and c_t never leaves registers.
+//  * the 4-gate GEMM runs on v_mfma_f32_16x16x4_f32 (exact fp32).  Each wave keeps ITS slice of
+//    [W_i2g | W_o2g] (4 gates x 16 cols x K=128 = 128 VGPRs) register-stationary for the whole
+//    launch: weights are read from HBM/L2 once per CU, not once per step.
+//  * one wave per SIMD (the 512-entry unified VGPR/AGPR file is what makes the weights fit): the
+//    layers of a step run back-to-back in the same waves, handing h_l over through LDS with one
+//    s_barrier per layer per step.  (A 2-waves-per-SIMD layer-pipelined variant needs 128 weight
+//    registers + accumulators inside 256 and spilled ~100-180 VGPRs: measured, rejected.)
+//  * k-order trick: one ds_read_b128 of A[row][16S+4g..+3] feeds 4 consecutive MFMAs (slot g of
+//    MFMA jj <-> k = 16S+4g+jj); the matching B fragment is one 16-byte load of the ROW-MAJOR
+//    weight row, so no packed weight copy is needed.
+#include "lstm_fused_common.h"
+
+namespace fused {
+
+// ---- MFMA issue, hand-placed ---------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 as inline asm with the register FILES chosen here: the B operand (a register-
+// stationary weight) is read straight from the accumulation half of the unified register file ("a"), the
+// accumulators live in architectural VGPRs ("v") where the cell math can touch them.  Left to hipcc, the 256
+// weight registers of the 2-layer kernel were parked in AGPRs but staged through v_accvgpr_read in front of
+// most MFMAs; a staging copy that feeds the very next MFMA costs +16 cycles per 32-cycle MFMA
+// (scripts/ubench/mfma_rate.hip: 48.0 vs 32.07 ticks/MFMA), which is where the old kernel's 30 % went.
+constexpr float NLOG2E = -1.4426950408889634f;   // sigmoid(x) = rcp(1 + exp2(-x log2 e))
+constexpr float N2LOG2E = -2.8853900817779268f;  // tanh(x) = 2 rcp(1 + exp2(-2x log2 e)) - 1
+
+// The LSTM cell of ONE accumulator register (r) of the previous unit, cut into 16 small steps; step K is issued
+// behind MFMA K of a 16-MFMA group.  With one wave per SIMD nothing else hides the cell: a VALU op issues in
+// the shadow of the running MFMA only if it does not wait on the op right before it, so each step holds at
+// most one transcendental (16 cycles) and never consumes a value produced in the same step.
+struct CellRegs { float m0, m1, m2, m3, e0, e1, e2, e3, i, g, f, o, ig, c, cp, t; };
+template <bool SAVE, int R, int K>
+__device__ __forceinline__ void cell_step(CellRegs& x, const f32x4 (&acc)[4], float (&cst)[4], bool first, float* out_row, f32x4 (&sv)[NPL]) {
+  // accumulators are read gate 0 first: the MFMAs that wrote gates 2, 3 last are the most recent ones
+  if (K == 0) { x.m0 = acc[0][R] * NLOG2E; x.m1 = acc[1][R] * N2LOG2E; }
+  if (K == 1) { x.e0 = __builtin_amdgcn_exp2f(x.m0); x.m2 = acc[2][R] * NLOG2E; }
+  if (K == 2) { x.e1 = __builtin_amdgcn_exp2f(x.m1); x.m3 = acc[3][R] * NLOG2E; }
+  if (K == 3) { x.e2 = __builtin_amdgcn_exp2f(x.m2); x.e0 += 1.0f; }
+  if (K == 4) { x.e3 = __builtin_amdgcn_exp2f(x.m3); x.e1 += 1.0f; }
+  if (K == 5) { x.i = __builtin_amdgcn_rcpf(x.e0); x.e2 += 1.0f; }
+  if (K == 6) { x.g = __builtin_amdgcn_rcpf(x.e1); x.e3 += 1.0f; }
+  if (K == 7) { x.f = __builtin_amdgcn_rcpf(x.e2); x.g = 2.0f * x.g - 1.0f; x.cp = first ? 0.f : cst[R]; }
+  if (K == 8) { x.o = __builtin_amdgcn_rcpf(x.e3); x.ig = x.i * x.g; }
+  if (K == 9) { x.c = x.f * x.cp + x.ig; }
+  if (K == 10) { x.t = x.c * N2LOG2E; cst[R] = x.c; }
+  if (K == 11) { x.t = __builtin_amdgcn_exp2f(x.t); }
+  if (K == 12) { x.t += 1.0f; }
+  if (K == 13) { x.t = __builtin_amdgcn_rcpf(x.t); }
+  if (K == 14) { x.t = 2.0f * x.t - 1.0f; }
+  if (K == 15) {
+    const float hh = x.o * x.t;
+    out_row[R * LDA] = hh;
+    if (SAVE) {  // backward-ready factors (lstm_fused_common.h, NPL)
+      sv[0][R] = x.ig * (1.0f - x.i);
+      sv[1][R] = x.i * (1.0f - x.g * x.g);
+      sv[2][R] = x.cp * x.f * (1.0f - x.f);
+      sv[3][R] = hh * (1.0f - x.o);
+      sv[4][R] = x.o * (1.0f - x.t * x.t);
+      sv[5][R] = x.f;
+      sv[6][R] = hh;
+    }
+  }
+}
+
+template <bool SAVE, int R>
+__device__ __forceinline__ void cell_q(const f32x4 (&acc)[4], float (&cst)[4], bool first, float* out_row, f32x4 (&sv)[NPL]) {
+  CellRegs x;
+  cell_step<SAVE, R, 0>(x, acc, cst, first, out_row, sv);  cell_step<SAVE, R, 1>(x, acc, cst, first, out_row, sv);
+  cell_step<SAVE, R, 2>(x, acc, cst, first, out_row, sv);  cell_step<SAVE, R, 3>(x, acc, cst, first, out_row, sv);
+  cell_step<SAVE, R, 4>(x, acc, cst, first, out_row, sv);  cell_step<SAVE, R, 5>(x, acc, cst, first, out_row, sv);
+  cell_step<SAVE, R, 6>(x, acc, cst, first, out_row, sv);  cell_step<SAVE, R, 7>(x, acc, cst, first, out_row, sv);
+  cell_step<SAVE, R, 8>(x, acc, cst, first, out_row, sv);  cell_step<SAVE, R, 9>(x, acc, cst, first, out_row, sv);
+  cell_step<SAVE, R, 10>(x, acc, cst, first, out_row, sv); cell_step<SAVE, R, 11>(x, acc, cst, first, out_row, sv);
+  cell_step<SAVE, R, 12>(x, acc, cst, first, out_row, sv); cell_step<SAVE, R, 13>(x, acc, cst, first, out_row, sv);
+  cell_step<SAVE, R, 14>(x, acc, cst, first, out_row, sv); cell_step<SAVE, R, 15>(x, acc, cst, first, out_row, sv);
+}
+
+// One k-group: 16 MFMAs (k-slots jj x gates q) on the A fragment a4 and the weights w[q][S].  BIAS: these are
+// the first MFMAs of the unit's accumulation chains (srcC = bias).  The A fragment of the NEXT group is
+// requested half way through (a read placed first would wait for the previous group's last MFMA to pick up
+// the register it overwrites).  CELL: one cell_step of the previous unit behind every MFMA; the order is
+// pinned with sched_barrier (the asm MFMAs carry no latency the scheduler could reason about).
+template <bool SAVE, bool CELL, bool BIAS, bool PF, int S>
+__device__ __forceinline__ void k_group(const f32x4 a4, f32x4& apre, const float* next_addr, const f32x4 (&w)[4][4], const f32x4 (&bias4)[4],
+                                        f32x4 (&acc)[4], CellRegs& x, const f32x4 (&pacc)[4], float (&pc)[4], bool pfirst, float* pout_row,
+                                        f32x4 (&sv)[NPL]) {
+#define KPRN_G1(K)                                                                                  \
+  {                                                                                                 \
+    constexpr int jj = (K) >> 2, q = (K) & 3;                                                       \
+    if (BIAS && jj == 0) KPRN_MFMA_C(acc[q], a4[jj], w[q][S][jj], bias4[q]);                        \
+    else KPRN_MFMA(acc[q], a4[jj], w[q][S][jj]);                                                    \
+    if (PF && (K) == 7) apre = *(const f32x4*)(next_addr);                                          \
+    if (CELL) { cell_step<SAVE, S, (K)>(x, pacc, pc, pfirst, pout_row, sv); __builtin_amdgcn_sched_barrier(0); } \
+  }
+  KPRN_G1(0) KPRN_G1(1) KPRN_G1(2) KPRN_G1(3) KPRN_G1(4) KPRN_G1(5) KPRN_G1(6) KPRN_G1(7)
+  KPRN_G1(8) KPRN_G1(9) KPRN_G1(10) KPRN_G1(11) KPRN_G1(12) KPRN_G1(13) KPRN_G1(14) KPRN_G1(15)
+#undef KPRN_G1
+}
+
+// Half of a unit's 4-gate GEMM: 4 k-groups over one LDS tile (the recurrent h_{t-1} tile or the step-input
+// tile).  apre always holds the A fragment of the group about to run.
+template <bool SAVE, bool CELL, bool BIAS, bool PF>
+__device__ __forceinline__ void half_unit(const float* abase, const f32x4 (&w)[4][4], const f32x4 (&bias4)[4], f32x4 (&acc)[4], f32x4& apre,
+                                          const float* next_abase, const f32x4 (&pacc)[4], float (&pc)[4], bool pfirst, float* pout_row,
+                                          f32x4 (&sv)[NPL]) {
+  CellRegs x;
+  f32x4 a4 = apre;
+  k_group<SAVE, CELL, BIAS, true, 0>(a4, apre, abase + 16, w, bias4, acc, x, pacc, pc, pfirst, pout_row, sv);
+  a4 = apre;
+  k_group<SAVE, CELL, false, true, 1>(a4, apre, abase + 32, w, bias4, acc, x, pacc, pc, pfirst, pout_row, sv);
+  a4 = apre;
+  k_group<SAVE, CELL, false, true, 2>(a4, apre, abase + 48, w, bias4, acc, x, pacc, pc, pfirst, pout_row, sv);
+  a4 = apre;
+  k_group<SAVE, CELL, false, PF, 3>(a4, apre, next_abase, w, bias4, acc, x, pacc, pc, pfirst, pout_row, sv);
+}
+
+template <bool SAVE>
+__device__ __forceinline__ void cell_all(const f32x4 (&pacc)[4], float (&pc)[4], bool pfirst, float* pout_row, f32x4 (&sv)[NPL]) {
+  cell_q<SAVE, 0>(pacc, pc, pfirst, pout_row, sv);
+  cell_q<SAVE, 1>(pacc, pc, pfirst, pout_row, sv);
+  cell_q<SAVE, 2>(pacc, pc, pfirst, pout_row, sv);
+  cell_q<SAVE, 3>(pacc, pc, pfirst, pout_row, sv);
+}
+
+// nn.Linear(H, C) on the tile's h_T (LDS) -> S[n][0..C)
+__device__ __forceinline__ void head_tile(const FwdArgs& a, const float* hbuf, int64_t tile, int j, int lane) {
+  const int ntiles = (a.C + 15) >> 4;
+  const int arow = lane & 15, ag = lane >> 4;
+  for (int nt = j; nt < ntiles; nt += 4) {
+    const int col = nt * 16 + arow;
+    const bool cv = col < a.C;
+    const float b = cv ? a.bout[col] : 0.f;
+    f32x4 w4[4];
+#pragma unroll
+    for (int S = 0; S < 4; ++S) w4[S] = cv ? *(const f32x4*)(a.Wout + (int64_t)col * DH + S * 16 + ag * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 acc = f32x4{b, b, b, b};
+#pragma unroll
+      for (int S = 0; S < 4; ++S) {
+        const f32x4 a4 = *(const f32x4*)(hbuf + (mt * 16 + arow) * LDA + S * 16 + ag * 4);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], w4[S][jj], acc, 0, 0, 0);
+      }
+      if (cv) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = tile * MT + mt * 16 + ag * 4 + r;
+          if (n < a.N) a.S[n * a.C + col] = acc[r];
+        }
+      }
+    }
+  }
+}
+
+template <int L, bool SAVE>
+__global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
+  constexpr int NT = 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // LDS carve (floats): x double buffer | h(layer l) double buffer, l = 0..L-1
+  auto xbuf = [&](int i) -> float* { return lds + i * (MT * LDA); };
+  auto hbuf = [&](int g, int i) -> float* { return lds + (2 + 2 * g + i) * (MT * LDA); };
+  // id tiles (double-buffered by tile parity): [64][T][4] ints each
+  auto idbuf = [&](int i) -> int32_t* { return (int32_t*)(lds + (2 + 2 * L) * (MT * LDA)) + i * (MT * MAXT_LDS * 4); };
+
+  const int lane = threadIdx.x & 63;
+  const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // hidden tile owned by this wave
+  const int arow = lane & 15, ag = lane >> 4;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = a.timing ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long tstart = tlast;
+#define FPROBE(slot_)                                              \
+  if (a.timing) {                                                  \
+    const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+    tacc[slot_] += now__ - tlast;                                  \
+    tlast = now__;                                                 \
+  }
+
+  // ---- register-stationary weights of EVERY layer: rows (q*H + 16j + arow), 16-byte pieces at k = 16S + 4ag
+  f32x4 wi[L][4][4], wo[L][4][4];
+  f32x4 bias4[L][4];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t row = (int64_t)q * DH + j * 16 + arow;
+      const float bv = a.bi[l][row];
+      bias4[l][q] = f32x4{bv, bv, bv, bv};
+#pragma unroll
+      for (int S = 0; S < 4; ++S) {
+        wi[l][q][S] = *(const f32x4*)(a.Wi[l] + row * DH + S * 16 + ag * 4);
+        wo[l][q][S] = *(const f32x4*)(a.Wo[l] + row * DH + S * 16 + ag * 4);
+      }
+    }
+  }
+  // B-operand-only values: pin them to the accumulation half of the unified register file so that the 256
+  // architectural VGPRs stay free for everything the VALU touches (all loads are issued before the first pin:
+  // a pin waits for its load)
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int S = 0; S < 4; ++S) {
+        asm volatile("" : "+a"(wi[l][q][S]));
+        asm volatile("" : "+a"(wo[l][q][S]));
+      }
+  float c[L][4][4];
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[l][m][r] = 0.f;
+
+  const int T = a.T;
+  const int64_t my_tiles = (a.n_tiles > blockIdx.x) ? (a.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t total_slots = my_tiles * T;
+  if (my_tiles == 0) return;
+
+  f32x4 gv[1024 / NT];
+  const GatherSrc gsrc = gather_src(a);
+  ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, blockIdx.x, idbuf(0));
+  lds_barrier();
+  gather_load<NT>(a, gsrc, blockIdx.x, 0, idbuf(0), gv);
+  gather_store<NT>(xbuf(0), gv);
+
+  // The work of a slot (one step t of one tile) is a chain of units u = (layer l, 16-row m-tile mt).  Unit u:
+  //   [recurrent half: 64 MFMAs over h^l_{t-1}, with the CELL of unit u-1 interleaved]  (skipped at t == 0)
+  //   [mt == 0: LDS barrier -- the tile this unit's input half reads is complete]
+  //   [input half: 64 MFMAs over x_t / h^{l-1}_t]                                        (cell of u-1 here at t == 0)
+  // so the cell math (40 transcendentals per lane per m-tile) and the barrier skew sit under MFMAs of the
+  // next unit; accumulators ping-pong between two register sets.
+  f32x4 accs[2][4];
+  f32x4 apre = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 sv[NPL];
+  const int64_t frag_unit = (int64_t)NPL * 256;           // floats per (m-tile, t, layer, wave)
+  const int64_t frag_mt_stride = (int64_t)T * L * 4 * frag_unit;
+  const int a_off = arow * LDA + ag * 4;                   // this lane's A-fragment offset inside a 16-row block
+  const int o_off = (ag * 4) * LDA + j * 16 + arow;        // this lane's cell-output offset inside a 16-row block
+
+  auto save_unit = [&](int64_t p_tile, int p_t, int pl, int pm) {
+    if (!SAVE) return;
+    float* fb = a.save_frag + (p_tile * 4 + pm) * frag_mt_stride + ((int64_t)(p_t * L + pl) * 4 + j) * frag_unit + lane * 4;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) *(f32x4*)(fb + k * 256) = sv[k];
+  };
+  // training: h_T rows of the top layer -> save_h[n][:] row-major (head backward), coalesced 16-byte stores
+  auto copy_h = [&](int64_t f_tile, int f_t, int l, const float* hb) {
+    if (!SAVE) return;
+    if (l != L - 1 || f_t != T - 1) return;
+    float* dst = a.save_h + f_tile * MT * DH;
+    const int64_t rows_valid = a.N - f_tile * MT;
+#pragma unroll
+    for (int k = 0; k < 1024 / NT; ++k) {
+      const int cch = threadIdx.x + k * NT;
+      const int row = cch >> 4, ch = cch & 15;
+      if (row < rows_valid) *(f32x4*)(dst + row * DH + ch * 4) = *(const f32x4*)(hb + row * LDA + ch * 4);
+    }
+  };
+
+  auto slot = [&](auto first_tag, const int64_t tile, const int t, const int par, const bool has_prev, const int64_t p_tile, const int p_t,
+                  const bool p_first) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float* in_buf = (l == 0) ? xbuf(par) : hbuf(l - 1, par);
+      const float* hp_buf = hbuf(l, par ^ 1);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        // the unit whose cell is still outstanding
+        const int pl = (mt > 0) ? l : ((l > 0) ? l - 1 : L - 1);
+        const int pm = (mt > 0) ? mt - 1 : 3;
+        const bool cross = (l == 0 && mt == 0);             // it belongs to the previous slot
+        const int64_t q_tile = cross ? p_tile : tile;
+        const int q_t = cross ? p_t : t;
+        const int q_par = cross ? (par ^ 1) : par;
+        const bool q_first = cross ? p_first : FIRST;
+        float* pout = hbuf(pl, q_par) + pm * 16 * LDA + o_off;
+        f32x4(&acc)[4] = accs[mt & 1];
+        f32x4(&pacc)[4] = accs[(mt & 1) ^ 1];
+        const float* in_base = in_buf + mt * 16 * LDA + a_off;
+        // first A fragment of the unit that follows this one (always a readable LDS address; unused when that
+        // unit starts behind a barrier)
+        const float* nxt;
+        if (mt < 3) nxt = (FIRST ? in_buf : hp_buf) + (mt + 1) * 16 * LDA + a_off;
+        else if (l + 1 < L) nxt = hbuf(l + 1, par ^ 1) + a_off;
+        else nxt = hbuf(0, par) + a_off;
+        if (!FIRST) {
+          half_unit<SAVE, true, true, true>(hp_buf + mt * 16 * LDA + a_off, wo[l], bias4[l], acc, apre, in_base, pacc, c[pl][pm], q_first, pout, sv);
+          save_unit(q_tile, q_t, pl, pm);
+          if (mt == 0) {
+            lds_barrier();
+            copy_h(q_tile, q_t, pl, hbuf(pl, q_par));
+            apre = *(const f32x4*)(in_base);
+          }
+          half_unit<SAVE, false, false, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
+        } else if (mt == 0) {
+          if (!cross || has_prev) {
+            KPRN_MFMA_DRAIN();  // last MFMAs of the previous unit -> VALU reads
+            cell_all<SAVE>(pacc, c[pl][pm], q_first, pout, sv);
+            save_unit(q_tile, q_t, pl, pm);
+          }
+          lds_barrier();
+          if (!cross || has_prev) copy_h(q_tile, q_t, pl, hbuf(pl, q_par));
+          if (cross && has_prev) head_tile(a, hbuf(L - 1, q_par), p_tile, j, lane);
+          apre = *(const f32x4*)(in_base);
+          half_unit<SAVE, false, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
+        } else {
+          half_unit<SAVE, true, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
+          save_unit(q_tile, q_t, pl, pm);
+        }
+      }
+    }
+  };
+
+  FPROBE(0)  // prologue: weights, first ids, first gather
+  int64_t tile = blockIdx.x;
+  int t = 0;
+  int tpar = 0;  // parity of the tile's id buffer
+  int64_t p_tile = tile;
+  int p_t = 0;
+  for (int64_t s = 0; s < total_slots; ++s) {
+    const int par = (int)(s & 1);
+    // (1) issue the gather for the NEXT slot (latency hidden under this slot's MFMAs)
+    int tn = t + 1;
+    int64_t tile_n = tile;
+    int tpar_n = tpar;
+    if (tn == T) { tn = 0; tile_n += gridDim.x; tpar_n ^= 1; }
+    const bool have_next = (s + 1) < total_slots;
+    // the next tile's ids are staged while this tile's first step computes (visible after >= 1 barrier)
+    if (t == 0 && tile + gridDim.x < a.n_tiles) ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
+    if (have_next) gather_load<NT>(a, gsrc, tile_n, tn, idbuf(tpar_n), gv);
+    FPROBE(1)  // id staging + gather issue
+    // (2) the units of this slot
+    if (t == 0) { slot(std::true_type{}, tile, t, par, s > 0, p_tile, p_t, p_t == 0); FPROBE(2) }
+    else { slot(std::false_type{}, tile, t, par, true, p_tile, p_t, p_t == 0); FPROBE(3) }
+    // (3) land the gathered rows of the next slot (xbuf[par^1] was last read one slot ago); visible to the
+    //     other waves after the next slot's first barrier
+    // the last unit's accumulators stay pending across the loop back-edge: keep hipcc from touching them (phi
+    // copies, spills) before the MFMAs that wrote them have landed
+    KPRN_MFMA_DRAIN();
+    if (have_next) gather_store<NT>(xbuf(par ^ 1), gv);
+    FPROBE(4)  // landing the gathered rows (waits for the loads -- and, when saving, for the stores in flight)
+    p_tile = tile; p_t = t;
+    t = tn; tile = tile_n; tpar = tpar_n;
+  }
+  // drain: the cell of the very last unit, then the last tile's head
+  {
+    const int par = (int)((total_slots - 1) & 1);
+    KPRN_MFMA_DRAIN();
+    cell_all<SAVE>(accs[1], c[L - 1][3], p_t == 0, hbuf(L - 1, par) + 3 * 16 * LDA + o_off, sv);
+    save_unit(p_tile, p_t, L - 1, 3);
+    lds_barrier();
+    copy_h(p_tile, p_t, L - 1, hbuf(L - 1, par));
+    head_tile(a, hbuf(L - 1, par), p_tile, j, lane);
+  }
+  FPROBE(5)  // drain
+  if (a.timing && threadIdx.x == 0) {
+    tacc[7] = __builtin_amdgcn_s_memtime() - tstart;
+    for (int k = 0; k < 8; ++k) a.timing[(int64_t)blockIdx.x * 8 + k] = tacc[k];
+  }
+#undef FPROBE
+}
+
+// ---- host side ----
+bool fwd_supported(const kprn_handle* h, int T) {
+  const kprn_config& c = h->cfg;
+  return (h->D == DH && c.H == DH && c.L >= 1 && c.L <= 2 && (c.dt % 4) == 0 && (c.de % 4) == 0 && (c.dr % 4) == 0 && T >= 2 && T <= MAXT_LDS);
+}
+
+template <int L, bool SAVE>
+static void launch_fwd(kprn_handle* h, const FwdArgs& a, int grid) {
+  const size_t lds_bytes = (size_t)(2 + 2 * L) * MT * LDA * sizeof(float) + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t);
+  static bool attr_done = false;  // one per template instantiation
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd<L, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_lstm_fwd<L, SAVE>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
+  HIP_TRY(hipGetLastError());
+}
+
+void forward(kprn_handle* h, const kprn_batch* b, bool save) {
+  const kprn_config& c = h->cfg;
+  State* s = st(h);
+  const int64_t N = (int64_t)b->B * b->P;
+  FwdArgs a;
+  a.idx = b->idx; a.N = N; a.T = b->T; a.F = b->F; a.nT = c.num_types;
+  a.Wt = h->dense + h->off_Wt; a.We = h->We; a.Wr = h->dense + h->off_Wr;
+  a.dt = c.dt; a.de = c.de; a.dr = c.dr;
+  for (int l = 0; l < 2; ++l) {
+    const int ll = l < c.L ? l : 0;
+    a.Wi[l] = h->dense + h->layer[ll].Wi; a.bi[l] = h->dense + h->layer[ll].bi; a.Wo[l] = h->dense + h->layer[ll].Wo;
+  }
+  a.Wout = h->dense + h->off_outW; a.bout = h->dense + h->off_outb; a.C = c.C;
+  a.S = h->ws.S;
+  a.n_tiles = (N + MT - 1) / MT;
+  a.save_frag = nullptr; a.save_h = nullptr;
+  if (save) {
+    if (N > s->cap_N || b->T > s->cap_T) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (s->save_frag) hipFree(s->save_frag);
+      if (s->save_h) hipFree(s->save_h);
+      const int64_t cn = std::max<int64_t>(N, s->cap_N);
+      const int ct = std::max(b->T, s->cap_T);
+      const int64_t mts = (cn + 15) / 16 + 4;
+      HIP_TRY(hipMalloc((void**)&s->save_frag, (size_t)mts * ct * c.L * 4 * NPL * 256 * sizeof(float)));
+      HIP_TRY(hipMalloc((void**)&s->save_h, (size_t)(cn + 64) * DH * sizeof(float)));
+      s->cap_N = cn; s->cap_T = ct;
+    }
+    a.save_frag = s->save_frag; a.save_h = s->save_h;
+  }
+  const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)s->num_cu);
+  static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
+  if (want_timing && !s->timing) HIP_TRY(hipMalloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
+  a.timing = s->timing;
+  ProfScope ps(h, save ? "lstm_fused_fwd_train" : "lstm_fused_fwd");
+  if (c.L == 1) { if (save) launch_fwd<1, true>(h, a, grid); else launch_fwd<1, false>(h, a, grid); }
+  else { if (save) launch_fwd<2, true>(h, a, grid); else launch_fwd<2, false>(h, a, grid); }
+  if (s->timing) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> tb((size_t)grid * 8);
+    HIP_TRY(hipMemcpy(tb.data(), s->timing, tb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum[8] = {0};
+    for (int g = 0; g < grid; ++g) for (int k = 0; k < 8; ++k) sum[k] += (double)tb[(size_t)g * 8 + k];
+    fprintf(stderr, "[kprn timing] fwd save=%d N=%lld grid=%d avg cycles/WG: prologue %.0f ids+gather-issue %.0f first-slots %.0f rec-slots %.0f gather-land %.0f drain %.0f total %.0f\n",
+            (int)save, (long long)N, grid, sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[7] / grid);
+  }
+}
+
+}  // namespace fused
