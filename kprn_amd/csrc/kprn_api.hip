@@ -525,6 +525,7 @@ void kprn_destroy(kprn_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   prof_drain(h);
   fused::release(h);
+  if (h->bidx_scratch) { hipFree(h->bidx_scratch); h->bidx_scratch = nullptr; }
   for (auto e : h->event_pool) hipEventDestroy(e);
   Workspace& w = h->ws;
   for (float** p : {&w.X, &w.Hs, &w.Cs, &w.ACT, &w.dA, &w.dIn, &w.dH, &w.dC, &w.S, &w.dS, &w.pooled, &w.probs, &w.sel, &w.dy}) dfree(*p);
@@ -630,20 +631,26 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
     HIP_TRY(hipMemcpyAsync(&flag, h->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     KPRN_REQUIRE(flag == 0, KPRN_E_INDEX, "an index is outside 1..vocabSize (ids are 1-based, int2torch.lua:60-63)");
+    // occurrence index: positions sorted by entity row + the sorted distinct rows (count at the tail of the list)
     b->uniq_cap = nsteps;
     b->uniq = dalloc<int32_t>(nsteps + 4);
-    HIP_TRY(hipMemsetAsync(b->uniq + b->uniq_cap, 0, sizeof(int32_t), h->stream));
-    const int32_t tag = h->next_tag++;
-    kk::unique_rows(h->stream, b->idx, nsteps, F, h->We_stamp, tag, b->uniq, b->uniq + b->uniq_cap);
-    HIP_TRY(hipMemcpyAsync(&b->n_uniq, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    if (labels) {  // training batches: duplicate-row leaders per 64-row tile for the fused backward
-      const int64_t N = (int64_t)B * P;
-      b->lead = dalloc<int32_t>(((N + 63) / 64) * 64 * T);
-      kk::tile_leaders(h->stream, b->idx, N, T, F, b->lead);
+    b->key_sorted = dalloc<int32_t>(nsteps);
+    b->pos_sorted = dalloc<int32_t>(nsteps);
+    {
+      const size_t need = bidx::scratch_bytes(nsteps, h->cfg.Ve);
+      if (need > h->bidx_scratch_bytes) {
+        if (h->bidx_scratch) hipFree(h->bidx_scratch);
+        h->bidx_scratch = nullptr;
+        HIP_TRY(hipMalloc(&h->bidx_scratch, need * 2));
+        h->bidx_scratch_bytes = need * 2;
+      }
     }
+    bidx::build(h->stream, b->idx, nsteps, F, h->cfg.Ve, b->key_sorted, b->pos_sorted, b->uniq, b->uniq + b->uniq_cap, h->bidx_scratch,
+                h->bidx_scratch_bytes);
+    HIP_TRY(hipMemcpyAsync(&b->n_uniq, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
   } catch (...) {
-    dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->lead);
+    dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->key_sorted); dfree(b->pos_sorted);
     delete b;
     throw;
   }
@@ -654,7 +661,7 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
 void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
   if (!b) return;
   if (h) { hipSetDevice(h->cfg.device_id); hipStreamSynchronize(h->stream); }
-  dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->lead);
+  dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->key_sorted); dfree(b->pos_sorted);
   delete b;
 }
 

@@ -66,7 +66,9 @@ struct kprn_batch {
   int32_t* uniq = nullptr;    // device: distinct entity rows of this batch (0-based); count at uniq[uniq_cap]
   int64_t uniq_cap = 0;
   int32_t n_uniq = 0;
-  int32_t* lead = nullptr;    // device [ceil(N/64)*64][T]: first row of the 64-row tile with the same entity id at step t, -1 past N
+  // occurrence index (batch_index.hip): all B*P*T positions sorted by entity row
+  int32_t* key_sorted = nullptr;  // device [B*P*T] entity row (0-based)
+  int32_t* pos_sorted = nullptr;  // device [B*P*T] position n*T + t
 };
 
 struct kprn_handle {
@@ -115,7 +117,8 @@ struct kprn_handle {
 
   Workspace ws;
   float* score_buf = nullptr;   // where the mapper output [N][C] of the last forward lives (ws.S)
-  void* fused_state = nullptr;  // owned by lstm_fused.hip
+  void* fused_state = nullptr;  // owned by lstm_fused_*.hip
+  void* bidx_scratch = nullptr; size_t bidx_scratch_bytes = 0;  // batch_index.hip temporaries
   int impl = 0;                 // 0 auto, 1 generic
   int32_t last_B = 0;
 
@@ -172,6 +175,14 @@ void fill_i32(hipStream_t s, int32_t* x, int64_t n, int32_t v);
 void tile_leaders(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int32_t* lead);
 void clear_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d);
 }  // namespace kk
+
+// ---- batch occurrence index (batch_index.hip) -------------------------------------------------
+namespace bidx {
+size_t scratch_bytes(int64_t nsteps, int Ve);
+// uniq: sorted distinct entity rows; *n_uniq_dev: their count
+void build(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int Ve, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq,
+           int32_t* n_uniq_dev, void* scratch, size_t scratch_sz);
+}  // namespace bidx
 
 // ---- GEMM (gemm_f32.hip): C[M,N] (+)= A(M,K) * B(K,N), arbitrary strides, fp32 MFMA -----------
 namespace gemm {

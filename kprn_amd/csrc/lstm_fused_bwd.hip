@@ -40,8 +40,6 @@ struct BwdArgs {
   float* part;             // [grid][2*256*64 + 256] per-workgroup partial dW_i2g | dW_o2g | db
   unsigned long long* timing;  // optional [grid][8] cycle counters (KPRN_TIMING=1)
   int dbg;                 // KPRN_DBG bit 0: skip the embedding scatter (measurement only)
-  const int32_t* lead;     // [Npad][T] tile leaders (bottom layer)
-  int mfma_scatter;        // 1: one-hot MFMA scatter (dims multiples of 16, one type slot, tables <= 16 rows)
   int64_t n_tiles;
 };
 
@@ -63,27 +61,20 @@ struct Pre {
   f32x4 bhp[4];  // B operands of dW_o2g: h^l_{t-1}, same layout
 };
 
-template <bool BOTTOM, bool TOP, bool MSCAT>
+template <bool BOTTOM, bool TOP, bool SMALL>
 __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = a.timing ? __builtin_amdgcn_s_memtime() : 0ull;
-  constexpr bool mscat = BOTTOM && MSCAT;  // compile-time: the two scatter forms never share a register allocation
   float* dA_t = lds;                                        // [64][LDD]
   float* in_t = dA_t + MT * LDD;                            // bottom: [64][LDA] x_t
-  int32_t* ids = (int32_t*)(in_t + (BOTTOM ? MT * LDA : 0));  // bottom: [64][T][4] the tile's ids, 0-based (slot 3: tile leader)
-  int32_t* lead = ids + (BOTTOM ? MT * MAXT_LDS * 4 : 0);     // bottom, general scatter: [64] leader row of each row's entity id
-  float* dxt = (float*)(lead + (BOTTOM ? MT : 0));            // bottom, general scatter: [64][LDA] dx tile
-  float* small_g = dxt + ((BOTTOM && !mscat) ? MT * LDA : 0); // bottom, general scatter: [Vt*dt + Vr*dr] partial sums (if they fit)
+  int32_t* ids = (int32_t*)(in_t + (BOTTOM ? MT * LDA : 0));  // bottom: [64][T][4] the tile's ids, 0-based (x_t re-gather)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int arow = lane & 15, ag = lane >> 4;
   const int T = a.T, L = a.L, ly = a.layer;
-  const int n_small = BOTTOM ? (a.Vt * a.dt + a.Vr * a.dr) : 0;
-  const bool small_in_lds = BOTTOM && !mscat && n_small <= 4096;
-  if (small_in_lds) for (int i = tid; i < n_small; i += 256) small_g[i] = 0.f;
 
   // ---- AGPR residents: this wave's slice of [W_i2g^T | W_o2g^T] (stage E's B operand) and the dW accumulators
   //      dwi/dwo[q][nt][r] <-> dW row q*64 + 16j + 4ag + r, col 16nt + arow
@@ -110,10 +101,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
 
   const int64_t frag_unit = (int64_t)NPL * 256;                // floats per (m-tile, t, layer, wave)
   const int64_t frag_mt_stride = (int64_t)T * L * 4 * frag_unit;  // floats per m-tile
-  // one-hot MFMA scatter: class of this wave's 16 columns (0 type, 1 entity, 2 relation) and the launch-
-  // persistent accumulator of its small table: acc_s[r] <-> table row 4ag + r, column 16j + arow
-  const int wcls = (j * 16 < a.dt) ? 0 : ((j * 16 < a.dt + a.de) ? 1 : 2);
-  f32x4 acc_s = f32x4{0.f, 0.f, 0.f, 0.f}, acc_s2 = f32x4{0.f, 0.f, 0.f, 0.f};  // two chains: an asm MFMA never reads the result of the MFMA right before it
+  // type / relation gradients (bottom layer, SMALL: one type slot, slice widths multiples of 16, tables <= 16 rows):
+  // nn.LookupTable backward as a matrix product, grad_table[v][:] += sum_rows onehot(id[row] == v) dx[row][:].  The
+  // dx accumulators already sit in the MFMA B layout (k-slot ag <-> row mt*16+4ag+r); the one-hot A operand comes
+  // from the LDS id tile; exact (products by 1.0 / 0.0).  acc_s[r] <-> table row 4ag + r, column 16j + arow, for
+  // the whole launch; two chains so that an MFMA never reads the result of the MFMA right before it.
+  const int wcls = (j * 16 < a.dt) ? 0 : ((j * 16 < a.dt + a.de) ? 1 : 2);  // this wave's 16 columns: type / entity / relation
+  f32x4 acc_s = f32x4{0.f, 0.f, 0.f, 0.f}, acc_s2 = f32x4{0.f, 0.f, 0.f, 0.f};
   GatherSrc gsrc;
   if (BOTTOM) gsrc = gather_src(a);
   TPROBE(0)
@@ -140,7 +134,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     if (BOTTOM) {
       lds_barrier();  // previous tile's id tile / x tile fully consumed
       ids_stage<256>(a.idx, a.N, T, a.F, a.nT, tile, ids);
-      if (mscat) lead_stage(a.lead, T, tile, ids);
       lds_barrier();
       f32x4 nin[4];
       gather_load<256>(a, gsrc, tile, T - 1, ids, nin);
@@ -198,6 +191,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
           dbias[q] += (dA[q][0] + dA[q][1]) + (dA[q][2] + dA[q][3]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        TPROBE(7)  // stage C, VALU part (incl. waiting for the factors)
         // the factors are dead: request the next m-tile's (first m-tile of step t-1 after the last one)
         if (mt < 3) load_P(mt + 1, t);
         else if (REC) load_P(0, t - 1);
@@ -215,8 +209,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
           if (mt < 3) { load_B(nt, mt + 1, t, REC); if (BOTTOM) load_bin_lds(nt, mt + 1); }
           else if (REC) load_B(nt, 0, t - 1, t > 1);
         }
+        TPROBE(2)  // stage C, dW MFMAs (incl. waiting for the B fragments)
       }
-      TPROBE(2)  // stage C (cell backward + dW MFMAs)
       lds_barrier();
       TPROBE(3)  // mid barrier wait
       // bottom layer: x_{t-1} is requested here (latency hides under stage E) and lands after it
@@ -266,127 +260,35 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
           }
         }
       }
-      KPRN_MFMA_DRAIN();  // ax / ah are read by VALU, stores and (as B operand) the scatter MFMAs below
+      KPRN_MFMA_DRAIN();  // ax / ah are read by VALU and stores below
       if (BOTTOM && REC) gather_store<256>(in_t, nin);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         if (REC) dh[mt] = ah[mt];  // already in the layout stage C of step t-1 reads
-        if (!BOTTOM) *(f32x4*)(a.DX + (((tile * 4 + mt) * T + t) * 4 + j) * 256 + lane * 4) = ax[mt];  // rows past N: exact zeros (dA = 0 there)
+        // dx in fragment order: the layer below (or, bottom layer, k_embed_scatter_frag) reloads it the same way,
+        // 1 KiB per instruction; in place -- this thread read this very slot as `up` at the start of the step.
+        // Rows past N: exact zeros (dA = 0 there).
+        *(f32x4*)(a.DX + (((tile * 4 + mt) * T + t) * 4 + j) * 256 + lane * 4) = ax[mt];
       }
-      const int col = j * 16 + arow;
-      if constexpr (mscat) if (!(a.dbg & 1)) {
-        // nn.LookupTable backward as a matrix product: grad_table[v][:] += sum_rows onehot(id[row] == v) dx[row][:].
-        // The dx accumulators ax[mt][r] already sit in the MFMA B layout (k-slot ag <-> row mt*16+4ag+r),
-        // the one-hot A operand is built from the LDS id tile; exact (products by 1.0 / 0.0).
-        if (wcls != 1) {
-          const int which = (wcls == 0) ? 0 : 2;
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int32_t* id = ids + ((mt * 16 + ag * 4 + r) * T + t) * 4;
-              // branch-free on purpose (both ids are read unconditionally): a short-circuit here became a divergent
-              // branch whose EXEC restore sat right in front of the asm MFMA
-              const int iv = id[which], il = id[3];
-              const float oh = (((int)(iv == arow)) & ((int)(il >= 0))) ? 1.f : 0.f;
-              if (r & 1) KPRN_MFMA_VV(acc_s2, oh, ax[mt][r]); else KPRN_MFMA_VV(acc_s, oh, ax[mt][r]);
-            }
-          // acc_s lives across the rest of the launch: if hipcc parks it (spill store / register copy) right behind
-          // the last MFMA it would read a result that has not landed -- seen as intermittently wrong type /
-          // relation gradients.  Nothing may touch it for the MFMA latency.
-          KPRN_MFMA_DRAIN();
-        } else {
-          // entity rows: fold the tile's duplicate ids onto their leader row (every pad step hits ONE row,
-          // a pair's user / item repeat across its paths), then one L2 atomic per distinct id
-          f32x4 comb[4];
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int ld = ids[((mt * 16 + ag * 4 + r) * T + t) * 4 + 3];
-#pragma unroll
-              for (int m = 0; m < 4; ++m) {  // four independent accumulation chains (one per 16-leader block)
-                const float oh = (ld == m * 16 + arow) ? 1.f : 0.f;
-                if (mt == 0 && r == 0) KPRN_MFMA_VVZ(comb[m], oh, ax[mt][r]);
-                else KPRN_MFMA_VV(comb[m], oh, ax[mt][r]);
-              }
-            }
-          KPRN_MFMA_DRAIN();
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = m * 16 + ag * 4 + r;
-              const int32_t* id = ids + (row * T + t) * 4;
-              if (id[3] == row) unsafeAtomicAdd(a.gWe + (int64_t)id[1] * a.de + (col - a.dt), comb[m][r]);
-            }
-        }
-      }
-      if constexpr (BOTTOM && !mscat) {
+      if constexpr (BOTTOM && SMALL) if (wcls != 1) {
+        const int which = (wcls == 0) ? 0 : 2;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dxt[(mt * 16 + ag * 4 + r) * LDA + col] = ax[mt][r];
+          for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + ag * 4 + r;
+            // branch-free on purpose: no EXEC games in front of an asm MFMA
+            const int iv = ids[(row * T + t) * 4 + which];
+            const float oh = (((int)(iv == arow)) & ((int)(n0 + row < a.N))) ? 1.f : 0.f;
+            if (r & 1) KPRN_MFMA_VV(acc_s2, oh, ax[mt][r]); else KPRN_MFMA_VV(acc_s, oh, ax[mt][r]);
+          }
+        // acc_s lives across the rest of the launch: if hipcc parks it (spill store / register copy) right behind the
+        // last MFMA it reads a result that has not landed (seen as intermittently wrong type / relation gradients)
+        KPRN_MFMA_DRAIN();
       }
       TPROBE(4)  // stage E (dX MFMAs) + outputs
-      if constexpr (BOTTOM && !mscat) if (!(a.dbg & 1)) {
-        // nn.LookupTable backward = scatter-add with duplicates accumulating (FeatureEmbedding.lua:29,41-49,86).
-        // Pad steps all hit ONE entity row and a pair's user / item repeat across its paths, so rows
-        // with the same entity id are first summed inside the tile (LDS); one L2 atomic row per distinct id.
-        {
-          // leader = first row of the tile with the same entity id; 4 threads per row, 16 candidates each
-          const int row = tid >> 2, part = tid & 3;
-          const int e = ids[(row * T + t) * 4 + 1];
-          int cand[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) cand[u] = ids[((part * 16 + u) * T + t) * 4 + 1];
-          int ld = row;
-#pragma unroll
-          for (int u = 15; u >= 0; --u) {
-            const int r2 = part * 16 + u;
-            ld = (r2 < row && cand[u] == e) ? r2 : ld;
-          }
-          ld = min(ld, __shfl_xor(ld, 1, 64));
-          ld = min(ld, __shfl_xor(ld, 2, 64));
-          if (part == 0) lead[row] = (n0 + row < a.N) ? ld : -1;
-        }
-        lds_barrier();
-        const int e0 = a.dt, e1 = a.dt + a.de;
-        const int colx = tid & 63, rg = tid >> 6;  // this thread: one column, rows rg, rg+4, ...
-        const bool is_ent = colx >= e0 && colx < e1;
-        int ldk[16];
-        for (int k = 0; k < 16; ++k) {
-          const int row = rg + 4 * k;
-          const int ld = lead[row];
-          ldk[k] = ld;
-          if (ld < 0) continue;
-          const float v = dxt[row * LDA + colx];
-          const int32_t* id = ids + (row * T + t) * 4;
-          if (colx < e0) {
-            const int32_t* f = a.idx + ((n0 + row) * T + t) * a.F;
-            for (int kk = 0; kk < a.nT; ++kk) {
-              const int rr = (kk == 0) ? id[0] : f[a.F - a.nT - 2 + kk] - 1;
-              if (small_in_lds) lds_atomic_add(&small_g[rr * a.dt + colx], v);
-              else unsafeAtomicAdd(a.gWt + (int64_t)rr * a.dt + colx, v);
-            }
-          } else if (colx < e1) {
-            if (ld != row) lds_atomic_add(&dxt[ld * LDA + colx], v);
-          } else {
-            if (small_in_lds) lds_atomic_add(&small_g[a.Vt * a.dt + id[2] * a.dr + (colx - e1)], v);
-            else unsafeAtomicAdd(a.gWr + (int64_t)id[2] * a.dr + (colx - e1), v);
-          }
-        }
-        lds_barrier();
-        // leaders add their (combined) entity slice to the gradient table (fire-and-forget atomics)
-        if (is_ent) {
-          for (int k = 0; k < 16; ++k) {
-            const int row = rg + 4 * k;
-            if (ldk[k] == row) unsafeAtomicAdd(a.gWe + (int64_t)ids[(row * T + t) * 4 + 1] * a.de + (colx - e0), dxt[row * LDA + colx]);
-          }
-        }
-      }
-      lds_barrier();  // dA_t / dxt / lead free for reuse, x_{t-1} tile visible
-      TPROBE(5)  // scatter + end barrier
+      lds_barrier();  // dA_t free for reuse, x_{t-1} tile visible
+      TPROBE(5)  // end barrier
     };
     for (int t = T - 1; t > 0; --t) step(std::true_type{}, t);
     step(std::false_type{}, 0);
@@ -415,9 +317,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       if (ag == 0) pw[2 * 256 * 64 + q * DH + j * 16 + arow] = v;
     }
   }
-  if constexpr (mscat) if (wcls != 1) {
+  if constexpr (BOTTOM && SMALL) if (wcls != 1) {
     acc_s += acc_s2;
-    // acc_s[r] <-> table row 4ag + r, column 16j + arow of the type (wcls 0) / relation (wcls 2) gradient
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int v = ag * 4 + r;
@@ -426,17 +327,203 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       else { if (v < a.Vr) unsafeAtomicAdd(a.gWr + (int64_t)v * a.dr + (col - a.dt - a.de), acc_s[r]); }
     }
   }
-  if constexpr (!mscat) if (small_in_lds) {
-    lds_barrier();
-    const int nt_small = a.Vt * a.dt;
-    for (int i = tid; i < n_small; i += 256) {
-      const float v = small_g[i];
-      if (v != 0.f) { if (i < nt_small) unsafeAtomicAdd(a.gWt + i, v); else unsafeAtomicAdd(a.gWr + (i - nt_small), v); }
-    }
-  }
   TPROBE(6)  // flush
   if (a.timing && tid == 0) {
     for (int k = 0; k < 8; ++k) a.timing[(int64_t)blockIdx.x * 8 + k] = tacc[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// nn.LookupTable backward for the three tables (FeatureEmbedding.lua:29,41-49,86 + CAddTable over type slots):
+// scatter-add of the bottom layer's dx, duplicates accumulating.  Input = the fused backward's fragment-order dx
+// (block (m-tile, t, wave w): lane (ag, arow), register r <-> row 4 ag + r, col 16 w + arow).  One workgroup per
+// 64-path tile, t by t:
+//   dx tile -> LDS row-major; rows of the tile with the same entity id (every pad step hits ONE row, a pair's
+//   user / item repeat across its P paths) are folded onto their leader row in LDS, then ONE L2 atomic row per
+//   distinct id; the two tiny tables accumulate in LDS for the whole workgroup and are flushed once.
+// HBM-bound: reads N T D floats once; algorithmic bytes per path = T (D + F) 4.
+struct ScatArgs {
+  const int32_t* idx; int64_t N; int T, F, nT;
+  int dt, de, dr, Vt, Vr;
+  const float* DX;        // [(Npad/16)][T][4][64][4]
+  const int32_t* lead;    // [Npad][T] leader row inside the tile (first row with the same entity id), -1 past N; nullable
+  float *gWt, *gWe, *gWr;
+  int do_small, do_entity;  // which tables this launch handles
+  float* part_small;      // [grid][Vt*dt + Vr*dr] per-workgroup partial small tables; null: tables too big for LDS -> global atomics
+  int64_t n_tiles;
+};
+
+__global__ __launch_bounds__(256) void k_embed_scatter_frag(ScatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dxt = lds;                                   // [64][LDA]
+  int32_t* ids = (int32_t*)(dxt + MT * LDA);          // [64][4]: first type, entity, relation (0-based), leader
+  float* small_g = (float*)(ids + MT * 4);            // [Vt*dt + Vr*dr] (if it fits)
+  const int tid = threadIdx.x, lane = tid & 63, w0 = tid >> 6;
+  const int arow = lane & 15, ag = lane >> 4;
+  const int T = a.T, D = a.dt + a.de + a.dr;
+  const int n_small = a.Vt * a.dt + a.Vr * a.dr;
+  const bool small_in_lds = a.part_small != nullptr && a.do_small;
+  if (small_in_lds) for (int i = tid; i < n_small; i += 256) small_g[i] = 0.f;
+  const int e0 = a.dt, e1 = a.dt + a.de;
+  const int col = tid & 63, rg = tid >> 6;  // combine phase: this thread owns one column, rows rg, rg+4, ...
+  // work items = (tile, t): independent, so the grid is sized for occupancy (latency-bound: load -> LDS -> atomics)
+  const int64_t n_items = a.n_tiles * T;
+  for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int64_t tile = item / T;
+    const int t = (int)(item - tile * T);
+    const int64_t n0 = tile * MT;
+    // (1) this step's dx tile: 16 blocks of 1 KiB, wave w0 takes blocks (mt, w) = (k, w0)
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *(const f32x4*)(a.DX + (((tile * 4 + k) * T + t) * 4 + w0) * 256 + lane * 4);
+    int my_ids[4] = {0, 0, 0, -1};
+    if (tid < MT) {
+      int64_t n = n0 + tid;
+      const bool valid = n < a.N;
+      if (!valid) n = a.N - 1;
+      const int32_t* f = a.idx + (n * T + t) * a.F;
+      my_ids[0] = f[a.F - a.nT - 2] - 1;
+      my_ids[1] = f[a.F - 2] - 1;
+      my_ids[2] = f[a.F - 1] - 1;
+      my_ids[3] = valid ? (a.lead ? a.lead[(n0 + tid) * T + t] : tid) : -1;
+    }
+    __syncthreads();  // previous item's readers are done with dxt / ids
+    if (tid < MT) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ids[tid * 4 + k] = my_ids[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dxt[(k * 16 + ag * 4 + r) * LDA + w0 * 16 + arow] = v[k][r];
+    __syncthreads();
+    if (!a.lead) {
+      // leader = first row of the tile with the same entity id
+      int ld = -1;
+      if (tid < MT && ids[tid * 4 + 3] >= 0) {
+        const int e = ids[tid * 4 + 1];
+        ld = tid;
+        for (int r2 = tid - 1; r2 >= 0; --r2) if (ids[r2 * 4 + 1] == e) ld = r2;
+      }
+      __syncthreads();
+      if (tid < MT) ids[tid * 4 + 3] = ld;
+      __syncthreads();
+    }
+    // (2) fold follower rows onto their leader (entity slice); types / relations into the small tables
+    if (col < D) {
+      for (int k = 0; k < 16; ++k) {
+        const int row = rg + 4 * k;
+        const int ld = ids[row * 4 + 3];
+        if (ld < 0) continue;
+        const float val = dxt[row * LDA + col];
+        if (col < e0) {
+          if (!a.do_small) continue;
+          const int32_t* f = a.idx + ((n0 + row) * T + t) * a.F;
+          for (int kk = 0; kk < a.nT; ++kk) {
+            const int rr = (kk == 0) ? ids[row * 4 + 0] : f[a.F - a.nT - 2 + kk] - 1;
+            if (small_in_lds) lds_atomic_add(&small_g[rr * a.dt + col], val);
+            else unsafeAtomicAdd(a.gWt + (int64_t)rr * a.dt + col, val);
+          }
+        } else if (col < e1) {
+          if (a.do_entity && ld != row) lds_atomic_add(&dxt[ld * LDA + col], val);
+        } else {
+          if (!a.do_small) continue;
+          const int rr = ids[row * 4 + 2];
+          if (small_in_lds) lds_atomic_add(&small_g[a.Vt * a.dt + rr * a.dr + (col - e1)], val);
+          else unsafeAtomicAdd(a.gWr + (int64_t)rr * a.dr + (col - e1), val);
+        }
+      }
+    }
+    __syncthreads();
+    // (3) leaders add their combined entity slice to the gradient table (fire-and-forget atomics)
+    if (col >= e0 && col < e1 && a.do_entity) {
+      for (int k = 0; k < 16; ++k) {
+        const int row = rg + 4 * k;
+        if (ids[row * 4 + 3] == row) unsafeAtomicAdd(a.gWe + (int64_t)ids[row * 4 + 1] * a.de + (col - e0), dxt[row * LDA + col]);
+      }
+    }
+  }
+  // the small tables leave as one plain slab per workgroup; k_reduce_small sums the slabs (thousands of
+  // workgroups' atomics onto the same few cache lines serialise at the memory side)
+  if (small_in_lds) {
+    __syncthreads();
+    for (int i = tid; i < n_small; i += 256) a.part_small[(int64_t)blockIdx.x * n_small + i] = small_g[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Entity-table gradient as a gather-reduce over the batch's occurrence index (batch_index.hip): positions sorted
+// by entity id are cut into 64-position segments, one wave per segment, lane = column of the entity slice.  All
+// 64 dx values of a lane are requested up front (independent loads), then summed run by run.  A run that lies
+// inside its segment is written with a plain store: no atomics, a fixed summation order.  Only runs that straddle
+// segments (hub entities, the pad row) add their per-segment partial sums atomically.
+struct EntArgs {
+  const float* DX;            // fragment-order dx of the bottom layer
+  const int32_t* key_sorted;  // [nsteps] entity row (0-based) of each sorted position
+  const int32_t* pos_sorted;  // [nsteps] position = n*T + t
+  int64_t nsteps;
+  int T, dt, de;
+  float* gWe;
+};
+
+__global__ __launch_bounds__(256) void k_entity_grad(EntArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t base = seg * 64;
+  if (base >= a.nsteps) return;
+  const int cnt = (int)((a.nsteps - base < 64) ? (a.nsteps - base) : 64);
+  const int my_key = (lane < cnt) ? a.key_sorted[base + lane] : -1;
+  const int my_pos = (lane < cnt) ? a.pos_sorted[base + lane] : 0;
+  const int key_before = (base > 0) ? a.key_sorted[base - 1] : -1;
+  const int key_after = (base + cnt < a.nsteps) ? a.key_sorted[base + cnt] : -1;
+  const int col = a.dt + lane;
+  const bool act = lane < a.de;
+  const int coff = (col >> 4) * 256 + (col & 15) * 4;  // wave block + lane slot of this column inside a (m-tile, t) group
+  float v[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const int p = __builtin_amdgcn_readlane(my_pos, i);
+    const int n = p / a.T, t = p - n * a.T;
+    const int rr = n & 15;
+    const int64_t off = ((int64_t)(n >> 4) * a.T + t) * 1024 + (rr >> 2) * 64 + (rr & 3);
+    v[i] = (act && i < cnt) ? a.DX[off + coff] : 0.f;
+  }
+  float acc = 0.f;
+  bool opened_here = __builtin_amdgcn_readlane(my_key, 0) != key_before;  // the first run starts in this segment
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    if (i < cnt) {  // wave-uniform
+      acc += v[i];
+      const int k = __builtin_amdgcn_readlane(my_key, i);
+      const bool more = (i < 63) && (i + 1 < cnt);
+      const int knext = more ? __builtin_amdgcn_readlane(my_key, (i + 1) & 63) : key_after;
+      if (!more || knext != k) {  // the run ends, or the segment does
+        const bool whole = opened_here && (knext != k);  // every occurrence of row k was in this segment
+        if (act) {
+          float* dst = a.gWe + (int64_t)k * a.de + lane;
+          if (whole) *dst = acc; else unsafeAtomicAdd(dst, acc);
+        }
+        acc = 0.f;
+        opened_here = true;
+      }
+    }
+  }
+}
+
+// gWt | gWr += sum over the scatter workgroups' slabs: one workgroup per 16 table entries, 16 slab lanes each
+__global__ __launch_bounds__(256) void k_reduce_small(const float* __restrict__ part, int nslab, int n_small, int nt_small, float* __restrict__ gWt, float* __restrict__ gWr) {
+  __shared__ float red[16][17];
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + e;
+  float acc = 0.f;
+  if (i < n_small) for (int s = sl; s < nslab; s += 16) acc += part[(int64_t)s * n_small + i];
+  red[sl][e] = acc;
+  __syncthreads();
+  if (sl == 0 && i < n_small) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][e];
+    if (i < nt_small) unsafeAtomicAdd(gWt + i, v); else unsafeAtomicAdd(gWr + (i - nt_small), v);
   }
 }
 
@@ -466,14 +553,12 @@ __global__ void k_transpose_256x64(const float* __restrict__ W, float* __restric
 // ---- host side ----
 bool bwd_supported(const kprn_handle* h, int T) { return fwd_supported(h, T); }
 
-template <bool BOTTOM, bool TOP, bool MSCAT>
+template <bool BOTTOM, bool TOP, bool SMALL>
 static void launch_bwd(kprn_handle* h, const BwdArgs& a, int grid) {
-  const int n_small = BOTTOM ? (a.Vt * a.dt + a.Vr * a.dr) : 0;
   size_t lds_bytes = (size_t)MT * LDD * sizeof(float);
-  if (BOTTOM) lds_bytes += (size_t)MT * LDA * sizeof(float) + (MT * MAXT_LDS * 4 + MT) * sizeof(int32_t);
-  if (BOTTOM && !MSCAT) lds_bytes += (size_t)MT * LDA * sizeof(float) + (size_t)(n_small <= 4096 ? n_small : 0) * sizeof(float);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP, MSCAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP, MSCAT>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
+  if (BOTTOM) lds_bytes += (size_t)MT * LDA * sizeof(float) + (MT * MAXT_LDS * 4) * sizeof(int32_t);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP, SMALL>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());
 }
 
@@ -528,16 +613,49 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     a.n_tiles = n_tiles;
     a.part = s->part; a.timing = s->timing;
     { static const char* d = getenv("KPRN_DBG"); a.dbg = d ? atoi(d) : 0; }
-    a.lead = b->lead;
-    a.mfma_scatter = (b->lead && c.num_types == 1 && (c.dt % 16) == 0 && (c.de % 16) == 0 && (c.dr % 16) == 0 && c.Vt <= 16 && c.Vr <= 16 &&
-                      !(a.dbg & 8)) ? 1 : 0;
     const bool bottom = (l == 0), top = (l == L - 1);
+    // small tables inside the bottom kernel (one-hot MFMA) when the shapes allow, else the general scatter kernel
+    const bool small_in_kernel = c.num_types == 1 && (c.dt % 16) == 0 && (c.de % 16) == 0 && (c.dr % 16) == 0 && c.Vt <= 16 && c.Vr <= 16 &&
+                                 !(a.dbg & 8);
+    const bool have_index = b->key_sorted != nullptr && !(a.dbg & 16);
     {
       ProfScope ps(h, "lstm_fused_bwd");
-      if (bottom && top) { if (a.mfma_scatter) launch_bwd<true, true, true>(h, a, grid); else launch_bwd<true, true, false>(h, a, grid); }
-      else if (bottom) { if (a.mfma_scatter) launch_bwd<true, false, true>(h, a, grid); else launch_bwd<true, false, false>(h, a, grid); }
+      if (bottom && top) { if (small_in_kernel) launch_bwd<true, true, true>(h, a, grid); else launch_bwd<true, true, false>(h, a, grid); }
+      else if (bottom) { if (small_in_kernel) launch_bwd<true, false, true>(h, a, grid); else launch_bwd<true, false, false>(h, a, grid); }
       else if (top) launch_bwd<false, true, false>(h, a, grid);
       else launch_bwd<false, false, false>(h, a, grid);
+    }
+    if (bottom && have_index && !(a.dbg & 1)) {
+      ProfScope ps(h, "entity_grad");
+      EntArgs ea;
+      ea.DX = s->DX; ea.key_sorted = b->key_sorted; ea.pos_sorted = b->pos_sorted; ea.nsteps = N * T; ea.T = T; ea.dt = c.dt; ea.de = c.de;
+      ea.gWe = a.gWe;
+      const int64_t segs = (N * T + 63) / 64;
+      hipLaunchKernelGGL(k_entity_grad, dim3((unsigned)((segs + 3) / 4)), dim3(256), 0, strm, ea);
+      HIP_TRY(hipGetLastError());
+    }
+    if (bottom && !(a.dbg & 1) && (!small_in_kernel || !have_index)) {
+      ProfScope ps(h, "embed_scatter");
+      ScatArgs sa;
+      sa.idx = b->idx; sa.N = N; sa.T = T; sa.F = b->F; sa.nT = c.num_types;
+      sa.dt = c.dt; sa.de = c.de; sa.dr = c.dr; sa.Vt = c.Vt; sa.Vr = c.Vr;
+      sa.DX = s->DX; sa.lead = nullptr; sa.gWt = a.gWt; sa.gWe = a.gWe; sa.gWr = a.gWr; sa.n_tiles = n_tiles;
+      sa.do_small = small_in_kernel ? 0 : 1; sa.do_entity = have_index ? 0 : 1;
+      const int n_small = c.Vt * c.dt + c.Vr * c.dr;
+      const bool small_fits = n_small <= 4096;
+      const size_t lds_b = (size_t)MT * LDA * sizeof(float) + MT * 4 * sizeof(int32_t) + (size_t)(small_fits ? n_small : 0) * sizeof(float);
+      const int sgrid = (int)std::min<int64_t>(n_tiles * T, (int64_t)s->num_cu * 8);
+      const bool slabs = small_fits && sa.do_small;
+      if (slabs && (!s->part_small || s->part_small_n < n_small)) {
+        HIP_TRY(hipStreamSynchronize(strm));
+        if (s->part_small) hipFree(s->part_small);
+        HIP_TRY(hipMalloc((void**)&s->part_small, (size_t)s->num_cu * 8 * n_small * sizeof(float)));
+        s->part_small_n = n_small;
+      }
+      sa.part_small = small_fits ? s->part_small : nullptr;
+      hipLaunchKernelGGL(k_embed_scatter_frag, dim3(sgrid), dim3(256), lds_b, strm, sa);
+      if (slabs) hipLaunchKernelGGL(k_reduce_small, dim3((n_small + 15) / 16), dim3(256), 0, strm, s->part_small, sgrid, n_small, c.Vt * c.dt, sa.gWt, sa.gWr);
+      HIP_TRY(hipGetLastError());
     }
     {
       ProfScope ps(h, "dw_reduce");
@@ -550,8 +668,8 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       HIP_TRY(hipMemcpy(tb.data(), s->timing, tb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       double sum[8] = {0};
       for (int g = 0; g < grid; ++g) for (int k = 0; k < 8; ++k) sum[k] += (double)tb[(size_t)g * 8 + k];
-      fprintf(stderr, "[kprn timing] bwd layer %d N=%lld grid=%d avg cycles/WG: prologue %.0f tile-prologue %.0f stageC %.0f midbar %.0f stageE %.0f scatter+bar %.0f flush %.0f\n",
-              l, (long long)N, grid, sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid);
+      fprintf(stderr, "[kprn timing] bwd layer %d N=%lld grid=%d avg cycles/WG: prologue %.0f tile-prologue %.0f stageC-valu %.0f stageC-mfma %.0f midbar %.0f stageE %.0f endbar %.0f flush %.0f\n",
+              l, (long long)N, grid, sum[0] / grid, sum[1] / grid, sum[7] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid);
     }
   }
 }
@@ -561,7 +679,7 @@ void params_changed(kprn_handle* h) { if (h->fused_state) ((State*)h->fused_stat
 void release(kprn_handle* h) {
   State* s = (State*)h->fused_state;
   if (!s) return;
-  for (float* p : {s->save_frag, s->save_h, s->WT, s->dHhead, s->DX, s->part}) if (p) hipFree(p);
+  for (float* p : {s->save_frag, s->save_h, s->WT, s->dHhead, s->DX, s->part, s->part_small}) if (p) hipFree(p);
   if (s->timing) hipFree(s->timing);
   delete s;
   h->fused_state = nullptr;

@@ -170,6 +170,8 @@ struct State {
   float* dHhead = nullptr;  // [N][64]
   float* DX = nullptr;      // [T][N][64]
   float* part = nullptr;    // [num_cu][PART]
+  float* part_small = nullptr;  // [8 num_cu][Vt*dt + Vr*dr] small-table partials of the embedding scatter
+  int part_small_n = 0;
   unsigned long long* timing = nullptr;  // [num_cu][8] when KPRN_TIMING=1
   int64_t cap_Nb = 0; int cap_Tb = 0;
 };
