@@ -165,14 +165,8 @@ def main():
     dpx = None
     if world > 1:
         dpx = dp.DataParallel(dp.GpuAdapter(eng, dev))
-        dpx.set_capacity(max(int(b.B) * b.P * b.T for b in batches))  # safe upper bound; tightened below
-        # tight capacity: largest distinct-row count of any batch on any rank
-        # (n_uniq is not exposed through ctypes; one dry backward per batch reads it back)
-        mx = 0
-        for b in batches:
-            eng.backward(b, 1, False, 0.0, want_loss=False)
-            mx = max(mx, eng.sparse_grad_capacity())
-        dpx.set_capacity(mx)
+        # packing capacity = largest distinct-row count of any batch on any rank (known from the batch index)
+        dpx.set_capacity(max(b.n_uniq for b in batches))
 
     def step(i):
         b = batches[i % len(batches)]

@@ -117,6 +117,8 @@ int kprn_zero_pad_tokens(kprn_handle* h);
 int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels,
                       int32_t B, int32_t P, int32_t T, int32_t F, kprn_batch** out);
 void kprn_batch_destroy(kprn_handle* h, kprn_batch* b);
+/* number of distinct entity rows the batch references (= the rows one training step on it touches) */
+int kprn_batch_distinct_rows(kprn_handle* h, const kprn_batch* b, int32_t* n);
 
 /* ---- scoring: model:forward(inputs) (test_from_checkpoint.lua:81-82,109) ------------
  * probs[B]      = Sigmoid(reduce_p(mapper))[:, classId]       (Select(2,classId))
@@ -153,15 +155,18 @@ int kprn_sync(kprn_handle* h);
 /* ---- data-parallel hooks (new design; the reference is single-device) -----
  * The dense gradients (type_emb, relation_emb, LSTM, head) live in ONE contiguous device
  * buffer that the caller all-reduces (RCCL).  entity_emb gradients are row-sparse: pack
- * -> all-gather -> unpack(add) on every rank.  All pointers are DEVICE pointers.        */
+ * -> ONE all-gather -> merge on every rank.  All pointers are DEVICE pointers.           */
 int kprn_dense_grad_buffer(kprn_handle* h, void** dev_ptr, int64_t* n_floats);
-/* copies the touched rows' ids and gradient rows to the packing buffers (capacity rows);
- * clears them from the local accumulator; count written to *dev_count (device int32)    */
+/* upper bound of the rows one step of this rank touches (agree on the MAX over ranks as the packing capacity) */
 int kprn_sparse_grad_capacity(kprn_handle* h, int32_t* max_rows_per_step);
-int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_ids, void** dev_rows, void** dev_count);
-/* adds `count` packed rows (device pointers, possibly another rank's) into the accumulator */
-int kprn_sparse_grad_unpack_add(kprn_handle* h, const void* dev_ids, const void* dev_rows,
-                                const void* dev_count, int32_t capacity);
+/* moves this step's touched entity rows into ONE packed device buffer of 32-bit words
+ *   { int32 count, 3 x pad, int32 ids[capacity] (sorted, 0-based), float rows[capacity][d_entity] }
+ * and clears them from the local accumulator; *n_words = 4 + capacity (1 + d_entity): the unit of the all-gather. */
+int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int64_t* n_words);
+/* dev_all = the `world` packed buffers back to back (all-gather output, THIS rank's included).  Builds the union
+ * of the rows and their sum in rank order (one stable sort + one gather-reduce; identical bits on every rank) in
+ * the accumulator; the next kprn_apply_update walks that union.                                              */
+int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, int32_t capacity);
 /* the stream everything is queued on (hipStream_t), so the caller can order collectives  */
 int kprn_stream(kprn_handle* h, void** stream);
 

@@ -103,6 +103,13 @@ class Batch:
     def n_paths(self):
         return self.B * self.P
 
+    @property
+    def n_uniq(self):
+        """distinct entity rows of the batch (the rows one training step touches)"""
+        n = C.c_int32()
+        self.engine._ck(self.engine.L.kprn_batch_distinct_rows(self.engine.h, self.ptr, C.byref(n)))
+        return int(n.value)
+
     def free(self):
         if self.ptr:
             self.engine.L.kprn_batch_destroy(self.engine.h, self.ptr)
@@ -297,12 +304,13 @@ class Engine:
         return int(n.value)
 
     def sparse_grad_pack(self, capacity):
-        ids, rows, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        self._ck(self.L.kprn_sparse_grad_pack(self.h, int(capacity), C.byref(ids), C.byref(rows), C.byref(cnt)))
-        return int(ids.value), int(rows.value), int(cnt.value)
+        """-> (device pointer of the packed buffer, its length in 32-bit words)"""
+        buf, n = C.c_void_p(), C.c_int64()
+        self._ck(self.L.kprn_sparse_grad_pack(self.h, int(capacity), C.byref(buf), C.byref(n)))
+        return int(buf.value), int(n.value)
 
-    def sparse_grad_unpack_add(self, ids_ptr, rows_ptr, count_ptr, capacity):
-        self._ck(self.L.kprn_sparse_grad_unpack_add(self.h, C.c_void_p(ids_ptr), C.c_void_p(rows_ptr), C.c_void_p(count_ptr), int(capacity)))
+    def sparse_grad_merge(self, all_ptr, world, capacity):
+        self._ck(self.L.kprn_sparse_grad_merge(self.h, C.c_void_p(all_ptr), int(world), int(capacity)))
 
     def stream(self):
         p = C.c_void_p()

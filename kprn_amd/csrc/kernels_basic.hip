@@ -185,14 +185,18 @@ __device__ float reduce_col(const float* s, int P, int C, int reducer, int K) {
   }
 }
 
-__global__ void k_pool(const float* __restrict__ S, int B, int P, int C, int reducer, int K, float* __restrict__ pooled, float* __restrict__ probs) {
+// + nn.Select(2, classId) (MyOptimizer.lua:126 / test_from_checkpoint.lua:82): sel[b] = probs[b][cid]
+__global__ void k_pool(const float* __restrict__ S, int B, int P, int C, int reducer, int K, float* __restrict__ pooled, float* __restrict__ probs,
+                       int cid, float* __restrict__ sel) {
   int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (int64_t)B * C) return;
   int c = (int)(gid % C);
   int64_t b = gid / C;
   float y = reduce_col(S + b * P * C + c, P, C, reducer, K);
+  float pr = sigmoidf_(y);
   pooled[gid] = y;
-  probs[gid] = sigmoidf_(y);
+  probs[gid] = pr;
+  if (sel && c == cid) sel[b] = pr;
 }
 
 __global__ void k_select(const float* __restrict__ probs, int B, int C, int cid, float* __restrict__ sel) {
@@ -247,6 +251,131 @@ __global__ void k_bce_dscore(const float* __restrict__ S, const float* __restric
       d[bi] = dy / (float)kk; last_v = best; last_i = bi;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// The whole loss stage of a training step in one launch:
+//   A  reducer over the P paths + nn.Sigmoid + nn.Select for every class          (OneModel.lua:284-294, MyOptimizer.lua:126)
+//   B  nn.BCECriterion forward / backward on column classId, back through sigmoid and reducer -> dS[n]   (MyOptimizer.lua:193-195)
+//   C  nn.Linear(H,46) backward restricted to that column: gW[cid][:] += sum_n dS[n] hT[n][:], gb[cid] += sum_n dS[n]
+//   D  loss = fixed-order sum of the per-pair terms: per-workgroup partials, summed in index order by the last workgroup
+// (was five launches: pool, select, bce, sum, head_bwd).  One workgroup = LOSS_PPW pairs.  hT may be null (generic pipeline: its own head backward).
+__device__ float bce_pair(const float* __restrict__ s, int P, int C, int reducer, int K, int literal, float invB, float t, float* __restrict__ d,
+                          float* lossterm) {
+  const float eps = 1e-12f;
+  const float y = reduce_col(s, P, C, reducer, K);
+  const float p = sigmoidf_(y);
+  *lossterm = -(t * logf(p + eps) + (1.f - t) * logf(1.f - p + eps)) * invB;
+  float dy;
+  if (literal) {
+    float dp = -(t - p) / ((1.f - p + eps) * (p + eps)) * invB;
+    dy = dp * p * (1.f - p);
+  } else {
+    dy = (p - t) * invB;
+  }
+  if (reducer == 2) {
+    float m = s[0];
+    for (int q = 1; q < P; ++q) m = fmaxf(m, s[(int64_t)q * C]);
+    float sum = 0.f;
+    for (int q = 0; q < P; ++q) sum += expf(s[(int64_t)q * C] - m);
+    for (int q = 0; q < P; ++q) d[q] = expf(s[(int64_t)q * C] - m) / sum * dy;
+  } else if (reducer == 0) {
+    int arg = 0;
+    for (int q = 1; q < P; ++q) if (s[(int64_t)q * C] > s[(int64_t)arg * C]) arg = q;
+    for (int q = 0; q < P; ++q) d[q] = (q == arg) ? dy : 0.f;
+  } else {
+    int kk = K < P ? K : P;
+    for (int q = 0; q < P; ++q) d[q] = 0.f;
+    float last_v = INFINITY; int last_i = -1;
+    for (int r = 0; r < kk; ++r) {
+      float best = -INFINITY; int bi = -1;
+      for (int q = 0; q < P; ++q) {
+        float v = s[(int64_t)q * C];
+        bool after = (v < last_v) || (v == last_v && q > last_i);
+        if (after && (bi < 0 || v > best)) { best = v; bi = q; }
+      }
+      d[bi] = dy / (float)kk; last_v = best; last_i = bi;
+    }
+  }
+  return p;
+}
+
+constexpr int LOSS_PPW = 16;  // pairs per workgroup of the loss stage: small on purpose (latency-bound: many workgroups in flight)
+__global__ __launch_bounds__(256) void k_loss_stage(const float* __restrict__ S, const float* __restrict__ labels, const float* __restrict__ hT,
+                                                    int B, int P, int C, int H, int cid, int reducer, int K, int literal, float invB,
+                                                    float* __restrict__ pooled, float* __restrict__ probs, float* __restrict__ sel,
+                                                    float* __restrict__ dS, float* __restrict__ gW_row, float* __restrict__ gb_c,
+                                                    float* __restrict__ partial) {
+  __shared__ float lossw[LOSS_PPW];
+  __shared__ float red[4][65];
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * LOSS_PPW;
+  const int nb = (B - b0 < LOSS_PPW) ? (B - b0) : LOSS_PPW;
+  // A
+  for (int i = tid; i < nb * C; i += 256) {
+    const int b = b0 + i / C, c = i % C;
+    const float y = reduce_col(S + (int64_t)b * P * C + c, P, C, reducer, K);
+    const float pr = sigmoidf_(y);
+    pooled[(int64_t)b * C + c] = y;
+    probs[(int64_t)b * C + c] = pr;
+    if (c == cid) sel[b] = pr;
+  }
+  // B
+  if (tid < LOSS_PPW) {
+    float lt = 0.f;
+    if (tid < nb) {
+      const int b = b0 + tid;
+      bce_pair(S + (int64_t)b * P * C + cid, P, C, reducer, K, literal, invB, labels[b], dS + (int64_t)b * P, &lt);
+    }
+    lossw[tid] = lt;
+  }
+  __syncthreads();  // this workgroup's dS rows are visible to it
+  // C
+  if (hT) {
+    const int64_t n0 = (int64_t)b0 * P, n1 = n0 + (int64_t)nb * P;
+    const int sub = tid >> 6, col = tid & 63;
+    for (int c0 = 0; c0 < H; c0 += 64) {
+      const int cc = c0 + col;
+      float acc = 0.f, sd = 0.f;
+      for (int64_t n = n0 + sub; n < n1; n += 4) {
+        const float d = dS[n];
+        sd += d;
+        if (cc < H) acc += d * hT[n * H + cc];
+      }
+      red[sub][col] = acc;
+      if (col == 0) red[sub][64] = sd;
+      __syncthreads();
+      if (sub == 0) {
+        if (cc < H) unsafeAtomicAdd(gW_row + cc, (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]));
+        if (col == 0 && c0 == 0) unsafeAtomicAdd(gb_c, (red[0][64] + red[1][64]) + (red[2][64] + red[3][64]));
+      }
+      __syncthreads();
+    }
+  }
+  // D: per-workgroup partial, summed in index order by k_sum_partials when the loss is asked for (a last-workgroup
+  //    reduction here needs a device-scope release per workgroup = an L2 write-back each: measured 30 us)
+  if (tid == 0) {
+    float s = 0.f;
+    for (int i = 0; i < LOSS_PPW; ++i) s += lossw[i];
+    partial[blockIdx.x] = s;
+  }
+}
+
+// loss = fixed-order sum of the per-workgroup partials (reproducible)
+__global__ void k_sum_partials(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ float pl[256];
+  float s = 0.f;
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + (int)threadIdx.x;
+    pl[threadIdx.x] = (i < n) ? partial[i] : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int m = (n - base < 256) ? (n - base) : 256;
+      for (int k = 0; k < m; ++k) s += pl[k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = s;
 }
 
 // deterministic single-block sum
@@ -366,20 +495,28 @@ __device__ __forceinline__ void adam_elem(float& x, float& m, float& v, float g,
   x = x - step * (m / denom);
 }
 
-__global__ void k_adam_dense(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                             float step, float b1, float b2, float eps, const float* __restrict__ norm2, float clip, float l2, int reg) {
+// consume != 0: the gradient is zeroed as it is used (zeroGradParameters of the next trainBatch, MyOptimizer.lua:186, done here);
+// [z0,z0+zn0) and [z1,z1+zn1): pad rows of the arena, re-zeroed after the update (zeroPadTokens, MyOptimizer.lua:219);
+// tab_slot: this step's entry of the device step-size table (read by the lazy row replay).
+__global__ void k_adam_dense(float* __restrict__ x, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                             float step, float b1, float b2, float eps, const float* __restrict__ norm2, float clip, float l2, int reg,
+                             int consume, int64_t z0, int zn0, int64_t z1, int zn1, float* __restrict__ tab_slot) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && tab_slot) *tab_slot = step;
   if (i >= n) return;
   float gi = g[i];
   float xi = x[i];
   if (reg) { gi = gi * clip_factor(norm2, clip); gi = gi + l2 * xi; }
   float mi = m[i], vi = v[i];
   adam_elem(xi, mi, vi, gi, step, b1, b2, eps);
+  if ((i >= z0 && i < z0 + zn0) || (i >= z1 && i < z1 + zn1)) xi = 0.f;
   x[i] = xi; m[i] = mi; v[i] = vi;
+  if (consume) g[i] = 0.f;
 }
 
-__global__ void k_adagrad_dense(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ G, int64_t n, float clr,
-                                const float* __restrict__ norm2, float clip, float l2, int reg) {
+__global__ void k_adagrad_dense(float* __restrict__ x, float* __restrict__ g, float* __restrict__ G, int64_t n, float clr,
+                                const float* __restrict__ norm2, float clip, float l2, int reg, int consume, int64_t z0, int zn0, int64_t z1,
+                                int zn1) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float gi = g[i];
@@ -387,7 +524,10 @@ __global__ void k_adagrad_dense(float* __restrict__ x, const float* __restrict__
   if (reg) { gi = gi * clip_factor(norm2, clip); gi = gi + l2 * xi; }
   float Gi = G[i] + gi * gi;
   G[i] = Gi;
-  x[i] = xi - clr * gi / (sqrtf(Gi) + 1e-10f);
+  xi = xi - clr * gi / (sqrtf(Gi) + 1e-10f);
+  if ((i >= z0 && i < z0 + zn0) || (i >= z1 && i < z1 + zn1)) xi = 0.f;
+  x[i] = xi;
+  if (consume) g[i] = 0.f;
 }
 
 // lazy-exact Adam over a list of rows: one wave per row.  Replays the steps the row missed
@@ -396,7 +536,7 @@ __global__ void k_adagrad_dense(float* __restrict__ x, const float* __restrict__
 // row at every step, which is what optim.adam does to the flat vector.
 __global__ void k_adam_rows(float* __restrict__ W, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             int32_t* __restrict__ last, const int32_t* __restrict__ rows, const int32_t* __restrict__ count, int d,
-                            int32_t t_now, int apply_step, const float* __restrict__ step_tab, float b1, float b2, float eps) {
+                            int32_t t_now, int apply_step, const float* __restrict__ step_tab, float b1, float b2, float eps, int64_t pad_row) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wave >= *count) return;
@@ -412,13 +552,14 @@ __global__ void k_adam_rows(float* __restrict__ W, float* __restrict__ g, float*
       adam_elem(x, mm, vv, g[o], step_tab[t_now], b1, b2, eps);
       g[o] = 0.f;
     }
+    if (r == pad_row) x = 0.f;  // zeroPadTokens after every step the row lived through (MyOptimizer.lua:219)
     W[o] = x; m[o] = mm; v[o] = vv;
   }
   if (lane == 0) last[r] = t_now;
 }
 
 __global__ void k_adam_flush_all(float* __restrict__ W, float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ last, int64_t V,
-                                 int d, int32_t t_now, const float* __restrict__ step_tab, float b1, float b2, float eps) {
+                                 int d, int32_t t_now, const float* __restrict__ step_tab, float b1, float b2, float eps, int64_t pad_row) {
   const int lane = threadIdx.x & 63;
   const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (r >= V) return;
@@ -428,13 +569,14 @@ __global__ void k_adam_flush_all(float* __restrict__ W, float* __restrict__ m, f
     const int64_t o = r * d + e;
     float x = W[o], mm = m[o], vv = v[o];
     for (int32_t k = l + 1; k <= t_now; ++k) adam_elem(x, mm, vv, 0.f, step_tab[k], b1, b2, eps);
+    if (r == pad_row) x = 0.f;
     W[o] = x; m[o] = mm; v[o] = vv;
   }
   if (lane == 0) last[r] = t_now;
 }
 
 __global__ void k_adagrad_rows(float* __restrict__ W, float* __restrict__ g, float* __restrict__ G, const int32_t* __restrict__ rows,
-                               const int32_t* __restrict__ count, int d, float clr) {
+                               const int32_t* __restrict__ count, int d, float clr, int64_t pad_row) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wave >= *count) return;
@@ -444,7 +586,7 @@ __global__ void k_adagrad_rows(float* __restrict__ W, float* __restrict__ g, flo
     float gi = g[o];
     float Gi = G[o] + gi * gi;
     G[o] = Gi;
-    W[o] = W[o] - clr * gi / (sqrtf(Gi) + 1e-10f);
+    W[o] = (r == pad_row) ? 0.f : W[o] - clr * gi / (sqrtf(Gi) + 1e-10f);
     g[o] = 0.f;
   }
 }
@@ -453,6 +595,14 @@ __global__ void k_adagrad_rows(float* __restrict__ W, float* __restrict__ g, flo
 __global__ void k_zero_row(float* __restrict__ W, int64_t row, int d) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < d) W[row * d + j] = 0.f;
+}
+
+// MyOptimizer:zeroPadTokens (MyOptimizer.lua:74-93): the three pad rows in one launch
+__global__ void k_zero_pad3(float* __restrict__ a, int na, float* __restrict__ b, int nb, float* __restrict__ c, int nc) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < na) a[j] = 0.f;
+  if (j < nb) b[j] = 0.f;
+  if (j < nc) c[j] = 0.f;
 }
 
 __global__ void k_fill_i32(int32_t* __restrict__ x, int64_t n, int32_t v) {
@@ -587,9 +737,24 @@ void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* o
   CHECK_LAUNCH();
 }
 
-void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs) {
+void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_pool, dim3(nblocks((int64_t)B * C)), dim3(TPB), 0, s, S, B, P, C, reducer, K, pooled, probs);
+  hipLaunchKernelGGL(k_pool, dim3(nblocks((int64_t)B * C)), dim3(TPB), 0, s, S, B, P, C, reducer, K, pooled, probs, cid, sel);
+  CHECK_LAUNCH();
+}
+
+void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
+                int literal, float invB, float* pooled, float* probs, float* sel, float* dS, float* gW_row, float* gb_c, float* partial) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_loss_stage, dim3((unsigned)((B + LOSS_PPW - 1) / LOSS_PPW)), dim3(256), 0, s, S, labels, hT, B, P, C, H, cid, reducer, K, literal, invB,
+                     pooled, probs, sel, dS, gW_row, gb_c, partial);
+  CHECK_LAUNCH();
+}
+
+int loss_partials(int B) { return (B + LOSS_PPW - 1) / LOSS_PPW; }
+
+void sum_partials(hipStream_t s, const float* partial, int n, float* out) {
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n, out);
   CHECK_LAUNCH();
 }
 
@@ -645,38 +810,47 @@ void sumsq_rows(hipStream_t s, const float* G, const int32_t* rows, const int32_
   CHECK_LAUNCH();
 }
 
-void adam_dense(hipStream_t s, float* x, const float* g, float* m, float* v, int64_t n, float step, float b1, float b2, float eps,
-                const float* norm2, float clip, float l2) {
+void adam_dense(hipStream_t s, float* x, float* g, float* m, float* v, int64_t n, float step, float b1, float b2, float eps,
+                const float* norm2, float clip, float l2, int consume, int64_t z0, int zn0, int64_t z1, int zn1, float* tab_slot) {
   if (n <= 0) return;
   int reg = (norm2 != nullptr || l2 != 0.f) ? 1 : 0;
-  hipLaunchKernelGGL(k_adam_dense, dim3(nblocks(n)), dim3(TPB), 0, s, x, g, m, v, n, step, b1, b2, eps, norm2, clip, l2, reg);
+  hipLaunchKernelGGL(k_adam_dense, dim3(nblocks(n)), dim3(TPB), 0, s, x, g, m, v, n, step, b1, b2, eps, norm2, clip, l2, reg, consume, z0, zn0, z1,
+                     zn1, tab_slot);
   CHECK_LAUNCH();
 }
 
-void adagrad_dense(hipStream_t s, float* x, const float* g, float* G, int64_t n, float clr, const float* norm2, float clip, float l2) {
+void adagrad_dense(hipStream_t s, float* x, float* g, float* G, int64_t n, float clr, const float* norm2, float clip, float l2, int consume,
+                   int64_t z0, int zn0, int64_t z1, int zn1) {
   if (n <= 0) return;
   int reg = (norm2 != nullptr || l2 != 0.f) ? 1 : 0;
-  hipLaunchKernelGGL(k_adagrad_dense, dim3(nblocks(n)), dim3(TPB), 0, s, x, g, G, n, clr, norm2, clip, l2, reg);
+  hipLaunchKernelGGL(k_adagrad_dense, dim3(nblocks(n)), dim3(TPB), 0, s, x, g, G, n, clr, norm2, clip, l2, reg, consume, z0, zn0, z1, zn1);
   CHECK_LAUNCH();
 }
 
 void adam_rows(hipStream_t s, float* W, float* g, float* m, float* v, int32_t* last, const int32_t* rows, const int32_t* count, int64_t max_rows,
-               int d, int32_t t_now, int apply_step, const float* step_tab, float b1, float b2, float eps) {
+               int d, int32_t t_now, int apply_step, const float* step_tab, float b1, float b2, float eps, int64_t pad_row) {
   if (max_rows <= 0) return;
   hipLaunchKernelGGL(k_adam_rows, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, d, t_now, apply_step, step_tab, b1,
-                     b2, eps);
+                     b2, eps, pad_row);
   CHECK_LAUNCH();
 }
 
 void adam_flush_all(hipStream_t s, float* W, float* m, float* v, int32_t* last, int64_t V, int d, int32_t t_now, const float* step_tab, float b1,
-                    float b2, float eps) {
-  hipLaunchKernelGGL(k_adam_flush_all, dim3(nblocks(V * 64)), dim3(TPB), 0, s, W, m, v, last, V, d, t_now, step_tab, b1, b2, eps);
+                    float b2, float eps, int64_t pad_row) {
+  hipLaunchKernelGGL(k_adam_flush_all, dim3(nblocks(V * 64)), dim3(TPB), 0, s, W, m, v, last, V, d, t_now, step_tab, b1, b2, eps, pad_row);
   CHECK_LAUNCH();
 }
 
-void adagrad_rows(hipStream_t s, float* W, float* g, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, float clr) {
+void adagrad_rows(hipStream_t s, float* W, float* g, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, float clr,
+                  int64_t pad_row) {
   if (max_rows <= 0) return;
-  hipLaunchKernelGGL(k_adagrad_rows, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, W, g, G, rows, count, d, clr);
+  hipLaunchKernelGGL(k_adagrad_rows, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, W, g, G, rows, count, d, clr, pad_row);
+  CHECK_LAUNCH();
+}
+
+void zero_pad3(hipStream_t s, float* a, int na, float* b, int nb, float* c, int nc) {
+  const int n = na > nb ? (na > nc ? na : nc) : (nb > nc ? nb : nc);
+  hipLaunchKernelGGL(k_zero_pad3, dim3(nblocks(n)), dim3(TPB), 0, s, a, na, b, nb, c, nc);
   CHECK_LAUNCH();
 }
 

@@ -124,18 +124,54 @@ static void flush_lazy(kprn_handle* h) {
   if (!h->lazy_pending) return;
   ProfScope ps(h, "adam_flush_all");
   kk::adam_flush_all(h->stream, h->We, h->s1_We, h->s2_We, h->We_last, h->cfg.Ve, h->cfg.de, (int32_t)h->opt_step, h->step_tab,
-                     h->last_b1, h->last_b2, h->last_eps);
+                     h->last_b1, h->last_b2, h->last_eps, (int64_t)h->cfg.Ve - 1);
   h->lazy_pending = false;
 }
 
 static void zero_pad_tokens(kprn_handle* h) {
   const kprn_config& c = h->cfg;
-  kk::zero_rows(h->stream, h->dense + h->off_Wt, c.Vt - 1, c.dt);
-  kk::zero_rows(h->stream, h->dense + h->off_Wr, c.Vr - 1, c.dr);
-  kk::zero_rows(h->stream, h->We, c.Ve - 1, c.de);
+  kk::zero_pad3(h->stream, h->dense + h->off_Wt + (int64_t)(c.Vt - 1) * c.dt, c.dt, h->dense + h->off_Wr + (int64_t)(c.Vr - 1) * c.dr, c.dr,
+                h->We + (int64_t)(c.Ve - 1) * c.de, c.de);
+  h->pad_clean = true;
+}
+
+// parameters were written from outside the optimiser: every steady-state shortcut is off
+static void params_touched(kprn_handle* h) {
+  h->pad_clean = false;
+  h->caught_serial = -1;
+  fused::params_changed(h);
+}
+
+// the optimiser's row list: a view of the batch's distinct-row list until something needs an owned copy
+static void view_step_rows(kprn_handle* h, const kprn_batch* b) {
+  h->rows_view = b->uniq; h->count_view = b->uniq + b->uniq_cap; h->view_batch = b;
+  h->step_rows_ub = b->n_uniq;
+}
+
+static void materialize_step_rows(kprn_handle* h) {
+  if (!h->view_batch) { h->rows_view = h->step_rows; h->count_view = h->step_count; return; }
+  const kprn_batch* b = h->view_batch;
+  int64_t need = std::max<int64_t>(b->n_uniq, 1);
+  if (need > h->step_rows_cap) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dfree(h->step_rows);
+    h->step_rows_cap = need * 2;
+    h->step_rows = dalloc<int32_t>(h->step_rows_cap);
+  }
+  if (b->n_uniq > 0)
+    HIP_TRY(hipMemcpyAsync(h->step_rows, b->uniq, (size_t)b->n_uniq * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->step_count, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  h->step_rows_ub = b->n_uniq;
+  h->rows_view = h->step_rows; h->count_view = h->step_count; h->view_batch = nullptr;
 }
 
 static void ensure_ws_common(kprn_handle* h, int64_t N, int64_t B) {
+  if (kk::loss_partials((int)B) > h->loss_partial_cap) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dfree(h->loss_partial);
+    h->loss_partial_cap = (int64_t)kk::loss_partials((int)B) * 2;
+    h->loss_partial = dalloc<float>(h->loss_partial_cap);
+  }
   Workspace& w = h->ws;
   const kprn_config& c = h->cfg;
   if (N > w.cap_Nc) {
@@ -181,10 +217,12 @@ static void ensure_ws_generic(kprn_handle* h, int64_t N, int T) {
 // rows of this batch that are behind opt_step are replayed before the forward reads them
 static void catch_up(kprn_handle* h, const kprn_batch* b) {
   if (!h->lazy_pending || b->n_uniq == 0) return;
+  if (h->caught_serial == b->serial && h->caught_step == h->opt_step) return;  // this batch's rows are already current
   ProfScope ps(h, "adam_rows_catchup");
   // count lives at the tail of the list buffer
   kk::adam_rows(h->stream, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, b->uniq, b->uniq + b->uniq_cap, b->n_uniq, h->cfg.de,
-                (int32_t)h->opt_step, 0, h->step_tab, h->last_b1, h->last_b2, h->last_eps);
+                (int32_t)h->opt_step, 0, h->step_tab, h->last_b1, h->last_b2, h->last_eps, (int64_t)h->cfg.Ve - 1);
+  h->caught_serial = b->serial; h->caught_step = h->opt_step;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -233,8 +271,7 @@ static void pool_stage(kprn_handle* h, const kprn_batch* b, int cid) {
   const kprn_config& c = h->cfg;
   Workspace& w = h->ws;
   ProfScope ps(h, "pool_sigmoid");
-  kk::pool_sigmoid(h->stream, w.S, b->B, b->P, c.C, c.reducer, c.K, w.pooled, w.probs);
-  kk::select_col(h->stream, w.probs, b->B, c.C, cid, w.sel);
+  kk::pool_sigmoid(h->stream, w.S, b->B, b->P, c.C, c.reducer, c.K, w.pooled, w.probs, cid, w.sel);
 }
 
 static void check_batch(kprn_handle* h, const kprn_batch* b, int class_id) {
@@ -247,7 +284,7 @@ static bool use_fused(kprn_handle* h, const kprn_batch* b, bool save_for_backwar
   return !save_for_backward || fused::bwd_supported(h, b->T);
 }
 
-static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool save_for_backward) {
+static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool save_for_backward, bool do_pool = true) {
   check_batch(h, b, class_id);
   const int64_t N = (int64_t)b->B * b->P;
   catch_up(h, b);
@@ -258,32 +295,18 @@ static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool
     ensure_ws_generic(h, N, b->T);
     forward_generic(h, b);
   }
-  pool_stage(h, b, class_id - 1);
+  if (do_pool) pool_stage(h, b, class_id - 1);
   h->last_B = b->B;
 }
 
 // zeroGradParameters (MyOptimizer.lua:186): dense arena memset; entity rows cleared by list
 static void zero_grads(kprn_handle* h) {
-  HIP_TRY(hipMemsetAsync(h->g_dense, 0, (size_t)h->n_dense * sizeof(float), h->stream));
-  if (h->ent_grads_dirty && h->step_rows_ub > 0) {
-    // reuse pack-style clear: adagrad_rows with zero lr would touch state; use a dedicated tiny path
-    kk::clear_rows(h->stream, h->g_We, h->step_rows, h->step_count, h->step_rows_ub, h->cfg.de);
-  }
+  if (!h->dense_grads_clean) HIP_TRY(hipMemsetAsync(h->g_dense, 0, (size_t)h->n_dense * sizeof(float), h->stream));
+  if (!h->view_batch) { h->rows_view = h->step_rows; h->count_view = h->step_count; }
+  if (h->ent_grads_dirty && h->step_rows_ub > 0 && h->rows_view)
+    kk::clear_rows(h->stream, h->g_We, h->rows_view, h->count_view, h->step_rows_ub, h->cfg.de);
   h->ent_grads_dirty = false;
-}
-
-static void set_step_rows_from_batch(kprn_handle* h, const kprn_batch* b) {
-  int64_t need = std::max<int64_t>(b->n_uniq, 1);
-  if (need > h->step_rows_cap) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    dfree(h->step_rows);
-    h->step_rows_cap = need * 2;
-    h->step_rows = dalloc<int32_t>(h->step_rows_cap);
-  }
-  if (b->n_uniq > 0)
-    HIP_TRY(hipMemcpyAsync(h->step_rows, b->uniq, (size_t)b->n_uniq * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->step_count, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-  h->step_rows_ub = b->n_uniq;
+  h->dense_grads_clean = true;
 }
 
 static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
@@ -350,25 +373,39 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
   (void)D;
 }
 
+// the loss of the last backward = fixed-order sum of the loss stage's per-workgroup partials, formed on demand
+static void form_loss(kprn_handle* h) {
+  if (h->loss_pending <= 0) return;
+  kk::sum_partials(h->stream, h->loss_partial, h->loss_pending, h->d_loss);
+  h->loss_pending = 0;
+}
+
 static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int literal, float inv_batch) {
   check_batch(h, b, class_id);
   KPRN_REQUIRE(b->labels != nullptr, KPRN_E_ARG, "batch has no labels (targets are required, MyOptimizer.lua:179)");
   const kprn_config& c = h->cfg;
   zero_grads(h);
-  forward_impl(h, b, class_id, true);
+  h->dense_grads_clean = false;
+  forward_impl(h, b, class_id, true, /*do_pool=*/false);
   Workspace& w = h->ws;
   const int cid = class_id - 1;
   float invB = inv_batch > 0.f ? inv_batch : 1.0f / (float)b->B;
   if (inv_batch <= 0.f && c.world > 1) invB = 1.0f / ((float)b->B * (float)c.world);
+  const bool fusedp = use_fused(h, b, true);
   {
-    ProfScope ps(h, "bce_dscore");
-    kk::bce_and_dscore(h->stream, h->score_buf, w.pooled, w.probs, b->labels, b->B, b->P, c.C, cid, c.reducer, c.K, literal,
-                       invB, h->d_loss, w.dS);
+    // pooling + sigmoid + select + BCE + reducer backward in one launch (the nn.Linear head's weight gradient is formed by the
+    // top layer's backward kernel, fused path, or by the generic pipeline's own head backward)
+    ProfScope ps(h, "loss_stage");
+    float* gd = h->g_dense;
+    kk::loss_stage(h->stream, h->score_buf, b->labels, /*hT=*/nullptr, b->B, b->P, c.C, c.H, cid, c.reducer, c.K, literal,
+                   invB, w.pooled, w.probs, w.sel, w.dS, gd + h->off_outW + (int64_t)cid * c.H, gd + h->off_outb + cid, h->loss_partial);
+    h->loss_pending = kk::loss_partials(b->B);
   }
-  set_step_rows_from_batch(h, b);
-  if (use_fused(h, b, true)) fused::backward(h, b, cid);
+  view_step_rows(h, b);
+  if (fusedp) fused::backward(h, b, cid);
   else backward_generic(h, b, cid);
   h->ent_grads_dirty = true;
+  h->grads_serial = b->serial;
 }
 
 static void apply_update_impl(kprn_handle* h, const kprn_opt* o) {
@@ -378,15 +415,22 @@ static void apply_update_impl(kprn_handle* h, const kprn_opt* o) {
   hipStream_t s = h->stream;
   const bool reg = (o->regularize == 1);
   const bool dense_ent = reg || o->entity_update == 1;
+  if (!h->view_batch) { h->rows_view = h->step_rows; h->count_view = h->step_count; }  // (the exchange may have re-allocated the list)
+  const int32_t* rows = h->rows_view;
+  const int32_t* rcount = h->count_view;
   const float* norm2 = nullptr;
   if (reg && o->use_grad_clip) {
     ProfScope ps(h, "grad_norm");
     HIP_TRY(hipMemsetAsync(h->d_norm2, 0, sizeof(float), s));
     kk::sumsq(s, h->g_dense, h->n_dense, h->d_norm2);
-    if (h->step_rows_ub > 0) kk::sumsq_rows(s, h->g_We, h->step_rows, h->step_count, c.de, h->d_norm2);
+    if (h->step_rows_ub > 0) kk::sumsq_rows(s, h->g_We, rows, rcount, c.de, h->d_norm2);
     norm2 = h->d_norm2;
   }
   const float l2 = reg ? o->l2 : 0.f;
+  // pad rows of the dense arena: re-zeroed by the dense kernels right after the update (zeroPadTokens, MyOptimizer.lua:219)
+  const int64_t z0 = h->off_Wt + (int64_t)(c.Vt - 1) * c.dt, z1 = h->off_Wr + (int64_t)(c.Vr - 1) * c.dr;
+  const int64_t pad_row = (int64_t)c.Ve - 1;
+  bool pad_done = false;
   if (o->method == 1) {
     h->last_b1 = o->beta1; h->last_b2 = o->beta2; h->last_eps = o->eps;
     if (dense_ent && !h->ent_dense_mode) { flush_lazy(h); h->ent_dense_mode = true; }
@@ -399,41 +443,50 @@ static void apply_update_impl(kprn_handle* h, const kprn_opt* o) {
     step_tab_reserve(h, t + 1);
     const double bc1 = 1.0 - pow((double)o->beta1, (double)t), bc2 = 1.0 - pow((double)o->beta2, (double)t);
     const float step = (float)((double)o->lr * sqrt(bc2) / bc1);
-    h->step_tab_host[t] = step;
-    HIP_TRY(hipMemcpyAsync(h->step_tab + t, h->step_tab_host + t, sizeof(float), hipMemcpyHostToDevice, s));
+    h->step_tab_host[t] = step;  // host mirror (table growth); the device entry is written by the dense kernel
     {
       ProfScope ps(h, "adam_dense");
-      kk::adam_dense(s, h->dense, h->g_dense, h->s1_dense, h->s2_dense, h->n_dense, step, o->beta1, o->beta2, o->eps, norm2, o->grad_clip_norm, l2);
+      kk::adam_dense(s, h->dense, h->g_dense, h->s1_dense, h->s2_dense, h->n_dense, step, o->beta1, o->beta2, o->eps, norm2, o->grad_clip_norm, l2,
+                     /*consume=*/1, z0, c.dt, z1, c.dr, h->step_tab + t);
     }
     if (dense_ent) {
       ProfScope ps(h, "adam_entity_dense");
-      kk::adam_dense(s, h->We, h->g_We, h->s1_We, h->s2_We, h->n_ent, step, o->beta1, o->beta2, o->eps, norm2, o->grad_clip_norm, l2);
-      if (h->step_rows_ub > 0) kk::clear_rows(s, h->g_We, h->step_rows, h->step_count, h->step_rows_ub, c.de);
+      kk::adam_dense(s, h->We, h->g_We, h->s1_We, h->s2_We, h->n_ent, step, o->beta1, o->beta2, o->eps, norm2, o->grad_clip_norm, l2,
+                     /*consume=*/0, pad_row * c.de, c.de, 0, 0, nullptr);
+      if (h->step_rows_ub > 0) kk::clear_rows(s, h->g_We, rows, rcount, h->step_rows_ub, c.de);
+      pad_done = true;
     } else {
       ProfScope ps(h, "adam_entity_rows");
-      kk::adam_rows(s, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, h->step_rows, h->step_count, h->step_rows_ub, c.de, (int32_t)t, 1,
-                    h->step_tab, o->beta1, o->beta2, o->eps);
+      kk::adam_rows(s, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, rows, rcount, h->step_rows_ub, c.de, (int32_t)t, 1,
+                    h->step_tab, o->beta1, o->beta2, o->eps, pad_row);
       h->lazy_pending = true;
+      pad_done = h->pad_clean;  // the pad row is re-zeroed whenever the row update touches it; untouched it stays what it was
     }
   } else {
     const float clr = (float)((double)o->lr / (1.0 + (double)h->opt_step * (double)o->lr_decay));
     {
       ProfScope ps(h, "adagrad_dense");
-      kk::adagrad_dense(s, h->dense, h->g_dense, h->s1_dense, h->n_dense, clr, norm2, o->grad_clip_norm, l2);
+      kk::adagrad_dense(s, h->dense, h->g_dense, h->s1_dense, h->n_dense, clr, norm2, o->grad_clip_norm, l2, /*consume=*/1, z0, c.dt, z1, c.dr);
     }
     if (reg) {
       ProfScope ps(h, "adagrad_entity_dense");
-      kk::adagrad_dense(s, h->We, h->g_We, h->s1_We, h->n_ent, clr, norm2, o->grad_clip_norm, l2);
-      if (h->step_rows_ub > 0) kk::clear_rows(s, h->g_We, h->step_rows, h->step_count, h->step_rows_ub, c.de);
+      kk::adagrad_dense(s, h->We, h->g_We, h->s1_We, h->n_ent, clr, norm2, o->grad_clip_norm, l2, /*consume=*/0, pad_row * c.de, c.de, 0, 0);
+      if (h->step_rows_ub > 0) kk::clear_rows(s, h->g_We, rows, rcount, h->step_rows_ub, c.de);
+      pad_done = true;
     } else {
       ProfScope ps(h, "adagrad_entity_rows");
-      kk::adagrad_rows(s, h->We, h->g_We, h->s1_We, h->step_rows, h->step_count, h->step_rows_ub, c.de, clr);
+      kk::adagrad_rows(s, h->We, h->g_We, h->s1_We, rows, rcount, h->step_rows_ub, c.de, clr, pad_row);
+      pad_done = h->pad_clean;
     }
     h->opt_step += 1;
   }
   h->ent_grads_dirty = false;
+  h->dense_grads_clean = true;
   h->opt_method = o->method;
-  zero_pad_tokens(h);   // MyOptimizer.lua:219
+  if (pad_done) h->pad_clean = true;
+  else zero_pad_tokens(h);   // MyOptimizer.lua:219
+  // the rows this step updated are current; if they were one batch's rows, a forward over that batch needs no catch-up
+  h->caught_serial = h->grads_serial; h->caught_step = h->opt_step;
   fused::params_changed(h);
 }
 
@@ -526,13 +579,14 @@ void kprn_destroy(kprn_handle* h) {
   prof_drain(h);
   fused::release(h);
   if (h->bidx_scratch) { hipFree(h->bidx_scratch); h->bidx_scratch = nullptr; }
+  dfree(h->loss_partial);
   for (auto e : h->event_pool) hipEventDestroy(e);
   Workspace& w = h->ws;
   for (float** p : {&w.X, &w.Hs, &w.Cs, &w.ACT, &w.dA, &w.dIn, &w.dH, &w.dC, &w.S, &w.dS, &w.pooled, &w.probs, &w.sel, &w.dy}) dfree(*p);
   for (float** p : {&h->dense, &h->g_dense, &h->s1_dense, &h->s2_dense, &h->We, &h->g_We, &h->s1_We, &h->s2_We, &h->d_loss, &h->d_norm2,
-                    &h->step_tab, &h->pack_rows})
+                    &h->step_tab})
     dfree(*p);
-  for (int32_t** p : {&h->We_last, &h->We_stamp, &h->d_flag, &h->step_rows, &h->step_count, &h->pack_ids, &h->pack_count}) dfree(*p);
+  for (int32_t** p : {&h->We_last, &h->We_stamp, &h->d_flag, &h->step_rows, &h->step_count, &h->pack_buf}) dfree(*p);
   if (h->step_tab_host) hipHostFree(h->step_tab_host);
   if (h->h_pinned) hipHostFree(h->h_pinned);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -561,7 +615,7 @@ static int copy_named(kprn_handle* h, const char* name, float* dst, const float*
     HIP_TRY(hipMemcpyAsync(dst, base, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   } else {
     HIP_TRY(hipMemcpyAsync(base, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    fused::params_changed(h);
+    if (which == 0) params_touched(h);
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   API_END(h)
@@ -589,7 +643,7 @@ static int copy_flat(kprn_handle* h, float* dst, const float* src, int64_t n, in
     if (dst) HIP_TRY(hipMemcpyAsync(dst + p.flat_off, base, bytes, hipMemcpyDeviceToHost, h->stream));
     else HIP_TRY(hipMemcpyAsync(base, src + p.flat_off, bytes, hipMemcpyHostToDevice, h->stream));
   }
-  if (!dst) fused::params_changed(h);
+  if (!dst) params_touched(h);
   HIP_TRY(hipStreamSynchronize(h->stream));
   API_END(h)
 }
@@ -654,15 +708,28 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
     delete b;
     throw;
   }
+  b->serial = h->next_serial++;
   *out = b;
   API_END(h)
 }
 
 void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
   if (!b) return;
-  if (h) { hipSetDevice(h->cfg.device_id); hipStreamSynchronize(h->stream); }
+  if (h) {
+    hipSetDevice(h->cfg.device_id);
+    if (h->view_batch == b) { try { materialize_step_rows(h); } catch (...) { h->view_batch = nullptr; h->rows_view = nullptr; h->step_rows_ub = 0; } }
+    if (h->caught_serial == b->serial) h->caught_serial = -1;
+    hipStreamSynchronize(h->stream);
+  }
   dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->key_sorted); dfree(b->pos_sorted);
   delete b;
+}
+
+int kprn_batch_distinct_rows(kprn_handle* h, const kprn_batch* b, int32_t* n) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(b && n, KPRN_E_ARG, "NULL argument");
+  *n = b->n_uniq;
+  API_END(h)
 }
 
 int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id) {
@@ -732,7 +799,9 @@ int kprn_backward_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, i
   API_BEGIN(h)
   backward_impl(h, b, class_id, bce_literal, inv_batch);
   if (loss) {
-    HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    form_loss(h);
+    form_loss(h);
+  HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     prof_drain(h);
   }
@@ -750,12 +819,13 @@ int kprn_train_step_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id,
   KPRN_REQUIRE(opt, KPRN_E_ARG, "opt is NULL");
   check_batch(h, b, class_id);
   catch_up(h, b);
-  zero_pad_tokens(h);  // MyOptimizer.lua:181
-  fused::params_changed(h);
+  if (!h->pad_clean) { zero_pad_tokens(h); fused::params_changed(h); }  // MyOptimizer.lua:181 (a no-op when the last step left them zero)
   backward_impl(h, b, class_id, opt->bce_literal, 0.f);
   apply_update_impl(h, opt);
   if (loss) {
-    HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    form_loss(h);
+    form_loss(h);
+  HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     prof_drain(h);
   }
@@ -779,6 +849,7 @@ int kprn_train_step(kprn_handle* h, const int32_t* idx, int32_t B, int32_t P, in
 int kprn_read_loss(kprn_handle* h, float* loss) {
   API_BEGIN(h)
   KPRN_REQUIRE(loss, KPRN_E_ARG, "loss is NULL");
+  form_loss(h);
   HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   prof_drain(h);
@@ -808,53 +879,63 @@ int kprn_sparse_grad_capacity(kprn_handle* h, int32_t* max_rows) {
   API_END(h)
 }
 
-int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_ids, void** dev_rows, void** dev_count) {
+int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int64_t* n_words) {
   API_BEGIN(h)
-  KPRN_REQUIRE(dev_ids && dev_rows && dev_count, KPRN_E_ARG, "NULL argument");
+  KPRN_REQUIRE(dev_buf && n_words, KPRN_E_ARG, "NULL argument");
   KPRN_REQUIRE(capacity >= h->step_rows_ub && capacity > 0, KPRN_E_ARG, "capacity smaller than this step's touched-row count");
+  const int de = h->cfg.de;
+  const int64_t words = 4 + (int64_t)capacity * (1 + de);
   if (capacity > h->pack_cap) {
     HIP_TRY(hipStreamSynchronize(h->stream));
-    dfree(h->pack_ids); dfree(h->pack_rows); dfree(h->pack_count);
-    h->pack_ids = dalloc<int32_t>(capacity);
-    h->pack_rows = dalloc<float>((int64_t)capacity * h->cfg.de);
-    h->pack_count = dalloc<int32_t>(4);
+    dfree(h->pack_buf);
+    h->pack_buf = dalloc<int32_t>(words);
     h->pack_cap = capacity;
   }
+  if (!h->view_batch) { h->rows_view = h->step_rows; h->count_view = h->step_count; }
   {
     ProfScope ps(h, "dp_pack_rows");
-    kk::pack_rows(h->stream, h->g_We, h->step_rows, h->step_count, h->step_rows_ub, h->cfg.de, h->pack_ids, h->pack_rows, h->pack_count);
+    kk::pack_rows(h->stream, h->g_We, h->rows_view, h->count_view, h->step_rows_ub, de, h->pack_buf + 4, (float*)(h->pack_buf + 4 + capacity),
+                  h->pack_buf);
   }
-  // the per-step list is rebuilt as the union over ranks by kprn_sparse_grad_unpack_add
-  HIP_TRY(hipMemsetAsync(h->step_count, 0, sizeof(int32_t), h->stream));
-  h->step_rows_ub = 0;
-  h->step_tag = h->next_tag++;
-  *dev_ids = h->pack_ids; *dev_rows = h->pack_rows; *dev_count = h->pack_count;
+  *dev_buf = h->pack_buf;
+  *n_words = 4 + (int64_t)h->pack_cap * (1 + de);
   API_END(h)
 }
 
-int kprn_sparse_grad_unpack_add(kprn_handle* h, const void* dev_ids, const void* dev_rows, const void* dev_count, int32_t capacity) {
+int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, int32_t capacity) {
   API_BEGIN(h)
-  KPRN_REQUIRE(dev_ids && dev_rows && dev_count && capacity > 0, KPRN_E_ARG, "bad argument");
-  KPRN_REQUIRE(h->step_tag != 0, KPRN_E_ARG, "kprn_sparse_grad_pack must be called first");
-  int64_t need = std::min<int64_t>(h->step_rows_ub + capacity, h->cfg.Ve);
-  if (need > h->step_rows_cap) {
+  KPRN_REQUIRE(dev_all && world > 0 && capacity > 0, KPRN_E_ARG, "bad argument");
+  KPRN_REQUIRE(capacity == h->pack_cap, KPRN_E_ARG, "capacity differs from the packed buffer's (every rank packs with the same capacity)");
+  const int64_t n = (int64_t)world * capacity;
+  if (n + 4 > h->step_rows_cap) {
     HIP_TRY(hipStreamSynchronize(h->stream));
-    int32_t* nl = dalloc<int32_t>(need * 2);
-    if (h->step_rows && h->step_rows_ub > 0)
-      HIP_TRY(hipMemcpy(nl, h->step_rows, (size_t)h->step_rows_ub * sizeof(int32_t), hipMemcpyDeviceToDevice));
     dfree(h->step_rows);
-    h->step_rows = nl; h->step_rows_cap = need * 2;
+    h->step_rows_cap = (n + 4) * 2;
+    h->step_rows = dalloc<int32_t>(h->step_rows_cap);
   }
   {
-    ProfScope ps(h, "dp_unpack_add");
-    kk::unpack_add_rows(h->stream, h->g_We, (const int32_t*)dev_ids, (const float*)dev_rows, (const int32_t*)dev_count, capacity, h->cfg.de,
-                        h->We_stamp, h->step_tag, h->step_rows, h->step_count);
+    const size_t need = bidx::merge_scratch_bytes(n, h->cfg.Ve);
+    if (need > h->bidx_scratch_bytes) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->bidx_scratch) hipFree(h->bidx_scratch);
+      h->bidx_scratch = nullptr;
+      HIP_TRY(hipMalloc(&h->bidx_scratch, need * 2));
+      h->bidx_scratch_bytes = need * 2;
+    }
   }
-  h->step_rows_ub = need;
+  {
+    ProfScope ps(h, "dp_merge_rows");
+    bidx::merge_rows(h->stream, dev_all, world, capacity, h->cfg.de, h->cfg.Ve, h->g_We, h->step_rows, h->step_count, h->bidx_scratch,
+                     h->bidx_scratch_bytes);
+  }
+  // the optimiser now walks the union of all ranks' rows (sorted); exact count on the device, upper bound here
+  h->view_batch = nullptr; h->rows_view = h->step_rows; h->count_view = h->step_count;
+  h->step_rows_ub = std::min<int64_t>(n, h->cfg.Ve);
   h->ent_grads_dirty = true;
   API_END(h)
 }
 
+/* the stream everything is queued on */
 int kprn_stream(kprn_handle* h, void** stream) {
   API_BEGIN(h)
   KPRN_REQUIRE(stream, KPRN_E_ARG, "NULL argument");

@@ -66,6 +66,7 @@ struct kprn_batch {
   int32_t* uniq = nullptr;    // device: distinct entity rows of this batch (0-based); count at uniq[uniq_cap]
   int64_t uniq_cap = 0;
   int32_t n_uniq = 0;
+  int64_t serial = 0;         // identity of this batch for the catch-up bookkeeping
   // occurrence index (batch_index.hip): all B*P*T positions sorted by entity row
   int32_t* key_sorted = nullptr;  // device [B*P*T] entity row (0-based)
   int32_t* pos_sorted = nullptr;  // device [B*P*T] position n*T + t
@@ -106,8 +107,18 @@ struct kprn_handle {
   int64_t step_rows_cap = 0;
   int64_t step_rows_ub = 0;      // host-side upper bound of *step_count
   int32_t step_tag = 0;
+  // the list the optimiser walks: the handle's own buffers, or a VIEW of a batch's distinct-row list (single-rank
+  // training: no copy; materialised before the batch can go away or the data-parallel exchange rewrites it)
+  const int32_t* rows_view = nullptr; const int32_t* count_view = nullptr; const kprn_batch* view_batch = nullptr;
+  // steady-state shortcuts (each one is a launch the previous step already did the work of)
+  bool pad_clean = false;          // the three pad rows are zero (zeroPadTokens done and nothing wrote parameters since)
+  bool dense_grads_clean = false;  // g_dense is all zero (the optimiser consumed it)
+  int64_t caught_serial = -1, caught_step = -1;  // batch whose entity rows are current to opt_step
+  int64_t grads_serial = -1;       // batch the gradients in g_We / g_dense came from
+  int64_t next_serial = 1;
+  float* loss_partial = nullptr; int64_t loss_partial_cap = 0; int loss_pending = 0;  // >0: d_loss = sum of that many partials, not formed yet
   // packing buffers for the data-parallel exchange
-  int32_t* pack_ids = nullptr; float* pack_rows = nullptr; int32_t* pack_count = nullptr; int64_t pack_cap = 0;
+  int32_t* pack_buf = nullptr; int64_t pack_cap = 0;  // {count,-,-,-, ids[cap], rows[cap*de]} 32-bit words
 
   // scalars on device
   float* d_loss = nullptr;      // [1]
@@ -148,7 +159,12 @@ void lstm_gates_bwd(hipStream_t s, const float* act, const float* c, const float
                     float* dH, float* dC, float* dA, int64_t N, int H);
 void add_bias_rows(hipStream_t s, float* Y, const float* b, int64_t rows, int cols);
 void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out);
-void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs);
+void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel);
+void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
+                int literal, float invB, float* pooled, float* probs, float* sel, float* dS, float* gW_row, float* gb_c, float* partial);
+void sum_partials(hipStream_t s, const float* partial, int n, float* out);
+int loss_partials(int B);  // number of per-workgroup loss partials the loss stage writes for B pairs
+void zero_pad3(hipStream_t s, float* a, int na, float* b, int nb, float* c, int nc);
 void select_col(hipStream_t s, const float* probs, int B, int C, int cid, float* sel);
 void bce_and_dscore(hipStream_t s, const float* S, const float* pooled, const float* probs, const float* labels, int B, int P, int C,
                     int cid, int reducer, int K, int literal, float invB, float* loss, float* dS /*[N]*/);
@@ -158,18 +174,18 @@ void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, i
 void sumsq(hipStream_t s, const float* x, int64_t n, float* out);
 void sumsq_rows(hipStream_t s, const float* G, const int32_t* rows, const int32_t* count, int d, float* out);
 // dense optimiser over a contiguous span; scale_src: device float norm2 -> clip factor computed in-kernel
-void adam_dense(hipStream_t s, float* x, const float* g, float* m, float* v, int64_t n, float step, float b1, float b2, float eps,
-                const float* norm2, float clip, float l2);
-void adagrad_dense(hipStream_t s, float* x, const float* g, float* G, int64_t n, float clr, const float* norm2, float clip, float l2);
+// consume: zero the gradient as it is used; [z0,z0+zn0), [z1,z1+zn1): pad rows re-zeroed after the update; tab_slot: device step table entry
+void adam_dense(hipStream_t s, float* x, float* g, float* m, float* v, int64_t n, float step, float b1, float b2, float eps,
+                const float* norm2, float clip, float l2, int consume, int64_t z0, int zn0, int64_t z1, int zn1, float* tab_slot);
+void adagrad_dense(hipStream_t s, float* x, float* g, float* G, int64_t n, float clr, const float* norm2, float clip, float l2, int consume,
+                   int64_t z0, int zn0, int64_t z1, int zn1);
 // lazy-exact row update of the entity table
 void adam_rows(hipStream_t s, float* W, float* g, float* m, float* v, int32_t* last, const int32_t* rows, const int32_t* count, int64_t max_rows,
-               int d, int32_t t_now, int apply_step, const float* step_tab, float b1, float b2, float eps);
-void adam_flush_all(hipStream_t s, float* W, float* m, float* v, int32_t* last, int64_t V, int d, int32_t t_now, const float* step_tab, float b1, float b2, float eps);
-void adagrad_rows(hipStream_t s, float* W, float* g, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, float clr);
+               int d, int32_t t_now, int apply_step, const float* step_tab, float b1, float b2, float eps, int64_t pad_row);
+void adam_flush_all(hipStream_t s, float* W, float* m, float* v, int32_t* last, int64_t V, int d, int32_t t_now, const float* step_tab, float b1, float b2, float eps, int64_t pad_row);
+void adagrad_rows(hipStream_t s, float* W, float* g, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, float clr, int64_t pad_row);
 void zero_rows(hipStream_t s, float* W, int64_t row, int d);
 void pack_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, int32_t* ids_out, float* rows_out, int32_t* count_out);
-void unpack_add_rows(hipStream_t s, float* G, const int32_t* ids, const float* rows, const int32_t* count, int64_t max_rows, int d,
-                     int32_t* stamp, int32_t tag, int32_t* list, int32_t* list_count);
 void fill_uniform(hipStream_t s, float* x, int64_t n, float a, uint64_t seed, uint64_t offset);
 void fill_i32(hipStream_t s, int32_t* x, int64_t n, int32_t v);
 void tile_leaders(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int32_t* lead);
@@ -182,6 +198,9 @@ size_t scratch_bytes(int64_t nsteps, int Ve);
 // uniq: sorted distinct entity rows; *n_uniq_dev: their count
 void build(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int Ve, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq,
            int32_t* n_uniq_dev, void* scratch, size_t scratch_sz);
+size_t merge_scratch_bytes(int64_t n, int Ve);
+void merge_rows(hipStream_t s, const void* all, int world, int cap, int de, int Ve, float* G, int32_t* union_rows, int32_t* union_count,
+                void* scratch, size_t scratch_sz);
 }  // namespace bidx
 
 // ---- GEMM (gemm_f32.hip): C[M,N] (+)= A(M,K) * B(K,N), arbitrary strides, fp32 MFMA -----------

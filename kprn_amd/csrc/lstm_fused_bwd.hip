@@ -32,7 +32,9 @@ struct BwdArgs {
   const float* WiT;        // [64][256]  = W_i2g^T of this layer
   const float* WoT;        // [64][256]
   const float* save_frag;  // forward's fragment-order saves: [(N/16)][T][L][4 waves][NPL][64 lanes][4]
-  const float* dHhead;     // [N][64] (top layer) or null
+  const float* dS;         // [N] top layer: d loss / d S[n][classId]; the head backward dh_T = dS[n] W_out[classId][:] is formed in-kernel
+  const float* wout_row;   // W_out[classId][0..64)
+  float* gWout_row; float* gbout_c;  // top layer: gradient of W_out[classId][:] and b_out[classId] (sum_n dS[n] h_T[n][:], sum_n dS[n])
   float* DX;               // [(Npad/16)][T][4 waves][64 lanes][4] fragment order: in = dx of the layer above (not top), out = dx of this layer (not bottom)
   int64_t Npad;            // N rounded up to the 64-row tile
   float* gWi; float* gbi; float* gWo;   // [256][64], [256], [256][64]
@@ -110,6 +112,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   f32x4 acc_s = f32x4{0.f, 0.f, 0.f, 0.f}, acc_s2 = f32x4{0.f, 0.f, 0.f, 0.f};
   GatherSrc gsrc;
   if (BOTTOM) gsrc = gather_src(a);
+  const float wout_c = TOP ? a.wout_row[j * 16 + arow] : 0.f;
+  float gwo = 0.f, gbo = 0.f;  // head gradient partials of this lane: column 16j + arow over its rows / sum of dS over its rows
   TPROBE(0)
 
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -123,11 +127,17 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     for (int m = 0; m < 4; ++m) {
       dc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       dh[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (TOP) {  // recurrent dh starts at the head gradient
+      if (TOP) {
+        // nn.Linear(H,46) backward restricted to the selected column (OneModel.lua:275, MyOptimizer.lua:126): the recurrent
+        // dh starts at dS[n] W_out[cid][:], and gW_out[cid][:] += dS[n] h_T[n][:] straight from the saved h fragment
+        const f32x4 hf = *(const f32x4*)(frag_tile + m * frag_mt_stride + ((int64_t)((T - 1) * L + ly) * 4 + j) * frag_unit + 6 * 256);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t n = n0 + m * 16 + ag * 4 + r;
-          if (n < a.N) dh[m][r] = a.dHhead[n * DH + j * 16 + arow];
+          const float d = (n < a.N) ? a.dS[n] : 0.f;
+          dh[m][r] = d * wout_c;
+          gwo += d * hf[r];
+          gbo += d;
         }
       }
     }
@@ -326,6 +336,16 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       if (wcls == 0) { if (v < a.Vt) unsafeAtomicAdd(a.gWt + (int64_t)v * a.dt + col, acc_s[r]); }
       else { if (v < a.Vr) unsafeAtomicAdd(a.gWr + (int64_t)v * a.dr + (col - a.dt - a.de), acc_s[r]); }
     }
+  }
+  if (TOP) {
+    float v = gwo;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (ag == 0) unsafeAtomicAdd(a.gWout_row + j * 16 + arow, v);
+    float bsum = gbo;
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (j == 0 && lane == 0) unsafeAtomicAdd(a.gbout_c, bsum);
   }
   TPROBE(6)  // flush
   if (a.timing && tid == 0) {
@@ -527,27 +547,31 @@ __global__ __launch_bounds__(256) void k_reduce_small(const float* __restrict__ 
   }
 }
 
-// gW_i2g / gW_o2g / gb += sum over workgroup slabs
-__global__ void k_reduce_partials(const float* __restrict__ part, int nslab, float* __restrict__ gWi, float* __restrict__ gWo, float* __restrict__ gbi) {
+// gW_i2g / gW_o2g / gb += sum over workgroup slabs, every layer in one launch (blockIdx.z = layer)
+struct ReduceArgs { const float* part[2]; float* gWi[2]; float* gWo[2]; float* gbi[2]; int nslab; };
+__global__ void k_reduce_partials(ReduceArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= PART) return;
+  const int l = blockIdx.z;
+  const float* __restrict__ part = a.part[l];
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int s = blockIdx.y * 4; s < nslab; s += gridDim.y * 4) {
+  for (int s = blockIdx.y * 4; s < a.nslab; s += gridDim.y * 4) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (s + u < nslab) acc[u] += part[(int64_t)(s + u) * PART + i];
+    for (int u = 0; u < 4; ++u) if (s + u < a.nslab) acc[u] += part[(int64_t)(s + u) * PART + i];
   }
   const float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-  if (i < 256 * 64) unsafeAtomicAdd(gWi + i, v);
-  else if (i < 2 * 256 * 64) unsafeAtomicAdd(gWo + (i - 256 * 64), v);
-  else unsafeAtomicAdd(gbi + (i - 2 * 256 * 64), v);
+  if (i < 256 * 64) unsafeAtomicAdd(a.gWi[l] + i, v);
+  else if (i < 2 * 256 * 64) unsafeAtomicAdd(a.gWo[l] + (i - 256 * 64), v);
+  else unsafeAtomicAdd(a.gbi[l] + (i - 2 * 256 * 64), v);
 }
 
-// WT[n][k] = W[k][n] for a [256][64] weight
-__global__ void k_transpose_256x64(const float* __restrict__ W, float* __restrict__ WT) {
+// WT[n][k] = W[k][n] for the [256][64] weights of every layer in one launch (blockIdx.y = matrix)
+struct TransArgs { const float* W[4]; float* WT[4]; };
+__global__ void k_transpose_256x64(TransArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 64*256 outputs
   if (i >= 64 * 256) return;
   const int n = i >> 8, k = i & 255;
-  WT[i] = W[k * 64 + n];
+  a.WT[blockIdx.y][i] = a.W[blockIdx.y][k * 64 + n];
 }
 
 // ---- host side ----
@@ -571,33 +595,29 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   hipStream_t strm = h->stream;
   if (N > s->cap_Nb || T > s->cap_Tb) {
     HIP_TRY(hipStreamSynchronize(strm));
-    if (s->dHhead) hipFree(s->dHhead);
     if (s->DX) hipFree(s->DX);
     const int64_t cn = std::max<int64_t>(N, s->cap_Nb);
     const int ct = std::max(T, s->cap_Tb);
-    HIP_TRY(hipMalloc((void**)&s->dHhead, (size_t)(cn + 64) * DH * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&s->DX, (size_t)ct * (cn + 2 * MT) * DH * sizeof(float)));
     s->cap_Nb = cn; s->cap_Tb = ct;
   }
   if (!s->WT) HIP_TRY(hipMalloc((void**)&s->WT, (size_t)2 * 2 * 64 * 256 * sizeof(float)));
-  if (!s->part) HIP_TRY(hipMalloc((void**)&s->part, (size_t)s->num_cu * PART * sizeof(float)));
+  if (!s->part) HIP_TRY(hipMalloc((void**)&s->part, (size_t)2 * s->num_cu * PART * sizeof(float)));  // one slab set per layer
   static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
   if (want_timing && !s->timing) HIP_TRY(hipMalloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
   if (s->wt_dirty) {
     ProfScope ps(h, "weight_transpose");
-    for (int l = 0; l < L; ++l) {
-      hipLaunchKernelGGL(k_transpose_256x64, dim3(64), dim3(256), 0, strm, h->dense + h->layer[l].Wi, s->WT + (size_t)(l * 2 + 0) * 64 * 256);
-      hipLaunchKernelGGL(k_transpose_256x64, dim3(64), dim3(256), 0, strm, h->dense + h->layer[l].Wo, s->WT + (size_t)(l * 2 + 1) * 64 * 256);
+    TransArgs ta;
+    for (int l = 0; l < 2; ++l) {
+      const int ll = l < L ? l : 0;
+      ta.W[l * 2 + 0] = h->dense + h->layer[ll].Wi; ta.WT[l * 2 + 0] = s->WT + (size_t)(ll * 2 + 0) * 64 * 256;
+      ta.W[l * 2 + 1] = h->dense + h->layer[ll].Wo; ta.WT[l * 2 + 1] = s->WT + (size_t)(ll * 2 + 1) * 64 * 256;
     }
+    hipLaunchKernelGGL(k_transpose_256x64, dim3(64, 2 * L), dim3(256), 0, strm, ta);
     HIP_TRY(hipGetLastError());
     s->wt_dirty = false;
   }
   float* gd = h->g_dense;
-  {
-    ProfScope ps(h, "head_bwd");
-    const float* hT = s->save_h;  // h_T of the top layer, [N][64]
-    kk::head_bwd(strm, h->ws.dS, hT, h->dense + h->off_outW, N, DH, cid, s->dHhead, gd + h->off_outW, gd + h->off_outb);
-  }
   const int64_t n_tiles = (N + MT - 1) / MT;
   const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)s->num_cu);
   for (int l = L - 1; l >= 0; --l) {
@@ -607,11 +627,12 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     a.dt = c.dt; a.de = c.de; a.dr = c.dr; a.Vt = c.Vt; a.Vr = c.Vr;
     a.L = L; a.layer = l;
     a.WiT = s->WT + (size_t)(l * 2 + 0) * 64 * 256; a.WoT = s->WT + (size_t)(l * 2 + 1) * 64 * 256;
-    a.save_frag = s->save_frag; a.dHhead = s->dHhead; a.DX = s->DX; a.Npad = n_tiles * MT;
+    a.save_frag = s->save_frag; a.dS = h->ws.dS; a.wout_row = h->dense + h->off_outW + (int64_t)cid * DH; a.DX = s->DX;
+    a.gWout_row = gd + h->off_outW + (int64_t)cid * DH; a.gbout_c = gd + h->off_outb + cid; a.Npad = n_tiles * MT;
     a.gWi = gd + h->layer[l].Wi; a.gbi = gd + h->layer[l].bi; a.gWo = gd + h->layer[l].Wo;
     a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
     a.n_tiles = n_tiles;
-    a.part = s->part; a.timing = s->timing;
+    a.part = s->part + (size_t)l * s->num_cu * PART; a.timing = s->timing;
     { static const char* d = getenv("KPRN_DBG"); a.dbg = d ? atoi(d) : 0; }
     const bool bottom = (l == 0), top = (l == L - 1);
     // small tables inside the bottom kernel (one-hot MFMA) when the shapes allow, else the general scatter kernel
@@ -657,11 +678,6 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       if (slabs) hipLaunchKernelGGL(k_reduce_small, dim3((n_small + 15) / 16), dim3(256), 0, strm, s->part_small, sgrid, n_small, c.Vt * c.dt, sa.gWt, sa.gWr);
       HIP_TRY(hipGetLastError());
     }
-    {
-      ProfScope ps(h, "dw_reduce");
-      hipLaunchKernelGGL(k_reduce_partials, dim3((PART + 255) / 256, 16), dim3(256), 0, strm, s->part, grid, a.gWi, a.gWo, a.gbi);
-      HIP_TRY(hipGetLastError());
-    }
     if (s->timing) {
       HIP_TRY(hipStreamSynchronize(strm));
       std::vector<unsigned long long> tb((size_t)grid * 8);
@@ -672,6 +688,18 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
               l, (long long)N, grid, sum[0] / grid, sum[1] / grid, sum[7] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid);
     }
   }
+  {
+    ProfScope ps(h, "dw_reduce");
+    ReduceArgs ra;
+    for (int l = 0; l < 2; ++l) {
+      const int ll = l < L ? l : 0;
+      ra.part[l] = s->part + (size_t)ll * s->num_cu * PART;
+      ra.gWi[l] = gd + h->layer[ll].Wi; ra.gWo[l] = gd + h->layer[ll].Wo; ra.gbi[l] = gd + h->layer[ll].bi;
+    }
+    ra.nslab = grid;
+    hipLaunchKernelGGL(k_reduce_partials, dim3((PART + 255) / 256, 16, L), dim3(256), 0, strm, ra);
+    HIP_TRY(hipGetLastError());
+  }
 }
 
 void params_changed(kprn_handle* h) { if (h->fused_state) ((State*)h->fused_state)->wt_dirty = true; }
@@ -679,7 +707,7 @@ void params_changed(kprn_handle* h) { if (h->fused_state) ((State*)h->fused_stat
 void release(kprn_handle* h) {
   State* s = (State*)h->fused_state;
   if (!s) return;
-  for (float* p : {s->save_frag, s->save_h, s->WT, s->dHhead, s->DX, s->part, s->part_small}) if (p) hipFree(p);
+  for (float* p : {s->save_frag, s->WT, s->DX, s->part, s->part_small}) if (p) hipFree(p);
   if (s->timing) hipFree(s->timing);
   delete s;
   h->fused_state = nullptr;

@@ -31,7 +31,6 @@ struct FwdArgs {
   int C;
   float* S;          // [N][C]
   float* save_frag;  // training: [(N/16)][T][L][4 waves][NPL][64 lanes][4]   (nullable)
-  float* save_h;     // training: h_T of the top layer, [N][H] row-major (head backward)   (nullable)
   int64_t n_tiles;
   unsigned long long* timing;  // optional [grid][8] cycle counters (KPRN_TIMING=1)
 };
@@ -161,15 +160,13 @@ constexpr int NPL = 7;
 // ---- host-side state shared by forward() and backward() ----
 struct State {
   float* save_frag = nullptr;
-  float* save_h = nullptr;
   int64_t cap_N = 0;
   int cap_T = 0;
   int num_cu = 0;
   float* WT = nullptr;      // [L][2][64][256]
   bool wt_dirty = true;
-  float* dHhead = nullptr;  // [N][64]
   float* DX = nullptr;      // [T][N][64]
-  float* part = nullptr;    // [num_cu][PART]
+  float* part = nullptr;    // [L][num_cu][PART]
   float* part_small = nullptr;  // [8 num_cu][Vt*dt + Vr*dr] small-table partials of the embedding scatter
   int part_small_n = 0;
   unsigned long long* timing = nullptr;  // [num_cu][8] when KPRN_TIMING=1

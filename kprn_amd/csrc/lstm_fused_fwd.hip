@@ -258,20 +258,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 #pragma unroll
     for (int k = 0; k < NPL; ++k) *(f32x4*)(fb + k * 256) = sv[k];
   };
-  // training: h_T rows of the top layer -> save_h[n][:] row-major (head backward), coalesced 16-byte stores
-  auto copy_h = [&](int64_t f_tile, int f_t, int l, const float* hb) {
-    if (!SAVE) return;
-    if (l != L - 1 || f_t != T - 1) return;
-    float* dst = a.save_h + f_tile * MT * DH;
-    const int64_t rows_valid = a.N - f_tile * MT;
-#pragma unroll
-    for (int k = 0; k < 1024 / NT; ++k) {
-      const int cch = threadIdx.x + k * NT;
-      const int row = cch >> 4, ch = cch & 15;
-      if (row < rows_valid) *(f32x4*)(dst + row * DH + ch * 4) = *(const f32x4*)(hb + row * LDA + ch * 4);
-    }
-  };
-
   auto slot = [&](auto first_tag, const int64_t tile, const int t, const int par, const bool has_prev, const int64_t p_tile, const int p_t,
                   const bool p_first) {
     constexpr bool FIRST = decltype(first_tag)::value;
@@ -304,7 +290,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
           save_unit(q_tile, q_t, pl, pm);
           if (mt == 0) {
             lds_barrier();
-            copy_h(q_tile, q_t, pl, hbuf(pl, q_par));
             apre = *(const f32x4*)(in_base);
           }
           half_unit<SAVE, false, false, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
@@ -315,7 +300,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
             save_unit(q_tile, q_t, pl, pm);
           }
           lds_barrier();
-          if (!cross || has_prev) copy_h(q_tile, q_t, pl, hbuf(pl, q_par));
           if (cross && has_prev) head_tile(a, hbuf(L - 1, q_par), p_tile, j, lane);
           apre = *(const f32x4*)(in_base);
           half_unit<SAVE, false, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
@@ -365,7 +349,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
     cell_all<SAVE>(accs[1], c[L - 1][3], p_t == 0, hbuf(L - 1, par) + 3 * 16 * LDA + o_off, sv);
     save_unit(p_tile, p_t, L - 1, 3);
     lds_barrier();
-    copy_h(p_tile, p_t, L - 1, hbuf(L - 1, par));
     head_tile(a, hbuf(L - 1, par), p_tile, j, lane);
   }
   FPROBE(5)  // drain
@@ -409,20 +392,18 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   a.Wout = h->dense + h->off_outW; a.bout = h->dense + h->off_outb; a.C = c.C;
   a.S = h->ws.S;
   a.n_tiles = (N + MT - 1) / MT;
-  a.save_frag = nullptr; a.save_h = nullptr;
+  a.save_frag = nullptr;
   if (save) {
     if (N > s->cap_N || b->T > s->cap_T) {
       HIP_TRY(hipStreamSynchronize(h->stream));
       if (s->save_frag) hipFree(s->save_frag);
-      if (s->save_h) hipFree(s->save_h);
       const int64_t cn = std::max<int64_t>(N, s->cap_N);
       const int ct = std::max(b->T, s->cap_T);
       const int64_t mts = (cn + 15) / 16 + 4;
       HIP_TRY(hipMalloc((void**)&s->save_frag, (size_t)mts * ct * c.L * 4 * NPL * 256 * sizeof(float)));
-      HIP_TRY(hipMalloc((void**)&s->save_h, (size_t)(cn + 64) * DH * sizeof(float)));
       s->cap_N = cn; s->cap_T = ct;
     }
-    a.save_frag = s->save_frag; a.save_h = s->save_h;
+    a.save_frag = s->save_frag;
   }
   const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)s->num_cu);
   static const bool want_timing = getenv("KPRN_TIMING") != nullptr;

@@ -9,9 +9,10 @@ independent units: model/module/MapReduce.lua:24-47 never mixes them).  Per step
      1/B_global (the mean over the global minibatch, nn.BCECriterion sizeAverage);
   2. dense gradients (type/relation tables, LSTM, head: ONE contiguous device buffer, ~0.3 MB
      for D=H=64,L=2) -> one all-reduce(sum);
-  3. entity-table gradients are row-sparse -> each rank packs (row id, grad row) for the rows it
-     touched, one all-gather of fixed-capacity buffers, then every rank adds ALL ranks' rows in
-     rank order (identical addition order everywhere => replicas stay bit-identical);
+  3. entity-table gradients are row-sparse -> each rank packs {count, row ids, grad rows} of the rows it
+     touched into ONE fixed-capacity buffer, ONE all-gather, then every rank merges all ranks' rows:
+     union of the ids by a stable sort, sums in rank order (identical addition order everywhere =>
+     replicas stay bit-identical);
   4. the optimiser step runs locally on the summed gradient (MyOptimizer.lua:196-219).
 
 The collective calls only see an "adapter" that exposes the engine's buffers as torch tensors,
@@ -55,12 +56,11 @@ class GpuAdapter:
         return self.e.sparse_grad_capacity()
 
     def pack(self, capacity):
-        ids, rows, cnt = self.e.sparse_grad_pack(capacity)
-        return (wrap_device(ids, capacity, "i32", self.device), wrap_device(rows, capacity * self.de, "f32", self.device),
-                wrap_device(cnt, 1, "i32", self.device))
+        ptr, n_words = self.e.sparse_grad_pack(capacity)
+        return wrap_device(ptr, n_words, "i32", self.device)
 
-    def unpack_add(self, ids, rows, cnt, capacity):
-        self.e.sparse_grad_unpack_add(ids.data_ptr(), rows.data_ptr(), cnt.data_ptr(), capacity)
+    def merge(self, all_buf, world, capacity):
+        self.e.sparse_grad_merge(all_buf.data_ptr(), world, capacity)
 
     def apply_update(self, opt):
         self.e.apply_update(opt)
@@ -79,7 +79,7 @@ class DataParallel:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.capacity = 0
-        self._bufs = None
+        self._all = None
 
     def set_capacity(self, local_max_rows):
         """fixed per-rank packing capacity = max over ranks of the largest per-step touched-row count."""
@@ -89,8 +89,7 @@ class DataParallel:
                 t = t.to(self.a.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         self.capacity = max(1, int(t.item()))
-        a, w, cap = self.a, self.world, self.capacity
-        self._bufs = (a.new(w * cap, torch.int32), a.new(w * cap * a.de, torch.float32), a.new(w, torch.int32))
+        self._all = None
         return self.capacity
 
     def train_step(self, batch, opt, class_id=1, global_pairs=None):
@@ -104,17 +103,14 @@ class DataParallel:
         if self.capacity <= 0:
             self.set_capacity(a.local_rows())
         cap = self.capacity
-        ids, rows, cnt = a.pack(cap)
-        ids_all, rows_all, cnt_all = self._bufs
+        buf = a.pack(cap)  # one packed tensor per rank, same length everywhere
+        if self._all is None or self._all.numel() != buf.numel() * self.world or self._all.dtype != buf.dtype:
+            self._all = torch.empty(buf.numel() * self.world, dtype=buf.dtype, device=buf.device)
         if self.world > 1:
-            dist.all_gather_into_tensor(ids_all, ids, group=self.group)
-            dist.all_gather_into_tensor(rows_all, rows, group=self.group)
-            dist.all_gather_into_tensor(cnt_all, cnt, group=self.group)
+            dist.all_gather_into_tensor(self._all, buf, group=self.group)
         else:
-            ids_all.copy_(ids); rows_all.copy_(rows); cnt_all.copy_(cnt)
-        de = a.de
-        for r in range(self.world):  # rank order => same addition order on every replica
-            a.unpack_add(ids_all[r * cap:(r + 1) * cap], rows_all[r * cap * de:(r + 1) * cap * de], cnt_all[r:r + 1], cap)
+            self._all.copy_(buf)
+        a.merge(self._all, self.world, cap)  # union of the rows, summed in rank order
         a.apply_update(opt)
 
 

@@ -1,7 +1,7 @@
 """Data-parallel step (kprn_amd/dp.py) on CPU: world_size 2, gloo, 127.0.0.1.
 
 The collective logic -- loss scaled by the GLOBAL batch, dense all-reduce, fixed-capacity sparse
-row all-gather, rank-ordered unpack, local optimiser step -- is exercised with a numpy adapter that
+row all-gather, rank-ordered merge, local optimiser step -- is exercised with a numpy adapter that
 gets its gradients from the CPU oracle (test infrastructure).  Two ranks, each fed half of the
 pairs, must end exactly where one process fed the whole minibatch ends, and stay bit-identical to
 each other.  The GPU adapter shares every line of DataParallel.train_step with this test; the
@@ -62,19 +62,24 @@ class OracleAdapter:
         return len(self.rows)
 
     def pack(self, capacity):
+        """one packed float64 tensor {count, ids[cap], rows[cap*de]} (the GPU adapter packs 32-bit words)"""
         ge = self.g[self.e0:self.e1].reshape(-1, self.de)
-        ids = torch.zeros(capacity, dtype=torch.int32)
-        rows = torch.zeros(capacity * self.de, dtype=torch.float64)
+        buf = torch.zeros(1 + capacity * (1 + self.de), dtype=torch.float64)
         n = len(self.rows)
-        ids[:n] = torch.from_numpy(self.rows.astype(np.int32))
-        rows[:n * self.de] = torch.from_numpy(ge[self.rows].ravel().copy())
+        buf[0] = n
+        buf[1:1 + n] = torch.from_numpy(self.rows.astype(np.float64))
+        buf[1 + capacity:1 + capacity + n * self.de] = torch.from_numpy(ge[self.rows].ravel().copy())
         ge[self.rows] = 0
-        return ids, rows, torch.tensor([n], dtype=torch.int32)
+        return buf
 
-    def unpack_add(self, ids, rows, cnt, capacity):
-        n = int(cnt[0])
+    def merge(self, all_buf, world, capacity):
         ge = self.g[self.e0:self.e1].reshape(-1, self.de)
-        ge[ids[:n].numpy().astype(np.int64)] += rows[:n * self.de].numpy().reshape(n, self.de)
+        stride = 1 + capacity * (1 + self.de)
+        for r in range(world):  # rank order => same addition order on every replica
+            b = all_buf[r * stride:(r + 1) * stride].numpy()
+            n = int(b[0])
+            ids = b[1:1 + n].astype(np.int64)
+            ge[ids] += b[1 + capacity:1 + capacity + n * self.de].reshape(n, self.de)
 
     def apply_update(self, opt):
         d = self._dense.numpy()

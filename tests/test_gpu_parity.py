@@ -263,7 +263,7 @@ def test_checkpoint_roundtrip(tmp_path):
 @pytest.mark.parametrize("impl", IMPLS)
 def test_two_replicas_exchange_equals_one_big_batch(impl):
     """data-parallel hooks on ONE GPU: two handles each take half the pairs, exchange gradients
-    through the pack / unpack_add API (device pointers), and must end where a single handle fed
+    through the pack / merge API (device pointers), and must end where a single handle fed
     the whole minibatch ends.  (The RCCL transport itself is exercised by the driver's N>1 runs.)"""
     import torch
     from kprn_amd import dp
@@ -294,15 +294,14 @@ def test_two_replicas_exchange_equals_one_big_batch(impl):
             dens[r].copy_(tot)
         torch.cuda.synchronize()
         for r in range(2):
-            ids, rows, cnt = reps[r].sparse_grad_pack(cap)
+            ptr, n_words = reps[r].sparse_grad_pack(cap)
             reps[r].sync()
-            packed.append((dp.wrap_device(ids, cap, "i32", dev).clone(), dp.wrap_device(rows, cap * 32, "f32", dev).clone(),
-                           dp.wrap_device(cnt, 1, "i32", dev).clone()))
+            packed.append(dp.wrap_device(ptr, n_words, "i32", dev).clone())
+        torch.cuda.synchronize()
+        allbuf = torch.cat(packed)  # what the all-gather delivers on every rank
         torch.cuda.synchronize()
         for r in range(2):
-            for src in range(2):
-                i_, r_, c_ = packed[src]
-                reps[r].sparse_grad_unpack_add(i_.data_ptr(), r_.data_ptr(), c_.data_ptr(), cap)
+            reps[r].sparse_grad_merge(allbuf.data_ptr(), 2, cap)
             reps[r].apply_update(opt)
             reps[r].sync()
     a, b, c = ref.get_flat_params(), reps[0].get_flat_params(), reps[1].get_flat_params()
