@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--paths-per-step", type=int, default=32768, help="paths per rank per step")
+    ap.add_argument("--paths-per-step", type=int, default=65536, help="paths per rank per step")
     ap.add_argument("--dims", default="A", choices=["A", "B"], help="A: D=H=64 (16/32/16); B: 64/64/64 -> D=H=192")
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--T", type=int, default=6)
@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--train-only", action="store_true")
     ap.add_argument("--score-only", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (pack / all-gather / merge) even at world size 1")
     return ap.parse_args()
 
 
@@ -91,6 +92,25 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr):
     if name == "embed_scatter":
         return "hbm", N * T * (D * 4 + F * 4)
     return None
+
+
+def pmc_traffic(name, paths_per_step):
+    """HBM bytes per launch of kernel family `name` from the rocprofv3 PMC passes of this very command
+    (scripts/gpu_pmc.sh -> profiles/<round>/pmc_summary.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
+    passes).  bench.py cannot collect counters on itself; None when no summary for this workload size is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("paths_per_step") != paths_per_step:
+            continue
+        k = d.get("kernels", {}).get(name)
+        if k and "hbm_bytes_per_launch" in k:
+            best = {"hbm_bytes_per_launch": round(k["hbm_bytes_per_launch"]), "source": os.path.relpath(f, ROOT)}
+    return best
 
 
 def cpu_baseline(a, T, dt, de, dr, H, L, seconds):
@@ -137,10 +157,14 @@ def main():
         raise SystemExit("bench.py needs a GPU: kprn_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    if world > 1 or a.force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from kprn_amd import _ffi, synth, dp
@@ -163,7 +187,7 @@ def main():
     paths_of = [b.n_paths for b in batches]
 
     dpx = None
-    if world > 1:
+    if world > 1 or a.force_dp:
         dpx = dp.DataParallel(dp.GpuAdapter(eng, dev))
         # packing capacity = largest distinct-row count of any batch on any rank (known from the batch index)
         dpx.set_capacity(max(b.n_uniq for b in batches))
@@ -244,7 +268,11 @@ def main():
                 peak, unit = PEAK_HBM_GBS, "GB/s"
             roofline = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
                         "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(ms / launches, 5),
-                        "launches": launches}
+                        "launches": launches, "algorithmic_work_per_launch": round(total_work / launches)}
+            tr = pmc_traffic(name, a.paths_per_step)
+            if tr:
+                roofline["traffic"] = tr["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = tr["source"]
         else:
             roofline = {"kernel": name, "bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
                         "traffic": None, "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": launches}
@@ -272,7 +300,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or a.force_dp:
         dist.destroy_process_group()
 
 

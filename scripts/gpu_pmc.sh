@@ -20,7 +20,15 @@ EXTRA=("$@")
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
-python "$REPO/scripts/pmc_summary.py" "$OUT" > "$OUT/summary.json"
+python "$REPO/scripts/pmc_summary.py" "$OUT" > "$OUT/kernels.json"
+python - "$OUT" "$@" <<PY > "$OUT/summary.json"
+import json, sys
+d = json.load(open(sys.argv[1] + "/kernels.json"))
+pps = 65536
+args = sys.argv[2:]
+if "--paths-per-step" in args: pps = int(args[args.index("--paths-per-step") + 1])
+print(json.dumps({"paths_per_step": pps, "command": "python bench.py --steps 6 --warmup 2 " + " ".join(args), "kernels": d}, indent=1, sort_keys=True))
+PY
 cat "$OUT/summary.json"
 # the raw per-dispatch csv files are large; keep the summary + a head
 for f in fetch write sq; do [ -f "$OUT/$f.csv" ] && { head -3 "$OUT/$f.csv" > "$OUT/$f.head.csv"; rm "$OUT/$f.csv"; }; done

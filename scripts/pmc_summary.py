@@ -29,10 +29,11 @@ def load(path):
 
 
 def short(name):
-    for key in ("k_lstm_fwd<2, true>", "k_lstm_fwd<2, false>", "k_lstm_bwd<true, false", "k_lstm_bwd<false, true",
-                "k_lstm_fwd<1, true>", "k_lstm_fwd<1, false>"):
-        if key in name:
-            return key.replace(" ", "") + (">" if not key.endswith(">") else "")
+    """kernel family as bench.py's profiler names it"""
+    if "k_lstm_fwd" in name:
+        return "lstm_fused_fwd_train" if ", true>" in name.replace(" ", " ") else "lstm_fused_fwd"
+    if "k_lstm_bwd" in name:
+        return "lstm_fused_bwd"
     n = name.split("(")[0]
     return n.split("::")[-1]
 
@@ -41,11 +42,17 @@ def main(d):
     out = {}
     for fname in ("fetch", "write", "sq"):
         acc = load(os.path.join(d, fname + ".csv"))
+        merged = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))  # template variants of one family are pooled
         for k, cs in acc.items():
-            o = out.setdefault(short(k), {})
-            for c, (s, n) in cs.items():
-                o[c + "_avg"] = s / max(n, 1)
-                o["dispatches"] = n
+            for c, (s_, n_) in cs.items():
+                m = merged[short(k)][c]
+                m[0] += s_
+                m[1] += n_
+        for k, cs in merged.items():
+            o = out.setdefault(k, {})
+            for c, (s_, n_) in cs.items():
+                o[c + "_avg"] = s_ / max(n_, 1)
+                o["dispatches"] = n_
     for k, o in out.items():
         if "FETCH_SIZE_avg" in o:
             o["fetch_bytes_raw"] = o["FETCH_SIZE_avg"] * 1024.0
@@ -54,7 +61,10 @@ def main(d):
             o["write_bytes_raw"] = o["WRITE_SIZE_avg"] * 1024.0
         if "SQ_VALU_MFMA_BUSY_CYCLES_avg" in o and o.get("SQ_BUSY_CU_CYCLES_avg"):
             o["mfma_busy_over_cu_busy"] = o["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / o["SQ_BUSY_CU_CYCLES_avg"]
-    keep = {k: v for k, v in out.items() if "lstm" in k or "unique" in k or "adam" in k}
+    for k, o in out.items():
+        if "fetch_bytes_corrected" in o or "write_bytes_raw" in o:
+            o["hbm_bytes_per_launch"] = o.get("fetch_bytes_corrected", 0.0) + o.get("write_bytes_raw", 0.0)
+    keep = {k: v for k, v in out.items() if "lstm" in k or "entity_grad" in k or "adam" in k or "loss" in k}
     print(json.dumps(keep, indent=1, sort_keys=True))
 
 
