@@ -29,6 +29,7 @@
  *    lstm{l}.i2g.weight[4H,D_l] lstm{l}.i2g.bias[4H] lstm{l}.o2g.weight[4H,H] (l=1..L) |
  *    out.weight[C,H] | out.bias[C]          (host side: row-major fp32)
  *    FastLSTM gate order inside the 4H rows: input, candidate(tanh), forget, output.
+ *    rnnType rnn: per layer rnn{l}.i2h.weight[H,D_l] | rnn{l}.i2h.bias[H] | rnn{l}.h2h.weight[H,H] | rnn{l}.h2h.bias[H]
  */
 #ifndef KPRN_H
 #define KPRN_H
@@ -62,7 +63,10 @@ typedef struct {
   int32_t H;                 /* -rnnHidSize                                                      */
   int32_t L;                 /* -numLayers  (L>1 requires dt+de+dr == H, OneModel.lua:236,270)   */
   int32_t C;                 /* labelDimension, 46 in the reference (OneModel.lua:119)           */
-  int32_t rnn_type;          /* 0 = lstm (nn.FastLSTM).  1 = rnn, 2 = gru -> KPRN_E_UNSUPPORTED  */
+  int32_t rnn_type;          /* -rnnType: 0 = lstm (nn.FastLSTM), 1 = rnn (nn.Recurrence + nn.MaskZero, OneModel.lua:240-266;
+                                the shipped config.sh default; generic pipeline), 2 = gru -> KPRN_E_UNSUPPORTED */
+  int32_t use_relu;          /* -useReLU (rnn): 1 = nn.ReLU, else nn.Tanh (OneModel.lua:225-229)  */
+  int32_t rnn_init;          /* -rnnInitialization (rnn): i2h / h2h weights <- eye, biases <- 0 (OneModel.lua:310-322) */
   int32_t reducer;           /* -topK: 0 = Max, 1 = TopK+Mean, 2 = LogSumExp (OneModel.lua:284-293) */
   int32_t K;                 /* -K                                                               */
   int32_t device_id;         /* HIP device ordinal                                               */

@@ -26,7 +26,7 @@ E_ARG, E_INDEX, E_DEVICE, E_UNSUPPORTED, E_IO, E_NOMEM = -1, -2, -3, -4, -5, -6
 
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("Vt", "Ve", "Vr", "dt", "de", "dr", "F", "num_types", "H", "L", "C",
-                                          "rnn_type", "reducer", "K", "device_id", "rank", "world")] + \
+                                          "rnn_type", "use_relu", "rnn_init", "reducer", "K", "device_id", "rank", "world")] + \
                [("param_init", C.c_float), ("seed", C.c_uint64), ("stream", C.c_void_p)]
 
 
@@ -127,9 +127,9 @@ class Engine:
     """Thin object wrapper over one kprn_handle."""
 
     def __init__(self, Vt, Ve, Vr, dt, de, dr, H, L=1, F=3, num_types=1, C_=46, reducer=2, K=5, rnn_type=0, device_id=0,
-                 rank=0, world=1, param_init=0.1, seed=12345, stream=None):
+                 rank=0, world=1, param_init=0.1, seed=12345, stream=None, use_relu=1, rnn_init=0):
         self.L = lib()
-        self.cfg = Config(Vt, Ve, Vr, dt, de, dr, F, num_types, H, L, C_, rnn_type, reducer, K, device_id, rank, world,
+        self.cfg = Config(Vt, Ve, Vr, dt, de, dr, F, num_types, H, L, C_, rnn_type, use_relu, rnn_init, reducer, K, device_id, rank, world,
                           param_init, seed, stream)
         self.h = C.c_void_p()
         rc = self.L.kprn_create(C.byref(self.cfg), C.byref(self.h))
@@ -164,8 +164,12 @@ class Engine:
         items = [("type_emb", (c.Vt, c.dt)), ("entity_emb", (c.Ve, c.de)), ("relation_emb", (c.Vr, c.dr))]
         for i in range(c.L):
             din = self.D if i == 0 else c.H
-            items += [(f"lstm{i + 1}.i2g.weight", (4 * c.H, din)), (f"lstm{i + 1}.i2g.bias", (4 * c.H,)),
-                      (f"lstm{i + 1}.o2g.weight", (4 * c.H, c.H))]
+            if c.rnn_type == 1:  # nn.Recurrence: i2h / h2h nn.Linear (OneModel.lua:231-232)
+                items += [(f"rnn{i + 1}.i2h.weight", (c.H, din)), (f"rnn{i + 1}.i2h.bias", (c.H,)),
+                          (f"rnn{i + 1}.h2h.weight", (c.H, c.H)), (f"rnn{i + 1}.h2h.bias", (c.H,))]
+            else:
+                items += [(f"lstm{i + 1}.i2g.weight", (4 * c.H, din)), (f"lstm{i + 1}.i2g.bias", (4 * c.H,)),
+                          (f"lstm{i + 1}.o2g.weight", (4 * c.H, c.H))]
         items += [("out.weight", (c.C, c.H)), ("out.bias", (c.C,))]
         for nm, shp in items:
             out[nm] = (off, shp)

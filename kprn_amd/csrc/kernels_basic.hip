@@ -154,6 +154,45 @@ __global__ void k_colsum(const float* __restrict__ A, int64_t rows, int cols, fl
 }
 
 // ---------------------------------------------------------------------------------------
+// rnnType "rnn" (OneModel.lua:240-266): nn.Recurrence(nn.MaskZero(act(i2h x + h2h h'), 1)), one step of one layer.
+// mask[n] = the step input row n is not all zeros (MaskZero zeroes the output rows -- and their gradients -- of
+// all-zero input rows: pad steps have zero embeddings after zeroPadTokens).  One wave per row.
+__global__ void k_row_nonzero(const float* __restrict__ in, int64_t N, int D, float* __restrict__ mask) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (n >= N) return;
+  int nz = 0;
+  for (int k = lane; k < D; k += 64) nz |= (in[n * D + k] != 0.f) ? 1 : 0;
+  nz = __any(nz);
+  if (lane == 0) mask[n] = nz ? 1.f : 0.f;
+}
+
+// pre[n][j] (in: i2h x + i2h.b (+ h2h h')) += h2h.b[j]; h = mask * act(pre)
+__global__ void k_rnn_cell_fwd(float* __restrict__ pre, const float* __restrict__ bh, const float* __restrict__ mask, float* __restrict__ h,
+                               int64_t N, int H, int relu) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int j = (int)(i - n * H);
+  const float a = pre[i] + bh[j];
+  pre[i] = a;
+  const float v = relu ? fmaxf(a, 0.f) : tanhf(a);
+  h[i] = (mask[n] != 0.f) ? v : 0.f;
+}
+
+// dA = mask * (dH + dH_up) * act'(pre)
+__global__ void k_rnn_cell_bwd(const float* __restrict__ pre, const float* __restrict__ hcur, const float* __restrict__ mask,
+                               const float* __restrict__ dH_up, const float* __restrict__ dH, float* __restrict__ dA, int64_t N, int H, int relu) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  float d = dH[i];
+  if (dH_up) d += dH_up[i];
+  const float der = relu ? (pre[i] > 0.f ? 1.f : 0.f) : (1.f - hcur[i] * hcur[i]);
+  dA[i] = (mask[n] != 0.f) ? d * der : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------
 // reducer over the P paths of a pair + nn.Sigmoid (OneModel.lua:284-294):
 //   2: module/LogSumExp.lua:13-27   0: nn.Max(2)   1: module/TopK.lua:17-24 + nn.Mean(2)
 __device__ float reduce_col(const float* s, int P, int C, int reducer, int K) {
@@ -720,6 +759,25 @@ void lstm_gates_bwd(hipStream_t s, const float* act, const float* c, const float
                     int64_t N, int H) {
   if (N <= 0) return;
   hipLaunchKernelGGL(k_gates_bwd, dim3(nblocks(N * H)), dim3(TPB), 0, s, act, c, c_prev, dH_up, dH, dC, dA, N, H);
+  CHECK_LAUNCH();
+}
+
+void row_nonzero(hipStream_t s, const float* in, int64_t N, int D, float* mask) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_row_nonzero, dim3(nblocks(N * 64)), dim3(TPB), 0, s, in, N, D, mask);
+  CHECK_LAUNCH();
+}
+
+void rnn_cell_fwd(hipStream_t s, float* pre, const float* bh, const float* mask, float* h, int64_t N, int H, int relu) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_rnn_cell_fwd, dim3(nblocks(N * H)), dim3(TPB), 0, s, pre, bh, mask, h, N, H, relu);
+  CHECK_LAUNCH();
+}
+
+void rnn_cell_bwd(hipStream_t s, const float* pre, const float* hcur, const float* mask, const float* dH_up, const float* dH, float* dA, int64_t N,
+                  int H, int relu) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_rnn_cell_bwd, dim3(nblocks(N * H)), dim3(TPB), 0, s, pre, hcur, mask, dH_up, dH, dA, N, H, relu);
   CHECK_LAUNCH();
 }
 

@@ -81,12 +81,22 @@ static void build_layout(kprn_handle* h) {
   h->off_Wt = dn; add("type_emb", c.Vt, c.dt, 0, dn); dn += (int64_t)c.Vt * c.dt;
   add("entity_emb", c.Ve, c.de, 1, 0);
   h->off_Wr = dn; add("relation_emb", c.Vr, c.dr, 0, dn); dn += (int64_t)c.Vr * c.dr;
+  h->G = (c.rnn_type == 1) ? 1 : 4;
   for (int l = 0; l < c.L; ++l) {
     const int Din = (l == 0) ? h->D : c.H;
     h->layer[l].Din = Din;
-    h->layer[l].Wi = dn; add("lstm" + std::to_string(l + 1) + ".i2g.weight", 4 * c.H, Din, 0, dn); dn += (int64_t)4 * c.H * Din;
-    h->layer[l].bi = dn; add("lstm" + std::to_string(l + 1) + ".i2g.bias", 4 * c.H, 1, 0, dn); dn += (int64_t)4 * c.H;
-    h->layer[l].Wo = dn; add("lstm" + std::to_string(l + 1) + ".o2g.weight", 4 * c.H, c.H, 0, dn); dn += (int64_t)4 * c.H * c.H;
+    const std::string ln = std::to_string(l + 1);
+    if (c.rnn_type == 1) {  // nn.Recurrence(nn.MaskZero(...)): input2hidden / hidden2hidden nn.Linear, both with bias (OneModel.lua:231-232)
+      h->layer[l].Wi = dn; add("rnn" + ln + ".i2h.weight", c.H, Din, 0, dn); dn += (int64_t)c.H * Din;
+      h->layer[l].bi = dn; add("rnn" + ln + ".i2h.bias", c.H, 1, 0, dn); dn += c.H;
+      h->layer[l].Wo = dn; add("rnn" + ln + ".h2h.weight", c.H, c.H, 0, dn); dn += (int64_t)c.H * c.H;
+      h->layer[l].bo = dn; add("rnn" + ln + ".h2h.bias", c.H, 1, 0, dn); dn += c.H;
+    } else {
+      h->layer[l].Wi = dn; add("lstm" + ln + ".i2g.weight", 4 * c.H, Din, 0, dn); dn += (int64_t)4 * c.H * Din;
+      h->layer[l].bi = dn; add("lstm" + ln + ".i2g.bias", 4 * c.H, 1, 0, dn); dn += (int64_t)4 * c.H;
+      h->layer[l].Wo = dn; add("lstm" + ln + ".o2g.weight", 4 * c.H, c.H, 0, dn); dn += (int64_t)4 * c.H * c.H;
+      h->layer[l].bo = -1;
+    }
   }
   h->off_outW = dn; add("out.weight", c.C, c.H, 0, dn); dn += (int64_t)c.C * c.H;
   h->off_outb = dn; add("out.bias", c.C, 1, 0, dn); dn += c.C;
@@ -201,7 +211,8 @@ static void ensure_ws_generic(kprn_handle* h, int64_t N, int T) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     int64_t cn = std::max<int64_t>(N, w.cap_N);
     int ct = std::max(T, w.cap_T);
-    dfree(w.X); dfree(w.Hs); dfree(w.Cs); dfree(w.ACT); dfree(w.dA); dfree(w.dIn); dfree(w.dH); dfree(w.dC);
+    dfree(w.X); dfree(w.Hs); dfree(w.Cs); dfree(w.ACT); dfree(w.dA); dfree(w.dIn); dfree(w.dH); dfree(w.dC); dfree(w.mask);
+    w.mask = dalloc<float>((int64_t)L * ct * cn);
     w.X = dalloc<float>(cn * ct * D);
     w.Hs = dalloc<float>((int64_t)L * ct * cn * H);
     w.Cs = dalloc<float>((int64_t)L * ct * cn * H);
@@ -237,6 +248,34 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b) {
     ProfScope ps(h, "embed_gather");
     kk::embed_gather(s, b->idx, N, T, b->F, c.num_types, h->dense + h->off_Wt, h->We, h->dense + h->off_Wr, c.dt, c.de, c.dr, w.X, true);
   }
+  if (c.rnn_type == 1) {
+    // nn.Sequencer(nn.Recurrence(nn.MaskZero(act(i2h x_t + h2h h_{t-1}), 1))) x L (OneModel.lua:240-266,268-273)
+    for (int l = 0; l < L; ++l) {
+      const int Din = h->layer[l].Din;
+      const float* in = (l == 0) ? w.X : w.Hs + (int64_t)(l - 1) * T * N * H;
+      float* pre = w.ACT + (int64_t)l * T * N * H;
+      float* hs = w.Hs + (int64_t)l * T * N * H;
+      float* mask = w.mask + (int64_t)l * T * N;
+      {
+        ProfScope ps(h, "gemm_i2g_fwd");
+        gemm::run(s, in, Din, 1, h->dense + h->layer[l].Wi, 1, Din, pre, H, (int64_t)T * N, H, Din, false, h->dense + h->layer[l].bi, 1);
+      }
+      {
+        ProfScope ps(h, "rnn_mask");
+        kk::row_nonzero(s, in, (int64_t)T * N, Din, mask);  // layer l > 1: the mask follows the ACTUAL input rows (h^{l-1}_t), as MaskZero does
+      }
+      for (int t = 0; t < T; ++t) {
+        float* pre_t = pre + (int64_t)t * N * H;
+        if (t > 0) {
+          ProfScope ps(h, "gemm_o2g_fwd");
+          gemm::run(s, hs + (int64_t)(t - 1) * N * H, H, 1, h->dense + h->layer[l].Wo, 1, H, pre_t, H, N, H, H, true, nullptr, 1);
+        }
+        ProfScope ps(h, "rnn_cell_fwd");
+        kk::rnn_cell_fwd(s, pre_t, h->dense + h->layer[l].bo, mask + (int64_t)t * N, hs + (int64_t)t * N * H, N, H, c.use_relu == 1 ? 1 : 0);
+      }
+      // the mask of the NEXT layer reads hs: it is complete here
+    }
+  } else
   for (int l = 0; l < L; ++l) {
     const int Din = h->layer[l].Din;
     const float* in = (l == 0) ? w.X : w.Hs + (int64_t)(l - 1) * T * N * H;
@@ -280,7 +319,7 @@ static void check_batch(kprn_handle* h, const kprn_batch* b, int class_id) {
 }
 
 static bool use_fused(kprn_handle* h, const kprn_batch* b, bool save_for_backward) {
-  if (h->impl != 0 || !fused::fwd_supported(h, b->T)) return false;
+  if (h->impl != 0 || h->cfg.rnn_type != 0 || !fused::fwd_supported(h, b->T)) return false;
   return !save_for_backward || fused::bwd_supported(h, b->T);
 }
 
@@ -323,6 +362,49 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
   }
   HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), s));
   const int split = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (T * N) / 2048));
+  if (c.rnn_type == 1) {
+    const int relu = c.use_relu == 1 ? 1 : 0;
+    for (int l = L - 1; l >= 0; --l) {
+      const int Din = h->layer[l].Din;
+      const float* in = (l == 0) ? w.X : w.Hs + (int64_t)(l - 1) * T * N * H;
+      const float* pre = w.ACT + (int64_t)l * T * N * H;
+      const float* hs = w.Hs + (int64_t)l * T * N * H;
+      const float* mask = w.mask + (int64_t)l * T * N;
+      const float* Wi = h->dense + h->layer[l].Wi;
+      const float* Wo = h->dense + h->layer[l].Wo;
+      const bool has_up = (l < L - 1);
+      if (has_up) HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
+      for (int t = T - 1; t >= 0; --t) {
+        float* dA_t = w.dA + (int64_t)t * N * H;
+        {
+          ProfScope ps(h, "rnn_cell_bwd");
+          kk::rnn_cell_bwd(s, pre + (int64_t)t * N * H, hs + (int64_t)t * N * H, mask + (int64_t)t * N, has_up ? w.dIn + (int64_t)t * N * H : nullptr,
+                           w.dH, dA_t, N, H, relu);
+        }
+        if (t > 0) {
+          ProfScope ps(h, "gemm_o2g_bwd_dh");
+          gemm::run(s, dA_t, H, 1, Wo, H, 1, w.dH, H, N, H, H, false, nullptr, 1);
+        }
+      }
+      if (T > 1) {
+        ProfScope ps(h, "gemm_o2g_bwd_dw");
+        gemm::run(s, w.dA + (int64_t)N * H, 1, H, hs, H, 1, gd + h->layer[l].Wo, H, H, H, (int64_t)(T - 1) * N, true, nullptr, split);
+      }
+      {
+        ProfScope ps(h, "gemm_i2g_bwd_dw");
+        gemm::run(s, w.dA, 1, H, in, Din, 1, gd + h->layer[l].Wi, Din, H, Din, (int64_t)T * N, true, nullptr, split);
+      }
+      {
+        ProfScope ps(h, "bias_colsum");  // i2h.bias and h2h.bias see the same gradient (both are added to every pre-activation)
+        kk::col_sum_add(s, w.dA, (int64_t)T * N, H, gd + h->layer[l].bi);
+        kk::col_sum_add(s, w.dA, (int64_t)T * N, H, gd + h->layer[l].bo);
+      }
+      {
+        ProfScope ps(h, "gemm_i2g_bwd_dx");
+        gemm::run(s, w.dA, H, 1, Wi, Din, 1, w.dIn, Din, (int64_t)T * N, Din, H, false, nullptr, 1);
+      }
+    }
+  } else
   for (int l = L - 1; l >= 0; --l) {
     const int Din = h->layer[l].Din;
     const float* in = (l == 0) ? w.X : w.Hs + (int64_t)(l - 1) * T * N * H;
@@ -521,7 +603,7 @@ int kprn_create(const kprn_config* cfg, kprn_handle** out) {
     KPRN_REQUIRE(c.F >= c.num_types + 2, KPRN_E_ARG, "numFeatureTemplates must cover types + entity + relation (FeatureEmbedding.lua:51)");
     KPRN_REQUIRE(c.H > 0 && c.C > 0, KPRN_E_ARG, "rnnHidSize and labelDimension must be positive");
     KPRN_REQUIRE(c.L >= 1 && c.L <= KPRN_MAX_LAYERS, KPRN_E_ARG, "numLayers must be in 1..8");
-    KPRN_REQUIRE(c.rnn_type == 0, KPRN_E_UNSUPPORTED, "only rnnType=lstm (nn.FastLSTM) is built; rnn/gru are on the roadmap (SURVEY 8f N4)");
+    KPRN_REQUIRE(c.rnn_type == 0 || c.rnn_type == 1, KPRN_E_UNSUPPORTED, "rnnType gru (nn.GRU) is not built (SURVEY 8f N4c); lstm and rnn are");
     KPRN_REQUIRE(c.reducer >= 0 && c.reducer <= 2, KPRN_E_ARG, "topK must be 0 (max), 1 (topK) or 2 (LogSumExp)");
     KPRN_REQUIRE(c.reducer != 1 || c.K >= 1, KPRN_E_ARG, "K must be >= 1 for the topK reducer");
     KPRN_REQUIRE(c.L == 1 || (c.dt + c.de + c.dr) == c.H, KPRN_E_ARG,
@@ -557,6 +639,21 @@ int kprn_create(const kprn_config* cfg, kprn_handle** out) {
       float* dst = (p.where == 1 ? h->We : h->dense) + p.dev_off;
       kk::fill_uniform(s, dst, p.rows * p.cols, c.param_init, c.seed, (uint64_t)p.flat_off);
     }
+    if (c.rnn_type == 1 && c.rnn_init == 1) {
+      // -rnnInitialization 1 (OneModel.lua:310-322): i2h.weight <- torch.eye(D, H) copied in STORAGE order into the [H, D]
+      // tensor, h2h.weight <- eye(H), both biases <- 0
+      for (int l = 0; l < c.L; ++l) {
+        const int Din = h->layer[l].Din;
+        std::vector<float> wi((size_t)c.H * Din, 0.f), wh((size_t)c.H * c.H, 0.f), z((size_t)c.H, 0.f);
+        for (int r = 0; r < Din; ++r) if (r < c.H) wi[(size_t)r * c.H + r] = 1.f;  // eye(Din, H)[r][r], flat index r*H + r
+        for (int r = 0; r < c.H; ++r) wh[(size_t)r * c.H + r] = 1.f;
+        HIP_TRY(hipMemcpyAsync(h->dense + h->layer[l].Wi, wi.data(), wi.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->dense + h->layer[l].Wo, wh.data(), wh.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->dense + h->layer[l].bi, z.data(), z.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->dense + h->layer[l].bo, z.data(), z.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+      }
+    }
     step_tab_reserve(h, 1);
     HIP_TRY(hipStreamSynchronize(s));
     *out = h;
@@ -582,7 +679,7 @@ void kprn_destroy(kprn_handle* h) {
   dfree(h->loss_partial);
   for (auto e : h->event_pool) hipEventDestroy(e);
   Workspace& w = h->ws;
-  for (float** p : {&w.X, &w.Hs, &w.Cs, &w.ACT, &w.dA, &w.dIn, &w.dH, &w.dC, &w.S, &w.dS, &w.pooled, &w.probs, &w.sel, &w.dy}) dfree(*p);
+  for (float** p : {&w.X, &w.Hs, &w.Cs, &w.ACT, &w.dA, &w.dIn, &w.dH, &w.dC, &w.S, &w.dS, &w.pooled, &w.probs, &w.sel, &w.dy, &w.mask}) dfree(*p);
   for (float** p : {&h->dense, &h->g_dense, &h->s1_dense, &h->s2_dense, &h->We, &h->g_We, &h->s1_We, &h->s2_We, &h->d_loss, &h->d_norm2,
                     &h->step_tab})
     dfree(*p);
@@ -976,7 +1073,7 @@ int kprn_load(kprn_handle* h, const char* path) {
   bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kMagic, 8) == 0 && fread(hdr, sizeof(int32_t), 16, f) == 16 &&
             fread(&n, sizeof(int64_t), 1, f) == 1;
   const kprn_config& c = h->cfg;
-  const int32_t want[11] = {c.Vt, c.Ve, c.Vr, c.dt, c.de, c.dr, c.F, c.num_types, c.H, c.L, c.C};
+  const int32_t want[12] = {c.Vt, c.Ve, c.Vr, c.dt, c.de, c.dr, c.F, c.num_types, c.H, c.L, c.C, c.rnn_type};
   if (ok) ok = memcmp(hdr, want, sizeof(want)) == 0 && n == h->n_params;
   std::vector<float> flat;
   if (ok) { flat.resize((size_t)n); ok = fread(flat.data(), sizeof(float), flat.size(), f) == flat.size(); }

@@ -30,8 +30,8 @@ struct ParamInfo {
   int64_t dev_off;    // offset inside that device buffer
 };
 
-struct LayerOff {     // offsets into the dense arena
-  int64_t Wi, bi, Wo;
+struct LayerOff {     // offsets into the dense arena (rnn: Wi = i2h.weight, bi = i2h.bias, Wo = h2h.weight, bo = h2h.bias)
+  int64_t Wi, bi, Wo, bo;
   int Din;
 };
 
@@ -55,6 +55,7 @@ struct Workspace {
   float* probs = nullptr;  // [B][C]
   float* sel = nullptr;    // [B] probs[:, classId]
   float* dy = nullptr;     // [B]
+  float* mask = nullptr;   // [L][T][N]  rnn: MaskZero flags of the step inputs
 };
 
 struct ProfEntry { double total_ms = 0; int64_t launches = 0; };
@@ -75,6 +76,7 @@ struct kprn_batch {
 struct kprn_handle {
   kprn_config cfg;
   int D = 0;
+  int G = 4;  // rows of the recurrent weights per hidden unit: 4 (FastLSTM gates) or 1 (rnn)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
@@ -157,6 +159,10 @@ void embed_gather(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, in
 void lstm_gates_fwd(hipStream_t s, float* act /*[N][4H] in: pre-act, out: gates*/, const float* c_prev, float* c, float* h, int64_t N, int H);
 void lstm_gates_bwd(hipStream_t s, const float* act, const float* c, const float* c_prev, const float* dH_up /*nullable*/,
                     float* dH, float* dC, float* dA, int64_t N, int H);
+void row_nonzero(hipStream_t s, const float* in, int64_t N, int D, float* mask);
+void rnn_cell_fwd(hipStream_t s, float* pre, const float* bh, const float* mask, float* h, int64_t N, int H, int relu);
+void rnn_cell_bwd(hipStream_t s, const float* pre, const float* hcur, const float* mask, const float* dH_up, const float* dH, float* dA, int64_t N,
+                  int H, int relu);
 void add_bias_rows(hipStream_t s, float* Y, const float* b, int64_t rows, int cols);
 void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out);
 void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel);

@@ -67,6 +67,7 @@ def build_engine(params, rank=0, world=1, device_id=None, stream=None):
                       params.entityTypeEmbeddingDim, params.entityEmbeddingDim, params.relationEmbeddingDim,
                       params.rnnHidSize, params.numLayers, F=params.numFeatureTemplates, num_types=params.numEntityTypes,
                       C_=LABEL_DIMENSION, reducer=params.topK, K=params.K, rnn_type=RNN_TYPES[params.rnnType],
+                      use_relu=params.useReLU, rnn_init=params.rnnInitialization,
                       device_id=device_id, rank=rank, world=world, param_init=params.paramInit, seed=params.seed, stream=stream)
     if params.initModel:
         eng.load(params.initModel)  # OneModel.lua:277-282

@@ -22,6 +22,11 @@
  *   [A4] optim.adam: t+=1; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g*g;
  *        denom = sqrt(v) + eps; step = lr*sqrt(1-b2^t)/(1-b1^t); x -= step*m/denom.
  *   [A5] optim.adagrad: clr = lr/(1+nevals*lrd); G += g*g; x -= clr*g/(sqrt(G)+1e-10).
+ *   [A7] rnnType "rnn" (OneModel.lua:240-266): h_t = act(i2h.W x_t + i2h.b + h2h.W h_{t-1} + h2h.b), h_0 = 0,
+ *        act = ReLU when -useReLU 1 else Tanh (OneModel.lua:225-229), wrapped in nn.MaskZero(rm, 1): rows of the
+ *        output whose INPUT row x_t (layer > 1: h^{l-1}_t) is all zeros are zeroed, and so are their gradients
+ *        (pad steps have zero embeddings after zeroPadTokens: the state stays 0 until the first real step).
+ *        parameters() order per layer: i2h.weight[H,D_l], i2h.bias[H], h2h.weight[H,H], h2h.bias[H].
  *   [A6] getParameters() flat order = module traversal order:
  *        Wt | We | Wr | (i2g.W[4H,D_l], i2g.b[4H], o2g.W[4H,H]) x L | out.W[C,H] | out.b[C]
  * The restatement is cross-checked against an independent implementation (PyTorch CPU
@@ -72,6 +77,8 @@ typedef struct {
   int32_t H, L, C;        /* rnnHidSize, numLayers, labelDimension (46)             */
   int32_t reducer;        /* 0 = Max, 1 = TopK+Mean, 2 = LogSumExp (OneModel.lua:284-293) */
   int32_t K;              /* topK K                                                  */
+  int32_t rnn_type;       /* 0 = lstm (nn.FastLSTM), 1 = rnn (Recurrence + MaskZero) [A7]  */
+  int32_t use_relu;       /* rnn: -useReLU 1 -> ReLU, else Tanh                      */
 } okprn_cfg;
 
 typedef struct {
@@ -87,7 +94,8 @@ static inline REAL sigm(REAL x) { return (REAL)1 / ((REAL)1 + (REAL)exp(-(double
 /* ---- flat parameter layout [A6] ------------------------------------------------ */
 typedef struct {
   size_t Wt, We, Wr;
-  size_t i2gW[8], i2gb[8], o2gW[8];
+  size_t i2gW[8], i2gb[8], o2gW[8], h2hb[8];  /* rnn: i2gW = i2h.W, i2gb = i2h.b, o2gW = h2h.W, h2hb = h2h.b */
+  int G;  /* rows of the recurrent weights per hidden unit: 4 (lstm gates) or 1 (rnn) */
   size_t outW, outb, total;
   int D;
 } layout_t;
@@ -99,11 +107,13 @@ static layout_t make_layout(const okprn_cfg* c) {
   l.Wt = o; o += (size_t)c->Vt * c->dt;
   l.We = o; o += (size_t)c->Ve * c->de;
   l.Wr = o; o += (size_t)c->Vr * c->dr;
+  l.G = (c->rnn_type == 1) ? 1 : 4;
   for (int i = 0; i < c->L; ++i) {
     int Din = (i == 0) ? l.D : c->H;
-    l.i2gW[i] = o; o += (size_t)4 * c->H * Din;
-    l.i2gb[i] = o; o += (size_t)4 * c->H;
-    l.o2gW[i] = o; o += (size_t)4 * c->H * c->H;
+    l.i2gW[i] = o; o += (size_t)l.G * c->H * Din;
+    l.i2gb[i] = o; o += (size_t)l.G * c->H;
+    l.o2gW[i] = o; o += (size_t)l.G * c->H * c->H;
+    l.h2hb[i] = o; if (c->rnn_type == 1) o += (size_t)c->H;
   }
   l.outW = o; o += (size_t)c->C * c->H;
   l.outb = o; o += (size_t)c->C;
@@ -114,12 +124,15 @@ static layout_t make_layout(const okprn_cfg* c) {
 size_t FN(okprn_num_params)(const okprn_cfg* c) { return make_layout(c).total; }
 
 /* offsets of every named parameter, for the tests: out[0..2]=Wt,We,Wr; then 3 per
- * layer; then outW,outb,total */
+ * layer (rnn: 4 per layer); then outW,outb,total */
 void FN(okprn_layout)(const okprn_cfg* c, int64_t* out) {
   layout_t l = make_layout(c);
   int k = 0;
   out[k++] = (int64_t)l.Wt; out[k++] = (int64_t)l.We; out[k++] = (int64_t)l.Wr;
-  for (int i = 0; i < c->L; ++i) { out[k++] = (int64_t)l.i2gW[i]; out[k++] = (int64_t)l.i2gb[i]; out[k++] = (int64_t)l.o2gW[i]; }
+  for (int i = 0; i < c->L; ++i) {
+    out[k++] = (int64_t)l.i2gW[i]; out[k++] = (int64_t)l.i2gb[i]; out[k++] = (int64_t)l.o2gW[i];
+    if (c->rnn_type == 1) out[k++] = (int64_t)l.h2hb[i];
+  }
   out[k++] = (int64_t)l.outW; out[k++] = (int64_t)l.outb; out[k++] = (int64_t)l.total;
 }
 
@@ -167,6 +180,29 @@ static const REAL* path_forward(const okprn_cfg* c, const layout_t* l, const REA
       const REAL* Wo = th + l->o2gW[ly];
       REAL* cur = r->act + ((size_t)t * L + ly) * 6 * H;
       const REAL* prev = (t > 0) ? r->act + ((size_t)(t - 1) * L + ly) * 6 * H : NULL;
+      if (c->rnn_type == 1) { /* [A7] Recurrence(MaskZero(act(i2h x + h2h h'))) */
+        const REAL* bh = th + l->h2hb[ly];
+        int nonzero = 0;
+        for (int k = 0; k < Din; ++k) if (in[k] != (REAL)0) { nonzero = 1; break; }
+        for (int n = 0; n < H; ++n) {
+          REAL s = bi[n] + bh[n];  /* nn.Linear(h2h) of the zero initial state still adds its bias */
+          const REAL* w = Wi + (size_t)n * Din;
+          for (int k = 0; k < Din; ++k) s += w[k] * in[k];
+          if (prev) {
+            const REAL* hp = prev + 5 * H;
+            const REAL* w2 = Wo + (size_t)n * H;
+            for (int k = 0; k < H; ++k) s += w2[k] * hp[k];
+          }
+          REAL hh = c->use_relu ? (s > (REAL)0 ? s : (REAL)0) : (REAL)tanh((double)s);
+          if (!nonzero) hh = (REAL)0;
+          cur[n] = (REAL)nonzero;  /* slot 0: the MaskZero flag of this step */
+          cur[H + n] = s;          /* slot 1: pre-activation */
+          cur[5 * H + n] = hh;
+        }
+        in = cur + 5 * H;
+        Din = H;
+        continue;
+      }
       for (int n = 0; n < 4 * H; ++n) {
         REAL s = bi[n];
         const REAL* w = Wi + (size_t)n * Din;
@@ -228,6 +264,37 @@ static void path_backward(const okprn_cfg* c, const layout_t* l, const REAL* th,
       const REAL* in = (ly == 0) ? r->x + (size_t)t * D : r->act + ((size_t)t * L + ly - 1) * 6 * H + 5 * H;
       REAL* dhl = dh + (size_t)ly * H;
       REAL* dcl = dc + (size_t)ly * H;
+      if (c->rnn_type == 1) { /* [A7] */
+        const REAL* Wi = th + l->i2gW[ly];
+        const REAL* Wo = th + l->o2gW[ly];
+        REAL* gWi = gd + (l->i2gW[ly] - doff);
+        REAL* gbi = gd + (l->i2gb[ly] - doff);
+        REAL* gWo = gd + (l->o2gW[ly] - doff);
+        REAL* gbh = gd + (l->h2hb[ly] - doff);
+        const int nonzero = cur[0] != (REAL)0;
+        for (int j = 0; j < H; ++j) {
+          REAL hh = cur[5 * H + j], pre = cur[H + j];
+          REAL der = c->use_relu ? (pre > (REAL)0 ? (REAL)1 : (REAL)0) : ((REAL)1 - hh * hh);
+          da[j] = nonzero ? dhl[j] * der : (REAL)0;  /* MaskZero: masked rows pass no gradient */
+          dhl[j] = 0;
+        }
+        for (int k = 0; k < Din; ++k) dxin[k] = 0;
+        for (int n = 0; n < H; ++n) {
+          REAL d = da[n];
+          gbi[n] += d;
+          gbh[n] += d;
+          const REAL* w = Wi + (size_t)n * Din;
+          REAL* gw = gWi + (size_t)n * Din;
+          for (int k = 0; k < Din; ++k) { gw[k] += d * in[k]; dxin[k] += d * w[k]; }
+          if (prev) {
+            const REAL* hp = prev + 5 * H;
+            const REAL* w2 = Wo + (size_t)n * H;
+            REAL* gw2 = gWo + (size_t)n * H;
+            for (int k = 0; k < H; ++k) { gw2[k] += d * hp[k]; dhl[k] += d * w2[k]; }
+          }
+        }
+        goto below;
+      }
       for (int j = 0; j < H; ++j) {
         REAL ig = cur[j], gg = cur[H + j], fg = cur[2 * H + j], og = cur[3 * H + j], cc = cur[4 * H + j];
         REAL tc = (REAL)tanh((double)cc);
@@ -242,6 +309,7 @@ static void path_backward(const okprn_cfg* c, const layout_t* l, const REAL* th,
         dcl[j] = dC * fg; /* -> dc_{t-1} */
         dhl[j] = 0;       /* will be refilled with dh_{t-1} below */
       }
+      {
       const REAL* Wi = th + l->i2gW[ly];
       const REAL* Wo = th + l->o2gW[ly];
       REAL* gWi = gd + (l->i2gW[ly] - doff);
@@ -261,6 +329,8 @@ static void path_backward(const okprn_cfg* c, const layout_t* l, const REAL* th,
           for (int k = 0; k < H; ++k) { gw2[k] += d * hp[k]; dhl[k] += d * w2[k]; }
         }
       }
+      }
+    below:
       if (ly > 0) {
         REAL* dbelow = dh + (size_t)(ly - 1) * H;
         for (int k = 0; k < H; ++k) dbelow[k] += dxin[k];

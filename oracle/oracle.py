@@ -15,7 +15,7 @@ _LIB = None
 
 class Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("Vt", "Ve", "Vr", "dt", "de", "dr", "F", "numTypes", "H", "L", "C", "reducer", "K")]
+                ("Vt", "Ve", "Vr", "dt", "de", "dr", "F", "numTypes", "H", "L", "C", "reducer", "K", "rnn_type", "use_relu")]
 
 
 class Opt(C.Structure):
@@ -40,8 +40,8 @@ def lib():
     return _LIB
 
 
-def make_cfg(Vt=6, Ve=100, Vr=9, dt=4, de=8, dr=4, F=3, numTypes=1, H=16, L=1, C_=46, reducer=2, K=5):
-    return Cfg(Vt, Ve, Vr, dt, de, dr, F, numTypes, H, L, C_, reducer, K)
+def make_cfg(Vt=6, Ve=100, Vr=9, dt=4, de=8, dr=4, F=3, numTypes=1, H=16, L=1, C_=46, reducer=2, K=5, rnn_type=0, use_relu=1):
+    return Cfg(Vt, Ve, Vr, dt, de, dr, F, numTypes, H, L, C_, reducer, K, rnn_type, use_relu)
 
 
 def make_opt(method=1, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, lr_decay=0.0, regularize=0,
@@ -74,21 +74,39 @@ class Oracle:
     def layout(self):
         """dict name -> (offset, shape) in the flat vector, reference getParameters() order."""
         c = self.cfg
-        out = np.zeros(3 + 3 * c.L + 3, dtype=np.int64)
+        rnn = c.rnn_type == 1
+        out = np.zeros(3 + (4 if rnn else 3) * c.L + 3, dtype=np.int64)
         getattr(self.l, "okprn_layout" + self.sfx)(C.byref(c), _p(out))
         names = [("type_emb", (c.Vt, c.dt)), ("entity_emb", (c.Ve, c.de)), ("relation_emb", (c.Vr, c.dr))]
         for i in range(c.L):
             din = self.D if i == 0 else c.H
-            names += [(f"lstm{i + 1}.i2g.weight", (4 * c.H, din)), (f"lstm{i + 1}.i2g.bias", (4 * c.H,)),
-                      (f"lstm{i + 1}.o2g.weight", (4 * c.H, c.H))]
+            if rnn:
+                names += [(f"rnn{i + 1}.i2h.weight", (c.H, din)), (f"rnn{i + 1}.i2h.bias", (c.H,)),
+                          (f"rnn{i + 1}.h2h.weight", (c.H, c.H)), (f"rnn{i + 1}.h2h.bias", (c.H,))]
+            else:
+                names += [(f"lstm{i + 1}.i2g.weight", (4 * c.H, din)), (f"lstm{i + 1}.i2g.bias", (4 * c.H,)),
+                          (f"lstm{i + 1}.o2g.weight", (4 * c.H, c.H))]
         names += [("out.weight", (c.C, c.H)), ("out.bias", (c.C,))]
         assert out[-1] == self.n
         return {nm: (int(out[k]), shp) for k, (nm, shp) in enumerate(names)}
 
-    def init_params(self, seed, param_init=0.1):
-        """uniform(-paramInit, paramInit) over every parameter (OneModel.lua:306-309)."""
+    def init_params(self, seed, param_init=0.1, rnn_init=False):
+        """uniform(-paramInit, paramInit) over every parameter (OneModel.lua:306-309); rnn_init (-rnnInitialization 1,
+        rnnType rnn only): i2h.weight <- torch.eye(D, H) copied in STORAGE order into the [H, D] weight, h2h.weight <-
+        eye(H), both biases <- 0 (OneModel.lua:310-322)."""
         rng = np.random.default_rng(seed)
-        return rng.uniform(-param_init, param_init, self.n).astype(self.dtype)
+        th = rng.uniform(-param_init, param_init, self.n).astype(self.dtype)
+        if rnn_init and self.cfg.rnn_type == 1:
+            lay = self.layout()
+            for i in range(self.cfg.L):
+                off, (H, din) = lay[f"rnn{i + 1}.i2h.weight"]
+                th[off:off + H * din] = np.eye(din, H, dtype=self.dtype).ravel()
+                off, (H, _) = lay[f"rnn{i + 1}.h2h.weight"]
+                th[off:off + H * H] = np.eye(H, dtype=self.dtype).ravel()
+                for nm in ("i2h.bias", "h2h.bias"):
+                    off, shp = lay[f"rnn{i + 1}.{nm}"]
+                    th[off:off + shp[0]] = 0
+        return th
 
     def _idx(self, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int32)

@@ -39,6 +39,20 @@ def oracle_case(name, Ve, dt, de, dr, H, L, T, pairs, P, seed):
                         probs=probs, loss=np.float64(loss), grad=grad, theta_after3=th, losses3=np.array(losses))
 
 
+def rnn_case(name, Ve, dt, de, dr, H, L, T, pairs, P, seed, use_relu):
+    """rnnType rnn (the shipped config.sh default): Recurrence + MaskZero, pads masked"""
+    cfg = make_cfg(Vt=6, Ve=Ve, Vr=9, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=1, use_relu=use_relu)
+    o = Oracle(cfg, np.float64)
+    theta = o.init_params(seed, 0.2).astype(np.float32).astype(np.float64)
+    o.zero_pad(theta)
+    idx, labels = synth.make_paths(pairs, P, T, Ve=Ve, seed=seed + 1)
+    ps, pooled, probs = o.forward(theta, idx)
+    loss, grad, p = o.forward_backward(theta, idx, labels)
+    np.savez_compressed(os.path.join(HERE, name), cfg=np.array([6, Ve, 9, dt, de, dr, 3, 1, H, L, 46, 2, 5, 1, use_relu], np.int32),
+                        theta=theta.astype(np.float32), idx=idx, labels=labels, path_scores=ps, pooled=pooled,
+                        probs=probs, loss=np.float64(loss), grad=grad)
+
+
 def eval_slices():
     ref = "/root/reference/release/songPathRnn"
     out = os.path.join(HERE, "eval_chain")
@@ -68,6 +82,7 @@ def eval_slices():
 if __name__ == "__main__":
     oracle_case("c1_small.npz", 200, 4, 8, 4, 16, 1, 3, 24, 2, 11)
     oracle_case("c2_small.npz", 400, 16, 32, 16, 64, 2, 6, 16, 3, 21)
+    rnn_case("c1_rnn_small.npz", 200, 8, 16, 8, 32, 2, 6, 20, 3, 31, 1)
     if os.path.isdir("/root/reference"):
         eval_slices()
     print(sorted(os.listdir(HERE)))

@@ -230,7 +230,7 @@ def test_errors_are_codes_not_crashes():
         _ffi.Engine(6, 100, 9, 4, 8, 4, 32, L=2)  # D != H with 2 layers (OneModel.lua:236,270-273)
     assert e.value.code == _ffi.E_ARG
     with pytest.raises(_ffi.KprnError) as e:
-        _ffi.Engine(6, 100, 9, 4, 8, 4, 16, rnn_type=1)
+        _ffi.Engine(6, 100, 9, 4, 8, 4, 16, rnn_type=2)  # nn.GRU: not built, refused
     assert e.value.code == _ffi.E_UNSUPPORTED
     with pytest.raises(_ffi.KprnError) as e:
         eng.get_param("nope")
@@ -337,3 +337,69 @@ def test_large_batch_properties():
     touched[np.unique(idx[..., 1]) - 1] = True
     assert np.array_equal(before[~touched], after[~touched])
     assert np.any(before[touched] != after[touched])
+
+
+# ---- rnnType "rnn" (the shipped config.sh default): nn.Recurrence + nn.MaskZero, generic pipeline -------------
+def mk_rnn(use_relu, L, H=48, dt=8, de=24, dr=16, Ve=300, rnn_init=False, seed=5, init=0.2):
+    D = dt + de + dr
+    if L > 1:
+        assert D == H  # numLayers > 1 stacks Recurrence(D -> H) modules of one shape (OneModel.lua:268-273)
+    eng = _ffi.Engine(6, Ve, 9, dt, de, dr, H, L, rnn_type=1, use_relu=use_relu, rnn_init=1 if rnn_init else 0, param_init=init)
+    ocfg = make_cfg(Vt=6, Ve=Ve, Vr=9, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=1, use_relu=use_relu)
+    o64 = Oracle(ocfg, np.float64)
+    return eng, o64
+
+
+@pytest.mark.parametrize("use_relu,L", [(1, 1), (0, 1), (1, 2), (0, 2)])
+def test_rnn_cell_forward_backward_match_oracle(use_relu, L):
+    eng, o64 = mk_rnn(use_relu, L)
+    assert list(eng.layout().keys()) == list(o64.layout().keys())
+    theta = o64.init_params(5, 0.2).astype(np.float32).astype(np.float64)
+    o64.zero_pad(theta)  # pad embeddings are zero => pad steps are masked (MaskZero) until the first real step
+    eng.set_flat_params(theta.astype(np.float32))
+    idx, labels = synth.make_paths(37, 3, 6, Ve=300, seed=8)  # 73 % of the paths carry two LEFT pad steps
+    b = eng.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    ps, pooled, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5
+    np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=SCORE_RTOL)
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels, class_id=1)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], og[off:off + n]) < GRAD_RTOL, nm
+
+
+def test_rnn_identity_init_and_training_steps():
+    """-rnnInitialization 1: eye / zero-bias init (OneModel.lua:310-322); then 12 Adam steps track the oracle"""
+    eng, o64 = mk_rnn(1, 2, rnn_init=True, init=0.1)
+    got = eng.get_flat_params()
+    lay = eng.layout()
+    for l in (1, 2):
+        off, (H, din) = lay[f"rnn{l}.i2h.weight"]
+        assert np.array_equal(got[off:off + H * din], np.eye(din, H, dtype=np.float32).ravel())
+        off, _ = lay[f"rnn{l}.h2h.weight"]
+        assert np.array_equal(got[off:off + H * H], np.eye(H, dtype=np.float32).ravel())
+        for nm in ("i2h.bias", "h2h.bias"):
+            off, shp = lay[f"rnn{l}.{nm}"]
+            assert not got[off:off + shp[0]].any()
+    theta = got.astype(np.float64)
+    th = theta.copy()
+    st = o64.new_state()
+    batches = [synth.make_paths(24, P, 6, Ve=300, seed=30 + P) for P in (2, 3)]
+    gb = [eng.batch(i, l) for i, l in batches]
+    opt, oopt = _ffi.make_opt(method=1, lr=2e-3), make_opt(method=1, lr=2e-3)
+    for s in range(12):
+        i, l = batches[s % 2]
+        ol, _ = o64.train_step(th, st, oopt, i, l)
+        gl = eng.train_step(gb[s % 2], opt)
+        assert abs(gl - ol) < 2e-4 * max(1, abs(ol)), (s, gl, ol)
+    assert float(np.max(np.abs(eng.get_flat_params() - th))) < 2e-4
+
+
+def test_gru_is_refused_not_emulated():
+    with pytest.raises(_ffi.KprnError) as ei:
+        _ffi.Engine(6, 300, 9, 16, 32, 16, 64, 1, rnn_type=2)
+    assert ei.value.code == _ffi.E_UNSUPPORTED

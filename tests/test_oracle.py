@@ -2,6 +2,7 @@
 an independent PyTorch-CPU autograd implementation, finite differences and hand-computed
 known answers."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -167,3 +168,65 @@ def test_threads_do_not_change_the_answer():
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(__file__))).decode().split())
     assert abs(float(outs[0][0]) - float(outs[1][0])) < 1e-13
     assert abs(float(outs[0][1]) - float(outs[1][1])) < 1e-10
+
+
+# ---- rnnType "rnn": nn.Recurrence + nn.MaskZero [A7] --------------------------------------------------------
+def _torch_rnn_loss(o, theta, idx, labels, use_relu):
+    """independent restatement with torch autograd: the mask follows the actual step input rows of each layer"""
+    import torch
+    c = o.cfg
+    lay = o.layout()
+    th = torch.tensor(theta, dtype=torch.float64, requires_grad=True)
+
+    def P(name):
+        off, shp = lay[name]
+        return th[off:off + int(np.prod(shp))].reshape(shp)
+    ids = torch.tensor(idx.astype(np.int64)) - 1
+    B, Pn, T, F = idx.shape
+    x = torch.cat([P("type_emb")[ids[..., 0]], P("entity_emb")[ids[..., 1]], P("relation_emb")[ids[..., 2]]], dim=-1).reshape(B * Pn, T, -1)
+    seq = [x[:, t] for t in range(T)]
+    for l in range(c.L):
+        Wi, bi, Wh, bh = (P(f"rnn{l + 1}.{n}") for n in ("i2h.weight", "i2h.bias", "h2h.weight", "h2h.bias"))
+        h = torch.zeros(B * Pn, c.H, dtype=torch.float64)
+        out = []
+        for t in range(T):
+            a = seq[t] @ Wi.T + bi + h @ Wh.T + bh
+            v = torch.relu(a) if use_relu else torch.tanh(a)
+            m = (seq[t] != 0).any(dim=1, keepdim=True).to(torch.float64)
+            h = v * m
+            out.append(h)
+        seq = out
+    s = seq[-1] @ P("out.weight").T + P("out.bias")
+    y = torch.logsumexp(s.reshape(B, Pn, -1), dim=1)
+    p = torch.sigmoid(y)[:, 0]
+    t = torch.tensor(labels, dtype=torch.float64)
+    eps = 1e-12
+    loss = -(t * torch.log(p + eps) + (1 - t) * torch.log(1 - p + eps)).mean()
+    loss.backward()
+    return float(loss), th.grad.numpy()
+
+
+@pytest.mark.parametrize("use_relu,L", [(1, 1), (0, 2), (1, 2)])
+def test_rnn_cell_matches_torch_autograd(use_relu, L):
+    cfg = make_cfg(Vt=6, Ve=60, Vr=9, dt=4, de=4, dr=4, H=12, L=L, rnn_type=1, use_relu=use_relu)
+    o = Oracle(cfg, np.float64)
+    theta = o.init_params(2, 0.4)
+    o.zero_pad(theta)
+    idx, labels = synth.make_paths(9, 3, 5, Ve=60, seed=4)
+    loss, g, _ = o.forward_backward(theta, idx, labels, class_id=1, bce_literal=True)
+    tl, tg = _torch_rnn_loss(o, theta, idx, labels, use_relu)
+    assert abs(loss - tl) < 1e-12
+    assert np.max(np.abs(g - tg)) < 1e-11
+
+
+def test_rnn_golden_vector():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_rnn_small.npz"))
+    c = [int(x) for x in z["cfg"]]
+    cfg = make_cfg(Vt=c[0], Ve=c[1], Vr=c[2], dt=c[3], de=c[4], dr=c[5], F=c[6], numTypes=c[7], H=c[8], L=c[9], C_=c[10], reducer=c[11], K=c[12],
+                   rnn_type=c[13], use_relu=c[14])
+    o = Oracle(cfg, np.float64)
+    ps, pooled, probs = o.forward(z["theta"].astype(np.float64), z["idx"])
+    np.testing.assert_allclose(ps, z["path_scores"], rtol=0, atol=1e-12)
+    loss, g, _ = o.forward_backward(z["theta"].astype(np.float64), z["idx"], z["labels"])
+    assert abs(loss - float(z["loss"])) < 1e-12
+    np.testing.assert_allclose(g, z["grad"], rtol=0, atol=1e-12)
