@@ -403,3 +403,38 @@ def test_gru_is_refused_not_emulated():
     with pytest.raises(_ffi.KprnError) as ei:
         _ffi.Engine(6, 300, 9, 16, 32, 16, 64, 1, rnn_type=2)
     assert ei.value.code == _ffi.E_UNSUPPORTED
+
+
+# ---- BASELINE.json configs as parity cases (the bench line is configs[1]; the others are checked here) ---------------
+def test_config4_shape_d128_fp32_generic():
+    """configs[3] shape: d = 128 per slice => D = H = 384 (here L = 1, small vocabulary).  The bf16 MFMA variant of that
+    config is not built yet; the fp32 generic pipeline must already be correct at this shape (it is what a bf16 path
+    will be checked against)."""
+    eng = _ffi.Engine(6, 500, 100, 128, 128, 128, 384, 1)
+    ocfg = make_cfg(Vt=6, Ve=500, Vr=100, dt=128, de=128, dr=128, H=384, L=1)
+    o64 = Oracle(ocfg, np.float64)
+    theta = o64.init_params(9, 0.05).astype(np.float32).astype(np.float64)
+    eng.set_flat_params(theta.astype(np.float32))
+    idx, labels = synth.make_paths(40, 2, 6, Ve=500, Vr=100, seed=14)
+    b = eng.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    ps, _, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5
+    np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=SCORE_RTOL)
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    assert rel_inf(eng.get_flat_grads(), og) < GRAD_RTOL
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_config5_variable_length_buckets_inference(impl):
+    """configs[4]: variable path length <= 7, inference only.  Paths are bucketed by identical T (left-pad semantics are
+    kept inside a bucket: pads are NOT no-ops in the reference LSTM), d = 64, each bucket scored on its own."""
+    eng, o64, theta = mk(L=2, impl=impl)
+    for T in (3, 4, 5, 6, 7):
+        idx, _ = synth.make_paths(50, 2, T, Ve=300, seed=40 + T)
+        out = eng.forward(eng.batch(idx), 1, want=("probs", "path_scores"))
+        ps, _, probs = o64.forward(theta, idx)
+        assert rel_inf(out["path_scores"], ps) < 2e-5, T
+        np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=SCORE_RTOL)
