@@ -34,17 +34,6 @@ __global__ void k_validate(const int32_t* __restrict__ idx, int64_t nsteps, int 
   if (bad) atomicOr(flag, 1);
 }
 
-// distinct entity rows of a batch (0-based), via a tag array
-__global__ void k_unique(const int32_t* __restrict__ idx, int64_t nsteps, int F, int32_t* stamp, int32_t tag, int32_t* list, int32_t* count) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nsteps) return;
-  int32_t r = idx[i * F + F - 2] - 1;
-  if (atomicExch(&stamp[r], tag) != tag) {
-    int32_t pos = atomicAdd(count, 1);
-    list[pos] = r;
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // FeatureEmbedding:getEmbeddingNetworkBothEntitiesAndTypes (net/FeatureEmbedding.lua:112-121):
 // x[n,t,:] = [ sum_k Wt[type_k] | We[ent] | Wr[rel] ]; one float4 (or scalar) per thread.
@@ -238,60 +227,6 @@ __global__ void k_pool(const float* __restrict__ S, int B, int P, int C, int red
   if (sel && c == cid) sel[b] = pr;
 }
 
-__global__ void k_select(const float* __restrict__ probs, int B, int C, int cid, float* __restrict__ sel) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) sel[b] = probs[(int64_t)b * C + cid];
-}
-
-// nn.BCECriterion forward/backward + nn.Sigmoid backward + reducer backward, column classId only
-// (MyOptimizer.lua:193-195,126; LogSumExp.lua:30-36; TopK.lua:34-38).  lossb[b] = per-pair loss term.
-__global__ void k_bce_dscore(const float* __restrict__ S, const float* __restrict__ pooled, const float* __restrict__ probs,
-                             const float* __restrict__ labels, int B, int P, int C, int cid, int reducer, int K, int literal, float invB,
-                             float* __restrict__ lossb, float* __restrict__ dS) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const float eps = 1e-12f;
-  float p = probs[(int64_t)b * C + cid];
-  float t = labels[b];
-  lossb[b] = -(t * logf(p + eps) + (1.f - t) * logf(1.f - p + eps)) * invB;
-  float dy;
-  if (literal) {
-    float dp = -(t - p) / ((1.f - p + eps) * (p + eps)) * invB;
-    dy = dp * p * (1.f - p);
-  } else {
-    dy = (p - t) * invB;
-  }
-  const float* s = S + (int64_t)b * P * C + cid;
-  float* d = dS + (int64_t)b * P;
-  if (reducer == 2) {
-    float y = pooled[(int64_t)b * C + cid];
-    // exp(s - m)/sum == exp(s - y)
-    float m = s[0];
-    for (int q = 1; q < P; ++q) m = fmaxf(m, s[(int64_t)q * C]);
-    float sum = 0.f;
-    for (int q = 0; q < P; ++q) sum += expf(s[(int64_t)q * C] - m);
-    (void)y;
-    for (int q = 0; q < P; ++q) d[q] = expf(s[(int64_t)q * C] - m) / sum * dy;
-  } else if (reducer == 0) {
-    int arg = 0;
-    for (int q = 1; q < P; ++q) if (s[(int64_t)q * C] > s[(int64_t)arg * C]) arg = q;
-    for (int q = 0; q < P; ++q) d[q] = (q == arg) ? dy : 0.f;
-  } else {
-    int kk = K < P ? K : P;
-    for (int q = 0; q < P; ++q) d[q] = 0.f;
-    float last_v = INFINITY; int last_i = -1;
-    for (int r = 0; r < kk; ++r) {
-      float best = -INFINITY; int bi = -1;
-      for (int q = 0; q < P; ++q) {
-        float v = s[(int64_t)q * C];
-        bool after = (v < last_v) || (v == last_v && q > last_i);
-        if (after && (bi < 0 || v > best)) { best = v; bi = q; }
-      }
-      d[bi] = dy / (float)kk; last_v = best; last_i = bi;
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // The whole loss stage of a training step in one launch:
 //   A  reducer over the P paths + nn.Sigmoid + nn.Select for every class          (OneModel.lua:284-294, MyOptimizer.lua:126)
@@ -415,20 +350,6 @@ __global__ void k_sum_partials(const float* __restrict__ partial, int n, float* 
     __syncthreads();
   }
   if (threadIdx.x == 0) *out = s;
-}
-
-// deterministic single-block sum
-__global__ void k_sum_det(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
-  __shared__ float red[1024];
-  float acc = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += x[i];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *out = red[0];
 }
 
 // nn.Linear(H,46) backward restricted to the selected column (OneModel.lua:275; Select at MyOptimizer.lua:126)
@@ -665,21 +586,6 @@ __global__ void k_pack_rows(float* __restrict__ G, const int32_t* __restrict__ r
   }
 }
 
-__global__ void k_unpack_add(float* __restrict__ G, const int32_t* __restrict__ ids, const float* __restrict__ rows,
-                             const int32_t* __restrict__ count, int d, int32_t* __restrict__ stamp, int32_t tag, int32_t* __restrict__ list,
-                             int32_t* __restrict__ list_count) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (wave >= *count) return;
-  const int64_t r = ids[wave];
-  if (lane == 0) {
-    if (atomicExch(&stamp[r], tag) != tag) { int32_t pos = atomicAdd(list_count, 1); list[pos] = (int32_t)r; }
-  }
-  // ids within one packed buffer are distinct, and buffers are applied one launch at a time in
-  // rank order, so each element sees a fixed addition order on every rank.
-  for (int e = lane; e < d; e += 64) G[r * d + e] += rows[wave * d + e];
-}
-
 __global__ void k_clear_rows(float* __restrict__ G, const int32_t* __restrict__ rows, const int32_t* __restrict__ count, int d) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -690,21 +596,6 @@ __global__ void k_clear_rows(float* __restrict__ G, const int32_t* __restrict__ 
 
 // per (64-row tile, step): leader[row] = first row of the tile with the same entity id (-1 past N).
 // Used by the fused backward to fold duplicate rows before the embedding-gradient atomics.
-__global__ void k_tile_leaders(const int32_t* __restrict__ idx, int64_t N, int T, int F, int32_t* __restrict__ lead) {
-  __shared__ int32_t e[64];
-  const int64_t tile = blockIdx.x / T;
-  const int t = blockIdx.x % T;
-  const int r = threadIdx.x;
-  const int64_t n = tile * 64 + r;
-  const bool valid = n < N;
-  e[r] = valid ? idx[(n * T + t) * F + F - 2] : -1 - r;
-  __syncthreads();
-  int ld = r;
-  for (int r2 = 0; r2 < r; ++r2)
-    if (e[r2] == e[r]) { ld = r2; break; }
-  lead[n * T + t] = valid ? ld : -1;
-}
-
 // uniform(-a, a) init (OneModel.lua:306-309); counter-based splitmix64
 __global__ void k_fill_uniform(float* __restrict__ x, int64_t n, float a, uint64_t seed, uint64_t offset) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -729,11 +620,6 @@ void validate_indices(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, 
   CHECK_LAUNCH();
 }
 
-void unique_rows(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int32_t* stamp, int32_t tag, int32_t* list, int32_t* count) {
-  if (nsteps <= 0) return;
-  hipLaunchKernelGGL(k_unique, dim3(nblocks(nsteps)), dim3(TPB), 0, s, idx, nsteps, F, stamp, tag, list, count);
-  CHECK_LAUNCH();
-}
 
 void embed_gather(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* Wt, const float* We, const float* Wr,
                   int dt, int de, int dr, float* X, bool time_major) {
@@ -816,22 +702,7 @@ void sum_partials(hipStream_t s, const float* partial, int n, float* out) {
   CHECK_LAUNCH();
 }
 
-void select_col(hipStream_t s, const float* probs, int B, int C, int cid, float* sel) {
-  if (B <= 0) return;
-  hipLaunchKernelGGL(k_select, dim3(nblocks(B)), dim3(TPB), 0, s, probs, B, C, cid, sel);
-  CHECK_LAUNCH();
-}
 
-void bce_and_dscore(hipStream_t s, const float* S, const float* pooled, const float* probs, const float* labels, int B, int P, int C, int cid,
-                    int reducer, int K, int literal, float invB, float* loss, float* dS) {
-  if (B <= 0) return;
-  // dS doubles as scratch owner: per-pair loss terms live in the tail of dS ([N] .. [N+B))
-  float* lossb = dS + (int64_t)B * P;
-  hipLaunchKernelGGL(k_bce_dscore, dim3(nblocks(B)), dim3(TPB), 0, s, S, pooled, probs, labels, B, P, C, cid, reducer, K, literal, invB, lossb, dS);
-  CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_sum_det, dim3(1), dim3(1024), 0, s, lossb, (int64_t)B, loss);
-  CHECK_LAUNCH();
-}
 
 void head_bwd(hipStream_t s, const float* dS, const float* hT, const float* Wout, int64_t N, int H, int cid, float* dH, float* gWout, float* gbout) {
   if (N <= 0) return;
@@ -924,12 +795,6 @@ void pack_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* coun
   CHECK_LAUNCH();
 }
 
-void unpack_add_rows(hipStream_t s, float* G, const int32_t* ids, const float* rows, const int32_t* count, int64_t max_rows, int d, int32_t* stamp,
-                     int32_t tag, int32_t* list, int32_t* list_count) {
-  if (max_rows <= 0) return;
-  hipLaunchKernelGGL(k_unpack_add, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, G, ids, rows, count, d, stamp, tag, list, list_count);
-  CHECK_LAUNCH();
-}
 
 void fill_uniform(hipStream_t s, float* x, int64_t n, float a, uint64_t seed, uint64_t offset) {
   if (n <= 0) return;
@@ -943,12 +808,6 @@ void clear_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* cou
   CHECK_LAUNCH();
 }
 
-void tile_leaders(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int32_t* lead) {
-  if (N <= 0) return;
-  const int64_t tiles = (N + 63) / 64;
-  hipLaunchKernelGGL(k_tile_leaders, dim3((unsigned)(tiles * T)), dim3(64), 0, s, idx, N, T, F, lead);
-  CHECK_LAUNCH();
-}
 
 void fill_i32(hipStream_t s, int32_t* x, int64_t n, int32_t v) {
   if (n <= 0) return;

@@ -623,7 +623,7 @@ int kprn_create(const kprn_config* cfg, kprn_handle** out) {
     h->s1_dense = dalloc<float>(h->n_dense); h->s2_dense = dalloc<float>(h->n_dense);
     h->We = dalloc<float>(h->n_ent); h->g_We = dalloc<float>(h->n_ent);
     h->s1_We = dalloc<float>(h->n_ent); h->s2_We = dalloc<float>(h->n_ent);
-    h->We_last = dalloc<int32_t>(c.Ve); h->We_stamp = dalloc<int32_t>(c.Ve);
+    h->We_last = dalloc<int32_t>(c.Ve);
     h->d_loss = dalloc<float>(4); h->d_norm2 = dalloc<float>(4); h->d_flag = dalloc<int32_t>(4);
     h->step_count = dalloc<int32_t>(4);
     HIP_TRY(hipHostMalloc((void**)&h->h_pinned, 64 * sizeof(float)));
@@ -631,7 +631,6 @@ int kprn_create(const kprn_config* cfg, kprn_handle** out) {
     for (float* p : {h->g_dense, h->s1_dense, h->s2_dense}) HIP_TRY(hipMemsetAsync(p, 0, (size_t)h->n_dense * sizeof(float), s));
     for (float* p : {h->g_We, h->s1_We, h->s2_We}) HIP_TRY(hipMemsetAsync(p, 0, (size_t)h->n_ent * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(h->We_last, 0, (size_t)c.Ve * sizeof(int32_t), s));
-    HIP_TRY(hipMemsetAsync(h->We_stamp, 0, (size_t)c.Ve * sizeof(int32_t), s));
     HIP_TRY(hipMemsetAsync(h->d_loss, 0, 4 * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(h->step_count, 0, 4 * sizeof(int32_t), s));
     // param:uniform(-paramInit, paramInit) over training_net:parameters() (OneModel.lua:306-309)
@@ -683,7 +682,7 @@ void kprn_destroy(kprn_handle* h) {
   for (float** p : {&h->dense, &h->g_dense, &h->s1_dense, &h->s2_dense, &h->We, &h->g_We, &h->s1_We, &h->s2_We, &h->d_loss, &h->d_norm2,
                     &h->step_tab})
     dfree(*p);
-  for (int32_t** p : {&h->We_last, &h->We_stamp, &h->d_flag, &h->step_rows, &h->step_count, &h->pack_buf}) dfree(*p);
+  for (int32_t** p : {&h->We_last, &h->d_flag, &h->step_rows, &h->step_count, &h->pack_buf}) dfree(*p);
   if (h->step_tab_host) hipHostFree(h->step_tab_host);
   if (h->h_pinned) hipHostFree(h->h_pinned);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);

@@ -91,8 +91,6 @@ struct kprn_handle {
 
   // lazy-exact entity update bookkeeping
   int32_t* We_last = nullptr;   // [Ve] optimiser step each row is current to
-  int32_t* We_stamp = nullptr;  // [Ve] membership tags for the per-batch / per-step row lists
-  int32_t next_tag = 1;
   int64_t opt_step = 0;         // optState.t / evalCounter
   int opt_method = -1;
   float* step_tab = nullptr;    // device: adam step size of every step so far (index = step)
@@ -108,7 +106,6 @@ struct kprn_handle {
   int32_t* step_count = nullptr; // device scalar
   int64_t step_rows_cap = 0;
   int64_t step_rows_ub = 0;      // host-side upper bound of *step_count
-  int32_t step_tag = 0;
   // the list the optimiser walks: the handle's own buffers, or a VIEW of a batch's distinct-row list (single-rank
   // training: no copy; materialised before the batch can go away or the data-parallel exchange rewrites it)
   const int32_t* rows_view = nullptr; const int32_t* count_view = nullptr; const kprn_batch* view_batch = nullptr;
@@ -153,7 +150,6 @@ void prof_drain(kprn_handle* h);
 // ---- kernels (kernels_basic.hip) -----------------------------------------------------------
 namespace kk {
 void validate_indices(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int nT, int Vt, int Ve, int Vr, int32_t* flag);
-void unique_rows(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int32_t* stamp, int32_t tag, int32_t* list, int32_t* count);
 void embed_gather(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* Wt, const float* We,
                   const float* Wr, int dt, int de, int dr, float* X, bool time_major);
 void lstm_gates_fwd(hipStream_t s, float* act /*[N][4H] in: pre-act, out: gates*/, const float* c_prev, float* c, float* h, int64_t N, int H);
@@ -171,9 +167,6 @@ void loss_stage(hipStream_t s, const float* S, const float* labels, const float*
 void sum_partials(hipStream_t s, const float* partial, int n, float* out);
 int loss_partials(int B);  // number of per-workgroup loss partials the loss stage writes for B pairs
 void zero_pad3(hipStream_t s, float* a, int na, float* b, int nb, float* c, int nc);
-void select_col(hipStream_t s, const float* probs, int B, int C, int cid, float* sel);
-void bce_and_dscore(hipStream_t s, const float* S, const float* pooled, const float* probs, const float* labels, int B, int P, int C,
-                    int cid, int reducer, int K, int literal, float invB, float* loss, float* dS /*[N]*/);
 void head_bwd(hipStream_t s, const float* dS, const float* hT, const float* Wout, int64_t N, int H, int cid, float* dH, float* gWout, float* gbout);
 void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* dX /*[T][N][D]*/, int dt, int de, int dr,
                    int Vt, int Vr, float* gWt, float* gWe, float* gWr);
@@ -194,7 +187,6 @@ void zero_rows(hipStream_t s, float* W, int64_t row, int d);
 void pack_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, int32_t* ids_out, float* rows_out, int32_t* count_out);
 void fill_uniform(hipStream_t s, float* x, int64_t n, float a, uint64_t seed, uint64_t offset);
 void fill_i32(hipStream_t s, int32_t* x, int64_t n, int32_t v);
-void tile_leaders(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int32_t* lead);
 void clear_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d);
 }  // namespace kk
 

@@ -71,11 +71,6 @@ __device__ __forceinline__ void ids_stage(const int32_t* idx, int64_t N, int T, 
   }
 }
 
-// slot 3 of the id tile <- precomputed tile leader (fused backward, bottom layer)
-__device__ __forceinline__ void lead_stage(const int32_t* lead, int T, int64_t tile, int32_t* ids) {
-  for (int c = threadIdx.x; c < MT * T; c += 256) ids[c * 4 + 3] = lead[tile * MT * T + c];
-}
-
 // Per-thread source of the x-row gather.  A thread always serves the same 16-byte chunk column (ch = tid & 15)
 // of rows (tid >> 4) + 16k, so the table it reads from is fixed for the whole launch: no branches per load.
 struct GatherSrc {
