@@ -82,7 +82,7 @@ _TENSOR_OF = {np.dtype(np.float64): "Double", np.dtype(np.float32): "Float", np.
 
 class _T7Reader:
     def __init__(self, buf):
-        self.b, self.o, self.objs = buf, 0, {}
+        self.b, self.o, self.objs, self.tensor_ids = buf, 0, {}, {}
 
     def _rd(self, fmt):
         v = struct.unpack_from("<" + fmt, self.b, self.o)
@@ -139,20 +139,39 @@ class _T7Reader:
                 else:
                     ten = np.lib.stride_tricks.as_strided(storage[off:], shape=size, strides=[s * storage.itemsize for s in stride]).copy()
                 self.objs[ref] = ten
+                # identity of the view (storage object, offset, shape): shared-parameter clones of the rnn library
+                # (AbstractRecurrent.sharedClones) point at the same storage and are recognised by it
+                self.tensor_ids[id(ten)] = (id(storage) if storage is not None else 0, off, tuple(size))
                 return ten
-            raise ValueError(f"unsupported torch class in .torch file: {cls}")
+            # any other torch class (nn.* modules ...): torch.File writes the object's fields as one table
+            mod = T7Object(cls)
+            self.objs[ref] = mod
+            fields = self.obj()
+            if isinstance(fields, dict):
+                mod.update(fields)
+            return mod
         raise ValueError(f"unsupported Torch7 type tag {t}")
 
 
-def t7_load(path):
+class T7Object(dict):
+    """a non-tensor torch object (e.g. an nn module): its fields, plus the Lua class name"""
+
+    def __init__(self, cls):
+        super().__init__()
+        self.torch_class = cls
+
+
+def t7_load(path, with_ids=False):
     with open(path, "rb") as f:
         buf = memoryview(f.read())
-    return _T7Reader(buf).obj()
+    r = _T7Reader(buf)
+    o = r.obj()
+    return (o, r.tensor_ids) if with_ids else o
 
 
 class _T7Writer:
     def __init__(self):
-        self.parts, self.n = [], 0
+        self.parts, self.n, self.seen = [], 0, {}
 
     def _w(self, fmt, *v):
         self.parts.append(struct.pack("<" + fmt, *v))
@@ -172,6 +191,16 @@ class _T7Writer:
         elif isinstance(v, str):
             self._w("i", _T_STRING)
             self._string(v)
+        elif isinstance(v, T7Object):
+            if id(v) in self.seen:
+                self._w("ii", _T_TORCH, self.seen[id(v)])
+                return
+            self.n += 1
+            self.seen[id(v)] = self.n
+            self._w("ii", _T_TORCH, self.n)
+            self._string("V 1")
+            self._string(v.torch_class)
+            self.obj(dict(v))
         elif isinstance(v, dict):
             self.n += 1
             self._w("iii", _T_TABLE, self.n, len(v))
@@ -192,12 +221,17 @@ class _T7Writer:
             for s in st:
                 self._w("q", s)
             self._w("q", 1)
-            self.n += 1
-            self._w("ii", _T_TORCH, self.n)
-            self._string("V 1")
-            self._string(f"torch.{name}Storage")
-            self._w("q", a.size)
-            self.parts.append(a.tobytes())
+            base = a.base if a.base is not None else a
+            if id(base) in self.seen and a.base is not None:  # a second view of a storage already written: back-reference
+                self._w("ii", _T_TORCH, self.seen[id(base)])
+            else:
+                self.n += 1
+                self.seen[id(v)] = self.n
+                self._w("ii", _T_TORCH, self.n)
+                self._string("V 1")
+                self._string(f"torch.{name}Storage")
+                self._w("q", a.size)
+                self.parts.append(a.tobytes())
         else:
             raise TypeError(type(v))
 
@@ -251,3 +285,77 @@ def save_path_file(path, labels, data, class_id=1):
         write_int_file(path, labels, data, sub_one=True)
     else:
         t7_save(path, {"labels": labels.astype(np.float64), "data": data.astype(np.float64), "classId": float(class_id)})
+
+
+# ------------------------------------------------------------------------------------------
+# reference checkpoints: torch.save{embeddingLayer=..., predictor_net=...} (OneModel.lua:392-408), read back by
+# test_from_checkpoint.lua:68-75 and -initModel (OneModel.lua:277-282).  [restated from torch7 File.lua / nn / rnn
+# object layouts, unpinned: the tree ships no checkpoint -- SURVEY.md 8f N4d; verified on synthetic object graphs only]
+
+
+def _walk_modules(o, seen, out):
+    """depth-first over an nn object graph in module order (`modules[1..n]`, then named sub-modules), collecting
+    every parameter-holding leaf once (shared-parameter step clones are skipped by object identity)."""
+    if isinstance(o, T7Object):
+        if id(o) in seen:
+            return
+        seen.add(id(o))
+        cls = o.torch_class
+        if cls in ("nn.LookupTable", "nn.Linear", "nn.LinearNoBias") and "weight" in o:
+            out.append(o)
+            return
+        mods = o.get("modules")
+        if isinstance(mods, dict):
+            for k in sorted(k for k in mods if isinstance(k, (int, float))):
+                _walk_modules(mods[k], seen, out)
+        for k in ("module", "recurrentModule", "i2g", "o2g", "inputModule", "initialModule", "feedbackModule"):
+            if k in o:
+                _walk_modules(o[k], seen, out)
+    elif isinstance(o, dict):
+        for k in sorted(k for k in o if isinstance(k, (int, float))):
+            _walk_modules(o[k], seen, out)
+
+
+def checkpoint_params(path_or_obj, num_layers=None):
+    """-> dict reference-parameter-name -> float32 array, in the engine's names (`type_emb`, `entity_emb`,
+    `relation_emb`, `lstm{l}.i2g.weight|bias`, `lstm{l}.o2g.weight` or `rnn{l}.i2h.*|h2h.*`, `out.weight|bias`),
+    extracted from a {embeddingLayer, predictor_net} checkpoint.  Feed them to Engine.set_param / kprn_set_param."""
+    ck, ids = (t7_load(path_or_obj, with_ids=True) if isinstance(path_or_obj, str) else (path_or_obj, {}))
+    if not isinstance(ck, dict) or "embeddingLayer" not in ck or "predictor_net" not in ck:
+        raise ValueError("not a {embeddingLayer, predictor_net} checkpoint (OneModel.lua:396-400)")
+    emb, pred = [], []
+    _walk_modules(ck["embeddingLayer"], set(), emb)
+    _walk_modules(ck["predictor_net"], set(), pred)
+    # shared clones that were serialised as separate objects still share storages: keep the first of each weight view
+    def dedupe(mods):
+        keep, seen_w = [], set()
+        for m in mods:
+            key = ids.get(id(m["weight"]), id(m["weight"]))
+            if key in seen_w:
+                continue
+            seen_w.add(key)
+            keep.append(m)
+        return keep
+    emb, pred = dedupe(emb), dedupe(pred)
+    tables = [m for m in emb if m.torch_class == "nn.LookupTable"]
+    if len(tables) != 3:
+        raise ValueError(f"expected 3 lookup tables (type, entity, relation: FeatureEmbedding.lua:118), found {len(tables)}")
+    out = {"type_emb": tables[0]["weight"], "entity_emb": tables[1]["weight"], "relation_emb": tables[2]["weight"]}
+    lin = [m for m in pred if m.torch_class in ("nn.Linear", "nn.LinearNoBias")]
+    if not lin:
+        raise ValueError("no nn.Linear in predictor_net")
+    head, body = lin[-1], lin[:-1]
+    out["out.weight"], out["out.bias"] = head["weight"], head["bias"]
+    if len(body) % 2 != 0:
+        raise ValueError("recurrent layers must contribute two linear maps each (i2g/o2g or i2h/h2h)")
+    L = len(body) // 2
+    if num_layers is not None and L != num_layers:
+        raise ValueError(f"checkpoint has {L} recurrent layers, expected {num_layers}")
+    for l in range(L):
+        a, b = body[2 * l], body[2 * l + 1]
+        if b.torch_class == "nn.LinearNoBias" or "bias" not in b:  # nn.FastLSTM: i2g (Linear) + o2g (LinearNoBias)
+            out[f"lstm{l + 1}.i2g.weight"], out[f"lstm{l + 1}.i2g.bias"], out[f"lstm{l + 1}.o2g.weight"] = a["weight"], a["bias"], b["weight"]
+        else:                                                       # nn.Recurrence: input2hidden + hidden2hidden
+            out[f"rnn{l + 1}.i2h.weight"], out[f"rnn{l + 1}.i2h.bias"] = a["weight"], a["bias"]
+            out[f"rnn{l + 1}.h2h.weight"], out[f"rnn{l + 1}.h2h.bias"] = b["weight"], b["bias"]
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in out.items()}
