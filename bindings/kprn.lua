@@ -18,7 +18,7 @@ ffi.cdef[[
 typedef struct kprn_handle kprn_handle;
 typedef struct kprn_batch kprn_batch;
 typedef struct {
-  int32_t Vt, Ve, Vr, dt, de, dr, F, num_types, H, L, C, rnn_type, use_relu, rnn_init, reducer, K, device_id, rank, world;
+  int32_t Vt, Ve, Vr, dt, de, dr, F, num_types, H, L, C, rnn_type, use_relu, rnn_init, compute_dtype, reducer, K, device_id, rank, world;
   float param_init; uint64_t seed; void* stream;
 } kprn_config;
 typedef struct {
@@ -56,7 +56,7 @@ function M.create(o)
   cfg.F, cfg.num_types = o.F or 3, o.num_types or 1
   cfg.H, cfg.L, cfg.C = o.H, o.L or 1, o.C or 46
   cfg.rnn_type, cfg.reducer, cfg.K = o.rnn_type or 0, o.reducer or 2, o.K or 5
-  cfg.use_relu, cfg.rnn_init = o.use_relu or 1, o.rnn_init or 0
+  cfg.use_relu, cfg.rnn_init, cfg.compute_dtype = o.use_relu or 1, o.rnn_init or 0, o.compute_dtype or 0
   cfg.device_id, cfg.rank, cfg.world = o.device_id or 0, 0, 1
   cfg.param_init, cfg.seed = o.paramInit or 0.1, o.seed or 12345
   local ph = ffi.new('kprn_handle*[1]')

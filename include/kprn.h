@@ -67,6 +67,9 @@ typedef struct {
                                 the shipped config.sh default; generic pipeline), 2 = gru -> KPRN_E_UNSUPPORTED */
   int32_t use_relu;          /* -useReLU (rnn): 1 = nn.ReLU, else nn.Tanh (OneModel.lua:225-229)  */
   int32_t rnn_init;          /* -rnnInitialization (rnn): i2h / h2h weights <- eye, biases <- 0 (OneModel.lua:310-322) */
+  int32_t compute_dtype;     /* 0 = f32 (exact fp32 MFMA; the reference's arithmetic type on GPU).  1 = bf16: the recurrent / head GEMMs
+                                multiply in bf16 (operands rounded to nearest even) and accumulate in f32; parameters, activations and
+                                the optimiser stay f32.  New option (BASELINE configs[3]); generic pipeline only.          */
   int32_t reducer;           /* -topK: 0 = Max, 1 = TopK+Mean, 2 = LogSumExp (OneModel.lua:284-293) */
   int32_t K;                 /* -K                                                               */
   int32_t device_id;         /* HIP device ordinal                                               */

@@ -26,7 +26,7 @@ E_ARG, E_INDEX, E_DEVICE, E_UNSUPPORTED, E_IO, E_NOMEM = -1, -2, -3, -4, -5, -6
 
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("Vt", "Ve", "Vr", "dt", "de", "dr", "F", "num_types", "H", "L", "C",
-                                          "rnn_type", "use_relu", "rnn_init", "reducer", "K", "device_id", "rank", "world")] + \
+                                          "rnn_type", "use_relu", "rnn_init", "compute_dtype", "reducer", "K", "device_id", "rank", "world")] + \
                [("param_init", C.c_float), ("seed", C.c_uint64), ("stream", C.c_void_p)]
 
 
@@ -127,9 +127,9 @@ class Engine:
     """Thin object wrapper over one kprn_handle."""
 
     def __init__(self, Vt, Ve, Vr, dt, de, dr, H, L=1, F=3, num_types=1, C_=46, reducer=2, K=5, rnn_type=0, device_id=0,
-                 rank=0, world=1, param_init=0.1, seed=12345, stream=None, use_relu=1, rnn_init=0):
+                 rank=0, world=1, param_init=0.1, seed=12345, stream=None, use_relu=1, rnn_init=0, compute_dtype=0):
         self.L = lib()
-        self.cfg = Config(Vt, Ve, Vr, dt, de, dr, F, num_types, H, L, C_, rnn_type, use_relu, rnn_init, reducer, K, device_id, rank, world,
+        self.cfg = Config(Vt, Ve, Vr, dt, de, dr, F, num_types, H, L, C_, rnn_type, use_relu, rnn_init, compute_dtype, reducer, K, device_id, rank, world,
                           param_init, seed, stream)
         self.h = C.c_void_p()
         rc = self.L.kprn_create(C.byref(self.cfg), C.byref(self.h))

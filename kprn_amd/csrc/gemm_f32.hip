@@ -1,4 +1,7 @@
-// Generic fp32 GEMM on the gfx950 f32 MFMA (v_mfma_f32_16x16x4_f32, exact f32, 157 TF peak).
+// Generic GEMM on the gfx950 MFMA: fp32 (v_mfma_f32_16x16x4_f32, exact f32, 157 TF peak) or, compute_dtype = bf16,
+// bf16 products with fp32 accumulation (v_mfma_f32_16x16x16_bf16; operands stay fp32 in HBM / LDS and are rounded to
+// nearest-even bf16 as the fragments are formed -- BASELINE.json configs[3] "bf16 MFMA LSTM", first step: the
+// arithmetic; bf16 storage and a fused bf16 kernel are later rounds).
 //
 // This is the shape-agnostic fallback of the engine: any M, N, K, any operand strides
 // (so A*B^T, A*B and A^T*B are one kernel), boundary-checked, optional split-K.  The
@@ -13,10 +16,18 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// fp32 -> bf16, round to nearest even (finite inputs)
+__device__ __forceinline__ short to_bf16(float x) {
+  unsigned int u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (short)(u >> 16);
+}
 
 constexpr int BM = 64, BN = 64, BK = 16, LDT = 80;  // LDT: k-major tile row stride (conflict-free frag reads)
 
-template <bool A_KCONTIG, bool B_NCONTIG>
+template <bool A_KCONTIG, bool B_NCONTIG, bool BF16>
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int64_t sAm, int64_t sAk,
                                                    const float* __restrict__ B, int64_t sBk, int64_t sBn,
                                                    float* __restrict__ C, int64_t ldc, int64_t M, int N, int64_t K,
@@ -62,6 +73,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
       Bs[k][n] = v;
     }
     __syncthreads();
+    if (BF16) {
+      // one 16x16x16 bf16 MFMA per accumulator and k-step: lane (col = lane&15, kg = lane>>4) supplies k = 4kg..4kg+3
+      s16x4 a[2], b[2];
+      const int kb = (lane >> 4) * 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[i][q] = to_bf16(As[kb + q][wm * 32 + i * 16 + (lane & 15)]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[j][q] = to_bf16(Bs[kb + q][wn * 32 + j * 16 + (lane & 15)]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[j], acc[i][j], 0, 0, 0);
+    } else
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
       float a[2], b[2];
@@ -107,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 namespace gemm {
 
 void run(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C,
-         int64_t ldc, int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k) {
+         int64_t ldc, int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k, bool bf16) {
   if (M <= 0 || N <= 0) return;
   if (split_k < 1) split_k = 1;
   int64_t kchunk = (K + split_k - 1) / split_k;
@@ -120,8 +148,14 @@ void run(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B
   const int use_atomic = split_k > 1 ? 1 : 0;
   const bool akc = (sAk == 1), bnc = (sBn == 1);
 #define LAUNCH(AK, BNC)                                                                                            \
-  hipLaunchKernelGGL((gemm_kernel<AK, BNC>), grid, dim3(256), 0, s, A, sAm, sAk, B, sBk, sBn, C, ldc, M, N, K,     \
-                     accumulate ? 1 : 0, bias, kchunk, use_atomic)
+  do {                                                                                                             \
+    if (bf16)                                                                                                      \
+      hipLaunchKernelGGL((gemm_kernel<AK, BNC, true>), grid, dim3(256), 0, s, A, sAm, sAk, B, sBk, sBn, C, ldc, M, N, K, \
+                         accumulate ? 1 : 0, bias, kchunk, use_atomic);                                            \
+    else                                                                                                           \
+      hipLaunchKernelGGL((gemm_kernel<AK, BNC, false>), grid, dim3(256), 0, s, A, sAm, sAk, B, sBk, sBn, C, ldc, M, N, K, \
+                         accumulate ? 1 : 0, bias, kchunk, use_atomic);                                            \
+  } while (0)
   if (akc && bnc) LAUNCH(true, true);
   else if (akc && !bnc) LAUNCH(true, false);
   else if (!akc && bnc) LAUNCH(false, true);

@@ -240,6 +240,7 @@ static void catch_up(kprn_handle* h, const kprn_batch* b) {
 // generic (unfused) forward: gather -> per layer {input GEMM, per step recurrent GEMM + gates} -> head
 static void forward_generic(kprn_handle* h, const kprn_batch* b) {
   const kprn_config& c = h->cfg;
+  const bool bf = c.compute_dtype == 1;  // bf16 MFMA products, fp32 accumulation (gemm_f32.hip)
   Workspace& w = h->ws;
   const int H = c.H, L = c.L, D = h->D, T = b->T;
   const int64_t N = (int64_t)b->B * b->P;
@@ -258,7 +259,7 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b) {
       float* mask = w.mask + (int64_t)l * T * N;
       {
         ProfScope ps(h, "gemm_i2g_fwd");
-        gemm::run(s, in, Din, 1, h->dense + h->layer[l].Wi, 1, Din, pre, H, (int64_t)T * N, H, Din, false, h->dense + h->layer[l].bi, 1);
+        gemm::run(s, in, Din, 1, h->dense + h->layer[l].Wi, 1, Din, pre, H, (int64_t)T * N, H, Din, false, h->dense + h->layer[l].bi, 1, bf);
       }
       {
         ProfScope ps(h, "rnn_mask");
@@ -268,7 +269,7 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b) {
         float* pre_t = pre + (int64_t)t * N * H;
         if (t > 0) {
           ProfScope ps(h, "gemm_o2g_fwd");
-          gemm::run(s, hs + (int64_t)(t - 1) * N * H, H, 1, h->dense + h->layer[l].Wo, 1, H, pre_t, H, N, H, H, true, nullptr, 1);
+          gemm::run(s, hs + (int64_t)(t - 1) * N * H, H, 1, h->dense + h->layer[l].Wo, 1, H, pre_t, H, N, H, H, true, nullptr, 1, bf);
         }
         ProfScope ps(h, "rnn_cell_fwd");
         kk::rnn_cell_fwd(s, pre_t, h->dense + h->layer[l].bo, mask + (int64_t)t * N, hs + (int64_t)t * N * H, N, H, c.use_relu == 1 ? 1 : 0);
@@ -287,13 +288,13 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b) {
     const float* Wo = h->dense + h->layer[l].Wo;
     {
       ProfScope ps(h, "gemm_i2g_fwd");
-      gemm::run(s, in, Din, 1, Wi, 1, Din, act, 4 * H, (int64_t)T * N, 4 * H, Din, false, bi, 1);
+      gemm::run(s, in, Din, 1, Wi, 1, Din, act, 4 * H, (int64_t)T * N, 4 * H, Din, false, bi, 1, bf);
     }
     for (int t = 0; t < T; ++t) {
       float* act_t = act + (int64_t)t * N * 4 * H;
       if (t > 0) {
         ProfScope ps(h, "gemm_o2g_fwd");
-        gemm::run(s, hs + (int64_t)(t - 1) * N * H, H, 1, Wo, 1, H, act_t, 4 * H, N, 4 * H, H, true, nullptr, 1);
+        gemm::run(s, hs + (int64_t)(t - 1) * N * H, H, 1, Wo, 1, H, act_t, 4 * H, N, 4 * H, H, true, nullptr, 1, bf);
       }
       ProfScope ps(h, "lstm_gates_fwd");
       kk::lstm_gates_fwd(s, act_t, t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr, cs + (int64_t)t * N * H, hs + (int64_t)t * N * H, N, H);
@@ -302,7 +303,7 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b) {
   {
     ProfScope ps(h, "gemm_head_fwd");
     const float* hT = w.Hs + ((int64_t)(L - 1) * T + (T - 1)) * N * H;
-    gemm::run(s, hT, H, 1, h->dense + h->off_outW, 1, H, w.S, c.C, N, c.C, H, false, h->dense + h->off_outb, 1);
+    gemm::run(s, hT, H, 1, h->dense + h->off_outW, 1, H, w.S, c.C, N, c.C, H, false, h->dense + h->off_outb, 1, bf);
   }
 }
 
@@ -319,7 +320,7 @@ static void check_batch(kprn_handle* h, const kprn_batch* b, int class_id) {
 }
 
 static bool use_fused(kprn_handle* h, const kprn_batch* b, bool save_for_backward) {
-  if (h->impl != 0 || h->cfg.rnn_type != 0 || !fused::fwd_supported(h, b->T)) return false;
+  if (h->impl != 0 || h->cfg.rnn_type != 0 || h->cfg.compute_dtype != 0 || !fused::fwd_supported(h, b->T)) return false;
   return !save_for_backward || fused::bwd_supported(h, b->T);
 }
 
@@ -350,6 +351,7 @@ static void zero_grads(kprn_handle* h) {
 
 static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
   const kprn_config& c = h->cfg;
+  const bool bf = c.compute_dtype == 1;
   Workspace& w = h->ws;
   const int H = c.H, L = c.L, D = h->D, T = b->T;
   const int64_t N = (int64_t)b->B * b->P;
@@ -383,16 +385,16 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
         }
         if (t > 0) {
           ProfScope ps(h, "gemm_o2g_bwd_dh");
-          gemm::run(s, dA_t, H, 1, Wo, H, 1, w.dH, H, N, H, H, false, nullptr, 1);
+          gemm::run(s, dA_t, H, 1, Wo, H, 1, w.dH, H, N, H, H, false, nullptr, 1, bf);
         }
       }
       if (T > 1) {
         ProfScope ps(h, "gemm_o2g_bwd_dw");
-        gemm::run(s, w.dA + (int64_t)N * H, 1, H, hs, H, 1, gd + h->layer[l].Wo, H, H, H, (int64_t)(T - 1) * N, true, nullptr, split);
+        gemm::run(s, w.dA + (int64_t)N * H, 1, H, hs, H, 1, gd + h->layer[l].Wo, H, H, H, (int64_t)(T - 1) * N, true, nullptr, split, bf);
       }
       {
         ProfScope ps(h, "gemm_i2g_bwd_dw");
-        gemm::run(s, w.dA, 1, H, in, Din, 1, gd + h->layer[l].Wi, Din, H, Din, (int64_t)T * N, true, nullptr, split);
+        gemm::run(s, w.dA, 1, H, in, Din, 1, gd + h->layer[l].Wi, Din, H, Din, (int64_t)T * N, true, nullptr, split, bf);
       }
       {
         ProfScope ps(h, "bias_colsum");  // i2h.bias and h2h.bias see the same gradient (both are added to every pre-activation)
@@ -401,7 +403,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       }
       {
         ProfScope ps(h, "gemm_i2g_bwd_dx");
-        gemm::run(s, w.dA, H, 1, Wi, Din, 1, w.dIn, Din, (int64_t)T * N, Din, H, false, nullptr, 1);
+        gemm::run(s, w.dA, H, 1, Wi, Din, 1, w.dIn, Din, (int64_t)T * N, Din, H, false, nullptr, 1, bf);
       }
     }
   } else
@@ -427,17 +429,17 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       }
       if (t > 0) {
         ProfScope ps(h, "gemm_o2g_bwd_dh");
-        gemm::run(s, dA_t, 4 * H, 1, Wo, H, 1, w.dH, H, N, H, 4 * H, false, nullptr, 1);
+        gemm::run(s, dA_t, 4 * H, 1, Wo, H, 1, w.dH, H, N, H, 4 * H, false, nullptr, 1, bf);
       }
     }
     if (T > 1) {
       ProfScope ps(h, "gemm_o2g_bwd_dw");
       // gWo[4H,H] += dA[1..T-1]^T * h[0..T-2]
-      gemm::run(s, w.dA + (int64_t)N * 4 * H, 1, 4 * H, hs, H, 1, gd + h->layer[l].Wo, H, 4 * H, H, (int64_t)(T - 1) * N, true, nullptr, split);
+      gemm::run(s, w.dA + (int64_t)N * 4 * H, 1, 4 * H, hs, H, 1, gd + h->layer[l].Wo, H, 4 * H, H, (int64_t)(T - 1) * N, true, nullptr, split, bf);
     }
     {
       ProfScope ps(h, "gemm_i2g_bwd_dw");
-      gemm::run(s, w.dA, 1, 4 * H, in, Din, 1, gd + h->layer[l].Wi, Din, 4 * H, Din, (int64_t)T * N, true, nullptr, split);
+      gemm::run(s, w.dA, 1, 4 * H, in, Din, 1, gd + h->layer[l].Wi, Din, 4 * H, Din, (int64_t)T * N, true, nullptr, split, bf);
     }
     {
       ProfScope ps(h, "bias_colsum");
@@ -445,7 +447,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
     }
     {
       ProfScope ps(h, "gemm_i2g_bwd_dx");
-      gemm::run(s, w.dA, 4 * H, 1, Wi, Din, 1, w.dIn, Din, (int64_t)T * N, Din, 4 * H, false, nullptr, 1);
+      gemm::run(s, w.dA, 4 * H, 1, Wi, Din, 1, w.dIn, Din, (int64_t)T * N, Din, 4 * H, false, nullptr, 1, bf);
     }
   }
   {
@@ -603,6 +605,7 @@ int kprn_create(const kprn_config* cfg, kprn_handle** out) {
     KPRN_REQUIRE(c.F >= c.num_types + 2, KPRN_E_ARG, "numFeatureTemplates must cover types + entity + relation (FeatureEmbedding.lua:51)");
     KPRN_REQUIRE(c.H > 0 && c.C > 0, KPRN_E_ARG, "rnnHidSize and labelDimension must be positive");
     KPRN_REQUIRE(c.L >= 1 && c.L <= KPRN_MAX_LAYERS, KPRN_E_ARG, "numLayers must be in 1..8");
+    KPRN_REQUIRE(c.compute_dtype == 0 || c.compute_dtype == 1, KPRN_E_ARG, "compute_dtype must be 0 (f32) or 1 (bf16 MFMA products, f32 accumulate)");
     KPRN_REQUIRE(c.rnn_type == 0 || c.rnn_type == 1, KPRN_E_UNSUPPORTED, "rnnType gru (nn.GRU) is not built (SURVEY 8f N4c); lstm and rnn are");
     KPRN_REQUIRE(c.reducer >= 0 && c.reducer <= 2, KPRN_E_ARG, "topK must be 0 (max), 1 (topK) or 2 (LogSumExp)");
     KPRN_REQUIRE(c.reducer != 1 || c.K >= 1, KPRN_E_ARG, "K must be >= 1 for the topK reducer");

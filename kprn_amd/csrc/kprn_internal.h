@@ -206,5 +206,5 @@ namespace gemm {
 // element (m,k) of A at A[m*sAm + k*sAk]; (k,n) of B at B[k*sBk + n*sBn]; C row-major ldc.
 // accumulate: C += (atomic when split_k > 1); else C = A*B (+ bias[n]).
 void run(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C, int64_t ldc,
-         int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k);
+         int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k, bool bf16 = false);
 }

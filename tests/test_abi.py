@@ -46,7 +46,7 @@ def test_no_gpu_means_a_loud_error_not_a_fallback(so, gpu_available):
 
 def test_struct_layouts_match_the_header():
     # field order and sizes of kprn_config / kprn_opt as declared in include/kprn.h
-    assert ctypes.sizeof(_ffi.Config) == 19 * 4 + 4 + 8 + 8
+    assert ctypes.sizeof(_ffi.Config) == 20 * 4 + 4 + 4 + 8 + 8  # 20 int32, float, pad to 8, uint64, pointer
     assert ctypes.sizeof(_ffi.Opt) == 12 * 4
     assert ctypes.sizeof(_ffi.ProfEntry) == 48 + 8 + 8
 

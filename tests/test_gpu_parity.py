@@ -438,3 +438,34 @@ def test_config5_variable_length_buckets_inference(impl):
         ps, _, probs = o64.forward(theta, idx)
         assert rel_inf(out["path_scores"], ps) < 2e-5, T
         np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=SCORE_RTOL)
+
+
+def test_config4_bf16_compute_is_tolerance_gated_against_the_f64_oracle():
+    """configs[3] "bf16 MFMA LSTM": compute_dtype = 1 multiplies in bf16 (operands rounded to nearest even), accumulates in f32.
+    Tolerance-gated against the float64 oracle (bf16 has 8 mantissa bits; K = 768-term dot products): scores within 3e-2
+    relative of the largest score, probabilities within 3e-2, gradients within 5e-2 of each tensor's largest magnitude --
+    and measurably different from the fp32 path (so the test cannot pass by silently running fp32)."""
+    cfg = dict(Vt=6, Ve=500, Vr=100, dt=128, de=128, dr=128, H=384, L=1)
+    ocfg = make_cfg(**cfg)
+    o64 = Oracle(ocfg, np.float64)
+    theta = o64.init_params(9, 0.05).astype(np.float32).astype(np.float64)
+    idx, labels = synth.make_paths(40, 2, 6, Ve=500, Vr=100, seed=14)
+    ps, _, probs = o64.forward(theta, idx)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    outs = {}
+    for mode in (0, 1):
+        eng = _ffi.Engine(6, 500, 100, 128, 128, 128, 384, 1, compute_dtype=mode)
+        eng.set_flat_params(theta.astype(np.float32))
+        b = eng.batch(idx, labels)
+        out = eng.forward(b, 1, want=("probs", "path_scores"))
+        loss = eng.backward(b, 1)
+        outs[mode] = (out["path_scores"].copy(), out["probs"].copy(), loss, eng.get_flat_grads())
+    s_bf, p_bf, l_bf, g_bf = outs[1]
+    assert rel_inf(s_bf, ps) < 3e-2
+    np.testing.assert_allclose(p_bf, probs[:, 0], rtol=3e-2)
+    assert abs(l_bf - ol) < 3e-2 * max(1, abs(ol))
+    for nm, (off, shp) in o64.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g_bf[off:off + n], og[off:off + n]) < 5e-2, nm
+    assert rel_inf(outs[0][0], ps) < 2e-5            # the fp32 path at the same shape
+    assert rel_inf(s_bf, ps) > 20 * rel_inf(outs[0][0], ps)  # bf16 really ran
