@@ -30,6 +30,8 @@
  *    out.weight[C,H] | out.bias[C]          (host side: row-major fp32)
  *    FastLSTM gate order inside the 4H rows: input, candidate(tanh), forget, output.
  *    rnnType rnn: per layer rnn{l}.i2h.weight[H,D_l] | rnn{l}.i2h.bias[H] | rnn{l}.h2h.weight[H,H] | rnn{l}.h2h.bias[H]
+ *    rnnType gru: per layer gru{l}.i2g.weight[2H,D_l] | gru{l}.i2g.bias[2H] | gru{l}.o2g.weight[2H,H] (rows: reset, update) |
+ *                 gru{l}.c_i2h.weight[H,D_l] | gru{l}.c_i2h.bias[H] | gru{l}.c_h2h.weight[H,H]
  */
 #ifndef KPRN_H
 #define KPRN_H
@@ -64,7 +66,8 @@ typedef struct {
   int32_t L;                 /* -numLayers  (L>1 requires dt+de+dr == H, OneModel.lua:236,270)   */
   int32_t C;                 /* labelDimension, 46 in the reference (OneModel.lua:119)           */
   int32_t rnn_type;          /* -rnnType: 0 = lstm (nn.FastLSTM), 1 = rnn (nn.Recurrence + nn.MaskZero, OneModel.lua:240-266;
-                                the shipped config.sh default; generic pipeline), 2 = gru -> KPRN_E_UNSUPPORTED */
+                                the shipped config.sh default), 2 = gru (nn.GRU, OneModel.lua:237-238); rnn and gru run on the
+                                generic pipeline */
   int32_t use_relu;          /* -useReLU (rnn): 1 = nn.ReLU, else nn.Tanh (OneModel.lua:225-229)  */
   int32_t rnn_init;          /* -rnnInitialization (rnn): i2h / h2h weights <- eye, biases <- 0 (OneModel.lua:310-322) */
   int32_t compute_dtype;     /* 0 = f32 (exact fp32 MFMA; the reference's arithmetic type on GPU).  1 = bf16: the recurrent / head GEMMs

@@ -167,6 +167,10 @@ class Engine:
             if c.rnn_type == 1:  # nn.Recurrence: i2h / h2h nn.Linear (OneModel.lua:231-232)
                 items += [(f"rnn{i + 1}.i2h.weight", (c.H, din)), (f"rnn{i + 1}.i2h.bias", (c.H,)),
                           (f"rnn{i + 1}.h2h.weight", (c.H, c.H)), (f"rnn{i + 1}.h2h.bias", (c.H,))]
+            elif c.rnn_type == 2:  # nn.GRU: gates (r, z) + candidate maps
+                items += [(f"gru{i + 1}.i2g.weight", (2 * c.H, din)), (f"gru{i + 1}.i2g.bias", (2 * c.H,)),
+                          (f"gru{i + 1}.o2g.weight", (2 * c.H, c.H)), (f"gru{i + 1}.c_i2h.weight", (c.H, din)),
+                          (f"gru{i + 1}.c_i2h.bias", (c.H,)), (f"gru{i + 1}.c_h2h.weight", (c.H, c.H))]
             else:
                 items += [(f"lstm{i + 1}.i2g.weight", (4 * c.H, din)), (f"lstm{i + 1}.i2g.bias", (4 * c.H,)),
                           (f"lstm{i + 1}.o2g.weight", (4 * c.H, c.H))]

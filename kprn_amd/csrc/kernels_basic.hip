@@ -125,14 +125,14 @@ __global__ void k_add_bias(float* __restrict__ Y, const float* __restrict__ b, i
 }
 
 // out[c] += sum_r A[r][c]; block = 256 threads handles 256 rows x 64-col strip with LDS-free partials
-__global__ void k_colsum(const float* __restrict__ A, int64_t rows, int cols, float* __restrict__ out, int rows_per_block) {
+__global__ void k_colsum(const float* __restrict__ A, int64_t rows, int cols, int64_t ld, float* __restrict__ out, int rows_per_block) {
   int c = blockIdx.y * 64 + (threadIdx.x & 63);
   int sub = threadIdx.x >> 6;  // 4 row-subgroups
   int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float acc = 0.f;
   if (c < cols)
-    for (int64_t r = r0 + sub; r < r1; r += 4) acc += A[r * cols + c];
+    for (int64_t r = r0 + sub; r < r1; r += 4) acc += A[r * ld + c];
   __shared__ float red[4][64];
   red[sub][threadIdx.x & 63] = acc;
   __syncthreads();
@@ -179,6 +179,68 @@ __global__ void k_rnn_cell_bwd(const float* __restrict__ pre, const float* __res
   if (dH_up) d += dH_up[i];
   const float der = relu ? (pre[i] > 0.f ? 1.f : 0.f) : (1.f - hcur[i] * hcur[i]);
   dA[i] = (mask[n] != 0.f) ? d * der : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// rnnType "gru" (OneModel.lua:237-238, nn.GRU): one step of one layer on the step record a[n][4H] = [r | z | n | r*h'].
+//   [r; z] = sigmoid(i2g x + o2g h');  n = tanh(c_i2h x + c_h2h (r * h'));  h = (1 - z) n + z h'
+__global__ void k_gru_gates_fwd(float* __restrict__ a, const float* __restrict__ hp, int64_t N, int H) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int j = (int)(i - n * H);
+  float* row = a + n * 4 * H;
+  const float r = sigmoidf_(row[j]);
+  const float z = sigmoidf_(row[H + j]);
+  row[j] = r;
+  row[H + j] = z;
+  row[3 * H + j] = hp ? r * hp[i] : 0.f;
+}
+
+__global__ void k_gru_out_fwd(float* __restrict__ a, const float* __restrict__ hp, float* __restrict__ h, int64_t N, int H) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int j = (int)(i - n * H);
+  float* row = a + n * 4 * H;
+  const float nn = tanhf(row[2 * H + j]);
+  row[2 * H + j] = nn;
+  const float z = row[H + j];
+  h[i] = (1.f - z) * nn + z * (hp ? hp[i] : 0.f);
+}
+
+// dh = dH (+ dH_up): d pre_n -> dA[.,2H..3H), d pre_z -> dA[.,H..2H), direct path dh z -> dHdir
+__global__ void k_gru_bwd1(const float* __restrict__ a, const float* __restrict__ hp, const float* __restrict__ dH, const float* __restrict__ dH_up,
+                           float* __restrict__ dA, float* __restrict__ dHdir, int64_t N, int H) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int j = (int)(i - n * H);
+  const float* row = a + n * 4 * H;
+  float* drow = dA + n * 4 * H;
+  float dh = dH[i];
+  if (dH_up) dh += dH_up[i];
+  const float z = row[H + j], nn = row[2 * H + j];
+  const float hpv = hp ? hp[i] : 0.f;
+  drow[2 * H + j] = dh * (1.f - z) * (1.f - nn * nn);
+  drow[H + j] = dh * (hpv - nn) * z * (1.f - z);
+  drow[3 * H + j] = 0.f;
+  dHdir[i] = dh * z;
+}
+
+// d(r*h') (dA[.,3H..4H), from the candidate's recurrent GEMM) -> d pre_r -> dA[.,0..H); dH = direct + d(r*h') r
+__global__ void k_gru_bwd2(const float* __restrict__ a, const float* __restrict__ hp, float* __restrict__ dA, const float* __restrict__ dHdir,
+                           float* __restrict__ dH, int64_t N, int H) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int j = (int)(i - n * H);
+  const float* row = a + n * 4 * H;
+  float* drow = dA + n * 4 * H;
+  const float r = row[j];
+  const float drh = hp ? drow[3 * H + j] : 0.f;
+  drow[j] = hp ? drh * hp[i] * r * (1.f - r) : 0.f;
+  dH[i] = dHdir[i] + drh * r;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -667,17 +729,39 @@ void rnn_cell_bwd(hipStream_t s, const float* pre, const float* hcur, const floa
   CHECK_LAUNCH();
 }
 
+void gru_gates_fwd(hipStream_t s, float* a, const float* hp, int64_t N, int H) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_gru_gates_fwd, dim3(nblocks(N * H)), dim3(TPB), 0, s, a, hp, N, H);
+  CHECK_LAUNCH();
+}
+void gru_out_fwd(hipStream_t s, float* a, const float* hp, float* h, int64_t N, int H) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_gru_out_fwd, dim3(nblocks(N * H)), dim3(TPB), 0, s, a, hp, h, N, H);
+  CHECK_LAUNCH();
+}
+void gru_bwd1(hipStream_t s, const float* a, const float* hp, const float* dH, const float* dH_up, float* dA, float* dHdir, int64_t N, int H) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_gru_bwd1, dim3(nblocks(N * H)), dim3(TPB), 0, s, a, hp, dH, dH_up, dA, dHdir, N, H);
+  CHECK_LAUNCH();
+}
+void gru_bwd2(hipStream_t s, const float* a, const float* hp, float* dA, const float* dHdir, float* dH, int64_t N, int H) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_gru_bwd2, dim3(nblocks(N * H)), dim3(TPB), 0, s, a, hp, dA, dHdir, dH, N, H);
+  CHECK_LAUNCH();
+}
+
 void add_bias_rows(hipStream_t s, float* Y, const float* b, int64_t rows, int cols) {
   if (rows <= 0) return;
   hipLaunchKernelGGL(k_add_bias, dim3(nblocks(rows * cols)), dim3(TPB), 0, s, Y, b, rows * cols, cols);
   CHECK_LAUNCH();
 }
 
-void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out) {
+void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out, int64_t ld) {
   if (rows <= 0) return;
+  if (ld <= 0) ld = cols;
   const int rpb = 512;
   dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 63) / 64));
-  hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, A, rows, cols, out, rpb);
+  hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, A, rows, cols, ld, out, rpb);
   CHECK_LAUNCH();
 }
 

@@ -81,7 +81,7 @@ static void build_layout(kprn_handle* h) {
   h->off_Wt = dn; add("type_emb", c.Vt, c.dt, 0, dn); dn += (int64_t)c.Vt * c.dt;
   add("entity_emb", c.Ve, c.de, 1, 0);
   h->off_Wr = dn; add("relation_emb", c.Vr, c.dr, 0, dn); dn += (int64_t)c.Vr * c.dr;
-  h->G = (c.rnn_type == 1) ? 1 : 4;
+  h->G = (c.rnn_type == 1) ? 1 : ((c.rnn_type == 2) ? 2 : 4);
   for (int l = 0; l < c.L; ++l) {
     const int Din = (l == 0) ? h->D : c.H;
     h->layer[l].Din = Din;
@@ -91,6 +91,14 @@ static void build_layout(kprn_handle* h) {
       h->layer[l].bi = dn; add("rnn" + ln + ".i2h.bias", c.H, 1, 0, dn); dn += c.H;
       h->layer[l].Wo = dn; add("rnn" + ln + ".h2h.weight", c.H, c.H, 0, dn); dn += (int64_t)c.H * c.H;
       h->layer[l].bo = dn; add("rnn" + ln + ".h2h.bias", c.H, 1, 0, dn); dn += c.H;
+    } else if (c.rnn_type == 2) {  // nn.GRU: gates r, z from i2g (nn.Linear) + o2g (nn.LinearNoBias); candidate from its own pair of maps
+      h->layer[l].Wi = dn; add("gru" + ln + ".i2g.weight", 2 * c.H, Din, 0, dn); dn += (int64_t)2 * c.H * Din;
+      h->layer[l].bi = dn; add("gru" + ln + ".i2g.bias", 2 * c.H, 1, 0, dn); dn += (int64_t)2 * c.H;
+      h->layer[l].Wo = dn; add("gru" + ln + ".o2g.weight", 2 * c.H, c.H, 0, dn); dn += (int64_t)2 * c.H * c.H;
+      h->layer[l].Wc = dn; add("gru" + ln + ".c_i2h.weight", c.H, Din, 0, dn); dn += (int64_t)c.H * Din;
+      h->layer[l].bc = dn; add("gru" + ln + ".c_i2h.bias", c.H, 1, 0, dn); dn += c.H;
+      h->layer[l].Uc = dn; add("gru" + ln + ".c_h2h.weight", c.H, c.H, 0, dn); dn += (int64_t)c.H * c.H;
+      h->layer[l].bo = -1;
     } else {
       h->layer[l].Wi = dn; add("lstm" + ln + ".i2g.weight", 4 * c.H, Din, 0, dn); dn += (int64_t)4 * c.H * Din;
       h->layer[l].bi = dn; add("lstm" + ln + ".i2g.bias", 4 * c.H, 1, 0, dn); dn += (int64_t)4 * c.H;
@@ -249,7 +257,40 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b) {
     ProfScope ps(h, "embed_gather");
     kk::embed_gather(s, b->idx, N, T, b->F, c.num_types, h->dense + h->off_Wt, h->We, h->dense + h->off_Wr, c.dt, c.de, c.dr, w.X, true);
   }
-  if (c.rnn_type == 1) {
+  if (c.rnn_type == 2) {
+    // nn.Sequencer(nn.GRU(D, H)) x L (OneModel.lua:237-238,268-273); step record a[n][4H] = [r | z | n | r*h']
+    for (int l = 0; l < L; ++l) {
+      const int Din = h->layer[l].Din;
+      const float* in = (l == 0) ? w.X : w.Hs + (int64_t)(l - 1) * T * N * H;
+      float* act = w.ACT + (int64_t)l * T * N * 4 * H;
+      float* hs = w.Hs + (int64_t)l * T * N * H;
+      const float* Wo = h->dense + h->layer[l].Wo;
+      const float* Uc = h->dense + h->layer[l].Uc;
+      {
+        ProfScope ps(h, "gemm_i2g_fwd");
+        gemm::run(s, in, Din, 1, h->dense + h->layer[l].Wi, 1, Din, act, 4 * H, (int64_t)T * N, 2 * H, Din, false, h->dense + h->layer[l].bi, 1, bf);
+        gemm::run(s, in, Din, 1, h->dense + h->layer[l].Wc, 1, Din, act + 2 * H, 4 * H, (int64_t)T * N, H, Din, false, h->dense + h->layer[l].bc, 1, bf);
+      }
+      for (int t = 0; t < T; ++t) {
+        float* a_t = act + (int64_t)t * N * 4 * H;
+        const float* hp = t > 0 ? hs + (int64_t)(t - 1) * N * H : nullptr;
+        if (t > 0) {
+          ProfScope ps(h, "gemm_o2g_fwd");
+          gemm::run(s, hp, H, 1, Wo, 1, H, a_t, 4 * H, N, 2 * H, H, true, nullptr, 1, bf);
+        }
+        {
+          ProfScope ps(h, "gru_cell_fwd");
+          kk::gru_gates_fwd(s, a_t, hp, N, H);
+        }
+        if (t > 0) {
+          ProfScope ps(h, "gemm_o2g_fwd");
+          gemm::run(s, a_t + 3 * H, 4 * H, 1, Uc, 1, H, a_t + 2 * H, 4 * H, N, H, H, true, nullptr, 1, bf);
+        }
+        ProfScope ps(h, "gru_cell_fwd");
+        kk::gru_out_fwd(s, a_t, hp, hs + (int64_t)t * N * H, N, H);
+      }
+    }
+  } else if (c.rnn_type == 1) {
     // nn.Sequencer(nn.Recurrence(nn.MaskZero(act(i2h x_t + h2h h_{t-1}), 1))) x L (OneModel.lua:240-266,268-273)
     for (int l = 0; l < L; ++l) {
       const int Din = h->layer[l].Din;
@@ -364,7 +405,63 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
   }
   HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), s));
   const int split = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (T * N) / 2048));
-  if (c.rnn_type == 1) {
+  if (c.rnn_type == 2) {
+    for (int l = L - 1; l >= 0; --l) {
+      const int Din = h->layer[l].Din;
+      const float* in = (l == 0) ? w.X : w.Hs + (int64_t)(l - 1) * T * N * H;
+      const float* act = w.ACT + (int64_t)l * T * N * 4 * H;
+      const float* hs = w.Hs + (int64_t)l * T * N * H;
+      const float* Wi = h->dense + h->layer[l].Wi;
+      const float* Wo = h->dense + h->layer[l].Wo;
+      const float* Wc = h->dense + h->layer[l].Wc;
+      const float* Uc = h->dense + h->layer[l].Uc;
+      const bool has_up = (l < L - 1);
+      if (has_up) HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
+      for (int t = T - 1; t >= 0; --t) {
+        float* dA_t = w.dA + (int64_t)t * N * 4 * H;
+        const float* a_t = act + (int64_t)t * N * 4 * H;
+        const float* hp = t > 0 ? hs + (int64_t)(t - 1) * N * H : nullptr;
+        {
+          ProfScope ps(h, "gru_cell_bwd");
+          kk::gru_bwd1(s, a_t, hp, w.dH, has_up ? w.dIn + (int64_t)t * N * H : nullptr, dA_t, w.dC /* direct dh' path */, N, H);
+        }
+        if (t > 0) {
+          ProfScope ps(h, "gemm_o2g_bwd_dh");  // d(r*h') = d pre_n * c_h2h
+          gemm::run(s, dA_t + 2 * H, 4 * H, 1, Uc, H, 1, dA_t + 3 * H, 4 * H, N, H, H, false, nullptr, 1, bf);
+        }
+        {
+          ProfScope ps(h, "gru_cell_bwd");
+          kk::gru_bwd2(s, a_t, hp, dA_t, w.dC, w.dH, N, H);
+        }
+        if (t > 0) {
+          ProfScope ps(h, "gemm_o2g_bwd_dh");  // dh' += [d pre_r | d pre_z] * o2g
+          gemm::run(s, dA_t, 4 * H, 1, Wo, H, 1, w.dH, H, N, H, 2 * H, true, nullptr, 1, bf);
+        }
+      }
+      if (T > 1) {
+        ProfScope ps(h, "gemm_o2g_bwd_dw");
+        gemm::run(s, w.dA + (int64_t)N * 4 * H, 1, 4 * H, hs, H, 1, gd + h->layer[l].Wo, H, 2 * H, H, (int64_t)(T - 1) * N, true, nullptr, split, bf);
+        // c_h2h += d pre_n[1..T-1]^T (r*h')[1..T-1]
+        gemm::run(s, w.dA + (int64_t)N * 4 * H + 2 * H, 1, 4 * H, act + (int64_t)N * 4 * H + 3 * H, 4 * H, 1, gd + h->layer[l].Uc, H, H, H,
+                  (int64_t)(T - 1) * N, true, nullptr, split, bf);
+      }
+      {
+        ProfScope ps(h, "gemm_i2g_bwd_dw");
+        gemm::run(s, w.dA, 1, 4 * H, in, Din, 1, gd + h->layer[l].Wi, Din, 2 * H, Din, (int64_t)T * N, true, nullptr, split, bf);
+        gemm::run(s, w.dA + 2 * H, 1, 4 * H, in, Din, 1, gd + h->layer[l].Wc, Din, H, Din, (int64_t)T * N, true, nullptr, split, bf);
+      }
+      {
+        ProfScope ps(h, "bias_colsum");
+        kk::col_sum_add(s, w.dA, (int64_t)T * N, 2 * H, gd + h->layer[l].bi, 4 * H);
+        kk::col_sum_add(s, w.dA + 2 * H, (int64_t)T * N, H, gd + h->layer[l].bc, 4 * H);
+      }
+      {
+        ProfScope ps(h, "gemm_i2g_bwd_dx");
+        gemm::run(s, w.dA, 4 * H, 1, Wi, Din, 1, w.dIn, Din, (int64_t)T * N, Din, 2 * H, false, nullptr, 1, bf);
+        gemm::run(s, w.dA + 2 * H, 4 * H, 1, Wc, Din, 1, w.dIn, Din, (int64_t)T * N, Din, H, true, nullptr, 1, bf);
+      }
+    }
+  } else if (c.rnn_type == 1) {
     const int relu = c.use_relu == 1 ? 1 : 0;
     for (int l = L - 1; l >= 0; --l) {
       const int Din = h->layer[l].Din;
@@ -606,7 +703,7 @@ int kprn_create(const kprn_config* cfg, kprn_handle** out) {
     KPRN_REQUIRE(c.H > 0 && c.C > 0, KPRN_E_ARG, "rnnHidSize and labelDimension must be positive");
     KPRN_REQUIRE(c.L >= 1 && c.L <= KPRN_MAX_LAYERS, KPRN_E_ARG, "numLayers must be in 1..8");
     KPRN_REQUIRE(c.compute_dtype == 0 || c.compute_dtype == 1, KPRN_E_ARG, "compute_dtype must be 0 (f32) or 1 (bf16 MFMA products, f32 accumulate)");
-    KPRN_REQUIRE(c.rnn_type == 0 || c.rnn_type == 1, KPRN_E_UNSUPPORTED, "rnnType gru (nn.GRU) is not built (SURVEY 8f N4c); lstm and rnn are");
+    KPRN_REQUIRE(c.rnn_type >= 0 && c.rnn_type <= 2, KPRN_E_ARG, "rnn_type must be 0 (lstm), 1 (rnn) or 2 (gru)");
     KPRN_REQUIRE(c.reducer >= 0 && c.reducer <= 2, KPRN_E_ARG, "topK must be 0 (max), 1 (topK) or 2 (LogSumExp)");
     KPRN_REQUIRE(c.reducer != 1 || c.K >= 1, KPRN_E_ARG, "K must be >= 1 for the topK reducer");
     KPRN_REQUIRE(c.L == 1 || (c.dt + c.de + c.dr) == c.H, KPRN_E_ARG,

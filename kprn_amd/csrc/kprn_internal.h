@@ -32,6 +32,7 @@ struct ParamInfo {
 
 struct LayerOff {     // offsets into the dense arena (rnn: Wi = i2h.weight, bi = i2h.bias, Wo = h2h.weight, bo = h2h.bias)
   int64_t Wi, bi, Wo, bo;
+  int64_t Wc, bc, Uc;  // gru: candidate c_i2h.weight, c_i2h.bias, c_h2h.weight
   int Din;
 };
 
@@ -76,7 +77,7 @@ struct kprn_batch {
 struct kprn_handle {
   kprn_config cfg;
   int D = 0;
-  int G = 4;  // rows of the recurrent weights per hidden unit: 4 (FastLSTM gates) or 1 (rnn)
+  int G = 4;  // rows of the recurrent weights per hidden unit: 4 (FastLSTM gates), 2 (gru r, z) or 1 (rnn)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
@@ -160,7 +161,11 @@ void rnn_cell_fwd(hipStream_t s, float* pre, const float* bh, const float* mask,
 void rnn_cell_bwd(hipStream_t s, const float* pre, const float* hcur, const float* mask, const float* dH_up, const float* dH, float* dA, int64_t N,
                   int H, int relu);
 void add_bias_rows(hipStream_t s, float* Y, const float* b, int64_t rows, int cols);
-void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out);
+void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out, int64_t ld = 0);  // ld: row stride of A (0 = cols)
+void gru_gates_fwd(hipStream_t s, float* a, const float* hp, int64_t N, int H);
+void gru_out_fwd(hipStream_t s, float* a, const float* hp, float* h, int64_t N, int H);
+void gru_bwd1(hipStream_t s, const float* a, const float* hp, const float* dH, const float* dH_up, float* dA, float* dHdir, int64_t N, int H);
+void gru_bwd2(hipStream_t s, const float* a, const float* hp, float* dA, const float* dHdir, float* dH, int64_t N, int H);
 void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel);
 void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
                 int literal, float invB, float* pooled, float* probs, float* sel, float* dS, float* gW_row, float* gb_c, float* partial);

@@ -3,7 +3,7 @@
 `parse_flags` accepts the torch.CmdLine flags of OneModel.lua:27-87 with the same names and
 defaults; `build_engine` turns them into a kprn Engine the way OneModel.lua:204-309 builds
 predictor_net / reducer / training_net.  Options the engine does not implement yet fail loudly with
-the library's KPRN_E_UNSUPPORTED (rnnType rnn/gru: SURVEY.md 8f N4) instead of silently doing
+the library's KPRN_E_UNSUPPORTED (embedding ablations, dropout) instead of silently doing
 something else.
 """
 import argparse

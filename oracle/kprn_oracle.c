@@ -27,6 +27,11 @@
  *        output whose INPUT row x_t (layer > 1: h^{l-1}_t) is all zeros are zeroed, and so are their gradients
  *        (pad steps have zero embeddings after zeroPadTokens: the state stays 0 until the first real step).
  *        parameters() order per layer: i2h.weight[H,D_l], i2h.bias[H], h2h.weight[H,H], h2h.bias[H].
+ *   [A8] rnnType "gru" (OneModel.lua:237-238, nn.GRU of Element-Research/rnn, the 2016 graph with nn.SAdd(-1,true)):
+ *        [r; z] = sigmoid(i2g.W x + i2g.b + o2g.W h')   (i2g = nn.Linear(D,2H), o2g = nn.LinearNoBias(H,2H); first H rows = reset r)
+ *        n = tanh(c_i2h.W x + c_i2h.b + c_h2h.W (r * h'))   (the reset gate is applied BEFORE the candidate's recurrent product)
+ *        h = (1 - z) * n + z * h';  h_0 = 0;  no MaskZero.
+ *        parameters() order per layer: i2g.weight[2H,D_l], i2g.bias[2H], o2g.weight[2H,H], c_i2h.weight[H,D_l], c_i2h.bias[H], c_h2h.weight[H,H].
  *   [A6] getParameters() flat order = module traversal order:
  *        Wt | We | Wr | (i2g.W[4H,D_l], i2g.b[4H], o2g.W[4H,H]) x L | out.W[C,H] | out.b[C]
  * The restatement is cross-checked against an independent implementation (PyTorch CPU
@@ -77,7 +82,7 @@ typedef struct {
   int32_t H, L, C;        /* rnnHidSize, numLayers, labelDimension (46)             */
   int32_t reducer;        /* 0 = Max, 1 = TopK+Mean, 2 = LogSumExp (OneModel.lua:284-293) */
   int32_t K;              /* topK K                                                  */
-  int32_t rnn_type;       /* 0 = lstm (nn.FastLSTM), 1 = rnn (Recurrence + MaskZero) [A7]  */
+  int32_t rnn_type;       /* 0 = lstm (nn.FastLSTM), 1 = rnn (Recurrence + MaskZero) [A7], 2 = gru (nn.GRU) [A8] */
   int32_t use_relu;       /* rnn: -useReLU 1 -> ReLU, else Tanh                      */
 } okprn_cfg;
 
@@ -95,6 +100,7 @@ static inline REAL sigm(REAL x) { return (REAL)1 / ((REAL)1 + (REAL)exp(-(double
 typedef struct {
   size_t Wt, We, Wr;
   size_t i2gW[8], i2gb[8], o2gW[8], h2hb[8];  /* rnn: i2gW = i2h.W, i2gb = i2h.b, o2gW = h2h.W, h2hb = h2h.b */
+  size_t ciW[8], cib[8], chW[8];              /* gru: candidate c_i2h.W, c_i2h.b, c_h2h.W */
   int G;  /* rows of the recurrent weights per hidden unit: 4 (lstm gates) or 1 (rnn) */
   size_t outW, outb, total;
   int D;
@@ -107,13 +113,16 @@ static layout_t make_layout(const okprn_cfg* c) {
   l.Wt = o; o += (size_t)c->Vt * c->dt;
   l.We = o; o += (size_t)c->Ve * c->de;
   l.Wr = o; o += (size_t)c->Vr * c->dr;
-  l.G = (c->rnn_type == 1) ? 1 : 4;
+  l.G = (c->rnn_type == 1) ? 1 : ((c->rnn_type == 2) ? 2 : 4);
   for (int i = 0; i < c->L; ++i) {
     int Din = (i == 0) ? l.D : c->H;
     l.i2gW[i] = o; o += (size_t)l.G * c->H * Din;
     l.i2gb[i] = o; o += (size_t)l.G * c->H;
     l.o2gW[i] = o; o += (size_t)l.G * c->H * c->H;
     l.h2hb[i] = o; if (c->rnn_type == 1) o += (size_t)c->H;
+    l.ciW[i] = o; if (c->rnn_type == 2) o += (size_t)c->H * Din;
+    l.cib[i] = o; if (c->rnn_type == 2) o += (size_t)c->H;
+    l.chW[i] = o; if (c->rnn_type == 2) o += (size_t)c->H * c->H;
   }
   l.outW = o; o += (size_t)c->C * c->H;
   l.outb = o; o += (size_t)c->C;
@@ -132,6 +141,7 @@ void FN(okprn_layout)(const okprn_cfg* c, int64_t* out) {
   for (int i = 0; i < c->L; ++i) {
     out[k++] = (int64_t)l.i2gW[i]; out[k++] = (int64_t)l.i2gb[i]; out[k++] = (int64_t)l.o2gW[i];
     if (c->rnn_type == 1) out[k++] = (int64_t)l.h2hb[i];
+    if (c->rnn_type == 2) { out[k++] = (int64_t)l.ciW[i]; out[k++] = (int64_t)l.cib[i]; out[k++] = (int64_t)l.chW[i]; }
   }
   out[k++] = (int64_t)l.outW; out[k++] = (int64_t)l.outb; out[k++] = (int64_t)l.total;
 }
@@ -180,6 +190,33 @@ static const REAL* path_forward(const okprn_cfg* c, const layout_t* l, const REA
       const REAL* Wo = th + l->o2gW[ly];
       REAL* cur = r->act + ((size_t)t * L + ly) * 6 * H;
       const REAL* prev = (t > 0) ? r->act + ((size_t)(t - 1) * L + ly) * 6 * H : NULL;
+      if (c->rnn_type == 2) { /* [A8] nn.GRU: record slots 0 = r, 1 = z, 2 = n (candidate), 3 = r*h', 5 = h */
+        const REAL* Wc = th + l->ciW[ly];
+        const REAL* bc = th + l->cib[ly];
+        const REAL* Uc = th + l->chW[ly];
+        const REAL* hp = prev ? prev + 5 * H : NULL;
+        for (int n = 0; n < 2 * H; ++n) {
+          REAL s = bi[n];
+          const REAL* w = Wi + (size_t)n * Din;
+          for (int k = 0; k < Din; ++k) s += w[k] * in[k];
+          if (hp) { const REAL* w2 = Wo + (size_t)n * H; for (int k = 0; k < H; ++k) s += w2[k] * hp[k]; }
+          cur[n] = sigm(s);
+        }
+        for (int j = 0; j < H; ++j) cur[3 * H + j] = hp ? cur[j] * hp[j] : (REAL)0;
+        for (int n = 0; n < H; ++n) {
+          REAL s = bc[n];
+          const REAL* w = Wc + (size_t)n * Din;
+          for (int k = 0; k < Din; ++k) s += w[k] * in[k];
+          if (hp) { const REAL* w2 = Uc + (size_t)n * H; for (int k = 0; k < H; ++k) s += w2[k] * cur[3 * H + k]; }
+          REAL nn_ = (REAL)tanh((double)s);
+          REAL z = cur[H + n];
+          cur[2 * H + n] = nn_;
+          cur[5 * H + n] = ((REAL)1 - z) * nn_ + z * (hp ? hp[n] : (REAL)0);
+        }
+        in = cur + 5 * H;
+        Din = H;
+        continue;
+      }
       if (c->rnn_type == 1) { /* [A7] Recurrence(MaskZero(act(i2h x + h2h h'))) */
         const REAL* bh = th + l->h2hb[ly];
         int nonzero = 0;
@@ -264,6 +301,62 @@ static void path_backward(const okprn_cfg* c, const layout_t* l, const REAL* th,
       const REAL* in = (ly == 0) ? r->x + (size_t)t * D : r->act + ((size_t)t * L + ly - 1) * 6 * H + 5 * H;
       REAL* dhl = dh + (size_t)ly * H;
       REAL* dcl = dc + (size_t)ly * H;
+      if (c->rnn_type == 2) { /* [A8] */
+        const REAL* Wi = th + l->i2gW[ly];
+        const REAL* Wo = th + l->o2gW[ly];
+        const REAL* Wc = th + l->ciW[ly];
+        const REAL* Uc = th + l->chW[ly];
+        REAL* gWi = gd + (l->i2gW[ly] - doff);
+        REAL* gbi = gd + (l->i2gb[ly] - doff);
+        REAL* gWo = gd + (l->o2gW[ly] - doff);
+        REAL* gWc = gd + (l->ciW[ly] - doff);
+        REAL* gbc = gd + (l->cib[ly] - doff);
+        REAL* gUc = gd + (l->chW[ly] - doff);
+        const REAL* hp = prev ? prev + 5 * H : NULL;
+        REAL* dac = da;           /* [H]  candidate pre-activation grad */
+        REAL* dag = da + H;       /* [2H] gate pre-activation grads (r then z) */
+        REAL* drh = dcl;          /* [H]  scratch: grad wrt (r * h') -- the lstm cell-state slot is free for gru */
+        for (int k = 0; k < Din; ++k) dxin[k] = 0;
+        for (int j = 0; j < H; ++j) {
+          REAL z = cur[H + j], nn_ = cur[2 * H + j], dhh = dhl[j];
+          REAL hpj = hp ? hp[j] : (REAL)0;
+          dac[j] = dhh * ((REAL)1 - z) * ((REAL)1 - nn_ * nn_);
+          dag[H + j] = dhh * (hpj - nn_) * z * ((REAL)1 - z);
+          dhl[j] = dhh * z;   /* -> dh' (direct path) */
+          drh[j] = 0;
+        }
+        for (int n = 0; n < H; ++n) {
+          REAL d = dac[n];
+          gbc[n] += d;
+          const REAL* w = Wc + (size_t)n * Din;
+          REAL* gw = gWc + (size_t)n * Din;
+          for (int k = 0; k < Din; ++k) { gw[k] += d * in[k]; dxin[k] += d * w[k]; }
+          if (hp) {
+            const REAL* w2 = Uc + (size_t)n * H;
+            REAL* gw2 = gUc + (size_t)n * H;
+            for (int k = 0; k < H; ++k) { gw2[k] += d * cur[3 * H + k]; drh[k] += d * w2[k]; }
+          }
+        }
+        for (int j = 0; j < H; ++j) {
+          REAL r = cur[j], hpj = hp ? hp[j] : (REAL)0;
+          dag[j] = drh[j] * hpj * r * ((REAL)1 - r);
+          dhl[j] += drh[j] * r;
+        }
+        for (int n = 0; n < 2 * H; ++n) {
+          REAL d = dag[n];
+          gbi[n] += d;
+          const REAL* w = Wi + (size_t)n * Din;
+          REAL* gw = gWi + (size_t)n * Din;
+          for (int k = 0; k < Din; ++k) { gw[k] += d * in[k]; dxin[k] += d * w[k]; }
+          if (hp) {
+            const REAL* w2 = Wo + (size_t)n * H;
+            REAL* gw2 = gWo + (size_t)n * H;
+            for (int k = 0; k < H; ++k) { gw2[k] += d * hp[k]; dhl[k] += d * w2[k]; }
+          }
+        }
+        for (int j = 0; j < H; ++j) dcl[j] = 0;
+        goto below;
+      }
       if (c->rnn_type == 1) { /* [A7] */
         const REAL* Wi = th + l->i2gW[ly];
         const REAL* Wo = th + l->o2gW[ly];

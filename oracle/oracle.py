@@ -74,8 +74,8 @@ class Oracle:
     def layout(self):
         """dict name -> (offset, shape) in the flat vector, reference getParameters() order."""
         c = self.cfg
-        rnn = c.rnn_type == 1
-        out = np.zeros(3 + (4 if rnn else 3) * c.L + 3, dtype=np.int64)
+        rnn, gru = c.rnn_type == 1, c.rnn_type == 2
+        out = np.zeros(3 + (4 if rnn else (6 if gru else 3)) * c.L + 3, dtype=np.int64)
         getattr(self.l, "okprn_layout" + self.sfx)(C.byref(c), _p(out))
         names = [("type_emb", (c.Vt, c.dt)), ("entity_emb", (c.Ve, c.de)), ("relation_emb", (c.Vr, c.dr))]
         for i in range(c.L):
@@ -83,6 +83,10 @@ class Oracle:
             if rnn:
                 names += [(f"rnn{i + 1}.i2h.weight", (c.H, din)), (f"rnn{i + 1}.i2h.bias", (c.H,)),
                           (f"rnn{i + 1}.h2h.weight", (c.H, c.H)), (f"rnn{i + 1}.h2h.bias", (c.H,))]
+            elif gru:
+                names += [(f"gru{i + 1}.i2g.weight", (2 * c.H, din)), (f"gru{i + 1}.i2g.bias", (2 * c.H,)),
+                          (f"gru{i + 1}.o2g.weight", (2 * c.H, c.H)), (f"gru{i + 1}.c_i2h.weight", (c.H, din)),
+                          (f"gru{i + 1}.c_i2h.bias", (c.H,)), (f"gru{i + 1}.c_h2h.weight", (c.H, c.H))]
             else:
                 names += [(f"lstm{i + 1}.i2g.weight", (4 * c.H, din)), (f"lstm{i + 1}.i2g.bias", (4 * c.H,)),
                           (f"lstm{i + 1}.o2g.weight", (4 * c.H, c.H))]

@@ -134,13 +134,11 @@ def test_cli_train_and_score(tmp_path):
 
 
 def test_unsupported_reference_options_fail_loudly():
-    p = model.parse_flags(FLAGS.replace("-rnnType lstm", "-rnnType gru").split())
-    with pytest.raises(_ffi.KprnError) as e:
-        model.build_engine(p)
-    assert e.value.code == _ffi.E_UNSUPPORTED
-    # rnnType rnn (the shipped config.sh default) IS built: same flags, nn.Recurrence + nn.MaskZero on the generic pipeline
+    # rnnType rnn (the shipped config.sh default) and gru are built: same flags, generic pipeline
     eng = model.build_engine(model.parse_flags(FLAGS.replace("-rnnType lstm", "-rnnType rnn").split()))
     assert "rnn1.h2h.bias" in eng.layout()
+    eng = model.build_engine(model.parse_flags(FLAGS.replace("-rnnType lstm", "-rnnType gru").split()))
+    assert "gru2.c_h2h.weight" in eng.layout()
     p = model.parse_flags(FLAGS.replace("-includeEntity 1", "-includeEntity 0").split())
     with pytest.raises(_ffi.KprnError) as e:
         model.build_engine(p)

@@ -230,8 +230,8 @@ def test_errors_are_codes_not_crashes():
         _ffi.Engine(6, 100, 9, 4, 8, 4, 32, L=2)  # D != H with 2 layers (OneModel.lua:236,270-273)
     assert e.value.code == _ffi.E_ARG
     with pytest.raises(_ffi.KprnError) as e:
-        _ffi.Engine(6, 100, 9, 4, 8, 4, 16, rnn_type=2)  # nn.GRU: not built, refused
-    assert e.value.code == _ffi.E_UNSUPPORTED
+        _ffi.Engine(6, 100, 9, 4, 8, 4, 16, rnn_type=3)  # no such cell
+    assert e.value.code == _ffi.E_ARG
     with pytest.raises(_ffi.KprnError) as e:
         eng.get_param("nope")
     assert e.value.code == _ffi.E_ARG
@@ -399,10 +399,35 @@ def test_rnn_identity_init_and_training_steps():
     assert float(np.max(np.abs(eng.get_flat_params() - th))) < 2e-4
 
 
-def test_gru_is_refused_not_emulated():
-    with pytest.raises(_ffi.KprnError) as ei:
-        _ffi.Engine(6, 300, 9, 16, 32, 16, 64, 1, rnn_type=2)
-    assert ei.value.code == _ffi.E_UNSUPPORTED
+@pytest.mark.parametrize("L", [1, 2])
+def test_gru_cell_forward_backward_and_training_match_oracle(L):
+    """rnnType gru (nn.GRU, OneModel.lua:237-238) on the generic pipeline"""
+    H = 48
+    eng = _ffi.Engine(6, 300, 9, 8, 24, 16, H, L, rnn_type=2, param_init=0.2)
+    o64 = Oracle(make_cfg(Vt=6, Ve=300, Vr=9, dt=8, de=24, dr=16, H=H, L=L, rnn_type=2), np.float64)
+    assert list(eng.layout().keys()) == list(o64.layout().keys())
+    theta = o64.init_params(6, 0.2).astype(np.float32).astype(np.float64)
+    eng.set_flat_params(theta.astype(np.float32))
+    idx, labels = synth.make_paths(37, 3, 6, Ve=300, seed=9)
+    b = eng.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    ps, _, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5
+    np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=SCORE_RTOL)
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels, class_id=1)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], og[off:off + n]) < GRAD_RTOL, nm
+    th, st = theta.copy(), o64.new_state()
+    opt, oopt = _ffi.make_opt(method=1, lr=2e-3), make_opt(method=1, lr=2e-3)
+    for s_ in range(8):
+        ol, _ = o64.train_step(th, st, oopt, idx, labels)
+        gl = eng.train_step(b, opt)
+        assert abs(gl - ol) < 2e-4 * max(1, abs(ol)), (s_, gl, ol)
+    assert float(np.max(np.abs(eng.get_flat_params() - th))) < 2e-4
 
 
 # ---- BASELINE.json configs as parity cases (the bench line is configs[1]; the others are checked here) ---------------

@@ -230,3 +230,43 @@ def test_rnn_golden_vector():
     loss, g, _ = o.forward_backward(z["theta"].astype(np.float64), z["idx"], z["labels"])
     assert abs(loss - float(z["loss"])) < 1e-12
     np.testing.assert_allclose(g, z["grad"], rtol=0, atol=1e-12)
+
+
+# ---- rnnType "gru": nn.GRU [A8] -----------------------------------------------------------------------------
+@pytest.mark.parametrize("L", [1, 2])
+def test_gru_cell_matches_torch_autograd(L):
+    import torch
+    cfg = make_cfg(Vt=6, Ve=60, Vr=9, dt=4, de=4, dr=4, H=12, L=L, rnn_type=2)
+    o = Oracle(cfg, np.float64)
+    theta = o.init_params(2, 0.4)
+    idx, labels = synth.make_paths(9, 3, 5, Ve=60, seed=4)
+    loss, g, _ = o.forward_backward(theta, idx, labels, class_id=1, bce_literal=True)
+    lay = o.layout()
+    th = torch.tensor(theta, dtype=torch.float64, requires_grad=True)
+
+    def P(name):
+        off, shp = lay[name]
+        return th[off:off + int(np.prod(shp))].reshape(shp)
+    ids = torch.tensor(idx.astype(np.int64)) - 1
+    B, Pn, T, F = idx.shape
+    x = torch.cat([P("type_emb")[ids[..., 0]], P("entity_emb")[ids[..., 1]], P("relation_emb")[ids[..., 2]]], dim=-1).reshape(B * Pn, T, -1)
+    seq = [x[:, t] for t in range(T)]
+    H = cfg.H
+    for l in range(L):
+        Wi, bi, Wo, Wc, bc, Uc = (P(f"gru{l + 1}.{n}") for n in ("i2g.weight", "i2g.bias", "o2g.weight", "c_i2h.weight", "c_i2h.bias", "c_h2h.weight"))
+        h = torch.zeros(B * Pn, H, dtype=torch.float64)
+        out = []
+        for t in range(T):
+            gz = torch.sigmoid(seq[t] @ Wi.T + bi + h @ Wo.T)
+            r, z = gz[:, :H], gz[:, H:]
+            n_ = torch.tanh(seq[t] @ Wc.T + bc + (r * h) @ Uc.T)  # reset applied BEFORE the recurrent product (Element-Research nn.GRU)
+            h = (1 - z) * n_ + z * h
+            out.append(h)
+        seq = out
+    s = seq[-1] @ P("out.weight").T + P("out.bias")
+    p = torch.sigmoid(torch.logsumexp(s.reshape(B, Pn, -1), dim=1))[:, 0]
+    t = torch.tensor(labels, dtype=torch.float64)
+    tl = -(t * torch.log(p + 1e-12) + (1 - t) * torch.log(1 - p + 1e-12)).mean()
+    tl.backward()
+    assert abs(loss - float(tl.detach())) < 1e-12
+    assert np.max(np.abs(g - th.grad.numpy())) < 1e-11
