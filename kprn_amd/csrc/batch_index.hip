@@ -56,6 +56,86 @@ void build(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int Ve, int
 }  // namespace bidx
 
 // ---------------------------------------------------------------------------------------------------------
+// Entity-table gradient as a gather-reduce over the batch's occurrence index: positions sorted by entity id are
+// cut into 64-position segments, one wave per segment, lane = column of the entity slice.  All 64 dx values of a
+// lane are requested up front (independent loads), then summed run by run.  A run that lies inside its segment is
+// written with a plain store: no atomics, a fixed summation order.  Only runs that straddle segments (hub
+// entities, the pad row) add their per-segment partial sums atomically.
+//   FRAG = 1: dx in the fused backward's fragment order [(N/16)][T][D/16 waves][64 lanes][4]
+//             (lane (ag, arow), register r <-> row 4 ag + r of the 16-row block, col 16 w + arow);
+//   FRAG = 0: dx time-major row-major [T][N][D] (generic pipeline).
+namespace bidx {
+namespace {
+template <int FRAG>
+__global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ DX, const int32_t* __restrict__ key_sorted,
+                                                     const int32_t* __restrict__ pos_sorted, int64_t nsteps, int64_t N, int T, int D, int dt, int de,
+                                                     float* __restrict__ gWe) {
+  const int lane = threadIdx.x & 63;
+  const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t base = seg * 64;
+  if (base >= nsteps) return;
+  const int cnt = (int)((nsteps - base < 64) ? (nsteps - base) : 64);
+  const int my_key = (lane < cnt) ? key_sorted[base + lane] : -1;
+  const int my_pos = (lane < cnt) ? pos_sorted[base + lane] : 0;
+  const int key_before = (base > 0) ? key_sorted[base - 1] : -1;
+  const int key_after = (base + cnt < nsteps) ? key_sorted[base + cnt] : -1;
+  const int waves_per_group = D >> 4;  // FRAG: 16-column blocks per (16-row block, t)
+  for (int c0 = 0; c0 < de; c0 += 64) {
+    const int ecol = c0 + lane;       // column inside the entity slice
+    const bool act = ecol < de;
+    const int col = dt + ecol;        // column of dx
+    const int coff = (col >> 4) * 256 + (col & 15) * 4;
+    float v[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int p = __builtin_amdgcn_readlane(my_pos, i);
+      const int n = p / T, t = p - n * T;
+      int64_t off;
+      if (FRAG) {
+        const int rr = n & 15;
+        off = ((int64_t)(n >> 4) * T + t) * ((int64_t)waves_per_group * 256) + (rr >> 2) * 64 + (rr & 3) + coff;
+      } else {
+        off = ((int64_t)t * N + n) * D + col;
+      }
+      v[i] = (act && i < cnt) ? DX[off] : 0.f;
+    }
+    float acc = 0.f;
+    bool opened_here = __builtin_amdgcn_readlane(my_key, 0) != key_before;  // the first run starts in this segment
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (i < cnt) {  // wave-uniform
+        acc += v[i];
+        const int k = __builtin_amdgcn_readlane(my_key, i);
+        const bool more = (i < 63) && (i + 1 < cnt);
+        const int knext = more ? __builtin_amdgcn_readlane(my_key, (i + 1) & 63) : key_after;
+        if (!more || knext != k) {  // the run ends, or the segment does
+          const bool whole = opened_here && (knext != k);  // every occurrence of row k was in this segment
+          if (act) {
+            float* dst = gWe + (int64_t)k * de + ecol;
+            if (whole) *dst = acc; else unsafeAtomicAdd(dst, acc);
+          }
+          acc = 0.f;
+          opened_here = true;
+        }
+      }
+    }
+  }
+}
+}  // namespace
+
+void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* key_sorted, const int32_t* pos_sorted, int64_t N, int T, int D, int dt,
+                 int de, float* gWe) {
+  const int64_t nsteps = N * T;
+  if (nsteps <= 0) return;
+  const int64_t segs = (nsteps + 63) / 64;
+  const dim3 grid((unsigned)((segs + 3) / 4));
+  if (frag_order) hipLaunchKernelGGL(k_entity_grad<1>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, nsteps, N, T, D, dt, de, gWe);
+  else hipLaunchKernelGGL(k_entity_grad<0>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, nsteps, N, T, D, dt, de, gWe);
+  HIP_TRY(hipGetLastError());
+}
+}  // namespace bidx
+
+// ---------------------------------------------------------------------------------------------------------
 // Data-parallel exchange of the row-sparse entity gradients (new design): every rank's packed
 // buffer [count | ids | rows] has been all-gathered; the union of the rows and their sum IN RANK ORDER is built
 // by one stable sort of (row id, source slot) + one gather-reduce -- no per-row atomics on a shared counter, and

@@ -25,7 +25,7 @@ __device__ __forceinline__ short to_bf16(float x) {
   return (short)(u >> 16);
 }
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 80;  // LDT: k-major tile row stride (conflict-free frag reads)
+constexpr int BM = 64, BN = 64, BK = 32, LDT = 80;  // LDT: k-major tile row stride (2-way = minimal bank sharing for 64 lanes)
 
 template <bool A_KCONTIG, bool B_NCONTIG, bool BF16>
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int64_t sAm, int64_t sAk,
@@ -33,8 +33,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
                                                    float* __restrict__ C, int64_t ldc, int64_t M, int N, int64_t K,
                                                    int accumulate, const float* __restrict__ bias, int64_t kchunk,
                                                    int use_atomic) {
-  __shared__ float As[BK][LDT];
-  __shared__ float Bs[BK][LDT];
+  // double-buffered k-major tiles: the next tile's global loads are in flight while this tile's MFMAs run,
+  // one barrier per k-step
+  __shared__ float As[2][BK][LDT];
+  __shared__ float Bs[2][BK][LDT];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -49,61 +51,93 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int64_t k0 = k_beg; k0 < k_end; k0 += BK) {
-    // ---- stage A tile [BM x BK] and B tile [BK x BN], zero-filled outside the problem
+  constexpr int PER = BM * BK / 256;  // elements of each tile per thread
+  float ra[PER], rb[PER];
+  // element e of this thread: the fast thread index runs along the operand's contiguous dimension (coalesced loads)
+  auto a_mk = [&](int e, int& m, int& k) {
+    if (A_KCONTIG) { k = tid & (BK - 1); m = (tid / BK) + e * (256 / BK); }
+    else           { m = tid & 63; k = (tid >> 6) + e * 4; }
+  };
+  auto b_nk = [&](int e, int& n, int& k) {
+    if (B_NCONTIG) { n = tid & 63; k = (tid >> 6) + e * 4; }
+    else           { k = tid & (BK - 1); n = (tid / BK) + e * (256 / BK); }
+  };
+  auto load_tile = [&](int64_t k0) {  // zero-filled outside the problem
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int e = 0; e < PER; ++e) {
       int m, k;
-      if (A_KCONTIG) { k = tid & 15; m = (tid >> 4) + i * 16; }
-      else           { m = tid & 63; k = (tid >> 6) + i * 4; }
+      a_mk(e, m, k);
       const int64_t gm = m_base + m, gk = k0 + k;
-      float v = 0.f;
-      if (gm < M && gk < k_end) v = A[gm * sAm + gk * sAk];
-      As[k][m] = v;
+      ra[e] = (gm < M && gk < k_end) ? A[gm * sAm + gk * sAk] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int e = 0; e < PER; ++e) {
       int n, k;
-      if (B_NCONTIG) { n = tid & 63; k = (tid >> 6) + i * 4; }
-      else           { k = tid & 15; n = (tid >> 4) + i * 16; }
+      b_nk(e, n, k);
       const int gn = n_base + n;
       const int64_t gk = k0 + k;
-      float v = 0.f;
-      if (gn < N && gk < k_end) v = B[gk * sBk + (int64_t)gn * sBn];
-      Bs[k][n] = v;
+      rb[e] = (gn < N && gk < k_end) ? B[gk * sBk + (int64_t)gn * sBn] : 0.f;
     }
-    __syncthreads();
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      int m, k;
+      a_mk(e, m, k);
+      As[buf][k][m] = ra[e];
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      int n, k;
+      b_nk(e, n, k);
+      Bs[buf][k][n] = rb[e];
+    }
+  };
+
+  load_tile(k_beg);
+  store_tile(0);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = k_beg; k0 < k_end; k0 += BK) {
+    const bool more = k0 + BK < k_end;
+    if (more) load_tile(k0 + BK);
     if (BF16) {
-      // one 16x16x16 bf16 MFMA per accumulator and k-step: lane (col = lane&15, kg = lane>>4) supplies k = 4kg..4kg+3
-      s16x4 a[2], b[2];
-      const int kb = (lane >> 4) * 4;
+      // 16x16x16 bf16 MFMA: lane (col = lane&15, kg = lane>>4) supplies k = 4kg..4kg+3 of each 16-k slab
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int ks = 0; ks < BK; ks += 16) {
+        s16x4 a[2], b[2];
+        const int kb = ks + (lane >> 4) * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[i][q] = to_bf16(As[kb + q][wm * 32 + i * 16 + (lane & 15)]);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+          for (int q = 0; q < 4; ++q) a[i][q] = to_bf16(As[cur][kb + q][wm * 32 + i * 16 + (lane & 15)]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b[j][q] = to_bf16(Bs[kb + q][wn * 32 + j * 16 + (lane & 15)]);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+          for (int q = 0; q < 4; ++q) b[j][q] = to_bf16(Bs[cur][kb + q][wn * 32 + j * 16 + (lane & 15)]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[j], acc[i][j], 0, 0, 0);
-    } else
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 4) {
-      float a[2], b[2];
-      const int kr = kk + (lane >> 4);
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[kr][wm * 32 + i * 16 + (lane & 15)];
+      for (int kk = 0; kk < BK; kk += 4) {
+        float a[2], b[2];
+        const int kr = kk + (lane >> 4);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wn * 32 + j * 16 + (lane & 15)];
+        for (int i = 0; i < 2; ++i) a[i] = As[cur][kr][wm * 32 + i * 16 + (lane & 15)];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) b[j] = Bs[cur][kr][wn * 32 + j * 16 + (lane & 15)];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     }
+    if (more) store_tile(cur ^ 1);  // the other buffer was last read one step ago, before the previous barrier
     __syncthreads();
+    cur ^= 1;
   }
   // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll

@@ -441,7 +441,7 @@ __global__ void k_head_bwd(const float* __restrict__ dS, const float* __restrict
 // relations) are reduced in LDS per block first; entity rows go straight to L2 atomics.
 __global__ void k_embed_scatter(const int32_t* __restrict__ idx, int64_t N, int T, int F, int nT, const float* __restrict__ dX, int dt, int de,
                                 int dr, int Vt, int Vr, float* __restrict__ gWt, float* __restrict__ gWe, float* __restrict__ gWr,
-                                int use_lds, int steps_per_block) {
+                                int use_lds, int steps_per_block, int skip_entity) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int D = dt + de + dr;
   const int nt_small = Vt * dt, nr_small = Vr * dr;
@@ -467,7 +467,7 @@ __global__ void k_embed_scatter(const int32_t* __restrict__ idx, int64_t N, int 
         else unsafeAtomicAdd(gWt + (int64_t)row * dt + j, v);
       }
     } else if (j < dt + de) {
-      unsafeAtomicAdd(gWe + (int64_t)(f[F - 2] - 1) * de + (j - dt), v);
+      if (!skip_entity) unsafeAtomicAdd(gWe + (int64_t)(f[F - 2] - 1) * de + (j - dt), v);  // else: bidx::entity_grad (no atomics)
     } else {
       int row = f[F - 1] - 1;
       if (use_lds) lds_atomic_add(&lds[nt_small + row * dr + (j - dt - de)], v);
@@ -797,7 +797,7 @@ void head_bwd(hipStream_t s, const float* dS, const float* hT, const float* Wout
 }
 
 void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* dX, int dt, int de, int dr, int Vt, int Vr,
-                   float* gWt, float* gWe, float* gWr) {
+                   float* gWt, float* gWe, float* gWr, bool skip_entity) {
   if (N <= 0) return;
   size_t small = (size_t)((int64_t)Vt * dt + (int64_t)Vr * dr) * sizeof(float);
   int use_lds = small <= 96 * 1024 ? 1 : 0;
@@ -806,7 +806,7 @@ void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, i
   if (use_lds && small > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)k_embed_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small));
   hipLaunchKernelGGL(k_embed_scatter, dim3((unsigned)((total + spb - 1) / spb)), dim3(TPB), use_lds ? small : 0, s, idx, N, T, F, nT, dX, dt, de,
-                     dr, Vt, Vr, gWt, gWe, gWr, use_lds, spb);
+                     dr, Vt, Vr, gWt, gWe, gWr, use_lds, spb, skip_entity ? 1 : 0);
   CHECK_LAUNCH();
 }
 

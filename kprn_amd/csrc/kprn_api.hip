@@ -549,9 +549,10 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
   }
   {
     ProfScope ps(h, "embed_scatter");
-    kk::embed_scatter(s, b->idx, N, T, b->F, c.num_types, w.dIn, c.dt, c.de, c.dr, c.Vt, c.Vr, gd + h->off_Wt, h->g_We, gd + h->off_Wr);
+    const bool have_index = b->key_sorted != nullptr;
+    kk::embed_scatter(s, b->idx, N, T, b->F, c.num_types, w.dIn, c.dt, c.de, c.dr, c.Vt, c.Vr, gd + h->off_Wt, h->g_We, gd + h->off_Wr, have_index);
+    if (have_index) bidx::entity_grad(s, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, N, T, D, c.dt, c.de, h->g_We);
   }
-  (void)D;
 }
 
 // the loss of the last backward = fixed-order sum of the loss stage's per-workgroup partials, formed on demand

@@ -174,7 +174,7 @@ int loss_partials(int B);  // number of per-workgroup loss partials the loss sta
 void zero_pad3(hipStream_t s, float* a, int na, float* b, int nb, float* c, int nc);
 void head_bwd(hipStream_t s, const float* dS, const float* hT, const float* Wout, int64_t N, int H, int cid, float* dH, float* gWout, float* gbout);
 void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* dX /*[T][N][D]*/, int dt, int de, int dr,
-                   int Vt, int Vr, float* gWt, float* gWe, float* gWr);
+                   int Vt, int Vr, float* gWt, float* gWe, float* gWr, bool skip_entity = false);
 void sumsq(hipStream_t s, const float* x, int64_t n, float* out);
 void sumsq_rows(hipStream_t s, const float* G, const int32_t* rows, const int32_t* count, int d, float* out);
 // dense optimiser over a contiguous span; scale_src: device float norm2 -> clip factor computed in-kernel
@@ -201,6 +201,9 @@ size_t scratch_bytes(int64_t nsteps, int Ve);
 // uniq: sorted distinct entity rows; *n_uniq_dev: their count
 void build(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int Ve, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq,
            int32_t* n_uniq_dev, void* scratch, size_t scratch_sz);
+// entity-table gradient = gather-reduce of dx over the occurrence index (frag_order: fused backward's dx layout, else [T][N][D])
+void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* key_sorted, const int32_t* pos_sorted, int64_t N, int T, int D, int dt,
+                 int de, float* gWe);
 size_t merge_scratch_bytes(int64_t n, int Ve);
 void merge_rows(hipStream_t s, const void* all, int world, int cap, int de, int Ve, float* G, int32_t* union_rows, int32_t* union_count,
                 void* scratch, size_t scratch_sz);

@@ -471,65 +471,6 @@ __global__ __launch_bounds__(256) void k_embed_scatter_frag(ScatArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Entity-table gradient as a gather-reduce over the batch's occurrence index (batch_index.hip): positions sorted
-// by entity id are cut into 64-position segments, one wave per segment, lane = column of the entity slice.  All
-// 64 dx values of a lane are requested up front (independent loads), then summed run by run.  A run that lies
-// inside its segment is written with a plain store: no atomics, a fixed summation order.  Only runs that straddle
-// segments (hub entities, the pad row) add their per-segment partial sums atomically.
-struct EntArgs {
-  const float* DX;            // fragment-order dx of the bottom layer
-  const int32_t* key_sorted;  // [nsteps] entity row (0-based) of each sorted position
-  const int32_t* pos_sorted;  // [nsteps] position = n*T + t
-  int64_t nsteps;
-  int T, dt, de;
-  float* gWe;
-};
-
-__global__ __launch_bounds__(256) void k_entity_grad(EntArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t base = seg * 64;
-  if (base >= a.nsteps) return;
-  const int cnt = (int)((a.nsteps - base < 64) ? (a.nsteps - base) : 64);
-  const int my_key = (lane < cnt) ? a.key_sorted[base + lane] : -1;
-  const int my_pos = (lane < cnt) ? a.pos_sorted[base + lane] : 0;
-  const int key_before = (base > 0) ? a.key_sorted[base - 1] : -1;
-  const int key_after = (base + cnt < a.nsteps) ? a.key_sorted[base + cnt] : -1;
-  const int col = a.dt + lane;
-  const bool act = lane < a.de;
-  const int coff = (col >> 4) * 256 + (col & 15) * 4;  // wave block + lane slot of this column inside a (m-tile, t) group
-  float v[64];
-#pragma unroll
-  for (int i = 0; i < 64; ++i) {
-    const int p = __builtin_amdgcn_readlane(my_pos, i);
-    const int n = p / a.T, t = p - n * a.T;
-    const int rr = n & 15;
-    const int64_t off = ((int64_t)(n >> 4) * a.T + t) * 1024 + (rr >> 2) * 64 + (rr & 3);
-    v[i] = (act && i < cnt) ? a.DX[off + coff] : 0.f;
-  }
-  float acc = 0.f;
-  bool opened_here = __builtin_amdgcn_readlane(my_key, 0) != key_before;  // the first run starts in this segment
-#pragma unroll
-  for (int i = 0; i < 64; ++i) {
-    if (i < cnt) {  // wave-uniform
-      acc += v[i];
-      const int k = __builtin_amdgcn_readlane(my_key, i);
-      const bool more = (i < 63) && (i + 1 < cnt);
-      const int knext = more ? __builtin_amdgcn_readlane(my_key, (i + 1) & 63) : key_after;
-      if (!more || knext != k) {  // the run ends, or the segment does
-        const bool whole = opened_here && (knext != k);  // every occurrence of row k was in this segment
-        if (act) {
-          float* dst = a.gWe + (int64_t)k * a.de + lane;
-          if (whole) *dst = acc; else unsafeAtomicAdd(dst, acc);
-        }
-        acc = 0.f;
-        opened_here = true;
-      }
-    }
-  }
-}
-
 // gWt | gWr += sum over the scatter workgroups' slabs: one workgroup per 16 table entries, 16 slab lanes each
 __global__ __launch_bounds__(256) void k_reduce_small(const float* __restrict__ part, int nslab, int n_small, int nt_small, float* __restrict__ gWt, float* __restrict__ gWr) {
   __shared__ float red[16][17];
@@ -648,12 +589,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     }
     if (bottom && have_index && !(a.dbg & 1)) {
       ProfScope ps(h, "entity_grad");
-      EntArgs ea;
-      ea.DX = s->DX; ea.key_sorted = b->key_sorted; ea.pos_sorted = b->pos_sorted; ea.nsteps = N * T; ea.T = T; ea.dt = c.dt; ea.de = c.de;
-      ea.gWe = a.gWe;
-      const int64_t segs = (N * T + 63) / 64;
-      hipLaunchKernelGGL(k_entity_grad, dim3((unsigned)((segs + 3) / 4)), dim3(256), 0, strm, ea);
-      HIP_TRY(hipGetLastError());
+      bidx::entity_grad(strm, s->DX, /*frag_order=*/1, b->key_sorted, b->pos_sorted, N, T, DH, c.dt, c.de, a.gWe);
     }
     if (bottom && !(a.dbg & 1) && (!small_in_kernel || !have_index)) {
       ProfScope ps(h, "embed_scatter");
