@@ -494,3 +494,36 @@ def test_config4_bf16_compute_is_tolerance_gated_against_the_f64_oracle():
         assert rel_inf(g_bf[off:off + n], og[off:off + n]) < 5e-2, nm
     assert rel_inf(outs[0][0], ps) < 2e-5            # the fp32 path at the same shape
     assert rel_inf(s_bf, ps) > 20 * rel_inf(outs[0][0], ps)  # bf16 really ran
+
+
+def test_full_size_backward_is_additive_over_pairs():
+    """BASELINE-size shapes (T=6, D=H=64, L=2, KKBox-size entity table, ~16k paths per call): with the loss scale held
+    fixed, the gradient of a minibatch is the SUM of the gradients of any partition of its pairs (pairs are independent
+    units, MapReduce.lua:24-47) -- a size-independent check of the whole fused backward, the index-based embedding
+    gradient and the head, at a size the CPU oracle cannot reach in test time."""
+    eng = _ffi.Engine(6, 2851220, 9, 16, 32, 16, 64, 2)
+    idx, labels = synth.make_paths(4096, 4, 6, Ve=2851220, seed=77)
+    inv = 1.0 / 4096.0
+    lay = eng.layout()
+    dense_names = [n for n in lay if n != "entity_emb"]
+
+    def grads(sl):
+        b = eng.batch(idx[sl], labels[sl])
+        loss = eng.backward(b, 1, False, inv)
+        g = {n: eng.get_grad(n).astype(np.float64) for n in dense_names}
+        rows = np.unique(idx[sl][..., 1]) - 1
+        ge = eng.get_grad("entity_emb")[rows].astype(np.float64)
+        return loss, g, rows, ge
+
+    l_all, g_all, r_all, e_all = grads(slice(0, 4096))
+    l_a, g_a, r_a, e_a = grads(slice(0, 1500))
+    l_b, g_b, r_b, e_b = grads(slice(1500, 4096))
+    assert abs(l_all - (l_a + l_b)) < 1e-5 * max(1.0, abs(l_all))
+    for n in dense_names:
+        ref = g_all[n]
+        assert np.max(np.abs(ref - (g_a[n] + g_b[n]))) < 2e-5 * max(1e-30, np.max(np.abs(ref))), n
+    acc = {int(r): e_a[i].copy() for i, r in enumerate(r_a)}
+    for i, r in enumerate(r_b):
+        acc[int(r)] = acc.get(int(r), 0) + e_b[i]
+    tot = np.stack([acc[int(r)] for r in r_all])
+    assert np.max(np.abs(e_all - tot)) < 2e-5 * np.max(np.abs(e_all))
