@@ -4,9 +4,9 @@
   python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic paths already resident in
-HBM: ONE MyOptimizer:trainBatch (zeroPad, zeroGrad, forward, BCE, backward, Adam, zeroPad;
-release/songPathRnn/model/optimizer/MyOptimizer.lua:177-221) followed by ONE scoring forward
-(release/songPathRnn/eval/test_from_checkpoint.lua:109) over the same batch, i.e. the
+HBM: ONE scoring forward (release/songPathRnn/eval/test_from_checkpoint.lua:109) with the parameters
+as they stand, and ONE MyOptimizer:trainBatch (zeroPad, zeroGrad, forward, BCE, backward, Adam, zeroPad;
+release/songPathRnn/model/optimizer/MyOptimizer.lua:177-221) over the same batch, i.e. the
 "combined = N_paths / (t_train + t_score)" of SURVEY.md section 8d.  value = paths processed by
 all ranks / max-over-ranks wall time of the K timed steps.
 
@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--train-only", action="store_true")
     ap.add_argument("--score-only", action="store_true")
+    ap.add_argument("--reserve-cus", type=int, default=16, help="CUs the scoring pass leaves to the collective in data-parallel runs")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (pack / all-gather / merge) even at world size 1")
     return ap.parse_args()
 
@@ -192,15 +193,24 @@ def main():
         # packing capacity = largest distinct-row count of any batch on any rank (known from the batch index)
         dpx.set_capacity(max(b.n_uniq for b in batches))
 
+    # A step = one scoring forward + one trainBatch over the same batch.  The scoring pass uses the parameters as they are
+    # BEFORE this step's update ("score the batch, then learn from it"), so it does not depend on the step's gradient
+    # exchange: in data-parallel runs it is enqueued while the entity-row all-gather is in flight (kprn_amd/dp.py), with
+    # a few CUs left free for the collective's copy kernels.
+    if dpx is not None and world > 1:
+        eng.set_option("reserve_cus", str(a.reserve_cus))
+
     def step(i):
         b = batches[i % len(batches)]
-        if not a.score_only:
-            if dpx is not None:
-                dpx.train_step(b, opt, 1)
-            else:
-                eng.train_step(b, opt, 1, want_loss=False)
-        if not a.train_only:
+        score = (lambda: eng.forward_async(b, 1)) if not a.train_only else None
+        if a.score_only:
             eng.forward_async(b, 1)
+        elif dpx is not None:
+            dpx.train_step(b, opt, 1, overlap=score)
+        else:
+            if score:
+                score()
+            eng.train_step(b, opt, 1, want_loss=False)
         return paths_of[i % len(batches)]
 
     def barrier():

@@ -1221,6 +1221,12 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     if (strcmp(value, "auto") == 0) h->impl = 0;
     else if (strcmp(value, "generic") == 0) h->impl = 1;
     else throw KprnError{KPRN_E_ARG, "impl must be auto or generic"};
+  } else if (strcmp(key, "reserve_cus") == 0) {
+    // the fused SCORING forward is a persistent one-workgroup-per-CU kernel that fills the register file of every CU it runs
+    // on; leaving a few CUs free lets the copy kernels of a concurrently running collective (RCCL) make progress beside it
+    const int v = atoi(value);
+    KPRN_REQUIRE(v >= 0 && v <= 128, KPRN_E_ARG, "reserve_cus must be in 0..128");
+    h->reserve_cus = v;
   } else {
     throw KprnError{KPRN_E_ARG, std::string("unknown option: ") + key};
   }

@@ -131,6 +131,7 @@ struct kprn_handle {
   void* fused_state = nullptr;  // owned by lstm_fused_*.hip
   void* bidx_scratch = nullptr; size_t bidx_scratch_bytes = 0;  // batch_index.hip temporaries
   int impl = 0;                 // 0 auto, 1 generic
+  int reserve_cus = 0;          // CUs the SCORING forward leaves free (a collective's copy kernels run beside it; kprn_set_option)
   int32_t last_B = 0;
 
   bool prof_on = false;

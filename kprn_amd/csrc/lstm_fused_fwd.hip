@@ -405,7 +405,8 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
     }
     a.save_frag = s->save_frag;
   }
-  const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)s->num_cu);
+  const int cus = (!save && h->reserve_cus > 0) ? std::max(1, s->num_cu - h->reserve_cus) : s->num_cu;
+  const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)cus);
   static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
   if (want_timing && !s->timing) HIP_TRY(hipMalloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
   a.timing = s->timing;

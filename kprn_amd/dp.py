@@ -92,8 +92,10 @@ class DataParallel:
         self._all = None
         return self.capacity
 
-    def train_step(self, batch, opt, class_id=1, global_pairs=None):
-        """one data-parallel MyOptimizer:trainBatch; `batch` holds THIS rank's pairs."""
+    def train_step(self, batch, opt, class_id=1, global_pairs=None, overlap=None):
+        """one data-parallel MyOptimizer:trainBatch; `batch` holds THIS rank's pairs.
+        overlap: optional callable that ENQUEUES work which does not depend on this step's update (e.g. a scoring pass
+        with the pre-update parameters); it runs while the entity-row all-gather is in flight."""
         a = self.a
         gp = global_pairs if global_pairs is not None else batch.B * self.world
         a.zero_pad()  # MyOptimizer.lua:181
@@ -106,10 +108,15 @@ class DataParallel:
         buf = a.pack(cap)  # one packed tensor per rank, same length everywhere
         if self._all is None or self._all.numel() != buf.numel() * self.world or self._all.dtype != buf.dtype:
             self._all = torch.empty(buf.numel() * self.world, dtype=buf.dtype, device=buf.device)
+        work = None
         if self.world > 1:
-            dist.all_gather_into_tensor(self._all, buf, group=self.group)
+            work = dist.all_gather_into_tensor(self._all, buf, group=self.group, async_op=True)
         else:
             self._all.copy_(buf)
+        if overlap is not None:
+            overlap()      # compute that hides the exchange (xGMI is otherwise the only thing working right now)
+        if work is not None:
+            work.wait()    # stream-level wait: the merge below is ordered after the collective
         a.merge(self._all, self.world, cap)  # union of the rows, summed in rank order
         a.apply_update(opt)
 
