@@ -527,3 +527,22 @@ def test_full_size_backward_is_additive_over_pairs():
         acc[int(r)] = acc.get(int(r), 0) + e_b[i]
     tot = np.stack([acc[int(r)] for r in r_all])
     assert np.max(np.abs(e_all - tot)) < 2e-5 * np.max(np.abs(e_all))
+
+
+@pytest.mark.parametrize("T,L", [(2, 1), (2, 2), (16, 2)])
+def test_fused_kernels_at_the_edges_of_their_step_range(T, L):
+    """the fused kernels cover 2 <= T <= 16 (LDS id tile); T = 2 has a single recurrent step, T = 16 fills the id tile"""
+    eng, o64, theta = mk(L=L, impl="auto")
+    idx, labels = synth.make_paths(45, 3, T, Ve=300, seed=50 + T)
+    b = eng.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    ps, _, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5
+    np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=SCORE_RTOL)
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], og[off:off + n]) < GRAD_RTOL, (nm, T, L)
