@@ -41,7 +41,8 @@ struct BwdArgs {
   float* gWt; float* gWe; float* gWr;   // bottom layer only
   float* part;             // [grid][2*256*64 + 256] per-workgroup partial dW_i2g | dW_o2g | db
   unsigned long long* timing;  // optional [grid][8] cycle counters (KPRN_TIMING=1)
-  int dbg;                 // KPRN_DBG bit 0: skip the embedding scatter (measurement only)
+  int dbg;                 // KPRN_DBG (measurement / cross-checks only): 1 skip the embedding backward, 8 small tables through the
+                           // general scatter kernel, 16 entity table through the general scatter kernel (atomics) instead of the index
   int64_t n_tiles;
 };
 

@@ -546,3 +546,35 @@ def test_fused_kernels_at_the_edges_of_their_step_range(T, L):
     for nm, (off, shp) in eng.layout().items():
         n = int(np.prod(shp))
         assert rel_inf(g[off:off + n], og[off:off + n]) < GRAD_RTOL, (nm, T, L)
+
+
+def test_embedding_backward_variants_agree(monkeypatch):
+    """the three forms of the embedding backward are interchangeable: one-hot MFMA small tables + index gather-reduce
+    (default), general scatter kernel for the small tables (KPRN_DBG=8) and for everything (KPRN_DBG=24, atomics)"""
+    import subprocess, sys, json, textwrap
+    code = textwrap.dedent("""
+        import sys, json, numpy as np
+        sys.path.insert(0, %r)
+        from tests.test_gpu_parity import mk
+        from kprn_amd import synth
+        eng, o64, theta = mk(L=2, impl="auto")
+        idx, labels = synth.make_paths(300, 3, 6, Ve=300, seed=61)
+        eng.backward(eng.batch(idx, labels), 1)
+        g = eng.get_flat_grads()
+        lay = eng.layout()
+        out = {}
+        for nm in ("type_emb", "entity_emb", "relation_emb"):
+            off, shp = lay[nm]
+            out[nm] = g[off:off + int(np.prod(shp))].astype(float).tolist()
+        print(json.dumps(out))
+    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for dbg in ("0", "8", "24"):
+        env = dict(os.environ, KPRN_DBG=dbg)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[dbg] = {k: np.array(v) for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()}
+    for nm in res["0"]:
+        ref = res["0"][nm]
+        for dbg in ("8", "24"):
+            assert np.max(np.abs(res[dbg][nm] - ref)) < 1e-5 * max(1e-30, np.max(np.abs(ref))), (nm, dbg)
