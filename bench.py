@@ -197,7 +197,7 @@ def main():
     # BEFORE this step's update ("score the batch, then learn from it"), so it does not depend on the step's gradient
     # exchange: in data-parallel runs it is enqueued while the entity-row all-gather is in flight (kprn_amd/dp.py), with
     # a few CUs left free for the collective's copy kernels.
-    if dpx is not None and world > 1:
+    if dpx is not None:
         eng.set_option("reserve_cus", str(a.reserve_cus))
 
     def step(i):
@@ -215,7 +215,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or a.force_dp:
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -78,13 +78,16 @@ class DataParallel:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # with a process group (even of size 1: bench.py --force-dp) every collective below is really issued, so the
+        # single-GPU dev box exercises the exact call sequence of the N-GPU run
+        self.collectives = dist.is_initialized()
         self.capacity = 0
         self._all = None
 
     def set_capacity(self, local_max_rows):
         """fixed per-rank packing capacity = max over ranks of the largest per-step touched-row count."""
         t = torch.tensor([int(local_max_rows)], dtype=torch.int64)
-        if self.world > 1:
+        if self.collectives:
             if dist.get_backend(self.group) == "nccl":
                 t = t.to(self.a.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -100,7 +103,7 @@ class DataParallel:
         gp = global_pairs if global_pairs is not None else batch.B * self.world
         a.zero_pad()  # MyOptimizer.lua:181
         a.backward(batch, class_id, bool(opt.bce_literal), 1.0 / float(gp))
-        if self.world > 1:
+        if self.collectives:
             dist.all_reduce(a.dense_grads(), op=dist.ReduceOp.SUM, group=self.group)
         if self.capacity <= 0:
             self.set_capacity(a.local_rows())
@@ -109,7 +112,7 @@ class DataParallel:
         if self._all is None or self._all.numel() != buf.numel() * self.world or self._all.dtype != buf.dtype:
             self._all = torch.empty(buf.numel() * self.world, dtype=buf.dtype, device=buf.device)
         work = None
-        if self.world > 1:
+        if self.collectives:
             work = dist.all_gather_into_tensor(self._all, buf, group=self.group, async_op=True)
         else:
             self._all.copy_(buf)
