@@ -578,3 +578,24 @@ def test_embedding_backward_variants_agree(monkeypatch):
         ref = res["0"][nm]
         for dbg in ("8", "24"):
             assert np.max(np.abs(res[dbg][nm] - ref)) < 1e-5 * max(1e-30, np.max(np.abs(ref))), (nm, dbg)
+
+
+def test_shipped_config_sh_shape_rnn_h250():
+    """run_scripts/config.sh as shipped: rnnType rnn, rnnHidSize 250, embedding dims 50/100/50 (D = 200), 1 layer, ReLU,
+    identity initialisation, LogSumExp pool, Adam -- odd sizes for every GEMM edge (small vocabulary here)."""
+    eng = _ffi.Engine(6, 400, 9, 50, 100, 50, 250, 1, rnn_type=1, use_relu=1, rnn_init=1, param_init=0.1, reducer=2)
+    o64 = Oracle(make_cfg(Vt=6, Ve=400, Vr=9, dt=50, de=100, dr=50, H=250, L=1, rnn_type=1, use_relu=1), np.float64)
+    theta = eng.get_flat_params().astype(np.float64)
+    idx, labels = synth.make_paths(64, 2, 6, Ve=400, seed=71)   # batchSize=128 paths-ish
+    b = eng.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    ps, _, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5
+    np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=SCORE_RTOL)
+    th, st = theta.copy(), o64.new_state()
+    opt, oopt = _ffi.make_opt(method=1, lr=1e-3), make_opt(method=1, lr=1e-3)
+    for s_ in range(6):
+        ol, _ = o64.train_step(th, st, oopt, idx, labels)
+        gl = eng.train_step(b, opt)
+        assert abs(gl - ol) < 2e-4 * max(1, abs(ol)), (s_, gl, ol)
+    assert float(np.max(np.abs(eng.get_flat_params() - th))) < 2e-4
