@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--paths-per-step", type=int, default=65536, help="paths per rank per step")
-    ap.add_argument("--dims", default="A", choices=["A", "B"], help="A: D=H=64 (16/32/16); B: 64/64/64 -> D=H=192")
+    ap.add_argument("--dims", default="A", choices=["A", "B", "shipped"],
+                    help="A: D=H=64 (16/32/16); B: 64/64/64 -> D=H=192; shipped: run_scripts/config.sh as shipped (rnn, 50/100/50 -> D=200, H=250, L=1)")
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--T", type=int, default=6)
     ap.add_argument("--entities", type=int, default=2851220)
@@ -63,12 +64,15 @@ def parse():
 def dims_of(a):
     if a.dims == "A":
         return 16, 32, 16, 64
+    if a.dims == "shipped":
+        return 50, 100, 50, 250
     return 64, 64, 64, 192
 
 
-def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr):
-    """(bound, algorithmic work per launch) for a kernel family of the engine; None if unknown."""
-    g = 4 * H
+def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4):
+    """(bound, algorithmic work per launch) for a kernel family of the engine; None if unknown.
+    G = rows of the recurrent weights per hidden unit (4 FastLSTM, 1 rnn)."""
+    g = G * H
     if name in ("lstm_fused_fwd", "lstm_fused_fwd_train"):
         fl = 0
         for l in range(L):
@@ -170,11 +174,14 @@ def main():
 
     from kprn_amd import _ffi, synth, dp
     dt_, de_, dr_, H = dims_of(a)
-    D, L, T, C, F, nT = dt_ + de_ + dr_, a.layers, a.T, 46, 3, 1
+    shipped = a.dims == "shipped"
+    D, L, T, C, F, nT = dt_ + de_ + dr_, (1 if shipped else a.layers), a.T, 46, 3, 1
+    G = 1 if shipped else 4
     Vt, Ve, Vr = 6, a.entities, 9
     stream = torch.cuda.current_stream().cuda_stream
     eng = _ffi.Engine(Vt, Ve, Vr, dt_, de_, dr_, H, L, F=F, num_types=nT, C_=C, reducer=2, device_id=local_rank,
-                      rank=rank, world=world, param_init=0.1, seed=12345, stream=stream)
+                      rank=rank, world=world, param_init=0.1, seed=12345, stream=stream,
+                      rnn_type=1 if shipped else 0, use_relu=1, rnn_init=1 if shipped else 0)
     eng.set_option("impl", a.impl)
     opt = _ffi.make_opt(method=1, lr=1e-3, entity_update=a.entity_update)
 
@@ -261,13 +268,13 @@ def main():
         known = True
         for i in range(a.steps):
             N = paths_of[(a.warmup + i) % len(batches)]
-            fw = family_work(name, N, T, D, H, L, C, F, nT, dt_, de_, dr_)
+            fw = family_work(name, N, T, D, H, L, C, F, nT, dt_, de_, dr_, G)
             if fw is None:
                 known = False
                 break
             work += fw[1]
         if known and launches > 0 and ms > 0:
-            bound = family_work(name, 1, T, D, H, L, C, F, nT, dt_, de_, dr_)[0]
+            bound = family_work(name, 1, T, D, H, L, C, F, nT, dt_, de_, dr_, G)[0]
             # every launch of a family inside one step sees that step's N; launches per step is constant
             total_work = work * (launches / a.steps)
             if bound == "mfma":
@@ -293,14 +300,16 @@ def main():
 
     if rank == 0:
         value = npaths_total / elapsed
-        fwd_flops = sum(T * 2 * 4 * H * ((D if l == 0 else H) + H) for l in range(L)) + 2 * H * C
+        fwd_flops = sum(T * 2 * G * H * ((D if l == 0 else H) + H) for l in range(L)) + 2 * H * C
         step_flops = (0 if a.score_only else 3 * fwd_flops) + (0 if a.train_only else fwd_flops)
         out = {
             "metric": "paths/sec (train+score) at path_len=6 d=64", "value": round(value, 1), "unit": "paths/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2 KKBOX-MI synthetic: T={T}, D=H={H} ({dt_}/{de_}/{dr_}), L={L} FastLSTM, fp32, Ve={Ve}, "
-                                   f"C=46, LSE pool, Adam; train step + scoring pass per batch",
+            "config": {"workload": (f"C2 KKBOX-MI synthetic: T={T}, D=H={H} ({dt_}/{de_}/{dr_}), L={L} FastLSTM, fp32, Ve={Ve}, "
+                                    f"C=46, LSE pool, Adam; scoring pass + train step per batch") if not shipped else
+                                   (f"run_scripts/config.sh as shipped, synthetic KKBox-shaped paths: T={T}, rnn (ReLU, MaskZero, identity init), "
+                                    f"D={D} ({dt_}/{de_}/{dr_}), H={H}, L=1, fp32, Ve={Ve}, C=46, LSE pool, Adam; scoring pass + train step per batch"),
                        "paths_per_step_per_gpu": a.paths_per_step, "paths_per_pair_buckets": Ps, "impl": a.impl,
                        "entity_update": "lazy-exact" if a.entity_update == 0 else "dense",
                        "parallelism": f"dp{world}" if world > 1 else "single"},
