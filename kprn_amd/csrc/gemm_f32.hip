@@ -164,6 +164,128 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     }
 }
 
+
+// ---- 128 x 128 x 16 tile: each wave owns 64 x 64 (4 x 4 MFMA tiles), 8 LDS fragment reads per 16 MFMAs and a quarter
+// of the small kernel's global loads per MFMA.  Used when both M and N are at least ~100 (the i2g / dW / dx GEMMs of
+// the wider configurations: reading B, config.sh's H = 250, configs[3]).
+constexpr int GM = 128, GN = 128, GK = 16, GLD = 136;
+
+template <bool A_KCONTIG, bool B_NCONTIG, bool BF16>
+__global__ __launch_bounds__(256) void gemm_kernel_big(const float* __restrict__ A, int64_t sAm, int64_t sAk,
+                                                       const float* __restrict__ B, int64_t sBk, int64_t sBn,
+                                                       float* __restrict__ C, int64_t ldc, int64_t M, int N, int64_t K,
+                                                       int accumulate, const float* __restrict__ bias, int64_t kchunk,
+                                                       int use_atomic) {
+  __shared__ float As[2][GK][GLD];
+  __shared__ float Bs[2][GK][GLD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m_base = (int64_t)blockIdx.x * GM;
+  const int n_base = blockIdx.y * GN;
+  const int64_t k_beg = (int64_t)blockIdx.z * kchunk;
+  const int64_t k_end = (k_beg + kchunk < K) ? k_beg + kchunk : K;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int PER = GM * GK / 256;  // 8
+  float ra[PER], rb[PER];
+  auto a_mk = [&](int e, int& m, int& k) {
+    if (A_KCONTIG) { k = tid & (GK - 1); m = (tid / GK) + e * (256 / GK); }
+    else           { m = tid & 127; k = (tid >> 7) + e * 2; }
+  };
+  auto b_nk = [&](int e, int& n, int& k) {
+    if (B_NCONTIG) { n = tid & 127; k = (tid >> 7) + e * 2; }
+    else           { k = tid & (GK - 1); n = (tid / GK) + e * (256 / GK); }
+  };
+  auto load_tile = [&](int64_t k0) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      int m, k;
+      a_mk(e, m, k);
+      const int64_t gm = m_base + m, gk = k0 + k;
+      ra[e] = (gm < M && gk < k_end) ? A[gm * sAm + gk * sAk] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      int n, k;
+      b_nk(e, n, k);
+      const int gn = n_base + n;
+      const int64_t gk = k0 + k;
+      rb[e] = (gn < N && gk < k_end) ? B[gk * sBk + (int64_t)gn * sBn] : 0.f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) { int m, k; a_mk(e, m, k); As[buf][k][m] = ra[e]; }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) { int n, k; b_nk(e, n, k); Bs[buf][k][n] = rb[e]; }
+  };
+
+  load_tile(k_beg);
+  store_tile(0);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = k_beg; k0 < k_end; k0 += GK) {
+    const bool more = k0 + GK < k_end;
+    if (more) load_tile(k0 + GK);
+    if (BF16) {
+      s16x4 a[4], b[4];
+      const int kb = (lane >> 4) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[i][q] = to_bf16(As[cur][kb + q][wm * 64 + i * 16 + (lane & 15)]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[j][q] = to_bf16(Bs[cur][kb + q][wn * 64 + j * 16 + (lane & 15)]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < GK; kk += 4) {
+        float a[4], b[4];
+        const int kr = kk + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = As[cur][kr][wm * 64 + i * 16 + (lane & 15)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = Bs[cur][kr][wn * 64 + j * 16 + (lane & 15)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n_base + wn * 64 + j * 16 + (lane & 15);
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m_base + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (row >= M) continue;
+        float v = acc[i][j][r];
+        float* dst = C + row * ldc + col;
+        if (use_atomic) unsafeAtomicAdd(dst, v);
+        else if (accumulate) *dst += v;
+        else { if (bias) v += bias[col]; *dst = v; }
+      }
+    }
+}
+
 }  // namespace
 
 namespace gemm {
@@ -178,9 +300,30 @@ void run(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B
   split_k = (int)((K + kchunk - 1) / kchunk);
   if (split_k < 1) split_k = 1;
   KPRN_REQUIRE(!(split_k > 1 && !accumulate), KPRN_E_ARG, "gemm: split-K needs accumulate mode");
-  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN), (unsigned)split_k);
   const int use_atomic = split_k > 1 ? 1 : 0;
   const bool akc = (sAk == 1), bnc = (sBn == 1);
+  const bool big = (M >= 100 && N >= 100);
+  if (big) {
+    kchunk = ((kchunk + GK - 1) / GK) * GK;
+    dim3 grid((unsigned)((M + GM - 1) / GM), (unsigned)((N + GN - 1) / GN), (unsigned)split_k);
+#define LAUNCHB(AK, BNC)                                                                                           \
+  do {                                                                                                             \
+    if (bf16)                                                                                                      \
+      hipLaunchKernelGGL((gemm_kernel_big<AK, BNC, true>), grid, dim3(256), 0, s, A, sAm, sAk, B, sBk, sBn, C, ldc, M, N, K, \
+                         accumulate ? 1 : 0, bias, kchunk, use_atomic);                                            \
+    else                                                                                                           \
+      hipLaunchKernelGGL((gemm_kernel_big<AK, BNC, false>), grid, dim3(256), 0, s, A, sAm, sAk, B, sBk, sBn, C, ldc, M, N, K, \
+                         accumulate ? 1 : 0, bias, kchunk, use_atomic);                                            \
+  } while (0)
+    if (akc && bnc) LAUNCHB(true, true);
+    else if (akc && !bnc) LAUNCHB(true, false);
+    else if (!akc && bnc) LAUNCHB(false, true);
+    else LAUNCHB(false, false);
+#undef LAUNCHB
+    HIP_TRY(hipGetLastError());
+    return;
+  }
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN), (unsigned)split_k);
 #define LAUNCH(AK, BNC)                                                                                            \
   do {                                                                                                             \
     if (bf16)                                                                                                      \
