@@ -69,22 +69,26 @@ def dims_of(a):
     return 64, 64, 64, 192
 
 
-def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4):
+def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4, NT=None):
     """(bound, algorithmic work per launch) for a kernel family of the engine; None if unknown.
-    G = rows of the recurrent weights per hidden unit (4 FastLSTM, 1 rnn)."""
+    G = rows of the recurrent weights per hidden unit (4 FastLSTM, 1 rnn).
+    NT = (path, step) positions the fused kernels EXECUTE (kprn_batch_executed_steps: N*T less the identical leading
+    steps run once per batch); a path's first executed step has no recurrent half.  Only executed flops are counted."""
     g = G * H
+    if NT is None:
+        NT = N * T
     if name in ("lstm_fused_fwd", "lstm_fused_fwd_train"):
         fl = 0
         for l in range(L):
             din = D if l == 0 else H
-            fl += T * 2 * g * (din + H)
-        return "mfma", N * (fl + 2 * H * C)
+            fl += NT * 2 * g * din + (NT - N) * 2 * g * H
+        return "mfma", fl + N * 2 * H * C
     if name == "lstm_fused_bwd":
         fl = 0
         for l in range(L):
             din = D if l == 0 else H
-            fl += T * 2 * g * (din + H)
-        return "mfma", 2 * N * fl / L   # one launch per layer
+            fl += 2 * (NT * 2 * g * din + (NT - N) * 2 * g * H)   # dW and [dx | dh]
+        return "mfma", fl / L   # one launch per layer
     tbl = {
         "gemm_i2g_fwd": 2 * T * N * g * D, "gemm_o2g_fwd": 2 * N * g * H, "gemm_head_fwd": 2 * N * C * H,
         "gemm_o2g_bwd_dh": 2 * N * g * H, "gemm_o2g_bwd_dw": 2 * (T - 1) * N * g * H,
@@ -193,6 +197,7 @@ def main():
         idx, labels = synth.make_paths(pairs, P, T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, num_types=nT, seed=12345 + 97 * i + 7919 * rank)
         batches.append(eng.batch(idx, labels))
     paths_of = [b.n_paths for b in batches]
+    exec_of = [b.executed_steps for b in batches]
 
     dpx = None
     if world > 1 or a.force_dp:
@@ -268,7 +273,7 @@ def main():
         known = True
         for i in range(a.steps):
             N = paths_of[(a.warmup + i) % len(batches)]
-            fw = family_work(name, N, T, D, H, L, C, F, nT, dt_, de_, dr_, G)
+            fw = family_work(name, N, T, D, H, L, C, F, nT, dt_, de_, dr_, G, exec_of[(a.warmup + i) % len(batches)])
             if fw is None:
                 known = False
                 break
@@ -301,7 +306,8 @@ def main():
     if rank == 0:
         value = npaths_total / elapsed
         fwd_flops = sum(T * 2 * G * H * ((D if l == 0 else H) + H) for l in range(L)) + 2 * H * C
-        step_flops = (0 if a.score_only else 3 * fwd_flops) + (0 if a.train_only else fwd_flops)
+        step_flops = (0 if a.score_only else 3 * fwd_flops) + (0 if a.train_only else fwd_flops)  # nominal: every path, every step
+        exec_frac = sum(exec_of) / float(sum(p * T for p in paths_of))
         out = {
             "metric": "paths/sec (train+score) at path_len=6 d=64", "value": round(value, 1), "unit": "paths/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
@@ -313,6 +319,7 @@ def main():
                        "paths_per_step_per_gpu": a.paths_per_step, "paths_per_pair_buckets": Ps, "impl": a.impl,
                        "entity_update": "lazy-exact" if a.entity_update == 0 else "dense",
                        "parallelism": f"dp{world}" if world > 1 else "single"},
+            "executed_step_fraction": round(exec_frac, 4),  # (path, step) positions executed / nominal: identical leading (pad) steps run once per batch
             "model_tflops": round(value * step_flops / 1e12, 3),
             "mfma_frac_end_to_end": round(value * step_flops / 1e12 / (PEAK_TFLOPS_F32_MFMA * world), 4),
             "final_loss": round(loss, 6),

@@ -129,6 +129,10 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels,
 void kprn_batch_destroy(kprn_handle* h, kprn_batch* b);
 /* number of distinct entity rows the batch references (= the rows one training step on it touches) */
 int kprn_batch_distinct_rows(kprn_handle* h, const kprn_batch* b, int32_t* n);
+/* (path, step) positions a pass over the batch executes: B*P*T, less the leading steps that whole 64-path tiles share with
+ * the batch's reference step (left padding, movie_data_format.py:250-254) and that the fused kernels therefore run once
+ * for the batch instead of once per path -- same results; for work / roofline accounting                                  */
+int kprn_batch_executed_steps(kprn_handle* h, const kprn_batch* b, int64_t* steps);
 
 /* ---- scoring: model:forward(inputs) (test_from_checkpoint.lua:81-82,109) ------------
  * probs[B]      = Sigmoid(reduce_p(mapper))[:, classId]       (Select(2,classId))

@@ -110,6 +110,13 @@ class Batch:
         self.engine._ck(self.engine.L.kprn_batch_distinct_rows(self.engine.h, self.ptr, C.byref(n)))
         return int(n.value)
 
+    @property
+    def executed_steps(self):
+        """(path, step) positions a pass executes: B*P*T less the identical leading steps that are run once per batch"""
+        n = C.c_int64()
+        self.engine._ck(self.engine.L.kprn_batch_executed_steps(self.engine.h, self.ptr, C.byref(n)))
+        return int(n.value)
+
     def free(self):
         if self.ptr:
             self.engine.L.kprn_batch_destroy(self.engine.h, self.ptr)

@@ -14,43 +14,153 @@
 namespace bidx {
 
 namespace {
-__global__ void k_keys(const int32_t* __restrict__ idx, int64_t nsteps, int F, int32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+// Index entries: one per (path, step) position that the fused kernels really execute, plus -- when the batch has an
+// identical-prefix plan -- one VIRTUAL position per prefix step (position Npad*T + t, row 0 of a tile past the last one)
+// where the prefix backward (lstm_fused_prefix.hip) leaves the summed dx of all the skipped occurrences of that step.
+// Skipped positions and unused virtual slots get the sentinel key Ve (sorted last, dropped from the distinct rows).
+__global__ void k_keys(const int32_t* __restrict__ idx, int64_t N, int T, int F, const int32_t* __restrict__ tile_k,
+                       const int32_t* __restrict__ meta, int kcap, int sentinel, int32_t* __restrict__ keys, int32_t* __restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nsteps) return;
-  keys[i] = idx[i * F + F - 2] - 1;
-  vals[i] = (int32_t)i;
+  const int64_t nsteps = N * T;
+  if (i < nsteps) {
+    const int64_t n = i / T;
+    const int t = (int)(i - n * T);
+    const bool skipped = tile_k && t < tile_k[n >> 6];
+    keys[i] = skipped ? sentinel : idx[i * F + F - 2] - 1;
+    vals[i] = (int32_t)i;
+  } else if (i < nsteps + kcap) {
+    const int t = (int)(i - nsteps);
+    const int64_t npad = (N + 63) / 64 * 64;
+    keys[i] = (t < meta[0]) ? meta[8 + F - 2] - 1 : sentinel;
+    vals[i] = (int32_t)(npad * T + t);
+  }
+}
+__global__ void k_drop_sentinel(const int32_t* __restrict__ uniq, const int32_t* __restrict__ runs, int sentinel, int32_t* __restrict__ count_out) {
+  const int n = *runs;
+  *count_out = (n > 0 && uniq[n - 1] == sentinel) ? n - 1 : n;
 }
 int bits_for(int64_t v) { int b = 1; while (((int64_t)1 << b) < v) ++b; return b; }
+
+// ---- identical-prefix plan ---------------------------------------------------------------------------------
+// A path set padded on the left (movie_data_format.py:250-254) feeds every padded path the SAME id tuple for its first
+// steps, so the recurrent state after k such steps is one vector per layer, not one per path.  The reference tuple is
+// taken from the data, not from a vocabulary convention: step 0 of the first path whose steps 0 and 1 carry the same
+// ids (a real path never repeats a (type, entity, relation) tuple back to back).  k_n = leading steps of path n equal
+// to that tuple, capped so that at least two real steps remain.
+__global__ void k_find_ref(const int32_t* __restrict__ idx, int64_t N, int T, int F, int c0, int32_t* __restrict__ meta) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int32_t* r = idx + n * T * F;
+  bool same = true;
+  for (int c = c0; c < F; ++c) same &= (r[c] == r[F + c]);
+  if (same) atomicMin(meta + 1, (int32_t)n);
+}
+__global__ void k_prefix_len(const int32_t* __restrict__ idx, int64_t N, int T, int F, int c0, int kcap, int32_t* __restrict__ meta,
+                             int32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int ref = meta[1];
+  int k = 0;
+  if (ref != 0x7fffffff) {
+    const int32_t* q = idx + (int64_t)ref * T * F;
+    const int32_t* r = idx + n * T * F;
+    const int kmax = (T - 2 < kcap) ? T - 2 : kcap;
+    while (k < kmax) {
+      bool same = true;
+      for (int c = c0; c < F; ++c) same &= (r[k * F + c] == q[c]);
+      if (!same) break;
+      ++k;
+    }
+    if (n == 0) for (int c = 0; c < F; ++c) meta[8 + c] = q[c];
+  }
+  keys[n] = k;
+  vals[n] = (int32_t)n;
+}
+__global__ void k_prefix_apply(const int32_t* __restrict__ idx, int64_t N, int T, int F, const int32_t* __restrict__ ksorted,
+                               const int32_t* __restrict__ perm, int32_t* __restrict__ idx_s, int32_t* __restrict__ slot_of, int32_t* __restrict__ tile_k,
+                               int32_t* __restrict__ meta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = (int64_t)T * F;
+  if (i < N * row) {
+    const int64_t n = i / row;
+    idx_s[i] = idx[(int64_t)perm[n] * row + (i - n * row)];
+  }
+  if (i < N) slot_of[perm[i]] = (int32_t)i;
+  if (i < (N + 63) / 64) tile_k[i] = ksorted[i * 64];  // ascending order: the tile's first path has its shortest prefix
+  if (i == 0) meta[0] = ksorted[N - 1];
+}
 }  // namespace
 
-// scratch layout inside `scratch` (bytes): keys | vals | counts | rocPRIM temp
-size_t scratch_bytes(int64_t nsteps, int Ve) {
-  size_t t1 = 0, t2 = 0;
+size_t prefix_scratch_bytes(int64_t N, int kcap) {
+  size_t t1 = 0;
   int32_t* p = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, t1, p, p, p, p, (size_t)nsteps, 0, bits_for(Ve), (hipStream_t)0);
-  (void)rocprim::run_length_encode(nullptr, t2, p, (size_t)nsteps, p, p, p, (hipStream_t)0);
-  const size_t tmp = (t1 > t2 ? t1 : t2);
-  return (size_t)nsteps * 3 * sizeof(int32_t) + ((tmp + 255) & ~(size_t)255) + 1024;
+  (void)rocprim::radix_sort_pairs(nullptr, t1, p, p, p, p, (size_t)N, 0, bits_for(kcap + 1), (hipStream_t)0);
+  return (size_t)N * 3 * sizeof(int32_t) + ((t1 + 255) & ~(size_t)255) + 1024;
 }
 
-void build(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int Ve, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq,
-           int32_t* n_uniq_dev, void* scratch, size_t scratch_sz) {
-  if (nsteps <= 0) return;
+// paths reordered by prefix length (stable, ascending: the longest tiles first), per-tile shared prefix length, the
+// reference tuple.  meta: [0] longest prefix in the batch, [1] reference path (INT_MAX: none), [8..8+F) its step-0 ids.
+void prefix_plan(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, int kcap, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
+                 int32_t* meta, void* scratch, size_t scratch_sz) {
   int32_t* keys = (int32_t*)scratch;
-  int32_t* vals = keys + nsteps;
-  int32_t* counts = vals + nsteps;
-  char* tmp = (char*)(counts + nsteps);
+  int32_t* vals = keys + N;
+  int32_t* ksorted = vals + N;
+  char* tmp = (char*)(ksorted + N);
   tmp = (char*)(((uintptr_t)tmp + 255) & ~(uintptr_t)255);
-  size_t tmp_bytes = scratch_sz - (size_t)(tmp - (char*)scratch);
-  hipLaunchKernelGGL(k_keys, dim3((unsigned)((nsteps + 255) / 256)), dim3(256), 0, s, idx, nsteps, F, keys, vals);
+  const size_t tmp_bytes = scratch_sz - (size_t)(tmp - (char*)scratch);
+  const int c0 = F - nT - 2;
+  const int32_t init[2] = {0, 0x7fffffff};
+  HIP_TRY(hipMemsetAsync(meta, 0, (size_t)(8 + F) * sizeof(int32_t), s));
+  HIP_TRY(hipMemcpyAsync(meta, init, sizeof(init), hipMemcpyHostToDevice, s));
+  const dim3 gn((unsigned)((N + 255) / 256));
+  hipLaunchKernelGGL(k_find_ref, gn, dim3(256), 0, s, idx, N, T, F, c0, meta);
+  hipLaunchKernelGGL(k_prefix_len, gn, dim3(256), 0, s, idx, N, T, F, c0, kcap, meta, keys, vals);
   HIP_TRY(hipGetLastError());
   size_t need = 0;
-  HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, key_sorted, vals, pos_sorted, (size_t)nsteps, 0, bits_for(Ve), s));
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, ksorted, vals, perm, (size_t)N, 0, bits_for(kcap + 1), s));
+  KPRN_REQUIRE(need <= tmp_bytes, KPRN_E_DEVICE, "prefix plan scratch too small");
+  HIP_TRY(rocprim::radix_sort_pairs(tmp, need, keys, ksorted, vals, perm, (size_t)N, 0, bits_for(kcap + 1), s));
+  const int64_t work = N * T * F;
+  hipLaunchKernelGGL(k_prefix_apply, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, idx, N, T, F, ksorted, perm, idx_s, slot_of, tile_k, meta);
+  HIP_TRY(hipGetLastError());
+}
+
+// scratch layout inside `scratch` (bytes): keys | vals | counts | rocPRIM temp;  n_index = N*T (+ kcap virtual entries)
+size_t scratch_bytes(int64_t n_index, int Ve) {
+  size_t t1 = 0, t2 = 0;
+  int32_t* p = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, t1, p, p, p, p, (size_t)n_index, 0, bits_for((int64_t)Ve + 1), (hipStream_t)0);
+  (void)rocprim::run_length_encode(nullptr, t2, p, (size_t)n_index, p, p, p, (hipStream_t)0);
+  const size_t tmp = (t1 > t2 ? t1 : t2);
+  return (size_t)n_index * 3 * sizeof(int32_t) + ((tmp + 255) & ~(size_t)255) + 1024 + 256;
+}
+
+// tile_k / meta / kcap: the batch's identical-prefix plan (null / null / 0: every position is indexed)
+void build(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int Ve, const int32_t* tile_k, const int32_t* meta, int kcap,
+           int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq, int32_t* n_uniq_dev, void* scratch, size_t scratch_sz) {
+  const int64_t n_index = N * T + (tile_k ? kcap : 0);
+  if (n_index <= 0) return;
+  int32_t* keys = (int32_t*)scratch;
+  int32_t* vals = keys + n_index;
+  int32_t* counts = vals + n_index;
+  char* tmp = (char*)(counts + n_index);
+  tmp = (char*)(((uintptr_t)tmp + 255) & ~(uintptr_t)255);
+  int32_t* runs = (int32_t*)tmp;  // first 256 bytes of the temp area: the run count
+  tmp += 256;
+  size_t tmp_bytes = scratch_sz - (size_t)(tmp - (char*)scratch);
+  const int sentinel = Ve;
+  const int bits = bits_for((int64_t)Ve + 1);
+  hipLaunchKernelGGL(k_keys, dim3((unsigned)((n_index + 255) / 256)), dim3(256), 0, s, idx, N, T, F, tile_k, meta, tile_k ? kcap : 0, sentinel, keys, vals);
+  HIP_TRY(hipGetLastError());
+  size_t need = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, key_sorted, vals, pos_sorted, (size_t)n_index, 0, bits, s));
   KPRN_REQUIRE(need <= tmp_bytes, KPRN_E_DEVICE, "batch index scratch too small (sort)");
-  HIP_TRY(rocprim::radix_sort_pairs(tmp, need, keys, key_sorted, vals, pos_sorted, (size_t)nsteps, 0, bits_for(Ve), s));
-  HIP_TRY(rocprim::run_length_encode(nullptr, need, key_sorted, (size_t)nsteps, uniq, counts, n_uniq_dev, s));
+  HIP_TRY(rocprim::radix_sort_pairs(tmp, need, keys, key_sorted, vals, pos_sorted, (size_t)n_index, 0, bits, s));
+  HIP_TRY(rocprim::run_length_encode(nullptr, need, key_sorted, (size_t)n_index, uniq, counts, runs, s));
   KPRN_REQUIRE(need <= tmp_bytes, KPRN_E_DEVICE, "batch index scratch too small (rle)");
-  HIP_TRY(rocprim::run_length_encode(tmp, need, key_sorted, (size_t)nsteps, uniq, counts, n_uniq_dev, s));
+  HIP_TRY(rocprim::run_length_encode(tmp, need, key_sorted, (size_t)n_index, uniq, counts, runs, s));
+  hipLaunchKernelGGL(k_drop_sentinel, dim3(1), dim3(1), 0, s, uniq, runs, sentinel, n_uniq_dev);
+  HIP_TRY(hipGetLastError());
 }
 
 }  // namespace bidx
@@ -69,13 +179,14 @@ namespace {
 template <int FRAG>
 __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ DX, const int32_t* __restrict__ key_sorted,
                                                      const int32_t* __restrict__ pos_sorted, int64_t nsteps, int64_t N, int T, int D, int dt, int de,
-                                                     float* __restrict__ gWe) {
+                                                     int sentinel, float* __restrict__ gWe) {
   const int lane = threadIdx.x & 63;
   const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t base = seg * 64;
   if (base >= nsteps) return;
   const int cnt = (int)((nsteps - base < 64) ? (nsteps - base) : 64);
   const int my_key = (lane < cnt) ? key_sorted[base + lane] : -1;
+  if (__builtin_amdgcn_readlane(my_key, 0) == sentinel) return;  // sorted last: nothing but skipped positions from here on
   const int my_pos = (lane < cnt) ? pos_sorted[base + lane] : 0;
   const int key_before = (base > 0) ? key_sorted[base - 1] : -1;
   const int key_after = (base + cnt < nsteps) ? key_sorted[base + cnt] : -1;
@@ -97,7 +208,7 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
       } else {
         off = ((int64_t)t * N + n) * D + col;
       }
-      v[i] = (act && i < cnt) ? DX[off] : 0.f;
+      v[i] = (act && i < cnt && __builtin_amdgcn_readlane(my_key, i) != sentinel) ? DX[off] : 0.f;
     }
     float acc = 0.f;
     bool opened_here = __builtin_amdgcn_readlane(my_key, 0) != key_before;  // the first run starts in this segment
@@ -110,7 +221,7 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
         const int knext = more ? __builtin_amdgcn_readlane(my_key, (i + 1) & 63) : key_after;
         if (!more || knext != k) {  // the run ends, or the segment does
           const bool whole = opened_here && (knext != k);  // every occurrence of row k was in this segment
-          if (act) {
+          if (act && k != sentinel) {
             float* dst = gWe + (int64_t)k * de + ecol;
             if (whole) *dst = acc; else unsafeAtomicAdd(dst, acc);
           }
@@ -123,14 +234,13 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
 }
 }  // namespace
 
-void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* key_sorted, const int32_t* pos_sorted, int64_t N, int T, int D, int dt,
-                 int de, float* gWe) {
-  const int64_t nsteps = N * T;
-  if (nsteps <= 0) return;
-  const int64_t segs = (nsteps + 63) / 64;
+void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* key_sorted, const int32_t* pos_sorted, int64_t n_index, int64_t N,
+                 int T, int D, int dt, int de, int Ve, float* gWe) {
+  if (n_index <= 0) return;
+  const int64_t segs = (n_index + 63) / 64;
   const dim3 grid((unsigned)((segs + 3) / 4));
-  if (frag_order) hipLaunchKernelGGL(k_entity_grad<1>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, nsteps, N, T, D, dt, de, gWe);
-  else hipLaunchKernelGGL(k_entity_grad<0>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, nsteps, N, T, D, dt, de, gWe);
+  if (frag_order) hipLaunchKernelGGL(k_entity_grad<1>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe);
+  else hipLaunchKernelGGL(k_entity_grad<0>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe);
   HIP_TRY(hipGetLastError());
 }
 }  // namespace bidx

@@ -296,8 +296,10 @@ __global__ void k_pool(const float* __restrict__ S, int B, int P, int C, int red
 //   C  nn.Linear(H,46) backward restricted to that column: gW[cid][:] += sum_n dS[n] hT[n][:], gb[cid] += sum_n dS[n]
 //   D  loss = fixed-order sum of the per-pair terms: per-workgroup partials, summed in index order by the last workgroup
 // (was five launches: pool, select, bce, sum, head_bwd).  One workgroup = LOSS_PPW pairs.  hT may be null (generic pipeline: its own head backward).
-__device__ float bce_pair(const float* __restrict__ s, int P, int C, int reducer, int K, int literal, float invB, float t, float* __restrict__ d,
-                          float* lossterm) {
+// d[q] = d loss / d s[q]; slot (nullable): the pair's q-th gradient goes to dS[slot[q]] instead (fused path: tile slot of the path)
+__device__ float bce_pair(const float* __restrict__ s, int P, int C, int reducer, int K, int literal, float invB, float t, float* __restrict__ dpair,
+                          float* __restrict__ dS, const int32_t* __restrict__ slot, float* lossterm) {
+  auto d = [&](int q) -> float& { return slot ? dS[slot[q]] : dpair[q]; };
   const float eps = 1e-12f;
   const float y = reduce_col(s, P, C, reducer, K);
   const float p = sigmoidf_(y);
@@ -314,14 +316,14 @@ __device__ float bce_pair(const float* __restrict__ s, int P, int C, int reducer
     for (int q = 1; q < P; ++q) m = fmaxf(m, s[(int64_t)q * C]);
     float sum = 0.f;
     for (int q = 0; q < P; ++q) sum += expf(s[(int64_t)q * C] - m);
-    for (int q = 0; q < P; ++q) d[q] = expf(s[(int64_t)q * C] - m) / sum * dy;
+    for (int q = 0; q < P; ++q) d(q) = expf(s[(int64_t)q * C] - m) / sum * dy;
   } else if (reducer == 0) {
     int arg = 0;
     for (int q = 1; q < P; ++q) if (s[(int64_t)q * C] > s[(int64_t)arg * C]) arg = q;
-    for (int q = 0; q < P; ++q) d[q] = (q == arg) ? dy : 0.f;
+    for (int q = 0; q < P; ++q) d(q) = (q == arg) ? dy : 0.f;
   } else {
     int kk = K < P ? K : P;
-    for (int q = 0; q < P; ++q) d[q] = 0.f;
+    for (int q = 0; q < P; ++q) d(q) = 0.f;
     float last_v = INFINITY; int last_i = -1;
     for (int r = 0; r < kk; ++r) {
       float best = -INFINITY; int bi = -1;
@@ -330,7 +332,7 @@ __device__ float bce_pair(const float* __restrict__ s, int P, int C, int reducer
         bool after = (v < last_v) || (v == last_v && q > last_i);
         if (after && (bi < 0 || v > best)) { best = v; bi = q; }
       }
-      d[bi] = dy / (float)kk; last_v = best; last_i = bi;
+      d(bi) = dy / (float)kk; last_v = best; last_i = bi;
     }
   }
   return p;
@@ -340,8 +342,8 @@ constexpr int LOSS_PPW = 16;  // pairs per workgroup of the loss stage: small on
 __global__ __launch_bounds__(256) void k_loss_stage(const float* __restrict__ S, const float* __restrict__ labels, const float* __restrict__ hT,
                                                     int B, int P, int C, int H, int cid, int reducer, int K, int literal, float invB,
                                                     float* __restrict__ pooled, float* __restrict__ probs, float* __restrict__ sel,
-                                                    float* __restrict__ dS, float* __restrict__ gW_row, float* __restrict__ gb_c,
-                                                    float* __restrict__ partial) {
+                                                    float* __restrict__ dS, const int32_t* __restrict__ slot_of, float* __restrict__ gW_row,
+                                                    float* __restrict__ gb_c, float* __restrict__ partial) {
   __shared__ float lossw[LOSS_PPW];
   __shared__ float red[4][65];
   const int tid = threadIdx.x;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void k_loss_stage(const float* __restrict__ S,
     float lt = 0.f;
     if (tid < nb) {
       const int b = b0 + tid;
-      bce_pair(S + (int64_t)b * P * C + cid, P, C, reducer, K, literal, invB, labels[b], dS + (int64_t)b * P, &lt);
+      bce_pair(S + (int64_t)b * P * C + cid, P, C, reducer, K, literal, invB, labels[b], dS + (int64_t)b * P, dS, slot_of ? slot_of + (int64_t)b * P : nullptr, &lt);
     }
     lossw[tid] = lt;
   }
@@ -772,10 +774,11 @@ void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reduce
 }
 
 void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
-                int literal, float invB, float* pooled, float* probs, float* sel, float* dS, float* gW_row, float* gb_c, float* partial) {
+                int literal, float invB, float* pooled, float* probs, float* sel, float* dS, const int32_t* slot_of, float* gW_row, float* gb_c,
+                float* partial) {
   if (B <= 0) return;
   hipLaunchKernelGGL(k_loss_stage, dim3((unsigned)((B + LOSS_PPW - 1) / LOSS_PPW)), dim3(256), 0, s, S, labels, hT, B, P, C, H, cid, reducer, K, literal, invB,
-                     pooled, probs, sel, dS, gW_row, gb_c, partial);
+                     pooled, probs, sel, dS, slot_of, gW_row, gb_c, partial);
   CHECK_LAUNCH();
 }
 

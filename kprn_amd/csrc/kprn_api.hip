@@ -549,9 +549,9 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
   }
   {
     ProfScope ps(h, "embed_scatter");
-    const bool have_index = b->key_sorted != nullptr;
+    const bool have_index = b->key_sorted != nullptr && !b->tile_k;  // (an index built for a prefix plan lives in the reordered path space)
     kk::embed_scatter(s, b->idx, N, T, b->F, c.num_types, w.dIn, c.dt, c.de, c.dr, c.Vt, c.Vr, gd + h->off_Wt, h->g_We, gd + h->off_Wr, have_index);
-    if (have_index) bidx::entity_grad(s, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, N, T, D, c.dt, c.de, h->g_We);
+    if (have_index) bidx::entity_grad(s, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, b->n_index, N, T, D, c.dt, c.de, c.Ve, h->g_We);
   }
 }
 
@@ -580,7 +580,7 @@ static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int
     ProfScope ps(h, "loss_stage");
     float* gd = h->g_dense;
     kk::loss_stage(h->stream, h->score_buf, b->labels, /*hT=*/nullptr, b->B, b->P, c.C, c.H, cid, c.reducer, c.K, literal,
-                   invB, w.pooled, w.probs, w.sel, w.dS, gd + h->off_outW + (int64_t)cid * c.H, gd + h->off_outb + cid, h->loss_partial);
+                   invB, w.pooled, w.probs, w.sel, w.dS, fusedp ? b->slot_of : nullptr, gd + h->off_outW + (int64_t)cid * c.H, gd + h->off_outb + cid, h->loss_partial);
     h->loss_pending = kk::loss_partials(b->B);
   }
   view_step_rows(h, b);
@@ -882,13 +882,20 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
     HIP_TRY(hipMemcpyAsync(&flag, h->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     KPRN_REQUIRE(flag == 0, KPRN_E_INDEX, "an index is outside 1..vocabSize (ids are 1-based, int2torch.lua:60-63)");
+    // identical-prefix plan (fused path only): paths reordered by the number of leading steps they share with the batch's
+    // reference step; the fused kernels start each 64-path tile behind its shared steps (lstm_fused_prefix.hip)
+    const int64_t N = (int64_t)B * P;
+    static const char* dbg_env = getenv("KPRN_DBG");
+    const bool want_plan = use_fused(h, b, true) && !(dbg_env && (atoi(dbg_env) & 64));
+    b->kcap = want_plan ? fused::KCAP : 0;
+    b->n_index = nsteps + b->kcap;
     // occurrence index: positions sorted by entity row + the sorted distinct rows (count at the tail of the list)
-    b->uniq_cap = nsteps;
-    b->uniq = dalloc<int32_t>(nsteps + 4);
-    b->key_sorted = dalloc<int32_t>(nsteps);
-    b->pos_sorted = dalloc<int32_t>(nsteps);
+    b->uniq_cap = b->n_index;
+    b->uniq = dalloc<int32_t>(b->n_index + 4);
+    b->key_sorted = dalloc<int32_t>(b->n_index);
+    b->pos_sorted = dalloc<int32_t>(b->n_index);
     {
-      const size_t need = bidx::scratch_bytes(nsteps, h->cfg.Ve);
+      const size_t need = std::max(bidx::scratch_bytes(b->n_index, h->cfg.Ve), bidx::prefix_scratch_bytes(N, fused::KCAP));
       if (need > h->bidx_scratch_bytes) {
         if (h->bidx_scratch) hipFree(h->bidx_scratch);
         h->bidx_scratch = nullptr;
@@ -896,12 +903,29 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
         h->bidx_scratch_bytes = need * 2;
       }
     }
-    bidx::build(h->stream, b->idx, nsteps, F, h->cfg.Ve, b->key_sorted, b->pos_sorted, b->uniq, b->uniq + b->uniq_cap, h->bidx_scratch,
-                h->bidx_scratch_bytes);
+    if (want_plan) {
+      b->idx_s = dalloc<int32_t>(nsteps * F);
+      b->perm = dalloc<int32_t>(N);
+      b->slot_of = dalloc<int32_t>(N);
+      b->tile_k = dalloc<int32_t>((N + 63) / 64 + 1);
+      b->pmeta = dalloc<int32_t>(8 + F);
+      bidx::prefix_plan(h->stream, b->idx, N, T, F, h->cfg.num_types, b->kcap, b->idx_s, b->perm, b->slot_of, b->tile_k, b->pmeta, h->bidx_scratch,
+                        h->bidx_scratch_bytes);
+    }
+    bidx::build(h->stream, want_plan ? b->idx_s : b->idx, N, T, F, h->cfg.Ve, b->tile_k, b->pmeta, b->kcap, b->key_sorted, b->pos_sorted, b->uniq,
+                b->uniq + b->uniq_cap, h->bidx_scratch, h->bidx_scratch_bytes);
     HIP_TRY(hipMemcpyAsync(&b->n_uniq, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    std::vector<int32_t> tk;
+    if (want_plan) {
+      tk.resize((size_t)((N + 63) / 64));
+      HIP_TRY(hipMemcpyAsync(tk.data(), b->tile_k, tk.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    b->exec_steps = nsteps;
+    for (size_t tl = 0; tl < tk.size(); ++tl) b->exec_steps -= (int64_t)tk[tl] * std::min<int64_t>(64, N - (int64_t)tl * 64);
   } catch (...) {
     dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->key_sorted); dfree(b->pos_sorted);
+    dfree(b->idx_s); dfree(b->perm); dfree(b->slot_of); dfree(b->tile_k); dfree(b->pmeta);
     delete b;
     throw;
   }
@@ -919,6 +943,7 @@ void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
     hipStreamSynchronize(h->stream);
   }
   dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->key_sorted); dfree(b->pos_sorted);
+  dfree(b->idx_s); dfree(b->perm); dfree(b->slot_of); dfree(b->tile_k); dfree(b->pmeta);
   delete b;
 }
 
@@ -926,6 +951,13 @@ int kprn_batch_distinct_rows(kprn_handle* h, const kprn_batch* b, int32_t* n) {
   API_BEGIN(h)
   KPRN_REQUIRE(b && n, KPRN_E_ARG, "NULL argument");
   *n = b->n_uniq;
+  API_END(h)
+}
+
+int kprn_batch_executed_steps(kprn_handle* h, const kprn_batch* b, int64_t* steps) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(b && steps, KPRN_E_ARG, "NULL argument");
+  *steps = b->exec_steps;
   API_END(h)
 }
 
@@ -997,8 +1029,7 @@ int kprn_backward_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, i
   backward_impl(h, b, class_id, bce_literal, inv_batch);
   if (loss) {
     form_loss(h);
-    form_loss(h);
-  HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     prof_drain(h);
   }
@@ -1021,8 +1052,7 @@ int kprn_train_step_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id,
   apply_update_impl(h, opt);
   if (loss) {
     form_loss(h);
-    form_loss(h);
-  HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     prof_drain(h);
   }

@@ -61,6 +61,8 @@ struct Workspace {
 
 struct ProfEntry { double total_ms = 0; int64_t launches = 0; };
 
+namespace fused { constexpr int KCAP = 8; }  // longest identical prefix the fused kernels skip (lstm_fused_common.h)
+
 struct kprn_batch {
   int32_t B, P, T, F;
   int32_t* idx = nullptr;     // device [B,P,T,F]
@@ -72,6 +74,16 @@ struct kprn_batch {
   // occurrence index (batch_index.hip): all B*P*T positions sorted by entity row
   int32_t* key_sorted = nullptr;  // device [B*P*T] entity row (0-based)
   int32_t* pos_sorted = nullptr;  // device [B*P*T] position n*T + t
+  int64_t n_index = 0;            // entries of the index (B*P*T, + the virtual prefix positions of a plan)
+  // identical-prefix plan (fused path; batch_index.hip prefix_plan).  With a plan, the index above lives in the
+  // REORDERED path space and skips the positions the fused kernels do not execute.
+  int32_t* idx_s = nullptr;       // device [B*P][T][F] paths reordered by prefix length
+  int32_t* perm = nullptr;        // device [B*P] reordered slot -> original path
+  int32_t* slot_of = nullptr;     // device [B*P] original path -> reordered slot
+  int32_t* tile_k = nullptr;      // device [ceil(B*P/64)] shared prefix length of each 64-path tile
+  int32_t* pmeta = nullptr;       // device [8+F]: longest prefix, reference path, the reference step's ids
+  int kcap = 0;
+  int64_t exec_steps = 0;         // (path, step) positions the kernels execute (B*P*T without a plan)
 };
 
 struct kprn_handle {
@@ -169,7 +181,8 @@ void gru_bwd1(hipStream_t s, const float* a, const float* hp, const float* dH, c
 void gru_bwd2(hipStream_t s, const float* a, const float* hp, float* dA, const float* dHdir, float* dH, int64_t N, int H);
 void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel);
 void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
-                int literal, float invB, float* pooled, float* probs, float* sel, float* dS, float* gW_row, float* gb_c, float* partial);
+                int literal, float invB, float* pooled, float* probs, float* sel, float* dS, const int32_t* slot_of /*nullable: dS[slot_of[n]]*/,
+                float* gW_row, float* gb_c, float* partial);
 void sum_partials(hipStream_t s, const float* partial, int n, float* out);
 int loss_partials(int B);  // number of per-workgroup loss partials the loss stage writes for B pairs
 void zero_pad3(hipStream_t s, float* a, int na, float* b, int nb, float* c, int nc);
@@ -198,13 +211,16 @@ void clear_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* cou
 
 // ---- batch occurrence index (batch_index.hip) -------------------------------------------------
 namespace bidx {
-size_t scratch_bytes(int64_t nsteps, int Ve);
-// uniq: sorted distinct entity rows; *n_uniq_dev: their count
-void build(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int Ve, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq,
-           int32_t* n_uniq_dev, void* scratch, size_t scratch_sz);
+size_t scratch_bytes(int64_t n_index, int Ve);
+// uniq: sorted distinct entity rows; *n_uniq_dev: their count.  tile_k / meta / kcap: identical-prefix plan (null, null, 0: none)
+void build(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int Ve, const int32_t* tile_k, const int32_t* meta, int kcap,
+           int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq, int32_t* n_uniq_dev, void* scratch, size_t scratch_sz);
+size_t prefix_scratch_bytes(int64_t N, int kcap);
+void prefix_plan(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, int kcap, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
+                 int32_t* meta, void* scratch, size_t scratch_sz);
 // entity-table gradient = gather-reduce of dx over the occurrence index (frag_order: fused backward's dx layout, else [T][N][D])
-void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* key_sorted, const int32_t* pos_sorted, int64_t N, int T, int D, int dt,
-                 int de, float* gWe);
+void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* key_sorted, const int32_t* pos_sorted, int64_t n_index, int64_t N,
+                 int T, int D, int dt, int de, int Ve, float* gWe);
 size_t merge_scratch_bytes(int64_t n, int Ve);
 void merge_rows(hipStream_t s, const void* all, int world, int cap, int de, int Ve, float* G, int32_t* union_rows, int32_t* union_count,
                 void* scratch, size_t scratch_sz);

@@ -32,7 +32,7 @@ struct BwdArgs {
   const float* WiT;        // [64][256]  = W_i2g^T of this layer
   const float* WoT;        // [64][256]
   const float* save_frag;  // forward's fragment-order saves: [(N/16)][T][L][4 waves][NPL][64 lanes][4]
-  const float* dS;         // [N] top layer: d loss / d S[n][classId]; the head backward dh_T = dS[n] W_out[classId][:] is formed in-kernel
+  const float* dS;         // [N] (tile slot order) top layer: d loss / d S[n][classId]; the head backward dh_T = dS[n] W_out[classId][:] is formed in-kernel
   const float* wout_row;   // W_out[classId][0..64)
   float* gWout_row; float* gbout_c;  // top layer: gradient of W_out[classId][:] and b_out[classId] (sum_n dS[n] h_T[n][:], sum_n dS[n])
   float* DX;               // [(Npad/16)][T][4 waves][64 lanes][4] fragment order: in = dx of the layer above (not top), out = dx of this layer (not bottom)
@@ -44,6 +44,10 @@ struct BwdArgs {
   int dbg;                 // KPRN_DBG (measurement / cross-checks only): 1 skip the embedding backward, 8 small tables through the
                            // general scatter kernel, 16 entity table through the general scatter kernel (atomics) instead of the index
   int64_t n_tiles;
+  // identical-prefix plan of the batch (all nullable): a tile runs steps T-1 .. tile_k[tile]; what flows into the skipped
+  // steps is summed per prefix class into PG and finished by k_prefix_bwd
+  const int32_t* tile_k;
+  float* PG;               // [KCAP+1][PFB] this layer: sum over rows of dA at the tile's first executed step | of dc handed below it
 };
 
 constexpr int PART = 2 * 256 * 64 + 256;  // floats per workgroup partial slab
@@ -72,6 +76,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   float* dA_t = lds;                                        // [64][LDD]
   float* in_t = dA_t + MT * LDD;                            // bottom: [64][LDA] x_t
   int32_t* ids = (int32_t*)(in_t + (BOTTOM ? MT * LDA : 0));  // bottom: [64][T][4] the tile's ids, 0-based (x_t re-gather)
+  float* pg = (float*)(ids + (BOTTOM ? MT * MAXT_LDS * 4 : 0));  // [KCAP+1][PFB] this workgroup's share of PG
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -115,11 +120,19 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   if (BOTTOM) gsrc = gather_src(a);
   const float wout_c = TOP ? a.wout_row[j * 16 + arow] : 0.f;
   float gwo = 0.f, gbo = 0.f;  // head gradient partials of this lane: column 16j + arow over its rows / sum of dS over its rows
+  for (int c = tid; c < (KCAP + 1) * PFB; c += 256) pg[c] = 0.f;  // (first read: after the barriers of a whole tile)
   TPROBE(0)
 
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * MT;
-    const float* frag_tile = a.save_frag + tile * 4 * frag_mt_stride + lane * 4;
+    const int k0 = a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tile]) : 0;  // steps below k0 belong to the prefix
+    // Everything below counts steps from the tile's first executed one: tt = t - k0 in [0, Te).  The step index enters the
+    // addresses only through these per-tile bases, so the step bodies see the same (compile-time 0 for the last step)
+    // offsets whether or not the tile sits behind a prefix.
+    const int Te = T - k0;
+    const float* frag_tile = a.save_frag + tile * 4 * frag_mt_stride + (int64_t)k0 * L * 4 * frag_unit + lane * 4;
+    float* dx_tile = a.DX + (((tile * 4) * T + k0) * 4 + j) * 256 + lane * 4;  // + (mt * T + tt) * 1024
+    const int32_t* idk = ids + k0 * 4;                                           // [(row * T + tt) * 4 + slot]
     auto frag_ptr = [&](int mt, int t, int l, int w, int plane) -> const float* {
       return frag_tile + mt * frag_mt_stride + ((int64_t)(t * L + l) * 4 + w) * frag_unit + plane * 256;
     };
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       if (TOP) {
         // nn.Linear(H,46) backward restricted to the selected column (OneModel.lua:275, MyOptimizer.lua:126): the recurrent
         // dh starts at dS[n] W_out[cid][:], and gW_out[cid][:] += dS[n] h_T[n][:] straight from the saved h fragment
-        const f32x4 hf = *(const f32x4*)(frag_tile + m * frag_mt_stride + ((int64_t)((T - 1) * L + ly) * 4 + j) * frag_unit + 6 * 256);
+        const f32x4 hf = *(const f32x4*)(frag_tile + m * frag_mt_stride + ((int64_t)((Te - 1) * L + ly) * 4 + j) * frag_unit + 6 * 256);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t n = n0 + m * 16 + ag * 4 + r;
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       ids_stage<256>(a.idx, a.N, T, a.F, a.nT, tile, ids);
       lds_barrier();
       f32x4 nin[4];
-      gather_load<256>(a, gsrc, tile, T - 1, ids, nin);
+      gather_load<256>(a, gsrc, tile, Te - 1, idk, nin, T - 1);
       gather_store<256>(in_t, nin);
       lds_barrier();
     }
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     auto load_P = [&](int mt, int t) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) P[k] = *(const f32x4*)frag_ptr(mt, t, ly, j, k);
-      if (!TOP) up = *(const f32x4*)(a.DX + (((tile * 4 + mt) * T + t) * 4 + j) * 256 + lane * 4);
+      if (!TOP) up = *(const f32x4*)(dx_tile + (mt * T + t) * 1024);
     };
     auto load_B = [&](int nt, int mt, int t, bool has_hp) {
       if (!BOTTOM) bin[nt] = *(const f32x4*)frag_ptr(mt, t, ly - 1, nt, 6);
@@ -171,12 +184,12 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) bin[nt][r] = in_t[(mt * 16 + ag * 4 + r) * LDA + nt * 16 + arow];
     };
-    load_P(0, T - 1);
+    load_P(0, Te - 1);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) load_B(nt, 0, T - 1, T > 1);
+    for (int nt = 0; nt < 4; ++nt) load_B(nt, 0, Te - 1, Te > 1);
 
     // the step body is compiled twice (REC: t > 0, there is an h_{t-1} / c_{t-1}): no MFMA sits under a run-time condition
-    auto step = [&](auto rec_tag, const int t) {
+    auto step = [&](auto rec_tag, const int t) {  // t: step counted from the tile's first executed one
       constexpr bool REC = decltype(rec_tag)::value;
       // ---- C. cell backward + dW, one m-tile at a time ------------------------------------------------
       if (BOTTOM) {
@@ -223,10 +236,19 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         TPROBE(2)  // stage C, dW MFMAs (incl. waiting for the B fragments)
       }
       lds_barrier();
+      if (!REC && k0 > 0) {
+        // first executed step of a tile behind a prefix: the skipped steps see the same forward values on every row, so what
+        // enters them is needed only as a sum over rows (k_prefix_bwd: dh_{k0-1} = W_o2g^T sum dA_{k0}, dW_o2g += sum dA_{k0} (x)
+        // h_prefix).  Column sums of the dA tile, thread = column; kept out of the registers of the hot loop on purpose.
+        float cs0 = 0.f, cs1 = 0.f;
+#pragma unroll 8
+        for (int row = 0; row < MT; row += 2) { cs0 += dA_t[row * LDD + tid]; cs1 += dA_t[(row + 1) * LDD + tid]; }
+        pg[k0 * PFB + tid] += cs0 + cs1;  // one owner thread per entry
+      }
       TPROBE(3)  // mid barrier wait
       // bottom layer: x_{t-1} is requested here (latency hides under stage E) and lands after it
       f32x4 nin[4];
-      if (BOTTOM && REC) gather_load<256>(a, gsrc, tile, t - 1, ids, nin);
+      if (BOTTOM && REC) gather_load<256>(a, gsrc, tile, t - 1, idk, nin, k0 + t - 1);
 
       // ---- E. [dx | dh_prev] = dA * [W_i2g | W_o2g]; this wave: columns 16j..16j+15 of each ----------
       f32x4 ax[4], ah[4];
@@ -279,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         // dx in fragment order: the layer below (or, bottom layer, k_embed_scatter_frag) reloads it the same way,
         // 1 KiB per instruction; in place -- this thread read this very slot as `up` at the start of the step.
         // Rows past N: exact zeros (dA = 0 there).
-        *(f32x4*)(a.DX + (((tile * 4 + mt) * T + t) * 4 + j) * 256 + lane * 4) = ax[mt];
+        *(f32x4*)(dx_tile + (mt * T + t) * 1024) = ax[mt];
       }
       if constexpr (BOTTOM && SMALL) if (wcls != 1) {
         const int which = (wcls == 0) ? 0 : 2;
@@ -289,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
           for (int r = 0; r < 4; ++r) {
             const int row = mt * 16 + ag * 4 + r;
             // branch-free on purpose: no EXEC games in front of an asm MFMA
-            const int iv = ids[(row * T + t) * 4 + which];
+            const int iv = idk[(row * T + t) * 4 + which];
             const float oh = (((int)(iv == arow)) & ((int)(n0 + row < a.N))) ? 1.f : 0.f;
             if (r & 1) KPRN_MFMA_VV(acc_s2, oh, ax[mt][r]); else KPRN_MFMA_VV(acc_s, oh, ax[mt][r]);
           }
@@ -301,8 +323,24 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       lds_barrier();  // dA_t free for reuse, x_{t-1} tile visible
       TPROBE(5)  // end barrier
     };
-    for (int t = T - 1; t > 0; --t) step(std::true_type{}, t);
+    for (int tt = Te - 1; tt > 0; --tt) step(std::true_type{}, tt);
     step(std::false_type{}, 0);
+    if (k0 > 0) {
+      // ... and dc_{k0-1} = sum over rows of the dc this step hands down
+      float cs = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) cs += (dc[m][0] + dc[m][1]) + (dc[m][2] + dc[m][3]);
+      cs += __shfl_xor(cs, 16, 64);
+      cs += __shfl_xor(cs, 32, 64);
+      if (ag == 0) pg[k0 * PFB + 4 * DH + j * 16 + arow] += cs;  // one owner lane per entry
+    }
+  }
+  if (a.tile_k) {
+    lds_barrier();
+    for (int c = PFB + tid; c < (KCAP + 1) * PFB; c += 256) {
+      const float v = pg[c];
+      if (v != 0.f) unsafeAtomicAdd(a.PG + c, v);
+    }
   }
 
   // ---- flush the launch-persistent accumulators: plain coalesced stores into this workgroup's slab;
@@ -369,6 +407,7 @@ struct ScatArgs {
   const float* DX;        // [(Npad/16)][T][4][64][4]
   const int32_t* lead;    // [Npad][T] leader row inside the tile (first row with the same entity id), -1 past N; nullable
   float *gWt, *gWe, *gWr;
+  const int32_t* tile_k;    // identical-prefix plan: steps below tile_k[tile] are not executed (nullable)
   int do_small, do_entity;  // which tables this launch handles
   float* part_small;      // [grid][Vt*dt + Vr*dr] per-workgroup partial small tables; null: tables too big for LDS -> global atomics
   int64_t n_tiles;
@@ -393,6 +432,7 @@ __global__ __launch_bounds__(256) void k_embed_scatter_frag(ScatArgs a) {
     const int64_t tile = item / T;
     const int t = (int)(item - tile * T);
     const int64_t n0 = tile * MT;
+    if (a.tile_k && t < a.tile_k[tile]) continue;  // (uniform) the prefix backward owns these positions
     // (1) this step's dx tile: 16 blocks of 1 KiB, wave w0 takes blocks (mt, w) = (k, w0)
     f32x4 v[4];
 #pragma unroll
@@ -523,6 +563,7 @@ template <bool BOTTOM, bool TOP, bool SMALL>
 static void launch_bwd(kprn_handle* h, const BwdArgs& a, int grid) {
   size_t lds_bytes = (size_t)MT * LDD * sizeof(float);
   if (BOTTOM) lds_bytes += (size_t)MT * LDA * sizeof(float) + (MT * MAXT_LDS * 4) * sizeof(int32_t);
+  lds_bytes += (size_t)(KCAP + 1) * PFB * sizeof(float);
   HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP, SMALL>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());
@@ -564,7 +605,8 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)s->num_cu);
   for (int l = L - 1; l >= 0; --l) {
     BwdArgs a;
-    a.idx = b->idx; a.N = N; a.T = T; a.F = b->F; a.nT = c.num_types;
+    a.idx = b->idx_s ? b->idx_s : b->idx; a.N = N; a.T = T; a.F = b->F; a.nT = c.num_types;
+    a.tile_k = b->tile_k; a.PG = s->PG + (size_t)l * (KCAP + 1) * PFB;
     a.Wt = h->dense + h->off_Wt; a.We = h->We; a.Wr = h->dense + h->off_Wr;
     a.dt = c.dt; a.de = c.de; a.dr = c.dr; a.Vt = c.Vt; a.Vr = c.Vr;
     a.L = L; a.layer = l;
@@ -588,14 +630,15 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       else if (top) launch_bwd<false, true, false>(h, a, grid);
       else launch_bwd<false, false, false>(h, a, grid);
     }
+    if (bottom && b->tile_k) prefix_backward(h, b, n_tiles);  // the skipped steps of every layer; leaves their dx sums in DX's virtual tile
     if (bottom && have_index && !(a.dbg & 1)) {
       ProfScope ps(h, "entity_grad");
-      bidx::entity_grad(strm, s->DX, /*frag_order=*/1, b->key_sorted, b->pos_sorted, N, T, DH, c.dt, c.de, a.gWe);
+      bidx::entity_grad(strm, s->DX, /*frag_order=*/1, b->key_sorted, b->pos_sorted, b->n_index, N, T, DH, c.dt, c.de, c.Ve, a.gWe);
     }
     if (bottom && !(a.dbg & 1) && (!small_in_kernel || !have_index)) {
       ProfScope ps(h, "embed_scatter");
       ScatArgs sa;
-      sa.idx = b->idx; sa.N = N; sa.T = T; sa.F = b->F; sa.nT = c.num_types;
+      sa.idx = b->idx_s ? b->idx_s : b->idx; sa.tile_k = b->tile_k; sa.N = N; sa.T = T; sa.F = b->F; sa.nT = c.num_types;
       sa.dt = c.dt; sa.de = c.de; sa.dr = c.dr; sa.Vt = c.Vt; sa.Vr = c.Vr;
       sa.DX = s->DX; sa.lead = nullptr; sa.gWt = a.gWt; sa.gWe = a.gWe; sa.gWr = a.gWr; sa.n_tiles = n_tiles;
       sa.do_small = small_in_kernel ? 0 : 1; sa.do_entity = have_index ? 0 : 1;
@@ -639,12 +682,17 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   }
 }
 
-void params_changed(kprn_handle* h) { if (h->fused_state) ((State*)h->fused_state)->wt_dirty = true; }
+void params_changed(kprn_handle* h) {
+  if (!h->fused_state) return;
+  State* s = (State*)h->fused_state;
+  s->wt_dirty = true;
+  s->pf_batch = -1;  // the prefix table is a function of the parameters
+}
 
 void release(kprn_handle* h) {
   State* s = (State*)h->fused_state;
   if (!s) return;
-  for (float* p : {s->save_frag, s->WT, s->DX, s->part, s->part_small}) if (p) hipFree(p);
+  for (float* p : {s->save_frag, s->WT, s->DX, s->part, s->part_small, s->pfb, s->pfs, s->pfx, s->PG}) if (p) hipFree(p);
   if (s->timing) hipFree(s->timing);
   delete s;
   h->fused_state = nullptr;

@@ -30,6 +30,10 @@ struct FwdArgs {
   const float* bout;
   int C;
   float* S;          // [N][C]
+  const int32_t* perm;    // identical-prefix plan (nullable): tile slot n holds original path perm[n] (S is written in the original order)
+  const int32_t* tile_k;  // [n_tiles] leading steps of the tile that are replaced by the prefix state (nullable: 0)
+  const int32_t* pmeta;   // plan header: [0] longest prefix in the batch (nullable with tile_k)
+  const float* pfb;       // [KCAP+1][L][PFB] per prefix class: W_o2g h_prefix | c_prefix   (class 0: zeros)
   float* save_frag;  // training: [(N/16)][T][L][4 waves][NPL][64 lanes][4]   (nullable)
   int64_t n_tiles;
   unsigned long long* timing;  // optional [grid][8] cycle counters (KPRN_TIMING=1)
@@ -54,6 +58,10 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn
 __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 constexpr int MAXT_LDS = 16;  // steps whose ids are staged in LDS per tile
+
+// Identical-prefix skipping (batch_index.hip prefix_plan, lstm_fused_prefix.hip): a tile whose 64 paths all start with
+// k copies of the batch's reference step starts at step k from the state the prefix kernel computed once.
+constexpr int PFB = 4 * DH + DH; // floats per (class, layer) of the prefix table: recurrent half of the first step [256] | c[64]
 
 // all the tile's ids -> LDS: ids[(row*T + t)*4 + {0: first type, 1: entity, 2: relation}] (0-based).
 // Rows past N repeat row N-1 (their results are never stored).  Removes the dependent id -> row load
@@ -91,7 +99,9 @@ __device__ __forceinline__ GatherSrc gather_src(const Args& a) {
 
 // gather this thread's share of one step's x rows for `tile` into registers (ids from the LDS id tile)
 template <int NTHREADS, class Args>
-__device__ __forceinline__ void gather_load(const Args& a, const GatherSrc& g, int64_t tile, int t, const int32_t* ids, f32x4 (&v)[1024 / NTHREADS]) {
+// t indexes the LDS id tile handed in; tg = the step's index in the batch (differs when `ids` points behind a skipped prefix)
+__device__ __forceinline__ void gather_load(const Args& a, const GatherSrc& g, int64_t tile, int t, const int32_t* ids, f32x4 (&v)[1024 / NTHREADS],
+                                            int tg = -1) {
   constexpr int PER = 1024 / NTHREADS;  // 64 rows x 16 float4 chunks
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
@@ -105,7 +115,7 @@ __device__ __forceinline__ void gather_load(const Args& a, const GatherSrc& g, i
       const int row = (threadIdx.x >> 4) + k * (NTHREADS >> 4);
       int64_t n = tile * MT + row;
       if (n >= a.N) n = a.N - 1;
-      const int32_t* f = a.idx + (n * a.T + t) * a.F;
+      const int32_t* f = a.idx + (n * a.T + (tg >= 0 ? tg : t)) * a.F;
       for (int q = 1; q < a.nT; ++q) v[k] += *(const f32x4*)(g.base + (int64_t)(f[a.F - a.nT - 2 + q] - 1) * g.width);
     }
   }
@@ -161,6 +171,13 @@ struct State {
   float* WT = nullptr;      // [L][2][64][256]
   bool wt_dirty = true;
   float* DX = nullptr;      // [T][N][64]
+  // identical-prefix state (lstm_fused_prefix.hip)
+  float* pfb = nullptr;     // [KCAP+1][L][PFB] W_o2g h_prefix | c_prefix per prefix class
+  float* pfs = nullptr;     // [KCAP][L][NPL][64] backward factors + h of the prefix steps
+  float* pfx = nullptr;     // [64] the reference step's input row
+  float* PG = nullptr;      // [L][KCAP+1][PFB] per class: sum of dA at the first executed step | sum of dc handed to the prefix
+  int64_t pf_batch = -1;    // batch serial the table was computed for (-1: stale)
+
   float* part = nullptr;    // [L][num_cu][PART]
   float* part_small = nullptr;  // [8 num_cu][Vt*dt + Vr*dr] small-table partials of the embedding scatter
   int part_small_n = 0;
@@ -180,6 +197,8 @@ static inline State* st(kprn_handle* h) {
 }
 
 bool fwd_supported(const kprn_handle* h, int T);
+void prefix_forward(kprn_handle* h, const kprn_batch* b);
+void prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles);
 bool bwd_supported(const kprn_handle* h, int T);
 
 }  // namespace fused

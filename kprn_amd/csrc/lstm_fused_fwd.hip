@@ -52,7 +52,7 @@ __device__ __forceinline__ void cell_step(CellRegs& x, const f32x4 (&acc)[4], fl
   if (K == 4) { x.e3 = __builtin_amdgcn_exp2f(x.m3); x.e1 += 1.0f; }
   if (K == 5) { x.i = __builtin_amdgcn_rcpf(x.e0); x.e2 += 1.0f; }
   if (K == 6) { x.g = __builtin_amdgcn_rcpf(x.e1); x.e3 += 1.0f; }
-  if (K == 7) { x.f = __builtin_amdgcn_rcpf(x.e2); x.g = 2.0f * x.g - 1.0f; x.cp = first ? 0.f : cst[R]; }
+  if (K == 7) { x.f = __builtin_amdgcn_rcpf(x.e2); x.g = 2.0f * x.g - 1.0f; x.cp = cst[R]; }
   if (K == 8) { x.o = __builtin_amdgcn_rcpf(x.e3); x.ig = x.i * x.g; }
   if (K == 9) { x.c = x.f * x.cp + x.ig; }
   if (K == 10) { x.t = x.c * N2LOG2E; cst[R] = x.c; }
@@ -159,7 +159,7 @@ __device__ __forceinline__ void head_tile(const FwdArgs& a, const float* hbuf, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t n = tile * MT + mt * 16 + ag * 4 + r;
-          if (n < a.N) a.S[n * a.C + col] = acc[r];
+          if (n < a.N) a.S[(a.perm ? (int64_t)a.perm[n] : n) * a.C + col] = acc[r];
         }
       }
     }
@@ -175,6 +175,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   auto hbuf = [&](int g, int i) -> float* { return lds + (2 + 2 * g + i) * (MT * LDA); };
   // id tiles (double-buffered by tile parity): [64][T][4] ints each
   auto idbuf = [&](int i) -> int32_t* { return (int32_t*)(lds + (2 + 2 * L) * (MT * LDA)) + i * (MT * MAXT_LDS * 4); };
+  // prefix table [KCAP+1][L][PFB]: per class k the recurrent half of a tile's first executed step (W_o2g h_prefix(k)) and c_prefix(k)
+  const float* pft = (const float*)idbuf(2);
 
   const int lane = threadIdx.x & 63;
   const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // hidden tile owned by this wave
@@ -227,15 +229,19 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
       for (int r = 0; r < 4; ++r) c[l][m][r] = 0.f;
 
   const int T = a.T;
-  const int64_t my_tiles = (a.n_tiles > blockIdx.x) ? (a.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-  const int64_t total_slots = my_tiles * T;
-  if (my_tiles == 0) return;
+  if ((int64_t)blockIdx.x >= a.n_tiles) return;
+  auto tile_k0 = [&](int64_t tl) -> int { return a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tl]) : 0; };
 
   f32x4 gv[1024 / NT];
   const GatherSrc gsrc = gather_src(a);
   ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, blockIdx.x, idbuf(0));
+  if (a.tile_k) {  // classes 1 .. longest prefix of the batch (class 0 = no prefix: nothing to look up)
+    const int n_cls = __builtin_amdgcn_readfirstlane(a.pmeta[0]) + 1;
+    for (int c = L * PFB + threadIdx.x; c < n_cls * L * PFB; c += NT) ((float*)pft)[c] = a.pfb[c];
+  }
   lds_barrier();
-  gather_load<NT>(a, gsrc, blockIdx.x, 0, idbuf(0), gv);
+  int k0 = tile_k0(blockIdx.x);  // the tile runs steps k0 .. T-1 (k0 <= T-2)
+  gather_load<NT>(a, gsrc, blockIdx.x, k0, idbuf(0), gv);
   gather_store<NT>(xbuf(0), gv);
 
   // The work of a slot (one step t of one tile) is a chain of units u = (layer l, 16-row m-tile mt).  Unit u:
@@ -258,9 +264,36 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 #pragma unroll
     for (int k = 0; k < NPL; ++k) *(f32x4*)(fb + k * 256) = sv[k];
   };
+  // FIRST: the tile's first executed step.  There is no recurrent half: the tile's common prefix state enters as one
+  // extra k-slot per gate (A = 1 in k-slot 0, B = (W_o2g h_prefix)[col] in k-slot 0: adds that vector to every row) and
+  // through c, set here to c_prefix.  Class 0 (no prefix): nothing to add, c = 0.
   auto slot = [&](auto first_tag, const int64_t tile, const int t, const int par, const bool has_prev, const int64_t p_tile, const int p_t,
-                  const bool p_first) {
+                  const int cls) {
     constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr bool q_first = false, p_first = false;  // (the cell no longer needs to know)
+    float cinit[L];
+    float rec0[L][4];  // k-slot 0 of the B operand: (W_o2g h_prefix)[gate q, col 16j + arow]
+    const float one0 = (ag == 0) ? 1.0f : 0.f;
+    if (FIRST) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        cinit[l] = 0.f;
+        if (cls > 0) {  // (uniform)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float v = pft[(cls * L + l) * PFB + q * DH + j * 16 + arow];
+            rec0[l][q] = (ag == 0) ? v : 0.f;
+          }
+          cinit[l] = pft[(cls * L + l) * PFB + 4 * DH + j * 16 + arow];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (!(l == L - 1 && m == 3)) {  // c[L-1][3] still belongs to the previous slot's last cell
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[l][m][r] = cinit[l];
+          }
+      }
+    }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const float* in_buf = (l == 0) ? xbuf(par) : hbuf(l - 1, par);
@@ -274,7 +307,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
         const int64_t q_tile = cross ? p_tile : tile;
         const int q_t = cross ? p_t : t;
         const int q_par = cross ? (par ^ 1) : par;
-        const bool q_first = cross ? p_first : FIRST;
         float* pout = hbuf(pl, q_par) + pm * 16 * LDA + o_off;
         f32x4(&acc)[4] = accs[mt & 1];
         f32x4(&pacc)[4] = accs[(mt & 1) ^ 1];
@@ -299,13 +331,25 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
             cell_all<SAVE>(pacc, c[pl][pm], q_first, pout, sv);
             save_unit(q_tile, q_t, pl, pm);
           }
+          if (cross) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[L - 1][3][r] = cinit[L - 1];
+          }
           lds_barrier();
           if (cross && has_prev) head_tile(a, hbuf(L - 1, q_par), p_tile, j, lane);
           apre = *(const f32x4*)(in_base);
           half_unit<SAVE, false, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
+          if (cls > 0) {  // (uniform)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) KPRN_MFMA_VV(acc[q], one0, rec0[l][q]);
+          }
         } else {
           half_unit<SAVE, true, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
           save_unit(q_tile, q_t, pl, pm);
+          if (cls > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) KPRN_MFMA_VV(acc[q], one0, rec0[l][q]);
+          }
         }
       }
     }
@@ -313,25 +357,32 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 
   FPROBE(0)  // prologue: weights, first ids, first gather
   int64_t tile = blockIdx.x;
-  int t = 0;
+  int t = k0;
   int tpar = 0;  // parity of the tile's id buffer
   int64_t p_tile = tile;
-  int p_t = 0;
-  for (int64_t s = 0; s < total_slots; ++s) {
-    const int par = (int)(s & 1);
+  int p_t = t;
+  int par = 0;
+  for (int64_t s = 0;; ++s) {
+    par = (int)(s & 1);
     // (1) issue the gather for the NEXT slot (latency hidden under this slot's MFMAs)
     int tn = t + 1;
     int64_t tile_n = tile;
     int tpar_n = tpar;
-    if (tn == T) { tn = 0; tile_n += gridDim.x; tpar_n ^= 1; }
-    const bool have_next = (s + 1) < total_slots;
-    // the next tile's ids are staged while this tile's first step computes (visible after >= 1 barrier)
-    if (t == 0 && tile + gridDim.x < a.n_tiles) ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
+    int k0_n = k0;
+    if (tn == T) {
+      tile_n += gridDim.x;
+      tpar_n ^= 1;
+      k0_n = (tile_n < a.n_tiles) ? tile_k0(tile_n) : 0;
+      tn = k0_n;
+    }
+    const bool have_next = tile_n < a.n_tiles;
+    // the next tile's ids are staged while this tile's first step computes (visible after >= 1 barrier: a tile has >= 2 steps)
+    if (t == k0 && tile + gridDim.x < a.n_tiles) ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
     if (have_next) gather_load<NT>(a, gsrc, tile_n, tn, idbuf(tpar_n), gv);
     FPROBE(1)  // id staging + gather issue
     // (2) the units of this slot
-    if (t == 0) { slot(std::true_type{}, tile, t, par, s > 0, p_tile, p_t, p_t == 0); FPROBE(2) }
-    else { slot(std::false_type{}, tile, t, par, true, p_tile, p_t, p_t == 0); FPROBE(3) }
+    if (t == k0) { slot(std::true_type{}, tile, t, par, s > 0, p_tile, p_t, k0); FPROBE(2) }
+    else { slot(std::false_type{}, tile, t, par, true, p_tile, p_t, 0); FPROBE(3) }
     // (3) land the gathered rows of the next slot (xbuf[par^1] was last read one slot ago); visible to the
     //     other waves after the next slot's first barrier
     // the last unit's accumulators stay pending across the loop back-edge: keep hipcc from touching them (phi
@@ -340,13 +391,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
     if (have_next) gather_store<NT>(xbuf(par ^ 1), gv);
     FPROBE(4)  // landing the gathered rows (waits for the loads -- and, when saving, for the stores in flight)
     p_tile = tile; p_t = t;
-    t = tn; tile = tile_n; tpar = tpar_n;
+    if (!have_next) break;
+    t = tn; tile = tile_n; tpar = tpar_n; k0 = k0_n;
   }
   // drain: the cell of the very last unit, then the last tile's head
   {
-    const int par = (int)((total_slots - 1) & 1);
     KPRN_MFMA_DRAIN();
-    cell_all<SAVE>(accs[1], c[L - 1][3], p_t == 0, hbuf(L - 1, par) + 3 * 16 * LDA + o_off, sv);
+    cell_all<SAVE>(accs[1], c[L - 1][3], false, hbuf(L - 1, par) + 3 * 16 * LDA + o_off, sv);
     save_unit(p_tile, p_t, L - 1, 3);
     lds_barrier();
     head_tile(a, hbuf(L - 1, par), p_tile, j, lane);
@@ -367,7 +418,7 @@ bool fwd_supported(const kprn_handle* h, int T) {
 
 template <int L, bool SAVE>
 static void launch_fwd(kprn_handle* h, const FwdArgs& a, int grid) {
-  const size_t lds_bytes = (size_t)(2 + 2 * L) * MT * LDA * sizeof(float) + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t);
+  const size_t lds_bytes = (size_t)(2 + 2 * L) * MT * LDA * sizeof(float) + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t) + (size_t)(KCAP + 1) * L * PFB * sizeof(float);
   static bool attr_done = false;  // one per template instantiation
   if (!attr_done) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd<L, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -382,7 +433,9 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   State* s = st(h);
   const int64_t N = (int64_t)b->B * b->P;
   FwdArgs a;
-  a.idx = b->idx; a.N = N; a.T = b->T; a.F = b->F; a.nT = c.num_types;
+  prefix_forward(h, b);  // (cached while neither the parameters nor the batch change)
+  a.idx = b->idx_s ? b->idx_s : b->idx; a.N = N; a.T = b->T; a.F = b->F; a.nT = c.num_types;
+  a.perm = b->perm; a.tile_k = b->tile_k; a.pmeta = b->pmeta; a.pfb = s->pfb;
   a.Wt = h->dense + h->off_Wt; a.We = h->We; a.Wr = h->dense + h->off_Wr;
   a.dt = c.dt; a.de = c.de; a.dr = c.dr;
   for (int l = 0; l < 2; ++l) {

@@ -1,0 +1,296 @@
+// Identical-prefix steps of the fused LSTM path (gfx950; forward: lstm_fused_fwd.hip, backward: lstm_fused_bwd.hip).
+//
+// A left-padded path set (movie_data_format.py:250-254) feeds every padded path the same id tuple for its first k steps.
+// nn.Sequencer(nn.FastLSTM) (model/OneModel.lua:268-274) starts every path from h = c = 0, so after k such steps all
+// those paths are in ONE state per layer.  The fused kernels therefore start a tile of such paths at step k
+// (batch_index.hip prefix_plan orders the paths and gives every 64-path tile its k), and the shared steps are run here,
+// once per batch, on a single row:
+//   k_prefix_fwd   h, c after 1..kmax copies of the reference step -> per class k the recurrent half of the first executed
+//                  step (W_o2g h_{k-1}: one vector, added to every row by one extra MFMA k-slot) and c_{k-1}; plus the
+//                  backward factors of the prefix steps (same definition as the training saves, NPL).
+//   k_prefix_bwd   BPTT through the prefix steps on the SUM over paths of what flows into them.  The backward of a
+//                  step is linear in (dh, dc) with coefficients that depend on the forward values only -- identical
+//                  rows, so the sum over rows can be taken first:  the fused backward hands over, per class k,
+//                  sum_rows dA_k and sum_rows dc_{k-1}; this kernel adds the missing rank-1 term of step k
+//                  (dW_o2g += sum dA_k (x) h_{k-1}), walks t = k-1 .. 0, and leaves the summed dx of every prefix step
+//                  where the embedding backward expects it (type / relation rows directly, the entity slice in the
+//                  virtual tile of DX that the batch index points at).
+// Exact up to the order of fp32 additions.  One workgroup each; plain VALU dot products (a few microseconds, 1 row).
+#include "lstm_fused_common.h"
+
+namespace fused {
+
+struct PrefFwdArgs {
+  const int32_t* meta;  // plan: [0] longest prefix, [8..8+F) reference ids (1-based); null: class 0 only
+  int F, nT;
+  const float *Wt, *We, *Wr;
+  int dt, de, dr;
+  const float* Wi[2];
+  const float* bi[2];
+  const float* Wo[2];
+  float* pfb;  // [KCAP+1][L][PFB]
+  float* pfs;  // [KCAP][L][NPL][64]
+  float* pfx;  // [64]
+};
+
+// Register-resident weights: thread r keeps row r of W_i2g and W_o2g of every layer (2 x 64 floats per layer), requested
+// before anything else so that the whole kernel pays one memory round trip; the steps themselves are LDS + VALU only.
+__device__ __forceinline__ float row_dot(const f32x4 (&w)[16], const float* v) {
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    acc0 += w[i][0] * v[4 * i] + w[i][2] * v[4 * i + 2];
+    acc1 += w[i][1] * v[4 * i + 1] + w[i][3] * v[4 * i + 3];
+  }
+  return acc0 + acc1;
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void k_prefix_fwd(PrefFwdArgs a) {
+  __shared__ float x[DH], hcur[2][DH], cst[2][DH], gates[4 * DH];
+  const int r = threadIdx.x;
+  f32x4 wi[L][16], wo[L][16];
+  float bias[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      wi[l][i] = *(const f32x4*)(a.Wi[l] + (int64_t)r * DH + 4 * i);
+      wo[l][i] = *(const f32x4*)(a.Wo[l] + (int64_t)r * DH + 4 * i);
+    }
+    bias[l] = a.bi[l][r];
+  }
+  const int kmax = a.meta ? a.meta[0] : 0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    a.pfb[(0 * L + l) * PFB + r] = 0.f;
+    if (r < DH) a.pfb[(0 * L + l) * PFB + 4 * DH + r] = 0.f;
+  }
+  if (kmax == 0) return;
+  if (r < DH) {
+    const int32_t* ids = a.meta + 8;
+    float v = 0.f;
+    if (r < a.dt) {
+      for (int q = 0; q < a.nT; ++q) v += a.Wt[(int64_t)(ids[a.F - a.nT - 2 + q] - 1) * a.dt + r];  // CAddTable over the type slots
+    } else if (r < a.dt + a.de) {
+      v = a.We[(int64_t)(ids[a.F - 2] - 1) * a.de + (r - a.dt)];
+    } else {
+      v = a.Wr[(int64_t)(ids[a.F - 1] - 1) * a.dr + (r - a.dt - a.de)];
+    }
+    x[r] = v;
+    a.pfx[r] = v;
+    hcur[0][r] = 0.f; hcur[1][r] = 0.f;
+    cst[0][r] = 0.f; cst[1][r] = 0.f;
+  }
+  __syncthreads();
+  float rec[L];  // (W_o2g h_{t-1})[r] per layer
+#pragma unroll
+  for (int l = 0; l < L; ++l) rec[l] = 0.f;
+  for (int t = 0; t < kmax; ++t) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float* in = (l == 0) ? x : hcur[l - 1];
+      gates[r] = (bias[l] + rec[l]) + row_dot(wi[l], in);
+      __syncthreads();
+      if (r < DH) {
+        // gate order of the packed pre-activations: i, g, f, o (FastLSTM; lstm_fused_fwd.hip cell_step)
+        const float gi = fast_sigmoid(gates[r]), gg = fast_tanh(gates[DH + r]), gf = fast_sigmoid(gates[2 * DH + r]), go = fast_sigmoid(gates[3 * DH + r]);
+        const float cp = cst[l][r];
+        const float cn = gf * cp + gi * gg;
+        const float tc = fast_tanh(cn);
+        const float hh = go * tc;
+        float* sv = a.pfs + (int64_t)(t * L + l) * NPL * DH + r;
+        sv[0 * DH] = gi * gg * (1.0f - gi);
+        sv[1 * DH] = gi * (1.0f - gg * gg);
+        sv[2 * DH] = cp * gf * (1.0f - gf);
+        sv[3 * DH] = hh * (1.0f - go);
+        sv[4 * DH] = go * (1.0f - tc * tc);
+        sv[5 * DH] = gf;
+        sv[6 * DH] = hh;
+        cst[l][r] = cn;
+        hcur[l][r] = hh;
+      }
+      __syncthreads();
+      // class t+1 starts behind this step: the recurrent half of its first executed step
+      const float rr = row_dot(wo[l], hcur[l]);
+      rec[l] = rr;
+      a.pfb[((t + 1) * L + l) * PFB + r] = rr;
+      if (r < DH) a.pfb[((t + 1) * L + l) * PFB + 4 * DH + r] = cst[l][r];
+    }
+  }
+}
+
+struct PrefBwdArgs {
+  const int32_t* meta;
+  int F, nT, L, T;
+  int dt, de, dr;
+  const float* Wi[2];
+  const float* Wo[2];
+  const float* pfs;
+  const float* pfx;
+  float* PG;  // [L][KCAP+1][PFB], consumed (left zero)
+  float* gWi[2];
+  float* gWo[2];
+  float* gbi[2];
+  float *gWt, *gWe, *gWr;
+  float* DXv;         // row 0 of the virtual tile of DX (fragment order): [t][4 waves][256]
+  int entity_direct;  // no batch index in use: add the entity slice to gWe here
+};
+
+// Thread (c = tid & 63, part = tid >> 6) owns rows part*64 .. +63, column c of the layer's [256][64] matrices: its slice of
+// W_i2g / W_o2g (for the transposed products) and of dW_i2g / dW_o2g (accumulated over the prefix steps in registers,
+// added to the gradients once per layer with fire-and-forget atomics).
+__device__ __forceinline__ float col_dot(const float (&w)[64], const float* v256, float (*red)[DH]) {
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 64; i += 2) { acc0 += w[i] * v256[part * 64 + i]; acc1 += w[i + 1] * v256[part * 64 + i + 1]; }
+  red[part][c] = acc0 + acc1;
+  __syncthreads();
+  return (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);  // (valid in every thread; used by threads < 64)
+}
+
+__global__ __launch_bounds__(256) void k_prefix_bwd(PrefBwdArgs a) {
+  __shared__ float dAn[4 * DH], dAg[4 * DH], up[KCAP][DH], hb[DH], inb[DH], red[4][DH], red2[4][DH];
+  const int r = threadIdx.x;
+  const int c = r & 63, part = r >> 6;
+  const int L = a.L;
+  const int kmax = a.meta[0];
+  if (kmax == 0) return;
+  const int32_t* ids = a.meta + 8;
+  for (int l = L - 1; l >= 0; --l) {
+    float wi[64], wo[64], gwi[64], gwo[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      wi[i] = a.Wi[l][(int64_t)(part * 64 + i) * DH + c];
+      wo[i] = a.Wo[l][(int64_t)(part * 64 + i) * DH + c];
+      gwi[i] = 0.f; gwo[i] = 0.f;
+    }
+    float dA_next = 0.f;  // (summed) dA of prefix step t+1, element r
+    float dc_next = 0.f;  // (summed) dc handed from prefix step t+1 to t, element r < 64
+    float db = 0.f;
+    for (int t = kmax - 1; t >= 0; --t) {
+      float* pg = a.PG + ((int64_t)l * (KCAP + 1) + (t + 1)) * PFB;
+      // everything that enters step t from step t+1: the prefix's own dA_{t+1} and the paths whose first executed step is t+1
+      dAn[r] = dA_next + pg[r];
+      pg[r] = 0.f;
+      float pgc = 0.f;
+      if (r < DH) {
+        hb[r] = a.pfs[((int64_t)(t * L + l) * NPL + 6) * DH + r];
+        inb[r] = (l == 0) ? a.pfx[r] : a.pfs[((int64_t)(t * L + l - 1) * NPL + 6) * DH + r];
+        pgc = pg[4 * DH + r];
+        pg[4 * DH + r] = 0.f;
+      }
+      __syncthreads();
+      {  // dW_o2g += dA_{t+1} (x) h_t
+        const float hc = hb[c];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) gwo[i] += dAn[part * 64 + i] * hc;
+      }
+      const float dh = col_dot(wo, dAn, red);  // dh_t = W_o2g^T dA_{t+1}
+      if (r < DH) {
+        const float dc = dc_next + pgc;
+        const float dhv = dh + ((l < L - 1) ? up[t][r] : 0.f);
+        const float* P = a.pfs + (int64_t)(t * L + l) * NPL * DH + r;
+        const float dC = dc + dhv * P[4 * DH];
+        dAg[r] = dC * P[0 * DH];
+        dAg[DH + r] = dC * P[1 * DH];
+        dAg[2 * DH + r] = dC * P[2 * DH];
+        dAg[3 * DH + r] = dhv * P[3 * DH];
+        dc_next = dC * P[5 * DH];
+      }
+      __syncthreads();
+      dA_next = dAg[r];
+      db += dA_next;
+      {  // dW_i2g += dA_t (x) in_t
+        const float ic = inb[c];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) gwi[i] += dAg[part * 64 + i] * ic;
+      }
+      const float dx = col_dot(wi, dAg, red2);  // dx_t = W_i2g^T dA_t
+      if (r < DH) {
+        if (l > 0) {
+          up[t][r] = dx;  // (read above by this same thread)
+        } else {
+          // the reference step's rows of the three tables: every skipped occurrence of prefix step t, summed
+          a.DXv[((int64_t)t * 4 + (r >> 4)) * 256 + (r & 15) * 4] = dx;
+          if (r < a.dt) {
+            for (int q = 0; q < a.nT; ++q) unsafeAtomicAdd(a.gWt + (int64_t)(ids[a.F - a.nT - 2 + q] - 1) * a.dt + r, dx);
+          } else if (r < a.dt + a.de) {
+            if (a.entity_direct) unsafeAtomicAdd(a.gWe + (int64_t)(ids[a.F - 2] - 1) * a.de + (r - a.dt), dx);
+          } else {
+            unsafeAtomicAdd(a.gWr + (int64_t)(ids[a.F - 1] - 1) * a.dr + (r - a.dt - a.de), dx);
+          }
+        }
+      }
+      __syncthreads();  // dAn / dAg / hb / inb / red are rewritten by the next step
+    }
+    unsafeAtomicAdd(a.gbi[l] + r, db);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      unsafeAtomicAdd(a.gWi[l] + (int64_t)(part * 64 + i) * DH + c, gwi[i]);
+      unsafeAtomicAdd(a.gWo[l] + (int64_t)(part * 64 + i) * DH + c, gwo[i]);
+    }
+    // classes above kmax never occur; what is left of PG for this layer is zero already
+  }
+}
+
+// ---- host side ----
+static void ensure_prefix_buffers(State* s) {
+  if (s->pfb) return;
+  HIP_TRY(hipMalloc((void**)&s->pfb, (size_t)(KCAP + 1) * 2 * PFB * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&s->pfs, (size_t)KCAP * 2 * NPL * DH * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&s->pfx, (size_t)DH * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&s->PG, (size_t)2 * (KCAP + 1) * PFB * sizeof(float)));
+  HIP_TRY(hipMemset(s->PG, 0, (size_t)2 * (KCAP + 1) * PFB * sizeof(float)));
+  HIP_TRY(hipMemset(s->pfb, 0, (size_t)(KCAP + 1) * 2 * PFB * sizeof(float)));
+}
+
+// prefix table for (current parameters, this batch's reference step); cached until either changes
+void prefix_forward(kprn_handle* h, const kprn_batch* b) {
+  State* s = st(h);
+  ensure_prefix_buffers(s);
+  if (s->pf_batch == b->serial) return;
+  const kprn_config& c = h->cfg;
+  PrefFwdArgs a;
+  a.meta = b->tile_k ? b->pmeta : nullptr;
+  a.F = b->F; a.nT = c.num_types;
+  a.Wt = h->dense + h->off_Wt; a.We = h->We; a.Wr = h->dense + h->off_Wr;
+  a.dt = c.dt; a.de = c.de; a.dr = c.dr;
+  for (int l = 0; l < 2; ++l) {
+    const int ll = l < c.L ? l : 0;
+    a.Wi[l] = h->dense + h->layer[ll].Wi; a.bi[l] = h->dense + h->layer[ll].bi; a.Wo[l] = h->dense + h->layer[ll].Wo;
+  }
+  a.pfb = s->pfb; a.pfs = s->pfs; a.pfx = s->pfx;
+  ProfScope ps(h, "prefix_fwd");
+  if (c.L == 1) hipLaunchKernelGGL(k_prefix_fwd<1>, dim3(1), dim3(256), 0, h->stream, a);
+  else hipLaunchKernelGGL(k_prefix_fwd<2>, dim3(1), dim3(256), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  s->pf_batch = b->serial;
+}
+
+// after the fused backward of every layer: BPTT through the prefix steps on the class sums the layers left in PG
+void prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles) {
+  State* s = st(h);
+  const kprn_config& c = h->cfg;
+  PrefBwdArgs a;
+  a.meta = b->pmeta;
+  a.F = b->F; a.nT = c.num_types; a.L = c.L; a.T = b->T;
+  a.dt = c.dt; a.de = c.de; a.dr = c.dr;
+  float* gd = h->g_dense;
+  for (int l = 0; l < 2; ++l) {
+    const int ll = l < c.L ? l : 0;
+    a.Wi[l] = h->dense + h->layer[ll].Wi; a.Wo[l] = h->dense + h->layer[ll].Wo;
+    a.gWi[l] = gd + h->layer[ll].Wi; a.gWo[l] = gd + h->layer[ll].Wo; a.gbi[l] = gd + h->layer[ll].bi;
+  }
+  a.pfs = s->pfs; a.pfx = s->pfx; a.PG = s->PG;
+  a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
+  a.DXv = s->DX + (size_t)n_tiles * 4 * b->T * 4 * 256;
+  static const char* d = getenv("KPRN_DBG");
+  a.entity_direct = (d && (atoi(d) & 16)) ? 1 : 0;
+  ProfScope ps(h, "prefix_bwd");
+  hipLaunchKernelGGL(k_prefix_bwd, dim3(1), dim3(256), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+}
+
+}  // namespace fused

@@ -550,7 +550,8 @@ def test_fused_kernels_at_the_edges_of_their_step_range(T, L):
 
 def test_embedding_backward_variants_agree(monkeypatch):
     """the three forms of the embedding backward are interchangeable: one-hot MFMA small tables + index gather-reduce
-    (default), general scatter kernel for the small tables (KPRN_DBG=8) and for everything (KPRN_DBG=24, atomics)"""
+    (default), general scatter kernel for the small tables (KPRN_DBG=8) and for everything (KPRN_DBG=24, atomics);
+    with and without the identical-prefix plan (KPRN_DBG=64: every step of every path executed)"""
     import subprocess, sys, json, textwrap
     code = textwrap.dedent("""
         import sys, json, numpy as np
@@ -569,14 +570,14 @@ def test_embedding_backward_variants_agree(monkeypatch):
         print(json.dumps(out))
     """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for dbg in ("0", "8", "24"):
+    for dbg in ("0", "8", "24", "64", "16"):
         env = dict(os.environ, KPRN_DBG=dbg)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
         res[dbg] = {k: np.array(v) for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()}
     for nm in res["0"]:
         ref = res["0"][nm]
-        for dbg in ("8", "24"):
+        for dbg in ("8", "24", "64", "16"):  # 64: no identical-prefix plan; 16: plan + atomic entity scatter
             assert np.max(np.abs(res[dbg][nm] - ref)) < 1e-5 * max(1e-30, np.max(np.abs(ref))), (nm, dbg)
 
 
@@ -599,3 +600,132 @@ def test_shipped_config_sh_shape_rnn_h250():
         gl = eng.train_step(b, opt)
         assert abs(gl - ol) < 2e-4 * max(1, abs(ol)), (s_, gl, ol)
     assert float(np.max(np.abs(eng.get_flat_params() - th))) < 2e-4
+
+
+# ---- identical-prefix plan (batch_index.hip prefix_plan, lstm_fused_prefix.hip) ---------------------------------
+def _plan_executed_steps(idx, nT=1, kcap=8):
+    """numpy restatement of the plan: reference step = step 0 of the first path whose steps 0 and 1 carry the same ids;
+    k_n = leading steps equal to it (<= min(T-2, kcap)); paths sorted by k (stable); a 64-path tile skips its smallest k."""
+    B, P, T, F = idx.shape
+    rows = idx.reshape(B * P, T, F)[:, :, F - nT - 2:]
+    same = np.all(rows[:, 0] == rows[:, 1], axis=1)
+    if not same.any():
+        return B * P * T
+    ref = rows[np.argmax(same), 0]
+    eq = np.all(rows == ref[None, None, :], axis=2)
+    k = np.where(eq.all(axis=1), T, np.argmin(eq, axis=1))
+    k = np.minimum(k, min(T - 2, kcap))
+    ks = np.sort(k, kind="stable")
+    skipped = sum(int(ks[i]) * len(ks[i:i + 64]) for i in range(0, len(ks), 64))
+    return B * P * T - skipped
+
+
+def _pad_left(idx, pads, Vt=6, Ve=300, Vr=9):
+    """overwrite the first pads[n] steps of path n with the pad tuple (synth.make_paths conventions)"""
+    B, P, T, F = idx.shape
+    flat = idx.reshape(B * P, T, F)
+    for n, k in enumerate(pads):
+        flat[n, :k, :] = (Vt - 1, Ve, Vr - 1)
+    return idx
+
+
+@pytest.mark.parametrize("case", ["all_padded", "no_pads", "mixed_ragged", "T3", "deep_T8", "capped_T12", "L1"])
+def test_identical_prefix_plan_matches_oracle(case):
+    """Paths that share leading (pad) steps are started behind them from the state computed once per batch; forward,
+    every gradient (including the pad rows of the three tables, fed by the prefix backward) and one Adam step must match
+    the oracle, which runs every step of every path."""
+    rng = np.random.default_rng(7)
+    L, T, pairs, P = 2, 6, 70, 3
+    if case == "T3":
+        T = 3
+    elif case == "deep_T8":
+        T = 8
+    elif case == "capped_T12":
+        T = 12
+    elif case == "L1":
+        L = 1
+    if case == "mixed_ragged":
+        pairs, P = 67, 3   # 201 paths: ragged last tile, tiles that mix prefix lengths
+    eng, o64, theta = mk(L=L, impl="auto")
+    idx, labels = synth.make_paths(pairs, P, T, Ve=300, seed=90 + T, real_len=T)
+    N = pairs * P
+    if case == "all_padded":
+        pads = rng.integers(1, 3, size=N)
+    elif case == "no_pads":
+        pads = np.zeros(N, dtype=int)
+    elif case == "T3":
+        pads = rng.integers(0, 3, size=N)   # two pads of three steps: one is skipped (two steps always run)
+    elif case == "deep_T8":
+        pads = rng.integers(0, 7, size=N)
+    elif case == "capped_T12":
+        pads = rng.integers(0, 11, size=N)   # up to 10 pad steps: only 8 are skipped, the rest run as ordinary steps
+    else:
+        pads = rng.integers(0, 4, size=N)
+    idx = _pad_left(idx, pads)
+    b = eng.batch(idx, labels)
+    assert b.executed_steps == _plan_executed_steps(idx)
+    if case == "no_pads":
+        assert b.executed_steps == N * T
+    else:
+        assert b.executed_steps < N * T
+    assert b.n_uniq == len(np.unique(idx[..., 1]))
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    ps, _, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5
+    np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=SCORE_RTOL)
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], og[off:off + n]) < GRAD_RTOL, (nm, case)
+    # the pad rows themselves (their gradient comes from the prefix backward alone when every occurrence is skipped)
+    ge = eng.get_grad("entity_emb").astype(np.float64)
+    off, shp = eng.layout()["entity_emb"]
+    oge = og[off:off + int(np.prod(shp))].reshape(shp)
+    assert np.max(np.abs(ge[299] - oge[299])) <= GRAD_RTOL * max(1e-30, np.max(np.abs(oge)))
+    # a few optimiser steps on the same batch (prefix table recomputed after every update)
+    _train_compare(eng, o64, theta, [(idx, labels)], dict(method=1, lr=1e-2), 4, 2e-4)
+
+
+def test_identical_prefix_plan_full_size_equals_no_plan(monkeypatch):
+    """BASELINE size (65 536 paths, T = 6, L = 2): scores and gradients with the plan equal those of the same library
+    with every step executed (KPRN_DBG=64), to fp32 re-association."""
+    import subprocess, sys, json, textwrap
+    code = textwrap.dedent("""
+        import sys, json, numpy as np
+        sys.path.insert(0, %r)
+        from kprn_amd import _ffi, synth
+        eng = _ffi.Engine(6, 200000, 9, 16, 32, 16, 64, 2)
+        idx, labels = synth.make_paths(16384, 4, 6, Ve=200000, seed=3)
+        b = eng.batch(idx, labels)
+        out = eng.forward(b, 1, want=("probs",))
+        loss = eng.backward(b, 1)
+        g = eng.get_flat_grads()
+        lay = eng.layout()
+        res = {"loss": float(loss), "steps": b.executed_steps, "probs": out["probs"][:2000].astype(float).tolist()}
+        for nm in lay:
+            off, shp = lay[nm]
+            v = g[off:off + int(np.prod(shp))].astype(np.float64)
+            res[nm] = [float(np.abs(v).max()), float(v.sum()), float((v * np.cos(np.arange(v.size) * 0.37)).sum()), float(np.abs(v).sum())]
+        print(json.dumps(res))
+    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for dbg in ("0", "64"):
+        env = dict(os.environ, KPRN_DBG=dbg)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[dbg] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["64"]["steps"] == 65536 * 6 and res["0"]["steps"] < 0.8 * 65536 * 6
+    assert abs(res["0"]["loss"] - res["64"]["loss"]) < 1e-6 * max(1.0, abs(res["64"]["loss"]))
+    np.testing.assert_allclose(res["0"]["probs"], res["64"]["probs"], rtol=1e-5)
+    for nm, ref in res["64"].items():
+        if nm in ("loss", "steps", "probs"):
+            continue
+        got = res["0"][nm]
+        scale = max(1e-30, ref[0])
+        assert abs(got[0] - ref[0]) < 1e-4 * scale, nm
+        # plain and cosine-weighted sums of the tensor: fp32 re-association moves them by ~1e-6 of the sum of magnitudes
+        tol = 5e-5 * ref[3] + 1e-12
+        assert abs(got[1] - ref[1]) < tol and abs(got[2] - ref[2]) < tol, (nm, got, ref)
