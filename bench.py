@@ -308,6 +308,15 @@ def main():
         fwd_flops = sum(T * 2 * G * H * ((D if l == 0 else H) + H) for l in range(L)) + 2 * H * C
         step_flops = (0 if a.score_only else 3 * fwd_flops) + (0 if a.train_only else fwd_flops)  # nominal: every path, every step
         exec_frac = sum(exec_of) / float(sum(p * T for p in paths_of))
+        # flops the timed steps really executed (fused-kernel accounting of family_work: skipped identical steps and the
+        # absent recurrent half of a path's first executed step are NOT counted)
+        exec_flops = 0.0
+        for i in range(a.steps):
+            bi = (a.warmup + i) % len(batches)
+            fw = family_work("lstm_fused_fwd", paths_of[bi], T, D, H, L, C, F, nT, dt_, de_, dr_, G, exec_of[bi])[1]
+            bw = family_work("lstm_fused_bwd", paths_of[bi], T, D, H, L, C, F, nT, dt_, de_, dr_, G, exec_of[bi])[1] * L
+            exec_flops += (0 if a.score_only else fw + bw) + (0 if a.train_only else fw)
+        exec_tflops = exec_flops * world / elapsed / 1e12
         out = {
             "metric": "paths/sec (train+score) at path_len=6 d=64", "value": round(value, 1), "unit": "paths/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
@@ -320,8 +329,9 @@ def main():
                        "entity_update": "lazy-exact" if a.entity_update == 0 else "dense",
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "executed_step_fraction": round(exec_frac, 4),  # (path, step) positions executed / nominal: identical leading (pad) steps run once per batch
-            "model_tflops": round(value * step_flops / 1e12, 3),
-            "mfma_frac_end_to_end": round(value * step_flops / 1e12 / (PEAK_TFLOPS_F32_MFMA * world), 4),
+            "model_tflops_nominal": round(value * step_flops / 1e12, 3),   # as if every step of every path were computed
+            "executed_tflops": round(exec_tflops, 3),
+            "mfma_frac_end_to_end": round(exec_tflops / (PEAK_TFLOPS_F32_MFMA * world), 4),  # executed flops / wall clock / fp32 MFMA peak
             "final_loss": round(loss, 6),
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }

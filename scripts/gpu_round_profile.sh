@@ -1,0 +1,26 @@
+#!/bin/bash
+# Everything profiles/<round>/ holds for one state of the code, in one gpurun call:
+#   bench line (default command, with the CPU baseline leg), rocprofv3 kernel stats, PMC passes, train-/score-only lines.
+# usage: scripts/gpu_round_profile.sh <tag>      -> gpurun_out/{bench_<tag>.json, prof_<tag>/, pmc_<tag>/, ...}
+REPO="${GRAFT_REPO_ROOT:-/root/repo}"
+TAG="${1:-x}"
+cd "$REPO"; mkdir -p gpurun_out
+json_line() { grep '^{' "$1" | tail -1 > "$2"; }
+timeout 900 python bench.py > gpurun_out/bench_$TAG.log 2>&1; echo "bench exit: $?"
+json_line gpurun_out/bench_$TAG.log gpurun_out/bench_$TAG.json
+timeout 300 python bench.py --no-cpu-baseline --train-only > gpurun_out/bench_${TAG}_train_only.log 2>&1
+json_line gpurun_out/bench_${TAG}_train_only.log gpurun_out/bench_${TAG}_train_only.json
+timeout 300 python bench.py --no-cpu-baseline --score-only > gpurun_out/bench_${TAG}_score_only.log 2>&1
+json_line gpurun_out/bench_${TAG}_score_only.log gpurun_out/bench_${TAG}_score_only.json
+bash scripts/gpu_profile.sh $TAG > gpurun_out/prof_$TAG.txt 2>&1
+bash scripts/gpu_pmc.sh $TAG > gpurun_out/pmc_$TAG.txt 2>&1
+python - <<PY
+import json
+for f in ("bench_$TAG", "bench_${TAG}_train_only", "bench_${TAG}_score_only"):
+    try:
+        d = json.load(open("gpurun_out/%s.json" % f))
+        print(f, d["value"], d["ms_per_step"], d.get("roofline"), d.get("cpu_baseline"))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+head -12 gpurun_out/prof_$TAG/kernel_stats.csv

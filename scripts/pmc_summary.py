@@ -61,6 +61,7 @@ def main(d):
             o["write_bytes_raw"] = o["WRITE_SIZE_avg"] * 1024.0
         if "SQ_VALU_MFMA_BUSY_CYCLES_avg" in o and o.get("SQ_BUSY_CU_CYCLES_avg"):
             o["mfma_busy_over_cu_busy"] = o["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / o["SQ_BUSY_CU_CYCLES_avg"]
+            o["mfma_busy_frac_per_simd"] = o["mfma_busy_over_cu_busy"] / 4.0  # MFMA-busy is summed over the CU's 4 SIMDs
     for k, o in out.items():
         if "fetch_bytes_corrected" in o or "write_bytes_raw" in o:
             o["hbm_bytes_per_launch"] = o.get("fetch_bytes_corrected", 0.0) + o.get("write_bytes_raw", 0.0)
