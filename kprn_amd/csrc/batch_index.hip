@@ -179,7 +179,13 @@ namespace {
 template <int FRAG>
 __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ DX, const int32_t* __restrict__ key_sorted,
                                                      const int32_t* __restrict__ pos_sorted, int64_t nsteps, int64_t N, int T, int D, int dt, int de,
-                                                     int sentinel, float* __restrict__ gWe) {
+                                                     int sentinel, float* __restrict__ gWe, int n_ent_blocks, SlabReduce red) {
+  if ((int)blockIdx.x >= n_ent_blocks) {  // (workgroup-uniform) the passenger job: weight-gradient slab reduce
+    const int rb = blockIdx.x - n_ent_blocks;
+    const int nbx = (red.n_elem + 255) / 256;
+    slab_reduce_block(red, rb % nbx, (rb / nbx) % red.ny, rb / (nbx * red.ny));
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t base = seg * 64;
@@ -235,12 +241,17 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
 }  // namespace
 
 void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* key_sorted, const int32_t* pos_sorted, int64_t n_index, int64_t N,
-                 int T, int D, int dt, int de, int Ve, float* gWe) {
-  if (n_index <= 0) return;
+                 int T, int D, int dt, int de, int Ve, float* gWe, const SlabReduce* red) {
+  if (n_index <= 0 && !red) return;
   const int64_t segs = (n_index + 63) / 64;
-  const dim3 grid((unsigned)((segs + 3) / 4));
-  if (frag_order) hipLaunchKernelGGL(k_entity_grad<1>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe);
-  else hipLaunchKernelGGL(k_entity_grad<0>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe);
+  const int n_ent = (int)((segs + 3) / 4);
+  SlabReduce r;
+  memset(&r, 0, sizeof(r));
+  int n_red = 0;
+  if (red) { r = *red; n_red = ((r.n_elem + 255) / 256) * r.ny * r.L; }
+  const dim3 grid((unsigned)(n_ent + n_red));
+  if (frag_order) hipLaunchKernelGGL(k_entity_grad<1>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, r);
+  else hipLaunchKernelGGL(k_entity_grad<0>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, r);
   HIP_TRY(hipGetLastError());
 }
 }  // namespace bidx

@@ -886,7 +886,7 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
     // reference step; the fused kernels start each 64-path tile behind its shared steps (lstm_fused_prefix.hip)
     const int64_t N = (int64_t)B * P;
     static const char* dbg_env = getenv("KPRN_DBG");
-    const bool want_plan = use_fused(h, b, true) && !(dbg_env && (atoi(dbg_env) & 64));
+    const bool want_plan = use_fused(h, b, true) && F <= 16 && !(dbg_env && (atoi(dbg_env) & 64));
     b->kcap = want_plan ? fused::KCAP : 0;
     b->n_index = nsteps + b->kcap;
     // occurrence index: positions sorted by entity row + the sorted distinct rows (count at the tail of the list)
@@ -915,12 +915,18 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
     bidx::build(h->stream, want_plan ? b->idx_s : b->idx, N, T, F, h->cfg.Ve, b->tile_k, b->pmeta, b->kcap, b->key_sorted, b->pos_sorted, b->uniq,
                 b->uniq + b->uniq_cap, h->bidx_scratch, h->bidx_scratch_bytes);
     HIP_TRY(hipMemcpyAsync(&b->n_uniq, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    std::vector<int32_t> tk;
+    std::vector<int32_t> tk, hm;
     if (want_plan) {
       tk.resize((size_t)((N + 63) / 64));
+      hm.resize((size_t)(8 + F));
       HIP_TRY(hipMemcpyAsync(tk.data(), b->tile_k, tk.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipMemcpyAsync(hm.data(), b->pmeta, hm.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (want_plan) {
+      b->h_kmax = hm[0];
+      for (int c = 0; c < F && c < 16; ++c) b->h_ref[c] = hm[8 + c];
+    }
     b->exec_steps = nsteps;
     for (size_t tl = 0; tl < tk.size(); ++tl) b->exec_steps -= (int64_t)tk[tl] * std::min<int64_t>(64, N - (int64_t)tl * 64);
   } catch (...) {

@@ -83,6 +83,8 @@ struct kprn_batch {
   int32_t* tile_k = nullptr;      // device [ceil(B*P/64)] shared prefix length of each 64-path tile
   int32_t* pmeta = nullptr;       // device [8+F]: longest prefix, reference path, the reference step's ids
   int kcap = 0;
+  int h_kmax = 0;                 // host copy: longest shared prefix in the batch (0: nothing is skipped)
+  int32_t h_ref[16] = {0};        // host copy: the reference step's ids (1-based, all F <= 16 columns)
   int64_t exec_steps = 0;         // (path, step) positions the kernels execute (B*P*T without a plan)
 };
 
@@ -218,9 +220,41 @@ void build(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int Ve, c
 size_t prefix_scratch_bytes(int64_t N, int kcap);
 void prefix_plan(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, int kcap, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
                  int32_t* meta, void* scratch, size_t scratch_sz);
-// entity-table gradient = gather-reduce of dx over the occurrence index (frag_order: fused backward's dx layout, else [T][N][D])
+// Sum of the fused backward's per-workgroup weight-gradient slabs (lstm_fused_bwd.hip) -- a second, independent job that the
+// entity-gradient launch can carry in extra workgroups (both run right after the backward kernels and neither fills the chip).
+struct SlabReduce {
+  const float* part[2]; float* gWi[2]; float* gWo[2]; float* gbi[2];
+  int nslab, n_elem;   // slabs per layer, floats per slab (2 * G * H + G rows: W_i2g | W_o2g | b)
+  int L, ny;           // layers, slab-range splits
+  const float* r1; int kmax, kcap, r1_stride, G, H;  // rank-1 terms of the identical-prefix steps; kmax = 0: none
+};
+__device__ __forceinline__ void slab_reduce_block(const SlabReduce& a, int bx, int by, int l) {
+  const int i = bx * 256 + threadIdx.x;
+  if (i >= a.n_elem) return;
+  const float* __restrict__ part = a.part[l];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = by * 4; s < a.nslab; s += a.ny * 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (s + u < a.nslab) acc[u] += part[(int64_t)(s + u) * a.n_elem + i];
+  }
+  float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  const int GH = a.G * a.H, nW = GH * a.H;
+  if (by == 0) {
+    for (int t = 0; t < a.kmax; ++t) {
+      const float* r1 = a.r1 + ((int64_t)l * a.kcap + t) * a.r1_stride;  // dA_{t+1}[GH] | dA_t[GH] | h_t[H] | in_t[H]
+      if (i < nW) v += r1[GH + i / a.H] * r1[2 * GH + a.H + i % a.H];               // dW_i2g += dA_t (x) in_t
+      else if (i < 2 * nW) v += r1[(i - nW) / a.H] * r1[2 * GH + (i - nW) % a.H];   // dW_o2g += dA_{t+1} (x) h_t
+      else v += r1[GH + (i - 2 * nW)];                                               // db += dA_t
+    }
+  }
+  if (i < nW) unsafeAtomicAdd(a.gWi[l] + i, v);
+  else if (i < 2 * nW) unsafeAtomicAdd(a.gWo[l] + (i - nW), v);
+  else unsafeAtomicAdd(a.gbi[l] + (i - 2 * nW), v);
+}
+// entity-table gradient = gather-reduce of dx over the occurrence index (frag_order: fused backward's dx layout, else [T][N][D]);
+// red (nullable): slab reduce carried by the same launch
 void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* key_sorted, const int32_t* pos_sorted, int64_t n_index, int64_t N,
-                 int T, int D, int dt, int de, int Ve, float* gWe);
+                 int T, int D, int dt, int de, int Ve, float* gWe, const SlabReduce* red = nullptr);
 size_t merge_scratch_bytes(int64_t n, int Ve);
 void merge_rows(hipStream_t s, const void* all, int world, int cap, int de, int Ve, float* G, int32_t* union_rows, int32_t* union_count,
                 void* scratch, size_t scratch_sz);

@@ -529,23 +529,9 @@ __global__ __launch_bounds__(256) void k_reduce_small(const float* __restrict__ 
   }
 }
 
-// gW_i2g / gW_o2g / gb += sum over workgroup slabs, every layer in one launch (blockIdx.z = layer)
-struct ReduceArgs { const float* part[2]; float* gWi[2]; float* gWo[2]; float* gbi[2]; int nslab; };
-__global__ void k_reduce_partials(ReduceArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= PART) return;
-  const int l = blockIdx.z;
-  const float* __restrict__ part = a.part[l];
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int s = blockIdx.y * 4; s < a.nslab; s += gridDim.y * 4) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (s + u < a.nslab) acc[u] += part[(int64_t)(s + u) * PART + i];
-  }
-  const float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-  if (i < 256 * 64) unsafeAtomicAdd(a.gWi[l] + i, v);
-  else if (i < 2 * 256 * 64) unsafeAtomicAdd(a.gWo[l] + (i - 256 * 64), v);
-  else unsafeAtomicAdd(a.gbi[l] + (i - 2 * 256 * 64), v);
-}
+// gW_i2g / gW_o2g / gb += sum over workgroup slabs, every layer in one launch (blockIdx.z = layer).  Normally this job rides in
+// the entity-gradient launch (bidx::entity_grad, SlabReduce); this kernel is the stand-alone form.
+__global__ void k_reduce_partials(bidx::SlabReduce a) { bidx::slab_reduce_block(a, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // WT[n][k] = W[k][n] for the [256][64] weights of every layer in one launch (blockIdx.y = matrix)
 struct TransArgs { const float* W[4]; float* WT[4]; };
@@ -603,6 +589,8 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   float* gd = h->g_dense;
   const int64_t n_tiles = (N + MT - 1) / MT;
   const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)s->num_cu);
+  bool have_r1 = false, reduced = false;
+  bidx::SlabReduce ra;
   for (int l = L - 1; l >= 0; --l) {
     BwdArgs a;
     a.idx = b->idx_s ? b->idx_s : b->idx; a.N = N; a.T = T; a.F = b->F; a.nT = c.num_types;
@@ -630,10 +618,21 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       else if (top) launch_bwd<false, true, false>(h, a, grid);
       else launch_bwd<false, false, false>(h, a, grid);
     }
-    if (bottom && b->tile_k) prefix_backward(h, b, n_tiles);  // the skipped steps of every layer; leaves their dx sums in DX's virtual tile
+    if (bottom) have_r1 = prefix_backward(h, b, n_tiles);  // the skipped steps of every layer; leaves their dx sums in DX's virtual tile
+    if (bottom) {
+      for (int q = 0; q < 2; ++q) {
+        const int ll = q < L ? q : 0;
+        ra.part[q] = s->part + (size_t)ll * s->num_cu * PART;
+        ra.gWi[q] = gd + h->layer[ll].Wi; ra.gWo[q] = gd + h->layer[ll].Wo; ra.gbi[q] = gd + h->layer[ll].bi;
+      }
+      ra.nslab = grid; ra.n_elem = PART; ra.L = L; ra.ny = 16;
+      ra.r1 = s->r1; ra.kmax = have_r1 ? b->h_kmax : 0; ra.kcap = KCAP; ra.r1_stride = R1; ra.G = 4; ra.H = DH;
+    }
     if (bottom && have_index && !(a.dbg & 1)) {
-      ProfScope ps(h, "entity_grad");
-      bidx::entity_grad(strm, s->DX, /*frag_order=*/1, b->key_sorted, b->pos_sorted, b->n_index, N, T, DH, c.dt, c.de, c.Ve, a.gWe);
+      // the weight-gradient slab reduce rides along: two independent, latency-bound jobs in one launch
+      ProfScope ps(h, "entity_grad+dw_reduce");
+      bidx::entity_grad(strm, s->DX, /*frag_order=*/1, b->key_sorted, b->pos_sorted, b->n_index, N, T, DH, c.dt, c.de, c.Ve, a.gWe, &ra);
+      reduced = true;
     }
     if (bottom && !(a.dbg & 1) && (!small_in_kernel || !have_index)) {
       ProfScope ps(h, "embed_scatter");
@@ -668,16 +667,9 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
               l, (long long)N, grid, sum[0] / grid, sum[1] / grid, sum[7] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid);
     }
   }
-  {
+  if (!reduced) {
     ProfScope ps(h, "dw_reduce");
-    ReduceArgs ra;
-    for (int l = 0; l < 2; ++l) {
-      const int ll = l < L ? l : 0;
-      ra.part[l] = s->part + (size_t)ll * s->num_cu * PART;
-      ra.gWi[l] = gd + h->layer[ll].Wi; ra.gWo[l] = gd + h->layer[ll].Wo; ra.gbi[l] = gd + h->layer[ll].bi;
-    }
-    ra.nslab = grid;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((PART + 255) / 256, 16, L), dim3(256), 0, strm, ra);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((PART + 255) / 256, ra.ny, L), dim3(256), 0, strm, ra);
     HIP_TRY(hipGetLastError());
   }
 }
@@ -692,7 +684,7 @@ void params_changed(kprn_handle* h) {
 void release(kprn_handle* h) {
   State* s = (State*)h->fused_state;
   if (!s) return;
-  for (float* p : {s->save_frag, s->WT, s->DX, s->part, s->part_small, s->pfb, s->pfs, s->pfx, s->PG}) if (p) hipFree(p);
+  for (float* p : {s->save_frag, s->WT, s->DX, s->part, s->part_small, s->pfb, s->pfs, s->pfx, s->PG, s->r1}) if (p) hipFree(p);
   if (s->timing) hipFree(s->timing);
   delete s;
   h->fused_state = nullptr;

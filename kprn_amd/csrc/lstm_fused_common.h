@@ -61,6 +61,7 @@ constexpr int MAXT_LDS = 16;  // steps whose ids are staged in LDS per tile
 
 // Identical-prefix skipping (batch_index.hip prefix_plan, lstm_fused_prefix.hip): a tile whose 64 paths all start with
 // k copies of the batch's reference step starts at step k from the state the prefix kernel computed once.
+constexpr int R1 = 2 * 4 * DH + 2 * DH;  // floats per (layer, prefix step) of the rank-1 term buffer
 constexpr int PFB = 4 * DH + DH; // floats per (class, layer) of the prefix table: recurrent half of the first step [256] | c[64]
 
 // all the tile's ids -> LDS: ids[(row*T + t)*4 + {0: first type, 1: entity, 2: relation}] (0-based).
@@ -176,6 +177,7 @@ struct State {
   float* pfs = nullptr;     // [KCAP][L][NPL][64] backward factors + h of the prefix steps
   float* pfx = nullptr;     // [64] the reference step's input row
   float* PG = nullptr;      // [L][KCAP+1][PFB] per class: sum of dA at the first executed step | sum of dc handed to the prefix
+  float* r1 = nullptr;      // [L][KCAP][R1] rank-1 weight-gradient terms of the prefix steps: dA_{t+1}[256] | dA_t[256] | h_t[64] | in_t[64]
   int64_t pf_batch = -1;    // batch serial the table was computed for (-1: stale)
 
   float* part = nullptr;    // [L][num_cu][PART]
@@ -198,7 +200,7 @@ static inline State* st(kprn_handle* h) {
 
 bool fwd_supported(const kprn_handle* h, int T);
 void prefix_forward(kprn_handle* h, const kprn_batch* b);
-void prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles);
+bool prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles);
 bool bwd_supported(const kprn_handle* h, int T);
 
 }  // namespace fused

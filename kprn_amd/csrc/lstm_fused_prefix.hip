@@ -21,7 +21,8 @@
 namespace fused {
 
 struct PrefFwdArgs {
-  const int32_t* meta;  // plan: [0] longest prefix, [8..8+F) reference ids (1-based); null: class 0 only
+  int kmax;        // longest prefix of the batch (host copy of the plan header)
+  int32_t ref[16]; // the reference step's ids (1-based)
   int F, nT;
   const float *Wt, *We, *Wr;
   int dt, de, dr;
@@ -33,8 +34,11 @@ struct PrefFwdArgs {
   float* pfx;  // [64]
 };
 
-// Register-resident weights: thread r keeps row r of W_i2g and W_o2g of every layer (2 x 64 floats per layer), requested
-// before anything else so that the whole kernel pays one memory round trip; the steps themselves are LDS + VALU only.
+// Register-resident weights: thread r keeps row r of W_i2g and W_o2g of every layer (2 x 64 floats per layer).  The rows
+// come in through LDS (coalesced 16-byte global loads, all four matrices requested before anything else; a thread-per-row
+// read from global would touch 64 cache lines per wave instruction), so the whole kernel pays one memory round trip and
+// the steps themselves are LDS + VALU only.
+constexpr int LDW = DH + 4;
 __device__ __forceinline__ float row_dot(const f32x4 (&w)[16], const float* v) {
   float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
@@ -44,31 +48,53 @@ __device__ __forceinline__ float row_dot(const f32x4 (&w)[16], const float* v) {
   }
   return acc0 + acc1;
 }
+__device__ __forceinline__ void rows_request(const float* __restrict__ W, f32x4 (&st)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st[i] = *(const f32x4*)(W + (int64_t)(i * 256 + threadIdx.x) * 4);
+}
+// staged [256][64] matrix -> LDS, 128 rows at a time -> this thread's row
+__device__ __forceinline__ void rows_land(const f32x4 (&st)[16], float* tile, f32x4 (&row)[16]) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();  // previous use of the tile is over
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = (i * 256 + threadIdx.x) * 4;  // element inside this half: row e / 64 (0..127)
+      *(f32x4*)(tile + (e >> 6) * LDW + (e & 63)) = st[half * 8 + i];
+    }
+    __syncthreads();
+    if ((int)(threadIdx.x >> 7) == half) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) row[i] = *(const f32x4*)(tile + (threadIdx.x & 127) * LDW + 4 * i);
+    }
+  }
+}
 
 template <int L>
 __global__ __launch_bounds__(256) void k_prefix_fwd(PrefFwdArgs a) {
   __shared__ float x[DH], hcur[2][DH], cst[2][DH], gates[4 * DH];
+  __shared__ __attribute__((aligned(16))) float wtile[128 * LDW];
   const int r = threadIdx.x;
   f32x4 wi[L][16], wo[L][16];
   float bias[L];
+  {
+    f32x4 sa[16], sb[16];
+    rows_request(a.Wi[0], sa);
+    rows_request(a.Wo[0], sb);
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      wi[l][i] = *(const f32x4*)(a.Wi[l] + (int64_t)r * DH + 4 * i);
-      wo[l][i] = *(const f32x4*)(a.Wo[l] + (int64_t)r * DH + 4 * i);
+    for (int l = 0; l < L; ++l) bias[l] = a.bi[l][r];
+    rows_land(sa, wtile, wi[0]);
+    if (L > 1) rows_request(a.Wi[L - 1], sa);
+    rows_land(sb, wtile, wo[0]);
+    if (L > 1) {
+      rows_request(a.Wo[L - 1], sb);
+      rows_land(sa, wtile, wi[L - 1]);
+      rows_land(sb, wtile, wo[L - 1]);
     }
-    bias[l] = a.bi[l][r];
   }
-  const int kmax = a.meta ? a.meta[0] : 0;
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    a.pfb[(0 * L + l) * PFB + r] = 0.f;
-    if (r < DH) a.pfb[(0 * L + l) * PFB + 4 * DH + r] = 0.f;
-  }
-  if (kmax == 0) return;
+  const int kmax = a.kmax;
   if (r < DH) {
-    const int32_t* ids = a.meta + 8;
+    const int32_t* ids = a.ref;
     float v = 0.f;
     if (r < a.dt) {
       for (int q = 0; q < a.nT; ++q) v += a.Wt[(int64_t)(ids[a.F - a.nT - 2 + q] - 1) * a.dt + r];  // CAddTable over the type slots
@@ -121,7 +147,8 @@ __global__ __launch_bounds__(256) void k_prefix_fwd(PrefFwdArgs a) {
 }
 
 struct PrefBwdArgs {
-  const int32_t* meta;
+  int kmax;
+  int32_t ref[16];
   int F, nT, L, T;
   int dt, de, dr;
   const float* Wi[2];
@@ -129,17 +156,15 @@ struct PrefBwdArgs {
   const float* pfs;
   const float* pfx;
   float* PG;  // [L][KCAP+1][PFB], consumed (left zero)
-  float* gWi[2];
-  float* gWo[2];
-  float* gbi[2];
+  float* r1;  // [L][KCAP][R1]: per prefix step the vectors of its rank-1 weight-gradient terms (added by k_reduce_partials)
   float *gWt, *gWe, *gWr;
   float* DXv;         // row 0 of the virtual tile of DX (fragment order): [t][4 waves][256]
   int entity_direct;  // no batch index in use: add the entity slice to gWe here
 };
 
-// Thread (c = tid & 63, part = tid >> 6) owns rows part*64 .. +63, column c of the layer's [256][64] matrices: its slice of
-// W_i2g / W_o2g (for the transposed products) and of dW_i2g / dW_o2g (accumulated over the prefix steps in registers,
-// added to the gradients once per layer with fire-and-forget atomics).
+// Thread (c = tid & 63, part = tid >> 6) owns rows part*64 .. +63, column c of the layer's [256][64] weights (for the
+// transposed products).  The weight-gradient terms of the prefix steps are rank-1: their vectors go to `r1`, and the slab
+// reduce that follows adds sum_t u_t (x) v_t while it touches every element of the gradient anyway.
 __device__ __forceinline__ float col_dot(const float (&w)[64], const float* v256, float (*red)[DH]) {
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
   float acc0 = 0.f, acc1 = 0.f;
@@ -151,42 +176,37 @@ __device__ __forceinline__ float col_dot(const float (&w)[64], const float* v256
 }
 
 __global__ __launch_bounds__(256) void k_prefix_bwd(PrefBwdArgs a) {
-  __shared__ float dAn[4 * DH], dAg[4 * DH], up[KCAP][DH], hb[DH], inb[DH], red[4][DH], red2[4][DH];
+  __shared__ float dAn[4 * DH], dAg[4 * DH], up[KCAP][DH], red[4][DH], red2[4][DH];
   const int r = threadIdx.x;
   const int c = r & 63, part = r >> 6;
   const int L = a.L;
-  const int kmax = a.meta[0];
-  if (kmax == 0) return;
-  const int32_t* ids = a.meta + 8;
+  const int kmax = a.kmax;
+  const int32_t* ids = a.ref;
   for (int l = L - 1; l >= 0; --l) {
-    float wi[64], wo[64], gwi[64], gwo[64];
+    float wi[64], wo[64];
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
       wi[i] = a.Wi[l][(int64_t)(part * 64 + i) * DH + c];
       wo[i] = a.Wo[l][(int64_t)(part * 64 + i) * DH + c];
-      gwi[i] = 0.f; gwo[i] = 0.f;
     }
     float dA_next = 0.f;  // (summed) dA of prefix step t+1, element r
     float dc_next = 0.f;  // (summed) dc handed from prefix step t+1 to t, element r < 64
-    float db = 0.f;
     for (int t = kmax - 1; t >= 0; --t) {
       float* pg = a.PG + ((int64_t)l * (KCAP + 1) + (t + 1)) * PFB;
+      float* r1 = a.r1 + ((int64_t)l * KCAP + t) * R1;
       // everything that enters step t from step t+1: the prefix's own dA_{t+1} and the paths whose first executed step is t+1
-      dAn[r] = dA_next + pg[r];
+      const float v = dA_next + pg[r];
       pg[r] = 0.f;
+      dAn[r] = v;
+      r1[r] = v;                                                                      // dW_o2g += dA_{t+1} (x) h_t
       float pgc = 0.f;
       if (r < DH) {
-        hb[r] = a.pfs[((int64_t)(t * L + l) * NPL + 6) * DH + r];
-        inb[r] = (l == 0) ? a.pfx[r] : a.pfs[((int64_t)(t * L + l - 1) * NPL + 6) * DH + r];
+        r1[2 * 4 * DH + r] = a.pfs[((int64_t)(t * L + l) * NPL + 6) * DH + r];        // h_t
+        r1[2 * 4 * DH + DH + r] = (l == 0) ? a.pfx[r] : a.pfs[((int64_t)(t * L + l - 1) * NPL + 6) * DH + r];  // in_t
         pgc = pg[4 * DH + r];
         pg[4 * DH + r] = 0.f;
       }
       __syncthreads();
-      {  // dW_o2g += dA_{t+1} (x) h_t
-        const float hc = hb[c];
-#pragma unroll
-        for (int i = 0; i < 64; ++i) gwo[i] += dAn[part * 64 + i] * hc;
-      }
       const float dh = col_dot(wo, dAn, red);  // dh_t = W_o2g^T dA_{t+1}
       if (r < DH) {
         const float dc = dc_next + pgc;
@@ -201,12 +221,7 @@ __global__ __launch_bounds__(256) void k_prefix_bwd(PrefBwdArgs a) {
       }
       __syncthreads();
       dA_next = dAg[r];
-      db += dA_next;
-      {  // dW_i2g += dA_t (x) in_t
-        const float ic = inb[c];
-#pragma unroll
-        for (int i = 0; i < 64; ++i) gwi[i] += dAg[part * 64 + i] * ic;
-      }
+      r1[4 * DH + r] = dA_next;                                                       // dW_i2g += dA_t (x) in_t, db += dA_t
       const float dx = col_dot(wi, dAg, red2);  // dx_t = W_i2g^T dA_t
       if (r < DH) {
         if (l > 0) {
@@ -223,13 +238,7 @@ __global__ __launch_bounds__(256) void k_prefix_bwd(PrefBwdArgs a) {
           }
         }
       }
-      __syncthreads();  // dAn / dAg / hb / inb / red are rewritten by the next step
-    }
-    unsafeAtomicAdd(a.gbi[l] + r, db);
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      unsafeAtomicAdd(a.gWi[l] + (int64_t)(part * 64 + i) * DH + c, gwi[i]);
-      unsafeAtomicAdd(a.gWo[l] + (int64_t)(part * 64 + i) * DH + c, gwo[i]);
+      __syncthreads();  // dAn / dAg / red are rewritten by the next step
     }
     // classes above kmax never occur; what is left of PG for this layer is zero already
   }
@@ -242,6 +251,7 @@ static void ensure_prefix_buffers(State* s) {
   HIP_TRY(hipMalloc((void**)&s->pfs, (size_t)KCAP * 2 * NPL * DH * sizeof(float)));
   HIP_TRY(hipMalloc((void**)&s->pfx, (size_t)DH * sizeof(float)));
   HIP_TRY(hipMalloc((void**)&s->PG, (size_t)2 * (KCAP + 1) * PFB * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&s->r1, (size_t)2 * KCAP * R1 * sizeof(float)));
   HIP_TRY(hipMemset(s->PG, 0, (size_t)2 * (KCAP + 1) * PFB * sizeof(float)));
   HIP_TRY(hipMemset(s->pfb, 0, (size_t)(KCAP + 1) * 2 * PFB * sizeof(float)));
 }
@@ -253,7 +263,9 @@ void prefix_forward(kprn_handle* h, const kprn_batch* b) {
   if (s->pf_batch == b->serial) return;
   const kprn_config& c = h->cfg;
   PrefFwdArgs a;
-  a.meta = b->tile_k ? b->pmeta : nullptr;
+  if (!b->tile_k || b->h_kmax == 0) { s->pf_batch = b->serial; return; }  // class 0 only: zeros since allocation, never rewritten
+  a.kmax = b->h_kmax;
+  for (int q = 0; q < 16; ++q) a.ref[q] = b->h_ref[q];
   a.F = b->F; a.nT = c.num_types;
   a.Wt = h->dense + h->off_Wt; a.We = h->We; a.Wr = h->dense + h->off_Wr;
   a.dt = c.dt; a.de = c.de; a.dr = c.dr;
@@ -269,21 +281,23 @@ void prefix_forward(kprn_handle* h, const kprn_batch* b) {
   s->pf_batch = b->serial;
 }
 
-// after the fused backward of every layer: BPTT through the prefix steps on the class sums the layers left in PG
-void prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles) {
+// after the fused backward of every layer: BPTT through the prefix steps on the class sums the layers left in PG.
+// Returns false when the batch skips nothing (no launch).
+bool prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles) {
   State* s = st(h);
   const kprn_config& c = h->cfg;
+  if (!b->tile_k || b->h_kmax == 0) return false;
   PrefBwdArgs a;
-  a.meta = b->pmeta;
+  a.kmax = b->h_kmax;
+  for (int q = 0; q < 16; ++q) a.ref[q] = b->h_ref[q];
   a.F = b->F; a.nT = c.num_types; a.L = c.L; a.T = b->T;
   a.dt = c.dt; a.de = c.de; a.dr = c.dr;
   float* gd = h->g_dense;
   for (int l = 0; l < 2; ++l) {
     const int ll = l < c.L ? l : 0;
     a.Wi[l] = h->dense + h->layer[ll].Wi; a.Wo[l] = h->dense + h->layer[ll].Wo;
-    a.gWi[l] = gd + h->layer[ll].Wi; a.gWo[l] = gd + h->layer[ll].Wo; a.gbi[l] = gd + h->layer[ll].bi;
   }
-  a.pfs = s->pfs; a.pfx = s->pfx; a.PG = s->PG;
+  a.pfs = s->pfs; a.pfx = s->pfx; a.PG = s->PG; a.r1 = s->r1;
   a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
   a.DXv = s->DX + (size_t)n_tiles * 4 * b->T * 4 * 256;
   static const char* d = getenv("KPRN_DBG");
@@ -291,6 +305,7 @@ void prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles) {
   ProfScope ps(h, "prefix_bwd");
   hipLaunchKernelGGL(k_prefix_bwd, dim3(1), dim3(256), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
+  return true;
 }
 
 }  // namespace fused
