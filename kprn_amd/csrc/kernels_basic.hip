@@ -1,6 +1,7 @@
 // HBM-bound and element-wise kernels of the path-scoring engine (gfx950).
 // Each kernel cites the reference module it stands in for (paths under
 // /root/reference/release/songPathRnn/).
+#include <string.h>
 #include "kprn_internal.h"
 
 namespace {
@@ -289,6 +290,13 @@ __global__ void k_pool(const float* __restrict__ S, int B, int P, int C, int red
   if (sel && c == cid) sel[b] = pr;
 }
 
+// nn.Select(2, classId) first: only the selected class is reduced (what model:forward hands the caller, test_from_checkpoint.lua:82)
+__global__ void k_pool_sel(const float* __restrict__ S, int B, int P, int C, int reducer, int K, int cid, float* __restrict__ sel) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  sel[b] = sigmoidf_(reduce_col(S + (int64_t)b * P * C + cid, P, C, reducer, K));
+}
+
 // ---------------------------------------------------------------------------------------
 // The whole loss stage of a training step in one launch:
 //   A  reducer over the P paths + nn.Sigmoid + nn.Select for every class          (OneModel.lua:284-294, MyOptimizer.lua:126)
@@ -343,14 +351,20 @@ __global__ __launch_bounds__(256) void k_loss_stage(const float* __restrict__ S,
                                                     int B, int P, int C, int H, int cid, int reducer, int K, int literal, float invB,
                                                     float* __restrict__ pooled, float* __restrict__ probs, float* __restrict__ sel,
                                                     float* __restrict__ dS, const int32_t* __restrict__ slot_of, float* __restrict__ gW_row,
-                                                    float* __restrict__ gb_c, float* __restrict__ partial) {
+                                                    float* __restrict__ gb_c, float* __restrict__ partial, int n_loss_blocks, kk::TransposeJob tj) {
+  if ((int)blockIdx.x >= n_loss_blocks) {  // (workgroup-uniform) the passenger job: 256x64 weight transposes
+    const int rb = blockIdx.x - n_loss_blocks;
+    const int m = rb >> 6, i = (rb & 63) * 256 + threadIdx.x;  // over the 64*256 outputs of matrix m
+    tj.WT[m][i] = tj.W[m][(i & 255) * 64 + (i >> 8)];
+    return;
+  }
   __shared__ float lossw[LOSS_PPW];
   __shared__ float red[4][65];
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * LOSS_PPW;
   const int nb = (B - b0 < LOSS_PPW) ? (B - b0) : LOSS_PPW;
-  // A
-  for (int i = tid; i < nb * C; i += 256) {
+  // A (only when the caller wants every class: training needs column classId alone, which B computes)
+  if (pooled) for (int i = tid; i < nb * C; i += 256) {
     const int b = b0 + i / C, c = i % C;
     const float y = reduce_col(S + (int64_t)b * P * C + c, P, C, reducer, K);
     const float pr = sigmoidf_(y);
@@ -363,7 +377,9 @@ __global__ __launch_bounds__(256) void k_loss_stage(const float* __restrict__ S,
     float lt = 0.f;
     if (tid < nb) {
       const int b = b0 + tid;
-      bce_pair(S + (int64_t)b * P * C + cid, P, C, reducer, K, literal, invB, labels[b], dS + (int64_t)b * P, dS, slot_of ? slot_of + (int64_t)b * P : nullptr, &lt);
+      const float pr = bce_pair(S + (int64_t)b * P * C + cid, P, C, reducer, K, literal, invB, labels[b], dS + (int64_t)b * P, dS,
+                                slot_of ? slot_of + (int64_t)b * P : nullptr, &lt);
+      if (!pooled) sel[b] = pr;
     }
     lossw[tid] = lt;
   }
@@ -769,16 +785,21 @@ void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* o
 
 void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_pool, dim3(nblocks((int64_t)B * C)), dim3(TPB), 0, s, S, B, P, C, reducer, K, pooled, probs, cid, sel);
+  if (!pooled) hipLaunchKernelGGL(k_pool_sel, dim3(nblocks((int64_t)B)), dim3(TPB), 0, s, S, B, P, C, reducer, K, cid, sel);
+  else hipLaunchKernelGGL(k_pool, dim3(nblocks((int64_t)B * C)), dim3(TPB), 0, s, S, B, P, C, reducer, K, pooled, probs, cid, sel);
   CHECK_LAUNCH();
 }
 
 void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
                 int literal, float invB, float* pooled, float* probs, float* sel, float* dS, const int32_t* slot_of, float* gW_row, float* gb_c,
-                float* partial) {
+                float* partial, const TransposeJob* tj) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_loss_stage, dim3((unsigned)((B + LOSS_PPW - 1) / LOSS_PPW)), dim3(256), 0, s, S, labels, hT, B, P, C, H, cid, reducer, K, literal, invB,
-                     pooled, probs, sel, dS, slot_of, gW_row, gb_c, partial);
+  TransposeJob t;
+  memset(&t, 0, sizeof(t));
+  if (tj) t = *tj;
+  const int nlb = (B + LOSS_PPW - 1) / LOSS_PPW;
+  hipLaunchKernelGGL(k_loss_stage, dim3((unsigned)(nlb + 64 * t.n)), dim3(256), 0, s, S, labels, hT, B, P, C, H, cid, reducer, K, literal, invB,
+                     pooled, probs, sel, dS, slot_of, gW_row, gb_c, partial, nlb, t);
   CHECK_LAUNCH();
 }
 

@@ -18,6 +18,7 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save);
 bool bwd_supported(const kprn_handle* h, int T);
 void backward(kprn_handle* h, const kprn_batch* b, int cid);
 void params_changed(kprn_handle* h);
+bool transpose_job(kprn_handle* h, kk::TransposeJob* tj);
 void release(kprn_handle* h);
 }  // namespace fused
 
@@ -27,6 +28,8 @@ static thread_local std::string g_create_error;
 // profiling scopes
 ProfScope::ProfScope(kprn_handle* h_, const char* n) : h(h_), name(n) {
   if (!h->prof_on) return;
+  // an event pair costs ~4 us of stream time: a filter keeps the measurement of ONE kernel family from taxing all the others
+  if (!h->prof_filter.empty() && strncmp(n, h->prof_filter.c_str(), h->prof_filter.size()) != 0) return;
   auto get = [&]() {
     hipEvent_t e;
     if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
@@ -348,11 +351,12 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b) {
   }
 }
 
-static void pool_stage(kprn_handle* h, const kprn_batch* b, int cid) {
+// every_class: also pooled / probs of all C classes (what kprn_forward_batch can hand out); else the selected class only
+static void pool_stage(kprn_handle* h, const kprn_batch* b, int cid, bool every_class) {
   const kprn_config& c = h->cfg;
   Workspace& w = h->ws;
   ProfScope ps(h, "pool_sigmoid");
-  kk::pool_sigmoid(h->stream, w.S, b->B, b->P, c.C, c.reducer, c.K, w.pooled, w.probs, cid, w.sel);
+  kk::pool_sigmoid(h->stream, w.S, b->B, b->P, c.C, c.reducer, c.K, every_class ? w.pooled : nullptr, every_class ? w.probs : nullptr, cid, w.sel);
 }
 
 static void check_batch(kprn_handle* h, const kprn_batch* b, int class_id) {
@@ -365,7 +369,7 @@ static bool use_fused(kprn_handle* h, const kprn_batch* b, bool save_for_backwar
   return !save_for_backward || fused::bwd_supported(h, b->T);
 }
 
-static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool save_for_backward, bool do_pool = true) {
+static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool save_for_backward, bool do_pool = true, bool every_class = true) {
   check_batch(h, b, class_id);
   const int64_t N = (int64_t)b->B * b->P;
   catch_up(h, b);
@@ -376,7 +380,7 @@ static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool
     ensure_ws_generic(h, N, b->T);
     forward_generic(h, b);
   }
-  if (do_pool) pool_stage(h, b, class_id - 1);
+  if (do_pool) pool_stage(h, b, class_id - 1, every_class);
   h->last_B = b->B;
 }
 
@@ -579,8 +583,11 @@ static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int
     // top layer's backward kernel, fused path, or by the generic pipeline's own head backward)
     ProfScope ps(h, "loss_stage");
     float* gd = h->g_dense;
+    kk::TransposeJob tj;  // fused path: the backward's W^T copies, stale after an update, are rebuilt by passenger workgroups
+    const bool have_tj = fusedp && fused::transpose_job(h, &tj);
     kk::loss_stage(h->stream, h->score_buf, b->labels, /*hT=*/nullptr, b->B, b->P, c.C, c.H, cid, c.reducer, c.K, literal,
-                   invB, w.pooled, w.probs, w.sel, w.dS, fusedp ? b->slot_of : nullptr, gd + h->off_outW + (int64_t)cid * c.H, gd + h->off_outb + cid, h->loss_partial);
+                   invB, /*pooled=*/nullptr, /*probs=*/nullptr, w.sel, w.dS, fusedp ? b->slot_of : nullptr, gd + h->off_outW + (int64_t)cid * c.H, gd + h->off_outb + cid, h->loss_partial,
+                   have_tj ? &tj : nullptr);
     h->loss_pending = kk::loss_partials(b->B);
   }
   view_step_rows(h, b);
@@ -969,7 +976,7 @@ int kprn_batch_executed_steps(kprn_handle* h, const kprn_batch* b, int64_t* step
 
 int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id) {
   API_BEGIN(h)
-  forward_impl(h, b, class_id, false);
+  forward_impl(h, b, class_id, false, true, /*every_class=*/false);  // kprn_read_probs hands out the selected class
   API_END(h)
 }
 
@@ -1257,6 +1264,8 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     if (strcmp(value, "auto") == 0) h->impl = 0;
     else if (strcmp(value, "generic") == 0) h->impl = 1;
     else throw KprnError{KPRN_E_ARG, "impl must be auto or generic"};
+  } else if (strcmp(key, "profile_filter") == 0) {
+    h->prof_filter = value;  // "" = every kernel family; else only families whose name starts with this
   } else if (strcmp(key, "reserve_cus") == 0) {
     // the fused SCORING forward is a persistent one-workgroup-per-CU kernel that fills the register file of every CU it runs
     // on; leaving a few CUs free lets the copy kernels of a concurrently running collective (RCCL) make progress beside it

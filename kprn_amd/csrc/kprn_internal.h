@@ -149,6 +149,8 @@ struct kprn_handle {
   int32_t last_B = 0;
 
   bool prof_on = false;
+
+  std::string prof_filter;  // profile only the kernel families whose name starts with this ("": all)
   std::map<std::string, ProfEntry> prof;
   struct Pending { std::string name; hipEvent_t a, b; };
   std::vector<Pending> prof_pending;
@@ -182,9 +184,12 @@ void gru_out_fwd(hipStream_t s, float* a, const float* hp, float* h, int64_t N, 
 void gru_bwd1(hipStream_t s, const float* a, const float* hp, const float* dH, const float* dH_up, float* dA, float* dHdir, int64_t N, int H);
 void gru_bwd2(hipStream_t s, const float* a, const float* hp, float* dA, const float* dHdir, float* dH, int64_t N, int H);
 void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel);
+// A second, independent job the loss-stage launch can carry in extra workgroups: WT[m] = W[m]^T for up to four [256][64]
+// matrices (the fused backward's transposed LSTM weights, stale after every update).
+struct TransposeJob { const float* W[4]; float* WT[4]; int n; };
 void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
                 int literal, float invB, float* pooled, float* probs, float* sel, float* dS, const int32_t* slot_of /*nullable: dS[slot_of[n]]*/,
-                float* gW_row, float* gb_c, float* partial);
+                float* gW_row, float* gb_c, float* partial, const TransposeJob* tj = nullptr);
 void sum_partials(hipStream_t s, const float* partial, int n, float* out);
 int loss_partials(int B);  // number of per-workgroup loss partials the loss stage writes for B pairs
 void zero_pad3(hipStream_t s, float* a, int na, float* b, int nb, float* c, int nc);

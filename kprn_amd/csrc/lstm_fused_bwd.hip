@@ -543,6 +543,22 @@ __global__ void k_transpose_256x64(TransArgs a) {
 }
 
 // ---- host side ----
+// the W^T copies the backward kernels read are stale: hand out the job (and consider it done -- the caller launches it)
+bool transpose_job(kprn_handle* h, kk::TransposeJob* tj) {
+  State* s = st(h);
+  if (!s->wt_dirty) return false;
+  const int L = h->cfg.L;
+  if (!s->WT) HIP_TRY(hipMalloc((void**)&s->WT, (size_t)2 * 2 * 64 * 256 * sizeof(float)));
+  tj->n = 2 * L;
+  for (int m = 0; m < 4; ++m) {
+    const int l = (m >> 1) < L ? (m >> 1) : 0;
+    tj->W[m] = h->dense + ((m & 1) ? h->layer[l].Wo : h->layer[l].Wi);
+    tj->WT[m] = s->WT + (size_t)(l * 2 + (m & 1)) * 64 * 256;
+  }
+  s->wt_dirty = false;
+  return true;
+}
+
 bool bwd_supported(const kprn_handle* h, int T) { return fwd_supported(h, T); }
 
 template <bool BOTTOM, bool TOP, bool SMALL>
@@ -570,21 +586,17 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     HIP_TRY(hipMalloc((void**)&s->DX, (size_t)ct * (cn + 2 * MT) * DH * sizeof(float)));
     s->cap_Nb = cn; s->cap_Tb = ct;
   }
-  if (!s->WT) HIP_TRY(hipMalloc((void**)&s->WT, (size_t)2 * 2 * 64 * 256 * sizeof(float)));
   if (!s->part) HIP_TRY(hipMalloc((void**)&s->part, (size_t)2 * s->num_cu * PART * sizeof(float)));  // one slab set per layer
   static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
   if (want_timing && !s->timing) HIP_TRY(hipMalloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
-  if (s->wt_dirty) {
+  if (s->wt_dirty) {  // (normally done already: the transposes ride in the loss-stage launch, transpose_job())
     ProfScope ps(h, "weight_transpose");
+    kk::TransposeJob tj;
+    transpose_job(h, &tj);
     TransArgs ta;
-    for (int l = 0; l < 2; ++l) {
-      const int ll = l < L ? l : 0;
-      ta.W[l * 2 + 0] = h->dense + h->layer[ll].Wi; ta.WT[l * 2 + 0] = s->WT + (size_t)(ll * 2 + 0) * 64 * 256;
-      ta.W[l * 2 + 1] = h->dense + h->layer[ll].Wo; ta.WT[l * 2 + 1] = s->WT + (size_t)(ll * 2 + 1) * 64 * 256;
-    }
-    hipLaunchKernelGGL(k_transpose_256x64, dim3(64, 2 * L), dim3(256), 0, strm, ta);
+    for (int m = 0; m < 4; ++m) { ta.W[m] = tj.W[m < tj.n ? m : 0]; ta.WT[m] = tj.WT[m < tj.n ? m : 0]; }
+    hipLaunchKernelGGL(k_transpose_256x64, dim3(64, tj.n), dim3(256), 0, strm, ta);
     HIP_TRY(hipGetLastError());
-    s->wt_dirty = false;
   }
   float* gd = h->g_dense;
   const int64_t n_tiles = (N + MT - 1) / MT;

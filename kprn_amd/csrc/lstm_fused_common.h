@@ -202,5 +202,6 @@ bool fwd_supported(const kprn_handle* h, int T);
 void prefix_forward(kprn_handle* h, const kprn_batch* b);
 bool prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles);
 bool bwd_supported(const kprn_handle* h, int T);
+bool transpose_job(kprn_handle* h, kk::TransposeJob* tj);
 
 }  // namespace fused
