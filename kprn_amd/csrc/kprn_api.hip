@@ -19,6 +19,7 @@ bool bwd_supported(const kprn_handle* h, int T);
 void backward(kprn_handle* h, const kprn_batch* b, int cid);
 void params_changed(kprn_handle* h);
 bool transpose_job(kprn_handle* h, kk::TransposeJob* tj);
+void prefix_forward(kprn_handle* h, const kprn_batch* b);
 void release(kprn_handle* h);
 }  // namespace fused
 
@@ -47,6 +48,7 @@ ProfScope::~ProfScope() {
 }
 void prof_drain(kprn_handle* h) {
   if (h->prof_pending.empty()) return;
+  if (h->score_stream) hipStreamSynchronize(h->score_stream);
   hipStreamSynchronize(h->stream);
   for (auto& p : h->prof_pending) {
     float ms = 0.f;
@@ -140,8 +142,17 @@ static void step_tab_reserve(kprn_handle* h, int64_t need) {
   h->step_tab = nd; h->step_tab_host = nh; h->step_tab_cap = cap;
 }
 
+// scoring overlap: the main stream waits for the pass running on the side stream (before anything that changes what that pass
+// reads -- parameters, the prefix table -- and before the backward kernels, which want the chip to themselves)
+void join_score(kprn_handle* h) {
+  if (!h->score_pending) return;
+  HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_score_done, 0));
+  h->score_pending = false;
+}
+
 // bring every entity row up to opt_step (needed before anything reads the whole table)
 static void flush_lazy(kprn_handle* h) {
+  join_score(h);
   if (!h->lazy_pending) return;
   ProfScope ps(h, "adam_flush_all");
   kk::adam_flush_all(h->stream, h->We, h->s1_We, h->s2_We, h->We_last, h->cfg.Ve, h->cfg.de, (int32_t)h->opt_step, h->step_tab,
@@ -151,6 +162,7 @@ static void flush_lazy(kprn_handle* h) {
 
 static void zero_pad_tokens(kprn_handle* h) {
   const kprn_config& c = h->cfg;
+  join_score(h);
   kk::zero_pad3(h->stream, h->dense + h->off_Wt + (int64_t)(c.Vt - 1) * c.dt, c.dt, h->dense + h->off_Wr + (int64_t)(c.Vr - 1) * c.dr, c.dr,
                 h->We + (int64_t)(c.Ve - 1) * c.de, c.de);
   h->pad_clean = true;
@@ -158,6 +170,7 @@ static void zero_pad_tokens(kprn_handle* h) {
 
 // parameters were written from outside the optimiser: every steady-state shortcut is off
 static void params_touched(kprn_handle* h) {
+  join_score(h);
   h->pad_clean = false;
   h->caught_serial = -1;
   fused::params_changed(h);
@@ -240,6 +253,7 @@ static void ensure_ws_generic(kprn_handle* h, int64_t N, int T) {
 static void catch_up(kprn_handle* h, const kprn_batch* b) {
   if (!h->lazy_pending || b->n_uniq == 0) return;
   if (h->caught_serial == b->serial && h->caught_step == h->opt_step) return;  // this batch's rows are already current
+  join_score(h);
   ProfScope ps(h, "adam_rows_catchup");
   // count lives at the tail of the list buffer
   kk::adam_rows(h->stream, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, b->uniq, b->uniq + b->uniq_cap, b->n_uniq, h->cfg.de,
@@ -591,6 +605,7 @@ static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int
     h->loss_pending = kk::loss_partials(b->B);
   }
   view_step_rows(h, b);
+  join_score(h);
   if (fusedp) fused::backward(h, b, cid);
   else backward_generic(h, b, cid);
   h->ent_grads_dirty = true;
@@ -601,6 +616,7 @@ static void apply_update_impl(kprn_handle* h, const kprn_opt* o) {
   KPRN_REQUIRE(o != nullptr, KPRN_E_ARG, "opt is NULL");
   KPRN_REQUIRE(o->method == 0 || o->method == 1, KPRN_E_ARG, "opt.method must be 0 (adagrad) or 1 (adam)");
   const kprn_config& c = h->cfg;
+  join_score(h);
   hipStream_t s = h->stream;
   const bool reg = (o->regularize == 1);
   const bool dense_ent = reg || o->entity_update == 1;
@@ -779,8 +795,11 @@ int kprn_create(const kprn_config* cfg, kprn_handle** out) {
 void kprn_destroy(kprn_handle* h) {
   if (!h) return;
   hipSetDevice(h->cfg.device_id);
+  if (h->score_stream) hipStreamSynchronize(h->score_stream);
   if (h->stream) hipStreamSynchronize(h->stream);
   prof_drain(h);
+  if (h->score_stream) { hipStreamDestroy(h->score_stream); hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_score_done); }
+  dfree(h->S2); dfree(h->sel2);
   fused::release(h);
   if (h->bidx_scratch) { hipFree(h->bidx_scratch); h->bidx_scratch = nullptr; }
   dfree(h->loss_partial);
@@ -976,6 +995,43 @@ int kprn_batch_executed_steps(kprn_handle* h, const kprn_batch* b, int64_t* step
 
 int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id) {
   API_BEGIN(h)
+  h->last_forward_side = false;
+  if (h->score_overlap && b && use_fused(h, b, false)) {
+    // the pass goes to the side stream with its own output buffers; everything it reads is final on the main stream first
+    check_batch(h, b, class_id);
+    const int64_t N = (int64_t)b->B * b->P;
+    catch_up(h, b);
+    ensure_ws_common(h, N, b->B);
+    if (!h->score_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->score_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_score_done, hipEventDisableTiming));
+    }
+    if (N > h->cap_N2 || b->B > h->cap_B2) {
+      HIP_TRY(hipStreamSynchronize(h->score_stream));
+      dfree(h->S2); dfree(h->sel2);
+      h->cap_N2 = std::max(N, h->cap_N2); h->cap_B2 = std::max<int64_t>(b->B, h->cap_B2);
+      h->S2 = dalloc<float>(h->cap_N2 * h->cfg.C);
+      h->sel2 = dalloc<float>(h->cap_B2);
+    }
+    fused::prefix_forward(h, b);  // (main stream; cached for the pass below and for the training forward of the same batch)
+    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_fork, 0));
+    Workspace& w = h->ws;
+    hipStream_t main_stream = h->stream;
+    float* S0 = w.S; float* sel0 = w.sel;
+    h->stream = h->score_stream; w.S = h->S2; w.sel = h->sel2;
+    try {
+      fused::forward(h, b, false);
+      pool_stage(h, b, class_id - 1, false);
+    } catch (...) { h->stream = main_stream; w.S = S0; w.sel = sel0; throw; }
+    h->stream = main_stream; w.S = S0; w.sel = sel0;
+    HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
+    h->score_pending = true;
+    h->last_forward_side = true;
+    h->last_B = b->B;
+    return KPRN_OK;
+  }
   forward_impl(h, b, class_id, false, true, /*every_class=*/false);  // kprn_read_probs hands out the selected class
   API_END(h)
 }
@@ -983,7 +1039,12 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
 int kprn_read_probs(kprn_handle* h, float* probs, int32_t B) {
   API_BEGIN(h)
   KPRN_REQUIRE(probs && B > 0 && B <= h->last_B, KPRN_E_ARG, "bad probs buffer / B");
-  HIP_TRY(hipMemcpyAsync(probs, h->ws.sel, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (h->last_forward_side) {
+    HIP_TRY(hipMemcpyAsync(probs, h->sel2, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->score_stream));
+    HIP_TRY(hipStreamSynchronize(h->score_stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(probs, h->ws.sel, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   prof_drain(h);
   API_END(h)
@@ -1098,6 +1159,7 @@ int kprn_read_loss(kprn_handle* h, float* loss) {
 
 int kprn_sync(kprn_handle* h) {
   API_BEGIN(h)
+  if (h->score_stream) HIP_TRY(hipStreamSynchronize(h->score_stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   prof_drain(h);
   API_END(h)
@@ -1264,6 +1326,10 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     if (strcmp(value, "auto") == 0) h->impl = 0;
     else if (strcmp(value, "generic") == 0) h->impl = 1;
     else throw KprnError{KPRN_E_ARG, "impl must be auto or generic"};
+  } else if (strcmp(key, "score_overlap") == 0) {
+    // kprn_forward_batch_async on a second stream (fused path): the scoring pass shares the chip with the work enqueued after it
+    join_score(h);
+    h->score_overlap = atoi(value) ? 1 : 0;
   } else if (strcmp(key, "profile_filter") == 0) {
     h->prof_filter = value;  // "" = every kernel family; else only families whose name starts with this
   } else if (strcmp(key, "reserve_cus") == 0) {

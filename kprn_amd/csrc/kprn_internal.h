@@ -145,6 +145,15 @@ struct kprn_handle {
   void* fused_state = nullptr;  // owned by lstm_fused_*.hip
   void* bidx_scratch = nullptr; size_t bidx_scratch_bytes = 0;  // batch_index.hip temporaries
   int impl = 0;                 // 0 auto, 1 generic
+  // scoring overlap (kprn_set_option "score_overlap"): kprn_forward_batch_async runs the fused scoring pass on a second stream
+  // with its own output buffers, so that it shares the chip with whatever the main stream does next (the training forward
+  // of the same step: neither depends on the other); every operation that would change what the pass reads waits for it
+  int score_overlap = 0;
+  hipStream_t score_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_score_done = nullptr;
+  bool score_pending = false;     // a pass is (possibly) still running on score_stream
+  bool last_forward_side = false; // kprn_read_probs reads the side buffers
+  float* S2 = nullptr; float* sel2 = nullptr; int64_t cap_N2 = 0, cap_B2 = 0;
   int reserve_cus = 0;          // CUs the SCORING forward leaves free (a collective's copy kernels run beside it; kprn_set_option)
   int32_t last_B = 0;
 
@@ -164,6 +173,7 @@ struct ProfScope {
   ~ProfScope();
 };
 void prof_drain(kprn_handle* h);
+void join_score(kprn_handle* h);  // main stream waits for the scoring pass on the side stream, if any
 
 // ---- kernels (kernels_basic.hip) -----------------------------------------------------------
 namespace kk {

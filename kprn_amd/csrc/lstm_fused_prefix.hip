@@ -264,6 +264,7 @@ void prefix_forward(kprn_handle* h, const kprn_batch* b) {
   const kprn_config& c = h->cfg;
   PrefFwdArgs a;
   if (!b->tile_k || b->h_kmax == 0) { s->pf_batch = b->serial; return; }  // class 0 only: zeros since allocation, never rewritten
+  join_score(h);  // a scoring pass on the side stream may still be reading the table
   a.kmax = b->h_kmax;
   for (int q = 0; q < 16; ++q) a.ref[q] = b->h_ref[q];
   a.F = b->F; a.nT = c.num_types;

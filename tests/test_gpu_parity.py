@@ -729,3 +729,27 @@ def test_identical_prefix_plan_full_size_equals_no_plan(monkeypatch):
         # plain and cosine-weighted sums of the tensor: fp32 re-association moves them by ~1e-6 of the sum of magnitudes
         tol = 5e-5 * ref[3] + 1e-12
         assert abs(got[1] - ref[1]) < tol and abs(got[2] - ref[2]) < tol, (nm, got, ref)
+
+
+def test_scoring_pass_on_the_side_stream_changes_nothing():
+    """score_overlap: kprn_forward_batch_async on a second stream, sharing the chip with the train step enqueued behind it.
+    Scores are those of the parameters BEFORE the step's update, and the training trajectory is untouched."""
+    outs = []
+    for overlap in ("0", "1"):
+        eng, o64, theta = mk(L=2, impl="auto")
+        eng.set_option("score_overlap", overlap)
+        batches = [synth.make_paths(300, P, 6, Ve=300, seed=40 + P) for P in (2, 3)]
+        gb = [eng.batch(i, l) for i, l in batches]
+        opt = _ffi.make_opt(method=1, lr=1e-2)
+        probs, losses = [], []
+        eng.train_step(gb[0], opt, 1)   # (the first trainBatch zeroes the pad rows, MyOptimizer.lua:181; scoring never does)
+        for s_ in range(6):
+            b = gb[s_ % 2]
+            eng.forward_async(b, 1)
+            losses.append(eng.train_step(b, opt, 1))
+            probs.append(eng.read_probs(b.B))      # the pass enqueued before the step: pre-update parameters
+        outs.append((np.concatenate(probs), np.array(losses), eng.get_flat_params()))
+    # (without overlap read_probs returns what the step's own training forward left: same parameters, the SAVE variant of the kernel)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-6)
+    assert np.max(np.abs(outs[0][2] - outs[1][2])) < 1e-6   # (atomics in the embedding backward: run-to-run noise only)
