@@ -267,7 +267,7 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b) {
   const kprn_config& c = h->cfg;
   const bool bf = c.compute_dtype == 1;  // bf16 MFMA products, fp32 accumulation (gemm_f32.hip)
   Workspace& w = h->ws;
-  const int H = c.H, L = c.L, D = h->D, T = b->T;
+  const int H = c.H, L = c.L, T = b->T;
   const int64_t N = (int64_t)b->B * b->P;
   hipStream_t s = h->stream;
   {

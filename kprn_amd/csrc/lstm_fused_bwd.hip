@@ -405,7 +405,6 @@ struct ScatArgs {
   const int32_t* idx; int64_t N; int T, F, nT;
   int dt, de, dr, Vt, Vr;
   const float* DX;        // [(Npad/16)][T][4][64][4]
-  const int32_t* lead;    // [Npad][T] leader row inside the tile (first row with the same entity id), -1 past N; nullable
   float *gWt, *gWe, *gWr;
   const int32_t* tile_k;    // identical-prefix plan: steps below tile_k[tile] are not executed (nullable)
   int do_small, do_entity;  // which tables this launch handles
@@ -446,7 +445,7 @@ __global__ __launch_bounds__(256) void k_embed_scatter_frag(ScatArgs a) {
       my_ids[0] = f[a.F - a.nT - 2] - 1;
       my_ids[1] = f[a.F - 2] - 1;
       my_ids[2] = f[a.F - 1] - 1;
-      my_ids[3] = valid ? (a.lead ? a.lead[(n0 + tid) * T + t] : tid) : -1;
+      my_ids[3] = valid ? tid : -1;
     }
     __syncthreads();  // previous item's readers are done with dxt / ids
     if (tid < MT) {
@@ -458,7 +457,7 @@ __global__ __launch_bounds__(256) void k_embed_scatter_frag(ScatArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) dxt[(k * 16 + ag * 4 + r) * LDA + w0 * 16 + arow] = v[k][r];
     __syncthreads();
-    if (!a.lead) {
+    {
       // leader = first row of the tile with the same entity id
       int ld = -1;
       if (tid < MT && ids[tid * 4 + 3] >= 0) {
@@ -651,7 +650,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       ScatArgs sa;
       sa.idx = b->idx_s ? b->idx_s : b->idx; sa.tile_k = b->tile_k; sa.N = N; sa.T = T; sa.F = b->F; sa.nT = c.num_types;
       sa.dt = c.dt; sa.de = c.de; sa.dr = c.dr; sa.Vt = c.Vt; sa.Vr = c.Vr;
-      sa.DX = s->DX; sa.lead = nullptr; sa.gWt = a.gWt; sa.gWe = a.gWe; sa.gWr = a.gWr; sa.n_tiles = n_tiles;
+      sa.DX = s->DX; sa.gWt = a.gWt; sa.gWe = a.gWe; sa.gWr = a.gWr; sa.n_tiles = n_tiles;
       sa.do_small = small_in_kernel ? 0 : 1; sa.do_entity = have_index ? 0 : 1;
       const int n_small = c.Vt * c.dt + c.Vr * c.dr;
       const bool small_fits = n_small <= 4096;

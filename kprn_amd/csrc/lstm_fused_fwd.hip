@@ -43,11 +43,13 @@ constexpr float N2LOG2E = -2.8853900817779268f;  // tanh(x) = 2 rcp(1 + exp2(-2x
 // most one transcendental (16 cycles) and never consumes a value produced in the same step.
 struct CellRegs { float m0, m1, m2, m3, e0, e1, e2, e3, i, g, f, o, ig, c, cp, t; };
 template <bool SAVE, int R, int K>
-__device__ __forceinline__ void cell_step(CellRegs& x, const f32x4 (&acc)[4], float (&cst)[4], bool first, float* out_row, f32x4 (&sv)[NPL]) {
-  // accumulators are read gate 0 first: the MFMAs that wrote gates 2, 3 last are the most recent ones
-  if (K == 0) { x.m0 = acc[0][R] * NLOG2E; x.m1 = acc[1][R] * N2LOG2E; }
-  if (K == 1) { x.e0 = __builtin_amdgcn_exp2f(x.m0); x.m2 = acc[2][R] * NLOG2E; }
-  if (K == 2) { x.e1 = __builtin_amdgcn_exp2f(x.m1); x.m3 = acc[3][R] * NLOG2E; }
+__device__ __forceinline__ void cell_step(CellRegs& x, const f32x4 (&acc)[4], float (&cst)[4], float* out_row, f32x4 (&sv)[NPL]) {
+  // The accumulators hold the pre-activations ALREADY scaled for exp2 (-log2 e for the sigmoid gates, -2 log2 e for the tanh
+  // gate: the kernel folds the factors into its register copies of the weights and the bias), so no multiply is spent here.
+  // They are read gate 0 first: the MFMAs that wrote gates 2, 3 last are the most recent ones.
+  if (K == 0) { x.m0 = acc[0][R]; x.m1 = acc[1][R]; }
+  if (K == 1) { x.e0 = __builtin_amdgcn_exp2f(x.m0); x.m2 = acc[2][R]; }
+  if (K == 2) { x.e1 = __builtin_amdgcn_exp2f(x.m1); x.m3 = acc[3][R]; }
   if (K == 3) { x.e2 = __builtin_amdgcn_exp2f(x.m2); x.e0 += 1.0f; }
   if (K == 4) { x.e3 = __builtin_amdgcn_exp2f(x.m3); x.e1 += 1.0f; }
   if (K == 5) { x.i = __builtin_amdgcn_rcpf(x.e0); x.e2 += 1.0f; }
@@ -76,16 +78,16 @@ __device__ __forceinline__ void cell_step(CellRegs& x, const f32x4 (&acc)[4], fl
 }
 
 template <bool SAVE, int R>
-__device__ __forceinline__ void cell_q(const f32x4 (&acc)[4], float (&cst)[4], bool first, float* out_row, f32x4 (&sv)[NPL]) {
+__device__ __forceinline__ void cell_q(const f32x4 (&acc)[4], float (&cst)[4], float* out_row, f32x4 (&sv)[NPL]) {
   CellRegs x;
-  cell_step<SAVE, R, 0>(x, acc, cst, first, out_row, sv);  cell_step<SAVE, R, 1>(x, acc, cst, first, out_row, sv);
-  cell_step<SAVE, R, 2>(x, acc, cst, first, out_row, sv);  cell_step<SAVE, R, 3>(x, acc, cst, first, out_row, sv);
-  cell_step<SAVE, R, 4>(x, acc, cst, first, out_row, sv);  cell_step<SAVE, R, 5>(x, acc, cst, first, out_row, sv);
-  cell_step<SAVE, R, 6>(x, acc, cst, first, out_row, sv);  cell_step<SAVE, R, 7>(x, acc, cst, first, out_row, sv);
-  cell_step<SAVE, R, 8>(x, acc, cst, first, out_row, sv);  cell_step<SAVE, R, 9>(x, acc, cst, first, out_row, sv);
-  cell_step<SAVE, R, 10>(x, acc, cst, first, out_row, sv); cell_step<SAVE, R, 11>(x, acc, cst, first, out_row, sv);
-  cell_step<SAVE, R, 12>(x, acc, cst, first, out_row, sv); cell_step<SAVE, R, 13>(x, acc, cst, first, out_row, sv);
-  cell_step<SAVE, R, 14>(x, acc, cst, first, out_row, sv); cell_step<SAVE, R, 15>(x, acc, cst, first, out_row, sv);
+  cell_step<SAVE, R, 0>(x, acc, cst, out_row, sv);  cell_step<SAVE, R, 1>(x, acc, cst, out_row, sv);
+  cell_step<SAVE, R, 2>(x, acc, cst, out_row, sv);  cell_step<SAVE, R, 3>(x, acc, cst, out_row, sv);
+  cell_step<SAVE, R, 4>(x, acc, cst, out_row, sv);  cell_step<SAVE, R, 5>(x, acc, cst, out_row, sv);
+  cell_step<SAVE, R, 6>(x, acc, cst, out_row, sv);  cell_step<SAVE, R, 7>(x, acc, cst, out_row, sv);
+  cell_step<SAVE, R, 8>(x, acc, cst, out_row, sv);  cell_step<SAVE, R, 9>(x, acc, cst, out_row, sv);
+  cell_step<SAVE, R, 10>(x, acc, cst, out_row, sv); cell_step<SAVE, R, 11>(x, acc, cst, out_row, sv);
+  cell_step<SAVE, R, 12>(x, acc, cst, out_row, sv); cell_step<SAVE, R, 13>(x, acc, cst, out_row, sv);
+  cell_step<SAVE, R, 14>(x, acc, cst, out_row, sv); cell_step<SAVE, R, 15>(x, acc, cst, out_row, sv);
 }
 
 // One k-group: 16 MFMAs (k-slots jj x gates q) on the A fragment a4 and the weights w[q][S].  BIAS: these are
@@ -95,15 +97,14 @@ __device__ __forceinline__ void cell_q(const f32x4 (&acc)[4], float (&cst)[4], b
 // pinned with sched_barrier (the asm MFMAs carry no latency the scheduler could reason about).
 template <bool SAVE, bool CELL, bool BIAS, bool PF, int S>
 __device__ __forceinline__ void k_group(const f32x4 a4, f32x4& apre, const float* next_addr, const f32x4 (&w)[4][4], const f32x4 (&bias4)[4],
-                                        f32x4 (&acc)[4], CellRegs& x, const f32x4 (&pacc)[4], float (&pc)[4], bool pfirst, float* pout_row,
-                                        f32x4 (&sv)[NPL]) {
+                                        f32x4 (&acc)[4], CellRegs& x, const f32x4 (&pacc)[4], float (&pc)[4], float* pout_row, f32x4 (&sv)[NPL]) {
 #define KPRN_G1(K)                                                                                  \
   {                                                                                                 \
     constexpr int jj = (K) >> 2, q = (K) & 3;                                                       \
     if (BIAS && jj == 0) KPRN_MFMA_C(acc[q], a4[jj], w[q][S][jj], bias4[q]);                        \
     else KPRN_MFMA(acc[q], a4[jj], w[q][S][jj]);                                                    \
     if (PF && (K) == 7) apre = *(const f32x4*)(next_addr);                                          \
-    if (CELL) { cell_step<SAVE, S, (K)>(x, pacc, pc, pfirst, pout_row, sv); __builtin_amdgcn_sched_barrier(0); } \
+    if (CELL) { cell_step<SAVE, S, (K)>(x, pacc, pc, pout_row, sv); __builtin_amdgcn_sched_barrier(0); } \
   }
   KPRN_G1(0) KPRN_G1(1) KPRN_G1(2) KPRN_G1(3) KPRN_G1(4) KPRN_G1(5) KPRN_G1(6) KPRN_G1(7)
   KPRN_G1(8) KPRN_G1(9) KPRN_G1(10) KPRN_G1(11) KPRN_G1(12) KPRN_G1(13) KPRN_G1(14) KPRN_G1(15)
@@ -114,25 +115,24 @@ __device__ __forceinline__ void k_group(const f32x4 a4, f32x4& apre, const float
 // tile).  apre always holds the A fragment of the group about to run.
 template <bool SAVE, bool CELL, bool BIAS, bool PF>
 __device__ __forceinline__ void half_unit(const float* abase, const f32x4 (&w)[4][4], const f32x4 (&bias4)[4], f32x4 (&acc)[4], f32x4& apre,
-                                          const float* next_abase, const f32x4 (&pacc)[4], float (&pc)[4], bool pfirst, float* pout_row,
-                                          f32x4 (&sv)[NPL]) {
+                                          const float* next_abase, const f32x4 (&pacc)[4], float (&pc)[4], float* pout_row, f32x4 (&sv)[NPL]) {
   CellRegs x;
   f32x4 a4 = apre;
-  k_group<SAVE, CELL, BIAS, true, 0>(a4, apre, abase + 16, w, bias4, acc, x, pacc, pc, pfirst, pout_row, sv);
+  k_group<SAVE, CELL, BIAS, true, 0>(a4, apre, abase + 16, w, bias4, acc, x, pacc, pc, pout_row, sv);
   a4 = apre;
-  k_group<SAVE, CELL, false, true, 1>(a4, apre, abase + 32, w, bias4, acc, x, pacc, pc, pfirst, pout_row, sv);
+  k_group<SAVE, CELL, false, true, 1>(a4, apre, abase + 32, w, bias4, acc, x, pacc, pc, pout_row, sv);
   a4 = apre;
-  k_group<SAVE, CELL, false, true, 2>(a4, apre, abase + 48, w, bias4, acc, x, pacc, pc, pfirst, pout_row, sv);
+  k_group<SAVE, CELL, false, true, 2>(a4, apre, abase + 48, w, bias4, acc, x, pacc, pc, pout_row, sv);
   a4 = apre;
-  k_group<SAVE, CELL, false, PF, 3>(a4, apre, next_abase, w, bias4, acc, x, pacc, pc, pfirst, pout_row, sv);
+  k_group<SAVE, CELL, false, PF, 3>(a4, apre, next_abase, w, bias4, acc, x, pacc, pc, pout_row, sv);
 }
 
 template <bool SAVE>
-__device__ __forceinline__ void cell_all(const f32x4 (&pacc)[4], float (&pc)[4], bool pfirst, float* pout_row, f32x4 (&sv)[NPL]) {
-  cell_q<SAVE, 0>(pacc, pc, pfirst, pout_row, sv);
-  cell_q<SAVE, 1>(pacc, pc, pfirst, pout_row, sv);
-  cell_q<SAVE, 2>(pacc, pc, pfirst, pout_row, sv);
-  cell_q<SAVE, 3>(pacc, pc, pfirst, pout_row, sv);
+__device__ __forceinline__ void cell_all(const f32x4 (&pacc)[4], float (&pc)[4], float* pout_row, f32x4 (&sv)[NPL]) {
+  cell_q<SAVE, 0>(pacc, pc, pout_row, sv);
+  cell_q<SAVE, 1>(pacc, pc, pout_row, sv);
+  cell_q<SAVE, 2>(pacc, pc, pout_row, sv);
+  cell_q<SAVE, 3>(pacc, pc, pout_row, sv);
 }
 
 // nn.Linear(H, C) on the tile's h_T (LDS) -> S[n][0..C)
@@ -199,12 +199,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t row = (int64_t)q * DH + j * 16 + arow;
-      const float bv = a.bi[l][row];
+      const float sc = (q == 1) ? N2LOG2E : NLOG2E;  // gate order i, g, f, o: g is the tanh gate
+      const float bv = a.bi[l][row] * sc;
       bias4[l][q] = f32x4{bv, bv, bv, bv};
 #pragma unroll
       for (int S = 0; S < 4; ++S) {
-        wi[l][q][S] = *(const f32x4*)(a.Wi[l] + row * DH + S * 16 + ag * 4);
-        wo[l][q][S] = *(const f32x4*)(a.Wo[l] + row * DH + S * 16 + ag * 4);
+        wi[l][q][S] = *(const f32x4*)(a.Wi[l] + row * DH + S * 16 + ag * 4) * sc;
+        wo[l][q][S] = *(const f32x4*)(a.Wo[l] + row * DH + S * 16 + ag * 4) * sc;
       }
     }
   }
@@ -270,7 +271,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   auto slot = [&](auto first_tag, const int64_t tile, const int t, const int par, const bool has_prev, const int64_t p_tile, const int p_t,
                   const int cls) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    constexpr bool q_first = false, p_first = false;  // (the cell no longer needs to know)
     float cinit[L];
     float rec0[L][4];  // k-slot 0 of the B operand: (W_o2g h_prefix)[gate q, col 16j + arow]
     const float one0 = (ag == 0) ? 1.0f : 0.f;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float v = pft[(cls * L + l) * PFB + q * DH + j * 16 + arow];
-            rec0[l][q] = (ag == 0) ? v : 0.f;
+            rec0[l][q] = (ag == 0) ? v * ((q == 1) ? N2LOG2E : NLOG2E) : 0.f;
           }
           cinit[l] = pft[(cls * L + l) * PFB + 4 * DH + j * 16 + arow];
         }
@@ -318,17 +318,17 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
         else if (l + 1 < L) nxt = hbuf(l + 1, par ^ 1) + a_off;
         else nxt = hbuf(0, par) + a_off;
         if (!FIRST) {
-          half_unit<SAVE, true, true, true>(hp_buf + mt * 16 * LDA + a_off, wo[l], bias4[l], acc, apre, in_base, pacc, c[pl][pm], q_first, pout, sv);
+          half_unit<SAVE, true, true, true>(hp_buf + mt * 16 * LDA + a_off, wo[l], bias4[l], acc, apre, in_base, pacc, c[pl][pm], pout, sv);
           save_unit(q_tile, q_t, pl, pm);
           if (mt == 0) {
             lds_barrier();
             apre = *(const f32x4*)(in_base);
           }
-          half_unit<SAVE, false, false, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
+          half_unit<SAVE, false, false, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], pout, sv);
         } else if (mt == 0) {
           if (!cross || has_prev) {
             KPRN_MFMA_DRAIN();  // last MFMAs of the previous unit -> VALU reads
-            cell_all<SAVE>(pacc, c[pl][pm], q_first, pout, sv);
+            cell_all<SAVE>(pacc, c[pl][pm], pout, sv);
             save_unit(q_tile, q_t, pl, pm);
           }
           if (cross) {
@@ -338,13 +338,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
           lds_barrier();
           if (cross && has_prev) head_tile(a, hbuf(L - 1, q_par), p_tile, j, lane);
           apre = *(const f32x4*)(in_base);
-          half_unit<SAVE, false, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
+          half_unit<SAVE, false, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], pout, sv);
           if (cls > 0) {  // (uniform)
 #pragma unroll
             for (int q = 0; q < 4; ++q) KPRN_MFMA_VV(acc[q], one0, rec0[l][q]);
           }
         } else {
-          half_unit<SAVE, true, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], q_first, pout, sv);
+          half_unit<SAVE, true, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], pout, sv);
           save_unit(q_tile, q_t, pl, pm);
           if (cls > 0) {
 #pragma unroll
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   // drain: the cell of the very last unit, then the last tile's head
   {
     KPRN_MFMA_DRAIN();
-    cell_all<SAVE>(accs[1], c[L - 1][3], false, hbuf(L - 1, par) + 3 * 16 * LDA + o_off, sv);
+    cell_all<SAVE>(accs[1], c[L - 1][3], hbuf(L - 1, par) + 3 * 16 * LDA + o_off, sv);
     save_unit(p_tile, p_t, L - 1, 3);
     lds_barrier();
     head_tile(a, hbuf(L - 1, par), p_tile, j, lane);
