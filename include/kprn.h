@@ -197,7 +197,16 @@ int kprn_profile_reset(kprn_handle* h);
 /* fills up to cap entries; returns the number of kernel families seen in *n             */
 typedef struct { char name[48]; double total_ms; int64_t launches; } kprn_prof_entry;
 int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t* n);
-/* selects the implementation: "auto" (fused where the shape allows), "generic"           */
+/* options (all strings):
+ *   "impl"            "auto" (fused kernels where the shape allows) | "generic"
+ *   "score_overlap"   "1": kprn_forward_batch_async runs the (fused) scoring pass on a second stream with its own output
+ *                     buffers, so that it shares the chip with the work enqueued after it -- typically the training forward of the
+ *                     same step, which does not depend on it.  Whatever would change what the pass reads (an optimiser step, a row
+ *                     catch-up, kprn_set_*) waits for it; kprn_read_probs / kprn_sync wait for it on the host.  "0" (default): in
+ *                     order on the handle's stream.
+ *   "reserve_cus"     CUs the persistent scoring kernel leaves free (a collective's copy kernels run beside it), 0..128
+ *   "profile_filter"  kernel-family name prefix: only those families get HIP events while profiling is on ("" = all); an event
+ *                     pair costs ~4 us of stream time                                                                            */
 int kprn_set_option(kprn_handle* h, const char* key, const char* value);
 
 #ifdef __cplusplus
