@@ -43,7 +43,7 @@ ProfScope::ProfScope(kprn_handle* h_, const char* n) : h(h_), name(n) {
 ProfScope::~ProfScope() {
   if (!h->prof_on || !a || !b) return;
   hipEventRecord(b, h->stream);
-  h->prof_pending.push_back({name, a, b});
+  h->prof_pending.push_back({name, a, b, launches});
   if (h->prof_pending.size() > 4096) prof_drain(h);
 }
 void prof_drain(kprn_handle* h) {
@@ -55,7 +55,7 @@ void prof_drain(kprn_handle* h) {
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
       auto& e = h->prof[p.name];
       e.total_ms += ms;
-      e.launches += 1;
+      e.launches += p.launches;
     }
     h->event_pool.push_back(p.a);
     h->event_pool.push_back(p.b);

@@ -161,7 +161,7 @@ struct kprn_handle {
 
   std::string prof_filter;  // profile only the kernel families whose name starts with this ("": all)
   std::map<std::string, ProfEntry> prof;
-  struct Pending { std::string name; hipEvent_t a, b; };
+  struct Pending { std::string name; hipEvent_t a, b;  int launches = 1; };
   std::vector<Pending> prof_pending;
   std::vector<hipEvent_t> event_pool;
 };
@@ -169,6 +169,7 @@ struct kprn_handle {
 // ---- profiling scope: HIP events on the handle's stream ------------------------------------
 struct ProfScope {
   kprn_handle* h; const char* name; hipEvent_t a = nullptr, b = nullptr;
+  int launches = 1;  // launches of the family this scope spans (one event pair around several back-to-back launches)
   ProfScope(kprn_handle* h_, const char* n);
   ~ProfScope();
 };

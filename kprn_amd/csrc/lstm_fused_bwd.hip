@@ -1,4 +1,6 @@
 // Fused BPTT kernels of the KPRN path scorer for gfx950 (forward: lstm_fused_fwd.hip; design: DESIGN.md).
+#include <memory>
+
 #include "lstm_fused_common.h"
 
 namespace fused {
@@ -601,6 +603,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   const int64_t n_tiles = (N + MT - 1) / MT;
   const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)s->num_cu);
   bool have_r1 = false, reduced = false;
+  std::unique_ptr<ProfScope> bwd_scope;
   bidx::SlabReduce ra;
   for (int l = L - 1; l >= 0; --l) {
     BwdArgs a;
@@ -623,11 +626,13 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
                                  !(a.dbg & 8);
     const bool have_index = b->key_sorted != nullptr && !(a.dbg & 16);
     {
-      ProfScope ps(h, "lstm_fused_bwd");
+      // one event pair around the L back-to-back launches of the family (an event pair costs ~4 us of stream time)
+      if (top) { bwd_scope.reset(new ProfScope(h, "lstm_fused_bwd")); bwd_scope->launches = L; }
       if (bottom && top) { if (small_in_kernel) launch_bwd<true, true, true>(h, a, grid); else launch_bwd<true, true, false>(h, a, grid); }
       else if (bottom) { if (small_in_kernel) launch_bwd<true, false, true>(h, a, grid); else launch_bwd<true, false, false>(h, a, grid); }
       else if (top) launch_bwd<false, true, false>(h, a, grid);
       else launch_bwd<false, false, false>(h, a, grid);
+      if (bottom || s->timing) bwd_scope.reset();
     }
     if (bottom) have_r1 = prefix_backward(h, b, n_tiles);  // the skipped steps of every layer; leaves their dx sums in DX's virtual tile
     if (bottom) {
