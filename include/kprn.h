@@ -199,6 +199,8 @@ typedef struct { char name[48]; double total_ms; int64_t launches; } kprn_prof_e
 int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t* n);
 /* options (all strings):
  *   "impl"            "auto" (fused kernels where the shape allows) | "generic"
+ *   "prefix_plan"     "1" (default): batches created from now on get an identical-prefix plan (leading steps shared by whole
+ *                     64-path tiles are run once per batch, fused path); "0": every step of every path is executed
  *   "score_overlap"   "1": kprn_forward_batch_async runs the (fused) scoring pass on a second stream with its own output
  *                     buffers, so that it shares the chip with the work enqueued after it -- typically the training forward of the
  *                     same step, which does not depend on it.  Whatever would change what the pass reads (an optimiser step, a row

@@ -912,7 +912,7 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
     // reference step; the fused kernels start each 64-path tile behind its shared steps (lstm_fused_prefix.hip)
     const int64_t N = (int64_t)B * P;
     static const char* dbg_env = getenv("KPRN_DBG");
-    const bool want_plan = use_fused(h, b, true) && F <= 16 && !(dbg_env && (atoi(dbg_env) & 64));
+    const bool want_plan = h->prefix_plan && use_fused(h, b, true) && F <= 16 && !(dbg_env && (atoi(dbg_env) & 64));
     b->kcap = want_plan ? fused::KCAP : 0;
     b->n_index = nsteps + b->kcap;
     // occurrence index: positions sorted by entity row + the sorted distinct rows (count at the tail of the list)
@@ -972,6 +972,7 @@ void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
     hipSetDevice(h->cfg.device_id);
     if (h->view_batch == b) { try { materialize_step_rows(h); } catch (...) { h->view_batch = nullptr; h->rows_view = nullptr; h->step_rows_ub = 0; } }
     if (h->caught_serial == b->serial) h->caught_serial = -1;
+    if (h->score_stream) hipStreamSynchronize(h->score_stream);  // a scoring pass on the second stream may still read the batch
     hipStreamSynchronize(h->stream);
   }
   dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->key_sorted); dfree(b->pos_sorted);
@@ -1326,6 +1327,8 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     if (strcmp(value, "auto") == 0) h->impl = 0;
     else if (strcmp(value, "generic") == 0) h->impl = 1;
     else throw KprnError{KPRN_E_ARG, "impl must be auto or generic"};
+  } else if (strcmp(key, "prefix_plan") == 0) {
+    h->prefix_plan = atoi(value) ? 1 : 0;  // batches created from now on (an existing batch keeps what it was built with)
   } else if (strcmp(key, "score_overlap") == 0) {
     // kprn_forward_batch_async on a second stream (fused path): the scoring pass shares the chip with the work enqueued after it
     join_score(h);

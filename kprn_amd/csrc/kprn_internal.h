@@ -148,6 +148,7 @@ struct kprn_handle {
   // scoring overlap (kprn_set_option "score_overlap"): kprn_forward_batch_async runs the fused scoring pass on a second stream
   // with its own output buffers, so that it shares the chip with whatever the main stream does next (the training forward
   // of the same step: neither depends on the other); every operation that would change what the pass reads waits for it
+  int prefix_plan = 1;            // kprn_set_option "prefix_plan": build identical-prefix plans for new batches (fused path)
   int score_overlap = 0;
   hipStream_t score_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_score_done = nullptr;

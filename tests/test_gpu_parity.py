@@ -753,3 +753,49 @@ def test_scoring_pass_on_the_side_stream_changes_nothing():
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-6)
     assert np.max(np.abs(outs[0][2] - outs[1][2])) < 1e-6   # (atomics in the embedding backward: run-to-run noise only)
+
+
+def test_identical_prefix_plan_random_shapes_agree_with_every_step_executed():
+    """Random shapes and pad patterns (all paths identical, everything padded, nothing padded, ragged tiles, deep prefixes):
+    the same engine, the same data, once with the plan and once with every step executed."""
+    rng = np.random.default_rng(123)
+    for trial in range(14):
+        L = int(rng.integers(1, 3))
+        T = int(rng.integers(2, 13))
+        pairs, P = int(rng.integers(1, 160)), int(rng.integers(1, 6))
+        eng, o64, theta = mk(L=L, impl="auto", seed=10 + trial)
+        idx, labels = synth.make_paths(pairs, P, T, Ve=300, seed=500 + trial, real_len=T)
+        N = pairs * P
+        mode = trial % 5
+        if mode == 0:
+            pads = rng.integers(0, T, size=N)           # anything, including fully padded paths
+        elif mode == 1:
+            pads = np.full(N, min(T - 1, 3))            # one class only
+        elif mode == 2:
+            pads = np.zeros(N, dtype=int)
+            if N > 3:
+                pads[N // 2:N // 2 + 2] = min(T, 2)     # two padded paths in the middle of a tile
+        elif mode == 3:
+            pads = rng.integers(0, min(T, 3), size=N)
+            idx[:] = idx[:1, :1]                        # every path identical
+        else:
+            pads = np.where(rng.random(N) < 0.73, min(T - 1, 2), 0)
+        idx = _pad_left(idx, pads)
+        res = []
+        for plan in ("1", "0"):
+            eng.set_option("prefix_plan", plan)
+            b = eng.batch(idx, labels)
+            out = eng.forward(b, 1, want=("probs", "path_scores"))
+            loss = eng.backward(b, 1)
+            res.append((b.executed_steps, out["path_scores"].astype(np.float64), float(loss), eng.get_flat_grads().astype(np.float64)))
+        assert res[1][0] == N * T and res[0][0] <= N * T
+        assert res[0][0] == _plan_executed_steps(idx), (trial, T, N)
+        assert rel_inf(res[0][1], res[1][1]) < 1e-5, (trial, "scores")
+        assert abs(res[0][2] - res[1][2]) < 1e-5 * max(1.0, abs(res[1][2])), (trial, "loss")
+        for nm, (off, shp) in eng.layout().items():
+            n = int(np.prod(shp))
+            ref = res[1][3][off:off + n]
+            assert np.max(np.abs(res[0][3][off:off + n] - ref)) < 2e-5 * max(1e-30, np.max(np.abs(ref))), (trial, nm, T, L, N)
+        if trial < 3:   # and against the oracle
+            ol, og, _ = o64.forward_backward(theta, idx, labels)
+            assert rel_inf(res[0][3], og) < GRAD_RTOL
