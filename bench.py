@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--train-only", action="store_true")
     ap.add_argument("--score-only", action="store_true")
     ap.add_argument("--reserve-cus", type=int, default=16, help="CUs the scoring pass leaves to the collective in data-parallel runs")
+    ap.add_argument("--compute-dtype", type=int, default=0, choices=[0, 1, 2],
+                    help="0: fp32 MFMA (default, the headline).  2: f32x6 -- fp32 products formed exactly from bf16 pieces on the matrix "
+                         "cores (forward only; same parity bars).  1: bf16 products (scoring only on the fused path)")
     ap.add_argument("--no-score-overlap", action="store_true",
                     help="run the scoring pass on the main stream, strictly before the train step (default: on a second stream, sharing "
                          "the chip with the training forward of the same step -- neither depends on the other)")
@@ -80,6 +83,12 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4, NT=None):
     g = G * H
     if NT is None:
         NT = N * T
+    if name in ("lstm_mc_fwd", "lstm_mc_fwd_train"):   # matrix-core forward: one launch per layer
+        fl = 0
+        for l in range(L):
+            din = D if l == 0 else H
+            fl += NT * 2 * g * din + (NT - N) * 2 * g * H
+        return "mfma", (fl + N * 2 * H * C) / L
     if name in ("lstm_fused_fwd", "lstm_fused_fwd_train"):
         fl = 0
         for l in range(L):
@@ -188,7 +197,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     eng = _ffi.Engine(Vt, Ve, Vr, dt_, de_, dr_, H, L, F=F, num_types=nT, C_=C, reducer=2, device_id=local_rank,
                       rank=rank, world=world, param_init=0.1, seed=12345, stream=stream,
-                      rnn_type=1 if shipped else 0, use_relu=1, rnn_init=1 if shipped else 0)
+                      rnn_type=1 if shipped else 0, use_relu=1, rnn_init=1 if shipped else 0, compute_dtype=a.compute_dtype)
     eng.set_option("impl", a.impl)
     eng.set_option("score_overlap", "0" if a.no_score_overlap else "1")
     opt = _ffi.make_opt(method=1, lr=1e-3, entity_update=a.entity_update)
@@ -345,7 +354,8 @@ def main():
         out = {
             "metric": "paths/sec (train+score) at path_len=6 d=64", "value": round(value, 1), "unit": "paths/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {0: "f32", 1: "bf16", 2: "f32x6"}[a.compute_dtype], "data": "synthetic",
             "config": {"workload": (f"C2 KKBOX-MI synthetic: T={T}, D=H={H} ({dt_}/{de_}/{dr_}), L={L} FastLSTM, fp32, Ve={Ve}, "
                                     f"C=46, LSE pool, Adam; scoring pass + train step per batch") if not shipped else
                                    (f"run_scripts/config.sh as shipped, synthetic KKBox-shaped paths: T={T}, rnn (ReLU, MaskZero, identity init), "
@@ -353,6 +363,8 @@ def main():
                        "paths_per_step_per_gpu": a.paths_per_step, "paths_per_pair_buckets": Ps, "impl": a.impl,
                        "entity_update": "lazy-exact" if a.entity_update == 0 else "dense",
                        "score_overlap": not a.no_score_overlap,
+                       "forward_arithmetic": {0: "fp32 MFMA", 1: "bf16 MFMA products, fp32 accumulate",
+                                              2: "f32x6: fp32 operands split exactly into 3 bf16 pieces, 6 partial products on the matrix cores, fp32 accumulate"}[a.compute_dtype],
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "executed_step_fraction": round(exec_frac, 4),  # (path, step) positions executed / nominal: identical leading (pad) steps run once per batch
             "model_tflops_nominal": round(value * step_flops / 1e12, 3),   # as if every step of every path were computed

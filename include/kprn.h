@@ -70,9 +70,15 @@ typedef struct {
                                 generic pipeline */
   int32_t use_relu;          /* -useReLU (rnn): 1 = nn.ReLU, else nn.Tanh (OneModel.lua:225-229)  */
   int32_t rnn_init;          /* -rnnInitialization (rnn): i2h / h2h weights <- eye, biases <- 0 (OneModel.lua:310-322) */
-  int32_t compute_dtype;     /* 0 = f32 (exact fp32 MFMA; the reference's arithmetic type on GPU).  1 = bf16: the recurrent / head GEMMs
-                                multiply in bf16 (operands rounded to nearest even) and accumulate in f32; parameters, activations and
-                                the optimiser stay f32.  New option (BASELINE configs[3]); generic pipeline only.          */
+  int32_t compute_dtype;     /* 0 = f32 (exact fp32 MFMA; the reference's arithmetic type on GPU).
+                                1 = bf16: the recurrent / head GEMMs multiply in bf16 (operands rounded to nearest even) and
+                                    accumulate in f32; parameters, activations and the optimiser stay f32 (BASELINE configs[3]).
+                                    Scoring at D = H = 64 takes the fused matrix-core forward, everything else the generic pipeline.
+                                2 = f32x6: fp32 results from the bf16 matrix cores -- every fp32 operand is split exactly into
+                                    three bf16 pieces and the six partial products of weight >= 2^-16 are accumulated in f32; the
+                                    dropped products are below 2^-24, i.e. the error is that of an fp32 FMA chain or smaller.
+                                    Fused path only (forward on the matrix cores, backward as for 0); held to the same parity
+                                    tolerances as 0.  New options, not in the reference.                                       */
   int32_t reducer;           /* -topK: 0 = Max, 1 = TopK+Mean, 2 = LogSumExp (OneModel.lua:284-293) */
   int32_t K;                 /* -K                                                               */
   int32_t device_id;         /* HIP device ordinal                                               */

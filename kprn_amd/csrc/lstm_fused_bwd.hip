@@ -695,12 +695,14 @@ void params_changed(kprn_handle* h) {
   State* s = (State*)h->fused_state;
   s->wt_dirty = true;
   s->pf_batch = -1;  // the prefix table is a function of the parameters
+  s->mc_dirty = true;
 }
 
 void release(kprn_handle* h) {
   State* s = (State*)h->fused_state;
   if (!s) return;
-  for (float* p : {s->save_frag, s->WT, s->DX, s->part, s->part_small, s->pfb, s->pfs, s->pfx, s->PG, s->r1}) if (p) hipFree(p);
+  for (float* p : {s->save_frag, s->WT, s->DX, s->part, s->part_small, s->pfb, s->pfs, s->pfx, s->PG, s->r1, s->mc_bias, s->mc_hseq[0], s->mc_hseq[1]}) if (p) hipFree(p);
+  if (s->mc_wsp) hipFree(s->mc_wsp);
   if (s->timing) hipFree(s->timing);
   delete s;
   h->fused_state = nullptr;

@@ -178,6 +178,9 @@ struct State {
   float* pfx = nullptr;     // [64] the reference step's input row
   float* PG = nullptr;      // [L][KCAP+1][PFB] per class: sum of dA at the first executed step | sum of dc handed to the prefix
   float* r1 = nullptr;      // [L][KCAP][R1] rank-1 weight-gradient terms of the prefix steps: dA_{t+1}[256] | dA_t[256] | h_t[64] | in_t[64]
+  // matrix-core forward (lstm_fused_fwd_mc.hip): split weights in register order, scaled biases, h hand-over between layers
+  void* mc_wsp = nullptr; float* mc_bias = nullptr; bool mc_dirty = true; int mc_ns = 0;
+  float* mc_hseq[2] = {nullptr, nullptr}; int64_t mc_capN[2] = {0, 0}; int mc_capT[2] = {0, 0};  // [stream: main, scoring]
   int64_t pf_batch = -1;    // batch serial the table was computed for (-1: stale)
 
   float* part = nullptr;    // [L][num_cu][PART]
@@ -200,6 +203,8 @@ static inline State* st(kprn_handle* h) {
 
 bool fwd_supported(const kprn_handle* h, int T);
 void prefix_forward(kprn_handle* h, const kprn_batch* b);
+void forward_mc(kprn_handle* h, const kprn_batch* b, bool save);
+void mc_prepare(kprn_handle* h);
 bool prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles);
 bool bwd_supported(const kprn_handle* h, int T);
 bool transpose_job(kprn_handle* h, kk::TransposeJob* tj);

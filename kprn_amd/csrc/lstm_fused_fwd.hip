@@ -430,6 +430,7 @@ static void launch_fwd(kprn_handle* h, const FwdArgs& a, int grid) {
 
 void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   const kprn_config& c = h->cfg;
+  if (c.compute_dtype != 0) { forward_mc(h, b, save); return; }  // bf16 / f32x6: the matrix-core forward (lstm_fused_fwd_mc.hip)
   State* s = st(h);
   const int64_t N = (int64_t)b->B * b->P;
   FwdArgs a;

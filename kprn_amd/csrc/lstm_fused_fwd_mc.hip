@@ -1,0 +1,555 @@
+// Fused LSTM forward on the bf16 MATRIX CORES of gfx950 (D = H = 64), one launch per layer.
+//
+// Why a second forward: v_mfma_f32_16x16x4_f32 runs on the SIMD's fp32 lanes -- 32 cycles per issue and no overlap with VALU
+// (DESIGN.md 3.0), so the fp32 forward (lstm_fused_fwd.hip) pays GEMM + cell math in sequence.  v_mfma_f32_16x16x32_bf16 runs
+// on the matrix cores: 8x the flops per issue in half the cycles, and VALU instructions issued behind it execute beside it
+// (scripts/ubench/mfma_bf16_overlap.hip: +8 cycles for exp2 + rcp behind a 17-cycle bf16 MFMA, +26 behind a 32-cycle fp32 one).
+//
+// compute_dtype (include/kprn.h):
+//   1  bf16:   operands rounded to bf16, products exact, fp32 accumulation                      NS = 1: 1 MFMA per K = 32
+//   2  f32x6:  every fp32 operand is split EXACTLY into three bf16 pieces (x = x1 + x2 + x3, 3 x 8 mantissa bits); the six
+//              partial products of weight >= 2^-16 relative to the leading one (11 12 21 13 22 31) are accumulated in fp32:
+//              the dropped ones are below 2^-24.  Error <= that of an fp32 FMA chain (measured on a 256x128x256 product:
+//              1.6e-7 of the largest result against 5.1e-7 for fp32 BLAS).                       NS = 3: 6 MFMAs per K = 32
+//
+// Replaces, per layer, nn.Sequencer(nn.FastLSTM(D,H)) (model/OneModel.lua:268-274) [+ FeatureEmbedding gather, bottom layer;
+// + nn.Linear(H,46), top layer]; same tiles, wave ownership (wave j: hidden units 16j..16j+15 of all four gates), C layout,
+// cell math, training saves and identical-prefix plan as lstm_fused_fwd.hip, so the fp32 backward runs unchanged behind it.
+// The split weights (3 x 2 B per element) of ONE layer fill 192 of the 256 accumulation registers; the layers therefore run
+// as separate launches and hand h over through HBM ([tile][t][64 rows][64] fp32, 100 MB per pass at 65 536 paths).
+//
+// LDS: the step input (x_t / h^{l-1}_t) and h^l as NS planes of bf16 [64 rows][72], double-buffered: an A fragment (row,
+// k-group of 8) is one ds_read_b128; the producer of a value splits it once (the gather for x, the cell for h).
+#include "lstm_fused_common.h"
+
+namespace fused {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LDB = DH + 8;  // bf16 row stride of an LDS plane: 144 B (16-byte aligned, spreads the ds_read_b128 slots)
+constexpr float MC_NLOG2E = -1.4426950408889634f;
+constexpr float MC_N2LOG2E = -2.8853900817779268f;
+
+#define MC_MFMA(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "a"(B_))
+#define MC_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
+#define MC_MFMA_C(ACC, A_, B_, C_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(ACC) : "v"(A_), "a"(B_), "v"(C_))
+
+struct McArgs {
+  const int32_t* idx; int64_t N; int T, F, nT;
+  const float *Wt, *We, *Wr; int dt, de, dr;
+  int L, layer;
+  const uint4* wsp;        // this layer's split weights in register order: [2 src][4 q][2 kc][NS][4 waves][64 lanes] x 16 B
+  const float* bias_sc;    // [256] bias * (-log2 e | -2 log2 e)
+  const float* Hin;        // layers above the bottom: h of the layer below, [tile][T][64][64] fp32
+  float* Hout;             // layers below the top: this layer's h, same layout
+  const float* Wout; const float* bout; int C; float* S;   // top layer: head
+  const int32_t* perm; const int32_t* tile_k; const int32_t* pmeta; const float* pfb;  // identical-prefix plan (lstm_fused_prefix.hip)
+  float* save_frag;        // training saves (nullable), layout of lstm_fused_common.h
+  int64_t n_tiles;
+};
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (every index of the MFMA stream must be a constant:
+// register arrays, the cell step issued behind each MFMA)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// the six partial products of a K chunk, (piece of A, piece of B), smallest first
+__device__ constexpr int mc_ta(int term) { return term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0; }
+__device__ constexpr int mc_tb(int term) { return term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0; }
+
+template <int NS>
+__device__ __forceinline__ void split_store(float x, __bf16* p, int plane_stride) {
+  const __bf16 a = (__bf16)x;
+  p[0] = a;
+  if (NS == 3) {
+    const float r1 = x - (float)a;
+    const __bf16 b = (__bf16)r1;
+    p[plane_stride] = b;
+    p[2 * plane_stride] = (__bf16)(r1 - (float)b);
+  }
+}
+
+// ---- the cell of one accumulator register of the previous unit, in 16 small steps (same arithmetic as lstm_fused_fwd.hip) ----
+struct McCell { float m0, m1, m2, m3, e0, e1, e2, e3, i, g, f, o, ig, c, cp, t; };
+template <int NS, bool SAVE, int R, int K>
+__device__ __forceinline__ void mc_cell_step(McCell& x, const f32x4 (&acc)[4], float (&cst)[4], __bf16* hrow, float* hout, f32x4 (&sv)[NPL]) {
+  if (K == 0) { x.m0 = acc[0][R]; x.m1 = acc[1][R]; }  // (pre-activations arrive scaled for exp2)
+  if (K == 1) { x.e0 = __builtin_amdgcn_exp2f(x.m0); x.m2 = acc[2][R]; }
+  if (K == 2) { x.e1 = __builtin_amdgcn_exp2f(x.m1); x.m3 = acc[3][R]; }
+  if (K == 3) { x.e2 = __builtin_amdgcn_exp2f(x.m2); x.e0 += 1.0f; }
+  if (K == 4) { x.e3 = __builtin_amdgcn_exp2f(x.m3); x.e1 += 1.0f; }
+  if (K == 5) { x.i = __builtin_amdgcn_rcpf(x.e0); x.e2 += 1.0f; }
+  if (K == 6) { x.g = __builtin_amdgcn_rcpf(x.e1); x.e3 += 1.0f; }
+  if (K == 7) { x.f = __builtin_amdgcn_rcpf(x.e2); x.g = 2.0f * x.g - 1.0f; x.cp = cst[R]; }
+  if (K == 8) { x.o = __builtin_amdgcn_rcpf(x.e3); x.ig = x.i * x.g; }
+  if (K == 9) { x.c = x.f * x.cp + x.ig; }
+  if (K == 10) { x.t = x.c * MC_N2LOG2E; cst[R] = x.c; }
+  if (K == 11) { x.t = __builtin_amdgcn_exp2f(x.t); }
+  if (K == 12) { x.t += 1.0f; }
+  if (K == 13) { x.t = __builtin_amdgcn_rcpf(x.t); }
+  if (K == 14) { x.t = 2.0f * x.t - 1.0f; }
+  if (K == 15) {
+    const float hh = x.o * x.t;
+    split_store<NS>(hh, hrow + R * LDB, MT * LDB);
+    if (hout) hout[R * DH] = hh;
+    if (SAVE) {
+      sv[0][R] = x.ig * (1.0f - x.i);
+      sv[1][R] = x.i * (1.0f - x.g * x.g);
+      sv[2][R] = x.cp * x.f * (1.0f - x.f);
+      sv[3][R] = hh * (1.0f - x.o);
+      sv[4][R] = x.o * (1.0f - x.t * x.t);
+      sv[5][R] = x.f;
+      sv[6][R] = hh;
+    }
+  }
+}
+template <int NS, bool SAVE>
+__device__ __forceinline__ void mc_cell_all(const f32x4 (&acc)[4], float (&cst)[4], __bf16* hrow, float* hout, f32x4 (&sv)[NPL]) {
+  McCell x;
+  static_for<0, 64>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int n = decltype(ic)::value;
+    mc_cell_step<NS, SAVE, (n >> 4), (n & 15)>(x, acc, cst, hrow, hout, sv);
+  });
+}
+
+// nn.Linear(H, C) on the tile's h_T (LDS planes; fp32 = exact sum of the pieces) -> S[n][0..C), fp32 MFMA (1 % of the work)
+template <int NS>
+__device__ __forceinline__ void mc_head_tile(const McArgs& a, const __bf16* hpl, int64_t tile, int j, int lane) {
+  const int ntiles = (a.C + 15) >> 4;
+  const int arow = lane & 15, ag = lane >> 4;
+  for (int nt = j; nt < ntiles; nt += 4) {
+    const int col = nt * 16 + arow;
+    const bool cv = col < a.C;
+    const float b = cv ? a.bout[col] : 0.f;
+    f32x4 w4[4];
+#pragma unroll
+    for (int S = 0; S < 4; ++S) w4[S] = cv ? *(const f32x4*)(a.Wout + (int64_t)col * DH + S * 16 + ag * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 acc = f32x4{b, b, b, b};
+#pragma unroll
+      for (int S = 0; S < 4; ++S) {
+        const __bf16* p = hpl + (mt * 16 + arow) * LDB + S * 16 + ag * 4;
+        f32x4 a4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = (float)p[e];
+          if (NS == 3) v += (float)p[MT * LDB + e] + (float)p[2 * MT * LDB + e];
+          a4[e] = v;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], w4[S][jj], acc, 0, 0, 0);
+      }
+      if (cv) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = tile * MT + mt * 16 + ag * 4 + r;
+          if (n < a.N) a.S[(a.perm ? (int64_t)a.perm[n] : n) * a.C + col] = acc[r];
+        }
+      }
+    }
+  }
+}
+
+template <int NS, bool SAVE>
+__global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
+  constexpr int NT = 256;
+  constexpr int PLANE = MT * LDB;            // bf16 elements per plane
+  constexpr int NTERM = (NS == 3) ? 6 : 1;   // partial products per K chunk
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __bf16* planes = (__bf16*)lds;
+  auto inb = [&](int i) -> __bf16* { return planes + (i * NS) * PLANE; };          // step input, buffer i
+  auto hb = [&](int i) -> __bf16* { return planes + ((2 + i) * NS) * PLANE; };     // this layer's h, buffer i
+  int32_t* idb0 = (int32_t*)(planes + 4 * NS * PLANE);
+  auto idbuf = [&](int i) -> int32_t* { return idb0 + i * (MT * MAXT_LDS * 4); };
+  float* pft = (float*)idbuf(2);             // [KCAP+1][PFB] this layer's prefix classes
+
+  const int lane = threadIdx.x & 63;
+  const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int arow = lane & 15, ag = lane >> 4;
+  const int T = a.T, L = a.L, ly = a.layer;
+  const bool bottom = (ly == 0), top = (ly == L - 1);
+  if ((int64_t)blockIdx.x >= a.n_tiles) return;
+
+  // ---- register-stationary split weights: B fragment (col 16j + arow of gate q, k = 32 kc + 8 ag + e) per (src, q, kc, piece)
+  f32x4 w[2][4][2][NS];  // (128-bit containers of 8 bf16)
+#pragma unroll
+  for (int src = 0; src < 2; ++src)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const uint4 u = a.wsp[((((src * 4 + q) * 2 + kc) * NS + s) * 4 + j) * 64 + lane];
+          w[src][q][kc][s] = __builtin_bit_cast(f32x4, u);
+        }
+  f32x4 bias4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const float bv = a.bias_sc[q * DH + j * 16 + arow]; bias4[q] = f32x4{bv, bv, bv, bv}; }
+#pragma unroll
+  for (int src = 0; src < 2; ++src)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) asm volatile("" : "+a"(w[src][q][kc][s]));
+
+  float c[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[m][r] = 0.f;
+
+  auto tile_k0 = [&](int64_t tl) -> int { return a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tl]) : 0; };
+
+  // ---- the step input of (tile, t): table gather (bottom) or the h of the layer below; each thread serves one 16-byte
+  //      chunk column of rows (tid >> 4) + 16 k
+  f32x4 gv[4];
+  GatherSrc gsrc;
+  if (bottom) gsrc = gather_src(a);
+  auto in_load = [&](int64_t tile, int t, const int32_t* ids) {
+    if (bottom) {
+      gather_load<NT>(a, gsrc, tile, t, ids, gv);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = (threadIdx.x >> 4) + k * 16, ch = threadIdx.x & 15;
+        gv[k] = *(const f32x4*)(a.Hin + (((int64_t)tile * T + t) * MT + row) * DH + ch * 4);
+      }
+    }
+  };
+  auto in_store = [&](__bf16* dst) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = (threadIdx.x >> 4) + k * 16, ch = threadIdx.x & 15;
+      __bf16* p = dst + row * LDB + ch * 4;
+      bf16x4 p1, p2, p3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = gv[k][e];
+        const __bf16 b1 = (__bf16)x;
+        p1[e] = b1;
+        if (NS == 3) {
+          const float r1 = x - (float)b1;
+          const __bf16 b2 = (__bf16)r1;
+          p2[e] = b2;
+          p3[e] = (__bf16)(r1 - (float)b2);
+        }
+      }
+      *(bf16x4*)p = p1;
+      if (NS == 3) { *(bf16x4*)(p + PLANE) = p2; *(bf16x4*)(p + 2 * PLANE) = p3; }
+    }
+  };
+
+  if (bottom) ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, blockIdx.x, idbuf(0));
+  if (a.tile_k) {
+    const int n_cls = __builtin_amdgcn_readfirstlane(a.pmeta[0]) + 1;
+    for (int cc = PFB + threadIdx.x; cc < n_cls * PFB; cc += NT) pft[cc] = a.pfb[(int64_t)(cc / PFB) * L * PFB + (int64_t)ly * PFB + cc % PFB];
+  }
+  lds_barrier();
+  int k0 = tile_k0(blockIdx.x);
+  in_load(blockIdx.x, k0, idbuf(0));
+  in_store(inb(0));
+
+  f32x4 accs[2][4];
+  f32x4 sv[NPL];
+  const int64_t frag_unit = (int64_t)NPL * 256;
+  const int64_t frag_mt_stride = (int64_t)T * L * 4 * frag_unit;
+  const int a_off = arow * LDB + ag * 8;               // this lane's A fragment inside a 16-row block (bf16 elements)
+  const int o_off = (ag * 4) * LDB + j * 16 + arow;    // this lane's cell output inside a 16-row block
+
+  auto save_unit = [&](int64_t p_tile, int p_t, int pm) __attribute__((always_inline)) {
+    if (!SAVE) return;
+    float* fb = a.save_frag + (p_tile * 4 + pm) * frag_mt_stride + ((int64_t)(p_t * L + ly) * 4 + j) * frag_unit + lane * 4;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) *(f32x4*)(fb + k * 256) = sv[k];
+  };
+  auto hout_ptr = [&](int64_t q_tile, int q_t, int pm) -> float* {
+    return top ? nullptr : a.Hout + (((int64_t)q_tile * T + q_t) * MT + pm * 16 + ag * 4) * DH + j * 16 + arow;
+  };
+
+  // One unit = the 4-gate GEMM of a 16-row m-tile: [recurrent half over h_{t-1}] + [input half], K = 64 each = 2 chunks of 32,
+  // NTERM MFMAs per (gate, chunk); the cell of the PREVIOUS unit is issued one step behind each of the first 64 MFMAs and
+  // (two MFMAs later: the previous unit's last results have landed by then) executes beside them.  Accumulator chains: the gates alternate, so an accumulator is touched every 4th MFMA.
+  auto unit = [&](auto rec_tag, auto cell_tag, const __bf16* in_base, const __bf16* h_base, f32x4 (&acc)[4], const f32x4 (&pacc)[4], float (&pc)[4],
+                  __bf16* phrow, float* phout) __attribute__((always_inline)) {
+    constexpr bool REC = decltype(rec_tag)::value;
+    constexpr bool CELL = decltype(cell_tag)::value;
+    constexpr int PER_CHUNK = 4 * NTERM;                   // MFMAs per K chunk of 32
+    constexpr int TOTAL = (REC ? 4 : 2) * PER_CHUNK;       // chunks: [h 0, h 1,] in 0, in 1
+    McCell x;
+    f32x4 af[NS], an[NS];  // (128-bit containers of 8 bf16) the running chunk's A pieces / the next chunk's
+    {
+      const __bf16* first = (REC ? h_base : in_base);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) af[s] = *(const f32x4*)(first + s * PLANE);
+    }
+    static_for<0, TOTAL>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int n = decltype(ic)::value;
+      constexpr int q = n & 3;
+      constexpr int term = (n >> 2) % NTERM;
+      constexpr int chunk = n / PER_CHUNK;
+      constexpr int src = REC ? (chunk >> 1) : 1;            // 0 = recurrent half (h_{t-1}), 1 = input half
+      constexpr int kc = chunk & 1;
+      constexpr int sa = (NS == 3) ? mc_ta(term) : 0, sb = (NS == 3) ? mc_tb(term) : 0;
+      constexpr bool has_next = (n / PER_CHUNK) + 1 < TOTAL / PER_CHUNK;
+      if constexpr (n < 4) MC_MFMA_C(acc[q], af[sa], w[src][q][kc][sb], bias4[q]);  // first MFMA of a gate's chain: srcC = the scaled bias
+      else MC_MFMA(acc[q], af[sa], w[src][q][kc][sb]);
+      if constexpr (has_next && term == 0 && q == 3) {
+        // the next chunk's A pieces: next 32 k of the same tile, or the first chunk of the input half
+        const __bf16* nb = (kc == 0) ? ((src == 0) ? h_base : in_base) + 32 : in_base;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) an[s] = *(const f32x4*)(nb + s * PLANE);
+      }
+      if constexpr (has_next && term == NTERM - 1 && q == 3) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) af[s] = an[s];
+      }
+      if constexpr (CELL && n >= 2 && n < 66) {
+        mc_cell_step<NS, SAVE, ((n - 2) >> 4), ((n - 2) & 15)>(x, pacc, pc, phrow, phout, sv);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    if constexpr (CELL && TOTAL < 66) {
+      // (bf16 mode, or a tile's first step: fewer than 66 MFMAs in the unit) the rest of the cell, exposed
+      static_for<0, 64>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int m = decltype(ic)::value;
+        if constexpr (m + 2 >= TOTAL) mc_cell_step<NS, SAVE, (m >> 4), (m & 15)>(x, pacc, pc, phrow, phout, sv);
+      });
+    }
+  };
+
+  auto slot = [&](auto first_tag, const int64_t tile, const int t, const int par, const bool has_prev, const int64_t p_tile, const int p_t,
+                  const int cls) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    float cinit = 0.f, rec0[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FIRST) {
+      if (cls > 0) {  // (uniform) prefix class: c_prefix, and W_o2g h_prefix joins the first step's pre-activations
+        cinit = pft[cls * PFB + 4 * DH + j * 16 + arow];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rec0[q] = pft[cls * PFB + q * DH + j * 16 + arow] * ((q == 1) ? MC_N2LOG2E : MC_NLOG2E);
+      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[m][r] = cinit;
+    }
+    static_for<0, 4>([&](auto mt_c) __attribute__((always_inline)) {
+      constexpr int mt = decltype(mt_c)::value;
+      constexpr int pm = (mt > 0) ? mt - 1 : 3;
+      constexpr bool cross = (mt == 0);  // the pending cell belongs to the previous slot
+      const int64_t q_tile = cross ? p_tile : tile;
+      const int q_t = cross ? p_t : t;
+      const int q_par = cross ? (par ^ 1) : par;
+      f32x4(&acc)[4] = accs[mt & 1];
+      f32x4(&pacc)[4] = accs[(mt & 1) ^ 1];
+      __bf16* phrow = hb(q_par) + pm * 16 * LDB + o_off;
+      float* phout = hout_ptr(q_tile, q_t, pm);
+      const __bf16* in_base = inb(par) + mt * 16 * LDB + a_off;
+      const __bf16* h_base = hb(par ^ 1) + mt * 16 * LDB + a_off;
+      if constexpr (mt == 0) {
+        if (FIRST) {
+          // tile switch: the previous tile's last cell first (its h_T row block completes the head's input), then the head
+          if (has_prev) {
+            MC_DRAIN();
+            mc_cell_all<NS, SAVE>(pacc, c[3], phrow, phout, sv);
+            save_unit(q_tile, q_t, pm);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[3][r] = cinit;
+          lds_barrier();  // (A) this step's input tile is complete; previous tile's h_T complete
+          if (has_prev && top) mc_head_tile<NS>(a, hb(q_par), p_tile, j, lane);
+          unit(std::false_type{}, std::false_type{}, in_base, h_base, acc, pacc, c[pm], phrow, phout);
+        } else {
+          lds_barrier();  // (A) input tile of this step + rows 0..47 of h_{t-1} are complete
+          unit(std::true_type{}, std::true_type{}, in_base, h_base, acc, pacc, c[pm], phrow, phout);
+          save_unit(q_tile, q_t, pm);
+        }
+        if (FIRST && cls > 0) {
+          MC_DRAIN();
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q][r] += rec0[q];
+        }
+        if (!FIRST) lds_barrier();  // (B) rows 48..63 of h_{t-1} (the cell that ran beside this unit) are complete in every wave
+      } else {
+        if (FIRST) {
+          unit(std::false_type{}, std::true_type{}, in_base, h_base, acc, pacc, c[pm], phrow, phout);
+          if (cls > 0) {
+            MC_DRAIN();
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[q][r] += rec0[q];
+          }
+        } else {
+          unit(std::true_type{}, std::true_type{}, in_base, h_base, acc, pacc, c[pm], phrow, phout);
+        }
+        save_unit(q_tile, q_t, pm);
+      }
+    });
+  };
+
+  int64_t tile = blockIdx.x;
+  int t = k0;
+  int tpar = 0;
+  int64_t p_tile = tile;
+  int p_t = t;
+  int par = 0;
+  for (int64_t s = 0;; ++s) {
+    par = (int)(s & 1);
+    int tn = t + 1;
+    int64_t tile_n = tile;
+    int tpar_n = tpar;
+    int k0_n = k0;
+    if (tn == T) {
+      tile_n += gridDim.x;
+      tpar_n ^= 1;
+      k0_n = (tile_n < a.n_tiles) ? tile_k0(tile_n) : 0;
+      tn = k0_n;
+    }
+    const bool have_next = tile_n < a.n_tiles;
+    if (bottom && t == k0 && tile + gridDim.x < a.n_tiles) ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
+    if (have_next) in_load(tile_n, tn, idbuf(tpar_n));
+    if (t == k0) slot(std::true_type{}, tile, t, par, s > 0, p_tile, p_t, k0);
+    else slot(std::false_type{}, tile, t, par, true, p_tile, p_t, 0);
+    MC_DRAIN();
+    if (have_next) in_store(inb(par ^ 1));
+    p_tile = tile; p_t = t;
+    if (!have_next) break;
+    t = tn; tile = tile_n; tpar = tpar_n; k0 = k0_n;
+  }
+  // drain: the cell of the very last unit, then the last tile's head
+  {
+    MC_DRAIN();
+    mc_cell_all<NS, SAVE>(accs[1], c[3], hb(par) + 3 * 16 * LDB + o_off, hout_ptr(p_tile, p_t, 3), sv);
+    save_unit(p_tile, p_t, 3);
+    lds_barrier();
+    if (top) mc_head_tile<NS>(a, hb(par), p_tile, j, lane);
+  }
+}
+
+// ---- split weights in register order (rebuilt when the parameters change) ----
+struct McPrepArgs { const float* Wi; const float* Wo; const float* bi; uint4* wsp; float* bias_sc; int ns; };
+__global__ void k_mc_prep(McPrepArgs a) {
+  // one thread per (src, q, kc, wave, lane): 8 consecutive k of one gate column
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 256) a.bias_sc[i] = a.bi[i] * (((i >> 6) == 1) ? MC_N2LOG2E : MC_NLOG2E);
+  if (i >= 2 * 4 * 2 * 4 * 64) return;
+  const int lane = i & 63, jw = (i >> 6) & 3, kc = (i >> 8) & 1, q = (i >> 9) & 3, src = i >> 11;
+  const int arow = lane & 15, ag = lane >> 4;
+  const float* W = (src == 0) ? a.Wo : a.Wi;  // src 0 = recurrent half (W_o2g), 1 = input half (W_i2g)
+  const float sc = (q == 1) ? MC_N2LOG2E : MC_NLOG2E;
+  const float* row = W + (int64_t)(q * DH + jw * 16 + arow) * DH + kc * 32 + ag * 8;
+  bf16x8 p[3];
+  for (int e = 0; e < 8; ++e) {
+    const float x = row[e] * sc;
+    const __bf16 b1 = (__bf16)x;
+    p[0][e] = b1;
+    const float r1 = x - (float)b1;
+    const __bf16 b2 = (__bf16)r1;
+    p[1][e] = b2;
+    p[2][e] = (__bf16)(r1 - (float)b2);
+  }
+  for (int s = 0; s < a.ns; ++s) a.wsp[((((src * 4 + q) * 2 + kc) * a.ns + s) * 4 + jw) * 64 + lane] = __builtin_bit_cast(uint4, p[s]);
+}
+
+// ---- host side ----
+template <int NS, bool SAVE>
+static void launch_mc(kprn_handle* h, const McArgs& a, int grid) {
+  const size_t lds_bytes = (size_t)4 * NS * MT * LDB * sizeof(__bf16) + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t) + (size_t)(KCAP + 1) * PFB * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd_mc<NS, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_lstm_fwd_mc<NS, SAVE>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
+  HIP_TRY(hipGetLastError());
+}
+
+// split weights / scaled biases of every layer for the current parameters (on the handle's current stream; cached)
+void mc_prepare(kprn_handle* h) {
+  const kprn_config& c = h->cfg;
+  if (c.compute_dtype == 0) return;
+  State* s = st(h);
+  const int ns = (c.compute_dtype == 2) ? 3 : 1;
+  if (!s->mc_wsp) {
+    HIP_TRY(hipMalloc((void**)&s->mc_wsp, (size_t)2 * 2 * 4 * 2 * 3 * 4 * 64 * sizeof(uint4)));
+    HIP_TRY(hipMalloc((void**)&s->mc_bias, (size_t)2 * 256 * sizeof(float)));
+    s->mc_dirty = true;
+  }
+  const size_t wsp_layer = (size_t)2 * 4 * 2 * 3 * 4 * 64;  // uint4 per layer (room for 3 pieces)
+  if (s->mc_dirty || s->mc_ns != ns) {
+    join_score(h);  // (a scoring pass on the second stream may still read the old pieces)
+    ProfScope ps(h, "mc_weight_split");
+    for (int l = 0; l < c.L; ++l) {
+      McPrepArgs pa;
+      pa.Wi = h->dense + h->layer[l].Wi; pa.Wo = h->dense + h->layer[l].Wo; pa.bi = h->dense + h->layer[l].bi;
+      pa.wsp = (uint4*)s->mc_wsp + l * wsp_layer; pa.bias_sc = s->mc_bias + l * 256; pa.ns = ns;
+      hipLaunchKernelGGL(k_mc_prep, dim3(16), dim3(256), 0, h->stream, pa);
+    }
+    HIP_TRY(hipGetLastError());
+    s->mc_dirty = false; s->mc_ns = ns;
+  }
+}
+
+// forward of the whole stack on the matrix cores; compute_dtype 1 (bf16) or 2 (f32x6)
+void forward_mc(kprn_handle* h, const kprn_batch* b, bool save) {
+  const kprn_config& c = h->cfg;
+  State* s = st(h);
+  const int ns = (c.compute_dtype == 2) ? 3 : 1;
+  const int64_t N = (int64_t)b->B * b->P;
+  const int L = c.L;
+  const int64_t n_tiles = (N + MT - 1) / MT;
+  prefix_forward(h, b);
+  mc_prepare(h);
+  const size_t wsp_layer = (size_t)2 * 4 * 2 * 3 * 4 * 64;  // uint4 per layer (room for 3 pieces)
+  // hand-over buffer between the layers: one per stream (a scoring pass on the second stream runs beside the training forward)
+  const int hs = (h->score_stream && h->stream == h->score_stream) ? 1 : 0;
+  if (L > 1 && (N > s->mc_capN[hs] || b->T > s->mc_capT[hs])) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (s->mc_hseq[hs]) HIP_TRY(hipFree(s->mc_hseq[hs]));
+    s->mc_capN[hs] = std::max<int64_t>(N, s->mc_capN[hs]); s->mc_capT[hs] = std::max(b->T, s->mc_capT[hs]);
+    HIP_TRY(hipMalloc((void**)&s->mc_hseq[hs], (size_t)((s->mc_capN[hs] + MT - 1) / MT + 1) * s->mc_capT[hs] * MT * DH * sizeof(float)));
+  }
+  if (save) {
+    if (N > s->cap_N || b->T > s->cap_T) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (s->save_frag) HIP_TRY(hipFree(s->save_frag));
+      const int64_t cn = std::max<int64_t>(N, s->cap_N);
+      const int ct = std::max(b->T, s->cap_T);
+      const int64_t mts = (cn + 15) / 16 + 4;
+      HIP_TRY(hipMalloc((void**)&s->save_frag, (size_t)mts * ct * c.L * 4 * NPL * 256 * sizeof(float)));
+      s->cap_N = cn; s->cap_T = ct;
+    }
+  }
+  const int cus = (!save && h->reserve_cus > 0) ? std::max(1, s->num_cu - h->reserve_cus) : s->num_cu;
+  const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cus);
+  for (int l = 0; l < L; ++l) {
+    McArgs a;
+    a.idx = b->idx_s ? b->idx_s : b->idx; a.N = N; a.T = b->T; a.F = b->F; a.nT = c.num_types;
+    a.Wt = h->dense + h->off_Wt; a.We = h->We; a.Wr = h->dense + h->off_Wr;
+    a.dt = c.dt; a.de = c.de; a.dr = c.dr;
+    a.L = L; a.layer = l;
+    a.wsp = (const uint4*)s->mc_wsp + l * wsp_layer; a.bias_sc = s->mc_bias + l * 256;
+    a.Hin = (l > 0) ? s->mc_hseq[hs] : nullptr;
+    a.Hout = (l < L - 1) ? s->mc_hseq[hs] : nullptr;   // (L <= 2: one hand-over buffer)
+    a.Wout = h->dense + h->off_outW; a.bout = h->dense + h->off_outb; a.C = c.C; a.S = h->ws.S;
+    a.perm = b->perm; a.tile_k = b->tile_k; a.pmeta = b->pmeta; a.pfb = s->pfb;
+    a.save_frag = save ? s->save_frag : nullptr;
+    a.n_tiles = n_tiles;
+    ProfScope ps(h, save ? "lstm_mc_fwd_train" : "lstm_mc_fwd");
+    if (ns == 3) { if (save) launch_mc<3, true>(h, a, grid); else launch_mc<3, false>(h, a, grid); }
+    else { if (save) launch_mc<1, true>(h, a, grid); else launch_mc<1, false>(h, a, grid); }
+  }
+}
+
+}  // namespace fused

@@ -18,8 +18,8 @@ SCORE_RTOL = 1e-4   # north_star: fp32 scores within 1e-4 relative
 GRAD_RTOL = 2e-4    # max|g_gpu - g_f64| / max|g_f64| per tensor
 
 
-def mk(Vt=6, Ve=300, Vr=9, dt=16, de=32, dr=16, H=64, L=2, F=3, nT=1, reducer=2, K=5, impl="auto", seed=1, init=0.1):
-    eng = _ffi.Engine(Vt, Ve, Vr, dt, de, dr, H, L, F=F, num_types=nT, reducer=reducer, K=K)
+def mk(Vt=6, Ve=300, Vr=9, dt=16, de=32, dr=16, H=64, L=2, F=3, nT=1, reducer=2, K=5, impl="auto", seed=1, init=0.1, compute_dtype=0):
+    eng = _ffi.Engine(Vt, Ve, Vr, dt, de, dr, H, L, F=F, num_types=nT, reducer=reducer, K=K, compute_dtype=compute_dtype)
     eng.set_option("impl", impl)
     ocfg = make_cfg(Vt=Vt, Ve=Ve, Vr=Vr, dt=dt, de=de, dr=dr, F=F, numTypes=nT, H=H, L=L, reducer=reducer, K=K)
     o64 = Oracle(ocfg, np.float64)
@@ -731,12 +731,13 @@ def test_identical_prefix_plan_full_size_equals_no_plan(monkeypatch):
         assert abs(got[1] - ref[1]) < tol and abs(got[2] - ref[2]) < tol, (nm, got, ref)
 
 
-def test_scoring_pass_on_the_side_stream_changes_nothing():
+@pytest.mark.parametrize("compute_dtype", [0, 2])
+def test_scoring_pass_on_the_side_stream_changes_nothing(compute_dtype):
     """score_overlap: kprn_forward_batch_async on a second stream, sharing the chip with the train step enqueued behind it.
     Scores are those of the parameters BEFORE the step's update, and the training trajectory is untouched."""
     outs = []
     for overlap in ("0", "1"):
-        eng, o64, theta = mk(L=2, impl="auto")
+        eng, o64, theta = mk(L=2, impl="auto", compute_dtype=compute_dtype)
         eng.set_option("score_overlap", overlap)
         batches = [synth.make_paths(300, P, 6, Ve=300, seed=40 + P) for P in (2, 3)]
         gb = [eng.batch(i, l) for i, l in batches]
@@ -799,3 +800,52 @@ def test_identical_prefix_plan_random_shapes_agree_with_every_step_executed():
         if trial < 3:   # and against the oracle
             ol, og, _ = o64.forward_backward(theta, idx, labels)
             assert rel_inf(res[0][3], og) < GRAD_RTOL
+
+
+# ---- forward on the bf16 matrix cores (lstm_fused_fwd_mc.hip) ---------------------------------------------------------
+@pytest.mark.parametrize("L,P,T,pairs", [(1, 1, 6, 70), (2, 3, 6, 45), (2, 7, 3, 37), (1, 28, 4, 11), (2, 2, 12, 130)])
+def test_f32x6_forward_backward_hold_the_fp32_bars(L, P, T, pairs):
+    """compute_dtype = 2: fp32 operands split exactly into three bf16 pieces, six partial products per term on the matrix
+    cores, fp32 accumulation.  Same tolerances as the fp32-MFMA path: scores 2e-5, gradients 2e-4 of the tensor's largest."""
+    eng, o64, theta = mk(L=L, impl="auto", compute_dtype=2)
+    idx, labels = synth.make_paths(pairs, P, T, Ve=300, seed=300 + T + P)
+    b = eng.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "all_probs", "path_scores"))
+    ps, pooled, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5
+    np.testing.assert_allclose(out["all_probs"], probs, rtol=SCORE_RTOL)
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], og[off:off + n]) < GRAD_RTOL, (nm, L, P, T)
+    _train_compare(eng, o64, theta, [(idx, labels)], dict(method=1, lr=1e-2), 4, 2e-4)
+
+
+def test_f32x6_is_as_close_to_the_f64_oracle_as_fp32_mfma():
+    """the split products are exact and the dropped ones are below 2^-24: the f32x6 scores must not be further from the
+    float64 oracle than the fp32-MFMA scores are (both measured on the same parameters and paths)."""
+    errs = {}
+    for dt in (0, 2):
+        eng, o64, theta = mk(L=2, impl="auto", compute_dtype=dt)
+        idx, _ = synth.make_paths(400, 3, 6, Ve=300, seed=77)
+        out = eng.forward(eng.batch(idx), 1, want=("path_scores",))
+        ps, _, _ = o64.forward(theta, idx)
+        errs[dt] = rel_inf(out["path_scores"], ps)
+    assert errs[2] < 2e-6 and errs[2] < 3 * errs[0] + 1e-7, errs
+
+
+def test_bf16_fused_scoring_is_tolerance_gated():
+    """compute_dtype = 1 at D = H = 64: scoring on the fused matrix-core forward (operands rounded to bf16, fp32 accumulation)"""
+    eng, o64, theta = mk(L=2, impl="auto", compute_dtype=1)
+    idx, _ = synth.make_paths(200, 3, 6, Ve=300, seed=78)
+    out = eng.forward(eng.batch(idx), 1, want=("probs", "path_scores"))
+    ps, _, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 3e-2      # bf16 has 8 mantissa bits; 12 layer-steps deep
+    np.testing.assert_allclose(out["probs"], probs[:, 0], atol=2e-2)
+    # and it agrees with the generic bf16 pipeline (same rounding of the operands) much more closely than with the oracle
+    eng.set_option("impl", "generic")
+    out_g = eng.forward(eng.batch(idx), 1, want=("path_scores",))
+    assert rel_inf(out["path_scores"], out_g["path_scores"].astype(np.float64)) < 1e-2
