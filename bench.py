@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--compute-dtype", type=int, default=0, choices=[0, 1, 2],
                     help="0: fp32 MFMA (default, the headline).  2: f32x6 -- fp32 products formed exactly from bf16 pieces on the matrix "
                          "cores (forward only; same parity bars).  1: bf16 products (scoring only on the fused path)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short second measurement with compute_dtype 2 (f32x6) that is reported under \"alt_f32x6\"")
     ap.add_argument("--no-score-overlap", action="store_true",
                     help="run the scoring pass on the main stream, strictly before the train step (default: on a second stream, sharing "
                          "the chip with the training forward of the same step -- neither depends on the other)")
@@ -337,6 +338,45 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a, T, dt_, de_, dr_, H, L, a.cpu_seconds)
 
+    # ---- not the headline: the same workload with the forward on the bf16 matrix cores (compute_dtype 2, "f32x6": every fp32
+    #      operand split exactly into three bf16 pieces, six partial products, fp32 accumulation; error <= an fp32 FMA chain;
+    #      held to the same parity tolerances by tests/test_gpu_parity.py).  A short second run on a second engine.
+    alt = None
+    if rank == 0 and world == 1 and a.compute_dtype == 0 and not a.no_alt and not shipped and a.dims == "A" and not a.force_dp \
+            and not a.score_only and not a.train_only and a.impl == "auto":
+        eng2 = _ffi.Engine(Vt, Ve, Vr, dt_, de_, dr_, H, L, F=F, num_types=nT, C_=C, reducer=2, device_id=local_rank, rank=rank, world=world,
+                           param_init=0.1, seed=12345, stream=stream, compute_dtype=2)
+        eng2.set_option("score_overlap", "0" if a.no_score_overlap else "1")
+        b2 = []
+        for i, P in enumerate(Ps):
+            pairs = max(1, a.paths_per_step // P)
+            idx, labels = synth.make_paths(pairs, P, T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, num_types=nT, seed=12345 + 97 * i + 7919 * rank)
+            b2.append(eng2.batch(idx, labels))
+        def step2(i):
+            b = b2[i % len(b2)]
+            eng2.forward_async(b, 1)
+            eng2.train_step(b, opt, 1, want_loss=False)
+            return b.n_paths
+        for i in range(a.warmup):
+            step2(i)
+        eng2.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n2 = 0
+        k2 = a.steps
+        for i in range(k2):
+            n2 += step2(a.warmup + i)
+        eng2.sync()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t0
+        alt = {"value": round(n2 / e2, 1), "unit": "paths/s", "ms_per_step": round(1e3 * e2 / k2, 4), "steps": k2, "dtype": "f32x6",
+               "final_loss": round(float(eng2.read_loss()), 6),
+               "what": "same workload, forward GEMMs on the bf16 matrix cores from an exact 3-way bf16 split of every fp32 operand "
+                       "(6 partial products, fp32 accumulate; backward unchanged); opt-in via kprn_config.compute_dtype = 2"}
+        for b in b2:
+            b.free()
+        eng2.close() if hasattr(eng2, "close") else None
+
     if rank == 0:
         value = npaths_total / elapsed
         fwd_flops = sum(T * 2 * G * H * ((D if l == 0 else H) + H) for l in range(L)) + 2 * H * C
@@ -371,7 +411,7 @@ def main():
             "executed_tflops": round(exec_tflops, 3),
             "mfma_frac_end_to_end": round(exec_tflops / (PEAK_TFLOPS_F32_MFMA * world), 4),  # executed flops / wall clock / fp32 MFMA peak
             "final_loss": round(loss, 6),
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "alt_f32x6": alt, "kernels": kernels,
         }
         print(json.dumps(out))
     if world > 1 or a.force_dp:

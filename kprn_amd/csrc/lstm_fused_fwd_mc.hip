@@ -22,6 +22,10 @@
 // k-group of 8) is one ds_read_b128; the producer of a value splits it once (the gather for x, the cell for h).
 #include "lstm_fused_common.h"
 
+#ifndef MC_EXP
+#define MC_EXP 0  // timing experiments (wrong results): 1 no cell, 2 no MFMAs, 4 no h hand-over stores, 8 no barrier B, 16 no A-fragment reads
+#endif
+
 namespace fused {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
     for (int k = 0; k < NPL; ++k) *(f32x4*)(fb + k * 256) = sv[k];
   };
   auto hout_ptr = [&](int64_t q_tile, int q_t, int pm) -> float* {
-    return top ? nullptr : a.Hout + (((int64_t)q_tile * T + q_t) * MT + pm * 16 + ag * 4) * DH + j * 16 + arow;
+    return (top || (MC_EXP & 4)) ? nullptr : a.Hout + (((int64_t)q_tile * T + q_t) * MT + pm * 16 + ag * 4) * DH + j * 16 + arow;
   };
 
   // One unit = the 4-gate GEMM of a 16-row m-tile: [recurrent half over h_{t-1}] + [input half], K = 64 each = 2 chunks of 32,
@@ -300,9 +304,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
       constexpr int kc = chunk & 1;
       constexpr int sa = (NS == 3) ? mc_ta(term) : 0, sb = (NS == 3) ? mc_tb(term) : 0;
       constexpr bool has_next = (n / PER_CHUNK) + 1 < TOTAL / PER_CHUNK;
-      if constexpr (n < 4) MC_MFMA_C(acc[q], af[sa], w[src][q][kc][sb], bias4[q]);  // first MFMA of a gate's chain: srcC = the scaled bias
-      else MC_MFMA(acc[q], af[sa], w[src][q][kc][sb]);
-      if constexpr (has_next && term == 0 && q == 3) {
+      if constexpr (!(MC_EXP & 2)) {
+        if constexpr (n < 4) MC_MFMA_C(acc[q], af[sa], w[src][q][kc][sb], bias4[q]);  // first MFMA of a gate's chain: srcC = the scaled bias
+        else MC_MFMA(acc[q], af[sa], w[src][q][kc][sb]);
+      }
+      if constexpr (has_next && term == 0 && q == 3 && !(MC_EXP & 16)) {
         // the next chunk's A pieces: next 32 k of the same tile, or the first chunk of the input half
         const __bf16* nb = (kc == 0) ? ((src == 0) ? h_base : in_base) + 32 : in_base;
 #pragma unroll
@@ -312,16 +318,23 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) af[s] = an[s];
       }
-      if constexpr (CELL && n >= 2 && n < 66) {
-        mc_cell_step<NS, SAVE, ((n - 2) >> 4), ((n - 2) & 15)>(x, pacc, pc, phrow, phout, sv);
-        __builtin_amdgcn_sched_barrier(0);
+      // The 64 cell steps of the previous unit are spread EVENLY over the MFMA slots 2 .. TOTAL-1 (a step is 1-3 VALU ops,
+      // at most one transcendental): the VALU work per slot stays below the MFMA cadence, so neither pipe waits for the other.
+      constexpr int SLOTS = TOTAL - 2;
+      if constexpr (CELL && n >= 2) {
+        constexpr int k = (SLOTS >= 64) ? ((n - 2) * 64 + SLOTS - 1) / SLOTS : (n - 2);   // candidate step for this slot
+        constexpr bool here = (SLOTS >= 64) ? (k < 64 && 2 + (k * SLOTS) / 64 == n) : (k < 64);
+        if constexpr (here && !(MC_EXP & 1)) {
+          mc_cell_step<NS, SAVE, (k >> 4), (k & 15)>(x, pacc, pc, phrow, phout, sv);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     });
-    if constexpr (CELL && TOTAL < 66) {
-      // (bf16 mode, or a tile's first step: fewer than 66 MFMAs in the unit) the rest of the cell, exposed
+    if constexpr (CELL && TOTAL - 2 < 64) {
+      // (bf16 mode, or a tile's first step: fewer MFMA slots than cell steps) the rest of the cell, exposed
       static_for<0, 64>([&](auto ic) __attribute__((always_inline)) {
         constexpr int m = decltype(ic)::value;
-        if constexpr (m + 2 >= TOTAL) mc_cell_step<NS, SAVE, (m >> 4), (m & 15)>(x, pacc, pc, phrow, phout, sv);
+        if constexpr (m >= TOTAL - 2) mc_cell_step<NS, SAVE, (m >> 4), (m & 15)>(x, pacc, pc, phrow, phout, sv);
       });
     }
   };
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[q][r] += rec0[q];
         }
-        if (!FIRST) lds_barrier();  // (B) rows 48..63 of h_{t-1} (the cell that ran beside this unit) are complete in every wave
+        if (!FIRST && !(MC_EXP & 8)) lds_barrier();  // (B) rows 48..63 of h_{t-1} (the cell that ran beside this unit) are complete in every wave
       } else {
         if (FIRST) {
           unit(std::false_type{}, std::true_type{}, in_base, h_base, acc, pacc, c[pm], phrow, phout);
