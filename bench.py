@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--train-only", action="store_true")
     ap.add_argument("--score-only", action="store_true")
     ap.add_argument("--reserve-cus", type=int, default=16, help="CUs the scoring pass leaves to the collective in data-parallel runs")
-    ap.add_argument("--compute-dtype", type=int, default=0, choices=[0, 1, 2],
+    ap.add_argument("--compute-dtype", type=int, default=0, choices=[0, 1, 2, 3],
                     help="0: fp32 MFMA (default, the headline).  2: f32x6 -- fp32 products formed exactly from bf16 pieces on the matrix "
                          "cores (forward only; same parity bars).  1: bf16 products (scoring only on the fused path)")
     ap.add_argument("--no-alt", action="store_true", help="skip the short second measurement with compute_dtype 2 (f32x6) that is reported under \"alt_f32x6\"")
@@ -395,7 +395,7 @@ def main():
             "metric": "paths/sec (train+score) at path_len=6 d=64", "value": round(value, 1), "unit": "paths/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {0: "f32", 1: "bf16", 2: "f32x6"}[a.compute_dtype], "data": "synthetic",
+            "dtype": {0: "f32", 1: "bf16", 2: "f32x6", 3: "f32x3"}[a.compute_dtype], "data": "synthetic",
             "config": {"workload": (f"C2 KKBOX-MI synthetic: T={T}, D=H={H} ({dt_}/{de_}/{dr_}), L={L} FastLSTM, fp32, Ve={Ve}, "
                                     f"C=46, LSE pool, Adam; scoring pass + train step per batch") if not shipped else
                                    (f"run_scripts/config.sh as shipped, synthetic KKBox-shaped paths: T={T}, rnn (ReLU, MaskZero, identity init), "
@@ -404,7 +404,8 @@ def main():
                        "entity_update": "lazy-exact" if a.entity_update == 0 else "dense",
                        "score_overlap": not a.no_score_overlap,
                        "forward_arithmetic": {0: "fp32 MFMA", 1: "bf16 MFMA products, fp32 accumulate",
-                                              2: "f32x6: fp32 operands split exactly into 3 bf16 pieces, 6 partial products on the matrix cores, fp32 accumulate"}[a.compute_dtype],
+                                              2: "f32x6: fp32 operands split exactly into 3 bf16 pieces, 6 partial products on the matrix cores, fp32 accumulate",
+                                              3: "f32x3: pre-scaled fp32 operands as 2 fp16 pieces, 3 partial products on the matrix cores, fp32 accumulate"}[a.compute_dtype],
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "executed_step_fraction": round(exec_frac, 4),  # (path, step) positions executed / nominal: identical leading (pad) steps run once per batch
             "model_tflops_nominal": round(value * step_flops / 1e12, 3),   # as if every step of every path were computed

@@ -383,7 +383,7 @@ static bool use_fused(kprn_handle* h, const kprn_batch* b, bool save_for_backwar
   if (h->impl != 0 || h->cfg.rnn_type != 0 || !fused::fwd_supported(h, b->T)) return false;
   // compute_dtype 0 (f32 MFMA) and 2 (f32x6: exact fp32 products from bf16 pieces on the matrix cores): fused forward + backward;
   // 1 (bf16 products): the fused matrix-core forward for scoring, the generic pipeline for training
-  if (h->cfg.compute_dtype == 1) return !save_for_backward;
+  if (h->cfg.compute_dtype == 1) return !save_for_backward;  // (2, 3: forward on the matrix cores, fp32 backward)
   return !save_for_backward || fused::bwd_supported(h, b->T);
 }
 
@@ -730,8 +730,9 @@ int kprn_create(const kprn_config* cfg, kprn_handle** out) {
     KPRN_REQUIRE(c.F >= c.num_types + 2, KPRN_E_ARG, "numFeatureTemplates must cover types + entity + relation (FeatureEmbedding.lua:51)");
     KPRN_REQUIRE(c.H > 0 && c.C > 0, KPRN_E_ARG, "rnnHidSize and labelDimension must be positive");
     KPRN_REQUIRE(c.L >= 1 && c.L <= KPRN_MAX_LAYERS, KPRN_E_ARG, "numLayers must be in 1..8");
-    KPRN_REQUIRE(c.compute_dtype >= 0 && c.compute_dtype <= 2, KPRN_E_ARG,
-                 "compute_dtype must be 0 (f32 MFMA), 1 (bf16 MFMA products, f32 accumulate) or 2 (f32x6: fp32 products from bf16 pieces)");
+    KPRN_REQUIRE(c.compute_dtype >= 0 && c.compute_dtype <= 3, KPRN_E_ARG,
+                 "compute_dtype must be 0 (f32 MFMA), 1 (bf16 MFMA products, f32 accumulate), 2 (f32x6: fp32 products from 3 bf16 pieces) or "
+                 "3 (f32x3: from 2 fp16 pieces)");
     KPRN_REQUIRE(c.rnn_type >= 0 && c.rnn_type <= 2, KPRN_E_ARG, "rnn_type must be 0 (lstm), 1 (rnn) or 2 (gru)");
     KPRN_REQUIRE(c.reducer >= 0 && c.reducer <= 2, KPRN_E_ARG, "topK must be 0 (max), 1 (topK) or 2 (LogSumExp)");
     KPRN_REQUIRE(c.reducer != 1 || c.K >= 1, KPRN_E_ARG, "K must be >= 1 for the topK reducer");

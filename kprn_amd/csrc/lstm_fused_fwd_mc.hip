@@ -6,11 +6,13 @@
 // (scripts/ubench/mfma_bf16_overlap.hip: +8 cycles for exp2 + rcp behind a 17-cycle bf16 MFMA, +26 behind a 32-cycle fp32 one).
 //
 // compute_dtype (include/kprn.h):
-//   1  bf16:   operands rounded to bf16, products exact, fp32 accumulation                      NS = 1: 1 MFMA per K = 32
+//   1  bf16:   operands rounded to bf16, products exact, fp32 accumulation                      1 MFMA per K = 32
 //   2  f32x6:  every fp32 operand is split EXACTLY into three bf16 pieces (x = x1 + x2 + x3, 3 x 8 mantissa bits); the six
 //              partial products of weight >= 2^-16 relative to the leading one (11 12 21 13 22 31) are accumulated in fp32:
 //              the dropped ones are below 2^-24.  Error <= that of an fp32 FMA chain (measured on a 256x128x256 product:
-//              1.6e-7 of the largest result against 5.1e-7 for fp32 BLAS).                       NS = 3: 6 MFMAs per K = 32
+//              1.6e-7 of the largest result against 5.1e-7 for fp32 BLAS).                       6 MFMAs per K = 32
+//   3  f32x3:  two fp16 pieces (2 x 11 mantissa bits) of every power-of-two pre-scaled operand, three products (11 12 21); what
+//              is dropped is below 2^-22.                                                         3 MFMAs per K = 32
 //
 // Replaces, per layer, nn.Sequencer(nn.FastLSTM(D,H)) (model/OneModel.lua:268-274) [+ FeatureEmbedding gather, bottom layer;
 // + nn.Linear(H,46), top layer]; same tiles, wave ownership (wave j: hidden units 16j..16j+15 of all four gates), C layout,
@@ -18,7 +20,7 @@
 // The split weights (3 x 2 B per element) of ONE layer fill 192 of the 256 accumulation registers; the layers therefore run
 // as separate launches and hand h over through HBM ([tile][t][64 rows][64] fp32, 100 MB per pass at 65 536 paths).
 //
-// LDS: the step input (x_t / h^{l-1}_t) and h^l as NS planes of bf16 [64 rows][72], double-buffered: an A fragment (row,
+// LDS: the step input (x_t / h^{l-1}_t) and h^l as one plane per piece, 2-byte elements [64 rows][72], double-buffered: an A fragment (row,
 // k-group of 8) is one ds_read_b128; the producer of a value splits it once (the gather for x, the cell for h).
 #include "lstm_fused_common.h"
 
@@ -28,14 +30,26 @@
 
 namespace fused {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// How an fp32 operand travels to the matrix cores (template parameter M of everything below):
+//   M = 1  one bf16 piece (rounded), 1 product per K chunk                                                  compute_dtype 1
+//   M = 3  three bf16 pieces (exact), 6 products: 11 12 21 13 22 31                                         compute_dtype 2
+//   M = 2  two fp16 pieces (2 x 11 bits; what is dropped is below 2^-22), 3 products: 11 12 21.  fp16 has 5 exponent bits, so the
+//          operands are pre-scaled by powers of two (exact): W_o2g by 2^KW, x by 2^KA, W_i2g by 2^(KW-KA) -- every product then
+//          carries 2^KW, which the cell removes with one multiply per gate.  Residual pieces of values below 2^-3 / scale go
+//          subnormal: an ABSOLUTE error of 2^-25 / scale, negligible against the operand's range.               compute_dtype 3
+template <int M> struct McFmt;
+template <> struct McFmt<1> { typedef __bf16 E; static constexpr int NP = 1, NTERM = 1, KW = 0, KA = 0; };
+template <> struct McFmt<3> { typedef __bf16 E; static constexpr int NP = 3, NTERM = 6, KW = 0, KA = 0; };
+template <> struct McFmt<2> { typedef _Float16 E; static constexpr int NP = 2, NTERM = 3, KW = 8, KA = 4; };
+__device__ __host__ constexpr float mc_pow2(int k) { return k >= 0 ? (float)(1u << k) : 1.0f / (float)(1u << (-k)); }
 
 constexpr int LDB = DH + 8;  // bf16 row stride of an LDS plane: 144 B (16-byte aligned, spreads the ds_read_b128 slots)
 constexpr float MC_NLOG2E = -1.4426950408889634f;
 constexpr float MC_N2LOG2E = -2.8853900817779268f;
 
 #define MC_MFMA(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "a"(B_))
+#define MC_MFMA_H(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "a"(B_))
+#define MC_MFMA_HC(ACC, A_, B_, C_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(ACC) : "v"(A_), "a"(B_), "v"(C_))
 #define MC_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
 #define MC_MFMA_C(ACC, A_, B_, C_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(ACC) : "v"(A_), "a"(B_), "v"(C_))
 
@@ -62,29 +76,30 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<I + 1, N>(f);
   }
 }
-// the six partial products of a K chunk, (piece of A, piece of B), smallest first
-__device__ constexpr int mc_ta(int term) { return term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0; }
-__device__ constexpr int mc_tb(int term) { return term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0; }
+// the partial products of a K chunk, (piece of A, piece of B), smallest first
+__device__ constexpr int mc_ta(int M, int term) { return M == 3 ? (term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0) : M == 2 ? (term == 0 ? 1 : 0) : 0; }
+__device__ constexpr int mc_tb(int M, int term) { return M == 3 ? (term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0) : M == 2 ? (term == 1 ? 1 : 0) : 0; }
 
-template <int NS>
-__device__ __forceinline__ void split_store(float x, __bf16* p, int plane_stride) {
-  const __bf16 a = (__bf16)x;
-  p[0] = a;
-  if (NS == 3) {
-    const float r1 = x - (float)a;
-    const __bf16 b = (__bf16)r1;
-    p[plane_stride] = b;
-    p[2 * plane_stride] = (__bf16)(r1 - (float)b);
+template <int M>
+__device__ __forceinline__ void split_store(float x, typename McFmt<M>::E* p, int plane_stride) {
+  typedef typename McFmt<M>::E E;
+  float r = x;
+#pragma unroll
+  for (int s = 0; s < McFmt<M>::NP; ++s) {
+    const E piece = (E)r;
+    p[s * plane_stride] = piece;
+    r -= (float)piece;
   }
 }
 
 // ---- the cell of one accumulator register of the previous unit, in 16 small steps (same arithmetic as lstm_fused_fwd.hip) ----
 struct McCell { float m0, m1, m2, m3, e0, e1, e2, e3, i, g, f, o, ig, c, cp, t; };
-template <int NS, bool SAVE, int R, int K>
-__device__ __forceinline__ void mc_cell_step(McCell& x, const f32x4 (&acc)[4], float (&cst)[4], __bf16* hrow, float* hout, f32x4 (&sv)[NPL]) {
-  if (K == 0) { x.m0 = acc[0][R]; x.m1 = acc[1][R]; }  // (pre-activations arrive scaled for exp2)
-  if (K == 1) { x.e0 = __builtin_amdgcn_exp2f(x.m0); x.m2 = acc[2][R]; }
-  if (K == 2) { x.e1 = __builtin_amdgcn_exp2f(x.m1); x.m3 = acc[3][R]; }
+template <int M, bool SAVE, int R, int K>
+__device__ __forceinline__ void mc_cell_step(McCell& x, const f32x4 (&acc)[4], float (&cst)[4], typename McFmt<M>::E* hrow, float* hout, f32x4 (&sv)[NPL]) {
+  constexpr float INV = mc_pow2(-McFmt<M>::KW);  // (1 for the bf16 forms: no multiply is emitted)
+  if (K == 0) { x.m0 = acc[0][R] * INV; x.m1 = acc[1][R] * INV; }  // (pre-activations arrive scaled for exp2)
+  if (K == 1) { x.e0 = __builtin_amdgcn_exp2f(x.m0); x.m2 = acc[2][R] * INV; }
+  if (K == 2) { x.e1 = __builtin_amdgcn_exp2f(x.m1); x.m3 = acc[3][R] * INV; }
   if (K == 3) { x.e2 = __builtin_amdgcn_exp2f(x.m2); x.e0 += 1.0f; }
   if (K == 4) { x.e3 = __builtin_amdgcn_exp2f(x.m3); x.e1 += 1.0f; }
   if (K == 5) { x.i = __builtin_amdgcn_rcpf(x.e0); x.e2 += 1.0f; }
@@ -99,7 +114,7 @@ __device__ __forceinline__ void mc_cell_step(McCell& x, const f32x4 (&acc)[4], f
   if (K == 14) { x.t = 2.0f * x.t - 1.0f; }
   if (K == 15) {
     const float hh = x.o * x.t;
-    split_store<NS>(hh, hrow + R * LDB, MT * LDB);
+    split_store<M>(hh, hrow + R * LDB, MT * LDB);
     if (hout) hout[R * DH] = hh;
     if (SAVE) {
       sv[0][R] = x.ig * (1.0f - x.i);
@@ -112,18 +127,19 @@ __device__ __forceinline__ void mc_cell_step(McCell& x, const f32x4 (&acc)[4], f
     }
   }
 }
-template <int NS, bool SAVE>
-__device__ __forceinline__ void mc_cell_all(const f32x4 (&acc)[4], float (&cst)[4], __bf16* hrow, float* hout, f32x4 (&sv)[NPL]) {
+template <int M, bool SAVE>
+__device__ __forceinline__ void mc_cell_all(const f32x4 (&acc)[4], float (&cst)[4], typename McFmt<M>::E* hrow, float* hout, f32x4 (&sv)[NPL]) {
   McCell x;
   static_for<0, 64>([&](auto ic) __attribute__((always_inline)) {
     constexpr int n = decltype(ic)::value;
-    mc_cell_step<NS, SAVE, (n >> 4), (n & 15)>(x, acc, cst, hrow, hout, sv);
+    mc_cell_step<M, SAVE, (n >> 4), (n & 15)>(x, acc, cst, hrow, hout, sv);
   });
 }
 
 // nn.Linear(H, C) on the tile's h_T (LDS planes; fp32 = exact sum of the pieces) -> S[n][0..C), fp32 MFMA (1 % of the work)
-template <int NS>
-__device__ __forceinline__ void mc_head_tile(const McArgs& a, const __bf16* hpl, int64_t tile, int j, int lane) {
+template <int M>
+__device__ __forceinline__ void mc_head_tile(const McArgs& a, const typename McFmt<M>::E* hpl, int64_t tile, int j, int lane) {
+  typedef typename McFmt<M>::E E;
   const int ntiles = (a.C + 15) >> 4;
   const int arow = lane & 15, ag = lane >> 4;
   for (int nt = j; nt < ntiles; nt += 4) {
@@ -138,12 +154,13 @@ __device__ __forceinline__ void mc_head_tile(const McArgs& a, const __bf16* hpl,
       f32x4 acc = f32x4{b, b, b, b};
 #pragma unroll
       for (int S = 0; S < 4; ++S) {
-        const __bf16* p = hpl + (mt * 16 + arow) * LDB + S * 16 + ag * 4;
+        const E* p = hpl + (mt * 16 + arow) * LDB + S * 16 + ag * 4;
         f32x4 a4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = (float)p[e];
-          if (NS == 3) v += (float)p[MT * LDB + e] + (float)p[2 * MT * LDB + e];
+#pragma unroll
+          for (int s2 = 1; s2 < McFmt<M>::NP; ++s2) v += (float)p[s2 * MT * LDB + e];
           a4[e] = v;
         }
 #pragma unroll
@@ -160,15 +177,19 @@ __device__ __forceinline__ void mc_head_tile(const McArgs& a, const __bf16* hpl,
   }
 }
 
-template <int NS, bool SAVE>
+template <int M, bool SAVE>
 __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
+  typedef McFmt<M> F;
+  typedef typename F::E E;                   // 2-byte element of the pieces (bf16 or fp16)
+  typedef E Ex4 __attribute__((ext_vector_type(4)));
+  constexpr int NS = F::NP;                  // pieces per operand
   constexpr int NT = 256;
   constexpr int PLANE = MT * LDB;            // bf16 elements per plane
-  constexpr int NTERM = (NS == 3) ? 6 : 1;   // partial products per K chunk
+  constexpr int NTERM = F::NTERM;            // partial products per K chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __bf16* planes = (__bf16*)lds;
-  auto inb = [&](int i) -> __bf16* { return planes + (i * NS) * PLANE; };          // step input, buffer i
-  auto hb = [&](int i) -> __bf16* { return planes + ((2 + i) * NS) * PLANE; };     // this layer's h, buffer i
+  E* planes = (E*)lds;
+  auto inb = [&](int i) -> E* { return planes + (i * NS) * PLANE; };          // step input, buffer i
+  auto hb = [&](int i) -> E* { return planes + ((2 + i) * NS) * PLANE; };     // this layer's h, buffer i
   int32_t* idb0 = (int32_t*)(planes + 4 * NS * PLANE);
   auto idbuf = [&](int i) -> int32_t* { return idb0 + i * (MT * MAXT_LDS * 4); };
   float* pft = (float*)idbuf(2);             // [KCAP+1][PFB] this layer's prefix classes
@@ -229,26 +250,20 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
       }
     }
   };
-  auto in_store = [&](__bf16* dst) {
+  auto in_store = [&](E* dst) {
+    const float xs = bottom ? mc_pow2(F::KA) : 1.0f;  // (fp16 pieces: the table rows are pre-scaled, W_i2g carries the inverse)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int row = (threadIdx.x >> 4) + k * 16, ch = threadIdx.x & 15;
-      __bf16* p = dst + row * LDB + ch * 4;
-      bf16x4 p1, p2, p3;
+      E* p = dst + row * LDB + ch * 4;
+      f32x4 r = gv[k] * xs;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x = gv[k][e];
-        const __bf16 b1 = (__bf16)x;
-        p1[e] = b1;
-        if (NS == 3) {
-          const float r1 = x - (float)b1;
-          const __bf16 b2 = (__bf16)r1;
-          p2[e] = b2;
-          p3[e] = (__bf16)(r1 - (float)b2);
-        }
+      for (int s2 = 0; s2 < NS; ++s2) {
+        Ex4 piece;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { piece[e] = (E)r[e]; r[e] -= (float)piece[e]; }
+        *(Ex4*)(p + s2 * PLANE) = piece;
       }
-      *(bf16x4*)p = p1;
-      if (NS == 3) { *(bf16x4*)(p + PLANE) = p2; *(bf16x4*)(p + 2 * PLANE) = p3; }
     }
   };
 
@@ -282,8 +297,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
   // One unit = the 4-gate GEMM of a 16-row m-tile: [recurrent half over h_{t-1}] + [input half], K = 64 each = 2 chunks of 32,
   // NTERM MFMAs per (gate, chunk); the cell of the PREVIOUS unit is issued one step behind each of the first 64 MFMAs and
   // (two MFMAs later: the previous unit's last results have landed by then) executes beside them.  Accumulator chains: the gates alternate, so an accumulator is touched every 4th MFMA.
-  auto unit = [&](auto rec_tag, auto cell_tag, const __bf16* in_base, const __bf16* h_base, f32x4 (&acc)[4], const f32x4 (&pacc)[4], float (&pc)[4],
-                  __bf16* phrow, float* phout) __attribute__((always_inline)) {
+  auto unit = [&](auto rec_tag, auto cell_tag, const E* in_base, const E* h_base, f32x4 (&acc)[4], const f32x4 (&pacc)[4], float (&pc)[4],
+                  E* phrow, float* phout) __attribute__((always_inline)) {
     constexpr bool REC = decltype(rec_tag)::value;
     constexpr bool CELL = decltype(cell_tag)::value;
     constexpr int PER_CHUNK = 4 * NTERM;                   // MFMAs per K chunk of 32
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
     McCell x;
     f32x4 af[NS], an[NS];  // (128-bit containers of 8 bf16) the running chunk's A pieces / the next chunk's
     {
-      const __bf16* first = (REC ? h_base : in_base);
+      const E* first = (REC ? h_base : in_base);
 #pragma unroll
       for (int s = 0; s < NS; ++s) af[s] = *(const f32x4*)(first + s * PLANE);
     }
@@ -302,15 +317,20 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
       constexpr int chunk = n / PER_CHUNK;
       constexpr int src = REC ? (chunk >> 1) : 1;            // 0 = recurrent half (h_{t-1}), 1 = input half
       constexpr int kc = chunk & 1;
-      constexpr int sa = (NS == 3) ? mc_ta(term) : 0, sb = (NS == 3) ? mc_tb(term) : 0;
+      constexpr int sa = mc_ta(M, term), sb = mc_tb(M, term);
       constexpr bool has_next = (n / PER_CHUNK) + 1 < TOTAL / PER_CHUNK;
       if constexpr (!(MC_EXP & 2)) {
-        if constexpr (n < 4) MC_MFMA_C(acc[q], af[sa], w[src][q][kc][sb], bias4[q]);  // first MFMA of a gate's chain: srcC = the scaled bias
-        else MC_MFMA(acc[q], af[sa], w[src][q][kc][sb]);
+        if constexpr (M == 2) {
+          if constexpr (n < 4) MC_MFMA_HC(acc[q], af[sa], w[src][q][kc][sb], bias4[q]);
+          else MC_MFMA_H(acc[q], af[sa], w[src][q][kc][sb]);
+        } else {
+          if constexpr (n < 4) MC_MFMA_C(acc[q], af[sa], w[src][q][kc][sb], bias4[q]);  // first MFMA of a gate's chain: srcC = the scaled bias
+          else MC_MFMA(acc[q], af[sa], w[src][q][kc][sb]);
+        }
       }
       if constexpr (has_next && term == 0 && q == 3 && !(MC_EXP & 16)) {
         // the next chunk's A pieces: next 32 k of the same tile, or the first chunk of the input half
-        const __bf16* nb = (kc == 0) ? ((src == 0) ? h_base : in_base) + 32 : in_base;
+        const E* nb = (kc == 0) ? ((src == 0) ? h_base : in_base) + 32 : in_base;
 #pragma unroll
         for (int s = 0; s < NS; ++s) an[s] = *(const f32x4*)(nb + s * PLANE);
       }
@@ -325,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
         constexpr int k = (SLOTS >= 64) ? ((n - 2) * 64 + SLOTS - 1) / SLOTS : (n - 2);   // candidate step for this slot
         constexpr bool here = (SLOTS >= 64) ? (k < 64 && 2 + (k * SLOTS) / 64 == n) : (k < 64);
         if constexpr (here && !(MC_EXP & 1)) {
-          mc_cell_step<NS, SAVE, (k >> 4), (k & 15)>(x, pacc, pc, phrow, phout, sv);
+          mc_cell_step<M, SAVE, (k >> 4), (k & 15)>(x, pacc, pc, phrow, phout, sv);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
       // (bf16 mode, or a tile's first step: fewer MFMA slots than cell steps) the rest of the cell, exposed
       static_for<0, 64>([&](auto ic) __attribute__((always_inline)) {
         constexpr int m = decltype(ic)::value;
-        if constexpr (m >= TOTAL - 2) mc_cell_step<NS, SAVE, (m >> 4), (m & 15)>(x, pacc, pc, phrow, phout, sv);
+        if constexpr (m >= TOTAL - 2) mc_cell_step<M, SAVE, (m >> 4), (m & 15)>(x, pacc, pc, phrow, phout, sv);
       });
     }
   };
@@ -347,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
       if (cls > 0) {  // (uniform) prefix class: c_prefix, and W_o2g h_prefix joins the first step's pre-activations
         cinit = pft[cls * PFB + 4 * DH + j * 16 + arow];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rec0[q] = pft[cls * PFB + q * DH + j * 16 + arow] * ((q == 1) ? MC_N2LOG2E : MC_NLOG2E);
+        for (int q = 0; q < 4; ++q) rec0[q] = pft[cls * PFB + q * DH + j * 16 + arow] * ((q == 1) ? MC_N2LOG2E : MC_NLOG2E) * mc_pow2(F::KW);
       }
 #pragma unroll
       for (int m = 0; m < 3; ++m)
@@ -363,22 +383,22 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
       const int q_par = cross ? (par ^ 1) : par;
       f32x4(&acc)[4] = accs[mt & 1];
       f32x4(&pacc)[4] = accs[(mt & 1) ^ 1];
-      __bf16* phrow = hb(q_par) + pm * 16 * LDB + o_off;
+      E* phrow = hb(q_par) + pm * 16 * LDB + o_off;
       float* phout = hout_ptr(q_tile, q_t, pm);
-      const __bf16* in_base = inb(par) + mt * 16 * LDB + a_off;
-      const __bf16* h_base = hb(par ^ 1) + mt * 16 * LDB + a_off;
+      const E* in_base = inb(par) + mt * 16 * LDB + a_off;
+      const E* h_base = hb(par ^ 1) + mt * 16 * LDB + a_off;
       if constexpr (mt == 0) {
         if (FIRST) {
           // tile switch: the previous tile's last cell first (its h_T row block completes the head's input), then the head
           if (has_prev) {
             MC_DRAIN();
-            mc_cell_all<NS, SAVE>(pacc, c[3], phrow, phout, sv);
+            mc_cell_all<M, SAVE>(pacc, c[3], phrow, phout, sv);
             save_unit(q_tile, q_t, pm);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) c[3][r] = cinit;
           lds_barrier();  // (A) this step's input tile is complete; previous tile's h_T complete
-          if (has_prev && top) mc_head_tile<NS>(a, hb(q_par), p_tile, j, lane);
+          if (has_prev && top) mc_head_tile<M>(a, hb(q_par), p_tile, j, lane);
           unit(std::false_type{}, std::false_type{}, in_base, h_base, acc, pacc, c[pm], phrow, phout);
         } else {
           lds_barrier();  // (A) input tile of this step + rows 0..47 of h_{t-1} are complete
@@ -443,48 +463,50 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
   // drain: the cell of the very last unit, then the last tile's head
   {
     MC_DRAIN();
-    mc_cell_all<NS, SAVE>(accs[1], c[3], hb(par) + 3 * 16 * LDB + o_off, hout_ptr(p_tile, p_t, 3), sv);
+    mc_cell_all<M, SAVE>(accs[1], c[3], hb(par) + 3 * 16 * LDB + o_off, hout_ptr(p_tile, p_t, 3), sv);
     save_unit(p_tile, p_t, 3);
     lds_barrier();
-    if (top) mc_head_tile<NS>(a, hb(par), p_tile, j, lane);
+    if (top) mc_head_tile<M>(a, hb(par), p_tile, j, lane);
   }
 }
 
 // ---- split weights in register order (rebuilt when the parameters change) ----
-struct McPrepArgs { const float* Wi; const float* Wo; const float* bi; uint4* wsp; float* bias_sc; int ns; };
+struct McPrepArgs { const float* Wi; const float* Wo; const float* bi; uint4* wsp; float* bias_sc; int layer; };
+template <int M>
 __global__ void k_mc_prep(McPrepArgs a) {
+  typedef McFmt<M> F;
+  typedef typename F::E E;
+  typedef E Ex8 __attribute__((ext_vector_type(8)));
   // one thread per (src, q, kc, wave, lane): 8 consecutive k of one gate column
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 256) a.bias_sc[i] = a.bi[i] * (((i >> 6) == 1) ? MC_N2LOG2E : MC_NLOG2E);
+  if (i < 256) a.bias_sc[i] = a.bi[i] * (((i >> 6) == 1) ? MC_N2LOG2E : MC_NLOG2E) * mc_pow2(F::KW);
   if (i >= 2 * 4 * 2 * 4 * 64) return;
   const int lane = i & 63, jw = (i >> 6) & 3, kc = (i >> 8) & 1, q = (i >> 9) & 3, src = i >> 11;
   const int arow = lane & 15, ag = lane >> 4;
   const float* W = (src == 0) ? a.Wo : a.Wi;  // src 0 = recurrent half (W_o2g), 1 = input half (W_i2g)
-  const float sc = (q == 1) ? MC_N2LOG2E : MC_NLOG2E;
+  // exp2 scaling of the gate, and (fp16 pieces) the power-of-two range scaling: the input half of the bottom layer sees
+  // table rows scaled by 2^KA, so its weights carry 2^(KW-KA); everything else 2^KW
+  const int ksc = (src == 1 && a.layer == 0) ? F::KW - F::KA : F::KW;
+  const float sc = ((q == 1) ? MC_N2LOG2E : MC_NLOG2E) * mc_pow2(ksc);
   const float* row = W + (int64_t)(q * DH + jw * 16 + arow) * DH + kc * 32 + ag * 8;
-  bf16x8 p[3];
+  Ex8 p[F::NP];
   for (int e = 0; e < 8; ++e) {
-    const float x = row[e] * sc;
-    const __bf16 b1 = (__bf16)x;
-    p[0][e] = b1;
-    const float r1 = x - (float)b1;
-    const __bf16 b2 = (__bf16)r1;
-    p[1][e] = b2;
-    p[2][e] = (__bf16)(r1 - (float)b2);
+    float r = row[e] * sc;
+    for (int s = 0; s < F::NP; ++s) { const E piece = (E)r; p[s][e] = piece; r -= (float)piece; }
   }
-  for (int s = 0; s < a.ns; ++s) a.wsp[((((src * 4 + q) * 2 + kc) * a.ns + s) * 4 + jw) * 64 + lane] = __builtin_bit_cast(uint4, p[s]);
+  for (int s = 0; s < F::NP; ++s) a.wsp[((((src * 4 + q) * 2 + kc) * F::NP + s) * 4 + jw) * 64 + lane] = __builtin_bit_cast(uint4, p[s]);
 }
 
 // ---- host side ----
-template <int NS, bool SAVE>
+template <int M, bool SAVE>
 static void launch_mc(kprn_handle* h, const McArgs& a, int grid) {
-  const size_t lds_bytes = (size_t)4 * NS * MT * LDB * sizeof(__bf16) + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t) + (size_t)(KCAP + 1) * PFB * sizeof(float);
+  const size_t lds_bytes = (size_t)4 * McFmt<M>::NP * MT * LDB * 2 + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t) + (size_t)(KCAP + 1) * PFB * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd_mc<NS, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd_mc<M, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_lstm_fwd_mc<NS, SAVE>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
+  hipLaunchKernelGGL((k_lstm_fwd_mc<M, SAVE>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());
 }
 
@@ -493,7 +515,7 @@ void mc_prepare(kprn_handle* h) {
   const kprn_config& c = h->cfg;
   if (c.compute_dtype == 0) return;
   State* s = st(h);
-  const int ns = (c.compute_dtype == 2) ? 3 : 1;
+  const int ns = (c.compute_dtype == 2) ? 3 : (c.compute_dtype == 3) ? 2 : 1;  // format M of McFmt
   if (!s->mc_wsp) {
     HIP_TRY(hipMalloc((void**)&s->mc_wsp, (size_t)2 * 2 * 4 * 2 * 3 * 4 * 64 * sizeof(uint4)));
     HIP_TRY(hipMalloc((void**)&s->mc_bias, (size_t)2 * 256 * sizeof(float)));
@@ -506,8 +528,10 @@ void mc_prepare(kprn_handle* h) {
     for (int l = 0; l < c.L; ++l) {
       McPrepArgs pa;
       pa.Wi = h->dense + h->layer[l].Wi; pa.Wo = h->dense + h->layer[l].Wo; pa.bi = h->dense + h->layer[l].bi;
-      pa.wsp = (uint4*)s->mc_wsp + l * wsp_layer; pa.bias_sc = s->mc_bias + l * 256; pa.ns = ns;
-      hipLaunchKernelGGL(k_mc_prep, dim3(16), dim3(256), 0, h->stream, pa);
+      pa.wsp = (uint4*)s->mc_wsp + l * wsp_layer; pa.bias_sc = s->mc_bias + l * 256; pa.layer = l;
+      if (ns == 3) hipLaunchKernelGGL(k_mc_prep<3>, dim3(16), dim3(256), 0, h->stream, pa);
+      else if (ns == 2) hipLaunchKernelGGL(k_mc_prep<2>, dim3(16), dim3(256), 0, h->stream, pa);
+      else hipLaunchKernelGGL(k_mc_prep<1>, dim3(16), dim3(256), 0, h->stream, pa);
     }
     HIP_TRY(hipGetLastError());
     s->mc_dirty = false; s->mc_ns = ns;
@@ -518,7 +542,7 @@ void mc_prepare(kprn_handle* h) {
 void forward_mc(kprn_handle* h, const kprn_batch* b, bool save) {
   const kprn_config& c = h->cfg;
   State* s = st(h);
-  const int ns = (c.compute_dtype == 2) ? 3 : 1;
+  const int ns = (c.compute_dtype == 2) ? 3 : (c.compute_dtype == 3) ? 2 : 1;  // format M of McFmt
   const int64_t N = (int64_t)b->B * b->P;
   const int L = c.L;
   const int64_t n_tiles = (N + MT - 1) / MT;
@@ -561,6 +585,7 @@ void forward_mc(kprn_handle* h, const kprn_batch* b, bool save) {
     a.n_tiles = n_tiles;
     ProfScope ps(h, save ? "lstm_mc_fwd_train" : "lstm_mc_fwd");
     if (ns == 3) { if (save) launch_mc<3, true>(h, a, grid); else launch_mc<3, false>(h, a, grid); }
+    else if (ns == 2) { if (save) launch_mc<2, true>(h, a, grid); else launch_mc<2, false>(h, a, grid); }
     else { if (save) launch_mc<1, true>(h, a, grid); else launch_mc<1, false>(h, a, grid); }
   }
 }

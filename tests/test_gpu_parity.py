@@ -731,7 +731,7 @@ def test_identical_prefix_plan_full_size_equals_no_plan(monkeypatch):
         assert abs(got[1] - ref[1]) < tol and abs(got[2] - ref[2]) < tol, (nm, got, ref)
 
 
-@pytest.mark.parametrize("compute_dtype", [0, 2])
+@pytest.mark.parametrize("compute_dtype", [0, 2, 3])
 def test_scoring_pass_on_the_side_stream_changes_nothing(compute_dtype):
     """score_overlap: kprn_forward_batch_async on a second stream, sharing the chip with the train step enqueued behind it.
     Scores are those of the parameters BEFORE the step's update, and the training trajectory is untouched."""
@@ -803,11 +803,13 @@ def test_identical_prefix_plan_random_shapes_agree_with_every_step_executed():
 
 
 # ---- forward on the bf16 matrix cores (lstm_fused_fwd_mc.hip) ---------------------------------------------------------
+@pytest.mark.parametrize("compute_dtype", [2, 3])
 @pytest.mark.parametrize("L,P,T,pairs", [(1, 1, 6, 70), (2, 3, 6, 45), (2, 7, 3, 37), (1, 28, 4, 11), (2, 2, 12, 130)])
-def test_f32x6_forward_backward_hold_the_fp32_bars(L, P, T, pairs):
+def test_f32x6_forward_backward_hold_the_fp32_bars(L, P, T, pairs, compute_dtype):
     """compute_dtype = 2: fp32 operands split exactly into three bf16 pieces, six partial products per term on the matrix
-    cores, fp32 accumulation.  Same tolerances as the fp32-MFMA path: scores 2e-5, gradients 2e-4 of the tensor's largest."""
-    eng, o64, theta = mk(L=L, impl="auto", compute_dtype=2)
+    cores, fp32 accumulation (3: two fp16 pieces of the pre-scaled operands, three products).  Same tolerances as the fp32-MFMA
+    path: scores 2e-5, gradients 2e-4 of the tensor's largest."""
+    eng, o64, theta = mk(L=L, impl="auto", compute_dtype=compute_dtype)
     idx, labels = synth.make_paths(pairs, P, T, Ve=300, seed=300 + T + P)
     b = eng.batch(idx, labels)
     out = eng.forward(b, 1, want=("probs", "all_probs", "path_scores"))
@@ -828,13 +830,15 @@ def test_f32x6_is_as_close_to_the_f64_oracle_as_fp32_mfma():
     """the split products are exact and the dropped ones are below 2^-24: the f32x6 scores must not be further from the
     float64 oracle than the fp32-MFMA scores are (both measured on the same parameters and paths)."""
     errs = {}
-    for dt in (0, 2):
+    for dt in (0, 2, 3):
         eng, o64, theta = mk(L=2, impl="auto", compute_dtype=dt)
         idx, _ = synth.make_paths(400, 3, 6, Ve=300, seed=77)
         out = eng.forward(eng.batch(idx), 1, want=("path_scores",))
         ps, _, _ = o64.forward(theta, idx)
         errs[dt] = rel_inf(out["path_scores"], ps)
+    print(errs)
     assert errs[2] < 2e-6 and errs[2] < 3 * errs[0] + 1e-7, errs
+    assert errs[3] < 2e-6 and errs[3] < 3 * errs[0] + 1e-7, errs
 
 
 def test_bf16_fused_scoring_is_tolerance_gated():
