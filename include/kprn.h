@@ -78,7 +78,10 @@ typedef struct {
                                     three bf16 pieces and the six partial products of weight >= 2^-16 are accumulated in f32; the
                                     dropped products are below 2^-24, i.e. the error is that of an fp32 FMA chain or smaller.
                                     Fused path only (forward on the matrix cores, backward as for 0); held to the same parity
-                                    tolerances as 0.  New options, not in the reference.                                       */
+                                    tolerances as 0.
+                                3 = f32x3: as 2 with two fp16 pieces (2 x 11 mantissa bits) of every power-of-two pre-scaled
+                                    operand and three partial products: half the matrix instructions of 2; the operands keep 22
+                                    of their 24 mantissa bits.  Same tolerances.  New options, not in the reference.            */
   int32_t reducer;           /* -topK: 0 = Max, 1 = TopK+Mean, 2 = LogSumExp (OneModel.lua:284-293) */
   int32_t K;                 /* -K                                                               */
   int32_t device_id;         /* HIP device ordinal                                               */
