@@ -12,11 +12,15 @@ timeout 300 python bench.py --no-cpu-baseline --train-only > gpurun_out/bench_${
 json_line gpurun_out/bench_${TAG}_train_only.log gpurun_out/bench_${TAG}_train_only.json
 timeout 300 python bench.py --no-cpu-baseline --score-only > gpurun_out/bench_${TAG}_score_only.log 2>&1
 json_line gpurun_out/bench_${TAG}_score_only.log gpurun_out/bench_${TAG}_score_only.json
+for cd in 2 3; do
+  timeout 300 python bench.py --no-cpu-baseline --no-alt --compute-dtype $cd > gpurun_out/bench_${TAG}_dtype$cd.log 2>&1
+  json_line gpurun_out/bench_${TAG}_dtype$cd.log gpurun_out/bench_${TAG}_dtype$cd.json
+done
 bash scripts/gpu_profile.sh $TAG > gpurun_out/prof_$TAG.txt 2>&1
 bash scripts/gpu_pmc.sh $TAG > gpurun_out/pmc_$TAG.txt 2>&1
 python - <<PY
 import json
-for f in ("bench_$TAG", "bench_${TAG}_train_only", "bench_${TAG}_score_only"):
+for f in ("bench_$TAG", "bench_${TAG}_train_only", "bench_${TAG}_score_only", "bench_${TAG}_dtype2", "bench_${TAG}_dtype3"):
     try:
         d = json.load(open("gpurun_out/%s.json" % f))
         print(f, d["value"], d["ms_per_step"], d.get("roofline"), d.get("cpu_baseline"))
