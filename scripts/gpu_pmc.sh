@@ -11,7 +11,7 @@ rocprofv3 -L 2>/dev/null | grep -i -E "mfma|^.*SQ_BUSY_CU|SQ_WAVE_CYCLES|SQ_ACTI
 pass() {  # name, counters...
   local name="$1"; shift
   timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d "$OUT/raw_$name" -o p --output-format csv -- \
-      python "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-events "${EXTRA[@]}" > "$OUT/$name.log" 2>&1
+      python "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-alt --no-kernel-events "${EXTRA[@]}" > "$OUT/$name.log" 2>&1
   echo "rocprof exit: $?" >> "$OUT/$name.log"
   find "$OUT/raw_$name" -name "*counter_collection.csv" -exec cp {} "$OUT/$name.csv" \;
   rm -rf "$OUT/raw_$name"

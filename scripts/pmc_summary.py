@@ -30,6 +30,8 @@ def load(path):
 
 def short(name):
     """kernel family as bench.py's profiler names it"""
+    if "k_lstm_fwd_mc" in name:
+        return "lstm_mc_fwd_train" if "true>" in name else "lstm_mc_fwd"
     if "k_lstm_fwd" in name:
         return "lstm_fused_fwd_train" if ", true>" in name.replace(" ", " ") else "lstm_fused_fwd"
     if "k_lstm_bwd" in name:
