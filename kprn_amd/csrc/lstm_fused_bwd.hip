@@ -296,6 +296,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         }
       }
       KPRN_MFMA_DRAIN();  // ax / ah are read by VALU and stores below
+      KPRN_PIN_V4(ax);
+      if (REC) KPRN_PIN_V4(ah);
       if (BOTTOM && REC) gather_store<256>(in_t, nin);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         // acc_s lives across the rest of the launch: if hipcc parks it (spill store / register copy) right behind the
         // last MFMA it reads a result that has not landed (seen as intermittently wrong type / relation gradients)
         KPRN_MFMA_DRAIN();
+        KPRN_PIN_V2(acc_s, acc_s2);
       }
       TPROBE(4)  // stage E (dX MFMAs) + outputs
       lds_barrier();  // dA_t free for reuse, x_{t-1} tile visible
@@ -349,6 +352,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   // k_reduce_partials sums the slabs (device-scope atomics from 256 workgroups onto the same 128 KB
   // were measured slower: they execute at the memory side, the per-XCD L2s are not coherent)
   KPRN_MFMA_DRAIN();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) KPRN_PIN_A8(dwi[q], dwo[q]);
+  if constexpr (BOTTOM && SMALL) KPRN_PIN_V2(acc_s, acc_s2);
   {
     float* pw = a.part + (int64_t)blockIdx.x * PART;
 #pragma unroll

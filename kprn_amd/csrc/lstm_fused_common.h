@@ -162,6 +162,15 @@ constexpr int NPL = 7;
 #define KPRN_MFMA_VV(ACC, A_, B_) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A_), "v"(B_))
 #define KPRN_MFMA_VVZ(ACC, A_, B_) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A_), "v"(B_))
 #define KPRN_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+// A drain orders nothing for hipcc's scheduler by itself: an operand-less asm statement has no data dependency on the values it
+// protects, and a VALU read of an MFMA result may be scheduled above it (seen on the matrix-core forward: the first two
+// registers of the last cell read accumulators that had not landed).  Every drain is therefore followed by a PIN of the
+// accumulators about to be read: an empty asm that takes them as read-write operands.  asm volatile statements keep their
+// order (MFMAs -> drain -> pin), and every later use of the values depends on the pin.
+#define KPRN_PIN_V4(A) asm volatile("" : "+v"((A)[0]), "+v"((A)[1]), "+v"((A)[2]), "+v"((A)[3]))
+#define KPRN_PIN_V2(X, Y) asm volatile("" : "+v"(X), "+v"(Y))
+#define KPRN_PIN_A8(A, B) \
+  asm volatile("" : "+a"((A)[0]), "+a"((A)[1]), "+a"((A)[2]), "+a"((A)[3]), "+a"((B)[0]), "+a"((B)[1]), "+a"((B)[2]), "+a"((B)[3]))
 
 // ---- host-side state shared by forward() and backward() ----
 struct State {

@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
         } else if (mt == 0) {
           if (!cross || has_prev) {
             KPRN_MFMA_DRAIN();  // last MFMAs of the previous unit -> VALU reads
+            KPRN_PIN_V4(pacc);
             cell_all<SAVE>(pacc, c[pl][pm], pout, sv);
             save_unit(q_tile, q_t, pl, pm);
           }
@@ -388,6 +389,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
     // the last unit's accumulators stay pending across the loop back-edge: keep hipcc from touching them (phi
     // copies, spills) before the MFMAs that wrote them have landed
     KPRN_MFMA_DRAIN();
+    KPRN_PIN_V4(accs[0]);
+    KPRN_PIN_V4(accs[1]);
     if (have_next) gather_store<NT>(xbuf(par ^ 1), gv);
     FPROBE(4)  // landing the gathered rows (waits for the loads -- and, when saving, for the stores in flight)
     p_tile = tile; p_t = t;
@@ -397,6 +400,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   // drain: the cell of the very last unit, then the last tile's head
   {
     KPRN_MFMA_DRAIN();
+    KPRN_PIN_V4(accs[1]);
     cell_all<SAVE>(accs[1], c[L - 1][3], hbuf(L - 1, par) + 3 * 16 * LDA + o_off, sv);
     save_unit(p_tile, p_t, L - 1, 3);
     lds_barrier();

@@ -65,6 +65,7 @@ struct McArgs {
   const int32_t* perm; const int32_t* tile_k; const int32_t* pmeta; const float* pfb;  // identical-prefix plan (lstm_fused_prefix.hip)
   float* save_frag;        // training saves (nullable), layout of lstm_fused_common.h
   int64_t n_tiles;
+  unsigned long long* timing;  // optional [grid][8] cycle counters (KPRN_TIMING=1)
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (every index of the MFMA stream must be a constant:
@@ -200,6 +201,15 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
   const int T = a.T, L = a.L, ly = a.layer;
   const bool bottom = (ly == 0), top = (ly == L - 1);
   if ((int64_t)blockIdx.x >= a.n_tiles) return;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = a.timing ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long tstart = tlast;
+#define MPROBE(slot_)                                              \
+  if (a.timing) {                                                  \
+    const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+    tacc[slot_] += now__ - tlast;                                  \
+    tlast = now__;                                                 \
+  }
 
   // ---- register-stationary split weights: B fragment (col 16j + arow of gate q, k = 32 kc + 8 ag + e) per (src, q, kc, piece)
   f32x4 w[2][4][2][NS];  // (128-bit containers of 8 bf16)
@@ -267,6 +277,29 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
     }
   };
 
+  // the NEXT tile's ids: requested (registers) before a tile's first step, landed in LDS behind it -- the load latency sits
+  // under a whole step of MFMAs instead of in front of it
+  int32_t idreg[MT * MAXT_LDS / NT][3];
+  auto ids_request = [&](int64_t tl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < MT * MAXT_LDS / NT; ++it) {
+      const int cc = threadIdx.x + it * NT;
+      if (cc < MT * T) {
+        const int row = cc / T, tt = cc - row * T;
+        int64_t n = tl * MT + row;
+        if (n >= a.N) n = a.N - 1;
+        const int32_t* f = a.idx + (n * T + tt) * a.F;
+        idreg[it][0] = f[a.F - a.nT - 2]; idreg[it][1] = f[a.F - 2]; idreg[it][2] = f[a.F - 1];
+      }
+    }
+  };
+  auto ids_land = [&](int32_t* ids) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < MT * MAXT_LDS / NT; ++it) {
+      const int cc = threadIdx.x + it * NT;
+      if (cc < MT * T) { ids[cc * 4 + 0] = idreg[it][0] - 1; ids[cc * 4 + 1] = idreg[it][1] - 1; ids[cc * 4 + 2] = idreg[it][2] - 1; }
+    }
+  };
   if (bottom) ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, blockIdx.x, idbuf(0));
   if (a.tile_k) {
     const int n_cls = __builtin_amdgcn_readfirstlane(a.pmeta[0]) + 1;
@@ -304,11 +337,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
     constexpr int PER_CHUNK = 4 * NTERM;                   // MFMAs per K chunk of 32
     constexpr int TOTAL = (REC ? 4 : 2) * PER_CHUNK;       // chunks: [h 0, h 1,] in 0, in 1
     McCell x;
-    f32x4 af[NS], an[NS];  // (128-bit containers of 8 bf16) the running chunk's A pieces / the next chunk's
+    // A pieces of the running chunk / of the next one, ping-pong by chunk parity: never copied (a register copy in front of
+    // an asm MFMA is a VALU write the hazard checker cannot see)
+    f32x4 fr[2][NS];
     {
       const E* first = (REC ? h_base : in_base);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) af[s] = *(const f32x4*)(first + s * PLANE);
+      for (int s = 0; s < NS; ++s) fr[0][s] = *(const f32x4*)(first + s * PLANE);
     }
     static_for<0, TOTAL>([&](auto ic) __attribute__((always_inline)) {
       constexpr int n = decltype(ic)::value;
@@ -319,6 +354,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
       constexpr int kc = chunk & 1;
       constexpr int sa = mc_ta(M, term), sb = mc_tb(M, term);
       constexpr bool has_next = (n / PER_CHUNK) + 1 < TOTAL / PER_CHUNK;
+      constexpr int cur = chunk & 1;   // (chunk counts from 0 in both forms of the unit)
+      f32x4(&af)[NS] = fr[cur];
       if constexpr (!(MC_EXP & 2)) {
         if constexpr (M == 2) {
           if constexpr (n < 4) MC_MFMA_HC(acc[q], af[sa], w[src][q][kc][sb], bias4[q]);
@@ -332,29 +369,26 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
         // the next chunk's A pieces: next 32 k of the same tile, or the first chunk of the input half
         const E* nb = (kc == 0) ? ((src == 0) ? h_base : in_base) + 32 : in_base;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) an[s] = *(const f32x4*)(nb + s * PLANE);
+        for (int s = 0; s < NS; ++s) fr[cur ^ 1][s] = *(const f32x4*)(nb + s * PLANE);
       }
-      if constexpr (has_next && term == NTERM - 1 && q == 3) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) af[s] = an[s];
-      }
-      // The 64 cell steps of the previous unit are spread EVENLY over the MFMA slots 2 .. TOTAL-1 (a step is 1-3 VALU ops,
+      // The 64 cell steps of the previous unit are spread EVENLY over the MFMA slots 3 .. TOTAL-1 (three MFMAs
+      // behind the previous unit's last results, whichever side of its neighbours the scheduler puts a step) (a step is 1-3 VALU ops,
       // at most one transcendental): the VALU work per slot stays below the MFMA cadence, so neither pipe waits for the other.
-      constexpr int SLOTS = TOTAL - 2;
-      if constexpr (CELL && n >= 2) {
-        constexpr int k = (SLOTS >= 64) ? ((n - 2) * 64 + SLOTS - 1) / SLOTS : (n - 2);   // candidate step for this slot
-        constexpr bool here = (SLOTS >= 64) ? (k < 64 && 2 + (k * SLOTS) / 64 == n) : (k < 64);
+      constexpr int SLOTS = TOTAL - 3;
+      if constexpr (CELL && n >= 3) {
+        constexpr int k = (SLOTS >= 64) ? ((n - 3) * 64 + SLOTS - 1) / SLOTS : (n - 3);   // candidate step for this slot
+        constexpr bool here = (SLOTS >= 64) ? (k < 64 && 3 + (k * SLOTS) / 64 == n) : (k < 64);
         if constexpr (here && !(MC_EXP & 1)) {
           mc_cell_step<M, SAVE, (k >> 4), (k & 15)>(x, pacc, pc, phrow, phout, sv);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     });
-    if constexpr (CELL && TOTAL - 2 < 64) {
+    if constexpr (CELL && TOTAL - 3 < 64) {
       // (bf16 mode, or a tile's first step: fewer MFMA slots than cell steps) the rest of the cell, exposed
       static_for<0, 64>([&](auto ic) __attribute__((always_inline)) {
         constexpr int m = decltype(ic)::value;
-        if constexpr (m >= TOTAL - 2) mc_cell_step<M, SAVE, (m >> 4), (m & 15)>(x, pacc, pc, phrow, phout, sv);
+        if constexpr (m >= TOTAL - 3) mc_cell_step<M, SAVE, (m >> 4), (m & 15)>(x, pacc, pc, phrow, phout, sv);
       });
     }
   };
@@ -392,6 +426,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
           // tile switch: the previous tile's last cell first (its h_T row block completes the head's input), then the head
           if (has_prev) {
             MC_DRAIN();
+            KPRN_PIN_V4(pacc);
             mc_cell_all<M, SAVE>(pacc, c[3], phrow, phout, sv);
             save_unit(q_tile, q_t, pm);
           }
@@ -401,23 +436,28 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
           if (has_prev && top) mc_head_tile<M>(a, hb(q_par), p_tile, j, lane);
           unit(std::false_type{}, std::false_type{}, in_base, h_base, acc, pacc, c[pm], phrow, phout);
         } else {
+          MPROBE(1)  // slot entry -> barrier A
           lds_barrier();  // (A) input tile of this step + rows 0..47 of h_{t-1} are complete
+          MPROBE(2)  // waiting at barrier A
           unit(std::true_type{}, std::true_type{}, in_base, h_base, acc, pacc, c[pm], phrow, phout);
           save_unit(q_tile, q_t, pm);
+          MPROBE(3)  // unit 0 (recurrent slots)
         }
         if (FIRST && cls > 0) {
           MC_DRAIN();
+          KPRN_PIN_V4(acc);
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[q][r] += rec0[q];
         }
-        if (!FIRST && !(MC_EXP & 8)) lds_barrier();  // (B) rows 48..63 of h_{t-1} (the cell that ran beside this unit) are complete in every wave
+        if (!FIRST && !(MC_EXP & 8)) { lds_barrier(); MPROBE(4) }  // (B) rows 48..63 of h_{t-1} (the cell that ran beside this unit) are complete in every wave
       } else {
         if (FIRST) {
           unit(std::false_type{}, std::true_type{}, in_base, h_base, acc, pacc, c[pm], phrow, phout);
           if (cls > 0) {
             MC_DRAIN();
+            KPRN_PIN_V4(acc);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -450,12 +490,18 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
       tn = k0_n;
     }
     const bool have_next = tile_n < a.n_tiles;
-    if (bottom && t == k0 && tile + gridDim.x < a.n_tiles) ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
+    const bool ids_pending = bottom && t == k0 && tile + gridDim.x < a.n_tiles;
+    if (ids_pending) ids_request(tile + gridDim.x);
     if (have_next) in_load(tile_n, tn, idbuf(tpar_n));
-    if (t == k0) slot(std::true_type{}, tile, t, par, s > 0, p_tile, p_t, k0);
-    else slot(std::false_type{}, tile, t, par, true, p_tile, p_t, 0);
+    MPROBE(0)  // slot control, id staging, input request
+    if (t == k0) { slot(std::true_type{}, tile, t, par, s > 0, p_tile, p_t, k0); MPROBE(6) }
+    else { slot(std::false_type{}, tile, t, par, true, p_tile, p_t, 0); MPROBE(5) }  // (5: units 1..3 of recurrent slots; 6: first slots, whole)
     MC_DRAIN();
+    KPRN_PIN_V4(accs[0]);
+    KPRN_PIN_V4(accs[1]);
+    if (ids_pending) ids_land(idbuf(tpar ^ 1));  // (read from the next tile's first gather, >= 1 step and 1 barrier later)
     if (have_next) in_store(inb(par ^ 1));
+    MPROBE(7)  // drain + landing the next input tile
     p_tile = tile; p_t = t;
     if (!have_next) break;
     t = tn; tile = tile_n; tpar = tpar_n; k0 = k0_n;
@@ -463,11 +509,18 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
   // drain: the cell of the very last unit, then the last tile's head
   {
     MC_DRAIN();
+    KPRN_PIN_V4(accs[1]);
     mc_cell_all<M, SAVE>(accs[1], c[3], hb(par) + 3 * 16 * LDB + o_off, hout_ptr(p_tile, p_t, 3), sv);
     save_unit(p_tile, p_t, 3);
     lds_barrier();
     if (top) mc_head_tile<M>(a, hb(par), p_tile, j, lane);
   }
+  if (a.timing && threadIdx.x == 0) {
+    tacc[0] += 0;
+    for (int k = 0; k < 8; ++k) a.timing[(int64_t)blockIdx.x * 8 + k] = tacc[k];
+    (void)tstart;
+  }
+#undef MPROBE
 }
 
 // ---- split weights in register order (rebuilt when the parameters change) ----
@@ -583,10 +636,22 @@ void forward_mc(kprn_handle* h, const kprn_batch* b, bool save) {
     a.perm = b->perm; a.tile_k = b->tile_k; a.pmeta = b->pmeta; a.pfb = s->pfb;
     a.save_frag = save ? s->save_frag : nullptr;
     a.n_tiles = n_tiles;
+    static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
+    if (want_timing && !s->timing) HIP_TRY(hipMalloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
+    a.timing = s->timing;
     ProfScope ps(h, save ? "lstm_mc_fwd_train" : "lstm_mc_fwd");
     if (ns == 3) { if (save) launch_mc<3, true>(h, a, grid); else launch_mc<3, false>(h, a, grid); }
     else if (ns == 2) { if (save) launch_mc<2, true>(h, a, grid); else launch_mc<2, false>(h, a, grid); }
     else { if (save) launch_mc<1, true>(h, a, grid); else launch_mc<1, false>(h, a, grid); }
+    if (s->timing) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      std::vector<unsigned long long> tb((size_t)grid * 8);
+      HIP_TRY(hipMemcpy(tb.data(), s->timing, tb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      double sum[8] = {0};
+      for (int g = 0; g < grid; ++g) for (int k = 0; k < 8; ++k) sum[k] += (double)tb[(size_t)g * 8 + k];
+      fprintf(stderr, "[kprn timing] mc fwd layer %d save=%d grid=%d avg cycles/WG: control+request %.0f to-barrierA %.0f wait-A %.0f unit0 %.0f wait-B %.0f units1-3 %.0f first-slots %.0f drain+land %.0f\n",
+              l, (int)save, grid, sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid, sum[7] / grid);
+    }
   }
 }
 

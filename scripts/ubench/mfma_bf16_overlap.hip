@@ -16,6 +16,9 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* cyc,
   float af = 0.5f + lane * 0.001f, bfv = 0.25f + lane * 0.002f;
   bf16x8 a8, b8;
   for (int i = 0; i < 8; ++i) { a8[i] = (__bf16)(0.5f + 0.01f * i + lane * 0.001f); b8[i] = (__bf16)(0.25f + 0.02f * i); }
+  bf16x8 bw[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { bw[i] = b8; bw[i][0] = (__bf16)(0.1f * i); if (KIND == 2) asm volatile("" : "+a"(bw[i])); else asm volatile("" : "+v"(bw[i])); }
   float x[8], y[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { x[i] = lane * 0.01f + i; y[i] = 0.5f * i; }
@@ -24,7 +27,9 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* cyc,
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) {
       if (KIND == 0) acc[k2 & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bfv, acc[k2 & 3], 0, 0, 0);
-      else acc[k2 & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[k2 & 3], 0, 0, 0);
+      else if (KIND == 1) acc[k2 & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[k2 & 3], 0, 0, 0);
+      else if (KIND == 2) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[k2 & 3]) : "v"(a8), "a"(bw[k2 & 7]));   // B from the AGPR half, 8 different registers
+      else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[k2 & 3]) : "v"(a8), "v"(bw[k2 & 7]));                   // same, B in VGPRs
       const int r = k2 & 7;
       if (VAR == 1) { x[r] = x[r] * 1.0001f + 0.5f; y[r] = y[r] * 1.0001f + 0.5f; }
       if (VAR == 2) { x[r] = __builtin_amdgcn_exp2f(x[r]); y[r] = __builtin_amdgcn_rcpf(y[r]); }
@@ -56,7 +61,7 @@ void run(const char* name) {
   unsigned long long h[256]; hipMemcpy(h, cyc, grid * 8, hipMemcpyDeviceToHost);
   double avg = 0; for (int i = 0; i < grid; ++i) avg += h[i]; avg /= grid;
   const double n = 16.0 * iters;
-  const double flops_per = KIND == 0 ? 2048.0 : 16384.0;
+  const double flops_per = KIND == 0 ? 2048.0 : 16384.0;  // (KIND 1..3: bf16)
   printf("%-44s %.2f ticks/MFMA, kernel %.3f ms -> %.1f TFLOP/s (ticks/us %.0f)\n", name, avg / n, ms, grid * 4 * n * flops_per / (ms * 1e-3) / 1e12,
          avg / (ms * 1e3));
   hipFree(out); hipFree(cyc);
@@ -70,5 +75,8 @@ int main() {
   run<1, 1>("bf16 16x16x32 + 2 fma per MFMA");
   run<1, 2>("bf16 16x16x32 + exp2 + rcp per MFMA");
   run<1, 3>("bf16 16x16x32 + 8 simple VALU per MFMA");
+  run<3, 0>("bf16 asm, B in VGPRs (8 regs rotating)");
+  run<2, 0>("bf16 asm, B in AGPRs (8 regs rotating)");
+  run<2, 2>("bf16 asm, B in AGPRs + exp2 + rcp");
   return 0;
 }
