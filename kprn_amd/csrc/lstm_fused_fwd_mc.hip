@@ -375,6 +375,12 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_mc(McArgs a) {
       // behind the previous unit's last results, whichever side of its neighbours the scheduler puts a step) (a step is 1-3 VALU ops,
       // at most one transcendental): the VALU work per slot stays below the MFMA cadence, so neither pipe waits for the other.
       constexpr int SLOTS = TOTAL - 3;
+      if constexpr (CELL && n == 3) {
+        // the first cell step reads the previous unit's accumulators: without this pin the scheduler may hoist that read up to
+        // the previous sched_barrier, i.e. to right behind the previous unit's last MFMA (34 cycles behind the writer of gate 1:
+        // less than the 8-pass latency).  Behind three MFMAs of this unit every result has landed.
+        KPRN_PIN_V4(const_cast<f32x4(&)[4]>(pacc));
+      }
       if constexpr (CELL && n >= 3) {
         constexpr int k = (SLOTS >= 64) ? ((n - 3) * 64 + SLOTS - 1) / SLOTS : (n - 3);   // candidate step for this slot
         constexpr bool here = (SLOTS >= 64) ? (k < 64 && 3 + (k * SLOTS) / 64 == n) : (k < 64);
