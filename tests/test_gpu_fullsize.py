@@ -1,0 +1,160 @@
+"""-m gpu: parity of the BENCHMARKED code path at the benchmarked size.
+
+bench.py's workload is 65 536 paths per step (1 024 tiles of 64 paths on 256 persistent workgroups = 4 tiles per workgroup:
+id-tile double buffering by tile parity, cell-state reset between tiles, next-tile prefetch, weight-gradient slab flush after
+several tiles), T = 6, D = H = 64, L = 2, the KKBox-size entity table (Ve = 2 851 220).  The small-shape parity tests never
+put more than one tile on a workgroup, so this file compares exactly that configuration with two independent implementations:
+  (a) the float64 CPU oracle (oracle/kprn_oracle.c; OpenMP over pairs: seconds at this size),
+  (b) the engine's own generic pipeline (impl=generic: plain GEMM + element-wise kernels, no persistent kernels, no plan),
+for compute_dtype 0 (fp32 MFMA), 2 (f32x6) and 3 (f32x3), identical-prefix plan on and off, plus five Adam steps, a ragged last
+tile and the scoring kernel restricted to half the CUs (reserve_cus: 8 tiles per workgroup).
+Reference semantics: module/MapReduce.lua:24-47, model/OneModel.lua:223-275, optimizer/MyOptimizer.lua:177-221.
+"""
+import numpy as np
+import pytest
+
+from kprn_amd import _ffi, synth
+from oracle.oracle import Oracle, make_cfg, make_opt
+
+pytestmark = pytest.mark.gpu
+
+VE = 2851220            # run_scripts/config.sh:25
+SHAPE = dict(Vt=6, Ve=VE, Vr=9, dt=16, de=32, dr=16, H=64, L=2)
+PAIRS, P, T = 16384, 4, 6   # 65 536 paths = 1 024 tiles
+SCORE_RTOL = 1e-4
+GRAD_RTOL = 2e-4
+
+
+def rel_inf(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / max(1e-30, np.max(np.abs(b))))
+
+
+class Case:
+    """parameters, paths and the oracle's answers, computed once per module"""
+
+    def __init__(self, pairs, seed):
+        self.ocfg = make_cfg(**SHAPE)
+        self.o64 = Oracle(self.ocfg, np.float64)
+        th32 = self.o64.init_params(seed, 0.1).astype(np.float32)
+        self.theta32 = th32
+        self.theta = th32.astype(np.float64)
+        self.idx, self.labels = synth.make_paths(pairs, P, T, Ve=VE, seed=seed + 1)
+        self.rows = np.unique(self.idx[..., 1]) - 1   # entity rows the batch touches (0-based)
+        self.ps, self.pooled, self.probs = self.o64.forward(self.theta, self.idx)
+        self.loss, self.grad, _ = self.o64.forward_backward(self.theta, self.idx, self.labels)
+        self.lay = self.o64.layout()
+
+    def engine(self, compute_dtype=0, impl="auto", plan=True):
+        eng = _ffi.Engine(SHAPE["Vt"], VE, SHAPE["Vr"], SHAPE["dt"], SHAPE["de"], SHAPE["dr"], SHAPE["H"], SHAPE["L"], compute_dtype=compute_dtype)
+        eng.set_option("impl", impl)
+        eng.set_option("prefix_plan", "1" if plan else "0")
+        eng.set_flat_params(self.theta32)
+        return eng
+
+    def check_forward(self, out):
+        assert rel_inf(out["path_scores"], self.ps) < 2e-5
+        # per element as well: 1e-4 relative, with an absolute floor for the scores that happen to sit near zero
+        np.testing.assert_allclose(out["path_scores"], self.ps, rtol=SCORE_RTOL, atol=2e-5 * float(np.max(np.abs(self.ps))))
+        np.testing.assert_allclose(out["pooled"], self.pooled, rtol=SCORE_RTOL, atol=2e-6)
+        np.testing.assert_allclose(out["all_probs"], self.probs, rtol=SCORE_RTOL)
+        np.testing.assert_allclose(out["probs"], self.probs[:, 0], rtol=SCORE_RTOL)
+
+    def check_grads(self, eng, loss):
+        assert abs(loss - self.loss) < 1e-5 * max(1.0, abs(self.loss)), (loss, self.loss)
+        g = eng.get_flat_grads()
+        for nm, (off, shp) in self.lay.items():
+            n = int(np.prod(shp))
+            got, want = g[off:off + n], self.grad[off:off + n]
+            if nm == "entity_emb":
+                got, want = got.reshape(shp), want.reshape(shp)
+                mask = np.ones(shp[0], bool)
+                mask[self.rows] = False
+                assert not np.any(got[mask]), "gradient on an entity row the batch does not reference"
+                got, want = got[self.rows], want[self.rows]
+            r = rel_inf(got, want)
+            assert r < GRAD_RTOL, (nm, r)
+
+
+@pytest.fixture(scope="module")
+def full():
+    return Case(PAIRS, 11)
+
+
+@pytest.mark.parametrize("plan", [True, False])
+@pytest.mark.parametrize("compute_dtype", [0, 2, 3])
+def test_benchmarked_size_forward_backward_match_the_f64_oracle(full, compute_dtype, plan):
+    eng = full.engine(compute_dtype, "auto", plan)
+    b = eng.batch(full.idx, full.labels)
+    n_exec = b.executed_steps
+    assert (n_exec < 0.8 * PAIRS * P * T) if plan else (n_exec == PAIRS * P * T)
+    out = eng.forward(b, 1, want=("probs", "all_probs", "pooled", "path_scores"))
+    full.check_forward(out)
+    loss = eng.backward(b, 1)
+    full.check_grads(eng, loss)
+    # the scoring kernel on half the CUs: 8 tiles per persistent workgroup
+    eng.set_option("reserve_cus", "128")
+    out2 = eng.forward(b, 1, want=("probs", "all_probs", "pooled", "path_scores"))
+    full.check_forward(out2)
+    eng.close()
+
+
+def test_benchmarked_size_fused_matches_the_generic_pipeline(full):
+    """two independent GPU implementations of the same step: persistent fused kernels with the plan vs GEMM + element-wise"""
+    res = {}
+    for impl in ("auto", "generic"):
+        eng = full.engine(0, impl, impl == "auto")
+        b = eng.batch(full.idx, full.labels)
+        out = eng.forward(b, 1, want=("probs", "path_scores"))
+        loss = eng.backward(b, 1)
+        g = eng.get_flat_grads()
+        res[impl] = (out, loss, g)
+        if impl == "generic":
+            full.check_grads(eng, loss)
+        eng.close()
+    (oa, la, ga), (og, lg, gg) = res["auto"], res["generic"]
+    assert rel_inf(oa["path_scores"], og["path_scores"].astype(np.float64)) < 2e-5
+    np.testing.assert_allclose(oa["probs"], og["probs"], rtol=SCORE_RTOL)
+    assert abs(la - lg) < 1e-5 * max(1.0, abs(lg))
+    for nm, (off, shp) in full.lay.items():
+        n = int(np.prod(shp))
+        assert rel_inf(ga[off:off + n], gg[off:off + n].astype(np.float64)) < GRAD_RTOL, nm
+
+
+@pytest.mark.parametrize("compute_dtype,plan", [(0, True), (0, False), (2, True)])
+def test_benchmarked_size_five_adam_steps_match_the_f64_oracle(full, compute_dtype, plan):
+    """MyOptimizer:trainBatch x 5 (optim.adam, lazy-exact entity rows) on two alternating 65 536-path batches"""
+    eng = full.engine(compute_dtype, "auto", plan)
+    idx2, lab2 = synth.make_paths(PAIRS, P, T, Ve=VE, seed=501)
+    batches = [(full.idx, full.labels), (idx2, lab2)]
+    gb = [eng.batch(i, l) for i, l in batches]
+    th = full.theta.copy()
+    st = full.o64.new_state()
+    oopt = make_opt(method=1, lr=1e-2)
+    gopt = _ffi.make_opt(method=1, lr=1e-2)
+    for s in range(5):
+        i, l = batches[s & 1]
+        ol, _ = full.o64.train_step(th, st, oopt, i, l)
+        gl = eng.train_step(gb[s & 1], gopt)
+        assert abs(gl - ol) < 2e-4 * max(1.0, abs(ol)), (s, gl, ol)
+    got = eng.get_flat_params()
+    d = float(np.max(np.abs(got - th)))
+    assert d < 2e-4, d
+    # and the scores of the trained model
+    out = eng.forward(gb[0], 1, want=("probs",))
+    _, _, probs = full.o64.forward(th, full.idx)
+    np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=5e-4)
+    eng.close()
+
+
+@pytest.mark.parametrize("compute_dtype", [0, 2])
+def test_ragged_last_tile_many_tiles_per_workgroup(compute_dtype):
+    """16 389 pairs x 4 paths = 65 556 paths: 1 024 full tiles + one of 20 rows; scoring with reserve_cus = 128"""
+    case = Case(16389, 23)
+    eng = case.engine(compute_dtype, "auto", True)
+    eng.set_option("reserve_cus", "128")
+    b = eng.batch(case.idx, case.labels)
+    out = eng.forward(b, 1, want=("probs", "all_probs", "pooled", "path_scores"))
+    case.check_forward(out)
+    loss = eng.backward(b, 1)
+    case.check_grads(eng, loss)
+    eng.close()
