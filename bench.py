@@ -16,8 +16,19 @@ Workload = BASELINE.json configs[1] ("C2", reading A of "d=64"): path_len T=6, D
 pool, Adam lr 1e-3.  Batches are bucketed by #paths-per-pair like the reference's files
 (movie_data_format.py:301-314) and sized to ~--paths-per-step paths.
 
-N>1: one process per GPU (torchrun), pairs sharded across ranks, dense-gradient all-reduce +
-sparse entity-row all-gather over RCCL (kprn_amd/dp.py); weak scaling.
+N>1: one process per GPU, pairs sharded across ranks, dense-gradient all-reduce + sparse entity-row
+all-gather over RCCL (kprn_amd/dp.py); weak scaling (fixed --paths-per-step per GPU) or, with
+--total-paths M, the M paths of the job split over ranks and steps (strong scaling).  Started as
+`python bench.py --gpus N` (no WORLD_SIZE in the environment) it launches its N ranks itself through
+torch.distributed.run on 127.0.0.1; started by torch.distributed.run it is one of the ranks.
+
+Batch feed.  `value` is measured with the batches resident in HBM (ids uploaded, validated, indexed, planned
+before the timed region).  The same K steps are then repeated with the STREAMING feed -- every step a batch that
+arrives from (page-locked) host memory: upload + validation + occurrence index + identical-prefix plan on the
+engine's feed stream, double-buffered under the previous step (kprn_batch_feed_async; the reference's
+BatcherFileList.lua:53-96) -- and reported under "streaming"; `value_no_prefix_plan` repeats them with every
+step of every path executed (the plan's saving depends on the share of left-padded paths in the data), and
+"long_run" with enough steps for a >= 0.3 s timed region.
 
 Extra objects on the JSON line: "roofline" (dominant kernel family, HIP events on the engine's
 stream inside the timed region) and "cpu_baseline" (the float64 oracle with OpenMP on the host
@@ -65,7 +76,88 @@ def parse():
                     help="run the scoring pass on the main stream, strictly before the train step (default: on a second stream, sharing "
                          "the chip with the training forward of the same step -- neither depends on the other)")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (pack / all-gather / merge) even at world size 1")
+    ap.add_argument("--total-paths", type=int, default=0,
+                    help="strong scaling: the K timed steps of all ranks together process this many paths (north_star: 1000000), "
+                         "i.e. paths per rank per step = total / (gpus * steps); 0 = weak scaling with --paths-per-step per GPU")
+    ap.add_argument("--batch-feed", default="both", choices=["resident", "streaming", "both"],
+                    help="resident: batches in HBM before the timed region (this is `value`); streaming: every step's batch is uploaded, "
+                         "validated, indexed and planned on the feed stream under the previous step; both: `value` resident + a second "
+                         "region reported under \"streaming\"")
+    ap.add_argument("--feed-build", default="host", choices=["host", "device"],
+                    help="streaming feed: derive plan + index on host worker threads (GPU sees DMA only) or with kernels on a side stream")
+    ap.add_argument("--feed-ahead", type=int, default=4, help="streaming feed: batches in flight ahead of the step being queued")
+    ap.add_argument("--feed-threads", type=int, default=0, help="helper threads per batch of the host-built feed (0: library default)")
+    ap.add_argument("--no-extra-regions", action="store_true", help="skip the value_no_prefix_plan / long_run regions")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rank wiring / timing / JSON check without a GPU: gloo backend, the step is a placeholder (CPU tests)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, torch.distributed.run on
+    127.0.0.1) and hand their exit code back.  Rank 0 prints the JSON line."""
+    import subprocess
+    if not a.dry_run:
+        import torch
+        n = torch.cuda.device_count()
+        if n < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {n} GPU(s) visible")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(a):
+    """No GPU, no engine: the ranks rendezvous over gloo, run K placeholder steps through the same barrier / max-over-ranks
+    timing as the real run and rank 0 prints a JSON line marked dry_run.  Checks the launcher and the rank plumbing only."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    pps = a.paths_per_step if not a.total_paths else max(64, a.total_paths // (world * max(1, a.steps)))
+    g = torch.ones(1024)
+    def step():
+        if world > 1:
+            dist.all_reduce(g.clone())
+        return pps
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n = sum(step() for _ in range(a.steps))
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0, float(n), 1.0], dtype=torch.float64)
+    tot = el.clone()
+    if world > 1:
+        mx = el.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        el[0] = mx[0]
+    if rank == 0:
+        print(json.dumps({"metric": "paths/sec (train+score) at path_len=6 d=64", "value": None, "unit": "paths/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * float(el[0]) / max(1, a.steps), 4),
+                          "higher_is_better": True, "scaling": "strong" if a.total_paths else "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "none (dry run: placeholder steps, launcher and rank wiring only)", "dry_run": True,
+                          "ranks_reporting": int(tot[2]), "paths_counted": int(tot[1]),
+                          "config": {"workload": "dry run", "paths_per_step_per_gpu": pps, "parallelism": f"dp{world}" if world > 1 else "single"}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def dims_of(a):
@@ -171,6 +263,10 @@ def cpu_baseline(a, T, dt, de, dr, H, L, seconds):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
+    if a.dry_run:
+        return dry_run(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -187,7 +283,9 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.total_paths:
+        a.paths_per_step = max(64, a.total_paths // (world * max(1, a.steps)))
 
     from kprn_amd import _ffi, synth, dp
     dt_, de_, dr_, H = dims_of(a)
@@ -201,15 +299,23 @@ def main():
                       rnn_type=1 if shipped else 0, use_relu=1, rnn_init=1 if shipped else 0, compute_dtype=a.compute_dtype)
     eng.set_option("impl", a.impl)
     eng.set_option("score_overlap", "0" if a.no_score_overlap else "1")
+    eng.set_option("feed_build", a.feed_build)
+    if a.feed_threads > 0:
+        eng.set_option("feed_threads", str(a.feed_threads))
     opt = _ffi.make_opt(method=1, lr=1e-3, entity_update=a.entity_update)
 
     # bucketed batches (constant P per batch, like the reference's train.txt.<P>.torch files)
     Ps = [1, 2, 3, 4, 5, 8]
-    batches = []
+    host = []      # the path set in host memory (page-locked: what a loader hands the feed)
+    batches = []   # ... and resident in HBM
     for i, P in enumerate(Ps):
         pairs = max(1, a.paths_per_step // P)
         idx, labels = synth.make_paths(pairs, P, T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, num_types=nT, seed=12345 + 97 * i + 7919 * rank)
-        batches.append(eng.batch(idx, labels))
+        hi, hl = eng.host_array(idx.shape, np.int32), eng.host_array(labels.shape, np.float32)
+        hi[...] = idx
+        hl[...] = labels
+        host.append((hi, hl))
+        batches.append(eng.batch(hi, hl))
     paths_of = [b.n_paths for b in batches]
     exec_of = [b.executed_steps for b in batches]
 
@@ -226,8 +332,7 @@ def main():
     if dpx is not None:
         eng.set_option("reserve_cus", str(a.reserve_cus))
 
-    def step(i):
-        b = batches[i % len(batches)]
+    def run_batch(b):
         score = (lambda: eng.forward_async(b, 1)) if not a.train_only else None
         if a.score_only:
             eng.forward_async(b, 1)
@@ -237,13 +342,63 @@ def main():
             if score:
                 score()
             eng.train_step(b, opt, 1, want_loss=False)
-        return paths_of[i % len(batches)]
+
+    def step_resident(pool):
+        def step(i):
+            run_batch(pool[i % len(pool)])
+            return paths_of[i % len(pool)]
+        return step
+
+    # streaming feed: AHEAD + 1 slots; the batch of step i + AHEAD is handed to the feed right before step i is queued.  Host
+    # worker threads validate it and derive its identical-prefix plan and occurrence index into page-locked staging, and its
+    # uploads (DMA: no CUs) start behind the slot's last reader (step i - 1); queueing step i + AHEAD waits for the worker, never for
+    # the device (BatcherFileList.lua:53-96's double buffer, a few slots deeper)
+    AHEAD = max(1, a.feed_ahead)
+    NS = AHEAD + 1
+    # slots sized once for the largest bucket (BatcherFileList.lua:53-60 preallocates its GPU tensors the same way)
+    slots = ([_ffi.Batch.reserve(eng, max(b.B for b in batches), max(paths_of), T, F) for _ in range(NS)]
+             if a.batch_feed != "resident" else [None] * NS)
+    fed_upto = [-1]
+    host_t = {"feed": [], "run": []}   # host-side seconds per step spent queueing the feed / the step (KPRN_BENCH_HOST_TIMING=1 prints them)
+    def step_streaming(i):
+        if fed_upto[0] < i - 1 or fed_upto[0] >= i + AHEAD:   # (a region starts: restart the ring at i)
+            fed_upto[0] = i - 1
+        t0 = time.perf_counter()
+        while fed_upto[0] < i + AHEAD:
+            j = fed_upto[0] + 1
+            slots[j % NS] = eng.feed(*host[j % len(host)], slot=slots[j % NS])
+            fed_upto[0] = j
+        t1 = time.perf_counter()
+        run_batch(slots[i % NS])
+        host_t["feed"].append(t1 - t0)
+        host_t["run"].append(time.perf_counter() - t1)
+        return paths_of[i % len(host)]
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1 or a.force_dp:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed_region(step, first, k):
+        """exactly k steps between barriers; returns (max-over-ranks seconds, paths of all ranks)"""
+        barrier()
+        t0 = time.perf_counter()
+        n = 0
+        for i in range(k):
+            n += step(first + i)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tn = torch.tensor([n], dtype=torch.float64, device=dev)
+            dist.all_reduce(tn, op=dist.ReduceOp.SUM)
+            return float(tt.item()), float(tn.item())
+        return el, float(n)
+
+    main_streaming = a.batch_feed == "streaming"
+    step = step_streaming if main_streaming else step_resident(batches)
 
     # Warm-up steps run with HIP events around EVERY kernel family (untimed): that gives the per-family table and names the
     # dominant family.  Inside the timed region only the dominant family keeps its events (an event pair costs ~4 us of
@@ -270,30 +425,75 @@ def main():
         dominant = max(known, key=known.get) if known else max(fams_warm.items(), key=lambda kv: kv[1][0])[0]
     eng.profile_reset()
     eng.set_option("profile_filter", dominant)
-    barrier()
-    t0 = time.perf_counter()
-    npaths = 0
-    for i in range(a.steps):
-        npaths += step(a.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, npaths_total = timed_region(step, a.warmup, a.steps)
     eng.profile(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        tn = torch.tensor([npaths], dtype=torch.float64, device=dev)
-        dist.all_reduce(tn, op=dist.ReduceOp.SUM)
-        npaths_total = float(tn.item())
-    else:
-        npaths_total = float(npaths)
+    fams = eng.profile_get() if prof else {}
+    value = npaths_total / elapsed
+
+    # ---- further regions (not the headline; N = 1 only, no kernel events)
+    def region_line(el, n, k):
+        return {"value": round(n / el, 1), "unit": "paths/s", "ms_per_step": round(1e3 * el / k, 4), "steps": k}
+    extras = {}
+    plain = world == 1 and not a.force_dp and not a.no_extra_regions
+    if plain and a.batch_feed == "both":
+        # the SAME K steps with the streaming feed
+        for i in range(3):
+            step_streaming(i)
+        eng.sync()
+        el, n = timed_region(step_streaming, 3, a.steps)
+        extras["streaming"] = dict(region_line(el, n, a.steps), ratio_to_resident=round((n / el) / value, 4),
+                                   feed_build=a.feed_build, feed_ahead=a.feed_ahead,
+                                   what="every step's batch arrives from page-locked host memory: id validation + identical-prefix plan + occurrence "
+                                        "index derived per batch (host worker threads, or kernels on a side stream with --feed-build device) and "
+                                        "uploaded under the steps in flight")
+    if plain and not main_streaming:
+        # enough steps for a >= 0.3 s timed region
+        k_long = int(min(4000, max(a.steps, np.ceil(0.35 / max(elapsed / a.steps, 1e-6)))))
+        el, n = timed_region(step, a.warmup + a.steps, k_long)
+        extras["long_run"] = region_line(el, n, k_long)
+        # every step of every path executed (no identical-prefix plan)
+        eng.set_option("prefix_plan", "0")
+        full = [eng.batch(hi, hl) for hi, hl in host]
+        eng.set_option("prefix_plan", "1")
+        st = step_resident(full)
+        for i in range(3):
+            st(i)
+        eng.sync()
+        el, n = timed_region(st, 3, a.steps)
+        extras["no_prefix_plan"] = region_line(el, n, a.steps)
+        for b in full:
+            b.free()
+    # data-parallel runs: the exchange's own time, from a short extra region with events around its parts
+    dp_info = None
+    if dpx is not None:
+        dpx.timing = True
+        eng.profile_reset()
+        eng.set_option("profile_filter", "dp_")
+        eng.profile(True)
+        k_x = min(a.steps, 12)
+        timed_region(step, a.warmup + a.steps, k_x)
+        eng.profile(False)
+        fx = eng.profile_get()
+        dp_info = {"world": world, "capacity_rows": dpx.capacity, "packed_MB_per_rank": round((4 + dpx.capacity * (1 + de_)) * 4 / 1e6, 2),
+                   "exchange_ms_per_step": dpx.timing_summary(),
+                   "pack_rows_ms": round(fx.get("dp_pack_rows", (0, 1))[0] / max(1, fx.get("dp_pack_rows", (0, 1))[1]), 4),
+                   "merge_rows_ms": round(fx.get("dp_merge_rows", (0, 1))[0] / max(1, fx.get("dp_merge_rows", (0, 1))[1]), 4)}
+        dpx.timing = False
+        tr = torch.ones(1, device=dev)
+        if world > 1:
+            dist.all_reduce(tr)
+        dp_info["ranks_reporting"] = int(tr.item())
 
     loss = eng.read_loss()
     assert np.isfinite(loss), "training diverged"
+    if os.environ.get("KPRN_BENCH_HOST_TIMING") and host_t["feed"]:
+        f, r = np.array(host_t["feed"][-a.steps:]) * 1e3, np.array(host_t["run"][-a.steps:]) * 1e3
+        print(f"[bench host timing] feed call ms mean {f.mean():.3f} max {f.max():.3f} | step queueing ms mean {r.mean():.3f} max {r.max():.3f}", file=sys.stderr)
+        print("[bench host timing] feed:", np.round(f[:24], 2).tolist(), file=sys.stderr)
+        print("[bench host timing] run: ", np.round(r[:24], 2).tolist(), file=sys.stderr)
 
     # ---- roofline of the dominant kernel family (HIP events recorded inside the timed region)
     roofline = None
-    fams = eng.profile_get() if prof else {}
     kernels = {}
     if fams:
         # algorithmic work per family over the timed steps
@@ -378,7 +578,6 @@ def main():
         eng2.close() if hasattr(eng2, "close") else None
 
     if rank == 0:
-        value = npaths_total / elapsed
         fwd_flops = sum(T * 2 * G * H * ((D if l == 0 else H) + H) for l in range(L)) + 2 * H * C
         step_flops = (0 if a.score_only else 3 * fwd_flops) + (0 if a.train_only else fwd_flops)  # nominal: every path, every step
         exec_frac = sum(exec_of) / float(sum(p * T for p in paths_of))
@@ -394,7 +593,7 @@ def main():
         out = {
             "metric": "paths/sec (train+score) at path_len=6 d=64", "value": round(value, 1), "unit": "paths/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if a.total_paths else "weak", "vs_baseline": None,
             "dtype": {0: "f32", 1: "bf16", 2: "f32x6", 3: "f32x3"}[a.compute_dtype], "data": "synthetic",
             "config": {"workload": (f"C2 KKBOX-MI synthetic: T={T}, D=H={H} ({dt_}/{de_}/{dr_}), L={L} FastLSTM, fp32, Ve={Ve}, "
                                     f"C=46, LSE pool, Adam; scoring pass + train step per batch") if not shipped else
@@ -403,6 +602,8 @@ def main():
                        "paths_per_step_per_gpu": a.paths_per_step, "paths_per_pair_buckets": Ps, "impl": a.impl,
                        "entity_update": "lazy-exact" if a.entity_update == 0 else "dense",
                        "score_overlap": not a.no_score_overlap,
+                       "batch_feed": "streaming" if main_streaming else "resident",
+                       "total_paths": a.total_paths or None,
                        "forward_arithmetic": {0: "fp32 MFMA", 1: "bf16 MFMA products, fp32 accumulate",
                                               2: "f32x6: fp32 operands split exactly into 3 bf16 pieces, 6 partial products on the matrix cores, fp32 accumulate",
                                               3: "f32x3: pre-scaled fp32 operands as 2 fp16 pieces, 3 partial products on the matrix cores, fp32 accumulate"}[a.compute_dtype],
@@ -412,7 +613,10 @@ def main():
             "executed_tflops": round(exec_tflops, 3),
             "mfma_frac_end_to_end": round(exec_tflops / (PEAK_TFLOPS_F32_MFMA * world), 4),  # executed flops / wall clock / fp32 MFMA peak
             "final_loss": round(loss, 6),
-            "roofline": roofline, "cpu_baseline": cpu, "alt_f32x6": alt, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu,
+            "streaming": extras.get("streaming"), "long_run": extras.get("long_run"),
+            "value_no_prefix_plan": (extras.get("no_prefix_plan") or {}).get("value"), "no_prefix_plan": extras.get("no_prefix_plan"),
+            "dp": dp_info, "alt_f32x6": alt, "kernels": kernels,
         }
         print(json.dumps(out))
     if world > 1 or a.force_dp:

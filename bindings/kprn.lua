@@ -8,7 +8,7 @@ same symbols with the same struct layouts; tests/test_abi.py checks both against
   local kprn = require 'kprn'
   local net  = kprn.create{Vt=6, Ve=2851220, Vr=9, dt=16, de=32, dr=16, F=3, num_types=1, H=64, L=2, reducer=2}
   -- MyOptimizer:trainBatch(inputs, targets)          (model/optimizer/MyOptimizer.lua:177-221)
-  local err = net:trainBatch(inputs, targets, classId, optConfig)
+  local err = net:trainBatch(inputs, targets, classId, self.optConfig, self.optInfo)
   -- test_from_checkpoint.lua:109   local preds = model:forward(inputs)
   local preds = net:forward(inputs, 1)
 ]]
@@ -83,10 +83,16 @@ function Net:forward(inputs, classId)  -- == nn.Sequential():add(training_net):a
   return out
 end
 
+-- optConfig / optInfo: the tables model/OneModel.lua:340-383 builds and MyOptimizer keeps (MyOptimizer.lua:19-27).  Only fields
+-- that exist there are read: optInfo.optimMethod (optim.adam | optim.adagrad -- there is no useAdam field), optInfo.regularize,
+-- optInfo.useGradClip (a boolean, OneModel.lua:114), optInfo.gradClipNorm, optInfo.l2; optConfig.learningRate, .beta1, .beta2,
+-- .epsilon (adam) or .learningRateDecay (adagrad).  tests/test_host.py checks this list against the reference.
 function Net:trainBatch(inputs, targets, classId, optConfig, optInfo)
   local B, P, T, F = inputs:size(1), inputs:size(2), inputs:size(3), inputs:size(4)
   local opt = ffi.new('kprn_opt')
-  opt.method = optInfo.useAdam and 1 or 0
+  local optim = rawget(_G, 'optim') or require 'optim'   -- OneModel.lua:16 has it loaded
+  assert(optInfo.optimMethod == optim.adam or optInfo.optimMethod == optim.adagrad, 'optimMethod must be optim.adam or optim.adagrad')
+  opt.method = (optInfo.optimMethod == optim.adam) and 1 or 0
   opt.lr, opt.beta1, opt.beta2, opt.eps = optConfig.learningRate, optConfig.beta1 or 0.9, optConfig.beta2 or 0.999, optConfig.epsilon or 1e-8
   opt.lr_decay = optConfig.learningRateDecay or 0
   opt.regularize, opt.use_grad_clip = optInfo.regularize, optInfo.useGradClip and 1 or 0

@@ -136,6 +136,31 @@ int kprn_zero_pad_tokens(kprn_handle* h);
 int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels,
                       int32_t B, int32_t P, int32_t T, int32_t F, kprn_batch** out);
 void kprn_batch_destroy(kprn_handle* h, kprn_batch* b);
+/* Streaming feed = BatcherFileList's GPU double buffer (BatcherFileList.lua:53-96: tensors preallocated once, every minibatch
+ * :copy()'d into them): (re)fills *slot (NULL: a new slot is allocated; a refill that fits the slot's buffers allocates nothing)
+ * with the upload, the id validation, the occurrence index and the identical-prefix plan queued on a dedicated FEED stream, and
+ * returns at once.  The feed starts behind everything queued on the handle so far (the last readers of the slot's previous
+ * contents among it) and runs under whatever is queued next -- call it for batch i+1 right before the step on batch i.  The first
+ * call that uses the slot waits for its feed; an out-of-range id surfaces there as KPRN_E_INDEX.  idx / labels must stay
+ * unchanged until then; only page-locked host memory (kprn_host_alloc) is copied without holding the calling thread.      */
+int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx, const float* labels,
+                          int32_t B, int32_t P, int32_t T, int32_t F);
+/* BatcherFileList.lua:53-60: size a slot once for the largest minibatch it will hold (max_pairs pairs, max_paths paths of T steps), so that
+ * no later feed allocates (an allocation waits for the device).  *slot NULL: a new, empty slot.  Capacities only ever grow.           */
+int kprn_batch_slot_reserve(kprn_handle* h, kprn_batch** slot, int32_t max_pairs, int64_t max_paths, int32_t T, int32_t F, int32_t with_labels);
+/* Where the feed derives a batch's plan and index: kprn_set_option(h, "feed_build", "host") (default) -- worker threads on the host
+ * cores write them into page-locked staging and the GPU sees DMA traffic only ("feed_workers" batches at once, "feed_threads" helper
+ * threads each) -- or "device": the kernels of kprn_batch_create on a side stream.  Same arrays either way.
+ * kprn_host_batch_index is the host derivation on its own (no handle, no GPU): ids [B,P,T,F] -> validation, identical-prefix plan
+ * (plan != 0: idx_s [B*P*T*F], perm / slot_of [B*P], tile_k [ceil(B*P/64)], pmeta [24]) and the entity-occurrence index
+ * (key_sorted / pos_sorted / uniq: B*P*T + 8 entries each); summary[4] = {an id out of range, longest shared prefix, distinct
+ * entity rows, (path, step) positions the kernels execute}.                                                             */
+int kprn_host_batch_index(const int32_t* idx, int32_t B, int32_t P, int32_t T, int32_t F, int32_t num_types, int32_t Vt, int32_t Ve, int32_t Vr,
+                          int32_t plan, int32_t threads, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k, int32_t* pmeta,
+                          int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq, int64_t* summary);
+/* page-locked host buffers for the feed (the reference preallocates its staging tensors likewise, BatcherFileList.lua:53-60) */
+int kprn_host_alloc(kprn_handle* h, size_t bytes, void** out);
+int kprn_host_free(kprn_handle* h, void* p);
 /* number of distinct entity rows the batch references (= the rows one training step on it touches) */
 int kprn_batch_distinct_rows(kprn_handle* h, const kprn_batch* b, int32_t* n);
 /* (path, step) positions a pass over the batch executes: B*P*T, less the leading steps that whole 64-path tiles share with

@@ -70,6 +70,8 @@ def lib():
     L.kprn_destroy.argtypes = [C.c_void_p]
     L.kprn_batch_destroy.restype = None
     L.kprn_batch_destroy.argtypes = [C.c_void_p, C.c_void_p]
+    L.kprn_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.kprn_host_free.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -86,18 +88,46 @@ def make_opt(method=1, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, lr_decay=0.0, 
 class Batch:
     """A minibatch resident in HBM (BatcherFileList:populateGPUTensor, BatcherFileList.lua:78-96)."""
 
-    def __init__(self, engine, idx, labels=None):
+    def __init__(self, engine, idx, labels=None, feed=False):
+        """feed=False: kprn_batch_create (ready on return).  feed=True: a slot for Batch.refill -- the upload and the index build
+        run on the engine's feed stream, under whatever is queued next (kprn_batch_feed_async)."""
+        self.engine = engine
+        self.ptr = C.c_void_p()
+        self._src = None
+        if feed:
+            self.refill(idx, labels)
+            return
+        idx, lab = self._check(idx, labels)
+        engine._ck(engine.L.kprn_batch_create(engine.h, _fp(idx), _fp(lab), self.B, self.P, self.T, self.F, C.byref(self.ptr)))
+
+    def _check(self, idx, labels):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         if idx.ndim != 4:
             raise KprnError(E_ARG, "idx must be [B,P,T,F]")
-        self.engine = engine
         self.B, self.P, self.T, self.F = (int(x) for x in idx.shape)
         lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.float32)
         if lab is not None and lab.shape != (self.B,):
             raise KprnError(E_ARG, "labels must be [B]")
-        self.ptr = C.c_void_p()
-        engine._ck(engine.L.kprn_batch_create(engine.h, _fp(idx), _fp(lab), self.B, self.P, self.T, self.F, C.byref(self.ptr)))
         self.has_labels = lab is not None
+        return idx, lab
+
+    @classmethod
+    def reserve(cls, engine, max_pairs, max_paths, T, F, with_labels=True):
+        """an empty feed slot sized for the largest minibatch it will hold (kprn_batch_slot_reserve)"""
+        self = cls.__new__(cls)
+        self.engine, self.ptr, self._src = engine, C.c_void_p(), None
+        self.B = self.P = 0
+        self.T, self.F, self.has_labels = T, F, with_labels
+        engine._ck(engine.L.kprn_batch_slot_reserve(engine.h, C.byref(self.ptr), int(max_pairs), C.c_int64(int(max_paths)), int(T), int(F), int(bool(with_labels))))
+        return self
+
+    def refill(self, idx, labels=None):
+        """streaming feed: new contents for this slot, asynchronously.  idx / labels should live in page-locked memory
+        (Engine.host_array) and must stay unchanged until the slot is first used."""
+        idx, lab = self._check(idx, labels)
+        self._src = (idx, lab)  # keep the host buffers alive until the copy has run
+        self.engine._ck(self.engine.L.kprn_batch_feed_async(self.engine.h, C.byref(self.ptr), _fp(idx), _fp(lab), self.B, self.P, self.T, self.F))
+        return self
 
     @property
     def n_paths(self):
@@ -155,6 +185,9 @@ class Engine:
 
     def close(self):
         if self.h:
+            for p in getattr(self, "_pinned", []):
+                self.L.kprn_host_free(self.h, p)
+            self._pinned = []
             self.L.kprn_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -237,6 +270,24 @@ class Engine:
     # -- scoring -------------------------------------------------------------------------
     def batch(self, idx, labels=None):
         return Batch(self, idx, labels)
+
+    def feed(self, idx, labels=None, slot=None):
+        """streaming feed (BatcherFileList.lua:53-96): fills `slot` (or a new one) on the feed stream and returns at once"""
+        if slot is None:
+            return Batch(self, idx, labels, feed=True)
+        return slot.refill(idx, labels)
+
+    def host_array(self, shape, dtype=np.int32):
+        """numpy array in page-locked host memory (kprn_host_alloc): the staging buffers of the streaming feed"""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._ck(self.L.kprn_host_alloc(self.h, C.c_size_t(max(n, 1)), C.byref(p)))
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return arr
 
     def forward(self, batch, class_id=1, want=("probs",)):
         """want: any of probs [B], all_probs [B,C], pooled [B,C], path_scores [B*P,C]."""

@@ -95,6 +95,11 @@ class BatcherFileList:
         for b in self.batchers:
             b.reset()
 
+    def max_batch_positions(self):
+        """largest B*P*T of any minibatch this list can hand out: an upper bound of the entity rows one step touches
+        (the fixed packing capacity of the data-parallel row exchange, kprn_amd/dp.py)"""
+        return max((min(self.batchSize, b.labels.shape[0]) * b.numPaths * b.numTokensInPath for b in self.batchers), default=0)
+
     def getBatchInternal(self):  # CPU path, BatcherFileList.lua:133-146
         if self.currentIndex >= self.numBatchers:
             self.currentIndex = 1

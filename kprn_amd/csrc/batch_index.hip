@@ -109,9 +109,10 @@ void prefix_plan(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int
   tmp = (char*)(((uintptr_t)tmp + 255) & ~(uintptr_t)255);
   const size_t tmp_bytes = scratch_sz - (size_t)(tmp - (char*)scratch);
   const int c0 = F - nT - 2;
-  const int32_t init[2] = {0, 0x7fffffff};
+  // (no host-to-device copy from pageable memory here: it would make the host wait for the stream -- the feed stream runs
+  //  this a whole step ahead of the consumer)
   HIP_TRY(hipMemsetAsync(meta, 0, (size_t)(8 + F) * sizeof(int32_t), s));
-  HIP_TRY(hipMemcpyAsync(meta, init, sizeof(init), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(meta + 1), 0x7fffffff, 1, s));
   const dim3 gn((unsigned)((N + 255) / 256));
   hipLaunchKernelGGL(k_find_ref, gn, dim3(256), 0, s, idx, N, T, F, c0, meta);
   hipLaunchKernelGGL(k_prefix_len, gn, dim3(256), 0, s, idx, N, T, F, c0, kcap, meta, keys, vals);

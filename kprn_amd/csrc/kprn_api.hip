@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <exception>
+#include <functional>
+#include <thread>
 
 #include "kprn_internal.h"
 
@@ -374,8 +376,10 @@ static void pool_stage(kprn_handle* h, const kprn_batch* b, int cid, bool every_
   kk::pool_sigmoid(h->stream, w.S, b->B, b->P, c.C, c.reducer, c.K, every_class ? w.pooled : nullptr, every_class ? w.probs : nullptr, cid, w.sel);
 }
 
+static void batch_ready(kprn_handle* h, const kprn_batch* cb);
 static void check_batch(kprn_handle* h, const kprn_batch* b, int class_id) {
   KPRN_REQUIRE(b != nullptr, KPRN_E_ARG, "batch is NULL");
+  batch_ready(h, b);  // (a slot filled by kprn_batch_feed_async: its feed was issued a step ago)
   KPRN_REQUIRE(class_id >= 1 && class_id <= h->cfg.C, KPRN_E_ARG, "classId must be in 1..C (nn.Select(2,classId), MyOptimizer.lua:126)");
 }
 
@@ -805,6 +809,11 @@ void kprn_destroy(kprn_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   prof_drain(h);
   if (h->score_stream) { hipStreamDestroy(h->score_stream); hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_score_done); }
+  if (h->feed_pool) { hostfeed::free_pool((hostfeed::Pool*)h->feed_pool); h->feed_pool = nullptr; }  // (joins the workers)
+  if (h->upload_pool) { hostfeed::free_pool((hostfeed::Pool*)h->upload_pool); h->upload_pool = nullptr; }
+  if (h->upload_stream) { hipStreamSynchronize(h->upload_stream); hipStreamDestroy(h->upload_stream); h->upload_stream = nullptr; }
+  if (h->feed_stream) { hipStreamSynchronize(h->feed_stream); hipStreamDestroy(h->feed_stream); hipEventDestroy(h->ev_feed_fork); }
+  if (h->feed_scratch) { hipFree(h->feed_scratch); h->feed_scratch = nullptr; }
   dfree(h->S2); dfree(h->sel2);
   fused::release(h);
   if (h->bidx_scratch) { hipFree(h->bidx_scratch); h->bidx_scratch = nullptr; }
@@ -891,84 +900,394 @@ int kprn_zero_pad_tokens(kprn_handle* h) {
   API_END(h)
 }
 
+// ---- batches ---------------------------------------------------------------------------------------------------------------
+// A batch is a slot of device buffers (ids, labels, occurrence index, identical-prefix plan).  kprn_batch_create fills a new slot
+// on the handle's stream and returns when it is ready; kprn_batch_feed_async refills a slot on the FEED stream and returns at
+// once -- the role BatcherFileList:populateGPUTensor plays for the reference (preallocated tensors, one :copy per minibatch,
+// BatcherFileList.lua:53-96), plus the per-batch device work this engine adds (validation, index, plan).
+// All device arrays of a slot live in ONE allocation, laid out afresh for every fill from the batch's own sizes:
+//   idx | idx_s | perm | slot_of | tile_k | pmeta | key_sorted | pos_sorted | uniq ... count | labels | flag
+// (each rounded to 16 bytes).  The host-built feed prepares a page-locked image of exactly this block and uploads it with a
+// single copy.
+struct BatchLayout { int64_t idx, idx_s, perm, slot_of, tile_k, pmeta, key, pos, uniq, cnt, labels, flag, words; };
+static BatchLayout batch_layout(int64_t B, int64_t N, int T, int F, bool plan, bool labels) {
+  auto r4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
+  const int64_t nsteps = N * T, n_index = nsteps + (plan ? fused::KCAP : 0);
+  BatchLayout l;
+  int64_t o = 0;
+  l.idx = o; o += r4(nsteps * F);
+  l.idx_s = o; o += plan ? r4(nsteps * F) : 0;
+  l.perm = o; o += plan ? r4(N) : 0;
+  l.slot_of = o; o += plan ? r4(N) : 0;
+  l.tile_k = o; o += plan ? r4((N + 63) / 64 + 1) : 0;
+  l.pmeta = o; o += plan ? 24 : 0;
+  l.key = o; o += r4(n_index);
+  l.pos = o; o += r4(n_index);
+  l.uniq = o; o += r4(n_index);
+  l.cnt = o; o += 4;
+  l.labels = o; o += labels ? r4(B) : 0;
+  l.flag = o; o += 4;
+  l.words = o;
+  return l;
+}
+
+static void batch_free_buffers(kprn_batch* b) {
+  dfree(b->block);
+  b->block_cap = 0;
+  b->idx = b->idx_s = b->perm = b->slot_of = b->tile_k = b->pmeta = b->key_sorted = b->pos_sorted = b->uniq = b->d_flag = nullptr;
+  b->labels = nullptr;
+}
+
+static void batch_release(kprn_batch* b) {
+  if (b->job.valid()) { try { b->job.get(); } catch (...) {} }
+  if (b->hs) { hipHostFree(b->hs); b->hs = nullptr; }
+  if (b->ev_fork) { hipEventDestroy(b->ev_fork); hipEventDestroy(b->ev_fork2); b->ev_fork = b->ev_fork2 = nullptr; }
+  batch_free_buffers(b);
+  if (b->h_meta) { hipHostFree(b->h_meta); b->h_meta = nullptr; }
+  if (b->ev_ready) { hipEventDestroy(b->ev_ready); b->ev_ready = nullptr; }
+  delete b;
+}
+
+static bool batch_wants_plan(kprn_handle* h, const kprn_batch* b) {
+  static const char* dbg_env = getenv("KPRN_DBG");
+  return h->prefix_plan && use_fused(h, b, true) && b->F <= 16 && !(dbg_env && (atoi(dbg_env) & 64));
+}
+
+// buffers for a [B,P,T,F] batch; a refill that fits the slot's capacities allocates nothing.  quiesce(): called before any
+// buffer of a slot in use is freed.
+static void batch_reserve(kprn_handle* h, kprn_batch* b, int32_t B, int32_t P, int32_t T, int32_t F, bool labels, const std::function<void()>& quiesce,
+                          int64_t min_pairs = 0, int64_t min_paths = 0) {
+  b->B = B; b->P = P; b->T = T; b->F = F;
+  const int64_t nsteps = (int64_t)B * P * T, N = (int64_t)B * P;
+  const bool plan = batch_wants_plan(h, b);
+  b->kcap = plan ? fused::KCAP : 0;
+  b->n_index = nsteps + b->kcap;
+  // the allocation only grows (a slot that has held the largest minibatch never allocates again; kprn_batch_slot_reserve sizes
+  // it up front, for the larger of the two layouts)
+  const BatchLayout l = batch_layout(B, N, T, F, plan, labels);
+  int64_t want = l.words;
+  if (min_pairs > 0 || min_paths > 0)
+    want = std::max(want, batch_layout(std::max<int64_t>(B, min_pairs), std::max<int64_t>(N, min_paths), T, F, true, true).words);
+  if (want > b->block_cap) {
+    if (b->block) { quiesce(); batch_free_buffers(b); }
+    b->block = dalloc<int32_t>(want);
+    b->block_cap = want;
+  }
+  int32_t* k = b->block;
+  b->idx = k + l.idx;
+  b->idx_s = plan ? k + l.idx_s : nullptr; b->perm = plan ? k + l.perm : nullptr; b->slot_of = plan ? k + l.slot_of : nullptr;
+  b->tile_k = plan ? k + l.tile_k : nullptr; b->pmeta = plan ? k + l.pmeta : nullptr;
+  b->key_sorted = k + l.key; b->pos_sorted = k + l.pos; b->uniq = k + l.uniq;
+  b->uniq_cap = l.cnt - l.uniq;  // the distinct-row count lives at uniq[uniq_cap]
+  b->labels = labels ? (float*)(k + l.labels) : nullptr;
+  b->d_flag = k + l.flag;
+  const int64_t meta_need = 2 + 8 + 16 + (std::max<int64_t>(N, min_paths) + 63) / 64 + 1;
+  if (meta_need > b->h_meta_cap) {
+    if (b->h_meta) { quiesce(); hipHostFree(b->h_meta); b->h_meta = nullptr; }
+    HIP_TRY(hipHostMalloc((void**)&b->h_meta, (size_t)meta_need * 2 * sizeof(int32_t)));
+    b->h_meta_cap = meta_need * 2;
+  }
+}
+
+static void scratch_reserve(void** scratch, size_t* bytes, size_t need) {
+  if (need <= *bytes) return;
+  if (*scratch) hipFree(*scratch);
+  *scratch = nullptr; *bytes = 0;
+  HIP_TRY(hipMalloc(scratch, need * 2));
+  *bytes = need * 2;
+}
+
+// upload + validation + identical-prefix plan + occurrence index on stream s; the host-side summary (validation flag, distinct
+// rows, plan header, per-tile prefix lengths) lands in the slot's pinned block behind them.  Nothing here waits for the device.
+static void batch_enqueue(kprn_handle* h, kprn_batch* b, const int32_t* idx, const float* labels, hipStream_t s, void* scratch, size_t scratch_bytes) {
+  const int32_t B = b->B, P = b->P, T = b->T, F = b->F;
+  const int64_t nsteps = (int64_t)B * P * T, N = (int64_t)B * P;
+  const bool plan = b->kcap > 0;
+  HIP_TRY(hipMemcpyAsync(b->idx, idx, (size_t)nsteps * F * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  if (labels) HIP_TRY(hipMemcpyAsync(b->labels, labels, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(b->d_flag, 0, sizeof(int32_t), s));
+  kk::validate_indices(s, b->idx, nsteps, F, h->cfg.num_types, h->cfg.Vt, h->cfg.Ve, h->cfg.Vr, b->d_flag);
+  // identical-prefix plan (fused path only): paths reordered by the number of leading steps they share with the batch's
+  // reference step; the fused kernels start each 64-path tile behind its shared steps (lstm_fused_prefix.hip)
+  if (plan)
+    bidx::prefix_plan(s, b->idx, N, T, F, h->cfg.num_types, b->kcap, b->idx_s, b->perm, b->slot_of, b->tile_k, b->pmeta, scratch, scratch_bytes);
+  // occurrence index: positions sorted by entity row + the sorted distinct rows (count at the tail of the list)
+  bidx::build(s, plan ? b->idx_s : b->idx, N, T, F, h->cfg.Ve, plan ? b->tile_k : nullptr, plan ? b->pmeta : nullptr, b->kcap, b->key_sorted,
+              b->pos_sorted, b->uniq, b->uniq + b->uniq_cap, scratch, scratch_bytes);
+  int32_t* m = b->h_meta;
+  HIP_TRY(hipMemcpyAsync(m, b->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(m + 1, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (plan) {
+    HIP_TRY(hipMemcpyAsync(m + 2, b->pmeta, (size_t)(8 + F) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(m + 2 + 8 + 16, b->tile_k, (size_t)((N + 63) / 64) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  }
+}
+
+// the device work of batch_enqueue is complete: take the host-side summary over
+static void batch_finish(kprn_handle* h, kprn_batch* b) {
+  const int32_t* m = b->h_meta;
+  const int64_t nsteps = (int64_t)b->B * b->P * b->T, N = (int64_t)b->B * b->P;
+  b->pending = false;
+  b->n_uniq = m[1];
+  b->h_kmax = 0;
+  b->exec_steps = nsteps;
+  if (b->kcap > 0) {
+    b->h_kmax = m[2];
+    for (int c = 0; c < b->F && c < 16; ++c) b->h_ref[c] = m[2 + 8 + c];
+    const int32_t* tk = m + 2 + 8 + 16;
+    for (int64_t tl = 0; tl < (N + 63) / 64; ++tl) b->exec_steps -= (int64_t)tk[tl] * std::min<int64_t>(64, N - tl * 64);
+  }
+  b->serial = h->next_serial++;
+  b->bad = (m[0] != 0);
+  KPRN_REQUIRE(!b->bad, KPRN_E_INDEX, "an index is outside 1..vocabSize (ids are 1-based, int2torch.lua:60-63)");
+}
+
+// first use of a slot filled by kprn_batch_feed_async: wait for its feed (issued a step earlier), read the summary
+static void batch_ready(kprn_handle* h, const kprn_batch* cb) {
+  kprn_batch* b = const_cast<kprn_batch*>(cb);
+  if (!b) return;
+  if (b->pending && b->host_built) {
+    // the worker thread has derived plan + index and queued the uploads: take its summary, order this stream behind the uploads
+    b->pending = false;
+    b->job.get();  // (rethrows what the job threw)
+    const kprn_batch::HostResult& r = b->hres;
+    b->bad = r.bad; b->n_uniq = r.n_uniq; b->h_kmax = r.kmax; b->exec_steps = r.exec_steps;
+    for (int c = 0; c < 16; ++c) b->h_ref[c] = r.ref[c];
+    b->serial = h->next_serial++;
+    if (!b->bad) HIP_TRY(hipStreamWaitEvent(h->stream, b->ev_ready, 0));
+  } else if (b->pending) {
+    HIP_TRY(hipEventSynchronize(b->ev_ready));
+    batch_finish(h, b);
+  }
+  KPRN_REQUIRE(!b->bad, KPRN_E_INDEX, "an index is outside 1..vocabSize (ids are 1-based, int2torch.lua:60-63)");
+}
+
+static void check_batch_args(kprn_handle* h, const int32_t* idx, int32_t B, int32_t P, int32_t T, int32_t F) {
+  KPRN_REQUIRE(idx, KPRN_E_ARG, "idx is NULL");
+  KPRN_REQUIRE(B > 0 && P > 0 && T > 0, KPRN_E_ARG, "B, P, T must be positive");
+  KPRN_REQUIRE(F == h->cfg.F, KPRN_E_ARG, "F does not match numFeatureTemplates");
+}
+
 int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, int32_t B, int32_t P, int32_t T, int32_t F, kprn_batch** out) {
   API_BEGIN(h)
   KPRN_REQUIRE(out, KPRN_E_ARG, "out is NULL");
   *out = nullptr;
-  KPRN_REQUIRE(idx, KPRN_E_ARG, "idx is NULL");
-  KPRN_REQUIRE(B > 0 && P > 0 && T > 0, KPRN_E_ARG, "B, P, T must be positive");
-  KPRN_REQUIRE(F == h->cfg.F, KPRN_E_ARG, "F does not match numFeatureTemplates");
+  check_batch_args(h, idx, B, P, T, F);
   kprn_batch* b = new kprn_batch();
   try {
-    b->B = B; b->P = P; b->T = T; b->F = F;
-    const int64_t nsteps = (int64_t)B * P * T;
-    b->idx = dalloc<int32_t>(nsteps * F);
-    HIP_TRY(hipMemcpyAsync(b->idx, idx, (size_t)nsteps * F * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    if (labels) {
-      b->labels = dalloc<float>(B);
-      HIP_TRY(hipMemcpyAsync(b->labels, labels, (size_t)B * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    }
-    HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t), h->stream));
-    kk::validate_indices(h->stream, b->idx, nsteps, F, h->cfg.num_types, h->cfg.Vt, h->cfg.Ve, h->cfg.Vr, h->d_flag);
-    int32_t flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, h->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    KPRN_REQUIRE(flag == 0, KPRN_E_INDEX, "an index is outside 1..vocabSize (ids are 1-based, int2torch.lua:60-63)");
-    // identical-prefix plan (fused path only): paths reordered by the number of leading steps they share with the batch's
-    // reference step; the fused kernels start each 64-path tile behind its shared steps (lstm_fused_prefix.hip)
+    batch_reserve(h, b, B, P, T, F, labels != nullptr, [] {});
     const int64_t N = (int64_t)B * P;
-    static const char* dbg_env = getenv("KPRN_DBG");
-    const bool want_plan = h->prefix_plan && use_fused(h, b, true) && F <= 16 && !(dbg_env && (atoi(dbg_env) & 64));
-    b->kcap = want_plan ? fused::KCAP : 0;
-    b->n_index = nsteps + b->kcap;
-    // occurrence index: positions sorted by entity row + the sorted distinct rows (count at the tail of the list)
-    b->uniq_cap = b->n_index;
-    b->uniq = dalloc<int32_t>(b->n_index + 4);
-    b->key_sorted = dalloc<int32_t>(b->n_index);
-    b->pos_sorted = dalloc<int32_t>(b->n_index);
-    {
-      const size_t need = std::max(bidx::scratch_bytes(b->n_index, h->cfg.Ve), bidx::prefix_scratch_bytes(N, fused::KCAP));
-      if (need > h->bidx_scratch_bytes) {
-        if (h->bidx_scratch) hipFree(h->bidx_scratch);
-        h->bidx_scratch = nullptr;
-        HIP_TRY(hipMalloc(&h->bidx_scratch, need * 2));
-        h->bidx_scratch_bytes = need * 2;
-      }
-    }
-    if (want_plan) {
-      b->idx_s = dalloc<int32_t>(nsteps * F);
-      b->perm = dalloc<int32_t>(N);
-      b->slot_of = dalloc<int32_t>(N);
-      b->tile_k = dalloc<int32_t>((N + 63) / 64 + 1);
-      b->pmeta = dalloc<int32_t>(8 + F);
-      bidx::prefix_plan(h->stream, b->idx, N, T, F, h->cfg.num_types, b->kcap, b->idx_s, b->perm, b->slot_of, b->tile_k, b->pmeta, h->bidx_scratch,
-                        h->bidx_scratch_bytes);
-    }
-    bidx::build(h->stream, want_plan ? b->idx_s : b->idx, N, T, F, h->cfg.Ve, b->tile_k, b->pmeta, b->kcap, b->key_sorted, b->pos_sorted, b->uniq,
-                b->uniq + b->uniq_cap, h->bidx_scratch, h->bidx_scratch_bytes);
-    HIP_TRY(hipMemcpyAsync(&b->n_uniq, b->uniq + b->uniq_cap, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    std::vector<int32_t> tk, hm;
-    if (want_plan) {
-      tk.resize((size_t)((N + 63) / 64));
-      hm.resize((size_t)(8 + F));
-      HIP_TRY(hipMemcpyAsync(tk.data(), b->tile_k, tk.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipMemcpyAsync(hm.data(), b->pmeta, hm.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    }
+    scratch_reserve(&h->bidx_scratch, &h->bidx_scratch_bytes, std::max(bidx::scratch_bytes(b->n_index, h->cfg.Ve), bidx::prefix_scratch_bytes(N, fused::KCAP)));
+    batch_enqueue(h, b, idx, labels, h->stream, h->bidx_scratch, h->bidx_scratch_bytes);
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (want_plan) {
-      b->h_kmax = hm[0];
-      for (int c = 0; c < F && c < 16; ++c) b->h_ref[c] = hm[8 + c];
-    }
-    b->exec_steps = nsteps;
-    for (size_t tl = 0; tl < tk.size(); ++tl) b->exec_steps -= (int64_t)tk[tl] * std::min<int64_t>(64, N - (int64_t)tl * 64);
+    batch_finish(h, b);
   } catch (...) {
-    dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->key_sorted); dfree(b->pos_sorted);
-    dfree(b->idx_s); dfree(b->perm); dfree(b->slot_of); dfree(b->tile_k); dfree(b->pmeta);
-    delete b;
+    batch_release(b);
     throw;
   }
-  b->serial = h->next_serial++;
   *out = b;
+  API_END(h)
+}
+
+// host-built feed: a worker thread runs hostfeed::build into a page-locked image of the slot's device block; ONE upload thread
+// then moves each image with ONE copy, behind the positions the main / scoring streams had when the refill was requested, and
+// keeps a single copy in flight (several streams' worth of small concurrent copies fell back from the DMA engines to copy
+// kernels, which take CUs from the persistent kernels: measured, profiles/r02)
+static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const float* labels) {
+  const int32_t B = b->B, P = b->P, T = b->T, F = b->F;
+  const int64_t nsteps = (int64_t)B * P * T, N = (int64_t)B * P, n_index = b->n_index;
+  if (!h->feed_pool) {
+    if (h->feed_workers <= 0) {  // defaults from the machine: a GPU host has cores to spare, a small container does not
+      const unsigned hc = std::thread::hardware_concurrency();
+      h->feed_workers = hc >= 32 ? 4 : 2;
+      if (h->feed_threads <= 0) h->feed_threads = hc >= 64 ? 8 : (hc >= 16 ? 4 : 2);
+    }
+    if (h->feed_threads <= 0) h->feed_threads = 4;
+    h->feed_pool = hostfeed::make_pool(std::max(1, h->feed_workers));
+    h->upload_pool = hostfeed::make_pool(1);
+    HIP_TRY(hipStreamCreateWithFlags(&h->upload_stream, hipStreamNonBlocking));
+  }
+  if (!b->ev_fork) {
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_fork2, hipEventDisableTiming));
+  }
+  const bool plan = b->kcap > 0;
+  const BatchLayout l = batch_layout(B, N, T, F, plan, labels != nullptr);
+  if (b->block_cap > b->hs_cap) {  // the image is as large as the block: a reserved slot allocates it once
+    if (b->hs) hipHostFree(b->hs);
+    b->hs = nullptr; b->hs_cap = 0;
+    HIP_TRY(hipHostMalloc((void**)&b->hs, (size_t)b->block_cap * sizeof(int32_t)));
+    b->hs_cap = b->block_cap;
+  }
+  if ((int64_t)b->hw.size() < 4 * n_index) b->hw.resize((size_t)(4 * std::max(n_index, (b->block_cap / 8))));
+  HIP_TRY(hipEventRecord(b->ev_fork, h->stream));
+  const bool wait_score = h->score_pending && h->score_stream;
+  if (wait_score) HIP_TRY(hipEventRecord(b->ev_fork2, h->score_stream));
+  const hostfeed::Shape g{B, P, T, F, h->cfg.num_types, h->cfg.Vt, h->cfg.Ve, h->cfg.Vr};
+  const int kcap = b->kcap, nth = std::max(1, h->feed_threads), dev = h->cfg.device_id;
+  int32_t* hs = b->hs;
+  int32_t* hw = b->hw.data();
+  if (labels) memcpy(hs + l.labels, labels, (size_t)B * sizeof(float));
+  hs[l.flag] = 0;
+  b->host_built = true;
+  auto done = std::make_shared<std::promise<void>>();
+  b->job = done->get_future();
+  hostfeed::Pool* up_pool = (hostfeed::Pool*)h->upload_pool;
+  hipStream_t us = h->upload_stream;
+  hostfeed::submit((hostfeed::Pool*)h->feed_pool, [=]() {
+    try {
+      kprn_batch::HostResult* r = &b->hres;
+      hostfeed::build(g, idx, kcap, nth, r, hs + l.idx_s, hs + l.perm, hs + l.slot_of, hs + l.tile_k, hs + l.pmeta, hs + l.key, hs + l.pos, hs + l.uniq,
+                      hw, hw + n_index, hw + 2 * n_index, hw + 3 * n_index);
+      if (!r->bad) {
+        memcpy(hs + l.idx, idx, (size_t)(nsteps * F) * sizeof(int32_t));
+        hs[l.cnt] = r->n_uniq;
+      }
+    } catch (...) { done->set_exception(std::current_exception()); return; }
+    hostfeed::submit(up_pool, [=]() {
+      bool issued = false;
+      try {
+        HIP_TRY(hipSetDevice(dev));
+        if (!b->hres.bad) {
+          HIP_TRY(hipStreamWaitEvent(us, b->ev_fork, 0));
+          if (wait_score) HIP_TRY(hipStreamWaitEvent(us, b->ev_fork2, 0));
+          HIP_TRY(hipMemcpyAsync(b->block, hs, (size_t)l.words * sizeof(int32_t), hipMemcpyHostToDevice, us));
+        }
+        HIP_TRY(hipEventRecord(b->ev_ready, us));
+        issued = true;
+        done->set_value();
+        HIP_TRY(hipStreamSynchronize(us));  // one image in flight at a time
+      } catch (...) { if (!issued) done->set_exception(std::current_exception()); }
+    });
+  });
+}
+
+int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx, const float* labels, int32_t B, int32_t P, int32_t T, int32_t F) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(slot, KPRN_E_ARG, "slot is NULL");
+  check_batch_args(h, idx, B, P, T, F);
+  if (!h->feed_stream) {
+    // the feed's kernels are small and latency-bound; they get the CUs the persistent kernels leave idle in their tails.  High
+    // priority: when CUs free up, the feed's workgroups are placed before the next big kernel's (KPRN_FEED_PRIO=0: default priority)
+    static const char* prio_env = getenv("KPRN_FEED_PRIO");
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (prio_env && atoi(prio_env) == 0) HIP_TRY(hipStreamCreateWithFlags(&h->feed_stream, hipStreamNonBlocking));
+    else HIP_TRY(hipStreamCreateWithPriority(&h->feed_stream, hipStreamNonBlocking, hi));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_feed_fork, hipEventDisableTiming));
+  }
+  kprn_batch* b = *slot;
+  const bool fresh = (b == nullptr);
+  if (fresh) b = new kprn_batch();
+  try {
+    if (!fresh) {
+      // the slot's previous contents: whatever the handle still refers to goes to owned storage; their last readers were
+      // enqueued before this call, and the feed stream starts behind them (below)
+      if (h->view_batch == b) {
+        if (h->ent_grads_dirty) materialize_step_rows(h);  // gradients of a backward without an update still name these rows
+        else { h->view_batch = nullptr; h->rows_view = h->step_rows; h->count_view = h->step_count; h->step_rows_ub = 0; }
+      }
+      if (h->caught_serial == b->serial) h->caught_serial = -1;
+      if (b->pending && b->host_built) { b->job.get(); b->pending = false; }
+      // (also when the slot was used: its uploads read the page-locked staging the next fill overwrites -- this is the feed's
+      //  back-pressure on a host that runs ahead of the device)
+      if (b->ev_ready && (b->pending || b->host_built)) HIP_TRY(hipEventSynchronize(b->ev_ready));
+      b->pending = false;
+    }
+    auto quiesce = [&] {
+      if (h->score_stream) HIP_TRY(hipStreamSynchronize(h->score_stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(hipStreamSynchronize(h->feed_stream));
+      if (h->upload_stream) HIP_TRY(hipStreamSynchronize(h->upload_stream));
+    };
+    batch_reserve(h, b, B, P, T, F, labels != nullptr, quiesce);
+    if (!b->ev_ready) HIP_TRY(hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming));
+    if (h->feed_build_host) {
+      feed_host(h, b, idx, labels);
+    } else {
+      b->host_built = false;
+      const int64_t N = (int64_t)B * P;
+      const size_t need = std::max(bidx::scratch_bytes(b->n_index, h->cfg.Ve), bidx::prefix_scratch_bytes(N, fused::KCAP));
+      if (need > h->feed_scratch_bytes) {
+        HIP_TRY(hipStreamSynchronize(h->feed_stream));
+        scratch_reserve(&h->feed_scratch, &h->feed_scratch_bytes, need);
+      }
+      // everything enqueued on the handle so far (the last readers of this slot among it) comes first
+      HIP_TRY(hipEventRecord(h->ev_feed_fork, h->stream));
+      HIP_TRY(hipStreamWaitEvent(h->feed_stream, h->ev_feed_fork, 0));
+      if (h->score_pending) HIP_TRY(hipStreamWaitEvent(h->feed_stream, h->ev_score_done, 0));
+      batch_enqueue(h, b, idx, labels, h->feed_stream, h->feed_scratch, h->feed_scratch_bytes);
+      HIP_TRY(hipEventRecord(b->ev_ready, h->feed_stream));
+    }
+    b->pending = true;
+  } catch (...) {
+    if (fresh) batch_release(b);
+    throw;
+  }
+  *slot = b;
+  API_END(h)
+}
+
+int kprn_batch_slot_reserve(kprn_handle* h, kprn_batch** slot, int32_t max_pairs, int64_t max_paths, int32_t T, int32_t F, int32_t with_labels) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(slot && max_pairs > 0 && max_paths >= max_pairs && T > 0, KPRN_E_ARG, "bad argument");
+  KPRN_REQUIRE(F == h->cfg.F, KPRN_E_ARG, "F does not match numFeatureTemplates");
+  kprn_batch* b = *slot;
+  const bool fresh = (b == nullptr);
+  if (fresh) b = new kprn_batch();
+  try {
+    if (!fresh) {
+      if (h->view_batch == b) materialize_step_rows(h);
+      if (b->pending && b->host_built && b->job.valid()) { try { b->job.get(); } catch (...) {} }
+      b->pending = false; b->bad = true;  // (no contents until the next feed)
+    }
+    auto quiesce = [&] {
+      if (h->score_stream) HIP_TRY(hipStreamSynchronize(h->score_stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->feed_stream) HIP_TRY(hipStreamSynchronize(h->feed_stream));
+      if (h->upload_stream) HIP_TRY(hipStreamSynchronize(h->upload_stream));
+    };
+    const int32_t P1 = (int32_t)std::max<int64_t>(1, max_paths / max_pairs);
+    batch_reserve(h, b, max_pairs, P1, T, F, with_labels != 0, quiesce, max_pairs, max_paths);
+    if (fresh) b->bad = true;
+  } catch (...) {
+    if (fresh) batch_release(b);
+    throw;
+  }
+  *slot = b;
+  API_END(h)
+}
+
+int kprn_host_batch_index(const int32_t* idx, int32_t B, int32_t P, int32_t T, int32_t F, int32_t num_types, int32_t Vt, int32_t Ve, int32_t Vr,
+                          int32_t plan, int32_t threads, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k, int32_t* pmeta,
+                          int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq, int64_t* summary) {
+  if (!idx || B <= 0 || P <= 0 || T <= 0 || F < num_types + 2 || num_types < 1 || !key_sorted || !pos_sorted || !uniq || !summary) return KPRN_E_ARG;
+  if (plan && (T < 2 || F > 16 || !idx_s || !perm || !slot_of || !tile_k || !pmeta)) return KPRN_E_ARG;
+  try {
+    const int kcap = plan ? fused::KCAP : 0;
+    const int64_t n_index = (int64_t)B * P * T + kcap;
+    std::vector<int32_t> w((size_t)(4 * n_index));
+    kprn_batch::HostResult r;
+    const hostfeed::Shape g{B, P, T, F, num_types, Vt, Ve, Vr};
+    hostfeed::build(g, idx, kcap, std::max(1, (int)threads), &r, idx_s, perm, slot_of, tile_k, pmeta, key_sorted, pos_sorted, uniq, w.data(),
+                    w.data() + n_index, w.data() + 2 * n_index, w.data() + 3 * n_index);
+    summary[0] = r.bad ? 1 : 0; summary[1] = r.kmax; summary[2] = r.n_uniq; summary[3] = r.exec_steps;
+  } catch (...) { return KPRN_E_NOMEM; }
+  return KPRN_OK;
+}
+
+int kprn_host_alloc(kprn_handle* h, size_t bytes, void** out) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(out && bytes > 0, KPRN_E_ARG, "bad argument");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes);
+  if (e != hipSuccess) throw KprnError{KPRN_E_NOMEM, std::string("hipHostMalloc failed: ") + hipGetErrorString(e)};
+  API_END(h)
+}
+
+int kprn_host_free(kprn_handle* h, void* p) {
+  API_BEGIN(h)
+  if (p) HIP_TRY(hipHostFree(p));
   API_END(h)
 }
 
@@ -978,17 +1297,19 @@ void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
     hipSetDevice(h->cfg.device_id);
     if (h->view_batch == b) { try { materialize_step_rows(h); } catch (...) { h->view_batch = nullptr; h->rows_view = nullptr; h->step_rows_ub = 0; } }
     if (h->caught_serial == b->serial) h->caught_serial = -1;
+    if (b->job.valid()) { try { b->job.get(); } catch (...) {} }
+    if (h->upload_stream) hipStreamSynchronize(h->upload_stream);
+    if (h->feed_stream) hipStreamSynchronize(h->feed_stream);
     if (h->score_stream) hipStreamSynchronize(h->score_stream);  // a scoring pass on the second stream may still read the batch
     hipStreamSynchronize(h->stream);
   }
-  dfree(b->idx); dfree(b->labels); dfree(b->uniq); dfree(b->key_sorted); dfree(b->pos_sorted);
-  dfree(b->idx_s); dfree(b->perm); dfree(b->slot_of); dfree(b->tile_k); dfree(b->pmeta);
-  delete b;
+  batch_release(b);
 }
 
 int kprn_batch_distinct_rows(kprn_handle* h, const kprn_batch* b, int32_t* n) {
   API_BEGIN(h)
   KPRN_REQUIRE(b && n, KPRN_E_ARG, "NULL argument");
+  batch_ready(h, b);
   *n = b->n_uniq;
   API_END(h)
 }
@@ -996,6 +1317,7 @@ int kprn_batch_distinct_rows(kprn_handle* h, const kprn_batch* b, int32_t* n) {
 int kprn_batch_executed_steps(kprn_handle* h, const kprn_batch* b, int64_t* steps) {
   API_BEGIN(h)
   KPRN_REQUIRE(b && steps, KPRN_E_ARG, "NULL argument");
+  batch_ready(h, b);
   *steps = b->exec_steps;
   API_END(h)
 }
@@ -1195,12 +1517,13 @@ int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int6
   KPRN_REQUIRE(capacity >= h->step_rows_ub && capacity > 0, KPRN_E_ARG, "capacity smaller than this step's touched-row count");
   const int de = h->cfg.de;
   const int64_t words = 4 + (int64_t)capacity * (1 + de);
-  if (capacity > h->pack_cap) {
+  if (words > h->pack_words) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     dfree(h->pack_buf);
     h->pack_buf = dalloc<int32_t>(words);
-    h->pack_cap = capacity;
+    h->pack_words = words;
   }
+  h->pack_cap = capacity;  // the capacity THIS buffer is laid out with (ids at +4, rows at +4+capacity): merge checks against it
   if (!h->view_batch) { h->rows_view = h->step_rows; h->count_view = h->step_count; }
   {
     ProfScope ps(h, "dp_pack_rows");
@@ -1208,7 +1531,7 @@ int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int6
                   h->pack_buf);
   }
   *dev_buf = h->pack_buf;
-  *n_words = 4 + (int64_t)h->pack_cap * (1 + de);
+  *n_words = words;
   API_END(h)
 }
 
@@ -1227,10 +1550,7 @@ int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, i
     const size_t need = bidx::merge_scratch_bytes(n, h->cfg.Ve);
     if (need > h->bidx_scratch_bytes) {
       HIP_TRY(hipStreamSynchronize(h->stream));
-      if (h->bidx_scratch) hipFree(h->bidx_scratch);
-      h->bidx_scratch = nullptr;
-      HIP_TRY(hipMalloc(&h->bidx_scratch, need * 2));
-      h->bidx_scratch_bytes = need * 2;
+      scratch_reserve(&h->bidx_scratch, &h->bidx_scratch_bytes, need);
     }
   }
   {
@@ -1340,6 +1660,18 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // kprn_forward_batch_async on a second stream (fused path): the scoring pass shares the chip with the work enqueued after it
     join_score(h);
     h->score_overlap = atoi(value) ? 1 : 0;
+  } else if (strcmp(key, "feed_build") == 0) {
+    if (strcmp(value, "host") == 0) h->feed_build_host = 1;
+    else if (strcmp(value, "device") == 0) h->feed_build_host = 0;
+    else throw KprnError{KPRN_E_ARG, "feed_build must be host or device"};
+  } else if (strcmp(key, "feed_threads") == 0) {
+    const int v = atoi(value);
+    KPRN_REQUIRE(v >= 1 && v <= 64, KPRN_E_ARG, "feed_threads must be in 1..64");
+    h->feed_threads = v;
+  } else if (strcmp(key, "feed_workers") == 0) {
+    const int v = atoi(value);
+    KPRN_REQUIRE(v >= 1 && v <= 64 && !h->feed_pool, KPRN_E_ARG, "feed_workers must be in 1..64 and set before the first feed");
+    h->feed_workers = v;
   } else if (strcmp(key, "profile_filter") == 0) {
     h->prof_filter = value;  // "" = every kernel family; else only families whose name starts with this
   } else if (strcmp(key, "reserve_cus") == 0) {

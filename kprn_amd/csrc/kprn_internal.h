@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
+#include <future>
 #include <string>
 #include <vector>
 #include <map>
@@ -86,6 +88,23 @@ struct kprn_batch {
   int h_kmax = 0;                 // host copy: longest shared prefix in the batch (0: nothing is skipped)
   int32_t h_ref[16] = {0};        // host copy: the reference step's ids (1-based, all F <= 16 columns)
   int64_t exec_steps = 0;         // (path, step) positions the kernels execute (B*P*T without a plan)
+  // ---- streaming feed (kprn_batch_feed_async): a batch is a SLOT whose buffers are refilled in place, the way
+  // BatcherFileList:populateGPUTensor copies every minibatch into preallocated tensors (BatcherFileList.lua:53-96)
+  int32_t* block = nullptr; int64_t block_cap = 0;  // the ONE device allocation all arrays above point into (32-bit words)
+  int32_t* d_flag = nullptr;      // device [4]: id-validation flag of this batch
+  int32_t* h_meta = nullptr;      // pinned host [h_meta_cap]: flag, n_uniq, plan header [8+F], tile_k copy
+  int64_t h_meta_cap = 0;
+  hipEvent_t ev_ready = nullptr;  // recorded behind the slot's upload + index build on the feed stream
+  bool pending = false;           // filled asynchronously: the host-side fields above are read back at first use
+  bool bad = false;               // an id of the current contents is outside its vocabulary: every use returns KPRN_E_INDEX
+  // host-built feed (host_feed.hip): a worker thread derives plan + index on the host cores into page-locked staging and queues
+  // the uploads on the slot's own copy stream; the consumer waits for the job (host) and for ev_ready (stream-side, no host wait)
+  bool host_built = false;
+  std::future<void> job;          // valid while pending && host_built
+  int32_t* hs = nullptr; int64_t hs_cap = 0;   // page-locked image of the device block
+  std::vector<int32_t> hw;        // work arrays of the host build (4 x index entries)
+  hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr;  // main / scoring stream position when the refill was requested
+  struct HostResult { bool bad = false; int kmax = 0; int32_t ref[16] = {0}; int32_t n_uniq = 0; int64_t exec_steps = 0; } hres;
 };
 
 struct kprn_handle {
@@ -132,7 +151,7 @@ struct kprn_handle {
   int64_t next_serial = 1;
   float* loss_partial = nullptr; int64_t loss_partial_cap = 0; int loss_pending = 0;  // >0: d_loss = sum of that many partials, not formed yet
   // packing buffers for the data-parallel exchange
-  int32_t* pack_buf = nullptr; int64_t pack_cap = 0;  // {count,-,-,-, ids[cap], rows[cap*de]} 32-bit words
+  int32_t* pack_buf = nullptr; int64_t pack_cap = 0, pack_words = 0;  // {count,-,-,-, ids[cap], rows[cap*de]} 32-bit words; cap of the last pack, allocated words
 
   // scalars on device
   float* d_loss = nullptr;      // [1]
@@ -144,6 +163,15 @@ struct kprn_handle {
   float* score_buf = nullptr;   // where the mapper output [N][C] of the last forward lives (ws.S)
   void* fused_state = nullptr;  // owned by lstm_fused_*.hip
   void* bidx_scratch = nullptr; size_t bidx_scratch_bytes = 0;  // batch_index.hip temporaries
+  // streaming batch feed: upload + validation + occurrence index + prefix plan of the NEXT batch on their own stream, under
+  // the step that is running (kprn_batch_feed_async)
+  hipStream_t feed_stream = nullptr; hipEvent_t ev_feed_fork = nullptr;
+  void* feed_scratch = nullptr; size_t feed_scratch_bytes = 0;
+  int feed_build_host = 1;        // kprn_set_option "feed_build": host (worker threads + DMA, default) | device (kernels on the feed stream)
+  int feed_workers = 0, feed_threads = 0;  // batches in preparation at once / helper threads per batch (0: from the core count)
+  void* feed_pool = nullptr;      // hostfeed::Pool: builds the images
+  void* upload_pool = nullptr;    // hostfeed::Pool of ONE thread: issues the uploads, one in flight at a time
+  hipStream_t upload_stream = nullptr;
   int impl = 0;                 // 0 auto, 1 generic
   // scoring overlap (kprn_set_option "score_overlap"): kprn_forward_batch_async runs the fused scoring pass on a second stream
   // with its own output buffers, so that it shares the chip with whatever the main stream does next (the training forward
@@ -276,6 +304,18 @@ size_t merge_scratch_bytes(int64_t n, int Ve);
 void merge_rows(hipStream_t s, const void* all, int world, int cap, int de, int Ve, float* G, int32_t* union_rows, int32_t* union_count,
                 void* scratch, size_t scratch_sz);
 }  // namespace bidx
+
+// ---- host side of the streaming feed (host_feed.hip) -------------------------------------------------
+namespace hostfeed {
+struct Shape { int B, P, T, F, nT, Vt, Ve, Vr; };
+typedef kprn_batch::HostResult Result;
+class Pool;
+Pool* make_pool(int workers);
+void free_pool(Pool* p);
+std::future<void> submit(Pool* p, std::function<void()> fn);
+void build(const Shape& g, const int32_t* idx, int kcap, int nth, Result* r, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
+           int32_t* pmeta, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq, int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3);
+}  // namespace hostfeed
 
 // ---- GEMM (gemm_f32.hip): C[M,N] (+)= A(M,K) * B(K,N), arbitrary strides, fp32 MFMA -----------
 namespace gemm {

@@ -55,6 +55,10 @@ class GpuAdapter:
     def local_rows(self):
         return self.e.sparse_grad_capacity()
 
+    def batch_rows(self, batch):
+        """distinct entity rows a step on `batch` touches (known from the batch index before the backward runs)"""
+        return batch.n_uniq
+
     def pack(self, capacity):
         ptr, n_words = self.e.sparse_grad_pack(capacity)
         return wrap_device(ptr, n_words, "i32", self.device)
@@ -73,7 +77,19 @@ class GpuAdapter:
 
 
 class DataParallel:
-    def __init__(self, adapter, group=None):
+    """adapter: GpuAdapter (or the numpy stand-in of the CPU tests).
+
+    Packing capacity (rows per rank in the all-gathered buffer, identical on every rank):
+      * set_capacity(bound) with a TRUE upper bound of the distinct rows any rank touches in any step (bench.py: the
+        largest distinct-row count of its fixed batches; MyOptimizer: min(largest minibatch * P * T + 8, Ve) from the
+        batcher) -> no per-step agreement, nothing on the host waits for the device;
+      * otherwise (no bound promised) every step agrees on it: ONE small all-reduce carrying every rank's row count and
+        pair count, read on the host; the capacity grows when a step needs more.  Correct for ragged shards, one host
+        round trip per step slower.
+    Loss scale: 1 / (pairs of the GLOBAL minibatch).  equal_shards=True takes B * world; else the agreed sum (or the
+    caller's global_pairs)."""
+
+    def __init__(self, adapter, group=None, equal_shards=True):
         self.a = adapter
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -82,35 +98,91 @@ class DataParallel:
         # single-GPU dev box exercises the exact call sequence of the N-GPU run
         self.collectives = dist.is_initialized()
         self.capacity = 0
+        self.bounded = False
+        self.equal_shards = equal_shards
         self._all = None
+        self.timing = False   # bench.py: events around the parts of the exchange (GPU adapter only)
+        self._ev = []
 
-    def set_capacity(self, local_max_rows):
-        """fixed per-rank packing capacity = max over ranks of the largest per-step touched-row count."""
-        t = torch.tensor([int(local_max_rows)], dtype=torch.int64)
+    def _dev(self, t):
+        if self.collectives and dist.get_backend(self.group) == "nccl":
+            return t.to(self.a.device)
+        return t
+
+    def set_capacity(self, local_max_rows, bound=True):
+        """fixed per-rank packing capacity = max over ranks of local_max_rows; bound=True promises that no step of any rank
+        touches more distinct rows than that."""
+        t = self._dev(torch.tensor([int(local_max_rows)], dtype=torch.int64))
         if self.collectives:
-            if dist.get_backend(self.group) == "nccl":
-                t = t.to(self.a.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         self.capacity = max(1, int(t.item()))
+        self.bounded = bool(bound)
         self._all = None
         return self.capacity
+
+    def _agree(self, rows, pairs):
+        """-> (largest row count of any rank this step, pairs of the global minibatch)"""
+        t = torch.zeros(self.world + 1, dtype=torch.int64)
+        t[self.rank] = int(rows)
+        t[self.world] = int(pairs)
+        t = self._dev(t)
+        if self.collectives:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        t = t.cpu()
+        return int(t[:self.world].max().item()), int(t[self.world].item())
+
+    def _mark(self):
+        if self.timing:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._ev[-1].append(e)
+
+    def timing_summary(self):
+        """mean ms per step of the parts: dense all-reduce | pack | all-gather (+ whatever the overlap callable queued) | merge | update"""
+        torch.cuda.synchronize()
+        names = ["dense_allreduce", "pack", "allgather_and_overlapped_work", "merge", "optimizer_step"]
+        acc = {n: 0.0 for n in names}
+        k = 0
+        for ev in self._ev:
+            if len(ev) != len(names) + 1:
+                continue
+            for i, n in enumerate(names):
+                acc[n] += ev[i].elapsed_time(ev[i + 1])
+            k += 1
+        self._ev = []
+        return {n: round(v / max(k, 1), 4) for n, v in acc.items()}
 
     def train_step(self, batch, opt, class_id=1, global_pairs=None, overlap=None):
         """one data-parallel MyOptimizer:trainBatch; `batch` holds THIS rank's pairs.
         overlap: optional callable that ENQUEUES work which does not depend on this step's update (e.g. a scoring pass
         with the pre-update parameters); it runs while the entity-row all-gather is in flight."""
         a = self.a
+        need = None
+        if global_pairs is None and not self.equal_shards:
+            need, global_pairs = self._agree(a.batch_rows(batch), batch.B)
         gp = global_pairs if global_pairs is not None else batch.B * self.world
         a.zero_pad()  # MyOptimizer.lua:181
         a.backward(batch, class_id, bool(opt.bce_literal), 1.0 / float(gp))
+        if self.timing:
+            self._ev.append([])
+        self._mark()
         if self.collectives:
             dist.all_reduce(a.dense_grads(), op=dist.ReduceOp.SUM, group=self.group)
-        if self.capacity <= 0:
-            self.set_capacity(a.local_rows())
+        self._mark()
+        if not self.bounded:
+            if need is None:
+                need, _ = self._agree(a.local_rows(), batch.B)
+            if need > self.capacity:
+                self.capacity = int(need * 1.25) + 16   # the same number on every rank
+                self._all = None
+        elif a.local_rows() > self.capacity:
+            raise RuntimeError(f"rank {self.rank}: this step touches {a.local_rows()} entity rows, more than the capacity "
+                               f"{self.capacity} promised to set_capacity(bound=True)")
         cap = self.capacity
         buf = a.pack(cap)  # one packed tensor per rank, same length everywhere
         if self._all is None or self._all.numel() != buf.numel() * self.world or self._all.dtype != buf.dtype:
             self._all = torch.empty(buf.numel() * self.world, dtype=buf.dtype, device=buf.device)
+        self._mark()
         work = None
         if self.collectives:
             work = dist.all_gather_into_tensor(self._all, buf, group=self.group, async_op=True)
@@ -120,8 +192,11 @@ class DataParallel:
             overlap()      # compute that hides the exchange (xGMI is otherwise the only thing working right now)
         if work is not None:
             work.wait()    # stream-level wait: the merge below is ordered after the collective
+        self._mark()
         a.merge(self._all, self.world, cap)  # union of the rows, summed in rank order
+        self._mark()
         a.apply_update(opt)
+        self._mark()
 
 
 def shard_pairs(n_pairs, rank, world):

@@ -61,6 +61,9 @@ class OracleAdapter:
     def local_rows(self):
         return len(self.rows)
 
+    def batch_rows(self, batch):
+        return len(np.unique(batch.idx[..., -2]))
+
     def pack(self, capacity):
         """one packed float64 tensor {count, ids[cap], rows[cap*de]} (the GPU adapter packs 32-bit words)"""
         ge = self.g[self.e0:self.e1].reshape(-1, self.de)
@@ -133,6 +136,54 @@ def test_two_ranks_equal_one_big_batch(tmp_path):
     idx, labels = synth.make_paths(12, 3, 4, Ve=80, seed=7)
     st = o.new_state()
     for _ in range(3):
+        o.train_step(theta, st, make_opt(method=1, lr=1e-2), idx, labels)
+    np.testing.assert_allclose(t0, theta, rtol=1e-10, atol=1e-13)
+
+
+def _ragged_worker(rank, world, port, out_dir):
+    """ragged shards, batches of varying size, NO capacity bound promised (a capacity frozen at the first step's
+    row count aborted later steps; B * world is the wrong global batch for unequal shards)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = _cfg()
+        theta = Oracle(cfg).init_params(3, 0.3)
+        a = OracleAdapter(cfg, theta)
+        d = dp.DataParallel(a, equal_shards=False)
+        opt = make_opt(method=1, lr=1e-2)
+        caps = []
+        for step, n in enumerate(_RAGGED):
+            idx, labels = synth.make_paths(n, 3, 4, Ve=80, seed=40 + step)
+            cut = (n * 2) // 3          # rank 0: two thirds of the pairs, rank 1: the rest
+            sl = slice(0, cut) if rank == 0 else slice(cut, n)
+            d.train_step(_Batch(idx[sl], labels[sl]), opt, 1)
+            caps.append(d.capacity)
+        np.save(os.path.join(out_dir, f"rtheta{rank}.npy"), a.theta)
+        np.save(os.path.join(out_dir, f"rcaps{rank}.npy"), np.array(caps))
+    finally:
+        dist.destroy_process_group()
+
+
+_RAGGED = [2, 5, 17, 9, 30]   # pairs of the global minibatch, step by step: the touched-row count grows
+
+
+def test_ragged_shards_growing_capacity_equal_one_big_batch(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_ragged_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    t0 = np.load(tmp_path / "rtheta0.npy")
+    t1 = np.load(tmp_path / "rtheta1.npy")
+    assert np.array_equal(t0, t1)
+    c0, c1 = np.load(tmp_path / "rcaps0.npy"), np.load(tmp_path / "rcaps1.npy")
+    assert np.array_equal(c0, c1) and c0[-1] > c0[0]   # the capacity grew, identically on both ranks
+    cfg = _cfg()
+    o = Oracle(cfg)
+    theta = o.init_params(3, 0.3)
+    st = o.new_state()
+    for step, n in enumerate(_RAGGED):
+        idx, labels = synth.make_paths(n, 3, 4, Ve=80, seed=40 + step)
         o.train_step(theta, st, make_opt(method=1, lr=1e-2), idx, labels)
     np.testing.assert_allclose(t0, theta, rtol=1e-10, atol=1e-13)
 

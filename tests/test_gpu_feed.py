@@ -1,0 +1,135 @@
+"""-m gpu: the streaming batch feed (kprn_batch_feed_async) -- the engine's counterpart of BatcherFileList's GPU double buffer
+(release/songPathRnn/model/batcher/BatcherFileList.lua:53-96: tensors preallocated once, every minibatch :copy()'d into them).
+A slot refilled on the feed stream must behave exactly like a batch made by kprn_batch_create."""
+import numpy as np
+import pytest
+
+from kprn_amd import _ffi, synth
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = (6, 5000, 9, 16, 32, 16, 64, 2)
+
+
+def _pinned(eng, idx, labels):
+    hi = eng.host_array(idx.shape, np.int32)
+    hi[...] = idx
+    hl = eng.host_array(labels.shape, np.float32)
+    hl[...] = labels
+    return hi, hl
+
+
+def _batches(n, seed=0):
+    out = []
+    for i in range(n):
+        P = [1, 3, 2, 5, 4, 8][i % 6]
+        pairs = [700, 300, 900, 150, 1100, 90][i % 6]   # the slots must grow (realloc) and shrink (reuse)
+        out.append(synth.make_paths(pairs, P, 6, Ve=5000, seed=seed + 11 * i))
+    return out
+
+
+@pytest.mark.parametrize("build", ["host", "device"])
+@pytest.mark.parametrize("impl", ["auto", "generic"])
+def test_fed_slot_equals_created_batch(impl, build):
+    eng = _ffi.Engine(*SHAPE)
+    eng.set_option("impl", impl)
+    eng.set_option("feed_build", build)
+    idx, labels = synth.make_paths(500, 3, 6, Ve=5000, seed=3)
+    ref = eng.batch(idx, labels)
+    hi, hl = _pinned(eng, idx, labels)
+    slot = eng.feed(hi, hl)
+    assert slot.n_uniq == ref.n_uniq and slot.executed_steps == ref.executed_steps
+    a = eng.forward(ref, 1, want=("probs", "path_scores"))
+    b = eng.forward(slot, 1, want=("probs", "path_scores"))
+    assert np.array_equal(a["probs"], b["probs"]) and np.array_equal(a["path_scores"], b["path_scores"])
+    la = eng.backward(ref, 1)
+    ga = eng.get_flat_grads()
+    lb = eng.backward(slot, 1)
+    gb = eng.get_flat_grads()
+    assert abs(la - lb) < 1e-6 * max(1.0, abs(la))
+    assert np.max(np.abs(ga - gb)) <= 2e-6 * np.max(np.abs(ga))   # (a few fp32 atomics in the embedding backward)
+    eng.close()
+
+
+@pytest.mark.parametrize("build", ["host", "device"])
+@pytest.mark.parametrize("score_overlap", ["0", "1"])
+def test_slot_ring_trains_like_resident_batches(score_overlap, build):
+    """the loop bench.py --batch-feed streaming runs: feed the batches of the next steps, then score + train on batch i"""
+    data = _batches(9, seed=100)
+    opt = _ffi.make_opt(method=1, lr=1e-2)
+    res = []
+    for streaming in (False, True):
+        eng = _ffi.Engine(*SHAPE, seed=7)
+        eng.set_option("score_overlap", score_overlap)
+        eng.set_option("feed_build", build)
+        probs = []
+        if streaming:
+            host = [_pinned(eng, i, l) for i, l in data]
+            NS = 3
+            slots = [None] * NS
+            fed = -1
+            for s in range(len(data)):
+                while fed < min(s + NS - 1, len(data) - 1):
+                    fed += 1
+                    slots[fed % NS] = eng.feed(host[fed][0], host[fed][1], slot=slots[fed % NS])
+                b = slots[s % NS]
+                eng.forward_async(b, 1)
+                eng.train_step(b, opt, want_loss=False)
+                probs.append(eng.read_probs(b.B))
+        else:
+            for i, l in data:
+                b = eng.batch(i, l)
+                eng.forward_async(b, 1)
+                eng.train_step(b, opt, want_loss=False)
+                probs.append(eng.read_probs(b.B))
+        res.append((eng.get_flat_params(), probs, eng.read_loss()))
+        eng.close()
+    (pa, qa, la), (pb, qb, lb) = res
+    assert abs(la - lb) < 1e-5 * max(1.0, abs(la))
+    assert np.max(np.abs(pa - pb)) < 2e-6
+    for x, y in zip(qa, qb):
+        np.testing.assert_allclose(x, y, rtol=1e-5)
+
+
+@pytest.mark.parametrize("build", ["host", "device"])
+def test_bad_id_surfaces_at_first_use_and_the_slot_recovers(build):
+    eng = _ffi.Engine(*SHAPE)
+    eng.set_option("feed_build", build)
+    idx, labels = synth.make_paths(64, 2, 6, Ve=5000, seed=5)
+    bad = idx.copy()
+    bad[3, 1, 2, 1] = 5001   # entity id outside 1..Ve
+    slot = eng.feed(bad, labels)
+    with pytest.raises(_ffi.KprnError) as e:
+        eng.forward(slot, 1)
+    assert e.value.code == _ffi.E_INDEX
+    with pytest.raises(_ffi.KprnError):   # and it stays an error until the slot is refilled
+        eng.train_step(slot, _ffi.make_opt())
+    eng.feed(idx, labels, slot=slot)
+    ref = eng.batch(idx, labels)
+    assert np.array_equal(eng.forward(slot, 1)["probs"], eng.forward(ref, 1)["probs"])
+    # argument errors are reported by the feed call itself
+    with pytest.raises(_ffi.KprnError) as e:
+        eng.feed(idx[..., :2], labels)
+    assert e.value.code == _ffi.E_ARG
+    eng.close()
+
+
+@pytest.mark.parametrize("build", ["host", "device"])
+def test_prefix_plan_toggle_between_refills(build):
+    """a slot allocated with a plan and refilled with plans switched off (and back) must not read stale plan buffers"""
+    eng = _ffi.Engine(*SHAPE)
+    eng.set_option("feed_build", build)
+    idx, labels = synth.make_paths(400, 4, 6, Ve=5000, seed=9)
+    slot = eng.feed(idx, labels)
+    p1 = eng.forward(slot, 1)["probs"]
+    n1 = slot.executed_steps
+    eng.set_option("prefix_plan", "0")
+    eng.feed(idx, labels, slot=slot)
+    p0 = eng.forward(slot, 1)["probs"]
+    assert slot.executed_steps == 400 * 4 * 6 and n1 < slot.executed_steps
+    np.testing.assert_allclose(p1, p0, rtol=1e-5)
+    eng.set_option("prefix_plan", "1")
+    eng.feed(idx, labels, slot=slot)
+    assert slot.executed_steps == n1
+    assert np.array_equal(eng.forward(slot, 1)["probs"], p1)
+    eng.close()

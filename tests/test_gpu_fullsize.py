@@ -114,7 +114,7 @@ def test_benchmarked_size_fused_matches_the_generic_pipeline(full):
     (oa, la, ga), (og, lg, gg) = res["auto"], res["generic"]
     assert rel_inf(oa["path_scores"], og["path_scores"].astype(np.float64)) < 2e-5
     np.testing.assert_allclose(oa["probs"], og["probs"], rtol=SCORE_RTOL)
-    assert abs(la - lg) < 1e-5 * max(1.0, abs(lg))
+    assert abs(la - lg) < 2e-5 * max(1.0, abs(lg))   # (each is within 1e-5 of the oracle's)
     for nm, (off, shp) in full.lay.items():
         n = int(np.prod(shp))
         assert rel_inf(ga[off:off + n], gg[off:off + n].astype(np.float64)) < GRAD_RTOL, nm
