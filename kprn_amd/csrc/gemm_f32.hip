@@ -11,6 +11,8 @@
 //
 // Replaces the TH/THC BLAS calls under nn.Linear / FastLSTM's i2g,o2g
 // (release/songPathRnn/model/OneModel.lua:236,275).
+#include <stdlib.h>
+
 #include "kprn_internal.h"
 
 namespace {
@@ -294,6 +296,8 @@ void run(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B
          int64_t ldc, int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k, bool bf16) {
   if (M <= 0 || N <= 0) return;
   if (split_k < 1) split_k = 1;
+  static const bool no_tiled = getenv("KPRN_NO_TILED_GEMM") != nullptr;  // (measurement: the round-1 kernels)
+  if (!bf16 && !no_tiled && run_tiled(s, A, sAm, sAk, B, sBk, sBn, C, ldc, M, N, K, accumulate, bias, split_k)) return;
   int64_t kchunk = (K + split_k - 1) / split_k;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
   if (kchunk <= 0) kchunk = BK;

@@ -266,9 +266,10 @@ static void catch_up(kprn_handle* h, const kprn_batch* b) {
 
 // ---------------------------------------------------------------------------------------
 // generic (unfused) forward: gather -> per layer {input GEMM, per step recurrent GEMM + gates} -> head
-static void forward_generic(kprn_handle* h, const kprn_batch* b) {
+static void forward_generic(kprn_handle* h, const kprn_batch* b, bool save) {
   const kprn_config& c = h->cfg;
   const bool bf = c.compute_dtype == 1;  // bf16 MFMA products, fp32 accumulation (gemm_f32.hip)
+  static const bool no_step = getenv("KPRN_NO_STEP_KERNEL") != nullptr;  // (measurement: GEMM + element-wise kernels per step)
   Workspace& w = h->ws;
   const int H = c.H, L = c.L, T = b->T;
   const int64_t N = (int64_t)b->B * b->P;
@@ -318,13 +319,24 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b) {
       float* pre = w.ACT + (int64_t)l * T * N * H;
       float* hs = w.Hs + (int64_t)l * T * N * H;
       float* mask = w.mask + (int64_t)l * T * N;
-      {
+      const bool stepk = !bf && !no_step && gemm::step_supported(in, Din, Din, hs, H, H, h->dense + h->layer[l].Wi, h->dense + h->layer[l].Wo, N);
+      if (!stepk) {
         ProfScope ps(h, "gemm_i2g_fwd");
         gemm::run(s, in, Din, 1, h->dense + h->layer[l].Wi, 1, Din, pre, H, (int64_t)T * N, H, Din, false, h->dense + h->layer[l].bi, 1, bf);
       }
       {
         ProfScope ps(h, "rnn_mask");
         kk::row_nonzero(s, in, (int64_t)T * N, Din, mask);  // layer l > 1: the mask follows the ACTUAL input rows (h^{l-1}_t), as MaskZero does
+      }
+      if (stepk) {
+        // i2h, h2h, both biases, the activation and MaskZero in one launch per step (gemm_tiled.hip)
+        ProfScope ps(h, "rnn_step_fwd");
+        ps.launches = T;
+        for (int t = 0; t < T; ++t)
+          gemm::rnn_step(s, in + (int64_t)t * N * Din, Din, Din, h->dense + h->layer[l].Wi, h->dense + h->layer[l].bi,
+                         t > 0 ? hs + (int64_t)(t - 1) * N * H : nullptr, h->dense + h->layer[l].Wo, h->dense + h->layer[l].bo, mask + (int64_t)t * N,
+                         pre + (int64_t)t * N * H, hs + (int64_t)t * N * H, H, N, H, c.use_relu == 1 ? 1 : 0);
+        continue;
       }
       for (int t = 0; t < T; ++t) {
         float* pre_t = pre + (int64_t)t * N * H;
@@ -347,6 +359,17 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b) {
     const float* Wi = h->dense + h->layer[l].Wi;
     const float* bi = h->dense + h->layer[l].bi;
     const float* Wo = h->dense + h->layer[l].Wo;
+    if (!bf && !no_step && gemm::step_supported(in, Din, Din, hs, H, H, Wi, Wo, N)) {
+      // one launch per step: [x_t | h_{t-1}] [W_i2g | W_o2g]^T + b with the FastLSTM cell in the epilogue (gemm_tiled.hip);
+      // gate values are written only when a backward follows
+      ProfScope ps(h, "lstm_step_fwd");
+      ps.launches = T;
+      for (int t = 0; t < T; ++t)
+        gemm::lstm_step(s, in + (int64_t)t * N * Din, Din, Din, Wi, bi, t > 0 ? hs + (int64_t)(t - 1) * N * H : nullptr, Wo,
+                        t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr, cs + (int64_t)t * N * H, hs + (int64_t)t * N * H, H,
+                        save ? act + (int64_t)t * N * 4 * H : nullptr, N, H);
+      continue;
+    }
     {
       ProfScope ps(h, "gemm_i2g_fwd");
       gemm::run(s, in, Din, 1, Wi, 1, Din, act, 4 * H, (int64_t)T * N, 4 * H, Din, false, bi, 1, bf);
@@ -400,7 +423,7 @@ static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool
     fused::forward(h, b, save_for_backward);
   } else {
     ensure_ws_generic(h, N, b->T);
-    forward_generic(h, b);
+    forward_generic(h, b, save_for_backward);
   }
   if (do_pool) pool_stage(h, b, class_id - 1, every_class);
   h->last_B = b->B;

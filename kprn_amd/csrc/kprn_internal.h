@@ -323,4 +323,13 @@ namespace gemm {
 // accumulate: C += (atomic when split_k > 1); else C = A*B (+ bias[n]).
 void run(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C, int64_t ldc,
          int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k, bool bf16 = false);
+// gemm_tiled.hip: 128 x 128 x 32 LDS-tiled kernel (16-byte loads, XCD-aware tile order); false: shape / layout not covered
+bool run_tiled(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C, int64_t ldc, int64_t M, int N,
+               int64_t K, bool accumulate, const float* bias, int split_k);
+// one recurrent step of one layer with the cell in the GEMM's epilogue: gates = [x_t | h_{t-1}] [W_i | W_o]^T + b
+bool step_supported(const float* X, int64_t ldx, int Din, const float* Hprev, int64_t ldh, int H, const float* Wi, const float* Wo, int64_t N);
+void lstm_step(hipStream_t s, const float* X, int64_t ldx, int Din, const float* Wi, const float* bi, const float* Hprev, const float* Wo,
+               const float* Cprev, float* Cout, float* Hout, int64_t ldh, float* act, int64_t N, int H);
+void rnn_step(hipStream_t s, const float* X, int64_t ldx, int Din, const float* Wi, const float* bi, const float* Hprev, const float* Wh,
+              const float* bh, const float* mask, float* pre, float* Hout, int64_t ldh, int64_t N, int H, int relu);
 }

@@ -55,8 +55,15 @@ struct BwdArgs {
 constexpr int PART = 2 * 256 * 64 + 256;  // floats per workgroup partial slab
 constexpr int LDD = 4 * DH + 4;  // dA tile row stride
 
+// Cycle probes are compiled in only with -DKPRN_TIMING_PROBES (KPRN_TIMING=1 then prints them): eight 64-bit counters per wave cost
+// 16 scalar registers for the whole launch, and with them the bottom-layer kernel spilled.
+#ifdef KPRN_TIMING_PROBES
+#define KPRN_PROBES_ON 1
+#else
+#define KPRN_PROBES_ON 0
+#endif
 #define TPROBE(slot)                                                                 \
-  if (a.timing) {                                                                     \
+  if (KPRN_PROBES_ON && a.timing) {                                                   \
     const unsigned long long now__ = __builtin_amdgcn_s_memtime();                    \
     tacc[slot] += now__ - tlast;                                                      \
     tlast = now__;                                                                    \
@@ -74,7 +81,7 @@ template <bool BOTTOM, bool TOP, bool SMALL>
 __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = a.timing ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long tlast = (KPRN_PROBES_ON && a.timing) ? __builtin_amdgcn_s_memtime() : 0ull;
   float* dA_t = lds;                                        // [64][LDD]
   float* in_t = dA_t + MT * LDD;                            // bottom: [64][LDA] x_t
   int32_t* ids = (int32_t*)(in_t + (BOTTOM ? MT * LDA : 0));  // bottom: [64][T][4] the tile's ids, 0-based (x_t re-gather)
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     if (j == 0 && lane == 0) unsafeAtomicAdd(a.gbout_c, bsum);
   }
   TPROBE(6)  // flush
-  if (a.timing && tid == 0) {
+  if (KPRN_PROBES_ON && a.timing && tid == 0) {
     for (int k = 0; k < 8; ++k) a.timing[(int64_t)blockIdx.x * 8 + k] = tacc[k];
   }
 }

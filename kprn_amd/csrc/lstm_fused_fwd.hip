@@ -25,6 +25,12 @@
 //    weight row, so no packed weight copy is needed.
 #include "lstm_fused_common.h"
 
+#ifdef KPRN_TIMING_PROBES
+#define KPRN_PROBES_ON 1
+#else
+#define KPRN_PROBES_ON 0
+#endif
+
 namespace fused {
 
 // ---- MFMA issue, hand-placed ---------------------------------------------------------------------------
@@ -182,10 +188,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // hidden tile owned by this wave
   const int arow = lane & 15, ag = lane >> 4;
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = a.timing ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long tlast = (KPRN_PROBES_ON && a.timing) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long tstart = tlast;
 #define FPROBE(slot_)                                              \
-  if (a.timing) {                                                  \
+  if (KPRN_PROBES_ON && a.timing) {                                \
     const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
     tacc[slot_] += now__ - tlast;                                  \
     tlast = now__;                                                 \
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
     head_tile(a, hbuf(L - 1, par), p_tile, j, lane);
   }
   FPROBE(5)  // drain
-  if (a.timing && threadIdx.x == 0) {
+  if (KPRN_PROBES_ON && a.timing && threadIdx.x == 0) {
     tacc[7] = __builtin_amdgcn_s_memtime() - tstart;
     for (int k = 0; k < 8; ++k) a.timing[(int64_t)blockIdx.x * 8 + k] = tacc[k];
   }
