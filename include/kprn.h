@@ -244,6 +244,9 @@ int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t*
  *   "profile_filter"  kernel-family name prefix: only those families get HIP events while profiling is on ("" = all); an event
  *                     pair costs ~4 us of stream time                                                                            */
 int kprn_set_option(kprn_handle* h, const char* key, const char* value);
+/* measurement hook: mean milliseconds per launch of one GEMM shape of the generic pipeline on random data (scripts/gpu_gemm_bench.py).
+ * what: 0 C = A B^T, 1 C = A B, 2 C += A^T B (split-K), 3 FastLSTM step kernel (M paths, N = H, K = Din), 4 Recurrence step kernel */
+int kprn_debug_gemm(kprn_handle* h, int32_t what, int64_t M, int32_t N, int64_t K, int32_t iters, float* ms);
 
 #ifdef __cplusplus
 }

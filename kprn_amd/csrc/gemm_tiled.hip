@@ -46,6 +46,7 @@ struct TArgs {
   const float* bias;
   int64_t kchunk; int use_atomic;
   int64_t mtiles; int ntiles; int n_begin;   // column tiles of this launch start at n_begin
+  int split_major; int nsplit;               // split-K launches: XCD <-> K range (see the kernel)
   // cell epilogues
   int H;                                   // hidden units (EPI_LSTM: N = 4 H in gate-major columns; EPI_RNN: N = H)
   const float* cprev; float* cout; float* hout; int64_t ldh;   // [M][ldh]
@@ -55,38 +56,72 @@ struct TArgs {
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-// one operand tile [ROWS][32] (layout 0) or [32][ROWS] (layout 1), ROWS = 128 or 64: this thread's ROWS / 32 float4 pieces
-template <int LAY, int ROWS>
-__device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t rmax, int64_t k0, int64_t kend,
-                                          f32x4 (&v)[ROWS / 32], const int* rowmap /*EPI_LSTM B rows: tile row -> matrix row, -1 = none*/) {
-  const int tid = threadIdx.x;
+// one operand tile [ROWS][32] (layout 0) or [32][ROWS] (layout 1), ROWS = 128 or 64: this thread's ROWS / 8 floats, fetched
+// as VW-float vectors (VW = 4: 16-byte rows everywhere; VW = 2: even leading dimensions, e.g. config.sh's H = 250)
+template <int VW> struct VecOf;
+template <> struct VecOf<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
+// Loads of one operand tile, branch-free and address-cheap: every piece has a running pointer (set up once per K segment) and
+// is fetched from a clamped, always valid address; what lies outside the problem is zeroed when the piece is written to LDS --
+// AFTER the chunk's MFMAs, so the loads stay in flight under them (a select right behind the load made the compiler wait for
+// all eight loads before the first MFMA; conditional loads made each a basic block of its own).
+template <int LAY, int ROWS, int VW>
+struct TileLoader {
+  typedef typename VecOf<VW>::type vec_t;
+  static constexpr int NP = ROWS / (8 * VW);
+  const float* p[NP];
+  const float* safe;
+  bool rok[NP];
+  int kofs[NP];
+  int64_t step;
+  __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t rmax, int64_t k0, const int* rowmap) {
+    const int tid = threadIdx.x;
+    safe = P;
+    step = (LAY == 0) ? (int64_t)TK : (int64_t)TK * ld;
 #pragma unroll
-  for (int e = 0; e < ROWS / 32; ++e) {
-    const int f = tid + 256 * e;
-    f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (LAY == 0) {
-      const int row = f >> 3, kq = (f & 7) * 4;
-      int64_t gr = r0 + row;
-      bool ok = gr < rmax;
-      if (rowmap) { const int mr = rowmap[row]; ok = mr >= 0; gr = mr; }
-      const int64_t gk = k0 + kq;
-      if (ok && gk < kend) x = *(const f32x4*)(P + gr * ld + gk);
-    } else {
-      const int kr = f / (ROWS / 4), mq = (f % (ROWS / 4)) * 4;
-      const int64_t gk = k0 + kr, gr = r0 + mq;
-      if (gk < kend && gr < rmax) x = *(const f32x4*)(P + gk * ld + gr);
+    for (int e = 0; e < NP; ++e) {
+      const int f = tid + 256 * e;
+      if (LAY == 0) {
+        const int row = f / (32 / VW), kq = (f % (32 / VW)) * VW;
+        int64_t gr = r0 + row;
+        bool ok = gr < rmax;
+        if (rowmap) { const int mr = rowmap[row]; ok = mr >= 0; gr = mr; }
+        rok[e] = ok; kofs[e] = kq;
+        p[e] = P + (ok ? gr : 0) * ld + k0 + kq;
+      } else {
+        const int kr = f / (ROWS / VW), mq = (f % (ROWS / VW)) * VW;
+        const int64_t gr = r0 + mq;
+        rok[e] = gr < rmax; kofs[e] = kr;
+        p[e] = P + (k0 + kr) * ld + (rok[e] ? gr : 0);
+      }
     }
-    v[e] = x;
   }
-}
-template <int LAY, int ROWS>
-__device__ __forceinline__ void tile_store(float* __restrict__ T, const f32x4 (&v)[ROWS / 32]) {
+  // pieces of the chunk at k0; bit e of the result: piece e lies inside the problem
+  __device__ __forceinline__ unsigned load(int64_t k0, int64_t kend, vec_t (&v)[NP]) {
+    unsigned mask = 0;
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const bool ok = rok[e] && (k0 + kofs[e] < kend);
+      v[e] = *(const vec_t*)(ok ? p[e] : safe);
+      mask |= ok ? (1u << e) : 0u;
+      p[e] += step;
+    }
+    return mask;
+  }
+};
+template <int LAY, int ROWS, int VW>
+__device__ __forceinline__ void tile_store(float* __restrict__ T, const typename VecOf<VW>::type (&v)[ROWS / (8 * VW)], unsigned mask) {
+  typedef typename VecOf<VW>::type vec_t;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int e = 0; e < ROWS / 32; ++e) {
+  for (int e = 0; e < ROWS / (8 * VW); ++e) {
     const int f = tid + 256 * e;
-    if (LAY == 0) *(f32x4*)(T + (f >> 3) * LDK + (f & 7) * 4) = v[e];
-    else *(f32x4*)(T + (f / (ROWS / 4)) * (ROWS + 4) + (f % (ROWS / 4)) * 4) = v[e];
+    vec_t x = v[e];
+    const bool ok = (mask >> e) & 1u;
+#pragma unroll
+    for (int q = 0; q < VW; ++q) x[q] = ok ? x[q] : 0.f;
+    if (LAY == 0) *(vec_t*)(T + (f / (32 / VW)) * LDK + (f % (32 / VW)) * VW) = x;
+    else *(vec_t*)(T + (f / (ROWS / VW)) * (ROWS + 4) + (f % (ROWS / VW)) * VW) = x;
   }
 }
 // fragments of the NT MFMA tiles of this wave for one 16-k group: frag[t][jj] <-> row base + step t + arow, k = 16 kg + 4 ag + jj
@@ -104,9 +139,10 @@ __device__ __forceinline__ void frag_read(const float* __restrict__ T, int row_b
 }
 
 // NTW: MFMA column tiles per wave: 4 (workgroup tile 128 x 128) or 2 (128 x 64: the last column block of N = 192, 64, ...)
-template <int LA, int LB, int EPI, int NTW>
+template <int LA, int LB, int EPI, int NTW, int VW>
 __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
   constexpr int TNn = 32 * NTW;
+  typedef typename VecOf<VW>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   auto As = [&](int i) -> float* { return lds + i * (2 * TILE_F); };              // buffer i: A tile | B tile
   auto Bs = [&](int i) -> float* { return lds + i * (2 * TILE_F) + TILE_F; };
@@ -118,9 +154,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
   const int64_t id = blockIdx.x;
   const int xcd = (int)(id & 7);
   const int64_t j = id >> 3;
-  const int nt_idx = (int)(j % a.ntiles);
-  const int64_t mt_idx = (j / a.ntiles) * 8 + xcd;
-  if (mt_idx >= a.mtiles) return;
+  int nt_idx;
+  int64_t mt_idx, split_idx = blockIdx.y;
+  if (a.split_major) {
+    // split-K problems (dW = dA^T [x | h]: few output tiles, a very long K): every tile of ONE K range runs on ONE XCD, so the
+    // rows of both operands in that range come from HBM once and from that XCD's L2 for all the tiles
+    const int64_t tiles = a.mtiles * a.ntiles;
+    split_idx = (j / tiles) * 8 + xcd;
+    const int64_t tl = j % tiles;
+    mt_idx = tl / a.ntiles;
+    nt_idx = (int)(tl % a.ntiles);
+    if (split_idx >= a.nsplit) return;
+  } else {
+    nt_idx = (int)(j % a.ntiles);
+    mt_idx = (j / a.ntiles) * 8 + xcd;
+    if (mt_idx >= a.mtiles) return;
+  }
   const int64_t m0 = mt_idx * TM;
   const int n0 = a.n_begin + nt_idx * TNn;   // EPI_LSTM: first hidden unit of the tile is nt_idx * 32
   constexpr bool CELL = (EPI == EPI_LSTM);
@@ -133,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
     __syncthreads();
   }
   const int* rmap = CELL ? rowmap : nullptr;
-  const int64_t k_beg = (int64_t)blockIdx.y * a.kchunk;
+  const int64_t k_beg = split_idx * a.kchunk;
   const int64_t k_end1 = (k_beg + a.kchunk < a.K) ? k_beg + a.kchunk : a.K;   // (split-K applies to the first segment only)
   const int64_t nch1 = (k_end1 > k_beg) ? (k_end1 - k_beg + TK - 1) / TK : 0;
   const int64_t nch2 = (a.A2 != nullptr) ? (a.K2 + TK - 1) / TK : 0;
@@ -145,22 +194,28 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
 #pragma unroll
     for (int jn = 0; jn < NTW; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x4 ra[4], rb[NTW];
+  vec_t ra[TM / (8 * VW)], rb[TNn / (8 * VW)];
+  unsigned ma = 0, mb = 0;
+  TileLoader<LA, TM, VW> la;
+  TileLoader<LB, TNn, VW> lb;
+  const int64_t brow0 = CELL ? 0 : n0, bmax = CELL ? (int64_t)4 * a.H : (int64_t)a.N;
+  auto seg_init = [&](int seg) {   // K segment 0: (A, B) from k_beg; segment 1: (A2, B2) from 0
+    if (seg == 0) { la.init(a.A, a.lda, m0, a.M, k_beg, nullptr); lb.init(a.B, a.ldb, brow0, bmax, k_beg, rmap); }
+    else { la.init(a.A2, a.lda2, m0, a.M, 0, nullptr); lb.init(a.B2, a.ldb2, brow0, bmax, 0, rmap); }
+  };
   auto load_chunk = [&](int64_t c) {
-    if (c < nch1) {
-      const int64_t k0 = k_beg + c * TK;
-      tile_load<LA, TM>(a.A, a.lda, m0, a.M, k0, k_end1, ra, nullptr);
-      tile_load<LB, TNn>(a.B, a.ldb, CELL ? 0 : n0, CELL ? (int64_t)4 * a.H : (int64_t)a.N, k0, k_end1, rb, rmap);
-    } else {
-      const int64_t k0 = (c - nch1) * TK;
-      tile_load<LA, TM>(a.A2, a.lda2, m0, a.M, k0, a.K2, ra, nullptr);
-      tile_load<LB, TNn>(a.B2, a.ldb2, CELL ? 0 : n0, CELL ? (int64_t)4 * a.H : (int64_t)a.N, k0, a.K2, rb, rmap);
-    }
+    if (c == nch1) seg_init(1);   // (uniform)
+    const bool s0 = c < nch1;
+    const int64_t k0 = s0 ? k_beg + c * TK : (c - nch1) * TK;
+    const int64_t ke = s0 ? k_end1 : a.K2;
+    ma = la.load(k0, ke, ra);
+    mb = lb.load(k0, ke, rb);
   };
   if (nch > 0) {
+    if (nch1 > 0) seg_init(0);
     load_chunk(0);
-    tile_store<LA, TM>(As(0), ra);
-    tile_store<LB, TNn>(Bs(0), rb);
+    tile_store<LA, TM, VW>(As(0), ra, ma);
+    tile_store<LB, TNn, VW>(Bs(0), rb, mb);
   }
   __syncthreads();
   // B fragment rows: plain tiles: (16 NTW) wn + 16 nt + arow; cell tiles: gate nt, units 16 wn + arow  ->  32 nt + 16 wn + arow
@@ -183,8 +238,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
           for (int jn = 0; jn < NTW; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][jj], fb[jn][jj], acc[i][jn], 0, 0, 0);
     }
     if (more) {
-      tile_store<LA, TM>(As(cur ^ 1), ra);   // (last read one chunk ago, before the previous barrier)
-      tile_store<LB, TNn>(Bs(cur ^ 1), rb);
+      tile_store<LA, TM, VW>(As(cur ^ 1), ra, ma);   // (last read one chunk ago, before the previous barrier)
+      tile_store<LB, TNn, VW>(Bs(cur ^ 1), rb, mb);
     }
     __syncthreads();
   }
@@ -259,25 +314,44 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-template <int LA, int LB, int EPI, int NTW = 4>
+template <int LA, int LB, int EPI, int NTW, int VW>
 void launch(hipStream_t s, const TArgs& a, int split_k) {
   const size_t lds_bytes = (size_t)4 * TILE_F * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_tiled<LA, LB, EPI, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_tiled<LA, LB, EPI, NTW, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done = true;
   }
   const int64_t mgroups = (a.mtiles + 7) / 8;
-  const dim3 grid((unsigned)(mgroups * a.ntiles * 8), (unsigned)split_k);
-  hipLaunchKernelGGL((k_gemm_tiled<LA, LB, EPI, NTW>), grid, dim3(256), lds_bytes, s, a);
+  dim3 grid((unsigned)(mgroups * a.ntiles * 8), (unsigned)split_k);
+  TArgs b = a;
+  b.split_major = 0; b.nsplit = split_k;
+  if (split_k > 1 && a.mtiles * a.ntiles >= 16) {   // (measured: helps 36-tile problems, 4.96 vs 6.42 ms; hurts 6-tile ones)
+    b.split_major = 1;
+    grid = dim3((unsigned)(((split_k + 7) / 8) * 8 * a.mtiles * a.ntiles), 1);
+  }
+  hipLaunchKernelGGL((k_gemm_tiled<LA, LB, EPI, NTW, VW>), grid, dim3(256), lds_bytes, s, b);
   HIP_TRY(hipGetLastError());
 }
 // the column range [n_begin, n_begin + ntiles * 32 NTW) of one problem
 template <int EPI, int NTW>
-void launch_layouts(hipStream_t s, const TArgs& a, int LA, int LB, int split_k) {
-  if (LA == 0 && LB == 0) launch<0, 0, EPI, NTW>(s, a, split_k);
-  else if (LA == 0 && LB == 1) launch<0, 1, EPI, NTW>(s, a, split_k);
-  else launch<1, 1, EPI, NTW>(s, a, split_k);
+void launch_layouts(hipStream_t s, const TArgs& a, int LA, int LB, int split_k, int VW) {
+  if (VW == 4) {
+    if (LA == 0 && LB == 0) launch<0, 0, EPI, NTW, 4>(s, a, split_k);
+    else if (LA == 0 && LB == 1) launch<0, 1, EPI, NTW, 4>(s, a, split_k);
+    else launch<1, 1, EPI, NTW, 4>(s, a, split_k);
+  } else {
+    if (LA == 0 && LB == 0) launch<0, 0, EPI, NTW, 2>(s, a, split_k);
+    else if (LA == 0 && LB == 1) launch<0, 1, EPI, NTW, 2>(s, a, split_k);
+    else launch<1, 1, EPI, NTW, 2>(s, a, split_k);
+  }
+}
+// widest vector all of (pointer, leading dimension, extent along the contiguous dimension) allow: 4, 2, or 0
+inline int vec_width(const void* p, int64_t ld, int64_t extent) {
+  const uintptr_t u = (uintptr_t)p;
+  if (!(u & 15) && !(ld & 3) && !(extent & 3)) return 4;
+  if (!(u & 7) && !(ld & 1) && !(extent & 1)) return 2;
+  return 0;
 }
 
 }  // namespace
@@ -290,22 +364,29 @@ bool run_tiled(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const fl
   if (M < 256 || N < 64 || K < 16) return false;
   int LA, LB;
   int64_t lda, ldb;
-  if (sAk == 1) { LA = 0; lda = sAm; if ((K & 3) || (lda & 3)) return false; }
-  else if (sAm == 1) { LA = 1; lda = sAk; if ((M & 3) || (lda & 3)) return false; }
+  int VW = 4;
+  // A: contiguous along k (its extent along the vectors is K) or along m (M); B: along k (K) or along n -- there a vector may run
+  // past column N inside the row (ld >= N rounded up), which only feeds columns that are never stored
+  if (sAk == 1) { LA = 0; lda = sAm; VW = std::min(VW, vec_width(A, lda, K)); }
+  else if (sAm == 1) { LA = 1; lda = sAk; VW = std::min(VW, vec_width(A, lda, M)); }
   else return false;
-  if (sBk == 1) { LB = 0; ldb = sBn; if ((K & 3) || (ldb & 3)) return false; }
-  else if (sBn == 1) { LB = 1; ldb = sBk; if ((ldb & 3) || ldb < (((int64_t)N + 3) & ~(int64_t)3)) return false; }
+  if (sBk == 1) { LB = 0; ldb = sBn; VW = std::min(VW, vec_width(B, ldb, K)); }
+  else if (sBn == 1) { LB = 1; ldb = sBk; VW = std::min(VW, vec_width(B, ldb, 0)); if (VW && ldb < (((int64_t)N + VW - 1) / VW) * VW) return false; }
   else return false;
-  if (!al16(A) || !al16(B)) return false;
+  if (VW == 0) return false;
   if (LA == 1 && LB == 0) return false;  // (no caller)
   TArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.bias = bias;
   a.mtiles = (M + TM - 1) / TM;
   // column blocks: 128-wide tiles, and a 64-wide tile for a remainder of at most 64 columns (N = 192: 128 + 64, no idle half tile)
-  const int n_full = N / TN, rem = N - n_full * TN;
-  const int nt128 = n_full + (rem > 64 ? 1 : 0);
-  const int nt64 = (rem > 0 && rem <= 64) ? 1 : 0;
+  int n_full = N / TN, rem = N - n_full * TN;
+  int nt128 = n_full + (rem > 64 ? 1 : 0);
+  int nt64 = (rem > 0 && rem <= 64) ? 1 : 0;
+  // split-K launches share their operands through one XCD's L2 only inside ONE launch: there a 128 + 64 split of the columns
+  // would read A twice from HBM; three 64-wide tiles in one launch do not (N = 192: dW of reading B)
+  const bool all64 = false;  // (measured: three 64-wide tiles are slower than 128 + 64 for N = 192: 1.51 vs 1.35 ms)
+  if (all64) { nt64 = (N + 63) / 64; nt128 = 0; n_full = 0; }
   if (split_k < 1) split_k = 1;
   if (split_k > 1) {
     // split-K only as far as the chip needs it: ~3 workgroups per CU in flight (every extra split is a tile of atomics)
@@ -320,18 +401,24 @@ bool run_tiled(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const fl
   KPRN_REQUIRE(!(split_k > 1 && !accumulate), KPRN_E_ARG, "gemm: split-K needs accumulate mode");
   if (nt128 > 0) {
     a.ntiles = nt128; a.n_begin = 0;
-    if (accumulate) launch_layouts<EPI_ACCUM, 4>(s, a, LA, LB, split_k); else launch_layouts<EPI_STORE, 4>(s, a, LA, LB, split_k);
+    if (accumulate) launch_layouts<EPI_ACCUM, 4>(s, a, LA, LB, split_k, VW); else launch_layouts<EPI_STORE, 4>(s, a, LA, LB, split_k, VW);
   }
   if (nt64 > 0) {
-    a.ntiles = 1; a.n_begin = n_full * TN;
-    if (accumulate) launch_layouts<EPI_ACCUM, 2>(s, a, LA, LB, split_k); else launch_layouts<EPI_STORE, 2>(s, a, LA, LB, split_k);
+    a.ntiles = nt64; a.n_begin = n_full * TN;
+    if (accumulate) launch_layouts<EPI_ACCUM, 2>(s, a, LA, LB, split_k, VW); else launch_layouts<EPI_STORE, 2>(s, a, LA, LB, split_k, VW);
   }
   return true;
 }
 
-// shapes the fused step kernels take: 16-byte rows everywhere
+// vector width the fused step kernels can use for this layer's operands (0: shape not covered -> unfused kernels)
+static int step_vw(const float* X, int64_t ldx, int Din, const float* Hprev, int64_t ldh, int H, const float* Wi, const float* Wo) {
+  int vw = std::min(vec_width(X, ldx, Din), vec_width(Wi, Din, Din));
+  vw = std::min(vw, vec_width(Wo, H, H));
+  if (Hprev) vw = std::min(vw, vec_width(Hprev, ldh, H));
+  return vw;
+}
 bool step_supported(const float* X, int64_t ldx, int Din, const float* Hprev, int64_t ldh, int H, const float* Wi, const float* Wo, int64_t N) {
-  return N >= 256 && (Din & 3) == 0 && (H & 3) == 0 && (ldx & 3) == 0 && (ldh & 3) == 0 && al16(X) && al16(Wi) && al16(Wo) && (!Hprev || al16(Hprev));
+  return N >= 256 && step_vw(X, ldx, Din, Hprev, ldh, H, Wi, Wo) > 0;
 }
 
 // one nn.FastLSTM step of one layer: gates = [x_t | h_{t-1}] [W_i2g | W_o2g]^T + b, cell in the epilogue.
@@ -346,7 +433,7 @@ void lstm_step(hipStream_t s, const float* X, int64_t ldx, int Din, const float*
   a.cprev = Cprev; a.cout = Cout; a.hout = Hout; a.ldh = ldh; a.act = act;
   a.mtiles = (N + TM - 1) / TM; a.ntiles = (H + 31) / 32;
   a.kchunk = ((Din + TK - 1) / TK) * TK;
-  launch<0, 0, EPI_LSTM>(s, a, 1);
+  if (step_vw(X, ldx, Din, Hprev, ldh, H, Wi, Wo) == 4) launch<0, 0, EPI_LSTM, 4, 4>(s, a, 1); else launch<0, 0, EPI_LSTM, 4, 2>(s, a, 1);
 }
 
 // one nn.Recurrence step: pre = i2h x_t + b_i2h + h2h h_{t-1} + b_h2h, h = MaskZero(act(pre)); pre is kept for the backward
@@ -360,7 +447,7 @@ void rnn_step(hipStream_t s, const float* X, int64_t ldx, int Din, const float* 
   a.hout = Hout; a.act = pre; a.ldh = ldh;
   a.mtiles = (N + TM - 1) / TM; a.ntiles = (H + TN - 1) / TN;
   a.kchunk = ((Din + TK - 1) / TK) * TK;
-  launch<0, 0, EPI_RNN>(s, a, 1);
+  if (step_vw(X, ldx, Din, Hprev, ldh, H, Wi, Wh) == 4) launch<0, 0, EPI_RNN, 4, 4>(s, a, 1); else launch<0, 0, EPI_RNN, 4, 2>(s, a, 1);
 }
 
 }  // namespace gemm

@@ -1670,6 +1670,45 @@ int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t*
   API_END(h)
 }
 
+/* measurement hook (scripts/gpu_gemm_bench.py): times one GEMM shape of the generic pipeline on random data.
+ * what: 0 = C = A B^T (forward i2g), 1 = C = A B (dx / dh), 2 = C += A^T B with split-K (dW), 3 = FastLSTM step kernel (M paths, N = H, K = Din),
+ *       4 = Recurrence step kernel.  Returns the mean milliseconds per launch in *ms. */
+int kprn_debug_gemm(kprn_handle* h, int32_t what, int64_t M, int32_t N, int64_t K, int32_t iters, float* ms) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(ms && M > 0 && N > 0 && K > 0 && iters > 0, KPRN_E_ARG, "bad argument");
+  hipStream_t s = h->stream;
+  float *A = nullptr, *B = nullptr, *C = nullptr, *X = nullptr, *Z = nullptr;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  try {
+    const int64_t H = N, Din = K;
+    if (what <= 2) {
+      const int64_t na = M * K, nb = (int64_t)N * K, nc = (what == 2) ? (int64_t)N * K : M * (int64_t)N;
+      A = dalloc<float>(what == 2 ? M * (int64_t)N : na); B = dalloc<float>(what == 2 ? M * K : nb); C = dalloc<float>(nc);
+      kk::fill_uniform(s, A, what == 2 ? M * (int64_t)N : na, 0.1f, 1, 0); kk::fill_uniform(s, B, what == 2 ? M * K : nb, 0.1f, 2, 0);
+      HIP_TRY(hipMemsetAsync(C, 0, (size_t)nc * sizeof(float), s));
+    } else {
+      X = dalloc<float>(M * Din); A = dalloc<float>(2 * M * H); B = dalloc<float>(4 * H * (Din + H) + 8 * H); C = dalloc<float>(2 * M * H); Z = dalloc<float>(M * 4 * H);
+      kk::fill_uniform(s, X, M * Din, 0.1f, 1, 0); kk::fill_uniform(s, A, 2 * M * H, 0.1f, 2, 0); kk::fill_uniform(s, B, 4 * H * (Din + H) + 8 * H, 0.1f, 3, 0);
+    }
+    for (int it = -2; it < iters; ++it) {
+      if (it == 0) HIP_TRY(hipEventRecord(e0, s));
+      if (what == 0) gemm::run(s, A, K, 1, B, 1, K, C, N, M, N, K, false, nullptr, 1);
+      else if (what == 1) gemm::run(s, A, K, 1, B, N, 1, C, N, M, N, K, false, nullptr, 1);            // B [K][N] n-contiguous
+      else if (what == 2) gemm::run(s, A, 1, N, B, K, 1, C, K, N, (int)K, M, true, nullptr, 1024);     // C[N][K] += A[M][N]^T B[M][K]
+      else if (what == 3) gemm::lstm_step(s, X, Din, (int)Din, B, B + 4 * H * (Din + H), A, B + 4 * H * Din, A + M * H, C, C + M * H, H, Z, M, (int)H);
+      else gemm::rnn_step(s, X, Din, (int)Din, B, B + 4 * H * (Din + H), A, B + H * Din, B + 4 * H * (Din + H) + H, A + M * H, Z, C, H, M, (int)H, 1);
+    }
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    *ms = t / (float)iters;
+  } catch (...) { dfree(A); dfree(B); dfree(C); dfree(X); dfree(Z); hipEventDestroy(e0); hipEventDestroy(e1); throw; }
+  dfree(A); dfree(B); dfree(C); dfree(X); dfree(Z); hipEventDestroy(e0); hipEventDestroy(e1);
+  API_END(h)
+}
+
 int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
   API_BEGIN(h)
   KPRN_REQUIRE(key && value, KPRN_E_ARG, "NULL argument");

@@ -70,16 +70,25 @@ def test_hidden_size_not_a_multiple_of_the_unit_tile():
     _check(eng, o64, theta, idx, labels, steps=3)
 
 
+def test_lstm_with_config_sh_dimensions():
+    """FastLSTM at config.sh's sizes (D = 200, H = 250): the 8-byte-vector variant of the step kernel and of the tiled GEMMs"""
+    eng, o64, theta = _lstm(50, 100, 50, 250, 1, init=0.05)
+    idx, labels = synth.make_paths(150, 2, 6, Ve=700, seed=12)
+    _check(eng, o64, theta, idx, labels, steps=2)
+
+
 def test_configs3_shape_d384_h384_at_tiled_size():
     eng, o64, theta = _lstm(128, 128, 128, 384, 1, Vr=100, init=0.05)
     idx, labels = synth.make_paths(150, 2, 6, Ve=700, Vr=100, seed=6)
     _check(eng, o64, theta, idx, labels)
 
 
-@pytest.mark.parametrize("use_relu,L,dims", [(1, 1, (50, 100, 50, 252)), (0, 1, (50, 100, 50, 252)), (1, 2, (32, 32, 32, 96)), (0, 2, (32, 32, 32, 96))])
+@pytest.mark.parametrize("use_relu,L,dims", [(1, 1, (50, 100, 50, 250)), (0, 1, (50, 100, 50, 250)), (1, 1, (50, 100, 50, 252)), (1, 2, (32, 32, 32, 96)),
+                                             (0, 2, (32, 32, 32, 96)), (1, 1, (3, 5, 7, 33))])
 def test_rnn_step_kernel(use_relu, L, dims):
-    """nn.Recurrence + nn.MaskZero (OneModel.lua:240-266) through the fused step kernel; config.sh's D = 200 with H = 252 (the
-    shipped H = 250 is not a multiple of 4 and stays on the unfused kernels: test_gpu_parity.py covers it)"""
+    """nn.Recurrence + nn.MaskZero (OneModel.lua:240-266) through the fused step kernel: run_scripts/config.sh exactly (D = 200,
+    H = 250: even leading dimensions -> 8-byte vectors), 16-byte shapes, two layers; odd dimensions (15 / 33) stay on the
+    unfused kernels and must still be right"""
     dt, de, dr, H = dims
     eng = _ffi.Engine(6, 700, 9, dt, de, dr, H, L, rnn_type=1, use_relu=use_relu, param_init=0.05)
     o64 = Oracle(make_cfg(Vt=6, Ve=700, Vr=9, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=1, use_relu=use_relu), np.float64)
