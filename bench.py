@@ -55,11 +55,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--paths-per-step", type=int, default=65536, help="paths per rank per step")
-    ap.add_argument("--dims", default="A", choices=["A", "B", "shipped"],
-                    help="A: D=H=64 (16/32/16); B: 64/64/64 -> D=H=192; shipped: run_scripts/config.sh as shipped (rnn, 50/100/50 -> D=200, H=250, L=1)")
+    ap.add_argument("--dims", default="A", choices=["A", "B", "shipped", "C4"],
+                    help="A: D=H=64 (16/32/16); B: 64/64/64 -> D=H=192; shipped: run_scripts/config.sh as shipped (rnn, 50/100/50 -> D=200, H=250, L=1); "
+                         "C4: BASELINE configs[3] -- 20 M entities, 100 relations, d = 128 -> D = H = 384, L = 1, bf16 storage + bf16 MFMA "
+                         "(--c4-fp32: the same shape in fp32)")
+    ap.add_argument("--c4-fp32", action="store_true")
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--T", type=int, default=6)
-    ap.add_argument("--entities", type=int, default=2851220)
+    ap.add_argument("--entities", type=int, default=0, help="entity vocabulary (default: 2 851 220, KKBox; 20 000 000 for --dims C4)")
     ap.add_argument("--impl", default="auto", choices=["auto", "generic"])
     ap.add_argument("--entity-update", type=int, default=0, help="0 lazy-exact, 1 dense (as the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,6 +91,9 @@ def parse():
     ap.add_argument("--feed-ahead", type=int, default=4, help="streaming feed: batches in flight ahead of the step being queued")
     ap.add_argument("--feed-threads", type=int, default=0, help="helper threads per batch of the host-built feed (0: library default)")
     ap.add_argument("--no-extra-regions", action="store_true", help="skip the value_no_prefix_plan / long_run regions")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
+                    help="c2 (default): BASELINE configs[1], train + score at T = 6.  c5: configs[4] -- inference-only scoring of a path set with "
+                         "variable path length <= 7, bucketed by identical T (3..7) as the reference pads per file, d = 64")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rank wiring / timing / JSON check without a GPU: gloo backend, the step is a placeholder (CPU tests)")
     return ap.parse_args()
@@ -160,9 +166,14 @@ def dry_run(a):
         dist.destroy_process_group()
 
 
+PEAK_TFLOPS_BF16_MFMA = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+
+
 def dims_of(a):
     if a.dims == "A":
         return 16, 32, 16, 64
+    if a.dims == "C4":
+        return 128, 128, 128, 384
     if a.dims == "shipped":
         return 50, 100, 50, 250
     return 64, 64, 64, 192
@@ -182,6 +193,12 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4, NT=None):
             din = D if l == 0 else H
             fl += NT * 2 * g * din + (NT - N) * 2 * g * H
         return "mfma", (fl + N * 2 * H * C) / L
+    if name in ("lstm_step_fwd", "lstm_step_bf16", "rnn_step_fwd"):   # one launch per (layer, step): [x_t | h_{t-1}] [W_i | W_o]^T, no recurrent half at t = 0
+        fl = 0
+        for l in range(L):
+            din = D if l == 0 else H
+            fl += N * 2 * g * (T * din + (T - 1) * H)
+        return "mfma", fl / (L * T)
     if name in ("lstm_fused_fwd", "lstm_fused_fwd_train"):
         fl = 0
         for l in range(L):
@@ -261,12 +278,108 @@ def cpu_baseline(a, T, dt, de, dr, H, L, seconds):
             "train_paths_per_s": n / (t1 - t0), "score_paths_per_s": n / (t2 - t1)}
 
 
+def run_c5(a):
+    """BASELINE configs[4]: inference-only scoring throughput, variable path length <= 7 with bucketed batching (the reference pads
+    every path of a file to that file's T -- movie_data_format.py:250-254 -- so a bucket = the paths of one T; pads are ordinary
+    steps for FastLSTM), d = 64 (16 / 32 / 16, H = 64, L = 2), KKBox-size vocabulary, LSE pool.  A step = one scoring
+    forward (test_from_checkpoint.lua:109) over one bucket batch of ~--paths-per-step paths; buckets T = 3..7 in turn."""
+    import torch
+    assert a.gpus == 1, "the c5 line is a single-GPU measurement"
+    torch.cuda.set_device(0)
+    from kprn_amd import _ffi, synth
+    dt_, de_, dr_, H, L, C, F = 16, 32, 16, 64, 2, 46, 3
+    Vt, Ve, Vr = 6, (a.entities if a.entities > 0 else 2851220), 9
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = _ffi.Engine(Vt, Ve, Vr, dt_, de_, dr_, H, L, F=F, C_=C, reducer=2, stream=stream, compute_dtype=a.compute_dtype)
+    eng.set_option("impl", a.impl)
+    Ts = [3, 4, 5, 6, 7]
+    host, batches = [], []
+    for i, T in enumerate(Ts):
+        P = [2, 1, 3, 4, 2][i]
+        idx, _ = synth.make_paths(max(1, a.paths_per_step // P), P, T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, seed=777 + i)
+        hi = eng.host_array(idx.shape, np.int32)
+        hi[...] = idx
+        host.append(hi)
+        batches.append(eng.batch(hi))
+    paths_of = [b.n_paths for b in batches]
+    exec_of = [b.executed_steps for b in batches]
+    D = dt_ + de_ + dr_
+    def flops(i):
+        return family_work("lstm_fused_fwd", paths_of[i], Ts[i], D, H, L, C, F, 1, dt_, de_, dr_, 4, exec_of[i])[1]
+    def region(step, first, k):
+        torch.cuda.synchronize(); eng.sync()
+        t0 = time.perf_counter()
+        n = sum(step(first + i) for i in range(k))
+        eng.sync(); torch.cuda.synchronize()
+        return time.perf_counter() - t0, n
+    def step_res(i):
+        eng.forward_async(batches[i % len(batches)], 1)
+        return paths_of[i % len(batches)]
+    NS = max(1, a.feed_ahead) + 1
+    slots = [_ffi.Batch.reserve(eng, max(b.B for b in batches), max(paths_of), 7, F, with_labels=False) for _ in range(NS)]
+    fed = [-1]
+    def step_str(i):
+        if fed[0] < i - 1 or fed[0] >= i + NS - 1:
+            fed[0] = i - 1
+        while fed[0] < i + NS - 1:
+            j = fed[0] + 1
+            slots[j % NS] = eng.feed(host[j % len(host)], None, slot=slots[j % NS])
+            fed[0] = j
+        eng.forward_async(slots[i % NS], 1)
+        return paths_of[i % len(host)]
+    for i in range(a.warmup):
+        step_res(i)
+    eng.sync()
+    eng.profile_reset(); eng.set_option("profile_filter", "lstm_fused_fwd" if a.impl == "auto" else ""); eng.profile(not a.no_kernel_events)
+    el, n = region(step_res, a.warmup, a.steps)
+    eng.profile(False)
+    fams = eng.profile_get()
+    for i in range(3):
+        step_str(i)
+    eng.sync()
+    el_s, n_s = region(step_str, 3, a.steps)
+    roofline = None
+    if "lstm_fused_fwd" in fams:
+        ms, launches = fams["lstm_fused_fwd"]
+        work = sum(flops((a.warmup + i) % len(batches)) for i in range(a.steps))
+        roofline = {"kernel": "lstm_fused_fwd", "bound": "mfma", "achieved": round(work / (ms * 1e-3) / 1e12, 3), "peak": PEAK_TFLOPS_F32_MFMA,
+                    "unit": "TFLOP/s", "frac": round(work / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_F32_MFMA, 4), "traffic": None,
+                    "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": launches}
+    cpu = None
+    if not a.no_cpu_baseline:
+        from oracle.oracle import Oracle, make_cfg
+        cores = len(os.sched_getaffinity(0))
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        orc = Oracle(make_cfg(Vt=6, Ve=100000, Vr=9, dt=dt_, de=de_, dr=dr_, H=H, L=L), np.float64)
+        theta = orc.init_params(1, 0.1)
+        tot, t0 = 0, time.perf_counter()
+        for T in Ts:
+            idx, _ = synth.make_paths(8000, 2, T, Ve=100000, seed=5 + T)
+            orc.forward(theta, idx)
+            tot += 16000
+        cpu = {"value": tot / (time.perf_counter() - t0), "unit": "paths/s", "cores": cores, "kind": "port",
+               "sample": f"{tot} synthetic paths, 16000 per bucket T = 3..7: float64 oracle scoring forward, OpenMP over pairs"}
+    print(json.dumps({
+        "metric": "paths/sec (score only) variable path_len<=7 bucketed, d=64", "value": round(n / el, 1), "unit": "paths/s", "n_gpus": 1,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": {0: "f32", 1: "bf16", 2: "f32x6", 3: "f32x3"}[a.compute_dtype], "data": "synthetic",
+        "config": {"workload": f"C5 (BASELINE configs[4]) MovieLens-KG-shaped synthetic: inference only, buckets T = 3..7, D = H = 64 (16/32/16), L = 2, "
+                               f"fp32, Ve = {Ve}, C = 46, LSE pool; one scoring forward per bucket batch", "paths_per_step": a.paths_per_step,
+                   "buckets_T": Ts, "impl": a.impl, "batch_feed": "resident"},
+        "executed_step_fraction": round(sum(exec_of) / float(sum(p * t for p, t in zip(paths_of, Ts))), 4),
+        "streaming": {"value": round(n_s / el_s, 1), "unit": "paths/s", "ms_per_step": round(1e3 * el_s / a.steps, 4),
+                      "ratio_to_resident": round((n_s / el_s) / (n / el), 4)},
+        "roofline": roofline, "cpu_baseline": cpu}))
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
     if a.dry_run:
         return dry_run(a)
+    if a.workload == "c5":
+        return run_c5(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -290,9 +403,14 @@ def main():
     from kprn_amd import _ffi, synth, dp
     dt_, de_, dr_, H = dims_of(a)
     shipped = a.dims == "shipped"
-    D, L, T, C, F, nT = dt_ + de_ + dr_, (1 if shipped else a.layers), a.T, 46, 3, 1
+    c4 = a.dims == "C4"
+    if c4 and a.compute_dtype == 0 and not a.c4_fp32:
+        a.compute_dtype = 1
+    if a.entities <= 0:
+        a.entities = 20_000_000 if c4 else 2851220
+    D, L, T, C, F, nT = dt_ + de_ + dr_, (1 if (shipped or c4) else a.layers), a.T, 46, 3, 1
     G = 1 if shipped else 4
-    Vt, Ve, Vr = 6, a.entities, 9
+    Vt, Ve, Vr = 6, a.entities, (100 if c4 else 9)
     stream = torch.cuda.current_stream().cuda_stream
     eng = _ffi.Engine(Vt, Ve, Vr, dt_, de_, dr_, H, L, F=F, num_types=nT, C_=C, reducer=2, device_id=local_rank,
                       rank=rank, world=world, param_init=0.1, seed=12345, stream=stream,
@@ -519,7 +637,7 @@ def main():
             total_work = work * (launches / a.steps)
             if bound == "mfma":
                 achieved = total_work / (ms * 1e-3) / 1e12
-                peak, unit = PEAK_TFLOPS_F32_MFMA, "TFLOP/s"
+                peak, unit = (PEAK_TFLOPS_BF16_MFMA if (a.compute_dtype == 1 and "bf16" in name) else PEAK_TFLOPS_F32_MFMA), "TFLOP/s"
             else:
                 achieved = total_work / (ms * 1e-3) / 1e9
                 peak, unit = PEAK_HBM_GBS, "GB/s"
@@ -590,15 +708,22 @@ def main():
             bw = family_work("lstm_fused_bwd", paths_of[bi], T, D, H, L, C, F, nT, dt_, de_, dr_, G, exec_of[bi])[1] * L
             exec_flops += (0 if a.score_only else fw + bw) + (0 if a.train_only else fw)
         exec_tflops = exec_flops * world / elapsed / 1e12
+        wl = (f"C2 KKBOX-MI synthetic: T={T}, D=H={H} ({dt_}/{de_}/{dr_}), L={L} FastLSTM, fp32, Ve={Ve}, "
+              f"C=46, LSE pool, Adam; scoring pass + train step per batch")
+        if shipped:
+            wl = (f"run_scripts/config.sh as shipped, synthetic KKBox-shaped paths: T={T}, rnn (ReLU, MaskZero, identity init), "
+                  f"D={D} ({dt_}/{de_}/{dr_}), H={H}, L=1, fp32, Ve={Ve}, C=46, LSE pool, Adam; scoring pass + train step per batch")
+        if c4:
+            wl = (f"C4 (BASELINE configs[3]) synthetic KG: {Ve} entities / {Vr} relations, T={T}, d=128 -> D=H={H}, L=1 FastLSTM, "
+                  + ("bf16 storage (shadow tables / weights, activations, gate saves) + bf16 MFMA, fp32 accumulate / cell state / master parameters / Adam"
+                     if a.compute_dtype == 1 else "fp32") + ", C=46, LSE pool; scoring pass + train step per batch")
         out = {
-            "metric": "paths/sec (train+score) at path_len=6 d=64", "value": round(value, 1), "unit": "paths/s",
+            "metric": ("paths/sec (train+score) at path_len=6 d=64" if not c4 else "paths/sec (train+score) at path_len=6 d=128 bf16"),
+            "value": round(value, 1), "unit": "paths/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
             "higher_is_better": True, "scaling": "strong" if a.total_paths else "weak", "vs_baseline": None,
             "dtype": {0: "f32", 1: "bf16", 2: "f32x6", 3: "f32x3"}[a.compute_dtype], "data": "synthetic",
-            "config": {"workload": (f"C2 KKBOX-MI synthetic: T={T}, D=H={H} ({dt_}/{de_}/{dr_}), L={L} FastLSTM, fp32, Ve={Ve}, "
-                                    f"C=46, LSE pool, Adam; scoring pass + train step per batch") if not shipped else
-                                   (f"run_scripts/config.sh as shipped, synthetic KKBox-shaped paths: T={T}, rnn (ReLU, MaskZero, identity init), "
-                                    f"D={D} ({dt_}/{de_}/{dr_}), H={H}, L=1, fp32, Ve={Ve}, C=46, LSE pool, Adam; scoring pass + train step per batch"),
+            "config": {"workload": wl,
                        "paths_per_step_per_gpu": a.paths_per_step, "paths_per_pair_buckets": Ps, "impl": a.impl,
                        "entity_update": "lazy-exact" if a.entity_update == 0 else "dense",
                        "score_overlap": not a.no_score_overlap,

@@ -142,7 +142,7 @@ static void radix_sort_pairs(int32_t* k0, int32_t* v0, int32_t* k1, int32_t* v1,
 
 // ids of one batch -> validation, plan, index.  All outputs are caller-provided (page-locked staging of the slot); w0..w3 are
 // work arrays of n_index int32 each.  Mirrors kk::validate_indices, bidx::prefix_plan and bidx::build line by line.
-void build(const Shape& g, const int32_t* idx, int kcap, int nth, Result* r, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
+void build(const Shape& g, const int32_t* idx, int kcap, int nth, bool want_index, Result* r, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
            int32_t* pmeta /*[8+16]*/, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq, int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3) {
   const int B = g.B, P = g.P, T = g.T, F = g.F, nT = g.nT;
   const int64_t N = (int64_t)B * P, nsteps = N * T;
@@ -252,6 +252,7 @@ void build(const Shape& g, const int32_t* idx, int kcap, int nth, Result* r, int
     for (int c = 0; c < F && c < 16; ++c) r->ref[c] = pmeta[8 + c];
     src = idx_s;
   }
+  if (!want_index) return;   // a scoring-only batch: nothing downstream walks its entity rows
   // ---- occurrence index (batch_index.hip k_keys / radix sort / run-length encode / k_drop_sentinel)
   const int64_t n_index = nsteps + kcap;
   const int sentinel = g.Ve;

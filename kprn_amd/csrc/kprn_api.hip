@@ -177,6 +177,7 @@ static void params_touched(kprn_handle* h) {
   h->pad_clean = false;
   h->caught_serial = -1;
   fused::params_changed(h);
+  bf16p::params_changed(h, false);
 }
 
 // the optimiser's row list: a view of the batch's distinct-row list until something needs an owned copy
@@ -253,7 +254,9 @@ static void ensure_ws_generic(kprn_handle* h, int64_t N, int T) {
 }
 
 // rows of this batch that are behind opt_step are replayed before the forward reads them
+static void flush_lazy(kprn_handle* h);
 static void catch_up(kprn_handle* h, const kprn_batch* b) {
+  if (h->lazy_pending && !b->has_index) { flush_lazy(h); return; }   // (no row list: bring the whole table up to date instead)
   if (!h->lazy_pending || b->n_uniq == 0) return;
   if (h->caught_serial == b->serial && h->caught_step == h->opt_step) return;  // this batch's rows are already current
   join_score(h);
@@ -261,6 +264,7 @@ static void catch_up(kprn_handle* h, const kprn_batch* b) {
   // count lives at the tail of the list buffer
   kk::adam_rows(h->stream, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, b->uniq, b->uniq + b->uniq_cap, b->n_uniq, h->cfg.de,
                 (int32_t)h->opt_step, 0, h->step_tab, h->last_b1, h->last_b2, h->last_eps, (int64_t)h->cfg.Ve - 1);
+  bf16p::rows_updated(h, b->uniq, b->uniq + b->uniq_cap, b->n_uniq);
   h->caught_serial = b->serial; h->caught_step = h->opt_step;
 }
 
@@ -421,6 +425,11 @@ static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool
   ensure_ws_common(h, N, b->B);
   if (use_fused(h, b, save_for_backward)) {
     fused::forward(h, b, save_for_backward);
+  } else if (!b->idx_valid) {
+    throw KprnError{KPRN_E_ARG, "this label-less batch was fed for the fused kernels (plan only); feed it again after changing impl"};
+  } else if (bf16p::supported(h, b)) {
+    ensure_ws_generic(h, N, b->T);   // (fp32 cell state, dx, h_T and the head's buffers are shared with the generic pipeline)
+    bf16p::forward(h, b, save_for_backward);
   } else {
     ensure_ws_generic(h, N, b->T);
     forward_generic(h, b, save_for_backward);
@@ -613,7 +622,7 @@ static void form_loss(kprn_handle* h) {
 
 static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int literal, float inv_batch) {
   check_batch(h, b, class_id);
-  KPRN_REQUIRE(b->labels != nullptr, KPRN_E_ARG, "batch has no labels (targets are required, MyOptimizer.lua:179)");
+  KPRN_REQUIRE(b->labels != nullptr && b->has_index, KPRN_E_ARG, "batch has no labels (targets are required, MyOptimizer.lua:179)");
   const kprn_config& c = h->cfg;
   zero_grads(h);
   h->dense_grads_clean = false;
@@ -638,6 +647,7 @@ static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int
   view_step_rows(h, b);
   join_score(h);
   if (fusedp) fused::backward(h, b, cid);
+  else if (bf16p::supported(h, b)) bf16p::backward(h, b, cid);
   else backward_generic(h, b, cid);
   h->ent_grads_dirty = true;
   h->grads_serial = b->serial;
@@ -724,6 +734,10 @@ static void apply_update_impl(kprn_handle* h, const kprn_opt* o) {
   // the rows this step updated are current; if they were one batch's rows, a forward over that batch needs no catch-up
   h->caught_serial = h->grads_serial; h->caught_step = h->opt_step;
   fused::params_changed(h);
+  // bf16 shadows: the dense arena always; the entity table row by row unless the whole table moved (dense sweep)
+  const bool whole_table = (o->method == 1) ? dense_ent : reg;
+  bf16p::params_changed(h, !whole_table);
+  if (!whole_table && h->step_rows_ub > 0) bf16p::rows_updated(h, rows, rcount, h->step_rows_ub);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -839,6 +853,7 @@ void kprn_destroy(kprn_handle* h) {
   if (h->feed_scratch) { hipFree(h->feed_scratch); h->feed_scratch = nullptr; }
   dfree(h->S2); dfree(h->sel2);
   fused::release(h);
+  bf16p::release(h);
   if (h->bidx_scratch) { hipFree(h->bidx_scratch); h->bidx_scratch = nullptr; }
   dfree(h->loss_partial);
   for (auto e : h->event_pool) hipEventDestroy(e);
@@ -920,6 +935,7 @@ int kprn_zero_pad_tokens(kprn_handle* h) {
   API_BEGIN(h)
   zero_pad_tokens(h);
   fused::params_changed(h);
+  bf16p::params_changed(h, false);
   API_END(h)
 }
 
@@ -1099,6 +1115,7 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
   kprn_batch* b = new kprn_batch();
   try {
     batch_reserve(h, b, B, P, T, F, labels != nullptr, [] {});
+    b->has_index = true; b->idx_valid = true;
     const int64_t N = (int64_t)B * P;
     scratch_reserve(&h->bidx_scratch, &h->bidx_scratch_bytes, std::max(bidx::scratch_bytes(b->n_index, h->cfg.Ve), bidx::prefix_scratch_bytes(N, fused::KCAP)));
     batch_enqueue(h, b, idx, labels, h->stream, h->bidx_scratch, h->bidx_scratch_bytes);
@@ -1136,6 +1153,11 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
   }
   const bool plan = b->kcap > 0;
   const BatchLayout l = batch_layout(B, N, T, F, plan, labels != nullptr);
+  // a label-less batch is scored only: with no lazy row update pending nothing walks its entity rows -> no occurrence index is
+  // built, and with a plan the ids in their original order are not uploaded either (a third of the bytes, none of the sorting)
+  const bool want_index = labels != nullptr || h->lazy_pending;
+  const bool want_idx = want_index || !plan;
+  b->has_index = want_index; b->idx_valid = want_idx;
   if (b->block_cap > b->hs_cap) {  // the image is as large as the block: a reserved slot allocates it once
     if (b->hs) hipHostFree(b->hs);
     b->hs = nullptr; b->hs_cap = 0;
@@ -1160,10 +1182,10 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
   hostfeed::submit((hostfeed::Pool*)h->feed_pool, [=]() {
     try {
       kprn_batch::HostResult* r = &b->hres;
-      hostfeed::build(g, idx, kcap, nth, r, hs + l.idx_s, hs + l.perm, hs + l.slot_of, hs + l.tile_k, hs + l.pmeta, hs + l.key, hs + l.pos, hs + l.uniq,
-                      hw, hw + n_index, hw + 2 * n_index, hw + 3 * n_index);
+      hostfeed::build(g, idx, kcap, nth, want_index, r, hs + l.idx_s, hs + l.perm, hs + l.slot_of, hs + l.tile_k, hs + l.pmeta, hs + l.key, hs + l.pos,
+                      hs + l.uniq, hw, hw + n_index, hw + 2 * n_index, hw + 3 * n_index);
       if (!r->bad) {
-        memcpy(hs + l.idx, idx, (size_t)(nsteps * F) * sizeof(int32_t));
+        if (want_idx) memcpy(hs + l.idx, idx, (size_t)(nsteps * F) * sizeof(int32_t));
         hs[l.cnt] = r->n_uniq;
       }
     } catch (...) { done->set_exception(std::current_exception()); return; }
@@ -1174,7 +1196,9 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
         if (!b->hres.bad) {
           HIP_TRY(hipStreamWaitEvent(us, b->ev_fork, 0));
           if (wait_score) HIP_TRY(hipStreamWaitEvent(us, b->ev_fork2, 0));
-          HIP_TRY(hipMemcpyAsync(b->block, hs, (size_t)l.words * sizeof(int32_t), hipMemcpyHostToDevice, us));
+          // the image is contiguous: idx | idx_s .. pmeta | key | pos | uniq | count | labels | flag -- a scoring-only batch moves the plan part
+          const int64_t w0 = want_idx ? 0 : l.idx_s, w1 = want_index ? l.words : l.key;
+          HIP_TRY(hipMemcpyAsync(b->block + w0, hs + w0, (size_t)(w1 - w0) * sizeof(int32_t), hipMemcpyHostToDevice, us));
         }
         HIP_TRY(hipEventRecord(b->ev_ready, us));
         issued = true;
@@ -1228,7 +1252,7 @@ int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx,
     if (h->feed_build_host) {
       feed_host(h, b, idx, labels);
     } else {
-      b->host_built = false;
+      b->host_built = false; b->has_index = true; b->idx_valid = true;
       const int64_t N = (int64_t)B * P;
       const size_t need = std::max(bidx::scratch_bytes(b->n_index, h->cfg.Ve), bidx::prefix_scratch_bytes(N, fused::KCAP));
       if (need > h->feed_scratch_bytes) {
@@ -1292,7 +1316,7 @@ int kprn_host_batch_index(const int32_t* idx, int32_t B, int32_t P, int32_t T, i
     std::vector<int32_t> w((size_t)(4 * n_index));
     kprn_batch::HostResult r;
     const hostfeed::Shape g{B, P, T, F, num_types, Vt, Ve, Vr};
-    hostfeed::build(g, idx, kcap, std::max(1, (int)threads), &r, idx_s, perm, slot_of, tile_k, pmeta, key_sorted, pos_sorted, uniq, w.data(),
+    hostfeed::build(g, idx, kcap, std::max(1, (int)threads), true, &r, idx_s, perm, slot_of, tile_k, pmeta, key_sorted, pos_sorted, uniq, w.data(),
                     w.data() + n_index, w.data() + 2 * n_index, w.data() + 3 * n_index);
     summary[0] = r.bad ? 1 : 0; summary[1] = r.kmax; summary[2] = r.n_uniq; summary[3] = r.exec_steps;
   } catch (...) { return KPRN_E_NOMEM; }
@@ -1474,7 +1498,7 @@ int kprn_train_step_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id,
   KPRN_REQUIRE(opt, KPRN_E_ARG, "opt is NULL");
   check_batch(h, b, class_id);
   catch_up(h, b);
-  if (!h->pad_clean) { zero_pad_tokens(h); fused::params_changed(h); }  // MyOptimizer.lua:181 (a no-op when the last step left them zero)
+  if (!h->pad_clean) { zero_pad_tokens(h); fused::params_changed(h); bf16p::params_changed(h, false); }  // MyOptimizer.lua:181 (a no-op when the last step left them zero)
   backward_impl(h, b, class_id, opt->bce_literal, 0.f);
   apply_update_impl(h, opt);
   if (loss) {

@@ -99,6 +99,9 @@ struct kprn_batch {
   bool bad = false;               // an id of the current contents is outside its vocabulary: every use returns KPRN_E_INDEX
   // host-built feed (host_feed.hip): a worker thread derives plan + index on the host cores into page-locked staging and queues
   // the uploads on the slot's own copy stream; the consumer waits for the job (host) and for ev_ready (stream-side, no host wait)
+  bool has_index = true;          // occurrence index + distinct rows present (a label-less batch fed while no lazy row update is
+                                  // pending carries none: scoring never walks them)
+  bool idx_valid = true;          // the ids in their original order are on the device (not uploaded for such a batch when it has a plan)
   bool host_built = false;
   std::future<void> job;          // valid while pending && host_built
   int32_t* hs = nullptr; int64_t hs_cap = 0;   // page-locked image of the device block
@@ -162,6 +165,7 @@ struct kprn_handle {
   Workspace ws;
   float* score_buf = nullptr;   // where the mapper output [N][C] of the last forward lives (ws.S)
   void* fused_state = nullptr;  // owned by lstm_fused_*.hip
+  void* bf16_state = nullptr;   // owned by lstm_bf16.hip (compute_dtype 1: bf16 shadows of tables / weights, bf16 activations)
   void* bidx_scratch = nullptr; size_t bidx_scratch_bytes = 0;  // batch_index.hip temporaries
   // streaming batch feed: upload + validation + occurrence index + prefix plan of the NEXT batch on their own stream, under
   // the step that is running (kprn_batch_feed_async)
@@ -305,6 +309,16 @@ void merge_rows(hipStream_t s, const void* all, int world, int cap, int de, int 
                 void* scratch, size_t scratch_sz);
 }  // namespace bidx
 
+// ---- bf16 pipeline (lstm_bf16.hip): compute_dtype 1 with bf16 storage, FastLSTM, 8-element rows, >= 256 paths ----------------
+namespace bf16p {
+bool supported(const kprn_handle* h, const kprn_batch* b);
+void forward(kprn_handle* h, const kprn_batch* b, bool save);
+void backward(kprn_handle* h, const kprn_batch* b, int cid);
+void params_changed(kprn_handle* h, bool entity_rows_only);   // parameters rewritten: shadows are stale (rows only: the dense arena + listed rows)
+void rows_updated(kprn_handle* h, const int32_t* rows, const int32_t* count, int64_t max_rows);
+void release(kprn_handle* h);
+}  // namespace bf16p
+
 // ---- host side of the streaming feed (host_feed.hip) -------------------------------------------------
 namespace hostfeed {
 struct Shape { int B, P, T, F, nT, Vt, Ve, Vr; };
@@ -313,7 +327,7 @@ class Pool;
 Pool* make_pool(int workers);
 void free_pool(Pool* p);
 std::future<void> submit(Pool* p, std::function<void()> fn);
-void build(const Shape& g, const int32_t* idx, int kcap, int nth, Result* r, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
+void build(const Shape& g, const int32_t* idx, int kcap, int nth, bool want_index, Result* r, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
            int32_t* pmeta, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq, int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3);
 }  // namespace hostfeed
 

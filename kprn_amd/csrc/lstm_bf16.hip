@@ -1,0 +1,610 @@
+// bf16 pipeline of the FastLSTM path (BASELINE.json configs[3]: 20 M entities, d = 128 -> D = H = 384, "bf16 MFMA LSTM"): bf16 STORAGE
+// of everything the matrix cores read -- a bf16 shadow of the embedding tables and of the weights, bf16 step inputs, hidden states,
+// gate values and pre-activation gradients -- products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, fp32 cell state, fp32 master
+// parameters and fp32 lazy-exact Adam (kprn_api.hip), which refreshes the shadow rows it touches.  gfx950 only.
+//
+// Stands for the same reference graph as gemm_tiled.hip (nn.LookupTable x 3 -> nn.Sequencer(nn.FastLSTM) x L -> nn.Linear:
+// release/songPathRnn/net/FeatureEmbedding.lua:112-121, model/OneModel.lua:236,268-275) at reduced precision; tolerance-gated against the
+// float64 oracle (tests/test_gpu_parity.py, tests/test_gpu_wide.py).
+//
+// One tile kernel: C[M,N] = A[M,K] B[N,K]^T, both operands k-contiguous bf16 (16-byte = 8-element global loads, LDS tiles [128][64 + 8],
+// one ds_read_b128 per MFMA operand), 128 x 128 x 64 tiles, 4 waves, 2 workgroups per CU, XCD-aware order.  Everything the backward needs
+// transposed (dW = dA^T [x | h]: the contraction runs over the path rows) is brought into that one layout by a bf16 transpose kernel --
+// memory-bound passes of a few hundred microseconds, instead of a second GEMM formulation with strided LDS reads.
+#include <string.h>
+
+#include <algorithm>
+
+#include "kprn_internal.h"
+
+namespace bf16p {
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 128, TN = 128, TK = 64, LDB = TK + 8;   // LDS row pitch in elements (144 bytes)
+constexpr int TILE_E = TM * LDB;
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ bf16 tobf(float x) { return (bf16)x; }   // round to nearest even
+
+enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_LSTM = 2 };
+
+struct GArgs {
+  const bf16* A; int64_t lda; const bf16* B; int64_t ldb; int64_t K;
+  const bf16* A2; int64_t lda2; const bf16* B2; int64_t ldb2; int64_t K2;   // second K segment (recurrent half)
+  float* C; int64_t ldc; int64_t M; int N; const float* bias;
+  int64_t kchunk; int use_atomic; int nsplit;
+  int64_t mtiles; int ntiles;
+  // EPI_LSTM: N = 4H gate-major rows of B; a column tile = 32 hidden units x 4 gates
+  int H; const float* cprev; float* cout; bf16* hout; int64_t ldh; bf16* act; float* hout_f32;
+};
+
+// pieces of one [128][64] bf16 tile: running pointers, clamped loads, zeroing at the LDS write (as gemm_tiled.hip's TileLoader)
+struct Loader {
+  const bf16* p[4]; const bf16* safe; bool rok[4]; int kq;
+  __device__ __forceinline__ void init(const bf16* __restrict__ P, int64_t ld, int64_t r0, int64_t rmax, int64_t k0, const int* rowmap) {
+    const int tid = threadIdx.x;
+    safe = P; kq = (tid & 7) * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = (tid >> 3) + 32 * e;
+      int64_t gr = r0 + row;
+      bool ok = gr < rmax;
+      if (rowmap) { const int mr = rowmap[row]; ok = mr >= 0; gr = mr; }
+      rok[e] = ok;
+      p[e] = P + (ok ? gr : 0) * ld + k0 + kq;
+    }
+  }
+  __device__ __forceinline__ unsigned load(int64_t k0, int64_t kend, bf16x8 (&v)[4]) {
+    unsigned mask = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = rok[e] && (k0 + kq < kend);
+      v[e] = *(const bf16x8*)(ok ? p[e] : safe);
+      mask |= ok ? (1u << e) : 0u;
+      p[e] += TK;
+    }
+    return mask;
+  }
+};
+__device__ __forceinline__ void tile_store(bf16* __restrict__ T, const bf16x8 (&v)[4], unsigned mask) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bf16x8 x = v[e];
+    if (!((mask >> e) & 1u)) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = (bf16)0.f;
+    }
+    *(bf16x8*)(T + ((tid >> 3) + 32 * e) * LDB + (tid & 7) * 8) = x;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm16(GArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16 lds16[];
+  auto As = [&](int i) -> bf16* { return lds16 + i * (2 * TILE_E); };
+  auto Bs = [&](int i) -> bf16* { return lds16 + i * (2 * TILE_E) + TILE_E; };
+  __shared__ int rowmap[TN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, arow = lane & 15, ag = lane >> 4;
+  const int64_t id = blockIdx.x;
+  const int xcd = (int)(id & 7);
+  const int64_t j = id >> 3;
+  int nt_idx; int64_t mt_idx, split_idx = 0;
+  if (a.nsplit > 1) {   // all tiles of one K range on one XCD (gemm_tiled.hip)
+    const int64_t tiles = a.mtiles * a.ntiles;
+    split_idx = (j / tiles) * 8 + xcd;
+    const int64_t tl = j % tiles;
+    mt_idx = tl / a.ntiles; nt_idx = (int)(tl % a.ntiles);
+    if (split_idx >= a.nsplit) return;
+  } else {
+    nt_idx = (int)(j % a.ntiles);
+    mt_idx = (j / a.ntiles) * 8 + xcd;
+    if (mt_idx >= a.mtiles) return;
+  }
+  const int64_t m0 = mt_idx * TM;
+  const int n0 = nt_idx * TN;
+  constexpr bool CELL = (EPI == EPI_LSTM);
+  if (CELL) {
+    if (tid < TN) {
+      const int q = tid >> 5, u = nt_idx * 32 + (tid & 31);
+      rowmap[tid] = (u < a.H) ? q * a.H + u : -1;
+    }
+    __syncthreads();
+  }
+  const int* rmap = CELL ? rowmap : nullptr;
+  const int64_t k_beg = split_idx * a.kchunk;
+  const int64_t k_end1 = (k_beg + a.kchunk < a.K) ? k_beg + a.kchunk : a.K;
+  const int64_t nch1 = (k_end1 > k_beg) ? (k_end1 - k_beg + TK - 1) / TK : 0;
+  const int64_t nch2 = (a.A2 != nullptr) ? (a.K2 + TK - 1) / TK : 0;
+  const int64_t nch = nch1 + nch2;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ra[4], rb[4];
+  unsigned ma = 0, mb = 0;
+  Loader la, lb;
+  const int64_t brow0 = CELL ? 0 : n0, bmax = CELL ? (int64_t)4 * a.H : (int64_t)a.N;
+  auto seg_init = [&](int seg) {
+    if (seg == 0) { la.init(a.A, a.lda, m0, a.M, k_beg, nullptr); lb.init(a.B, a.ldb, brow0, bmax, k_beg, rmap); }
+    else { la.init(a.A2, a.lda2, m0, a.M, 0, nullptr); lb.init(a.B2, a.ldb2, brow0, bmax, 0, rmap); }
+  };
+  auto load_chunk = [&](int64_t c) {
+    if (c == nch1) seg_init(1);
+    const bool s0 = c < nch1;
+    const int64_t k0 = s0 ? k_beg + c * TK : (c - nch1) * TK;
+    const int64_t ke = s0 ? k_end1 : a.K2;
+    ma = la.load(k0, ke, ra);
+    mb = lb.load(k0, ke, rb);
+  };
+  if (nch > 0) {
+    if (nch1 > 0) seg_init(0);
+    load_chunk(0);
+    tile_store(As(0), ra, ma);
+    tile_store(Bs(0), rb, mb);
+  }
+  __syncthreads();
+  const int b_base = CELL ? wn * 16 : wn * 64;
+  const int b_step = CELL ? 32 : 16;
+  for (int64_t c = 0; c < nch; ++c) {
+    const int cur = (int)(c & 1);
+    const bool more = c + 1 < nch;
+    if (more) load_chunk(c + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {   // two 32-k MFMA blocks per chunk; lane (row, ag) supplies k = 32 kk + 8 ag .. + 7
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(As(cur) + (wm * 64 + i * 16 + arow) * LDB + kk * 32 + ag * 8);
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) fb[jn] = *(const bf16x8*)(Bs(cur) + (b_base + jn * b_step + arow) * LDB + kk * 32 + ag * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+    }
+    if (more) {
+      tile_store(As(cur ^ 1), ra, ma);
+      tile_store(Bs(cur ^ 1), rb, mb);
+    }
+    __syncthreads();
+  }
+  if constexpr (EPI == EPI_STORE || EPI == EPI_ACCUM) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) {
+        const int col = n0 + wn * 64 + jn * 16 + arow;
+        if (col >= a.N) continue;
+        const float bv = (EPI == EPI_STORE && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = m0 + wm * 64 + i * 16 + ag * 4 + r;
+          if (row >= a.M) continue;
+          float* dst = a.C + row * a.ldc + col;
+          if (EPI == EPI_STORE) *dst = acc[i][jn][r] + bv;
+          else if (a.use_atomic) unsafeAtomicAdd(dst, acc[i][jn][r]);
+          else *dst += acc[i][jn][r];
+        }
+      }
+  } else {
+    const int u = nt_idx * 32 + wn * 16 + arow;
+    if (u < a.H) {
+      float bq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[q] = a.bias[q * a.H + u];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = m0 + wm * 64 + i * 16 + ag * 4 + r;
+          if (row >= a.M) continue;
+          const float ig = sigm(acc[i][0][r] + bq[0]);
+          const float gg = tanhf(acc[i][1][r] + bq[1]);
+          const float fg = sigm(acc[i][2][r] + bq[2]);
+          const float og = sigm(acc[i][3][r] + bq[3]);
+          const float cp = a.cprev ? a.cprev[row * a.ldh + u] : 0.f;
+          const float cc = fg * cp + ig * gg;
+          const float hh = og * tanhf(cc);
+          a.cout[row * a.ldh + u] = cc;
+          a.hout[row * a.ldh + u] = tobf(hh);
+          if (a.hout_f32) a.hout_f32[row * a.ldh + u] = hh;
+          if (a.act) {
+            bf16* g = a.act + row * (int64_t)4 * a.H + u;
+            g[0] = tobf(ig); g[a.H] = tobf(gg); g[2 * a.H] = tobf(fg); g[3 * a.H] = tobf(og);
+          }
+        }
+    }
+  }
+}
+
+template <int EPI>
+static void launch16(hipStream_t s, GArgs a, int split_k) {
+  const size_t lds_bytes = (size_t)4 * TILE_E * sizeof(bf16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_gemm16<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  a.nsplit = split_k;
+  dim3 grid((unsigned)(((a.mtiles + 7) / 8) * 8 * a.ntiles));
+  if (split_k > 1) grid = dim3((unsigned)(((split_k + 7) / 8) * 8 * a.mtiles * a.ntiles));
+  hipLaunchKernelGGL((k_gemm16<EPI>), grid, dim3(256), lds_bytes, s, a);
+  HIP_TRY(hipGetLastError());
+}
+
+// C[M][N] (fp32) = or += A[M][K] B[N][K]^T; K, lda, ldb multiples of 8 elements, 16-byte aligned pointers
+static void gemm16(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K,
+                   bool accumulate, const float* bias, int split_k) {
+  GArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.K = K; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.bias = bias;
+  a.mtiles = (M + TM - 1) / TM; a.ntiles = (N + TN - 1) / TN;
+  if (split_k < 1 || !accumulate) split_k = 1;
+  if (split_k > 1) {
+    const int64_t tiles = a.mtiles * a.ntiles;
+    split_k = (int)std::max<int64_t>(1, std::min<int64_t>(split_k, (3 * 256 + tiles - 1) / tiles));
+  }
+  int64_t kchunk = (K + split_k - 1) / split_k;
+  kchunk = ((kchunk + TK - 1) / TK) * TK;
+  split_k = (int)((K + kchunk - 1) / kchunk);
+  a.kchunk = kchunk; a.use_atomic = split_k > 1 ? 1 : 0;
+  if (accumulate) launch16<EPI_ACCUM>(s, a, split_k); else launch16<EPI_STORE>(s, a, split_k);
+}
+
+// ---- element-wise / layout kernels --------------------------------------------------------------------------------------
+__global__ void k_cvt(const float* __restrict__ x, bf16* __restrict__ y, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const f32x4 v = *(const f32x4*)(x + i);
+    bf16x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = tobf(v[q]);
+    *(bf16x4*)(y + i) = o;
+  } else {
+    for (int64_t k = i; k < n; ++k) y[k] = tobf(x[k]);
+  }
+}
+// y[c][r] = bf16(x[r][c]), x fp32 [R][C] (weights: small)
+__global__ void k_cvt_T(const float* __restrict__ x, bf16* __restrict__ y, int R, int Cc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)R * Cc) return;
+  const int c = (int)(i / R), r = (int)(i - (int64_t)c * R);
+  y[i] = tobf(x[(int64_t)r * Cc + c]);
+}
+// shadow rows of the entity table after a row update: rows[0 .. *count)
+__global__ void k_rows_cvt(const float* __restrict__ W, bf16* __restrict__ W16, const int32_t* __restrict__ rows, const int32_t* __restrict__ count,
+                           int d) {
+  const int n = *count;
+  const int per = d >> 2;  // float4 pieces per row
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n * per; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows[i / per];
+    const int c = (int)(i % per) * 4;
+    const f32x4 v = *(const f32x4*)(W + r * d + c);
+    bf16x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = tobf(v[q]);
+    *(bf16x4*)(W16 + r * d + c) = o;
+  }
+}
+// FeatureEmbedding (net/FeatureEmbedding.lua:112-121) on the bf16 shadows: X16[t][n][:] = [ sum_k Wt[type_k] | We[ent] | Wr[rel] ], 8 columns
+// per thread; ids are int32 (never through a float: 20 M entities exceed 2^24).  Several type slots: summed in fp32, rounded once.
+__global__ void k_gather16(const int32_t* __restrict__ idx, int64_t N, int T, int F, int nT, const bf16* __restrict__ Wt, const bf16* __restrict__ We,
+                           const bf16* __restrict__ Wr, int dt, int de, int dr, bf16* __restrict__ X) {
+  const int D = dt + de + dr, DV = D >> 3;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= N * T * DV) return;
+  const int cv = (int)(gid % DV);
+  const int64_t nt = gid / DV;
+  const int64_t n = nt / T;
+  const int t = (int)(nt - n * T);
+  const int32_t* f = idx + nt * F;
+  const int col = cv * 8;
+  bf16x8 v;
+  if (col < dt) {
+    v = *(const bf16x8*)(Wt + (int64_t)(f[F - nT - 2] - 1) * dt + col);
+    if (nT > 1) {
+      float acc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = (float)v[q];
+      for (int k = 1; k < nT; ++k) {
+        const bf16x8 w = *(const bf16x8*)(Wt + (int64_t)(f[F - nT - 2 + k] - 1) * dt + col);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += (float)w[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = tobf(acc[q]);
+    }
+  } else if (col < dt + de) {
+    v = *(const bf16x8*)(We + (int64_t)(f[F - 2] - 1) * de + (col - dt));
+  } else {
+    v = *(const bf16x8*)(Wr + (int64_t)(f[F - 1] - 1) * dr + (col - dt - de));
+  }
+  *(bf16x8*)(X + ((int64_t)t * N + n) * D + col) = v;
+}
+// cell backward of one step on the saved bf16 gate values (kernels_basic.hip k_gates_bwd, with dA written in bf16)
+__global__ void k_gates_bwd16(const bf16* __restrict__ act, const float* __restrict__ c, const float* __restrict__ c_prev, const float* __restrict__ dH_up,
+                              float* __restrict__ dH, float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= N * H) return;
+  const int jx = (int)(gid % H);
+  const int64_t n = gid / H;
+  const bf16* a = act + n * 4 * H;
+  const float ig = (float)a[jx], gg = (float)a[H + jx], fg = (float)a[2 * H + jx], og = (float)a[3 * H + jx];
+  const float tc = tanhf(c[gid]);
+  const float dh = dH[gid] + (dH_up ? dH_up[gid] : 0.f);
+  const float dO = dh * tc;
+  const float dc = dC[gid] + dh * og * (1.f - tc * tc);
+  const float cp = c_prev ? c_prev[gid] : 0.f;
+  bf16* d = dA + n * 4 * H;
+  d[jx] = tobf(dc * gg * ig * (1.f - ig));
+  d[H + jx] = tobf(dc * ig * (1.f - gg * gg));
+  d[2 * H + jx] = tobf(dc * cp * fg * (1.f - fg));
+  d[3 * H + jx] = tobf(dO * og * (1.f - og));
+  dC[gid] = dc * fg;
+  dH[gid] = 0.f;
+}
+// y[c][r] = x[r][c] for r < R, 0 for R <= r < Rp (the padded row count: 16-byte rows of y); x bf16 [R][C], y pitch ldy; 64 x 64 tiles via LDS
+__global__ __launch_bounds__(256) void k_transpose16(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t R, int64_t Rp, int64_t Cc, int64_t ldy) {
+  __shared__ bf16 t[64][66];
+  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int rr = ty + 4 * k;
+    t[rr][tx] = (r0 + rr < R && c0 + tx < Cc) ? x[(r0 + rr) * Cc + c0 + tx] : (bf16)0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int cc = ty + 4 * k;
+    if (c0 + cc < Cc && r0 + tx < Rp) y[(c0 + cc) * ldy + r0 + tx] = t[tx][cc];
+  }
+}
+// out[r] += sum of row r of x (bf16 [R][n]): the bias gradient from dA^T
+__global__ __launch_bounds__(256) void k_rowsum16(const bf16* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[256];
+  const bf16* row = x + (int64_t)blockIdx.x * n;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) acc += (float)row[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] += red[0];
+}
+
+// ---- state + orchestration --------------------------------------------------------------------------------------------------
+struct State {
+  bf16* We16 = nullptr; bool we_all_dirty = true;
+  bf16* dense16 = nullptr;      // bf16 image of the dense arena (same offsets)
+  bf16* WT16 = nullptr;         // per layer: W_i2g^T [Din][4H] | W_o2g^T [H][4H]
+  bool dense_dirty = true;
+  int64_t cap_N = 0; int cap_T = 0;
+  bf16 *X16 = nullptr, *XT16 = nullptr, *H16 = nullptr, *HT16 = nullptr, *ACT16 = nullptr, *dA16 = nullptr, *dAT16 = nullptr;
+};
+static State* st(kprn_handle* h) {
+  if (!h->bf16_state) h->bf16_state = new State();
+  return (State*)h->bf16_state;
+}
+template <typename Tp> static Tp* dal(int64_t n) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, (size_t)std::max<int64_t>(n, 1) * sizeof(Tp));
+  if (e != hipSuccess) throw KprnError{KPRN_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e)};
+  return (Tp*)p;
+}
+static int64_t wt_off(const kprn_handle* h, int l) {   // offset of layer l's transposed pair inside WT16
+  int64_t o = 0;
+  for (int k = 0; k < l; ++k) o += (int64_t)4 * h->cfg.H * (h->layer[k].Din + h->cfg.H);
+  return o;
+}
+
+bool supported(const kprn_handle* h, const kprn_batch* b) {
+  const kprn_config& c = h->cfg;
+  const int64_t N = (int64_t)b->B * b->P;
+  return c.compute_dtype == 1 && c.rnn_type == 0 && h->impl == 0 && N >= 256 && (c.dt % 8) == 0 && (c.de % 8) == 0 && (c.dr % 8) == 0 && (c.H % 8) == 0;
+}
+
+void params_changed(kprn_handle* h, bool entity_rows_only) {
+  if (!h->bf16_state) return;
+  State* s = (State*)h->bf16_state;
+  s->dense_dirty = true;
+  if (!entity_rows_only) s->we_all_dirty = true;
+}
+
+// the optimiser / the catch-up replay rewrote these rows of entity_emb: refresh their shadow
+void rows_updated(kprn_handle* h, const int32_t* rows, const int32_t* count, int64_t max_rows) {
+  if (!h->bf16_state) return;
+  State* s = (State*)h->bf16_state;
+  if (s->we_all_dirty || !s->We16 || max_rows <= 0) return;   // (a full conversion is pending anyway)
+  const int de = h->cfg.de;
+  const int64_t work = max_rows * (de >> 2);
+  hipLaunchKernelGGL(k_rows_cvt, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 4096)), dim3(256), 0, h->stream, h->We, s->We16, rows, count, de);
+  HIP_TRY(hipGetLastError());
+}
+
+void release(kprn_handle* h) {
+  State* s = (State*)h->bf16_state;
+  if (!s) return;
+  for (bf16* p : {s->We16, s->dense16, s->WT16, s->X16, s->XT16, s->H16, s->HT16, s->ACT16, s->dA16, s->dAT16}) if (p) hipFree(p);
+  delete s;
+  h->bf16_state = nullptr;
+}
+
+static void refresh_shadows(kprn_handle* h) {
+  State* s = st(h);
+  const kprn_config& c = h->cfg;
+  hipStream_t strm = h->stream;
+  if (!s->We16) { s->We16 = dal<bf16>(h->n_ent); s->we_all_dirty = true; }
+  if (!s->dense16) { s->dense16 = dal<bf16>(h->n_dense); s->WT16 = dal<bf16>(wt_off(h, c.L)); s->dense_dirty = true; }
+  if (s->we_all_dirty) {
+    ProfScope ps(h, "bf16_shadow_table");
+    hipLaunchKernelGGL(k_cvt, dim3((unsigned)((h->n_ent / 4 + 256) / 256)), dim3(256), 0, strm, h->We, s->We16, h->n_ent);
+    s->we_all_dirty = false;
+  }
+  if (s->dense_dirty) {
+    ProfScope ps(h, "bf16_shadow_weights");
+    hipLaunchKernelGGL(k_cvt, dim3((unsigned)((h->n_dense / 4 + 256) / 256)), dim3(256), 0, strm, h->dense, s->dense16, h->n_dense);
+    for (int l = 0; l < c.L; ++l) {
+      const int Din = h->layer[l].Din, G4 = 4 * c.H;
+      bf16* wt = s->WT16 + wt_off(h, l);
+      hipLaunchKernelGGL(k_cvt_T, dim3((unsigned)(((int64_t)G4 * Din + 255) / 256)), dim3(256), 0, strm, h->dense + h->layer[l].Wi, wt, G4, Din);
+      hipLaunchKernelGGL(k_cvt_T, dim3((unsigned)(((int64_t)G4 * c.H + 255) / 256)), dim3(256), 0, strm, h->dense + h->layer[l].Wo, wt + (int64_t)G4 * Din, G4, c.H);
+    }
+    s->dense_dirty = false;
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+static void ensure_buffers(kprn_handle* h, int64_t N, int T) {
+  State* s = st(h);
+  if (N <= s->cap_N && T <= s->cap_T) return;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (bf16** p : {&s->X16, &s->XT16, &s->H16, &s->HT16, &s->ACT16, &s->dA16, &s->dAT16}) if (*p) { hipFree(*p); *p = nullptr; }
+  const kprn_config& c = h->cfg;
+  const int64_t cn = std::max(N, s->cap_N);
+  const int ct = std::max(T, s->cap_T);
+  const int64_t rows = cn * ct, rows_p = ((cn + 7) & ~(int64_t)7) * ct;
+  const int Dm = std::max(h->D, c.H);
+  s->X16 = dal<bf16>(rows * h->D); s->XT16 = dal<bf16>(rows_p * Dm);
+  s->H16 = dal<bf16>((int64_t)c.L * rows * c.H); s->HT16 = dal<bf16>(rows_p * c.H);
+  s->ACT16 = dal<bf16>((int64_t)c.L * rows * 4 * c.H);
+  s->dA16 = dal<bf16>(rows * 4 * c.H); s->dAT16 = dal<bf16>(rows_p * 4 * c.H);
+  s->cap_N = cn; s->cap_T = ct;
+}
+
+// forward of the whole stack; the head runs on the fp32 h_T of the top layer (written by its last step) through the generic bf16-product GEMM
+void forward(kprn_handle* h, const kprn_batch* b, bool save) {
+  const kprn_config& c = h->cfg;
+  State* s = st(h);
+  Workspace& w = h->ws;
+  hipStream_t strm = h->stream;
+  const int H = c.H, L = c.L, T = b->T, D = h->D;
+  const int64_t N = (int64_t)b->B * b->P;
+  refresh_shadows(h);
+  ensure_buffers(h, N, T);
+  {
+    ProfScope ps(h, "embed_gather_bf16");
+    const int64_t work = N * T * (D >> 3);
+    hipLaunchKernelGGL(k_gather16, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, strm, b->idx, N, T, b->F, c.num_types, s->dense16 + h->off_Wt, s->We16,
+                       s->dense16 + h->off_Wr, c.dt, c.de, c.dr, s->X16);
+    HIP_TRY(hipGetLastError());
+  }
+  for (int l = 0; l < L; ++l) {
+    const int Din = h->layer[l].Din;
+    const bf16* in = (l == 0) ? s->X16 : s->H16 + (int64_t)(l - 1) * T * N * H;
+    bf16* hs = s->H16 + (int64_t)l * T * N * H;
+    float* cs = w.Cs + (int64_t)l * T * N * H;
+    bf16* act = s->ACT16 + (int64_t)l * T * N * 4 * H;
+    ProfScope ps(h, "lstm_step_bf16");
+    ps.launches = T;
+    for (int t = 0; t < T; ++t) {
+      GArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = in + (int64_t)t * N * Din; a.lda = Din; a.B = s->dense16 + h->layer[l].Wi; a.ldb = Din; a.K = Din;
+      if (t > 0) { a.A2 = hs + (int64_t)(t - 1) * N * H; a.lda2 = H; a.B2 = s->dense16 + h->layer[l].Wo; a.ldb2 = H; a.K2 = H; }
+      a.M = N; a.N = 4 * H; a.H = H; a.bias = h->dense + h->layer[l].bi;
+      a.cprev = t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr; a.cout = cs + (int64_t)t * N * H;
+      a.hout = hs + (int64_t)t * N * H; a.ldh = H; a.act = save ? act + (int64_t)t * N * 4 * H : nullptr;
+      a.hout_f32 = (l == L - 1 && t == T - 1) ? w.Hs + ((int64_t)(L - 1) * T + (T - 1)) * N * H : nullptr;
+      a.mtiles = (N + TM - 1) / TM; a.ntiles = (H + 31) / 32;
+      a.kchunk = ((Din + TK - 1) / TK) * TK;
+      launch16<EPI_LSTM>(strm, a, 1);
+    }
+  }
+  {
+    ProfScope ps(h, "gemm_head_fwd");
+    const float* hT = w.Hs + ((int64_t)(L - 1) * T + (T - 1)) * N * H;
+    gemm::run(strm, hT, H, 1, h->dense + h->off_outW, 1, H, w.S, c.C, N, c.C, H, false, h->dense + h->off_outb, 1, true);
+  }
+}
+
+// time-major x [T][N][C] -> y [C][T][Np] (Np = N rounded up to 8: every step's block of a row starts on 16 bytes, pad columns zero)
+static void transpose_steps(hipStream_t s, const bf16* x, bf16* y, int T, int64_t N, int64_t Np, int64_t Cc) {
+  for (int t = 0; t < T; ++t)
+    hipLaunchKernelGGL(k_transpose16, dim3((unsigned)((Np + 63) / 64), (unsigned)((Cc + 63) / 64)), dim3(256), 0, s, x + (int64_t)t * N * Cc, y + (int64_t)t * Np, N, Np,
+                       Cc, (int64_t)T * Np);
+  HIP_TRY(hipGetLastError());
+}
+
+// needs forward(save = true) of the same batch; ws.dS holds d loss / d S[:, cid]
+void backward(kprn_handle* h, const kprn_batch* b, int cid) {
+  const kprn_config& c = h->cfg;
+  State* s = st(h);
+  Workspace& w = h->ws;
+  hipStream_t strm = h->stream;
+  const int H = c.H, L = c.L, T = b->T, D = h->D, G4 = 4 * c.H;
+  const int64_t N = (int64_t)b->B * b->P, TN = (int64_t)T * N;
+  float* gd = h->g_dense;
+  {
+    ProfScope ps(h, "head_bwd");
+    const float* hT = w.Hs + ((int64_t)(L - 1) * T + (T - 1)) * N * H;
+    kk::head_bwd(strm, w.dS, hT, h->dense + h->off_outW, N, H, cid, w.dH, gd + h->off_outW, gd + h->off_outb);
+  }
+  HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), strm));
+  for (int l = L - 1; l >= 0; --l) {
+    const int Din = h->layer[l].Din;
+    const bf16* act = s->ACT16 + (int64_t)l * TN * G4;
+    const bf16* hs = s->H16 + (int64_t)l * TN * H;
+    const float* cs = w.Cs + (int64_t)l * TN * H;
+    const bf16* wt = s->WT16 + wt_off(h, l);          // W_i2g^T [Din][4H] | W_o2g^T [H][4H]
+    const bool has_up = (l < L - 1);
+    if (has_up) {
+      HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), strm));
+      HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), strm));
+    }
+    for (int t = T - 1; t >= 0; --t) {
+      bf16* dA_t = s->dA16 + (int64_t)t * N * G4;
+      {
+        ProfScope ps(h, "lstm_gates_bwd_bf16");
+        hipLaunchKernelGGL(k_gates_bwd16, dim3((unsigned)((N * H + 255) / 256)), dim3(256), 0, strm, act + (int64_t)t * N * G4, cs + (int64_t)t * N * H,
+                           t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr, has_up ? w.dIn + (int64_t)t * N * H : nullptr, w.dH, w.dC, dA_t, N, H);
+        HIP_TRY(hipGetLastError());
+      }
+      if (t > 0) {
+        ProfScope ps(h, "gemm_o2g_bwd_dh");   // dh_{t-1} = dA_t W_o2g
+        gemm16(strm, dA_t, G4, wt + (int64_t)G4 * Din, G4, w.dH, H, N, H, G4, false, nullptr, 1);
+      }
+    }
+    const int64_t Np = (N + 7) & ~(int64_t)7, TNp = (int64_t)T * Np;   // padded step blocks of the transposed images (pads are zero)
+    {
+      ProfScope ps(h, "bf16_transposes");
+      transpose_steps(strm, s->dA16, s->dAT16, T, N, Np, G4);                                                    // dA^T [4H][T][Np]
+      transpose_steps(strm, (l == 0) ? s->X16 : s->H16 + (int64_t)(l - 1) * TN * H, s->XT16, T, N, Np, Din);      // in^T [Din][T][Np]
+      if (T > 1) transpose_steps(strm, hs, s->HT16, T, N, Np, H);                                                // h^T  [H][T][Np]
+    }
+    const int split = (int)std::min<int64_t>(1024, std::max<int64_t>(1, TN / 4096));
+    {
+      ProfScope ps(h, "gemm_i2g_bwd_dw");   // gW_i2g [4H][Din] += dA^T in
+      gemm16(strm, s->dAT16, TNp, s->XT16, TNp, gd + h->layer[l].Wi, Din, G4, Din, TNp, true, nullptr, split);
+    }
+    if (T > 1) {
+      ProfScope ps(h, "gemm_o2g_bwd_dw");   // gW_o2g [4H][H] += dA[1..T-1]^T h[0..T-2]
+      gemm16(strm, s->dAT16 + Np, TNp, s->HT16, TNp, gd + h->layer[l].Wo, H, G4, H, (int64_t)(T - 1) * Np, true, nullptr, split);
+    }
+    {
+      ProfScope ps(h, "bias_colsum");
+      hipLaunchKernelGGL(k_rowsum16, dim3((unsigned)G4), dim3(256), 0, strm, s->dAT16, TNp, gd + h->layer[l].bi);
+      HIP_TRY(hipGetLastError());
+    }
+    {
+      ProfScope ps(h, "gemm_i2g_bwd_dx");   // dx [T N][Din] = dA W_i2g
+      gemm16(strm, s->dA16, G4, wt, G4, w.dIn, Din, TN, Din, G4, false, nullptr, 1);
+    }
+  }
+  {
+    ProfScope ps(h, "embed_scatter");
+    const bool have_index = b->key_sorted != nullptr && !b->tile_k;
+    kk::embed_scatter(strm, b->idx, N, T, b->F, c.num_types, w.dIn, c.dt, c.de, c.dr, c.Vt, c.Vr, gd + h->off_Wt, h->g_We, gd + h->off_Wr, have_index);
+    if (have_index) bidx::entity_grad(strm, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, b->n_index, N, T, D, c.dt, c.de, c.Ve, h->g_We);
+  }
+}
+
+}  // namespace bf16p

@@ -133,3 +133,32 @@ def test_prefix_plan_toggle_between_refills(build):
     assert slot.executed_steps == n1
     assert np.array_equal(eng.forward(slot, 1)["probs"], p1)
     eng.close()
+
+
+def test_label_less_slot_fed_before_training_scores_with_current_rows():
+    """a scoring-only batch (no labels) fed while no lazy row update is pending carries no occurrence index; if a training step
+    then leaves entity rows behind, scoring that slot must still see every row up to date (the whole table is flushed instead)"""
+    eng = _ffi.Engine(*SHAPE)
+    ia, la = synth.make_paths(300, 3, 6, Ve=5000, seed=21)
+    ib, _ = synth.make_paths(200, 2, 6, Ve=5000, seed=22)
+    slot = eng.feed(ib)                      # no labels, nothing pending -> plan only
+    assert slot.n_uniq == 0
+    ta = eng.batch(ia, la)
+    opt = _ffi.make_opt(method=1, lr=1e-2)
+    for _ in range(3):
+        eng.train_step(ta, opt)              # lazy-exact Adam: rows of B not in A fall behind
+    got = eng.forward(slot, 1, want=("probs", "path_scores"))
+    ref = eng.forward(eng.batch(ib), 1, want=("probs", "path_scores"))
+    assert np.array_equal(got["probs"], ref["probs"]) and np.array_equal(got["path_scores"], ref["path_scores"])
+    # fed while rows are pending: the slot carries its row list
+    eng.train_step(ta, opt)
+    slot2 = eng.feed(ib)
+    assert slot2.n_uniq == ref_uniq(ib)
+    assert np.array_equal(eng.forward(slot2, 1)["probs"], eng.forward(eng.batch(ib), 1)["probs"])
+    with pytest.raises(_ffi.KprnError):      # no labels -> no training on it
+        eng.train_step(slot, opt)
+    eng.close()
+
+
+def ref_uniq(idx):
+    return len(np.unique(idx[..., 1]))

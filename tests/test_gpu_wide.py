@@ -132,3 +132,75 @@ def test_tiled_kernels_agree_with_the_round1_kernels_at_the_bench_size():
         assert abs(got[0] - ref[0]) < 1e-4 * max(1e-30, ref[0]), nm
         tol = 5e-5 * ref[3] + 1e-12
         assert abs(got[1] - ref[1]) < tol and abs(got[2] - ref[2]) < tol, (nm, got, ref)
+
+
+# ---- BASELINE configs[3]: 20 M entities / 100 relations, d = 128, "bf16 MFMA LSTM" -------------------------------------------------
+def _bf16_case(dims, H, L, pairs, P, Vr=100, seed=4, init=0.05):
+    dt, de, dr = dims
+    eng = _ffi.Engine(6, 700, Vr, dt, de, dr, H, L, compute_dtype=1)
+    ref = _ffi.Engine(6, 700, Vr, dt, de, dr, H, L, compute_dtype=0)
+    o64 = Oracle(make_cfg(Vt=6, Ve=700, Vr=Vr, dt=dt, de=de, dr=dr, H=H, L=L), np.float64)
+    theta = o64.init_params(seed, init).astype(np.float32).astype(np.float64)
+    eng.set_flat_params(theta.astype(np.float32))
+    ref.set_flat_params(theta.astype(np.float32))
+    idx, labels = synth.make_paths(pairs, P, 6, Ve=700, Vr=Vr, seed=seed + 1)
+    return eng, ref, o64, theta, idx, labels
+
+
+@pytest.mark.parametrize("dims,H,L,pairs,P", [((128, 128, 128), 384, 1, 150, 2), ((16, 32, 16), 64, 2, 101, 3), ((64, 64, 64), 192, 2, 129, 2)])
+def test_bf16_storage_pipeline_is_tolerance_gated_against_the_f64_oracle(dims, H, L, pairs, P):
+    """compute_dtype = 1 from 256 paths up: bf16 shadow tables / weights, bf16 activations and gate saves, v_mfma_f32_16x16x32_bf16 with
+    fp32 accumulation, fp32 cell state and master parameters (kprn_amd/csrc/lstm_bf16.hip).  bf16 has 8 mantissa bits: scores within
+    3e-2 of the largest, probabilities 2e-2 absolute, loss 3e-2, every gradient tensor within 6e-2 of its largest entry; and the
+    result must differ from the fp32 path by far more than fp32 rounding (the bf16 path really ran).  (303 / 258 paths: not multiples of 8.)"""
+    eng, ref, o64, theta, idx, labels = _bf16_case(dims, H, L, pairs, P)
+    b, br = eng.batch(idx, labels), ref.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    out32 = ref.forward(br, 1, want=("path_scores",))
+    ps, _, probs = o64.forward(theta, idx)
+    e16, e32 = rel_inf(out["path_scores"], ps), rel_inf(out32["path_scores"], ps)
+    assert e16 < 3e-2 and e16 > 20 * e32, (e16, e32)
+    np.testing.assert_allclose(out["probs"], probs[:, 0], atol=2e-2)
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 3e-2 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        r = rel_inf(g[off:off + n], og[off:off + n])
+        assert r < 6e-2, (nm, r)
+    # training: a few Adam steps stay close to the fp32 engine's (the master parameters are fp32; the shadows follow every update)
+    opt = _ffi.make_opt(method=1, lr=2e-3)
+    for _ in range(4):
+        l16 = eng.train_step(b, opt)
+        l32 = ref.train_step(br, opt)
+        assert abs(l16 - l32) < 3e-2 * max(1.0, abs(l32))
+    d = np.max(np.abs(eng.get_flat_params() - ref.get_flat_params()))
+    assert d < 5e-3, d   # 4 steps of lr 2e-3 move a parameter by <= 8e-3
+    # scores after training use the refreshed shadows (a stale shadow would score with the old parameters)
+    s16 = eng.forward(b, 1, want=("probs",))["probs"]
+    s32 = ref.forward(br, 1, want=("probs",))["probs"]
+    np.testing.assert_allclose(s16, s32, atol=2e-2)
+
+
+def test_ids_beyond_2_pow_24_gather_bit_exact():
+    """configs[3] has 20 M entities: ids above 2^24 are not exact in float32 -- they stay int32 from the file to the kernel (SURVEY 7
+    "Index dtype").  FeatureEmbedding output rows for such ids must be bit-identical to the table rows."""
+    Ve = 20_000_000
+    eng = _ffi.Engine(6, Ve, 100, 8, 8, 8, 24, 1)
+    table = eng.get_param("entity_emb")
+    ids = np.array([1, (1 << 24) - 1, 1 << 24, (1 << 24) + 1, (1 << 24) + 2, (1 << 24) + 3, 19_999_999, Ve], np.int32)
+    idx = np.empty((len(ids), 1, 2, 3), np.int32)
+    idx[..., 0] = 2
+    idx[:, 0, 0, 1] = ids
+    idx[:, 0, 1, 1] = ids[::-1]
+    idx[..., 2] = 5
+    x = eng.embed(idx)   # [N, T, D] = [type 8 | entity 8 | relation 8]
+    assert np.array_equal(x[:, 0, 8:16], table[ids - 1]) and np.array_equal(x[:, 1, 8:16], table[ids[::-1] - 1])
+    assert len({tuple(r) for r in table[ids - 1].round(7).tolist()}) == len(ids)   # distinct rows: a truncated id would alias
+    # and the scoring path reads the same rows
+    probs = eng.forward(eng.batch(idx), 1)["probs"]
+    idx2 = idx.copy()
+    idx2[3, 0, 0, 1] = 1 << 24          # the float32 image of 2^24 + 1
+    assert eng.forward(eng.batch(idx2), 1)["probs"][3] != probs[3]
+    eng.close()
