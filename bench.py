@@ -554,12 +554,24 @@ def main():
     extras = {}
     plain = world == 1 and not a.force_dp and not a.no_extra_regions
     if plain and a.batch_feed == "both":
-        # the SAME K steps with the streaming feed
-        for i in range(3):
+        # the same steps with the streaming feed (its own warm-up: the ring of slots fills, their staging is allocated; at least 60 steps,
+        # so that the pipeline's start-up transient does not decide the figure)
+        k_s = max(a.steps, 60)
+        for i in range(12):
             step_streaming(i)
         eng.sync()
-        el, n = timed_region(step_streaming, 3, a.steps)
-        extras["streaming"] = dict(region_line(el, n, a.steps), ratio_to_resident=round((n / el) / value, 4),
+        el, n = timed_region(step_streaming, 12, k_s)
+        if os.environ.get("KPRN_BENCH_STREAM_PROF"):   # (diagnosis: per-family times of a few streaming steps)
+            eng.profile_reset(); eng.set_option("profile_filter", ""); eng.profile(True)
+            timed_region(step_streaming, 12 + k_s, 12)
+            eng.profile(False)
+            print("[bench stream prof]", {k: round(v[0] / max(1, v[1]), 4) for k, v in eng.profile_get().items()}, file=sys.stderr)
+            eng.profile_reset(); eng.profile(True)
+            timed_region(step_resident(batches), 0, 12)
+            eng.profile(False)
+            print("[bench resident prof]", {k: round(v[0] / max(1, v[1]), 4) for k, v in eng.profile_get().items()}, file=sys.stderr)
+            eng.profile_reset()
+        extras["streaming"] = dict(region_line(el, n, k_s), ratio_to_resident=round((n / el) / value, 4),
                                    feed_build=a.feed_build, feed_ahead=a.feed_ahead,
                                    what="every step's batch arrives from page-locked host memory: id validation + identical-prefix plan + occurrence "
                                         "index derived per batch (host worker threads, or kernels on a side stream with --feed-build device) and "

@@ -54,7 +54,7 @@ struct TArgs {
   const float* bias2; const float* mask; int relu;   // EPI_RNN: h2h bias, MaskZero flags [M], ReLU / Tanh
 };
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }   // (as kernels_basic.hip: the generic path is the accurate one)
 
 // one operand tile [ROWS][32] (layout 0) or [32][ROWS] (layout 1), ROWS = 128 or 64: this thread's ROWS / 8 floats, fetched
 // as VW-float vectors (VW = 4: 16-byte rows everywhere; VW = 2: even leading dimensions, e.g. config.sh's H = 250)

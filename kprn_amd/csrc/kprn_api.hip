@@ -1145,7 +1145,14 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
     if (h->feed_threads <= 0) h->feed_threads = 4;
     h->feed_pool = hostfeed::make_pool(std::max(1, h->feed_workers));
     h->upload_pool = hostfeed::make_pool(1);
-    HIP_TRY(hipStreamCreateWithFlags(&h->upload_stream, hipStreamNonBlocking));
+    {
+      // a queue of its own: HIP multiplexes the streams of one priority onto a few hardware queues, and this stream spends its
+      // life waiting on events of the compute streams -- sharing a hardware queue with one of them stalls that stream's
+      // kernels behind the waits (measured: every kernel of the step 1.2-5x slower).  The high-priority class has its own queues.
+      int lo = 0, hi = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIP_TRY(hipStreamCreateWithPriority(&h->upload_stream, hipStreamNonBlocking, hi));
+    }
   }
   if (!b->ev_fork) {
     HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -1213,14 +1220,13 @@ int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx,
   API_BEGIN(h)
   KPRN_REQUIRE(slot, KPRN_E_ARG, "slot is NULL");
   check_batch_args(h, idx, B, P, T, F);
-  if (!h->feed_stream) {
-    // the feed's kernels are small and latency-bound; they get the CUs the persistent kernels leave idle in their tails.  High
-    // priority: when CUs free up, the feed's workgroups are placed before the next big kernel's (KPRN_FEED_PRIO=0: default priority)
-    static const char* prio_env = getenv("KPRN_FEED_PRIO");
+  if (!h->feed_build_host && !h->feed_stream) {
+    // device-built feed: its kernels are small and latency-bound; they get the CUs the persistent kernels leave idle in their
+    // tails.  (Created only when used: HIP multiplexes streams onto a few hardware queues, and a stream that waits on events --
+    // as the feed's do -- blocks whatever shares its queue.)
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    if (prio_env && atoi(prio_env) == 0) HIP_TRY(hipStreamCreateWithFlags(&h->feed_stream, hipStreamNonBlocking));
-    else HIP_TRY(hipStreamCreateWithPriority(&h->feed_stream, hipStreamNonBlocking, hi));
+    HIP_TRY(hipStreamCreateWithPriority(&h->feed_stream, hipStreamNonBlocking, hi));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_feed_fork, hipEventDisableTiming));
   }
   kprn_batch* b = *slot;
@@ -1244,7 +1250,7 @@ int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx,
     auto quiesce = [&] {
       if (h->score_stream) HIP_TRY(hipStreamSynchronize(h->score_stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
-      HIP_TRY(hipStreamSynchronize(h->feed_stream));
+      if (h->feed_stream) HIP_TRY(hipStreamSynchronize(h->feed_stream));
       if (h->upload_stream) HIP_TRY(hipStreamSynchronize(h->upload_stream));
     };
     batch_reserve(h, b, B, P, T, F, labels != nullptr, quiesce);
