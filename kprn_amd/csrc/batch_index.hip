@@ -180,9 +180,11 @@ namespace {
 template <int FRAG>
 __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ DX, const int32_t* __restrict__ key_sorted,
                                                      const int32_t* __restrict__ pos_sorted, int64_t nsteps, int64_t N, int T, int D, int dt, int de,
-                                                     int sentinel, float* __restrict__ gWe, int n_ent_blocks, SlabReduce red) {
-  if ((int)blockIdx.x >= n_ent_blocks) {  // (workgroup-uniform) the passenger job: weight-gradient slab reduce
+                                                     int sentinel, float* __restrict__ gWe, int n_ent_blocks, int n_red_blocks, SlabReduce red,
+                                                     SmallGrad sg) {
+  if ((int)blockIdx.x >= n_ent_blocks) {  // (workgroup-uniform) the passenger jobs: weight-gradient slab reduce, small-table gradients
     const int rb = blockIdx.x - n_ent_blocks;
+    if (rb >= n_red_blocks) { small_grad_block(sg, rb - n_red_blocks); return; }
     const int nbx = (red.n_elem + 255) / 256;
     slab_reduce_block(red, rb % nbx, (rb / nbx) % red.ny, rb / (nbx * red.ny));
     return;
@@ -209,9 +211,11 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
       const int p = __builtin_amdgcn_readlane(my_pos, i);
       const int n = p / T, t = p - n * T;
       int64_t off;
-      if (FRAG) {
+      if (FRAG == 1) {
         const int rr = n & 15;
         off = ((int64_t)(n >> 4) * T + t) * ((int64_t)waves_per_group * 256) + (rr >> 2) * 64 + (rr & 3) + coff;
+      } else if (FRAG == 2) {
+        off = (int64_t)p * de + ecol;   // compact entity slice: 4 de contiguous bytes per position
       } else {
         off = ((int64_t)t * N + n) * D + col;
       }
@@ -242,17 +246,21 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
 }  // namespace
 
 void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* key_sorted, const int32_t* pos_sorted, int64_t n_index, int64_t N,
-                 int T, int D, int dt, int de, int Ve, float* gWe, const SlabReduce* red) {
-  if (n_index <= 0 && !red) return;
+                 int T, int D, int dt, int de, int Ve, float* gWe, const SlabReduce* red, const SmallGrad* sg) {
+  if (n_index <= 0 && !red && !sg) return;
   const int64_t segs = (n_index + 63) / 64;
   const int n_ent = (int)((segs + 3) / 4);
   SlabReduce r;
   memset(&r, 0, sizeof(r));
-  int n_red = 0;
+  SmallGrad g;
+  memset(&g, 0, sizeof(g));
+  int n_red = 0, n_sg = 0;
   if (red) { r = *red; n_red = ((r.n_elem + 255) / 256) * r.ny * r.L; }
-  const dim3 grid((unsigned)(n_ent + n_red));
-  if (frag_order) hipLaunchKernelGGL(k_entity_grad<1>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, r);
-  else hipLaunchKernelGGL(k_entity_grad<0>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, r);
+  if (sg) { g = *sg; n_sg = g.nblocks; }
+  const dim3 grid((unsigned)(n_ent + n_red + n_sg));
+  if (frag_order == 1) hipLaunchKernelGGL(k_entity_grad<1>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g);
+  else if (frag_order == 2) hipLaunchKernelGGL(k_entity_grad<2>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g);
+  else hipLaunchKernelGGL(k_entity_grad<0>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g);
   HIP_TRY(hipGetLastError());
 }
 }  // namespace bidx

@@ -300,10 +300,84 @@ __device__ __forceinline__ void slab_reduce_block(const SlabReduce& a, int bx, i
   else if (i < 2 * nW) unsafeAtomicAdd(a.gWo[l] + (i - nW), v);
   else unsafeAtomicAdd(a.gbi[l] + (i - 2 * nW), v);
 }
-// entity-table gradient = gather-reduce of dx over the occurrence index (frag_order: fused backward's dx layout, else [T][N][D]);
-// red (nullable): slab reduce carried by the same launch
+// Third job the entity-gradient launch can carry: the type / relation table gradients of the fused path (nn.LookupTable backward for the
+// two tiny tables, FeatureEmbedding.lua:29,41-49) from the bottom layer's fragment-order dx blocks: grad_table[v][:] = sum over the
+// executed (path, step) positions with id == v of dx[:, slice].  One wave = one 16-column block of a slice; it walks (16-row block, t)
+// items with one 1 KiB load each and keeps one accumulator per table row (<= 16 rows) per lane; a few atomics per wave at the end.
+struct SmallGrad {
+  const float* DX; const int32_t* idx; const int32_t* tile_k;
+  int64_t N, n_mtiles; int T, F, nT, dt, de, dr, Vt, Vr;
+  float* gWt; float* gWr; int nblocks;   // workgroups of this job
+};
+__device__ __forceinline__ void small_grad_block(const SmallGrad& a, int bx) {
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int arow = lane & 15, ag = lane >> 4;
+  const int ncb_t = a.dt >> 4, ncb = ncb_t + (a.dr >> 4);
+  // the four waves of a workgroup share one column block (their accumulators are summed in LDS: a quarter of the atomics)
+  const int cb = bx % ncb, part = (bx / ncb) * 4 + wv, nparts = ((a.nblocks + ncb - 1) / ncb) * 4;
+  const bool is_type = cb < ncb_t;
+  const int wave_of_block = is_type ? cb : ((a.dt + a.de) >> 4) + (cb - ncb_t);   // 16-column block inside the D = 64 row
+  const int idcol = is_type ? (a.F - a.nT - 2) : (a.F - 1);
+  const int V = is_type ? a.Vt : a.Vr;
+  float acc[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  const int64_t items = a.n_mtiles * a.T;
+  // latency-bound (one 1 KiB block + 4 ids per item): the next item's loads are in flight while this one is accumulated
+  auto fetch = [&](int64_t it, f32x4_& x, int (&id)[4]) -> bool {
+    const int64_t mtile = it / a.T;
+    const int t = (int)(it - mtile * a.T);
+    const bool live = !(a.tile_k && t < a.tile_k[mtile >> 2]);   // (wave-uniform) the prefix backward owns the skipped positions
+    x = *(const f32x4_*)(a.DX + ((mtile * a.T + t) * 4 + wave_of_block) * 256 + lane * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t n = mtile * 16 + ag * 4 + r;
+      id[r] = (live && n < a.N) ? a.idx[(n * a.T + t) * a.F + idcol] - 1 : -1;
+    }
+    return live;
+  };
+  constexpr int DEPTH = 6;   // items in flight per wave
+  for (int64_t it0 = part; it0 < items; it0 += (int64_t)nparts * DEPTH) {
+    f32x4_ x[DEPTH];
+    int id[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int64_t it = it0 + (int64_t)d * nparts;
+      if (it < items) fetch(it, x[d], id[d]);
+      else { x[d] = f32x4_{0.f, 0.f, 0.f, 0.f}; id[d][0] = id[d][1] = id[d][2] = id[d][3] = -1; }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] += (id[d][r] == v) ? x[d][r] : 0.f;
+      }
+  }
+  __shared__ float sg_red[4][16][16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    float s = acc[v];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (ag == 0) sg_red[wv][v][arow] = s;
+  }
+  __syncthreads();
+  {
+    const int v = threadIdx.x >> 4, c = threadIdx.x & 15;   // 256 threads = 16 table rows x 16 columns
+    const float s = (sg_red[0][v][c] + sg_red[1][v][c]) + (sg_red[2][v][c] + sg_red[3][v][c]);
+    if (v < V && s != 0.f) {
+      if (is_type) unsafeAtomicAdd(a.gWt + (int64_t)v * a.dt + cb * 16 + c, s);
+      else unsafeAtomicAdd(a.gWr + (int64_t)v * a.dr + (cb - ncb_t) * 16 + c, s);
+    }
+  }
+}
+// entity-table gradient = gather-reduce of dx over the occurrence index.  frag_order 1: the fused backward's fragment-order dx;
+// 2: its compact entity slice [(n T + t)][de]; 0: time-major row-major [T][N][D] (generic pipeline).
+// red / sg (nullable): the slab reduce / the small-table gradients carried by the same launch
 void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* key_sorted, const int32_t* pos_sorted, int64_t n_index, int64_t N,
-                 int T, int D, int dt, int de, int Ve, float* gWe, const SlabReduce* red = nullptr);
+                 int T, int D, int dt, int de, int Ve, float* gWe, const SlabReduce* red = nullptr, const SmallGrad* sg = nullptr);
 size_t merge_scratch_bytes(int64_t n, int Ve);
 void merge_rows(hipStream_t s, const void* all, int world, int cap, int de, int Ve, float* G, int32_t* union_rows, int32_t* union_count,
                 void* scratch, size_t scratch_sz);

@@ -37,7 +37,9 @@ struct BwdArgs {
   const float* dS;         // [N] (tile slot order) top layer: d loss / d S[n][classId]; the head backward dh_T = dS[n] W_out[classId][:] is formed in-kernel
   const float* wout_row;   // W_out[classId][0..64)
   float* gWout_row; float* gbout_c;  // top layer: gradient of W_out[classId][:] and b_out[classId] (sum_n dS[n] h_T[n][:], sum_n dS[n])
-  float* DX;               // [(Npad/16)][T][4 waves][64 lanes][4] fragment order: in = dx of the layer above (not top), out = dx of this layer (not bottom)
+  float* DX;               // [(Npad/16)][T][4 waves][64 lanes][4] fragment order: in = dx of the layer above (not top), out = dx of this layer
+  float* DXe;              // bottom layer, nullable: the ENTITY slice of dx row-major [(n T + t)][de] -- what the entity-gradient gather reads
+                           // (128 contiguous bytes per position instead of 4 of every 16 bytes of a fragment-order block)
   int64_t Npad;            // N rounded up to the 64-row tile
   float* gWi; float* gbi; float* gWo;   // [256][64], [256], [256][64]
   float* gWt; float* gWe; float* gWr;   // bottom layer only
@@ -77,7 +79,7 @@ struct Pre {
   f32x4 bhp[4];  // B operands of dW_o2g: h^l_{t-1}, same layout
 };
 
-template <bool BOTTOM, bool TOP, bool SMALL>
+template <bool BOTTOM, bool TOP>
 __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -118,13 +120,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
 
   const int64_t frag_unit = (int64_t)NPL * 256;                // floats per (m-tile, t, layer, wave)
   const int64_t frag_mt_stride = (int64_t)T * L * 4 * frag_unit;  // floats per m-tile
-  // type / relation gradients (bottom layer, SMALL: one type slot, slice widths multiples of 16, tables <= 16 rows):
-  // nn.LookupTable backward as a matrix product, grad_table[v][:] += sum_rows onehot(id[row] == v) dx[row][:].  The
-  // dx accumulators already sit in the MFMA B layout (k-slot ag <-> row mt*16+4ag+r); the one-hot A operand comes
-  // from the LDS id tile; exact (products by 1.0 / 0.0).  acc_s[r] <-> table row 4ag + r, column 16j + arow, for
-  // the whole launch; two chains so that an MFMA never reads the result of the MFMA right before it.
-  const int wcls = (j * 16 < a.dt) ? 0 : ((j * 16 < a.dt + a.de) ? 1 : 2);  // this wave's 16 columns: type / entity / relation
-  f32x4 acc_s = f32x4{0.f, 0.f, 0.f, 0.f}, acc_s2 = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this wave's 16 dx columns belong to the type (0), entity (1) or relation (2) slice.  (The type / relation gradients were once
+  // formed here as a one-hot MFMA on the dx accumulators: 16 extra MFMAs + a drain per step on two of the four waves, 8
+  // launch-long VGPRs and the only register spills of the kernel; they are now a passenger job of the entity-gradient launch,
+  // lstm_fused_bwd.hip k_small_grad.)
+  const int wcls = (j * 16 < a.dt) ? 0 : ((j * 16 < a.dt + a.de) ? 1 : 2);
   GatherSrc gsrc;
   if (BOTTOM) gsrc = gather_src(a);
   const float wout_c = TOP ? a.wout_row[j * 16 + arow] : 0.f;
@@ -306,30 +306,22 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       KPRN_PIN_V4(ax);
       if (REC) KPRN_PIN_V4(ah);
       if (BOTTOM && REC) gather_store<256>(in_t, nin);
+      const bool compact = BOTTOM && a.DXe != nullptr && wcls == 1;   // (wave-uniform)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         if (REC) dh[mt] = ah[mt];  // already in the layout stage C of step t-1 reads
-        // dx in fragment order: the layer below (or, bottom layer, k_embed_scatter_frag) reloads it the same way,
+        // dx in fragment order: the layer below (or, bottom layer, the small-table gradient job) reloads it the same way,
         // 1 KiB per instruction; in place -- this thread read this very slot as `up` at the start of the step.
         // Rows past N: exact zeros (dA = 0 there).
-        *(f32x4*)(dx_tile + (mt * T + t) * 1024) = ax[mt];
+        if (!compact) *(f32x4*)(dx_tile + (mt * T + t) * 1024) = ax[mt];
       }
-      if constexpr (BOTTOM && SMALL) if (wcls != 1) {
-        const int which = (wcls == 0) ? 0 : 2;
+      if (compact) {
+        // entity columns of the bottom layer: row-major for the gather-reduce over the occurrence index (16 lanes = 64 contiguous bytes)
+        float* de_row = a.DXe + ((n0 + ag * 4) * T + k0 + t) * (int64_t)a.de + (j * 16 + arow - a.dt);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = mt * 16 + ag * 4 + r;
-            // branch-free on purpose: no EXEC games in front of an asm MFMA
-            const int iv = idk[(row * T + t) * 4 + which];
-            const float oh = (((int)(iv == arow)) & ((int)(n0 + row < a.N))) ? 1.f : 0.f;
-            if (r & 1) KPRN_MFMA_VV(acc_s2, oh, ax[mt][r]); else KPRN_MFMA_VV(acc_s, oh, ax[mt][r]);
-          }
-        // acc_s lives across the rest of the launch: if hipcc parks it (spill store / register copy) right behind the
-        // last MFMA it reads a result that has not landed (seen as intermittently wrong type / relation gradients)
-        KPRN_MFMA_DRAIN();
-        KPRN_PIN_V2(acc_s, acc_s2);
+          for (int r = 0; r < 4; ++r) de_row[(int64_t)(mt * 16 + r) * T * a.de] = ax[mt][r];
       }
       TPROBE(4)  // stage E (dX MFMAs) + outputs
       lds_barrier();  // dA_t free for reuse, x_{t-1} tile visible
@@ -361,7 +353,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   KPRN_MFMA_DRAIN();
 #pragma unroll
   for (int q = 0; q < 4; ++q) KPRN_PIN_A8(dwi[q], dwo[q]);
-  if constexpr (BOTTOM && SMALL) KPRN_PIN_V2(acc_s, acc_s2);
   {
     float* pw = a.part + (int64_t)blockIdx.x * PART;
 #pragma unroll
@@ -379,16 +370,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       if (ag == 0) pw[2 * 256 * 64 + q * DH + j * 16 + arow] = v;
-    }
-  }
-  if constexpr (BOTTOM && SMALL) if (wcls != 1) {
-    acc_s += acc_s2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int v = ag * 4 + r;
-      const int col = j * 16 + arow;
-      if (wcls == 0) { if (v < a.Vt) unsafeAtomicAdd(a.gWt + (int64_t)v * a.dt + col, acc_s[r]); }
-      else { if (v < a.Vr) unsafeAtomicAdd(a.gWr + (int64_t)v * a.dr + (col - a.dt - a.de), acc_s[r]); }
     }
   }
   if (TOP) {
@@ -575,13 +556,13 @@ bool transpose_job(kprn_handle* h, kk::TransposeJob* tj) {
 
 bool bwd_supported(const kprn_handle* h, int T) { return fwd_supported(h, T); }
 
-template <bool BOTTOM, bool TOP, bool SMALL>
+template <bool BOTTOM, bool TOP>
 static void launch_bwd(kprn_handle* h, const BwdArgs& a, int grid) {
   size_t lds_bytes = (size_t)MT * LDD * sizeof(float);
   if (BOTTOM) lds_bytes += (size_t)MT * LDA * sizeof(float) + (MT * MAXT_LDS * 4) * sizeof(int32_t);
   lds_bytes += (size_t)(KCAP + 1) * PFB * sizeof(float);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP, SMALL>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());
 }
 
@@ -598,6 +579,8 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     const int64_t cn = std::max<int64_t>(N, s->cap_Nb);
     const int ct = std::max(T, s->cap_Tb);
     HIP_TRY(hipMalloc((void**)&s->DX, (size_t)ct * (cn + 2 * MT) * DH * sizeof(float)));
+    if (s->DXe) hipFree(s->DXe);
+    HIP_TRY(hipMalloc((void**)&s->DXe, (size_t)(ct * (cn + 2 * MT) + KCAP) * c.de * sizeof(float)));
     s->cap_Nb = cn; s->cap_Tb = ct;
   }
   if (!s->part) HIP_TRY(hipMalloc((void**)&s->part, (size_t)2 * s->num_cu * PART * sizeof(float)));  // one slab set per layer
@@ -634,17 +617,20 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     a.part = s->part + (size_t)l * s->num_cu * PART; a.timing = s->timing;
     { static const char* d = getenv("KPRN_DBG"); a.dbg = d ? atoi(d) : 0; }
     const bool bottom = (l == 0), top = (l == L - 1);
-    // small tables inside the bottom kernel (one-hot MFMA) when the shapes allow, else the general scatter kernel
-    const bool small_in_kernel = c.num_types == 1 && (c.dt % 16) == 0 && (c.de % 16) == 0 && (c.dr % 16) == 0 && c.Vt <= 16 && c.Vr <= 16 &&
-                                 !(a.dbg & 8);
+    // type / relation gradients: a passenger job of the entity-gradient launch when the shapes allow (one type slot, slices in
+    // 16-column blocks, tables of at most 16 rows), else the general scatter kernel
+    const bool small_job = c.num_types == 1 && (c.dt % 16) == 0 && (c.de % 16) == 0 && (c.dr % 16) == 0 && c.Vt <= 16 && c.Vr <= 16 && !(a.dbg & 8);
     const bool have_index = b->key_sorted != nullptr && !(a.dbg & 16);
+    // with the index, the entity columns of the bottom layer's dx leave the kernel row-major for the gather-reduce
+    s->DXe_on = have_index && !(a.dbg & 1);
+    a.DXe = (bottom && s->DXe_on) ? s->DXe : nullptr;
     {
       // one event pair around the L back-to-back launches of the family (an event pair costs ~4 us of stream time)
       if (top) { bwd_scope.reset(new ProfScope(h, "lstm_fused_bwd")); bwd_scope->launches = L; }
-      if (bottom && top) { if (small_in_kernel) launch_bwd<true, true, true>(h, a, grid); else launch_bwd<true, true, false>(h, a, grid); }
-      else if (bottom) { if (small_in_kernel) launch_bwd<true, false, true>(h, a, grid); else launch_bwd<true, false, false>(h, a, grid); }
-      else if (top) launch_bwd<false, true, false>(h, a, grid);
-      else launch_bwd<false, false, false>(h, a, grid);
+      if (bottom && top) launch_bwd<true, true>(h, a, grid);
+      else if (bottom) launch_bwd<true, false>(h, a, grid);
+      else if (top) launch_bwd<false, true>(h, a, grid);
+      else launch_bwd<false, false>(h, a, grid);
       if (bottom || s->timing) bwd_scope.reset();
     }
     if (bottom) have_r1 = prefix_backward(h, b, n_tiles);  // the skipped steps of every layer; leaves their dx sums in DX's virtual tile
@@ -658,11 +644,16 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       ra.r1 = s->r1; ra.kmax = have_r1 ? b->h_kmax : 0; ra.kcap = KCAP; ra.r1_stride = R1; ra.G = 4; ra.H = DH;
     }
     if (bottom && have_index && !(a.dbg & 1)) {
-      // the weight-gradient slab reduce rides along: two independent, latency-bound jobs in one launch
+      // the weight-gradient slab reduce and the small-table gradients ride along: independent, latency-bound jobs in one launch
       ProfScope ps(h, "entity_grad+dw_reduce");
-      bidx::entity_grad(strm, s->DX, /*frag_order=*/1, b->key_sorted, b->pos_sorted, b->n_index, N, T, DH, c.dt, c.de, c.Ve, a.gWe, &ra);
+      bidx::SmallGrad sg;
+      sg.DX = s->DX; sg.idx = b->idx_s ? b->idx_s : b->idx; sg.tile_k = b->tile_k; sg.N = N; sg.n_mtiles = n_tiles * 4; sg.T = T; sg.F = b->F;
+      sg.nT = c.num_types; sg.dt = c.dt; sg.de = c.de; sg.dr = c.dr; sg.Vt = c.Vt; sg.Vr = c.Vr; sg.gWt = a.gWt; sg.gWr = a.gWr; sg.nblocks = 4 * s->num_cu;
+      bidx::entity_grad(strm, s->DXe, /*compact entity slice=*/2, b->key_sorted, b->pos_sorted, b->n_index, N, T, DH, c.dt, c.de, c.Ve, a.gWe, &ra,
+                        small_job ? &sg : nullptr);
       reduced = true;
     }
+    const bool small_in_kernel = small_job && have_index;   // (handled above)
     if (bottom && !(a.dbg & 1) && (!small_in_kernel || !have_index)) {
       ProfScope ps(h, "embed_scatter");
       ScatArgs sa;
@@ -714,7 +705,7 @@ void params_changed(kprn_handle* h) {
 void release(kprn_handle* h) {
   State* s = (State*)h->fused_state;
   if (!s) return;
-  for (float* p : {s->save_frag, s->WT, s->DX, s->part, s->part_small, s->pfb, s->pfs, s->pfx, s->PG, s->r1, s->mc_bias, s->mc_hseq[0], s->mc_hseq[1]}) if (p) hipFree(p);
+  for (float* p : {s->save_frag, s->WT, s->DX, s->DXe, s->part, s->part_small, s->pfb, s->pfs, s->pfx, s->PG, s->r1, s->mc_bias, s->mc_hseq[0], s->mc_hseq[1]}) if (p) hipFree(p);
   if (s->mc_wsp) hipFree(s->mc_wsp);
   if (s->timing) hipFree(s->timing);
   delete s;

@@ -181,6 +181,8 @@ struct State {
   float* WT = nullptr;      // [L][2][64][256]
   bool wt_dirty = true;
   float* DX = nullptr;      // [T][N][64]
+  float* DXe = nullptr;     // compact entity slice of the bottom layer's dx: [(Npad T + KCAP)][de]
+  bool DXe_on = false;      // the backward in progress writes / reads it
   // identical-prefix state (lstm_fused_prefix.hip)
   float* pfb = nullptr;     // [KCAP+1][L][PFB] W_o2g h_prefix | c_prefix per prefix class
   float* pfs = nullptr;     // [KCAP][L][NPL][64] backward factors + h of the prefix steps

@@ -159,6 +159,7 @@ struct PrefBwdArgs {
   float* r1;  // [L][KCAP][R1]: per prefix step the vectors of its rank-1 weight-gradient terms (added by k_reduce_partials)
   float *gWt, *gWe, *gWr;
   float* DXv;         // row 0 of the virtual tile of DX (fragment order): [t][4 waves][256]
+  float* DXe_v;       // nullable: rows of the compact entity dx at the virtual positions (Npad T + t): [t][de]
   int entity_direct;  // no batch index in use: add the entity slice to gWe here
 };
 
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) void k_prefix_bwd(PrefBwdArgs a) {
         } else {
           // the reference step's rows of the three tables: every skipped occurrence of prefix step t, summed
           a.DXv[((int64_t)t * 4 + (r >> 4)) * 256 + (r & 15) * 4] = dx;
+          if (a.DXe_v && r >= a.dt && r < a.dt + a.de) a.DXe_v[(int64_t)t * a.de + (r - a.dt)] = dx;
           if (r < a.dt) {
             for (int q = 0; q < a.nT; ++q) unsafeAtomicAdd(a.gWt + (int64_t)(ids[a.F - a.nT - 2 + q] - 1) * a.dt + r, dx);
           } else if (r < a.dt + a.de) {
@@ -301,6 +303,7 @@ bool prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles) {
   a.pfs = s->pfs; a.pfx = s->pfx; a.PG = s->PG; a.r1 = s->r1;
   a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
   a.DXv = s->DX + (size_t)n_tiles * 4 * b->T * 4 * 256;
+  a.DXe_v = s->DXe_on ? s->DXe + (size_t)n_tiles * MT * b->T * c.de : nullptr;
   static const char* d = getenv("KPRN_DBG");
   a.entity_direct = (d && (atoi(d) & 16)) ? 1 : 0;
   ProfScope ps(h, "prefix_bwd");

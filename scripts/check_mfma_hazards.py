@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """Static check of the hand-placed (inline-asm) MFMAs: hipcc's hazard recogniser cannot see inside an asm statement, so
 nothing inserts the wait states gfx950 needs between a VALU write of a VGPR and an MFMA that reads it as SrcA / SrcB / SrcC
-(2 wait states), or between an MFMA result and a non-MFMA reader.  This script compiles the kernels to ISA and reports every
-v_mfma whose source registers are written by a VALU instruction in the 2 issue slots in front of it (s_nop N counts N+1).
+(2 wait states), or between an MFMA result and a non-MFMA reader.  This script compiles the kernels to ISA and reports
+  (a) every v_mfma whose source registers are written by a VALU instruction in the 2 issue slots in front of it (s_nop N counts N+1);
+  (b) every non-MFMA instruction (VALU, v_accvgpr_read, LDS / global / scratch store) that reads a register an MFMA wrote fewer
+      than 10 issue cycles earlier (another MFMA in between counts 8 -- it occupies the pipe for at least that --, s_nop N counts
+      N + 1, anything else 1; 10 is what hipcc's own hazard recogniser leaves behind its builtin f32 16x16x4 MFMAs).  This is the class that produced
+      wrong scores in round 1 (a VALU read hoisted above an operand-less drain); the drains are now followed by pins, and this
+      check looks at what the compiler finally emitted.  Loop bodies are covered by scanning every kernel twice back to back.
+tests/test_hazards.py runs both on the CPU (hipcc -S needs no GPU).
 
 usage: scripts/check_mfma_hazards.py [file.hip ...]      (default: every fused kernel file)
 """
@@ -23,12 +29,42 @@ def regs(tok):
     return None
 
 
+_ISA = {}
+
+
+def compile_isa(path):
+    """gfx950 ISA text of one .hip file (hipcc -S --cuda-device-only; cached per process)"""
+    if path not in _ISA:
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"),
+                                   "-S", "--cuda-device-only", "-o", out, path])
+            _ISA[path] = open(out).read()
+    return _ISA[path]
+
+
+def kernel_resources(text):
+    """{kernel symbol: {vgpr_count, vgpr_spill_count, sgpr_spill_count, private_segment_fixed_size}} from the .amdhsa metadata"""
+    out = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\s*\n(.*?)(?=\n\s+- \.|\namdhsa\.target|\Z)", text, re.S):
+        blk = m.group(0)
+        rec = {}
+        for key in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size"):
+            mm = re.search(r"\.%s:\s+(\d+)" % key, blk)
+            if mm:
+                rec[key] = int(mm.group(1))
+        if "vgpr_count" in rec:
+            out[m.group(1)] = rec
+    return out
+
+
 def check(path):
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"),
-                               "-S", "--cuda-device-only", "-o", out, path])
-        text = open(out).read()
+    text = compile_isa(path)
+    return check_text(text, os.path.basename(path))
+
+
+def check_text(text, fname):
+    path = fname
     bad = 0
     total = 0
     for km in re.finditer(r"\n(_Z\w+):[^\n]*\n(.*?)s_endpgm", text, re.S):
@@ -63,6 +99,76 @@ def check(path):
                 need -= 1
                 jx -= 1
     print(f"{os.path.basename(path)}: {total} MFMAs checked, {bad} unprotected VALU -> MFMA operand hazards")
+    bad_b = check_results(text, os.path.basename(path))
+    return bad + bad_b
+
+
+STORE_PREFIXES = ("global_store", "ds_write", "ds_add", "scratch_store", "buffer_store", "flat_store", "global_atomic", "flat_atomic", "ds_bpermute", "ds_permute")
+NEED = 10   # what hipcc itself leaves between its own (builtin) f32 16x16x4 MFMAs and the first read of their result
+
+
+def check_results(text, fname):
+    """(b): MFMA result -> non-MFMA reader closer than NEED issue cycles"""
+    bad = 0
+    checked = 0
+    for km in re.finditer(r"\n(_Z\w+):[^\n]*\n(.*?)s_endpgm", text, re.S):
+        name, body = km.group(1), km.group(2)
+        ins = []
+        for l in body.split("\n"):
+            l = l.split(";")[0].strip()
+            if l and not l.startswith(".") and not l.endswith(":"):
+                ins.append(l)
+        if not any(l.startswith("v_mfma") for l in ins):
+            continue
+        seq = ins + ins   # a second pass sees what the first iteration's tail does to the next iteration's head
+        pending = {}      # (file, reg) -> cycles since the MFMA that wrote it issued
+        seen = set()      # positions already reported (the second pass repeats the first pass's findings)
+        for pos_, l in enumerate(seq):
+            parts = l.split(None, 1)
+            op = parts[0]
+            ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+            if op.startswith("v_mfma"):
+                for k in list(pending):
+                    pending[k] += 8
+                    if pending[k] >= NEED:
+                        del pending[k]
+                d = regs(ops[0]) if ops else None
+                if d:
+                    for r in d[1]:
+                        pending[(d[0], r)] = 0
+                continue
+            if op.startswith("s_nop"):
+                step = int(ops[0]) + 1
+            else:
+                step = 1
+                if pending and (op.startswith("v_") or op.startswith(STORE_PREFIXES)):
+                    srcs = ops if op.startswith(STORE_PREFIXES) else ops[1:]
+                    if op.startswith(("v_fmac", "v_mac", "v_pk_fmac", "v_dot2c")):
+                        srcs = ops
+                    for o in srcs:
+                        rg = regs(o.split(" ")[0])
+                        if not rg:
+                            continue
+                        hit = [r for r in rg[1] if (rg[0], r) in pending]
+                        if hit:
+                            checked += 1
+                            if pos_ % len(ins) not in seen:
+                                seen.add(pos_ % len(ins))
+                                bad += 1
+                                print(f"{fname} {name[:48]}: '{l}' reads {rg[0]}{hit[0]} {pending[(rg[0], hit[0])]} cycle(s) after the MFMA that writes it")
+                            for r in hit:
+                                pending.pop((rg[0], r), None)
+                # a non-MFMA WRITE of the register ends the window too
+                if ops:
+                    d = regs(ops[0].split(" ")[0])
+                    if d and not op.startswith(STORE_PREFIXES):
+                        for r in d[1]:
+                            pending.pop((d[0], r), None)
+            for k in list(pending):
+                pending[k] += step
+                if pending[k] >= NEED:
+                    del pending[k]
+    print(f"{fname}: {bad} MFMA result -> non-MFMA reader hazards")
     return bad
 
 

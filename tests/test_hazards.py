@@ -1,0 +1,77 @@
+"""CPU: static checks of the hand-scheduled kernels' ISA (hipcc -S needs no GPU).
+
+The fused kernels issue their MFMAs as inline asm, which hipcc's hazard recogniser cannot see into; round 1 shipped a fix for wrong
+scores caused by exactly that (a VALU read scheduled above an operand-less drain).  scripts/check_mfma_hazards.py looks at the
+instructions the compiler finally emitted: (a) VALU write -> MFMA operand, (b) MFMA result -> non-MFMA reader.  Register spills of
+the persistent kernels are pinned here too: none in the forward / top-layer kernels, and in the bottom-layer backward only the
+per-tile address registers parked in the prologue -- nothing is spilled inside the step loop."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import check_mfma_hazards as chk  # noqa: E402
+
+CSRC = os.path.join(ROOT, "kprn_amd", "csrc")
+
+
+def _kernel(body):
+    return "\n_Zfake:\n" + body + "\n\ts_endpgm\n"
+
+
+def test_checker_sees_a_valu_result_fed_to_an_mfma_too_early():
+    bad = _kernel("\tv_add_f32_e32 v5, v1, v2\n\tv_mfma_f32_16x16x4_f32 v[8:11], v5, a4, v[8:11]")
+    ok = _kernel("\tv_add_f32_e32 v5, v1, v2\n\ts_nop 1\n\tv_mfma_f32_16x16x4_f32 v[8:11], v5, a4, v[8:11]")
+    assert chk.check_text(bad, "fake") == 1
+    assert chk.check_text(ok, "fake") == 0
+
+
+def test_checker_sees_an_mfma_result_read_before_it_has_landed():
+    """the round-1 bug class: the drain (s_nop) is BELOW the read"""
+    hoisted = _kernel("\tv_mfma_f32_16x16x4_f32 v[8:11], v5, a4, v[8:11]\n\tv_mul_f32_e32 v20, v8, v8\n\ts_nop 15\n\ts_nop 15")
+    drained = _kernel("\tv_mfma_f32_16x16x4_f32 v[8:11], v5, a4, v[8:11]\n\ts_nop 15\n\ts_nop 15\n\tv_mul_f32_e32 v20, v8, v8")
+    stored = _kernel("\tv_mfma_f32_16x16x4_f32 a[0:3], v5, v6, a[0:3]\n\ts_nop 3\n\tglobal_store_dwordx4 v[2:3], a[0:3], off")
+    behind_two_mfmas = _kernel("\tv_mfma_f32_16x16x4_f32 v[8:11], v5, a4, v[8:11]\n\tv_mfma_f32_16x16x4_f32 v[12:15], v5, a5, v[12:15]\n"
+                               "\tv_mfma_f32_16x16x4_f32 v[16:19], v5, a6, v[16:19]\n\tv_mul_f32_e32 v20, v8, v8")
+    assert chk.check_results(hoisted, "fake") == 1
+    assert chk.check_results(drained, "fake") == 0
+    assert chk.check_results(stored, "fake") == 1
+    assert chk.check_results(behind_two_mfmas, "fake") == 0
+    # loop back-edge: the read sits at the top of the body, the MFMA at its bottom
+    loop = _kernel("\tv_mul_f32_e32 v20, v8, v8\n\tv_mfma_f32_16x16x4_f32 v[8:11], v5, a4, v[8:11]")
+    assert chk.check_results(loop, "fake") == 1
+
+
+@pytest.mark.parametrize("fname", chk.DEFAULT)
+def test_fused_kernels_have_no_unprotected_mfma_hazards(fname):
+    assert chk.check(os.path.join(CSRC, fname)) == 0
+
+
+def test_register_spills_of_the_persistent_kernels():
+    res = {}
+    for f in ("lstm_fused_fwd.hip", "lstm_fused_bwd.hip", "lstm_fused_fwd_mc.hip"):
+        res.update(chk.kernel_resources(chk.compile_isa(os.path.join(CSRC, f))))
+    fused = {k: v for k, v in res.items() if re.search(r"k_lstm_(fwd|bwd|fwd_mc)I", k)}
+    assert len(fused) >= 12
+    for k, v in fused.items():
+        assert v["vgpr_count"] <= 512
+        bottom_bwd = "k_lstm_bwdILb1E" in k
+        if not bottom_bwd:
+            assert v["vgpr_spill_count"] <= 8, (k, v)    # forward, matrix-core forward, top / middle backward: none (training forward: 2)
+        else:
+            assert v["vgpr_spill_count"] <= 64, (k, v)   # bottom-layer backward (gather + three output layouts): 20 (L = 2) / 59 (L = 1)
+    # ... and what the bottom-layer backward spills is parked in the prologue, before its first MFMA: nothing is written to
+    # scratch between the MFMAs (a reload per TILE remains: 6 address pairs, not per step)
+    text = chk.compile_isa(os.path.join(CSRC, "lstm_fused_bwd.hip"))
+    for km in re.finditer(r"\n(_ZN5fused10k_lstm_bwdILb1E\w+):[^\n]*\n(.*?)s_endpgm", text, re.S):
+        ins = [l.split(";")[0].strip() for l in km.group(2).split("\n")]
+        ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
+        first = next(i for i, l in enumerate(ins) if l.startswith("v_mfma"))
+        last = max(i for i, l in enumerate(ins) if l.startswith("v_mfma"))
+        stores_inside = [l for l in ins[first:last] if l.startswith("scratch_store")]
+        loads_inside = [l for l in ins[first:last] if l.startswith("scratch_load")]
+        assert not stores_inside, (km.group(1), stores_inside[:3])
+        assert len(loads_inside) <= (16 if "ILb1ELb0E" in km.group(1) else 32), (km.group(1), len(loads_inside))   # (L = 2 bottom | L = 1)
