@@ -8,6 +8,10 @@
 #include <string.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include <algorithm>
 
 #include "kprn_internal.h"
 
@@ -272,105 +276,76 @@ void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* 
 // the same bits on every rank: a row has at most `world` occurrences, so a run touches at most two 64-entry
 // segments and the two partial sums commute.
 namespace bidx {
+// ---- union by marking (the exchange's merge since round 2) -------------------------------------------------------------------
+// Every rank's id list has each row at most once, so neither the union nor the sum needs a sort: rank by rank (W small launches in
+// stream order = RANK ORDER, the same addition order on every replica, no atomics: inside one rank's buffer every row is unique)
+// the rows are added into the gradient accumulator and flagged in a persistent [Ve] array; one rocprim::select over a counting
+// iterator compacts the flagged ids into the sorted union; the touched flags are reset (the array is clean between steps).
+// Replaces a stable radix sort of (row, source) pairs + run-length encode + gather-reduce (0.24 ms at 8 x 71 k rows).
 namespace {
-__global__ void k_merge_keys(const int32_t* __restrict__ all, int world, int cap, int64_t stride, int sentinel, int32_t* __restrict__ keys,
-                             int32_t* __restrict__ vals) {
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+// G[row][:] += rows[k][:] for the k < count rows of ONE rank's packed buffer; mark[row] = 1
+__global__ void k_add_rank(const int32_t* __restrict__ buf, int cap, int de, float* __restrict__ G, int32_t* __restrict__ mark) {
+  const int count = buf[0];
+  const int per = de >> 2;
+  const float* rows = (const float*)(buf + 4 + cap);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)count * per; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i / per), c = (int)(i - (int64_t)k * per) * 4;
+    const int row = buf[4 + k];
+    f32x4m* dst = (f32x4m*)(G + (int64_t)row * de + c);
+    *dst = *dst + *(const f32x4m*)(rows + (int64_t)k * de + c);
+    if (c == 0) mark[row] = 1;
+  }
+}
+__global__ void k_add_rank_scalar(const int32_t* __restrict__ buf, int cap, int de, float* __restrict__ G, int32_t* __restrict__ mark) {
+  const int count = buf[0];
+  const float* rows = (const float*)(buf + 4 + cap);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)count * de; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i / de), c = (int)(i - (int64_t)k * de);
+    const int row = buf[4 + k];
+    G[(int64_t)row * de + c] += rows[(int64_t)k * de + c];
+    if (c == 0) mark[row] = 1;
+  }
+}
+__global__ void k_unmark(const int32_t* __restrict__ all, int world, int cap, int64_t stride, int32_t* __restrict__ mark) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)world * cap) return;
   const int r = (int)(i / cap), k = (int)(i - (int64_t)r * cap);
   const int32_t* buf = all + (int64_t)r * stride;
-  keys[i] = (k < buf[0]) ? buf[4 + k] : sentinel;
-  vals[i] = (int32_t)i;
-}
-
-// drop the sentinel run from the union
-__global__ void k_merge_count(const int32_t* __restrict__ uniq, const int32_t* __restrict__ runs, int sentinel, int32_t* __restrict__ count_out) {
-  const int n = *runs;
-  *count_out = (n > 0 && uniq[n - 1] == sentinel) ? n - 1 : n;
-}
-
-__global__ __launch_bounds__(256) void k_merge_reduce(const int32_t* __restrict__ key_sorted, const int32_t* __restrict__ val_sorted, int64_t n,
-                                                      const float* __restrict__ all, int cap, int64_t stride, int de, int sentinel,
-                                                      float* __restrict__ G) {
-  const int lane = threadIdx.x & 63;
-  const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t base = seg * 64;
-  if (base >= n) return;
-  const int cnt = (int)((n - base < 64) ? (n - base) : 64);
-  const int my_key = (lane < cnt) ? key_sorted[base + lane] : sentinel;
-  const int my_val = (lane < cnt) ? val_sorted[base + lane] : 0;
-  const int key_before = (base > 0) ? key_sorted[base - 1] : -1;
-  const int key_after = (base + cnt < n) ? key_sorted[base + cnt] : -1;
-  for (int c0 = 0; c0 < de; c0 += 64) {
-    const int col = c0 + lane;
-    const bool act = col < de;
-    float acc = 0.f;
-    bool opened_here = __builtin_amdgcn_readlane(my_key, 0) != key_before;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) {
-      if (i >= cnt) break;
-      const int k = __shfl(my_key, i, 64);
-      const int v = __shfl(my_val, i, 64);
-      if (k != sentinel) {
-        const int r = v / cap, slot = v - r * cap;
-        if (act) acc += all[(int64_t)r * stride + 4 + cap + (int64_t)slot * de + col];
-      }
-      const bool more = (i + 1 < cnt);
-      const int knext = more ? __shfl(my_key, (i + 1) & 63, 64) : key_after;
-      if (!more || knext != k) {
-        if (k != sentinel && act) {
-          float* dst = G + (int64_t)k * de + col;
-          if (opened_here && knext != k) *dst = acc; else unsafeAtomicAdd(dst, acc);
-        }
-        acc = 0.f;
-        opened_here = true;
-      }
-    }
-  }
+  if (k < buf[0]) mark[buf[4 + k]] = 0;
 }
 }  // namespace
 
 size_t merge_scratch_bytes(int64_t n, int Ve) {
-  size_t t1 = 0, t2 = 0;
+  size_t t1 = 0;
   int32_t* p = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, t1, p, p, p, p, (size_t)n, 0, bits_for((int64_t)Ve + 1), (hipStream_t)0);
-  (void)rocprim::run_length_encode(nullptr, t2, p, (size_t)n, p, p, p, (hipStream_t)0);
-  const size_t tmp = (t1 > t2 ? t1 : t2);
-  return (size_t)n * 5 * sizeof(int32_t) + ((tmp + 255) & ~(size_t)255) + 1024;
+  (void)rocprim::select(nullptr, t1, rocprim::counting_iterator<int32_t>(0), p, p, p, (size_t)Ve, (hipStream_t)0);
+  return ((t1 + 255) & ~(size_t)255) + 1024;
 }
 
-// all: [world][stride] 32-bit words, each rank's buffer = {count, -, -, -, ids[cap], rows[cap*de] (fp32)}.
-// Out: G rows of the union = sum over ranks (rank order); union_rows (sorted) and *union_count.
+// all: [world][stride] 32-bit words, each rank's buffer = {count, -, -, -, ids[cap] (each row once), rows[cap*de] (fp32)}.
+// mark: persistent int32 [Ve], all zero on entry and on exit.
+// Out: G rows of the union += sum over ranks (rank order); union_rows (sorted) and *union_count.
 void merge_rows(hipStream_t s, const void* all, int world, int cap, int de, int Ve, float* G, int32_t* union_rows, int32_t* union_count,
-                void* scratch, size_t scratch_sz) {
+                int32_t* mark, void* scratch, size_t scratch_sz) {
   const int64_t n = (int64_t)world * cap;
   if (n <= 0) return;
   const int64_t stride = 4 + (int64_t)cap * (1 + de);
-  int32_t* keys = (int32_t*)scratch;
-  int32_t* vals = keys + n;
-  int32_t* key_sorted = vals + n;
-  int32_t* val_sorted = key_sorted + n;
-  int32_t* counts = val_sorted + n;
-  char* tmp = (char*)(counts + n);
-  tmp = (char*)(((uintptr_t)tmp + 255) & ~(uintptr_t)255);
-  int32_t* runs = (int32_t*)tmp;  // first 256 bytes of the temp area: the run count
-  tmp += 256;
-  size_t tmp_bytes = scratch_sz - (size_t)(tmp - (char*)scratch);
-  const int sentinel = Ve;
-  hipLaunchKernelGGL(k_merge_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int32_t*)all, world, cap, stride, sentinel, keys, vals);
-  HIP_TRY(hipGetLastError());
+  for (int r = 0; r < world; ++r) {   // stream order = rank order
+    const int32_t* buf = (const int32_t*)all + (int64_t)r * stride;
+    if ((de & 3) == 0) {
+      const int64_t work = (int64_t)cap * (de >> 2);
+      hipLaunchKernelGGL(k_add_rank, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 16384)), dim3(256), 0, s, buf, cap, de, G, mark);
+    } else {
+      const int64_t work = (int64_t)cap * de;
+      hipLaunchKernelGGL(k_add_rank_scalar, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 16384)), dim3(256), 0, s, buf, cap, de, G, mark);
+    }
+  }
   size_t need = 0;
-  const int bits = bits_for((int64_t)Ve + 1);
-  HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, key_sorted, vals, val_sorted, (size_t)n, 0, bits, s));
-  KPRN_REQUIRE(need <= tmp_bytes, KPRN_E_DEVICE, "merge scratch too small (sort)");
-  HIP_TRY(rocprim::radix_sort_pairs(tmp, need, keys, key_sorted, vals, val_sorted, (size_t)n, 0, bits, s));
-  HIP_TRY(rocprim::run_length_encode(nullptr, need, key_sorted, (size_t)n, union_rows, counts, runs, s));
-  KPRN_REQUIRE(need <= tmp_bytes, KPRN_E_DEVICE, "merge scratch too small (rle)");
-  HIP_TRY(rocprim::run_length_encode(tmp, need, key_sorted, (size_t)n, union_rows, counts, runs, s));
-  hipLaunchKernelGGL(k_merge_count, dim3(1), dim3(1), 0, s, union_rows, runs, sentinel, union_count);
-  const int64_t segs = (n + 63) / 64;
-  hipLaunchKernelGGL(k_merge_reduce, dim3((unsigned)((segs + 3) / 4)), dim3(256), 0, s, key_sorted, val_sorted, n, (const float*)all, cap, stride, de,
-                     sentinel, G);
+  HIP_TRY(rocprim::select(nullptr, need, rocprim::counting_iterator<int32_t>(0), mark, union_rows, union_count, (size_t)Ve, s));
+  KPRN_REQUIRE(need <= scratch_sz, KPRN_E_DEVICE, "merge scratch too small (select)");
+  HIP_TRY(rocprim::select(scratch, need, rocprim::counting_iterator<int32_t>(0), mark, union_rows, union_count, (size_t)Ve, s));
+  hipLaunchKernelGGL(k_unmark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int32_t*)all, world, cap, stride, mark);
   HIP_TRY(hipGetLastError());
 }
 

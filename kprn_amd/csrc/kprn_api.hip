@@ -862,7 +862,7 @@ void kprn_destroy(kprn_handle* h) {
   for (float** p : {&h->dense, &h->g_dense, &h->s1_dense, &h->s2_dense, &h->We, &h->g_We, &h->s1_We, &h->s2_We, &h->d_loss, &h->d_norm2,
                     &h->step_tab})
     dfree(*p);
-  for (int32_t** p : {&h->We_last, &h->d_flag, &h->step_rows, &h->step_count, &h->pack_buf}) dfree(*p);
+  for (int32_t** p : {&h->We_last, &h->d_flag, &h->step_rows, &h->step_count, &h->pack_buf, &h->dp_mark}) dfree(*p);
   if (h->step_tab_host) hipHostFree(h->step_tab_host);
   if (h->h_pinned) hipHostFree(h->h_pinned);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1606,9 +1606,13 @@ int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, i
       scratch_reserve(&h->bidx_scratch, &h->bidx_scratch_bytes, need);
     }
   }
+  if (!h->dp_mark) {
+    h->dp_mark = dalloc<int32_t>(h->cfg.Ve);
+    HIP_TRY(hipMemsetAsync(h->dp_mark, 0, (size_t)h->cfg.Ve * sizeof(int32_t), h->stream));
+  }
   {
     ProfScope ps(h, "dp_merge_rows");
-    bidx::merge_rows(h->stream, dev_all, world, capacity, h->cfg.de, h->cfg.Ve, h->g_We, h->step_rows, h->step_count, h->bidx_scratch,
+    bidx::merge_rows(h->stream, dev_all, world, capacity, h->cfg.de, h->cfg.Ve, h->g_We, h->step_rows, h->step_count, h->dp_mark, h->bidx_scratch,
                      h->bidx_scratch_bytes);
   }
   // the optimiser now walks the union of all ranks' rows (sorted); exact count on the device, upper bound here

@@ -15,12 +15,28 @@ def main(argv=None):
     args, rest = p.parse_known_args(argv)
     assert args.input_dir != "", "input_dir isnt set. Point to the dir where train/dev/test.list files reside"
     params = model.parse_flags(rest)
-    params.topK, params.K, params.initModel, params.gpuid = args.top_k, args.k, args.model_path, args.gpu_id
+    import os as _os
+    params.topK, params.K, params.initModel = args.top_k, args.k, args.model_path
+    params.gpuid = int(_os.environ.get("LOCAL_RANK", args.gpu_id)) if "LOCAL_RANK" in _os.environ else args.gpu_id
     print("using model:", args.model_path)
     eng = model.build_engine(params)
     print({0: "Reducer is max pool", 1: "Reducer is topK", 2: "Reducer is log sum"}[args.top_k])
     print("start predicting...")
-    scoring.test_from_checkpoint(eng, args.input_dir, args.test_list, args.out_file, log=sys.stdout)
+    # under torch.distributed.run (python -m torch.distributed.run --nproc-per-node N -m kprn_amd.score ...): one rank per GPU, the test
+    # list's files sharded over the ranks, test.res assembled by rank 0 in list order
+    import os
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    barrier = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")   # (a barrier only: no tensor moves between the ranks)
+        barrier = dist.barrier
+    scoring.test_from_checkpoint(eng, args.input_dir, args.test_list, args.out_file, log=sys.stdout if rank == 0 else None,
+                                 rank=rank, world=world, barrier=barrier)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

@@ -28,15 +28,60 @@ def score_lines(engine, batcher, class_id=1):
             counter += 1
 
 
-def test_from_checkpoint(engine, input_dir, test_list, out_file, minibatch=512, log=None):
-    """engine: built with the same -top_k reducer the script would rebuild (:69-79)."""
-    batcher = BatcherFileList(input_dir, minibatch, False, 1000, True, test_list)
+def test_from_checkpoint(engine, input_dir, test_list, out_file, minibatch=512, log=None, rank=0, world=1, barrier=None):
+    """engine: built with the same -top_k reducer the script would rebuild (:69-79).
+
+    Data-parallel scoring (new; the reference is single-device): pairs are independent units, so the FILES of the test list are
+    sharded over the ranks in contiguous ranges (dp.shard_pairs), every rank scores its files with no collective and writes
+    `<out_file>.part<rank>`; after `barrier()` (torch.distributed.barrier in a real run) rank 0 concatenates the parts in rank
+    order = list order and renumbers the global 0-based counter, so that `out_file` is byte-identical to the single-rank file
+    (the downstream join with test.list.entity is positional, eval/combine_result.py:24-27)."""
+    if world <= 1:
+        batcher = BatcherFileList(input_dir, minibatch, False, 1000, True, test_list)
+        start = time.time()
+        n = 0
+        with open(out_file, "w") as f:
+            for line in score_lines(engine, batcher, 1):
+                f.write(line)
+                n += 1
+        if log:
+            print("total cost time:", time.time() - start, file=log)
+        return n
+    import os
+    import tempfile
+    from .dp import shard_pairs
+    with open(os.path.join(input_dir, test_list)) as f:
+        files = [l.strip() for l in f if l.strip()]
+    lo, hi = shard_pairs(len(files), rank, world)
     start = time.time()
     n = 0
-    with open(out_file, "w") as f:
-        for line in score_lines(engine, batcher, 1):
-            f.write(line)
-            n += 1
-    if log:
-        print("total cost time:", time.time() - start, file=log)
+    part = f"{out_file}.part{rank}"
+    with open(part, "w") as out:
+        if hi > lo:
+            # a list file of this rank's shard, next to the original (paths in it stay relative to input_dir)
+            fd, shard_list = tempfile.mkstemp(prefix=f".{os.path.basename(test_list)}.rank{rank}.", dir=input_dir)
+            try:
+                with os.fdopen(fd, "w") as sl:
+                    sl.write("\n".join(files[lo:hi]) + "\n")
+                batcher = BatcherFileList(input_dir, minibatch, False, 1000, True, os.path.basename(shard_list))
+                for line in score_lines(engine, batcher, 1):
+                    out.write(line)
+                    n += 1
+            finally:
+                os.unlink(shard_list)
+    if barrier is not None:
+        barrier()
+    if rank == 0:
+        counter = 0
+        with open(out_file, "w") as f:
+            for r in range(world):
+                with open(f"{out_file}.part{r}") as pf:
+                    for line in pf:
+                        _, rest = line.split("\t", 1)
+                        f.write("%d\t%s" % (counter, rest))
+                        counter += 1
+        for r in range(world):
+            os.unlink(f"{out_file}.part{r}")
+        if log:
+            print("total cost time:", time.time() - start, file=log)
     return n
