@@ -59,7 +59,8 @@ typedef enum {
 /* mirrors the torch.CmdLine flags of model/OneModel.lua:27-87 that shape the graph */
 typedef struct {
   int32_t Vt, Ve, Vr;        /* -entityTypeVocabSize -entityVocabSize -relationVocabSize        */
-  int32_t dt, de, dr;        /* -entityTypeEmbeddingDim -entityEmbeddingDim -relationEmbeddingDim */
+  int32_t dt, de, dr;        /* -entityTypeEmbeddingDim -entityEmbeddingDim -relationEmbeddingDim; dt = 0: -includeEntityTypes 0 (no type
+                                table in x_t), de = 0: -includeEntity 0 (no entity table): OneModel.lua:207-219; generic pipeline */
   int32_t F;                 /* -numFeatureTemplates                                             */
   int32_t num_types;         /* -numEntityTypes                                                  */
   int32_t H;                 /* -rnnHidSize                                                      */

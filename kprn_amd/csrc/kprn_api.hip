@@ -412,6 +412,7 @@ static void check_batch(kprn_handle* h, const kprn_batch* b, int class_id) {
 
 static bool use_fused(kprn_handle* h, const kprn_batch* b, bool save_for_backward) {
   if (h->impl != 0 || h->cfg.rnn_type != 0 || !fused::fwd_supported(h, b->T)) return false;
+  if (h->cfg.dt == 0 || h->cfg.de == 0) return false;  // embedding ablations run on the generic pipeline
   // compute_dtype 0 (f32 MFMA) and 2 (f32x6: exact fp32 products from bf16 pieces on the matrix cores): fused forward + backward;
   // 1 (bf16 products): the fused matrix-core forward for scoring, the generic pipeline for training
   if (h->cfg.compute_dtype == 1) return !save_for_backward;  // (2, 3: forward on the matrix cores, fp32 backward)
@@ -765,7 +766,9 @@ int kprn_create(const kprn_config* cfg, kprn_handle** out) {
   try {
     const kprn_config& c = *cfg;
     KPRN_REQUIRE(c.Vt > 0 && c.Ve > 0 && c.Vr > 0, KPRN_E_ARG, "vocab sizes must be positive");
-    KPRN_REQUIRE(c.dt > 0 && c.de > 0 && c.dr > 0, KPRN_E_ARG, "embedding dims must be positive");
+    // dt == 0: no entity-type table (-includeEntityTypes 0), de == 0: no entity table (-includeEntity 0): the embedding variants of
+    // OneModel.lua:210-219 / FeatureEmbedding.lua:26-34,83-110 -- x_t = [types | relations], [entities | relations] or [relations]
+    KPRN_REQUIRE(c.dt >= 0 && c.de >= 0 && c.dr > 0, KPRN_E_ARG, "embedding dims: relation > 0, type / entity >= 0 (0 = that table is not part of the model)");
     KPRN_REQUIRE(c.num_types >= 1, KPRN_E_ARG, "numEntityTypes must be >= 1");
     KPRN_REQUIRE(c.num_types <= c.F, KPRN_E_ARG, "assert(numEntityTypes <= numFeatureTemplates) (OneModel.lua:107)");
     KPRN_REQUIRE(c.F >= c.num_types + 2, KPRN_E_ARG, "numFeatureTemplates must cover types + entity + relation (FeatureEmbedding.lua:51)");
@@ -881,6 +884,7 @@ static int copy_named(kprn_handle* h, const char* name, float* dst, const float*
   const ParamInfo* p = find_param(h, name);
   KPRN_REQUIRE(p, KPRN_E_ARG, std::string("unknown parameter name: ") + (name ? name : "(null)"));
   KPRN_REQUIRE(n == p->rows * p->cols, KPRN_E_ARG, "element count does not match the tensor");
+  if (n == 0) return KPRN_OK;   // (a table that is not part of the model: -includeEntity 0 / -includeEntityTypes 0)
   KPRN_REQUIRE(dst || src, KPRN_E_ARG, "NULL buffer");
   if (p->where == 1 && which == 0) flush_lazy(h);
   float* base;

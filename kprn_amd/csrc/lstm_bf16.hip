@@ -409,7 +409,7 @@ static int64_t wt_off(const kprn_handle* h, int l) {   // offset of layer l's tr
 bool supported(const kprn_handle* h, const kprn_batch* b) {
   const kprn_config& c = h->cfg;
   const int64_t N = (int64_t)b->B * b->P;
-  return c.compute_dtype == 1 && c.rnn_type == 0 && h->impl == 0 && N >= 256 && (c.dt % 8) == 0 && (c.de % 8) == 0 && (c.dr % 8) == 0 && (c.H % 8) == 0;
+  return c.compute_dtype == 1 && c.rnn_type == 0 && h->impl == 0 && N >= 256 && c.dt > 0 && c.de > 0 && (c.dt % 8) == 0 && (c.de % 8) == 0 && (c.dr % 8) == 0 && (c.H % 8) == 0;
 }
 
 void params_changed(kprn_handle* h, bool entity_rows_only) {

@@ -308,7 +308,7 @@ def _walk_modules(o, seen, out):
         if isinstance(mods, dict):
             for k in sorted(k for k in mods if isinstance(k, (int, float))):
                 _walk_modules(mods[k], seen, out)
-        for k in ("module", "recurrentModule", "i2g", "o2g", "inputModule", "initialModule", "feedbackModule"):
+        for k in ("module", "i2g", "o2g", "recurrentModule", "inputModule", "initialModule", "feedbackModule"):
             if k in o:
                 _walk_modules(o[k], seen, out)
     elif isinstance(o, dict):
@@ -346,16 +346,108 @@ def checkpoint_params(path_or_obj, num_layers=None):
         raise ValueError("no nn.Linear in predictor_net")
     head, body = lin[-1], lin[:-1]
     out["out.weight"], out["out.bias"] = head["weight"], head["bias"]
-    if len(body) % 2 != 0:
-        raise ValueError("recurrent layers must contribute two linear maps each (i2g/o2g or i2h/h2h)")
-    L = len(body) // 2
+    # nn.GRU (OneModel.lua:237-238) contributes FOUR maps per layer -- i2g (Linear, 2H rows), o2g (LinearNoBias, 2H rows) and the
+    # candidate's Linear(D, H) + LinearNoBias(H, H) -- nn.FastLSTM and nn.Recurrence two.  Told apart by the shapes: a GRU layer's
+    # first map has twice the rows of its third, an LSTM's four times its hidden size, a Recurrence's exactly its hidden size.
+    H = head["weight"].shape[1]
+    def rows(m):
+        return m["weight"].shape[0]
+    if body and rows(body[0]) == 2 * H:
+        if len(body) % 4 != 0:
+            raise ValueError("nn.GRU layers must contribute four linear maps each (i2g, o2g, candidate i2h, candidate h2h)")
+        L = len(body) // 4
+        for l in range(L):
+            a, b, c, d = body[4 * l:4 * l + 4]
+            if not (rows(a) == rows(b) == 2 * H and rows(c) == rows(d) == H and "bias" in a and "bias" in c):
+                raise ValueError(f"layer {l + 1}: not an nn.GRU parameter set")
+            out[f"gru{l + 1}.i2g.weight"], out[f"gru{l + 1}.i2g.bias"], out[f"gru{l + 1}.o2g.weight"] = a["weight"], a["bias"], b["weight"]
+            out[f"gru{l + 1}.c_i2h.weight"], out[f"gru{l + 1}.c_i2h.bias"], out[f"gru{l + 1}.c_h2h.weight"] = c["weight"], c["bias"], d["weight"]
+    else:
+        if len(body) % 2 != 0:
+            raise ValueError("recurrent layers must contribute two linear maps each (i2g/o2g or i2h/h2h)")
+        L = len(body) // 2
+        for l in range(L):
+            a, b = body[2 * l], body[2 * l + 1]
+            if rows(a) == 4 * H and (b.torch_class == "nn.LinearNoBias" or "bias" not in b):  # nn.FastLSTM: i2g (Linear) + o2g (LinearNoBias)
+                out[f"lstm{l + 1}.i2g.weight"], out[f"lstm{l + 1}.i2g.bias"], out[f"lstm{l + 1}.o2g.weight"] = a["weight"], a["bias"], b["weight"]
+            elif rows(a) == H and "bias" in a and "bias" in b:                                 # nn.Recurrence: input2hidden + hidden2hidden
+                out[f"rnn{l + 1}.i2h.weight"], out[f"rnn{l + 1}.i2h.bias"] = a["weight"], a["bias"]
+                out[f"rnn{l + 1}.h2h.weight"], out[f"rnn{l + 1}.h2h.bias"] = b["weight"], b["bias"]
+            else:
+                raise ValueError(f"layer {l + 1}: neither an nn.FastLSTM nor an nn.Recurrence parameter set (rows {rows(a)}, H {H})")
     if num_layers is not None and L != num_layers:
         raise ValueError(f"checkpoint has {L} recurrent layers, expected {num_layers}")
-    for l in range(L):
-        a, b = body[2 * l], body[2 * l + 1]
-        if b.torch_class == "nn.LinearNoBias" or "bias" not in b:  # nn.FastLSTM: i2g (Linear) + o2g (LinearNoBias)
-            out[f"lstm{l + 1}.i2g.weight"], out[f"lstm{l + 1}.i2g.bias"], out[f"lstm{l + 1}.o2g.weight"] = a["weight"], a["bias"], b["weight"]
-        else:                                                       # nn.Recurrence: input2hidden + hidden2hidden
-            out[f"rnn{l + 1}.i2h.weight"], out[f"rnn{l + 1}.i2h.bias"] = a["weight"], a["bias"]
-            out[f"rnn{l + 1}.h2h.weight"], out[f"rnn{l + 1}.h2h.bias"] = b["weight"], b["bias"]
     return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in out.items()}
+
+
+# ---- writer: an engine-trained model as a reference checkpoint (OneModel.lua:392-400 torch.save{embeddingLayer, predictor_net}) ----
+# Everything Torch7-side here is [from memory, unpinned] -- the tree ships no checkpoint and no Torch7.  What each assumption governs:
+#   * object framing (type tags, "V 1" + class name, reference indices): _T7Writer.obj above, byte for byte what _T7Reader expects;
+#   * an nn module serialises as a torch object whose payload is ONE table of its fields (torch.File:writeObject for non-tensor
+#     classes) -- T7Object; the fields written are the ones nn's updateOutput reads: weight / bias (+ empty gradWeight / gradBias /
+#     output / gradInput tensors, `_type`);
+#   * container children live in the `modules` table under 1-based number keys (nn.Container); the Element-Research classes keep
+#     theirs in named fields: nn.Sequencer.module, nn.FastLSTM.i2g / .o2g (+ recurrentModule), nn.Recurrence.recurrentModule, nn.GRU.i2g /
+#     .o2g (+ recurrentModule) -- the names _walk_modules follows;
+#   * predictor_net = Sequential{SplitTable(3), embeddingLayer, SplitTable(2), Sequencer(cell) x L, SelectTable(-1), Linear(H, 46)}
+#     (OneModel.lua:223-275) and embeddingLayer = Sequential{ConcatTableNoGrad{type net, entity net, relation net}, JoinTable(3)}
+#     (FeatureEmbedding.lua:112-121) share the embeddingLayer OBJECT (written once, back-referenced);
+#   * tensors are torch.DoubleTensor (the CPU reference computes in float64), contiguous, storageOffset 1.
+# A reviewer with a Torch7 install can falsify each line by torch.load()ing a file written here.
+
+
+def _t(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _mod(cls, **fields):
+    m = T7Object(cls)
+    m.update({"_type": "torch.DoubleTensor", "output": np.zeros(0), "gradInput": np.zeros(0), "train": False})
+    m.update(fields)
+    return m
+
+
+def _linear(w, b=None):
+    if b is None:
+        return _mod("nn.LinearNoBias", weight=_t(w), gradWeight=np.zeros(0))
+    return _mod("nn.Linear", weight=_t(w), bias=_t(b), gradWeight=np.zeros(0), gradBias=np.zeros(0))
+
+
+def _seq(*mods):
+    return _mod("nn.Sequential", modules={float(i + 1): m for i, m in enumerate(mods)})
+
+
+def write_checkpoint(path, params, num_entity_types=1, use_relu=1):
+    """params: dict engine parameter name -> array (Engine.get_param for every name of Engine.layout()).  Writes the
+    {embeddingLayer, predictor_net} table eval/test_from_checkpoint.lua:68 loads; checkpoint_params() reads it back."""
+    g = lambda n: params[n]
+    lut = lambda w: _mod("nn.LookupTable", weight=_t(w), gradWeight=np.zeros(0), shouldScaleGradByFreq=False)
+    type_lut = lut(g("type_emb"))
+    par = _mod("nn.ParallelTable", modules={float(i + 1): type_lut for i in range(max(1, num_entity_types))})   # shared weight (FeatureEmbedding.lua:44-48)
+    type_net = _seq(_mod("nn.NarrowTable"), par, _mod("nn.CAddTable"))
+    ent_net = _seq(_mod("nn.SelectTable"), lut(g("entity_emb")))
+    rel_net = _seq(_mod("nn.SelectTable"), lut(g("relation_emb")))
+    emb = _seq(_mod("nn.ConcatTableNoGrad", modules={1.0: type_net, 2.0: ent_net, 3.0: rel_net}), _mod("nn.JoinTable", dimension=3.0))
+    layers = []
+    l = 1
+    while True:
+        if f"lstm{l}.i2g.weight" in params:
+            cell = _mod("nn.FastLSTM", i2g=_linear(g(f"lstm{l}.i2g.weight"), g(f"lstm{l}.i2g.bias")), o2g=_linear(g(f"lstm{l}.o2g.weight")))
+        elif f"rnn{l}.i2h.weight" in params:
+            rm = _seq(_mod("nn.ParallelTable", modules={1.0: _linear(g(f"rnn{l}.i2h.weight"), g(f"rnn{l}.i2h.bias")),
+                                                        2.0: _linear(g(f"rnn{l}.h2h.weight"), g(f"rnn{l}.h2h.bias"))}),
+                      _mod("nn.CAddTable"), _mod("nn.ReLU" if use_relu else "nn.Tanh"))
+            cell = _mod("nn.Recurrence", recurrentModule=_mod("nn.MaskZero", module=rm, nInputDim=1.0))
+        elif f"gru{l}.i2g.weight" in params:
+            cand = _seq(_mod("nn.ParallelTable", modules={1.0: _linear(g(f"gru{l}.c_i2h.weight"), g(f"gru{l}.c_i2h.bias")),
+                                                          2.0: _linear(g(f"gru{l}.c_h2h.weight"))}), _mod("nn.CAddTable"), _mod("nn.Tanh"))
+            cell = _mod("nn.GRU", i2g=_linear(g(f"gru{l}.i2g.weight"), g(f"gru{l}.i2g.bias")), o2g=_linear(g(f"gru{l}.o2g.weight")), recurrentModule=cand)
+        else:
+            break
+        layers.append(_mod("nn.Sequencer", module=cell))
+        l += 1
+    if not layers:
+        raise ValueError("no recurrent layer parameters (lstm1.* / rnn1.* / gru1.*) in params")
+    pred = _seq(_mod("nn.SplitTable", dimension=3.0), emb, _mod("nn.SplitTable", dimension=2.0), *layers, _mod("nn.SelectTable", index=-1.0),
+                _linear(g("out.weight"), g("out.bias")))
+    t7_save(path, {"embeddingLayer": emb, "predictor_net": pred})

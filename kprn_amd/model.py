@@ -2,9 +2,8 @@
 
 `parse_flags` accepts the torch.CmdLine flags of OneModel.lua:27-87 with the same names and
 defaults; `build_engine` turns them into a kprn Engine the way OneModel.lua:204-309 builds
-predictor_net / reducer / training_net.  Options the engine does not implement yet fail loudly with
-the library's KPRN_E_UNSUPPORTED (embedding ablations, dropout) instead of silently doing
-something else.
+predictor_net / reducer / training_net.  Options the engine does not implement fail loudly with
+the library's KPRN_E_UNSUPPORTED (dropout) instead of silently doing something else.
 """
 import argparse
 
@@ -40,6 +39,7 @@ def flag_parser():
     a("-numLayers", type=int, default=1); a("-useDropout", type=int, default=0); a("-dropout", type=float, default=0.0)
     # engine-side additions (not in the reference)
     a("-seed", type=int, default=12345); a("-entityUpdate", type=int, default=0)
+    a("-checkpointFormat", default="native", choices=["native", "t7", "both"])   # t7: the reference's torch.save{embeddingLayer, predictor_net}
     return p
 
 
@@ -50,11 +50,52 @@ def parse_flags(argv=None):
 RNN_TYPES = {"lstm": 0, "rnn": 1, "gru": 2}
 
 
+def reducer_of_train_flag(topK):
+    """OneModel.lua:284-293: -topK 1 -> TopK+Mean, 2 -> LogSumExp, ANYTHING ELSE -> nn.Max"""
+    return {1: 1, 2: 2}.get(int(topK), 0)
+
+
+def reducer_of_score_flag(top_k):
+    """test_from_checkpoint.lua:69-79: -top_k 0 -> nn.Max, 2 -> LogSumExp, ANYTHING ELSE -> TopK+Mean"""
+    return {0: 0, 2: 2}.get(int(top_k), 1)
+
+
+REDUCER_NAME = {0: "Reducer is max pool", 1: "Reducer is topK", 2: "Reducer is LogSumExp"}
+
+NATIVE_MAGIC = b"KPRNAMD1"
+
+
+def load_checkpoint(eng, path):
+    """-initModel / -model_path: the native format (kprn_save) or a reference Torch7 checkpoint {embeddingLayer, predictor_net}
+    (OneModel.lua:392-400), told apart by the file's first bytes"""
+    with open(path, "rb") as f:
+        head = f.read(8)
+    if head == NATIVE_MAGIC:
+        eng.load(path)
+        return "native"
+    from . import formats
+    params = formats.checkpoint_params(path, num_layers=eng.cfg.L)
+    lay = eng.layout()
+    missing = [n for n in lay if n not in params]
+    if missing:
+        raise _ffi.KprnError(_ffi.E_IO, f"{path}: checkpoint lacks {missing}")
+    for n in lay:
+        eng.set_param(n, params[n])
+    return "t7"
+
+
+def save_checkpoint_t7(eng, path):
+    """the model as the reference writes it: torch.save(path, {embeddingLayer, predictor_net}) (OneModel.lua:392-400), so that the
+    reference's eval/test_from_checkpoint.lua:68 can load a model trained by this engine"""
+    from . import formats
+    formats.write_checkpoint(path, {n: eng.get_param(n) for n in eng.layout()}, num_entity_types=eng.cfg.num_types, use_relu=eng.cfg.use_relu)
+
+
 def build_engine(params, rank=0, world=1, device_id=None, stream=None):
-    """OneModel.lua:204-309.  Only the entity+type+relation embedding variant (includeEntityTypes==1 and
-    includeEntity==1, OneModel.lua:207-209) is the hot path; the ablation variants (210-219) are refused."""
-    if not (params.includeEntityTypes == 1 and params.includeEntity == 1):
-        raise _ffi.KprnError(_ffi.E_UNSUPPORTED, "only includeEntityTypes=1 includeEntity=1 is built (OneModel.lua:207-209)")
+    """OneModel.lua:204-309.  The embedding variants of OneModel.lua:207-219: a table that is left out (-includeEntityTypes 0 /
+    -includeEntity 0) is a table of width 0 to the engine -- x_t = [types | relations], [entities | relations] or [relations],
+    parameters in the same flat order with the absent table contributing nothing."""
+    inc_types, inc_ent = params.includeEntityTypes == 1, params.includeEntity == 1
     if params.numEntityTypes > params.numFeatureTemplates:
         raise _ffi.KprnError(_ffi.E_ARG, "assert(numEntityTypes <= numFeatureTemplates) (OneModel.lua:107)")
     if params.useDropout != 0:
@@ -64,13 +105,13 @@ def build_engine(params, rank=0, world=1, device_id=None, stream=None):
     if device_id is None:
         device_id = max(0, params.gpuid)
     eng = _ffi.Engine(params.entityTypeVocabSize, params.entityVocabSize, params.relationVocabSize,
-                      params.entityTypeEmbeddingDim, params.entityEmbeddingDim, params.relationEmbeddingDim,
+                      params.entityTypeEmbeddingDim if inc_types else 0, params.entityEmbeddingDim if inc_ent else 0, params.relationEmbeddingDim,
                       params.rnnHidSize, params.numLayers, F=params.numFeatureTemplates, num_types=params.numEntityTypes,
-                      C_=LABEL_DIMENSION, reducer=params.topK, K=params.K, rnn_type=RNN_TYPES[params.rnnType],
+                      C_=LABEL_DIMENSION, reducer=getattr(params, "reducer", reducer_of_train_flag(params.topK)), K=params.K, rnn_type=RNN_TYPES[params.rnnType],
                       use_relu=params.useReLU, rnn_init=params.rnnInitialization,
                       device_id=device_id, rank=rank, world=world, param_init=params.paramInit, seed=params.seed, stream=stream)
     if params.initModel:
-        eng.load(params.initModel)  # OneModel.lua:277-282
+        load_checkpoint(eng, params.initModel)  # OneModel.lua:277-282
     return eng
 
 

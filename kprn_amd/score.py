@@ -16,11 +16,11 @@ def main(argv=None):
     assert args.input_dir != "", "input_dir isnt set. Point to the dir where train/dev/test.list files reside"
     params = model.parse_flags(rest)
     import os as _os
-    params.topK, params.K, params.initModel = args.top_k, args.k, args.model_path
+    params.reducer, params.K, params.initModel = model.reducer_of_score_flag(args.top_k), args.k, args.model_path
     params.gpuid = int(_os.environ.get("LOCAL_RANK", args.gpu_id)) if "LOCAL_RANK" in _os.environ else args.gpu_id
     print("using model:", args.model_path)
     eng = model.build_engine(params)
-    print({0: "Reducer is max pool", 1: "Reducer is topK", 2: "Reducer is log sum"}[args.top_k])
+    print({0: "Reducer is max pool", 1: "Reducer is topK", 2: "Reducer is log sum"}[params.reducer])
     print("start predicting...")
     # under torch.distributed.run (python -m torch.distributed.run --nproc-per-node N -m kprn_amd.score ...): one rank per GPU, the test
     # list's files sharded over the ranks, test.res assembled by rank 0 in list order

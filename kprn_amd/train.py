@@ -20,7 +20,7 @@ def main(argv=None):
             for k, v in sorted(vars(params).items()):
                 f.write(f"{k}\t{v}\n")
     eng = model.build_engine(params)
-    print({0: "Reducer is max pool", 1: "Reducer is topK", 2: "Reducer is LogSumExp"}[params.topK])
+    print(model.REDUCER_NAME[model.reducer_of_train_flag(params.topK)])
     print("Using Adam!" if params.useAdam == 1 else "Using adagrad!")
     trainBatcher = BatcherFileList(params.dataDir, params.minibatch, True, 100, params.gpuid != -1, "train.list", seed=params.seed)
     callbacks = []
@@ -28,7 +28,10 @@ def main(argv=None):
         def saver(i):
             path = params.model + "-latest"
             print("saving to " + path)
-            eng.save(path)
+            if params.checkpointFormat in ("native", "both"):
+                eng.save(path)
+            if params.checkpointFormat in ("t7", "both"):
+                model.save_checkpoint_t7(eng, path if params.checkpointFormat == "t7" else path + ".t7")
         if params.createExptDir == 1:
             callbacks.append(OptimizerCallback(params.saveFrequency, saver, "saving"))
         else:

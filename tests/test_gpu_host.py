@@ -139,7 +139,11 @@ def test_unsupported_reference_options_fail_loudly():
     assert "rnn1.h2h.bias" in eng.layout()
     eng = model.build_engine(model.parse_flags(FLAGS.replace("-rnnType lstm", "-rnnType gru").split()))
     assert "gru2.c_h2h.weight" in eng.layout()
-    p = model.parse_flags(FLAGS.replace("-includeEntity 1", "-includeEntity 0").split())
+    # the embedding variants of OneModel.lua:207-219 are built (a left-out table has width 0); dropout is not
+    p = model.parse_flags(FLAGS.replace("-includeEntity 1", "-includeEntity 0").replace("-numLayers 2", "-numLayers 1").split())
+    eng = model.build_engine(p)
+    assert eng.D == 32 and eng.layout()["entity_emb"][1] == (500, 0)
+    p = model.parse_flags((FLAGS + " -useDropout 1").split())
     with pytest.raises(_ffi.KprnError) as e:
         model.build_engine(p)
     assert e.value.code == _ffi.E_UNSUPPORTED
@@ -184,3 +188,28 @@ def test_hit_and_ndcg_at_k_match_the_oracle_within_1e_3():
         assert abs(gh[k] - oh[k]) <= 1e-3, (k, gh[k], oh[k])
         assert abs(gn[k] - on[k]) <= 1e-3, (k, gn[k], on[k])
     assert 0.0 < oh[10] < 1.0  # the ranking is not degenerate (scores are spread, not all tied)
+
+
+def test_engine_trained_model_round_trips_through_a_torch7_checkpoint(tmp_path):
+    """OneModel.lua:392-400 <-> test_from_checkpoint.lua:68: a model trained here, written as torch.save{embeddingLayer, predictor_net},
+    read back into a fresh engine, scores identically (bit for bit: the file holds float64 images of the fp32 parameters); a shuffled
+    epoch exercises MyOptimizer's streaming feed on the way."""
+    root = str(tmp_path)
+    _write_dataset(root, ".npz")
+    params = model.parse_flags(FLAGS.split() + ["-dataDir", root])
+    eng = model.build_engine(params)
+    fl = batcher.BatcherFileList(root, params.minibatch, True, 100, True, "train.list", seed=5)   # shuffle: streamed batches
+    opt = optimizer.MyOptimizer(eng, {"numEpochs": 2, "epochHooks": [], "minibatchsize": 16}, model.opt_from_flags(params), out=io.StringIO())
+    hist = opt.train(fl)
+    assert len(hist) == 2 and np.isfinite(hist).all()
+    path = os.path.join(root, "model-latest")
+    model.save_checkpoint_t7(eng, path)
+    eng2 = model.build_engine(model.parse_flags(FLAGS.split() + ["-dataDir", root, "-seed", "777"]))
+    assert not np.array_equal(eng2.get_flat_params(), eng.get_flat_params())
+    assert model.load_checkpoint(eng2, path) == "t7"
+    assert np.array_equal(eng2.get_flat_params(), eng.get_flat_params())
+    idx, _ = synth.make_paths(40, 3, 6, Ve=500, seed=9)
+    assert np.array_equal(eng2.forward(eng2.batch(idx), 1)["probs"], eng.forward(eng.batch(idx), 1)["probs"])
+    native = os.path.join(root, "model-native")
+    eng.save(native)
+    assert model.load_checkpoint(eng2, native) == "native"

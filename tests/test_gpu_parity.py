@@ -853,3 +853,35 @@ def test_bf16_fused_scoring_is_tolerance_gated():
     eng.set_option("impl", "generic")
     out_g = eng.forward(eng.batch(idx), 1, want=("path_scores",))
     assert rel_inf(out["path_scores"], out_g["path_scores"].astype(np.float64)) < 1e-2
+
+
+@pytest.mark.parametrize("dt,de,rnn_type", [(0, 24, 0), (16, 0, 0), (0, 0, 0), (0, 24, 1), (16, 0, 2)])
+@pytest.mark.parametrize("pairs", [33, 150])
+def test_embedding_ablations_match_oracle(dt, de, rnn_type, pairs):
+    """OneModel.lua:207-219 / FeatureEmbedding.lua:26-34,83-110: -includeEntityTypes 0 (x_t = [entities | relations]), -includeEntity 0
+    ([types | relations]), both 0 ([relations]); a left-out table is a table of width 0.  Forward, backward and Adam steps against the
+    oracle at a small and at a tiled-GEMM size; the id columns of the absent tables are ignored, as the reference ignores them."""
+    Ve, dr, H = 300, 8, 40
+    eng = _ffi.Engine(6, Ve, 9, dt, de, dr, H, 1, rnn_type=rnn_type, param_init=0.2)
+    o64 = Oracle(make_cfg(Vt=6, Ve=Ve, Vr=9, dt=dt, de=de, dr=dr, H=H, L=1, rnn_type=rnn_type), np.float64)
+    assert eng.n_params == o64.n and eng.D == dt + de + dr
+    theta = o64.init_params(11, 0.2).astype(np.float32).astype(np.float64)
+    eng.set_flat_params(theta.astype(np.float32))
+    assert np.array_equal(eng.get_flat_params(), theta.astype(np.float32))
+    idx, labels = synth.make_paths(pairs, 3, 5, Ve=Ve, seed=13)
+    b = eng.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    ps, _, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5
+    np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=SCORE_RTOL)
+    x = eng.embed(idx)
+    assert x.shape[-1] == dt + de + dr and np.array_equal(x, Oracle(o64.cfg, np.float32).embed(theta.astype(np.float32), idx))
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        if n:
+            assert rel_inf(g[off:off + n], og[off:off + n]) < GRAD_RTOL, nm
+    _train_compare(eng, o64, theta, [(idx, labels)], dict(method=1, lr=1e-2), 5, 2e-4)
