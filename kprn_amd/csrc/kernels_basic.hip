@@ -459,7 +459,7 @@ __global__ void k_head_bwd(const float* __restrict__ dS, const float* __restrict
 // relations) are reduced in LDS per block first; entity rows go straight to L2 atomics.
 __global__ void k_embed_scatter(const int32_t* __restrict__ idx, int64_t N, int T, int F, int nT, const float* __restrict__ dX, int dt, int de,
                                 int dr, int Vt, int Vr, float* __restrict__ gWt, float* __restrict__ gWe, float* __restrict__ gWr,
-                                int use_lds, int steps_per_block, int skip_entity) {
+                                int use_lds, int steps_per_block, int skip_entity, int skip_type, int skip_rel) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int D = dt + de + dr;
   const int nt_small = Vt * dt, nr_small = Vr * dr;
@@ -477,6 +477,7 @@ __global__ void k_embed_scatter(const int32_t* __restrict__ idx, int64_t N, int 
     int t = (int)(step / N);
     int64_t n = step % N;
     const int32_t* f = idx + (n * T + t) * F;
+    if ((j < dt) ? skip_type : ((j < dt + de) ? skip_entity : skip_rel)) continue;   // (that table is handled elsewhere)
     float v = dX[step * D + j];
     if (j < dt) {
       for (int k = 0; k < nT; ++k) {
@@ -820,17 +821,84 @@ void head_bwd(hipStream_t s, const float* dS, const float* hT, const float* Wout
   CHECK_LAUNCH();
 }
 
+// nn.LookupTable backward for a table of at most 16 rows (the type table: 6 rows; the KKBox relation table: 9) from time-major
+// row-major dX [T][N][D]: with so few rows every position of the batch lands on the same handful of accumulators, and atomics (LDS
+// or L2) on them serialise.  Here a lane owns one column of the slice and keeps one register per table row; a wave reads 64
+// consecutive floats per position and adds them to the row its (wave-uniform) id names; one block-level reduction and a few atomics
+// per workgroup at the end.  slots > 1: several id columns feed the same slice (CAddTable over the type slots, FeatureEmbedding.lua:55).
+__global__ __launch_bounds__(256) void k_small_table_grad(const int32_t* __restrict__ idx, int64_t N, int T, int F, int idcol, int slots,
+                                                           const float* __restrict__ dX, int D, int col0, int dcols, int V, float* __restrict__ gW,
+                                                           int pos_per_block) {
+  __shared__ float red[4][16][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ngroups = (dcols + 63) >> 6;                      // 64-column groups of the slice
+  const int grp = blockIdx.y;                                  // one column group per grid row
+  const int col = grp * 64 + lane;
+  const bool act = col < dcols;
+  const int64_t total = N * T;
+  const int64_t p0 = (int64_t)blockIdx.x * pos_per_block;
+  const int64_t p1 = (p0 + pos_per_block < total) ? p0 + pos_per_block : total;
+  float acc[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  // latency-bound per position (one id, 256 bytes): eight positions in flight per wave
+  constexpr int UN = 8;
+  for (int64_t pb = p0 + wv; pb < p1; pb += 4 * UN) {         // time-major position p = t N + n
+    float x[UN];
+    const int32_t* f[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t p = pb + 4 * u;
+      const bool live = p < p1;
+      const int64_t pc = live ? p : p0;
+      const int t = (int)(pc / N);
+      const int64_t n = pc - (int64_t)t * N;
+      x[u] = (act && live) ? dX[pc * D + col0 + col] : 0.f;
+      f[u] = idx + (n * T + t) * F + idcol;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      for (int k = 0; k < slots; ++k) {
+        const int id = f[u][k] - 1;                            // (wave-uniform)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] += (id == v) ? x[u] : 0.f;
+      }
+    }
+  }
+  (void)ngroups;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) red[wv][v][lane] = acc[v];
+  __syncthreads();
+  for (int e = threadIdx.x; e < V * 64; e += 256) {
+    const int v = e >> 6, c = e & 63;
+    const float sum = (red[0][v][c] + red[1][v][c]) + (red[2][v][c] + red[3][v][c]);
+    if (grp * 64 + c < dcols && sum != 0.f) unsafeAtomicAdd(gW + (int64_t)v * dcols + grp * 64 + c, sum);
+  }
+}
+
 void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* dX, int dt, int de, int dr, int Vt, int Vr,
                    float* gWt, float* gWe, float* gWr, bool skip_entity) {
   if (N <= 0) return;
-  size_t small = (size_t)((int64_t)Vt * dt + (int64_t)Vr * dr) * sizeof(float);
+  // tiny tables (<= 16 rows): register accumulators instead of atomics on a handful of addresses
+  const int D_ = dt + de + dr;
+  const bool type_small = dt > 0 && Vt <= 16, rel_small = dr > 0 && Vr <= 16;
+  const int ppb = 512;
+  if (type_small)
+    hipLaunchKernelGGL(k_small_table_grad, dim3((unsigned)((N * T + ppb - 1) / ppb), (unsigned)((dt + 63) / 64)), dim3(256), 0, s, idx, N, T, F, F - nT - 2, nT,
+                       dX, D_, 0, dt, Vt, gWt, ppb);
+  if (rel_small)
+    hipLaunchKernelGGL(k_small_table_grad, dim3((unsigned)((N * T + ppb - 1) / ppb), (unsigned)((dr + 63) / 64)), dim3(256), 0, s, idx, N, T, F, F - 1, 1, dX,
+                       D_, dt + de, dr, Vr, gWr, ppb);
+  if ((type_small || dt == 0) && (rel_small || dr == 0) && (skip_entity || de == 0)) { CHECK_LAUNCH(); return; }
+  if (type_small) { Vt = 0; }   // (their LDS share is not needed)
+  size_t small = (size_t)((int64_t)(type_small ? 0 : Vt) * dt + (int64_t)(rel_small ? 0 : Vr) * dr) * sizeof(float);
   int use_lds = small <= 96 * 1024 ? 1 : 0;
   const int spb = 256;  // steps per block
   int64_t total = N * T;
   if (use_lds && small > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)k_embed_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small));
   hipLaunchKernelGGL(k_embed_scatter, dim3((unsigned)((total + spb - 1) / spb)), dim3(TPB), use_lds ? small : 0, s, idx, N, T, F, nT, dX, dt, de,
-                     dr, Vt, Vr, gWt, gWe, gWr, use_lds, spb, skip_entity ? 1 : 0);
+                     dr, type_small ? 0 : Vt, rel_small ? 0 : Vr, gWt, gWe, gWr, use_lds, spb, skip_entity ? 1 : 0, type_small ? 1 : 0, rel_small ? 1 : 0);
   CHECK_LAUNCH();
 }
 

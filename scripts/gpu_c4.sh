@@ -1,5 +1,6 @@
 #!/bin/bash
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_wide.py -x -q -m gpu -k "bf16 or 2_pow_24" 2>&1 | tail -15
 run() { name=$1; shift; timeout 900 python bench.py --no-cpu-baseline --no-alt --no-extra-regions --batch-feed resident --steps 8 --warmup 3 "$@" > gpurun_out/c4_$name.log 2>&1
   grep '^{' gpurun_out/c4_$name.log | tail -1 > gpurun_out/c4_$name.json
   python - <<PY || tail -8 gpurun_out/c4_$name.log
@@ -11,6 +12,4 @@ for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["ms"])[:14]:
 PY
 }
 run bf16 --dims C4
-run fp32 --dims C4 --c4-fp32
-timeout 300 python bench.py --workload c5 --steps 40 --warmup 5 > gpurun_out/c5.log 2>&1; grep '^{' gpurun_out/c5.log | tail -1 > gpurun_out/c5.json; python -c "
-import json; d=json.load(open('gpurun_out/c5.json')); print('c5', d['value'], d['ms_per_step'], d['streaming'], d['roofline'], d['cpu_baseline'])" || tail -5 gpurun_out/c5.log
+KPRN_BF16_TILE=small run bf16small --dims C4

@@ -147,12 +147,15 @@ def _bf16_case(dims, H, L, pairs, P, Vr=100, seed=4, init=0.05):
     return eng, ref, o64, theta, idx, labels
 
 
+@pytest.mark.parametrize("tile", ["small", "big"])
 @pytest.mark.parametrize("dims,H,L,pairs,P", [((128, 128, 128), 384, 1, 150, 2), ((16, 32, 16), 64, 2, 101, 3), ((64, 64, 64), 192, 2, 129, 2)])
-def test_bf16_storage_pipeline_is_tolerance_gated_against_the_f64_oracle(dims, H, L, pairs, P):
+def test_bf16_storage_pipeline_is_tolerance_gated_against_the_f64_oracle(dims, H, L, pairs, P, tile, monkeypatch):
     """compute_dtype = 1 from 256 paths up: bf16 shadow tables / weights, bf16 activations and gate saves, v_mfma_f32_16x16x32_bf16 with
     fp32 accumulation, fp32 cell state and master parameters (kprn_amd/csrc/lstm_bf16.hip).  bf16 has 8 mantissa bits: scores within
     3e-2 of the largest, probabilities 2e-2 absolute, loss 3e-2, every gradient tensor within 6e-2 of its largest entry; and the
-    result must differ from the fp32 path by far more than fp32 rounding (the bf16 path really ran).  (303 / 258 paths: not multiples of 8.)"""
+    result must differ from the fp32 path by far more than fp32 rounding (the bf16 path really ran).  (303 / 258 paths: not multiples of 8.)
+    Both tile geometries of the bf16 GEMM (128 x 128 / 4 waves, 256 x 256 / 8 waves: the latter is chosen from 512 tiles up) run here."""
+    monkeypatch.setenv("KPRN_BF16_TILE", tile)
     eng, ref, o64, theta, idx, labels = _bf16_case(dims, H, L, pairs, P)
     b, br = eng.batch(idx, labels), ref.batch(idx, labels)
     out = eng.forward(b, 1, want=("probs", "path_scores"))
