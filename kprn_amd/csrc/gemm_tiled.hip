@@ -54,74 +54,119 @@ struct TArgs {
   const float* bias2; const float* mask; int relu;   // EPI_RNN: h2h bias, MaskZero flags [M], ReLU / Tanh
 };
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }   // (as kernels_basic.hip: the generic path is the accurate one)
+// Gate functions at fp32 accuracy on v_exp_f32 / v_rcp_f32 (1 ulp each) instead of libm's ~40-instruction expf / tanhf: the cell
+// epilogue of a 128 x 32-unit tile evaluates 80 of them per thread, which with libm cost a quarter of the tile's MFMA time.
+// e^x = 2^t (1 + ln2 (x log2e - t)): the product's rounding residual (and log2e's low word) is folded back in, so the result
+// stays within ~2 ulp for any x; 1 / (1 + e^-x) and tanh x = (1 - e^-2|x|) / (1 + e^-2|x|) then have ABSOLUTE error <= 1.5e-7
+// (the same class as the D = H = 64 persistent kernels' gate math; tests/test_gpu_wide.py gates it against the f64 oracle).
+__device__ __forceinline__ float exp_fast(float x) {
+  const float t = x * 1.4426950408889634f;
+  const float lo = __builtin_fmaf(x, 1.9259629911e-8f, __builtin_fmaf(x, 1.4426950408889634f, -t));
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, lo * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_fast(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float t = exp_fast(-2.0f * __builtin_fabsf(x));
+  return __builtin_copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+}
+// 16-byte vectors at any 4-byte aligned address: gfx950 runs in unaligned access mode (the compiler itself emits
+// global_load/store_dwordx4 for an align-4 <4 x float>), so rows need no particular pitch -- config.sh's H = 250 takes the same
+// path as H = 256 (8-byte vectors, the previous answer to odd pitches, cost 25 % on the rnn step: twice the load / LDS-store count)
+typedef f32x4 f32x4u __attribute__((aligned(4)));
+// four consecutive columns of one row; nv = how many of the four lie inside the matrix
+__device__ __forceinline__ void store4(float* __restrict__ p, const f32x4 v, int nv) {
+  if (nv >= 4) *(f32x4u*)p = v;
+  else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) if (r < nv) p[r] = v[r];
+  }
+}
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int nv) {
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (nv >= 4) v = *(const f32x4u*)p;
+  else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) if (r < nv) v[r] = p[r];
+  }
+  return v;
+}
 
-// one operand tile [ROWS][32] (layout 0) or [32][ROWS] (layout 1), ROWS = 128 or 64: this thread's ROWS / 8 floats, fetched
-// as VW-float vectors (VW = 4: 16-byte rows everywhere; VW = 2: even leading dimensions, e.g. config.sh's H = 250)
-template <int VW> struct VecOf;
-template <> struct VecOf<4> { typedef float type __attribute__((ext_vector_type(4))); };
-template <> struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
-// Loads of one operand tile, branch-free and address-cheap: every piece has a running pointer (set up once per K segment) and
-// is fetched from a clamped, always valid address; what lies outside the problem is zeroed when the piece is written to LDS --
+// One operand tile [ROWS][32] (layout 0) or [32][ROWS] (layout 1), ROWS = 128 or 64: this thread's ROWS / 32 pieces of 4 floats.
+// Loads are branch-free and address-cheap: one running 64-bit base + 32-bit piece offsets (set up once per K segment), every piece
+// fetched from a clamped, always valid address; what lies outside the problem is zeroed ELEMENT-wise when the piece is written
+// to LDS (a vector may straddle the end of K or of the rows: every device buffer carries 64 bytes of slack for that) -- and
 // AFTER the chunk's MFMAs, so the loads stay in flight under them (a select right behind the load made the compiler wait for
 // all eight loads before the first MFMA; conditional loads made each a basic block of its own).
-template <int LAY, int ROWS, int VW>
+template <int LAY, int ROWS>
 struct TileLoader {
-  typedef typename VecOf<VW>::type vec_t;
-  static constexpr int NP = ROWS / (8 * VW);
-  const float* p[NP];
+  static constexpr int NP = ROWS / 32;
+  // piece e of thread tid is float 4 (tid + 256 e) of the tile: in layout 0 all pieces of a thread share their k offset and sit
+  // 32 rows apart; in layout 1 they share their m offset and sit 1024 / ROWS k-rows apart
+  const float* base;
   const float* safe;
-  bool rok[NP];
-  int kofs[NP];
+  int off[NP];
+  unsigned rmask;     // layout 0: bit e = piece e's row lies inside the problem;  layout 1: valid elements (0..4) of this thread's column group
+  int k0ofs;          // k offset of piece 0 inside the chunk
   int64_t step;
+  static constexpr int KSTEP = (LAY == 0) ? 0 : 1024 / ROWS;   // k distance between consecutive pieces
   __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int64_t r0, int64_t rmax, int64_t k0, const int* rowmap) {
     const int tid = threadIdx.x;
     safe = P;
     step = (LAY == 0) ? (int64_t)TK : (int64_t)TK * ld;
+    rmask = 0;
+    if (LAY == 0) {
+      const int kq = (tid & 7) * 4;
+      k0ofs = kq;
+      base = P + (rowmap ? 0 : r0 * ld) + k0 + kq;   // (offsets stay tile-relative: 32 bits hold 128 rows of any pitch)
 #pragma unroll
-    for (int e = 0; e < NP; ++e) {
-      const int f = tid + 256 * e;
-      if (LAY == 0) {
-        const int row = f / (32 / VW), kq = (f % (32 / VW)) * VW;
-        int64_t gr = r0 + row;
-        bool ok = gr < rmax;
-        if (rowmap) { const int mr = rowmap[row]; ok = mr >= 0; gr = mr; }
-        rok[e] = ok; kofs[e] = kq;
-        p[e] = P + (ok ? gr : 0) * ld + k0 + kq;
-      } else {
-        const int kr = f / (ROWS / VW), mq = (f % (ROWS / VW)) * VW;
-        const int64_t gr = r0 + mq;
-        rok[e] = gr < rmax; kofs[e] = kr;
-        p[e] = P + (k0 + kr) * ld + (rok[e] ? gr : 0);
+      for (int e = 0; e < NP; ++e) {
+        const int row = (tid >> 3) + 32 * e;
+        bool ok = r0 + row < rmax;
+        int64_t rel = row;
+        if (rowmap) { const int mr = rowmap[row]; ok = mr >= 0; rel = mr; }   // (rows of a weight matrix)
+        rmask |= ok ? (1u << e) : 0u;
+        off[e] = (int)((ok ? rel : 0) * ld);
       }
+    } else {
+      const int kr = tid / (ROWS / 4), mq = (tid % (ROWS / 4)) * 4;
+      const int64_t left = rmax - (r0 + mq);
+      rmask = (unsigned)(left >= 4 ? 4 : (left > 0 ? left : 0));
+      k0ofs = kr;
+      base = P + (k0 + kr) * ld + (left > 0 ? r0 + mq : 0);
+#pragma unroll
+      for (int e = 0; e < NP; ++e) off[e] = (int)(e * KSTEP * ld);
     }
   }
-  // pieces of the chunk at k0; bit e of the result: piece e lies inside the problem
-  __device__ __forceinline__ unsigned load(int64_t k0, int64_t kend, vec_t (&v)[NP]) {
+  // pieces of the chunk at k0; bits 3e .. 3e + 2 of the result: how many leading elements of piece e lie inside the problem
+  __device__ __forceinline__ unsigned load(int64_t k0, int64_t kend, f32x4 (&v)[NP]) {
     unsigned mask = 0;
+    const int64_t kleft = kend - (k0 + k0ofs);
+    const unsigned kv = (unsigned)(kleft >= 4 ? 4 : (kleft > 0 ? kleft : 0));   // layout 0: valid elements along k
 #pragma unroll
     for (int e = 0; e < NP; ++e) {
-      const bool ok = rok[e] && (k0 + kofs[e] < kend);
-      v[e] = *(const vec_t*)(ok ? p[e] : safe);
-      mask |= ok ? (1u << e) : 0u;
-      p[e] += step;
+      unsigned nv;
+      if (LAY == 0) nv = ((rmask >> e) & 1u) ? kv : 0u;
+      else nv = (kleft > e * KSTEP) ? rmask : 0u;
+      v[e] = *(const f32x4u*)(nv ? base + off[e] : safe);
+      mask |= nv << (3 * e);
     }
+    base += step;
     return mask;
   }
 };
-template <int LAY, int ROWS, int VW>
-__device__ __forceinline__ void tile_store(float* __restrict__ T, const typename VecOf<VW>::type (&v)[ROWS / (8 * VW)], unsigned mask) {
-  typedef typename VecOf<VW>::type vec_t;
+template <int LAY, int ROWS>
+__device__ __forceinline__ void tile_store(float* __restrict__ T, const f32x4 (&v)[ROWS / 32], unsigned mask) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int e = 0; e < ROWS / (8 * VW); ++e) {
+  for (int e = 0; e < ROWS / 32; ++e) {
     const int f = tid + 256 * e;
-    vec_t x = v[e];
-    const bool ok = (mask >> e) & 1u;
+    f32x4 x = v[e];
+    const int nv = (int)((mask >> (3 * e)) & 7u);
 #pragma unroll
-    for (int q = 0; q < VW; ++q) x[q] = ok ? x[q] : 0.f;
-    if (LAY == 0) *(vec_t*)(T + (f / (32 / VW)) * LDK + (f % (32 / VW)) * VW) = x;
-    else *(vec_t*)(T + (f / (ROWS / VW)) * (ROWS + 4) + (f % (ROWS / VW)) * VW) = x;
+    for (int q = 0; q < 4; ++q) x[q] = (q < nv) ? x[q] : 0.f;
+    if (LAY == 0) *(f32x4*)(T + (f >> 3) * LDK + (f & 7) * 4) = x;
+    else *(f32x4*)(T + (f / (ROWS / 4)) * (ROWS + 4) + (f % (ROWS / 4)) * 4) = x;
   }
 }
 // fragments of the NT MFMA tiles of this wave for one 16-k group: frag[t][jj] <-> row base + step t + arow, k = 16 kg + 4 ag + jj
@@ -139,10 +184,10 @@ __device__ __forceinline__ void frag_read(const float* __restrict__ T, int row_b
 }
 
 // NTW: MFMA column tiles per wave: 4 (workgroup tile 128 x 128) or 2 (128 x 64: the last column block of N = 192, 64, ...)
-template <int LA, int LB, int EPI, int NTW, int VW>
+template <int LA, int LB, int EPI, int NTW>
 __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
   constexpr int TNn = 32 * NTW;
-  typedef typename VecOf<VW>::type vec_t;
+  constexpr bool TR = (EPI != EPI_ACCUM);   // result blocks transposed in the lanes (see the epilogue)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   auto As = [&](int i) -> float* { return lds + i * (2 * TILE_F); };              // buffer i: A tile | B tile
   auto Bs = [&](int i) -> float* { return lds + i * (2 * TILE_F) + TILE_F; };
@@ -194,10 +239,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
 #pragma unroll
     for (int jn = 0; jn < NTW; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  vec_t ra[TM / (8 * VW)], rb[TNn / (8 * VW)];
+  f32x4 ra[TM / 32], rb[TNn / 32];
   unsigned ma = 0, mb = 0;
-  TileLoader<LA, TM, VW> la;
-  TileLoader<LB, TNn, VW> lb;
+  TileLoader<LA, TM> la;
+  TileLoader<LB, TNn> lb;
   const int64_t brow0 = CELL ? 0 : n0, bmax = CELL ? (int64_t)4 * a.H : (int64_t)a.N;
   auto seg_init = [&](int seg) {   // K segment 0: (A, B) from k_beg; segment 1: (A2, B2) from 0
     if (seg == 0) { la.init(a.A, a.lda, m0, a.M, k_beg, nullptr); lb.init(a.B, a.ldb, brow0, bmax, k_beg, rmap); }
@@ -214,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
   if (nch > 0) {
     if (nch1 > 0) seg_init(0);
     load_chunk(0);
-    tile_store<LA, TM, VW>(As(0), ra, ma);
-    tile_store<LB, TNn, VW>(Bs(0), rb, mb);
+    tile_store<LA, TM>(As(0), ra, ma);
+    tile_store<LB, TNn>(Bs(0), rb, mb);
   }
   __syncthreads();
   // B fragment rows: plain tiles: (16 NTW) wn + 16 nt + arow; cell tiles: gate nt, units 16 wn + arow  ->  32 nt + 16 wn + arow
@@ -235,91 +280,125 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int jn = 0; jn < NTW; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][jj], fb[jn][jj], acc[i][jn], 0, 0, 0);
+          for (int jn = 0; jn < NTW; ++jn) acc[i][jn] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(fb[jn][jj], fa[i][jj], acc[i][jn], 0, 0, 0)
+                                          : __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][jj], fb[jn][jj], acc[i][jn], 0, 0, 0);
     }
     if (more) {
-      tile_store<LA, TM, VW>(As(cur ^ 1), ra, ma);   // (last read one chunk ago, before the previous barrier)
-      tile_store<LB, TNn, VW>(Bs(cur ^ 1), rb, mb);
+      tile_store<LA, TM>(As(cur ^ 1), ra, ma);   // (last read one chunk ago, before the previous barrier)
+      tile_store<LB, TNn>(Bs(cur ^ 1), rb, mb);
     }
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane & 15, row = 4 (lane >> 4) + reg
-  if constexpr (EPI == EPI_STORE || EPI == EPI_ACCUM) {
+  // ---- epilogue.  Except for +=, the MFMAs took the B fragment as their first operand, so the 16 x 16 blocks sit TRANSPOSED in the lanes:
+  // lane (arow, ag) holds row arow, columns 4 ag .. 4 ag + 3 -- four consecutive columns of one row per lane, stored 16 bytes
+  // at a time (the plain C/D layout gives a lane four ROWS of one column: 4-byte stores, 64-byte segments)
+  if constexpr (EPI == EPI_ACCUM) {
+    // += (split-K partial sums land as atomics): plain C/D layout, lane = column -- a wave's atomic covers 64-byte row segments
+    // (with the transposed blocks it would touch 16 rows x 16 bytes: measured 14 % slower on the dW GEMMs)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int jn = 0; jn < NTW; ++jn) {
         const int col = n0 + wn * (16 * NTW) + jn * 16 + arow;
         if (col >= a.N) continue;
-        const float bv = (EPI == EPI_STORE && a.bias) ? a.bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t row = m0 + wm * 64 + i * 16 + ag * 4 + r;
           if (row >= a.M) continue;
           float* dst = a.C + row * a.ldc + col;
-          if (EPI == EPI_STORE) *dst = acc[i][jn][r] + bv;
-          else if (a.use_atomic) unsafeAtomicAdd(dst, acc[i][jn][r]);
+          if (a.use_atomic) unsafeAtomicAdd(dst, acc[i][jn][r]);
           else *dst += acc[i][jn][r];
         }
       }
+  } else if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = m0 + wm * 64 + i * 16 + arow;
+      if (row >= a.M) continue;
+#pragma unroll
+      for (int jn = 0; jn < NTW; ++jn) {
+        const int col = n0 + wn * (16 * NTW) + jn * 16 + ag * 4;
+        const int nv = a.N - col;
+        if (nv <= 0) continue;
+        f32x4 v = acc[i][jn];
+        if (a.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (r < nv) v[r] += a.bias[col + r];
+        }
+        store4(a.C + row * a.ldc + col, v, nv);
+      }
+    }
   } else if constexpr (EPI == EPI_LSTM && NTW == 4) {
-    // nn.FastLSTM step (gate order i, g, f, o in the 4H rows; OneModel.lua:236): acc[i][q] = pre-activation of gate q, unit u
-    const int u = nt_idx * 32 + wn * 16 + arow;
-    if (u < a.H) {
-      float bq[4];
+    // nn.FastLSTM step (gate order i, g, f, o in the 4H rows; OneModel.lua:236): acc[i][q] = pre-activations of gate q, units u .. u + 3
+    const int u = nt_idx * 32 + wn * 16 + ag * 4;
+    const int nv = a.H - u;
+    if (nv > 0) {
+      f32x4 bq[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bq[q] = a.bias[q * a.H + u];
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 4; ++r) bq[q][r] = (r < nv) ? a.bias[q * a.H + u + r] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = m0 + wm * 64 + i * 16 + arow;
+        if (row >= a.M) continue;
+        const f32x4 cp = a.cprev ? load4(a.cprev + row * a.ldh + u, nv) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 ig, gg, fg, og, cc, hh;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t row = m0 + wm * 64 + i * 16 + ag * 4 + r;
-          if (row >= a.M) continue;
-          const float ig = sigm(acc[i][0][r] + bq[0]);
-          const float gg = tanhf(acc[i][1][r] + bq[1]);
-          const float fg = sigm(acc[i][2][r] + bq[2]);
-          const float og = sigm(acc[i][3][r] + bq[3]);
-          const float cp = a.cprev ? a.cprev[row * a.ldh + u] : 0.f;
-          const float cc = fg * cp + ig * gg;
-          a.cout[row * a.ldh + u] = cc;
-          a.hout[row * a.ldh + u] = og * tanhf(cc);
-          if (a.act) {
-            float* g = a.act + row * (int64_t)4 * a.H + u;
-            g[0] = ig; g[a.H] = gg; g[2 * a.H] = fg; g[3 * a.H] = og;
-          }
+          ig[r] = sigm(acc[i][0][r] + bq[0][r]);
+          gg[r] = tanh_fast(acc[i][1][r] + bq[1][r]);
+          fg[r] = sigm(acc[i][2][r] + bq[2][r]);
+          og[r] = sigm(acc[i][3][r] + bq[3][r]);
+          cc[r] = fg[r] * cp[r] + ig[r] * gg[r];
+          hh[r] = og[r] * tanh_fast(cc[r]);
         }
+        store4(a.cout + row * a.ldh + u, cc, nv);
+        store4(a.hout + row * a.ldh + u, hh, nv);
+        if (a.act) {
+          float* g = a.act + row * (int64_t)4 * a.H + u;
+          store4(g, ig, nv); store4(g + a.H, gg, nv); store4(g + 2 * a.H, fg, nv); store4(g + 3 * a.H, og, nv);
+        }
+      }
     }
   } else if constexpr (EPI == EPI_RNN) {
     // nn.Recurrence(nn.MaskZero(act(i2h x_t + h2h h_{t-1}), 1)) (OneModel.lua:240-266): N = H plain columns
 #pragma unroll
     for (int jn = 0; jn < NTW; ++jn) {
-      const int col = n0 + wn * (16 * NTW) + jn * 16 + arow;
-      if (col >= a.N) continue;
-      const float bv = a.bias[col] + a.bias2[col];
+      const int col = n0 + wn * (16 * NTW) + jn * 16 + ag * 4;
+      const int nv = a.N - col;
+      if (nv <= 0) continue;
+      f32x4 bv;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int r = 0; r < 4; ++r) bv[r] = (r < nv) ? a.bias[col + r] + a.bias2[col + r] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = m0 + wm * 64 + i * 16 + arow;
+        if (row >= a.M) continue;
+        const f32x4 pre = acc[i][jn] + bv;
+        const bool live = a.mask[row] != 0.f;
+        f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t row = m0 + wm * 64 + i * 16 + ag * 4 + r;
-          if (row >= a.M) continue;
-          const float p = acc[i][jn][r] + bv;
-          a.act[row * a.ldh + col] = p;
-          const float v = a.relu ? fmaxf(p, 0.f) : tanhf(p);
-          a.hout[row * a.ldh + col] = (a.mask[row] != 0.f) ? v : 0.f;
+          const float x = a.relu ? fmaxf(pre[r], 0.f) : tanh_fast(pre[r]);
+          v[r] = live ? x : 0.f;
         }
+        store4(a.act + row * a.ldh + col, pre, nv);
+        store4(a.hout + row * a.ldh + col, v, nv);
+      }
     }
   }
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-template <int LA, int LB, int EPI, int NTW, int VW>
+template <int LA, int LB, int EPI, int NTW>
 void launch(hipStream_t s, const TArgs& a, int split_k) {
   const size_t lds_bytes = (size_t)4 * TILE_F * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_tiled<LA, LB, EPI, NTW, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_tiled<LA, LB, EPI, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done = true;
   }
   const int64_t mgroups = (a.mtiles + 7) / 8;
@@ -330,28 +409,15 @@ void launch(hipStream_t s, const TArgs& a, int split_k) {
     b.split_major = 1;
     grid = dim3((unsigned)(((split_k + 7) / 8) * 8 * a.mtiles * a.ntiles), 1);
   }
-  hipLaunchKernelGGL((k_gemm_tiled<LA, LB, EPI, NTW, VW>), grid, dim3(256), lds_bytes, s, b);
+  hipLaunchKernelGGL((k_gemm_tiled<LA, LB, EPI, NTW>), grid, dim3(256), lds_bytes, s, b);
   HIP_TRY(hipGetLastError());
 }
 // the column range [n_begin, n_begin + ntiles * 32 NTW) of one problem
 template <int EPI, int NTW>
-void launch_layouts(hipStream_t s, const TArgs& a, int LA, int LB, int split_k, int VW) {
-  if (VW == 4) {
-    if (LA == 0 && LB == 0) launch<0, 0, EPI, NTW, 4>(s, a, split_k);
-    else if (LA == 0 && LB == 1) launch<0, 1, EPI, NTW, 4>(s, a, split_k);
-    else launch<1, 1, EPI, NTW, 4>(s, a, split_k);
-  } else {
-    if (LA == 0 && LB == 0) launch<0, 0, EPI, NTW, 2>(s, a, split_k);
-    else if (LA == 0 && LB == 1) launch<0, 1, EPI, NTW, 2>(s, a, split_k);
-    else launch<1, 1, EPI, NTW, 2>(s, a, split_k);
-  }
-}
-// widest vector all of (pointer, leading dimension, extent along the contiguous dimension) allow: 4, 2, or 0
-inline int vec_width(const void* p, int64_t ld, int64_t extent) {
-  const uintptr_t u = (uintptr_t)p;
-  if (!(u & 15) && !(ld & 3) && !(extent & 3)) return 4;
-  if (!(u & 7) && !(ld & 1) && !(extent & 1)) return 2;
-  return 0;
+void launch_layouts(hipStream_t s, const TArgs& a, int LA, int LB, int split_k) {
+  if (LA == 0 && LB == 0) launch<0, 0, EPI, NTW>(s, a, split_k);
+  else if (LA == 0 && LB == 1) launch<0, 1, EPI, NTW>(s, a, split_k);
+  else launch<1, 1, EPI, NTW>(s, a, split_k);
 }
 
 }  // namespace
@@ -364,16 +430,12 @@ bool run_tiled(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const fl
   if (M < 256 || N < 64 || K < 16) return false;
   int LA, LB;
   int64_t lda, ldb;
-  int VW = 4;
-  // A: contiguous along k (its extent along the vectors is K) or along m (M); B: along k (K) or along n -- there a vector may run
-  // past column N inside the row (ld >= N rounded up), which only feeds columns that are never stored
-  if (sAk == 1) { LA = 0; lda = sAm; VW = std::min(VW, vec_width(A, lda, K)); }
-  else if (sAm == 1) { LA = 1; lda = sAk; VW = std::min(VW, vec_width(A, lda, M)); }
+  if (sAk == 1) { LA = 0; lda = sAm; }        // A contiguous along k, or along m; B along k, or along n
+  else if (sAm == 1) { LA = 1; lda = sAk; }
   else return false;
-  if (sBk == 1) { LB = 0; ldb = sBn; VW = std::min(VW, vec_width(B, ldb, K)); }
-  else if (sBn == 1) { LB = 1; ldb = sBk; VW = std::min(VW, vec_width(B, ldb, 0)); if (VW && ldb < (((int64_t)N + VW - 1) / VW) * VW) return false; }
+  if (sBk == 1) { LB = 0; ldb = sBn; }
+  else if (sBn == 1) { LB = 1; ldb = sBk; }
   else return false;
-  if (VW == 0) return false;
   if (LA == 1 && LB == 0) return false;  // (no caller)
   TArgs a;
   memset(&a, 0, sizeof(a));
@@ -401,24 +463,19 @@ bool run_tiled(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const fl
   KPRN_REQUIRE(!(split_k > 1 && !accumulate), KPRN_E_ARG, "gemm: split-K needs accumulate mode");
   if (nt128 > 0) {
     a.ntiles = nt128; a.n_begin = 0;
-    if (accumulate) launch_layouts<EPI_ACCUM, 4>(s, a, LA, LB, split_k, VW); else launch_layouts<EPI_STORE, 4>(s, a, LA, LB, split_k, VW);
+    if (accumulate) launch_layouts<EPI_ACCUM, 4>(s, a, LA, LB, split_k); else launch_layouts<EPI_STORE, 4>(s, a, LA, LB, split_k);
   }
   if (nt64 > 0) {
     a.ntiles = nt64; a.n_begin = n_full * TN;
-    if (accumulate) launch_layouts<EPI_ACCUM, 2>(s, a, LA, LB, split_k, VW); else launch_layouts<EPI_STORE, 2>(s, a, LA, LB, split_k, VW);
+    if (accumulate) launch_layouts<EPI_ACCUM, 2>(s, a, LA, LB, split_k); else launch_layouts<EPI_STORE, 2>(s, a, LA, LB, split_k);
   }
   return true;
 }
 
-// vector width the fused step kernels can use for this layer's operands (0: shape not covered -> unfused kernels)
-static int step_vw(const float* X, int64_t ldx, int Din, const float* Hprev, int64_t ldh, int H, const float* Wi, const float* Wo) {
-  int vw = std::min(vec_width(X, ldx, Din), vec_width(Wi, Din, Din));
-  vw = std::min(vw, vec_width(Wo, H, H));
-  if (Hprev) vw = std::min(vw, vec_width(Hprev, ldh, H));
-  return vw;
-}
+// the fused step kernels take any layer shape from 256 paths up (below that the launch cannot fill the chip: unfused kernels)
 bool step_supported(const float* X, int64_t ldx, int Din, const float* Hprev, int64_t ldh, int H, const float* Wi, const float* Wo, int64_t N) {
-  return N >= 256 && step_vw(X, ldx, Din, Hprev, ldh, H, Wi, Wo) > 0;
+  (void)X; (void)ldx; (void)Din; (void)Hprev; (void)ldh; (void)H; (void)Wi; (void)Wo;
+  return N >= 256;
 }
 
 // one nn.FastLSTM step of one layer: gates = [x_t | h_{t-1}] [W_i2g | W_o2g]^T + b, cell in the epilogue.
@@ -433,7 +490,7 @@ void lstm_step(hipStream_t s, const float* X, int64_t ldx, int Din, const float*
   a.cprev = Cprev; a.cout = Cout; a.hout = Hout; a.ldh = ldh; a.act = act;
   a.mtiles = (N + TM - 1) / TM; a.ntiles = (H + 31) / 32;
   a.kchunk = ((Din + TK - 1) / TK) * TK;
-  if (step_vw(X, ldx, Din, Hprev, ldh, H, Wi, Wo) == 4) launch<0, 0, EPI_LSTM, 4, 4>(s, a, 1); else launch<0, 0, EPI_LSTM, 4, 2>(s, a, 1);
+  launch<0, 0, EPI_LSTM, 4>(s, a, 1);
 }
 
 // one nn.Recurrence step: pre = i2h x_t + b_i2h + h2h h_{t-1} + b_h2h, h = MaskZero(act(pre)); pre is kept for the backward
@@ -447,7 +504,7 @@ void rnn_step(hipStream_t s, const float* X, int64_t ldx, int Din, const float* 
   a.hout = Hout; a.act = pre; a.ldh = ldh;
   a.mtiles = (N + TM - 1) / TM; a.ntiles = (H + TN - 1) / TN;
   a.kchunk = ((Din + TK - 1) / TK) * TK;
-  if (step_vw(X, ldx, Din, Hprev, ldh, H, Wi, Wh) == 4) launch<0, 0, EPI_RNN, 4, 4>(s, a, 1); else launch<0, 0, EPI_RNN, 4, 2>(s, a, 1);
+  launch<0, 0, EPI_RNN, 4>(s, a, 1);
 }
 
 }  // namespace gemm

@@ -71,7 +71,8 @@ template <typename T>
 static T* dalloc(int64_t n) {
   void* p = nullptr;
   if (n <= 0) n = 1;
-  hipError_t e = hipMalloc(&p, (size_t)n * sizeof(T));
+  // 64 bytes of slack: the tiled GEMMs fetch 16-byte vectors that may straddle the end of a matrix's last row (gemm_tiled.hip)
+  hipError_t e = hipMalloc(&p, (size_t)n * sizeof(T) + 64);
   if (e != hipSuccess) throw KprnError{KPRN_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e)};
   return (T*)p;
 }

@@ -17,6 +17,10 @@ cases = [
     ("C4 dW      [393k,1536]^T x [393k,384]", 2, NP * 6, 1536, 384, None),
     ("shipped rnn step (H=250, Din=200)", 4, NP, 250, 200, lambda M, N, K: 2 * M * N * (K + N)),
     ("shipped dx [393k,250]x[250,200]", 1, NP * 6, 200, 250, None),
+    ("probe rnn step (H=256, Din=200)", 4, NP, 256, 200, lambda M, N, K: 2 * M * N * (K + N)),
+    ("probe rnn step (H=256, Din=192)", 4, NP, 256, 192, lambda M, N, K: 2 * M * N * (K + N)),
+    ("probe rnn step (H=252, Din=200)", 4, NP, 252, 200, lambda M, N, K: 2 * M * N * (K + N)),
+    ("probe rnn step (H=512, Din=512)", 4, NP, 512, 512, lambda M, N, K: 2 * M * N * (K + N)),
     ("A generic fwd step (H=64)", 3, NP, 64, 64, lambda M, N, K: 2 * M * 4 * N * (K + N)),
 ]
 sel = sys.argv[1:]

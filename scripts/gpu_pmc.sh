@@ -11,7 +11,7 @@ rocprofv3 -L 2>/dev/null | grep -i -E "mfma|^.*SQ_BUSY_CU|SQ_WAVE_CYCLES|SQ_ACTI
 pass() {  # name, counters...
   local name="$1"; shift
   timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d "$OUT/raw_$name" -o p --output-format csv -- \
-      python "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-alt --no-kernel-events "${EXTRA[@]}" > "$OUT/$name.log" 2>&1
+      python "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-alt --no-extra-regions --batch-feed resident --no-kernel-events "${EXTRA[@]}" > "$OUT/$name.log" 2>&1
   echo "rocprof exit: $?" >> "$OUT/$name.log"
   find "$OUT/raw_$name" -name "*counter_collection.csv" -exec cp {} "$OUT/$name.csv" \;
   rm -rf "$OUT/raw_$name"
@@ -27,7 +27,7 @@ d = json.load(open(sys.argv[1] + "/kernels.json"))
 pps = 65536
 args = sys.argv[2:]
 if "--paths-per-step" in args: pps = int(args[args.index("--paths-per-step") + 1])
-print(json.dumps({"paths_per_step": pps, "command": "python bench.py --steps 6 --warmup 2 " + " ".join(args), "kernels": d}, indent=1, sort_keys=True))
+print(json.dumps({"paths_per_step": pps, "command": "python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-alt --no-extra-regions --batch-feed resident --no-kernel-events " + " ".join(args), "kernels": d}, indent=1, sort_keys=True))
 PY
 cat "$OUT/summary.json"
 # the raw per-dispatch csv files are large; keep the summary + a head

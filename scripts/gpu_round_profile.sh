@@ -28,3 +28,18 @@ for f in ("bench_$TAG", "bench_${TAG}_train_only", "bench_${TAG}_score_only", "b
         print(f, "unreadable", e)
 PY
 head -12 gpurun_out/prof_$TAG/kernel_stats.csv
+# the other configurations' lines (parity-tested configs, not the headline): dims B, shipped, configs[3] bf16 / fp32, configs[4], DP path
+extra() { name=$1; shift; timeout 600 python bench.py --no-cpu-baseline --no-alt --no-extra-regions --batch-feed resident "$@" > gpurun_out/bench_${TAG}_$name.log 2>&1
+  json_line gpurun_out/bench_${TAG}_$name.log gpurun_out/bench_${TAG}_$name.json
+  python -c "
+import json; d=json.load(open('gpurun_out/bench_${TAG}_$name.json')); print('$name', d['value'], d['ms_per_step'], d.get('roofline'))" || tail -5 gpurun_out/bench_${TAG}_$name.log; }
+extra dimsB --dims B --steps 8 --warmup 3
+extra shipped --dims shipped --steps 8 --warmup 3
+extra c4_bf16 --dims C4 --steps 8 --warmup 3
+extra c4_fp32 --dims C4 --c4-fp32 --steps 6 --warmup 2
+extra force_dp --force-dp
+timeout 300 python bench.py --workload c5 --steps 40 --warmup 5 > gpurun_out/bench_${TAG}_c5.log 2>&1; json_line gpurun_out/bench_${TAG}_c5.log gpurun_out/bench_${TAG}_c5.json
+python -c "
+import json; d=json.load(open('gpurun_out/bench_${TAG}_c5.json')); print('c5', d['value'], d['ms_per_step'], d.get('streaming'), d.get('roofline'), d.get('cpu_baseline'))"
+timeout 300 python scripts/gpu_dp_sim.py > gpurun_out/dp_sim_$TAG.json 2> gpurun_out/dp_sim_$TAG.log; tail -c 1500 gpurun_out/dp_sim_$TAG.json
+timeout 300 python scripts/gpu_gemm_bench.py > gpurun_out/gemm_bench_$TAG.txt 2>&1; tail -30 gpurun_out/gemm_bench_$TAG.txt
