@@ -38,6 +38,22 @@ int kprn_forward(kprn_handle*, const int32_t*, int32_t, int32_t, int32_t, int32_
 int kprn_train_step(kprn_handle*, const int32_t*, int32_t, int32_t, int32_t, int32_t, const float*, int32_t, const kprn_opt*, float*);
 int kprn_save(kprn_handle*, const char*);
 int kprn_load(kprn_handle*, const char*);
+/* batches resident in HBM and the streaming feed (BatcherFileList's GPU double buffer, BatcherFileList.lua:53-96) */
+int kprn_batch_create(kprn_handle*, const int32_t*, const float*, int32_t, int32_t, int32_t, int32_t, kprn_batch**);
+void kprn_batch_destroy(kprn_handle*, kprn_batch*);
+int kprn_batch_slot_reserve(kprn_handle*, kprn_batch**, int32_t, int64_t, int32_t, int32_t, int32_t);
+int kprn_batch_feed_async(kprn_handle*, kprn_batch**, const int32_t*, const float*, int32_t, int32_t, int32_t, int32_t);
+int kprn_batch_feed_rows_async(kprn_handle*, kprn_batch**, const int32_t*, const float*, int64_t, const int64_t*, int32_t, int32_t, int32_t, int32_t);
+int kprn_host_alloc(kprn_handle*, size_t, void**);
+int kprn_host_free(kprn_handle*, void*);
+int kprn_forward_batch(kprn_handle*, const kprn_batch*, int32_t, float*, float*, float*, float*);
+int kprn_forward_batch_async(kprn_handle*, const kprn_batch*, int32_t);
+int kprn_read_probs(kprn_handle*, float*, int32_t);
+int kprn_train_step_batch(kprn_handle*, const kprn_batch*, int32_t, const kprn_opt*, float*);
+int kprn_read_loss(kprn_handle*, float*);
+int kprn_read_loss_sum(kprn_handle*, float*, int32_t*, int32_t);
+int kprn_set_option(kprn_handle*, const char*, const char*);
+int kprn_sync(kprn_handle*);
 ]]
 
 local C = ffi.load('kprn')
@@ -103,6 +119,46 @@ function Net:trainBatch(inputs, targets, classId, optConfig, optInfo)
   local loss = ffi.new('float[1]')
   check(self.h, C.kprn_train_step(self.h, to_int32(inputs), B, P, T, F, lab, classId or 1, opt, loss))
   return loss[0]
+end
+
+-- ---- the fast path: what Batcher / BatcherFileList / MyOptimizer:train call when the data stays in the engine's hands ----------
+-- A file's tensors converted ONCE (Batcher.lua:12-16 loads labels / data): int32 ids [n,P,T,F] and float labels [n] in host memory.
+function M.file_arrays(labels, data)
+  local n = data:size(1)
+  local lab = ffi.new('float[?]', n)
+  local ld = labels:contiguous():data()
+  for i = 0, n - 1 do lab[i] = ld[i] end
+  return {n = n, P = data:size(2), T = data:size(3), F = data:size(4), idx = to_int32(data), labels = lab}
+end
+
+local function fill_opt(optConfig, optInfo)
+  local opt = ffi.new('kprn_opt')
+  local optim = rawget(_G, 'optim') or require 'optim'
+  opt.method = (optInfo.optimMethod == optim.adam) and 1 or 0
+  opt.lr, opt.beta1, opt.beta2, opt.eps = optConfig.learningRate, optConfig.beta1 or 0.9, optConfig.beta2 or 0.999, optConfig.epsilon or 1e-8
+  opt.lr_decay = optConfig.learningRateDecay or 0
+  opt.regularize, opt.use_grad_clip = optInfo.regularize, optInfo.useGradClip and 1 or 0
+  opt.grad_clip_norm, opt.l2 = optInfo.gradClipNorm, optInfo.l2
+  return opt
+end
+
+-- BatcherFileList:populateGPUTensor for a shuffled epoch: minibatch = rows `rows` (0-based int64 cdata, count B) of `file`
+-- (M.file_arrays); slot: ffi.new('kprn_batch*[1]') kept by the caller, refilled in place.  Returns at once; the gather, the
+-- index build and the upload run under the step queued next.
+function Net:feedRows(slot, file, rows, B)
+  check(self.h, C.kprn_batch_feed_rows_async(self.h, slot, file.idx, file.labels, file.n, rows, B, file.P, file.T, file.F))
+end
+
+-- MyOptimizer:trainBatch on a fed slot; no host synchronisation (the epoch's error comes from Net:lossSum)
+function Net:trainBatchSlot(slot, classId, optConfig, optInfo)
+  check(self.h, C.kprn_train_step_batch(self.h, slot[0], classId or 1, fill_opt(optConfig, optInfo), nil))
+end
+
+function Net:accumulateLoss(on) check(self.h, C.kprn_set_option(self.h, 'loss_accumulate', on and '1' or '0')) end
+function Net:lossSum(reset)  -- -> totalError, steps since the last reset (MyOptimizer.lua:148-156)
+  local s, n = ffi.new('float[1]'), ffi.new('int32_t[1]')
+  check(self.h, C.kprn_read_loss_sum(self.h, s, n, reset and 1 or 0))
+  return s[0], n[0]
 end
 
 function Net:zeroPadTokens() check(self.h, C.kprn_zero_pad_tokens(self.h)) end

@@ -146,6 +146,12 @@ void kprn_batch_destroy(kprn_handle* h, kprn_batch* b);
  * unchanged until then; only page-locked host memory (kprn_host_alloc) is copied without holding the calling thread.      */
 int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx, const float* labels,
                           int32_t B, int32_t P, int32_t T, int32_t F);
+/* The same for a SHUFFLED epoch (Batcher:shuffle, Batcher.lua:35-41, permutes the file's tensors; OneModel.lua:326 turns it on):
+ * pair i of the minibatch is row rows[i] (0-based, < n_rows) of the file's arrays data [n_rows,P,T,F] / labels [n_rows], gathered
+ * by the feed's worker threads straight into the upload image -- the caller permutes nothing and copies nothing.  data and rows
+ * must stay unchanged until the slot's first use; labels are read before the call returns.                              */
+int kprn_batch_feed_rows_async(kprn_handle* h, kprn_batch** slot, const int32_t* data, const float* labels, int64_t n_rows,
+                               const int64_t* rows, int32_t B, int32_t P, int32_t T, int32_t F);
 /* BatcherFileList.lua:53-60: size a slot once for the largest minibatch it will hold (max_pairs pairs, max_paths paths of T steps), so that
  * no later feed allocates (an allocation waits for the device).  *slot NULL: a new, empty slot.  Capacities only ever grow.           */
 int kprn_batch_slot_reserve(kprn_handle* h, kprn_batch** slot, int32_t max_pairs, int64_t max_paths, int32_t T, int32_t F, int32_t with_labels);
@@ -199,6 +205,10 @@ int kprn_train_step_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id,
                           float* loss /* NULL = async */);
 /* loss of the most recent backward, once the stream has drained */
 int kprn_read_loss(kprn_handle* h, float* loss);
+/* kprn_set_option(h, "loss_accumulate", "1"): every backward adds its loss to a running sum on the device; this reads the sum and
+ * the number of steps in it (MyOptimizer.lua:148-156 prints totalError / steps every gradientStepCounter steps and per epoch), so
+ * the training loop needs no host sync per step.  reset != 0 starts a new sum.                                          */
+int kprn_read_loss_sum(kprn_handle* h, float* sum, int32_t* steps, int32_t reset);
 int kprn_sync(kprn_handle* h);
 
 /* ---- data-parallel hooks (new design; the reference is single-device) -----

@@ -129,6 +129,20 @@ class Batch:
         self.engine._ck(self.engine.L.kprn_batch_feed_async(self.engine.h, C.byref(self.ptr), _fp(idx), _fp(lab), self.B, self.P, self.T, self.F))
         return self
 
+    def refill_rows(self, data, labels, rows):
+        """shuffled streaming feed (kprn_batch_feed_rows_async): pair i of the minibatch = row rows[i] of the file's arrays
+        data [n,P,T,F] int32 / labels [n] float32, gathered by the engine's worker threads -- no host-side copy here."""
+        if data.dtype != np.int32 or not data.flags.c_contiguous or data.ndim != 4:
+            raise KprnError(E_ARG, "data must be a C-contiguous int32 [n,P,T,F] array")
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.float32)
+        self.B, (_, self.P, self.T, self.F) = int(rows.shape[0]), (int(x) for x in data.shape)
+        self.has_labels = lab is not None
+        self._src = (data, lab, rows)   # alive until the worker threads have read them
+        self.engine._ck(self.engine.L.kprn_batch_feed_rows_async(self.engine.h, C.byref(self.ptr), _fp(data), _fp(lab), C.c_int64(int(data.shape[0])), _fp(rows),
+                                                                   self.B, self.P, self.T, self.F))
+        return self
+
     @property
     def n_paths(self):
         return self.B * self.P
@@ -277,6 +291,13 @@ class Engine:
             return Batch(self, idx, labels, feed=True)
         return slot.refill(idx, labels)
 
+    def feed_rows(self, data, labels, rows, slot=None):
+        """the feed for a shuffled order: rows of the file's arrays, gathered inside the engine (Batch.refill_rows)"""
+        if slot is None:
+            slot = Batch.__new__(Batch)
+            slot.engine, slot.ptr, slot._src = self, C.c_void_p(), None
+        return slot.refill_rows(data, labels, rows)
+
     def host_array(self, shape, dtype=np.int32):
         """numpy array in page-locked host memory (kprn_host_alloc): the staging buffers of the streaming feed"""
         dtype = np.dtype(dtype)
@@ -354,6 +375,12 @@ class Engine:
         loss = C.c_float()
         self._ck(self.L.kprn_read_loss(self.h, C.byref(loss)))
         return float(loss.value)
+
+    def loss_sum(self, reset=True):
+        """(sum of the losses, number of steps) accumulated on the device since the last reset (option loss_accumulate = 1)"""
+        v, n = C.c_float(), C.c_int32()
+        self._ck(self.L.kprn_read_loss_sum(self.h, C.byref(v), C.byref(n), int(bool(reset))))
+        return float(v.value), int(n.value)
 
     def sync(self):
         self._ck(self.L.kprn_sync(self.h))

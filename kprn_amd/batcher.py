@@ -27,25 +27,48 @@ class Batcher:
         self.numFeatureTemplates = self.data.shape[3]
         self.rng = rng if rng is not None else np.random.default_rng()
         self.epoch = 0
+        self.perm = None   # shuffled order: row perm[i] of the file's tensors stands at position i
         if self.doShuffle:
             self.shuffle()
         self.batchSize = int(batchSize)
         self.curStart = 0
 
     def shuffle(self):  # Batcher.lua:35-41
+        """The reference permutes the tensors themselves (labels:index(1, inds), data:index(1, inds)); here the permutation is
+        kept and composed -- same order, but an epoch's reshuffle moves 8 bytes per pair instead of the whole file, and the
+        engine gathers each minibatch's rows itself (kprn_batch_feed_rows_async)."""
         if self.doShuffle:
             inds = self.rng.permutation(self.labels.shape[0])
-            self.labels = self.labels[inds]
-            self.data = self.data[inds]
+            self.perm = inds if self.perm is None else self.perm[inds]
 
-    def getBatch(self):  # Batcher.lua:43-54 -> labels[B], data[B,P,T,F] (views) or None
+    def _next_span(self):
         dataSize = self.labels.shape[0]
         start = self.curStart
         if start >= dataSize:
             return None
         end = min(start + self.batchSize, dataSize)
         self.curStart = end
-        return self.labels[start:end], self.data[start:end]
+        return start, end
+
+    def getBatch(self):  # Batcher.lua:43-54 -> labels[B], data[B,P,T,F] (views; copies of the permuted rows when shuffled) or None
+        span = self._next_span()
+        if span is None:
+            return None
+        start, end = span
+        if self.perm is None:
+            return self.labels[start:end], self.data[start:end]
+        rows = self.perm[start:end]
+        return self.labels[rows], self.data[rows]
+
+    def getBatchRows(self):
+        """-> (labels of the whole file, data of the whole file, rows of this minibatch) or None: what getBatch would return is
+        (labels[rows], data[rows]); nothing is copied"""
+        span = self._next_span()
+        if span is None:
+            return None
+        start, end = span
+        rows = np.arange(start, end, dtype=np.int64) if self.perm is None else self.perm[start:end]
+        return self.labels, self.data, rows
 
     def reset(self):  # Batcher.lua:56-59
         self.curStart = 0
@@ -100,27 +123,29 @@ class BatcherFileList:
         (the fixed packing capacity of the data-parallel row exchange, kprn_amd/dp.py)"""
         return max((min(self.batchSize, b.labels.shape[0]) * b.numPaths * b.numTokensInPath for b in self.batchers), default=0)
 
-    def getBatchInternal(self):  # CPU path, BatcherFileList.lua:133-146
+    def getBatchInternal(self, rows=False):  # CPU path, BatcherFileList.lua:133-146
         if self.currentIndex >= self.numBatchers:
             self.currentIndex = 1
         for i in range(self.currentIndex, self.numBatchers + 1):
             batcher = self.batchers[self.index[i - 1] - 1]
-            got = batcher.getBatch()
+            got = batcher.getBatchRows() if rows else batcher.getBatch()
             if got is not None:
                 self.currentIndex = i
-                return got[0], got[1], batcher.getClassId(), (self.index[i - 1] - 1, batcher.curStart - got[0].shape[0], batcher.epoch)
+                n = got[2].shape[0] if rows else got[0].shape[0]
+                return got, n, batcher.getClassId(), (self.index[i - 1] - 1, batcher.curStart - n, batcher.epoch)
         return None
 
-    def getBatch(self, with_key=False):  # BatcherFileList.lua:169-188
+    def getBatch(self, with_key=False, rows=False):  # BatcherFileList.lua:169-188
+        """-> (labels, data, n, classId[, key]) or None.  rows=True: (labels_all, data_all, rows) of the file instead of the two
+        minibatch tensors -- (labels, data, rows, n, classId[, key]) -- for consumers that gather the rows themselves."""
         while self.startIndex <= self.numBatchers:
-            got = self.getBatchInternal()
+            got = self.getBatchInternal(rows)
             if got is None:
                 self.startIndex = self.endIndex + 1
                 self.endIndex = min(self.startIndex + self.maxBatches - 1, self.numBatchers)
                 self.currentIndex = self.startIndex
             else:
-                labels, data, classId, key = got
-                if with_key:
-                    return labels, data, labels.shape[0], classId, key
-                return labels, data, labels.shape[0], classId
+                arrays, n, classId, key = got
+                out = tuple(arrays) + (n, classId)
+                return out + (key,) if with_key else out
         return None

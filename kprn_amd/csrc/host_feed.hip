@@ -99,6 +99,14 @@ static inline void span(int64_t n, int part, int nparts, int64_t* lo, int64_t* h
   *hi = std::min<int64_t>(n, *lo + per);
 }
 
+void gather_rows(int32_t* dst, const int32_t* src, int64_t row_words, const int64_t* rows, int64_t n, int nth) {
+  parallel(std::max(1, nth), [&](int part, int nparts) {
+    int64_t lo, hi;
+    span(n, part, nparts, &lo, &hi);
+    for (int64_t i = lo; i < hi; ++i) memcpy(dst + i * row_words, src + rows[i] * row_words, (size_t)row_words * sizeof(int32_t));
+  });
+}
+
 static int bits_for(int64_t v) { int b = 1; while (((int64_t)1 << b) < v) ++b; return b; }
 
 // stable LSD radix sort of (key, val) pairs, 11-bit digits, parallel over contiguous chunks: chunk c counts its digits, the

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_loss_stage(const float* __restrict__ S,
 }
 
 // loss = fixed-order sum of the per-workgroup partials (reproducible)
-__global__ void k_sum_partials(const float* __restrict__ partial, int n, float* __restrict__ out) {
+__global__ void k_sum_partials(const float* __restrict__ partial, int n, float* __restrict__ out, int accumulate) {
   __shared__ float pl[256];
   float s = 0.f;
   for (int base = 0; base < n; base += 256) {
@@ -429,7 +429,10 @@ __global__ void k_sum_partials(const float* __restrict__ partial, int n, float* 
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out = s;
+  if (threadIdx.x == 0) {
+    out[0] = s;
+    if (accumulate) { out[1] += s; out[2] += 1.0f; }   // running sum / count of the losses since the last kprn_read_loss_sum
+  }
 }
 
 // nn.Linear(H,46) backward restricted to the selected column (OneModel.lua:275; Select at MyOptimizer.lua:126)
@@ -806,8 +809,8 @@ void loss_stage(hipStream_t s, const float* S, const float* labels, const float*
 
 int loss_partials(int B) { return (B + LOSS_PPW - 1) / LOSS_PPW; }
 
-void sum_partials(hipStream_t s, const float* partial, int n, float* out) {
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n, out);
+void sum_partials(hipStream_t s, const float* partial, int n, float* out, int accumulate) {
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n, out, accumulate);
   CHECK_LAUNCH();
 }
 

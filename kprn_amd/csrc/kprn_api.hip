@@ -618,7 +618,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
 // the loss of the last backward = fixed-order sum of the loss stage's per-workgroup partials, formed on demand
 static void form_loss(kprn_handle* h) {
   if (h->loss_pending <= 0) return;
-  kk::sum_partials(h->stream, h->loss_partial, h->loss_pending, h->d_loss);
+  kk::sum_partials(h->stream, h->loss_partial, h->loss_pending, h->d_loss, h->loss_accumulate);
   h->loss_pending = 0;
 }
 
@@ -645,6 +645,7 @@ static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int
                    invB, /*pooled=*/nullptr, /*probs=*/nullptr, w.sel, w.dS, fusedp ? b->slot_of : nullptr, gd + h->off_outW + (int64_t)cid * c.H, gd + h->off_outb + cid, h->loss_partial,
                    have_tj ? &tj : nullptr);
     h->loss_pending = kk::loss_partials(b->B);
+    if (h->loss_accumulate) form_loss(h);   // (one single-workgroup launch; otherwise the sum is formed when somebody asks)
   }
   view_step_rows(h, b);
   join_score(h);
@@ -1138,7 +1139,7 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
 // then moves each image with ONE copy, behind the positions the main / scoring streams had when the refill was requested, and
 // keeps a single copy in flight (several streams' worth of small concurrent copies fell back from the DMA engines to copy
 // kernels, which take CUs from the persistent kernels: measured, profiles/r02)
-static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const float* labels) {
+static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const float* labels, const int64_t* rows) {
   const int32_t B = b->B, P = b->P, T = b->T, F = b->F;
   const int64_t nsteps = (int64_t)B * P * T, N = (int64_t)B * P, n_index = b->n_index;
   if (!h->feed_pool) {
@@ -1184,7 +1185,8 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
   const int kcap = b->kcap, nth = std::max(1, h->feed_threads), dev = h->cfg.device_id;
   int32_t* hs = b->hs;
   int32_t* hw = b->hw.data();
-  if (labels) memcpy(hs + l.labels, labels, (size_t)B * sizeof(float));
+  if (labels && rows) { float* hl = (float*)(hs + l.labels); for (int32_t i = 0; i < B; ++i) hl[i] = labels[rows[i]]; }
+  else if (labels) memcpy(hs + l.labels, labels, (size_t)B * sizeof(float));
   hs[l.flag] = 0;
   b->host_built = true;
   auto done = std::make_shared<std::promise<void>>();
@@ -1194,10 +1196,15 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
   hostfeed::submit((hostfeed::Pool*)h->feed_pool, [=]() {
     try {
       kprn_batch::HostResult* r = &b->hres;
-      hostfeed::build(g, idx, kcap, nth, want_index, r, hs + l.idx_s, hs + l.perm, hs + l.slot_of, hs + l.tile_k, hs + l.pmeta, hs + l.key, hs + l.pos,
+      const int32_t* src = idx;
+      if (rows) {   // pair i of the minibatch = row rows[i] of the file's array: gathered straight into the image
+        hostfeed::gather_rows(hs + l.idx, idx, (int64_t)P * T * F, rows, B, nth);
+        src = hs + l.idx;
+      }
+      hostfeed::build(g, src, kcap, nth, want_index, r, hs + l.idx_s, hs + l.perm, hs + l.slot_of, hs + l.tile_k, hs + l.pmeta, hs + l.key, hs + l.pos,
                       hs + l.uniq, hw, hw + n_index, hw + 2 * n_index, hw + 3 * n_index);
       if (!r->bad) {
-        if (want_idx) memcpy(hs + l.idx, idx, (size_t)(nsteps * F) * sizeof(int32_t));
+        if (want_idx && !rows) memcpy(hs + l.idx, idx, (size_t)(nsteps * F) * sizeof(int32_t));
         hs[l.cnt] = r->n_uniq;
       }
     } catch (...) { done->set_exception(std::current_exception()); return; }
@@ -1221,8 +1228,7 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
   });
 }
 
-int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx, const float* labels, int32_t B, int32_t P, int32_t T, int32_t F) {
-  API_BEGIN(h)
+static void feed_impl(kprn_handle* h, kprn_batch** slot, const int32_t* idx, const float* labels, const int64_t* rows, int32_t B, int32_t P, int32_t T, int32_t F) {
   KPRN_REQUIRE(slot, KPRN_E_ARG, "slot is NULL");
   check_batch_args(h, idx, B, P, T, F);
   if (!h->feed_build_host && !h->feed_stream) {
@@ -1261,7 +1267,7 @@ int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx,
     batch_reserve(h, b, B, P, T, F, labels != nullptr, quiesce);
     if (!b->ev_ready) HIP_TRY(hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming));
     if (h->feed_build_host) {
-      feed_host(h, b, idx, labels);
+      feed_host(h, b, idx, labels, rows);
     } else {
       b->host_built = false; b->has_index = true; b->idx_valid = true;
       const int64_t N = (int64_t)B * P;
@@ -1274,7 +1280,16 @@ int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx,
       HIP_TRY(hipEventRecord(h->ev_feed_fork, h->stream));
       HIP_TRY(hipStreamWaitEvent(h->feed_stream, h->ev_feed_fork, 0));
       if (h->score_pending) HIP_TRY(hipStreamWaitEvent(h->feed_stream, h->ev_score_done, 0));
-      batch_enqueue(h, b, idx, labels, h->feed_stream, h->feed_scratch, h->feed_scratch_bytes);
+      const int32_t* src = idx;
+      const float* lsrc = labels;
+      if (rows) {   // device build: the rows are gathered by the calling thread into the slot's host scratch first
+        const int64_t rw = (int64_t)P * T * F;
+        if ((int64_t)b->hw.size() < (int64_t)B * rw + B) b->hw.resize((size_t)((int64_t)B * rw + B));
+        hostfeed::gather_rows(b->hw.data(), idx, rw, rows, B, std::max(1, h->feed_threads));
+        src = b->hw.data();
+        if (labels) { float* hl = (float*)(b->hw.data() + (int64_t)B * rw); for (int32_t i = 0; i < B; ++i) hl[i] = labels[rows[i]]; lsrc = hl; }
+      }
+      batch_enqueue(h, b, src, lsrc, h->feed_stream, h->feed_scratch, h->feed_scratch_bytes);
       HIP_TRY(hipEventRecord(b->ev_ready, h->feed_stream));
     }
     b->pending = true;
@@ -1283,6 +1298,20 @@ int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx,
     throw;
   }
   *slot = b;
+}
+
+int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx, const float* labels, int32_t B, int32_t P, int32_t T, int32_t F) {
+  API_BEGIN(h)
+  feed_impl(h, slot, idx, labels, nullptr, B, P, T, F);
+  API_END(h)
+}
+
+int kprn_batch_feed_rows_async(kprn_handle* h, kprn_batch** slot, const int32_t* data, const float* labels, int64_t n_rows, const int64_t* rows, int32_t B,
+                               int32_t P, int32_t T, int32_t F) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(rows, KPRN_E_ARG, "rows is NULL");
+  for (int32_t i = 0; i < B; ++i) KPRN_REQUIRE(rows[i] >= 0 && rows[i] < n_rows, KPRN_E_ARG, "a row index is outside 0..n_rows-1");
+  feed_impl(h, slot, data, labels, rows, B, P, T, F);
   API_END(h)
 }
 
@@ -1545,6 +1574,19 @@ int kprn_read_loss(kprn_handle* h, float* loss) {
   API_END(h)
 }
 
+int kprn_read_loss_sum(kprn_handle* h, float* sum, int32_t* steps, int32_t reset) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(sum && steps, KPRN_E_ARG, "sum / steps is NULL");
+  form_loss(h);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  HIP_TRY(hipMemcpyAsync(v, h->d_loss, 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (reset) HIP_TRY(hipMemsetAsync(h->d_loss + 1, 0, 2 * sizeof(float), h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *sum = v[1]; *steps = (int32_t)v[2];
+  prof_drain(h);
+  API_END(h)
+}
+
 int kprn_sync(kprn_handle* h) {
   API_BEGIN(h)
   if (h->score_stream) HIP_TRY(hipStreamSynchronize(h->score_stream));
@@ -1761,6 +1803,8 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // kprn_forward_batch_async on a second stream (fused path): the scoring pass shares the chip with the work enqueued after it
     join_score(h);
     h->score_overlap = atoi(value) ? 1 : 0;
+  } else if (strcmp(key, "loss_accumulate") == 0) {
+    h->loss_accumulate = atoi(value) ? 1 : 0;
   } else if (strcmp(key, "feed_build") == 0) {
     if (strcmp(value, "host") == 0) h->feed_build_host = 1;
     else if (strcmp(value, "device") == 0) h->feed_build_host = 0;

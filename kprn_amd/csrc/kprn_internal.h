@@ -152,6 +152,7 @@ struct kprn_handle {
   int64_t caught_serial = -1, caught_step = -1;  // batch whose entity rows are current to opt_step
   int64_t grads_serial = -1;       // batch the gradients in g_We / g_dense came from
   int64_t next_serial = 1;
+  int loss_accumulate = 0;   // option: every backward adds its loss to d_loss[1] (count in d_loss[2]) -- an epoch's error without a host sync per step
   float* loss_partial = nullptr; int64_t loss_partial_cap = 0; int loss_pending = 0;  // >0: d_loss = sum of that many partials, not formed yet
   // packing buffers for the data-parallel exchange
   int32_t* dp_mark = nullptr;   // [Ve] flags of the exchange's union (all zero between steps)
@@ -235,7 +236,7 @@ struct TransposeJob { const float* W[4]; float* WT[4]; int n; };
 void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
                 int literal, float invB, float* pooled, float* probs, float* sel, float* dS, const int32_t* slot_of /*nullable: dS[slot_of[n]]*/,
                 float* gW_row, float* gb_c, float* partial, const TransposeJob* tj = nullptr);
-void sum_partials(hipStream_t s, const float* partial, int n, float* out);
+void sum_partials(hipStream_t s, const float* partial, int n, float* out, int accumulate);
 int loss_partials(int B);  // number of per-workgroup loss partials the loss stage writes for B pairs
 void zero_pad3(hipStream_t s, float* a, int na, float* b, int nb, float* c, int nc);
 void head_bwd(hipStream_t s, const float* dS, const float* hT, const float* Wout, int64_t N, int H, int cid, float* dH, float* gWout, float* gbout);
@@ -402,6 +403,8 @@ class Pool;
 Pool* make_pool(int workers);
 void free_pool(Pool* p);
 std::future<void> submit(Pool* p, std::function<void()> fn);
+// dst[i] = src row rows[i] (row_words int32 each), i < n: a shuffled minibatch read straight out of the file's array
+void gather_rows(int32_t* dst, const int32_t* src, int64_t row_words, const int64_t* rows, int64_t n, int nth);
 void build(const Shape& g, const int32_t* idx, int kcap, int nth, bool want_index, Result* r, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
            int32_t* pmeta, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq, int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3);
 }  // namespace hostfeed

@@ -4,7 +4,6 @@ with the same method names and epoch log lines, driving the HIP engine through t
 import sys
 import time
 
-import numpy as np
 
 from . import _ffi
 
@@ -15,6 +14,8 @@ class OptimizerCallback:  # optimizer/OptimizerCallback.lua
 
 
 class MyOptimizer:
+    FEED_AHEAD = 3
+
     """MyOptimizer(engine, trainingOptions, opt)   (MyOptimizer.lua:13-72)
 
     trainingOptions: dict(numEpochs, epochHooks=[OptimizerCallback], minibatchsize)
@@ -33,8 +34,10 @@ class MyOptimizer:
         self.dp = dp
         self.out = out
         self._cache = {}  # device-resident batches keyed by (file, offset): only when the order is the same every epoch
-        self._slots = [None, None]   # streaming feed (shuffled order): two device slots ...
-        self._stage = [None, None]   # ... and their page-locked staging buffers (BatcherFileList.lua:53-60 preallocates likewise)
+        # streaming feed (shuffled order): a ring of device slots refilled in turn (BatcherFileList.lua:53-60 preallocates its GPU
+        # tensors likewise); FEED_AHEAD minibatches are in the feed's hands while one trains -- a feed (row gather + index build on
+        # the host cores + one upload) takes about as long as a step, so one in flight would not hide it
+        self._slots = [None] * (self.FEED_AHEAD + 1)
         for hook in trainingOptions.get("epochHooks", []):  # MyOptimizer.lua:65-70
             if hook.epochHookFreq == 1:
                 hook.hook(0)
@@ -54,26 +57,10 @@ class MyOptimizer:
             self._cache[key] = b
         return b
 
-    def _feed(self, k, inputs, targets):
-        """BatcherFileList:populateGPUTensor (BatcherFileList.lua:78-96): copy the minibatch into preallocated page-locked
-        buffers and hand it to the engine's feed stream; slot k is refilled in place."""
-        inputs = np.asarray(inputs)
-        targets = np.asarray(targets)
-        st = self._stage[k]
-        if st is None or st[0].size < inputs.size or st[1].size < targets.size:
-            st = (self.engine.host_array((max(inputs.size, 1) * 2,), np.int32), self.engine.host_array((max(targets.size, 1) * 2,), np.float32))
-            self._stage[k] = st
-        hi = st[0][:inputs.size].reshape(inputs.shape)
-        hl = st[1][:targets.size].reshape(targets.shape)
-        hi[...] = inputs   # (float64 ids of a .torch file are converted here, once per batch)
-        hl[...] = targets
-        self._slots[k] = self.engine.feed(hi, hl, slot=self._slots[k])
-        return self._slots[k]
-
     def trainBatch(self, inputs, targets, classId=1, key=None, want_loss=True):
         """MyOptimizer.lua:177-221: zeroPad; fEval{zeroGrad, forward, BCE, backward, clip/L2}; optim step; zeroPad."""
         assert inputs is not None
-        assert targets is not None
+        assert targets is not None or isinstance(inputs, _ffi.Batch)
         b = inputs if isinstance(inputs, _ffi.Batch) else self._device_batch(inputs, targets, key)
         if self.dp is not None:
             # ranks may hold shards of different sizes (last batch of a file): the global pair count is agreed per step unless the
@@ -86,49 +73,73 @@ class MyOptimizer:
             self.totalError += err
         return err
 
+    def _feed_rows(self, k, labels, data, rows):
+        """BatcherFileList:populateGPUTensor (BatcherFileList.lua:78-96) for a shuffled order: the engine's feed threads gather
+        the minibatch's rows out of the file's arrays into the slot's page-locked upload image; slot k is refilled in place."""
+        self._slots[k] = self.engine.feed_rows(data, labels, rows, slot=self._slots[k])
+        return self._slots[k]
+
+    def _epoch_error(self):
+        """(totalError, steps) of the steps since the last call: summed on the device (kprn_read_loss_sum), so that a step costs
+        the host no synchronisation (MyOptimizer.lua:199 adds err to totalError on the host after every step)"""
+        s, n = self.engine.loss_sum(reset=True)
+        self.totalError += s
+        return n
+
     def train(self, trainBatcher):  # MyOptimizer.lua:95-169
         prevTime = time.time()
         numProcessed = 0
         print("Making a pass of the data to count the batches", file=self.out)
         totalBatches = 0
-        while trainBatcher.getBatch() is not None:
+        while trainBatcher.getBatch(rows=True) is not None:
             totalBatches += 1
         print(f"Total num batches {totalBatches}", file=self.out)
         trainBatcher.reset()
         if self.dp is not None and not self.dp.bounded and hasattr(trainBatcher, "max_batch_positions"):
             # a true bound of the rows any step of any rank touches (+ the virtual prefix positions), agreed once
             self.dp.set_capacity(min(trainBatcher.max_batch_positions() + 8, self.engine.cfg.Ve), bound=True)
+        self.engine.set_option("loss_accumulate", "1")
+        self.engine.loss_sum(reset=True)
         i = self.startIteration
         history = []
         while i <= self.trainingOptions["numEpochs"]:
             self.totalError = 0.0
             batch_counter = 0
             gradientStepCounter = 0
-            # A shuffled epoch never repeats a batch: each one is streamed -- the next batch's upload + index build run on the
-            # engine's feed stream while this batch trains (two slots).  A fixed order keeps the batches resident in HBM.
+            # A shuffled epoch never repeats a batch: each one is streamed -- the next batch's row gather, index build and upload
+            # run in the engine's feed threads while earlier batches train.  A fixed order keeps the batches resident in HBM.
             streaming = bool(trainBatcher.doShuffle)
-            got = trainBatcher.getBatch(with_key=True)
+            ahead = []                    # minibatches handed to the feed, oldest first: (batcher tuple, slot)
             k = 0
-            fed = self._feed(k, got[1], got[0]) if (streaming and got is not None) else None
-            while got is not None:
-                targets, inputs, num, classId, key = got
-                nxt = trainBatcher.getBatch(with_key=True)
+            def fill():                   # keep FEED_AHEAD minibatches in flight behind the one being trained
+                nonlocal k
+                while len(ahead) < (self.FEED_AHEAD if streaming else 1):   # (+ the one being trained = the ring's slots)
+                    g = trainBatcher.getBatch(with_key=True, rows=streaming)
+                    if g is None:
+                        return
+                    ahead.append((g, self._feed_rows(k, g[0], g[1], g[2]) if streaming else None))
+                    k = (k + 1) % len(self._slots)
+            fill()
+            while ahead:
+                got, fed = ahead.pop(0)
                 if streaming:
-                    cur = fed
-                    if nxt is not None:
-                        fed = self._feed(k ^ 1, nxt[1], nxt[0])   # queued before this step: runs under it
-                    k ^= 1
-                    inputs = cur
+                    _, _, _, num, classId, key = got
+                    inputs, targets = fed, None
+                    fill()                # queued before this step: they run under it
+                else:
+                    targets, inputs, num, classId, key = got
+                    fill()
                 batch_counter += 1
-                numProcessed += targets.size
+                numProcessed += num
                 # (file, offset) names the same rows in every epoch of a fixed order -- Batcher.epoch is not part of the key
                 cache_key = (key[0], key[1]) if not streaming else None
-                self.trainBatch(inputs, targets, classId, cache_key)
-                got = nxt
+                self.trainBatch(inputs, targets, classId, cache_key, want_loss=False)
                 gradientStepCounter += 1
                 if gradientStepCounter % self.gradientStepCounter == 0:
+                    self._epoch_error()
                     avgError = self.totalError / gradientStepCounter
                     print("Printing after %d gradient steps\navg loss in epoch = %f\n" % (self.gradientStepCounter, avgError), file=self.out)
+            self._epoch_error()
             avgError = self.totalError / max(batch_counter, 1)
             currTime = time.time()
             elapsed = currTime - prevTime
@@ -145,6 +156,7 @@ class MyOptimizer:
                     hook.hook(i)
             trainBatcher.reset()
             i += 1
+        self.engine.set_option("loss_accumulate", "0")
         return history
 
     def postEpoch(self):  # MyOptimizer.lua:171-173

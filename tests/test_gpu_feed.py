@@ -160,5 +160,50 @@ def test_label_less_slot_fed_before_training_scores_with_current_rows():
     eng.close()
 
 
+@pytest.mark.parametrize("build", ["host", "device"])
+def test_rows_feed_gathers_a_shuffled_minibatch_inside_the_engine(build):
+    """kprn_batch_feed_rows_async: pair i = row rows[i] of the file's arrays (Batcher.lua:35-41's shuffle without moving the file)"""
+    eng = _ffi.Engine(*SHAPE)
+    eng.set_option("feed_build", build)
+    data, labels = synth.make_paths(900, 3, 6, Ve=5000, seed=31)
+    rng = np.random.default_rng(2)
+    slot = None
+    for n in (256, 100, 611):                               # the slot grows and shrinks between refills
+        rows = rng.permutation(900)[:n].astype(np.int64)
+        slot = eng.feed_rows(data, labels, rows, slot=slot)
+        ref = eng.batch(data[rows], labels[rows])
+        assert slot.B == n and slot.n_uniq == ref.n_uniq
+        a = eng.forward(ref, 1, want=("probs", "path_scores"))
+        b = eng.forward(slot, 1, want=("probs", "path_scores"))
+        assert np.array_equal(a["probs"], b["probs"]) and np.array_equal(a["path_scores"], b["path_scores"])
+        la = eng.backward(ref, 1)
+        lb = eng.backward(slot, 1)
+        assert abs(la - lb) < 1e-6 * max(1.0, abs(la))
+    with pytest.raises(_ffi.KprnError) as e:                # a row outside the file
+        eng.feed_rows(data, labels, np.array([0, 900], np.int64), slot=slot)
+    assert e.value.code == _ffi.E_ARG
+    eng.close()
+
+
+def test_loss_accumulator_sums_the_steps_without_a_sync_per_step():
+    """loss_accumulate = 1 + kprn_read_loss_sum: MyOptimizer's totalError (MyOptimizer.lua:199) formed on the device"""
+    eng = _ffi.Engine(*SHAPE, seed=3)
+    ref = _ffi.Engine(*SHAPE, seed=3)
+    opt = _ffi.make_opt(method=1, lr=1e-2)
+    data = _batches(5, seed=40)
+    eng.set_option("loss_accumulate", "1")
+    want = 0.0
+    for i, l in data:
+        eng.train_step(eng.batch(i, l), opt, want_loss=False)
+        want += ref.train_step(ref.batch(i, l), opt)
+    s, n = eng.loss_sum(reset=True)
+    assert n == 5 and abs(s - want) < 1e-5 * abs(want)
+    assert eng.loss_sum() == (0.0, 0)
+    eng.train_step(eng.batch(*data[0]), opt, want_loss=False)
+    s1, n1 = eng.loss_sum(reset=False)
+    assert n1 == 1 and abs(s1 - eng.read_loss()) < 1e-6 * max(1.0, abs(s1))
+    eng.close(); ref.close()
+
+
 def ref_uniq(idx):
     return len(np.unique(idx[..., 1]))

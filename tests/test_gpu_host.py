@@ -190,6 +190,44 @@ def test_hit_and_ndcg_at_k_match_the_oracle_within_1e_3():
     assert 0.0 < oh[10] < 1.0  # the ranking is not degenerate (scores are spread, not all tied)
 
 
+def test_shuffled_epochs_match_an_oracle_replay_in_the_same_order(tmp_path):
+    """OneModel.lua:326 trains with shuffle on: MyOptimizer streams every minibatch (rows of the untouched file, gathered inside the
+    engine, kprn_batch_feed_rows_async) and sums the epoch's error on the device; an f64 oracle fed the same BatcherFileList order
+    (same seed, tensors materialised on the host) must see the same per-epoch error and end at the same parameters."""
+    root = str(tmp_path)
+    _write_dataset(root, ".npz")
+    params = model.parse_flags(FLAGS.split() + ["-dataDir", root])
+    eng = model.build_engine(params)
+    theta = eng.get_flat_params().astype(np.float64)
+    log = io.StringIO()
+    fl = batcher.BatcherFileList(root, params.minibatch, True, 100, True, "train.list", seed=11)
+    opt = optimizer.MyOptimizer(eng, {"numEpochs": 3, "epochHooks": [], "minibatchsize": 16}, model.opt_from_flags(params), gradientStepCounter=4, out=log)
+    hist = opt.train(fl)
+    o64 = Oracle(make_cfg(Vt=6, Ve=500, Vr=9, dt=16, de=32, dr=16, H=64, L=2), np.float64)
+    fl2 = batcher.BatcherFileList(root, params.minibatch, True, 100, False, "train.list", seed=11)
+    while fl2.getBatch(rows=True) is not None:   # (MyOptimizer's counting pass consumes one epoch order before the first reset)
+        pass
+    fl2.reset()
+    st = o64.new_state()
+    oo = make_opt(method=1, lr=0.01, regularize=0)
+    ohist = []
+    for _ in range(3):
+        tot, nb = 0.0, 0
+        while True:
+            got = fl2.getBatch()
+            if got is None:
+                break
+            labels, data, n, cid = got
+            l, _ = o64.train_step(theta, st, oo, data, labels, cid)
+            tot += l
+            nb += 1
+        ohist.append(tot / nb)
+        fl2.reset()
+    np.testing.assert_allclose(hist, ohist, rtol=3e-4)
+    assert np.max(np.abs(eng.get_flat_params() - theta)) < 3e-4
+    assert log.getvalue().count("Printing after 4 gradient steps") == 3 and "Iter: 3" in log.getvalue()
+
+
 def test_engine_trained_model_round_trips_through_a_torch7_checkpoint(tmp_path):
     """OneModel.lua:392-400 <-> test_from_checkpoint.lua:68: a model trained here, written as torch.save{embeddingLayer, predictor_net},
     read back into a fresh engine, scores identically (bit for bit: the file holds float64 images of the fp32 parameters); a shuffled
