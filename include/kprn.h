@@ -211,6 +211,12 @@ int kprn_read_loss(kprn_handle* h, float* loss);
 int kprn_read_loss_sum(kprn_handle* h, float* sum, int32_t* steps, int32_t reset);
 int kprn_sync(kprn_handle* h);
 
+/* The scoring writer's lines (eval/test_from_checkpoint.lua:110-118: counter \t string.format("%.5f", score) \t label, one per
+ * pair, the label as Lua 5.1 prints a number = "%.14g"), n of them from counter0 on, formatted by the host cores into out.
+ * Host-only (no handle, no GPU).  *written = bytes written; KPRN_E_ARG with *written = -(bytes needed) when cap is too small. */
+int kprn_format_score_lines(int64_t counter0, const float* probs, const float* labels, int64_t n, char* out, int64_t cap,
+                            int64_t* written);
+
 /* ---- data-parallel hooks (new design; the reference is single-device) -----
  * The dense gradients (type_emb, relation_emb, LSTM, head) live in ONE contiguous device
  * buffer that the caller all-reduces (RCCL).  entity_emb gradients are row-sparse: pack

@@ -46,6 +46,24 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(kprn_[a-z_0-9]+)\s*\(", txt)))
 
 
+def format_score_lines(counter0, probs, labels):
+    """bytes of the scoring writer's lines for pairs counter0 .. (kprn_format_score_lines; host-only)"""
+    L = lib()
+    probs = np.ascontiguousarray(probs, np.float32)
+    labels = np.ascontiguousarray(labels, np.float32)
+    n = int(probs.shape[0])
+    cap = 32 * n + 64
+    w = C.c_int64()
+    while True:
+        buf = C.create_string_buffer(cap)
+        rc = L.kprn_format_score_lines(C.c_int64(int(counter0)), _fp(probs), _fp(labels), C.c_int64(n), buf, C.c_int64(cap), C.byref(w))
+        if rc == 0:
+            return buf.raw[:w.value]
+        if w.value >= 0:
+            raise KprnError(rc, "kprn_format_score_lines failed")
+        cap = -w.value + 64
+
+
 _lib = None
 
 

@@ -11,8 +11,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -105,6 +107,73 @@ void gather_rows(int32_t* dst, const int32_t* src, int64_t row_words, const int6
     span(n, part, nparts, &lo, &hi);
     for (int64_t i = lo; i < hi; ++i) memcpy(dst + i * row_words, src + rows[i] * row_words, (size_t)row_words * sizeof(int32_t));
   });
+}
+
+// printf("%.5f") of a float32 in [0, 2^20), exactly: v = M 2^e with a 24-bit M, so M * 10^5 (< 2^41) is an exact integer and the
+// 5-decimal rounding is an integer shift with round-half-to-even on the exact remainder -- what glibc does on the exact binary
+// value (ties do occur: 1/64 = 0.015625 -> "0.01562").  Anything else (negative, huge, inf, nan) goes through snprintf.
+static int fmt_5f(char* out, float v) {
+  if (!(v >= 0.0f) || v >= 1048576.0f) return snprintf(out, 64, "%.5f", (double)v);
+  int e;
+  const float fr = frexpf(v, &e);                                  // v = fr 2^e, fr in [0.5, 1)
+  const unsigned long long M = (unsigned long long)ldexpf(fr, 24); // exact: 24-bit integer
+  const int sh = 24 - e;                                           // v = M / 2^sh
+  unsigned long long q;
+  const unsigned long long num = M * 100000ULL;
+  if (sh <= 0) q = num << (-sh);
+  else if (sh >= 64) q = 0;
+  else {
+    q = num >> sh;
+    const unsigned long long rem = num & ((1ULL << sh) - 1), half = 1ULL << (sh - 1);
+    if (rem > half || (rem == half && (q & 1ULL))) ++q;
+  }
+  const unsigned long long ip = q / 100000ULL;
+  unsigned fp = (unsigned)(q % 100000ULL);
+  char tmp[24]; int k = 0, m = 0;
+  unsigned long long c = ip;
+  do { tmp[k++] = (char)('0' + c % 10); c /= 10; } while (c);
+  while (k) out[m++] = tmp[--k];
+  out[m++] = '.';
+  for (int d = 4; d >= 0; --d) { out[m + d] = (char)('0' + fp % 10); fp /= 10; }
+  return m + 5;
+}
+
+// eval/test_from_checkpoint.lua:110-118: one line per pair, counter \t string.format("%.5f", score) \t label (Lua 5.1's number
+// concatenation = "%.14g").  Chunks are formatted in parallel into per-thread strings and laid out in order.
+int64_t format_scores(int64_t counter0, const float* probs, const float* labels, int64_t n, char* out, int64_t cap, int nth) {
+  nth = (int)std::max<int64_t>(1, std::min<int64_t>(nth, n / 4096));
+  std::vector<std::string> parts((size_t)nth);
+  parallel(nth, [&](int part, int nparts) {
+    int64_t lo, hi;
+    span(n, part, nparts, &lo, &hi);
+    std::string& s = parts[(size_t)part];
+    s.reserve((size_t)(hi - lo) * 24);
+    char buf[96];
+    for (int64_t i = lo; i < hi; ++i) {
+      int m = 0;
+      {  // counter
+        char tmp[24]; int k = 0;
+        unsigned long long c = (unsigned long long)(counter0 + i);
+        if (counter0 + i < 0) { m = snprintf(buf, sizeof(buf), "%lld", (long long)(counter0 + i)); }
+        else { do { tmp[k++] = (char)('0' + c % 10); c /= 10; } while (c); while (k) buf[m++] = tmp[--k]; }
+      }
+      buf[m++] = '\t';
+      m += fmt_5f(buf + m, probs[i]);
+      buf[m++] = '\t';
+      const float lb = labels[i];
+      if (lb == 1.0f) buf[m++] = '1';
+      else if (lb == 0.0f && !std::signbit(lb)) buf[m++] = '0';
+      else m += snprintf(buf + m, sizeof(buf) - (size_t)m, "%.14g", (double)lb);
+      buf[m++] = '\n';
+      s.append(buf, (size_t)m);
+    }
+  });
+  int64_t total = 0;
+  for (const std::string& s : parts) total += (int64_t)s.size();
+  if (total > cap) return -total;   // (the caller sizes the buffer from this and calls again)
+  int64_t at = 0;
+  for (const std::string& s : parts) { memcpy(out + at, s.data(), s.size()); at += (int64_t)s.size(); }
+  return total;
 }
 
 static int bits_for(int64_t v) { int b = 1; while (((int64_t)1 << b) < v) ++b; return b; }

@@ -1574,6 +1574,15 @@ int kprn_read_loss(kprn_handle* h, float* loss) {
   API_END(h)
 }
 
+int kprn_format_score_lines(int64_t counter0, const float* probs, const float* labels, int64_t n, char* out, int64_t cap, int64_t* written) {
+  if (!probs || !labels || !written || n < 0 || (cap > 0 && !out)) return KPRN_E_ARG;
+  try {
+    const unsigned hc = std::thread::hardware_concurrency();
+    *written = hostfeed::format_scores(counter0, probs, labels, n, out, cap, hc >= 64 ? 16 : (hc >= 8 ? 4 : 1));
+  } catch (...) { return KPRN_E_NOMEM; }
+  return *written < 0 ? KPRN_E_ARG : KPRN_OK;
+}
+
 int kprn_read_loss_sum(kprn_handle* h, float* sum, int32_t* steps, int32_t reset) {
   API_BEGIN(h)
   KPRN_REQUIRE(sum && steps, KPRN_E_ARG, "sum / steps is NULL");

@@ -404,6 +404,8 @@ Pool* make_pool(int workers);
 void free_pool(Pool* p);
 std::future<void> submit(Pool* p, std::function<void()> fn);
 // dst[i] = src row rows[i] (row_words int32 each), i < n: a shuffled minibatch read straight out of the file's array
+// n score lines (counter \t %.5f \t %.14g) into out; returns the bytes written, or -(bytes needed) when cap is too small
+int64_t format_scores(int64_t counter0, const float* probs, const float* labels, int64_t n, char* out, int64_t cap, int nth);
 void gather_rows(int32_t* dst, const int32_t* src, int64_t row_words, const int64_t* rows, int64_t n, int nth);
 void build(const Shape& g, const int32_t* idx, int kcap, int nth, bool want_index, Result* r, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
            int32_t* pmeta, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq, int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3);

@@ -271,8 +271,8 @@ def load_path_file(path):
         if np.any(data != np.rint(data)):
             raise ValueError(f"{path}: non-integer id")
         data = data.astype(np.int64)
-    if data.size and (data.min() < 1 or data.max() >= 2 ** 31):
-        raise ValueError(f"{path}: id outside 1..2^31-1")
+    if data.dtype != np.int32 and data.size and (data.min() < 1 or data.max() >= 2 ** 31):
+        raise ValueError(f"{path}: id outside 1..2^31-1")   # (int32 files: the engine checks every id against its vocabulary)
     return np.asarray(labels, dtype=np.float32).reshape(-1), np.ascontiguousarray(data, dtype=np.int32), cid
 
 

@@ -15,17 +15,71 @@ def lua_number(x):
     return "%.14g" % float(x)
 
 
+ENGINE_BATCH_PATHS = 65536   # paths per engine call: the script's minibatch (512 pairs) is a memory knob of the Torch7 graph, not
+                             # part of the result -- pairs are scored independently, so the engine takes them in chip-sized groups
+FEED_AHEAD = 2
+
+
+def score_batches(engine, batcher, class_id=1):
+    """-> (labels [n], probabilities [n]) per group of pairs, in list x in-file order.  With the HIP engine every group is a
+    label-less feed slot (upload + identical-prefix plan built by the host threads under the previous group's kernels), scored
+    asynchronously; the probabilities of group i come back while group i + 1 runs, so the caller's formatting overlaps too."""
+    streaming = hasattr(engine, "feed") and hasattr(engine, "forward_async")
+    if streaming:
+        for b in getattr(batcher, "batchers", []):       # chip-sized groups per bucket file
+            b.batchSize = max(b.batchSize, ENGINE_BATCH_PATHS // max(1, b.numPaths))
+    if not streaming:
+        while True:
+            got = batcher.getBatch()
+            if got is None:
+                return
+            labs, inputs, count, _classId = got
+            yield labs, engine.forward(engine.batch(inputs), class_id)["probs"]  # nn.Select(2,1) is fixed in the script (:82)
+    slots = [None] * (FEED_AHEAD + 2)
+    k = 0
+    fed = []           # (slot, labels, count): fed, not yet scored
+    running = None     # (labels, count): scored asynchronously, probabilities not yet read
+    done = False
+    while True:
+        while not done and len(fed) < FEED_AHEAD:
+            got = batcher.getBatch()
+            if got is None:
+                done = True
+                break
+            labs, inputs, count, _classId = got
+            slots[k] = engine.feed(inputs, None, slot=slots[k])
+            fed.append((slots[k], labs, count))
+            k = (k + 1) % len(slots)
+        out = None
+        if running is not None:
+            out = (running[0], engine.read_probs(running[1]))
+        running = None
+        if fed:
+            slot, labs, count = fed.pop(0)
+            engine.forward_async(slot, class_id)
+            running = (labs, count)
+        if out is not None:
+            yield out
+        if running is None and not fed and done:
+            return
+
+
 def score_lines(engine, batcher, class_id=1):
     counter = 0
-    while True:
-        got = batcher.getBatch()
-        if got is None:
-            break
-        labs, inputs, count, _classId = got
-        preds = engine.forward(engine.batch(inputs), class_id)["probs"]  # nn.Select(2,1) is fixed in the script (:82)
-        for i in range(count):
+    for labs, preds in score_batches(engine, batcher, class_id):
+        for i in range(len(labs)):
             yield "%d\t%.5f\t%s\n" % (counter, preds[i], lua_number(labs[i]))
             counter += 1
+
+
+def write_scores(engine, batcher, f, class_id=1):
+    """the script's output loop (:110-118) into the binary file f; lines formatted by the host cores (kprn_format_score_lines)"""
+    from . import _ffi
+    counter = 0
+    for labs, preds in score_batches(engine, batcher, class_id):
+        f.write(_ffi.format_score_lines(counter, preds, labs))
+        counter += len(labs)
+    return counter
 
 
 def test_from_checkpoint(engine, input_dir, test_list, out_file, minibatch=512, log=None, rank=0, world=1, barrier=None):
@@ -40,10 +94,8 @@ def test_from_checkpoint(engine, input_dir, test_list, out_file, minibatch=512, 
         batcher = BatcherFileList(input_dir, minibatch, False, 1000, True, test_list)
         start = time.time()
         n = 0
-        with open(out_file, "w") as f:
-            for line in score_lines(engine, batcher, 1):
-                f.write(line)
-                n += 1
+        with open(out_file, "wb") as f:
+            n = write_scores(engine, batcher, f, 1)
         if log:
             print("total cost time:", time.time() - start, file=log)
         return n
@@ -56,7 +108,7 @@ def test_from_checkpoint(engine, input_dir, test_list, out_file, minibatch=512, 
     start = time.time()
     n = 0
     part = f"{out_file}.part{rank}"
-    with open(part, "w") as out:
+    with open(part, "wb") as out:
         if hi > lo:
             # a list file of this rank's shard, next to the original (paths in it stay relative to input_dir)
             fd, shard_list = tempfile.mkstemp(prefix=f".{os.path.basename(test_list)}.rank{rank}.", dir=input_dir)
@@ -64,9 +116,7 @@ def test_from_checkpoint(engine, input_dir, test_list, out_file, minibatch=512, 
                 with os.fdopen(fd, "w") as sl:
                     sl.write("\n".join(files[lo:hi]) + "\n")
                 batcher = BatcherFileList(input_dir, minibatch, False, 1000, True, os.path.basename(shard_list))
-                for line in score_lines(engine, batcher, 1):
-                    out.write(line)
-                    n += 1
+                n = write_scores(engine, batcher, out, 1)
             finally:
                 os.unlink(shard_list)
     if barrier is not None:
