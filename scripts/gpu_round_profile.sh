@@ -43,3 +43,6 @@ python -c "
 import json; d=json.load(open('gpurun_out/bench_${TAG}_c5.json')); print('c5', d['value'], d['ms_per_step'], d.get('streaming'), d.get('roofline'), d.get('cpu_baseline'))"
 timeout 300 python scripts/gpu_dp_sim.py > gpurun_out/dp_sim_$TAG.json 2> gpurun_out/dp_sim_$TAG.log; tail -c 1500 gpurun_out/dp_sim_$TAG.json
 timeout 300 python scripts/gpu_gemm_bench.py > gpurun_out/gemm_bench_$TAG.txt 2>&1; tail -30 gpurun_out/gemm_bench_$TAG.txt
+# the reference-shaped host loops end to end (files -> Batcher -> MyOptimizer / test_from_checkpoint -> engine)
+python scripts/gpu_train_epoch.py 2>&1 | tail -1 > gpurun_out/train_epoch_$TAG.json; cat gpurun_out/train_epoch_$TAG.json
+python scripts/gpu_score_files.py 400000 2>&1 | tail -1 > gpurun_out/score_files_$TAG.json; cat gpurun_out/score_files_$TAG.json
