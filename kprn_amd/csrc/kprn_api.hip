@@ -72,7 +72,7 @@ static T* dalloc(int64_t n) {
   void* p = nullptr;
   if (n <= 0) n = 1;
   // 64 bytes of slack: the tiled GEMMs fetch 16-byte vectors that may straddle the end of a matrix's last row (gemm_tiled.hip)
-  hipError_t e = hipMalloc(&p, (size_t)n * sizeof(T) + 64);
+  hipError_t e = kprn_dev_malloc(&p, (size_t)n * sizeof(T) + 64);
   if (e != hipSuccess) throw KprnError{KPRN_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e)};
   return (T*)p;
 }
@@ -1038,7 +1038,7 @@ static void scratch_reserve(void** scratch, size_t* bytes, size_t need) {
   if (need <= *bytes) return;
   if (*scratch) hipFree(*scratch);
   *scratch = nullptr; *bytes = 0;
-  HIP_TRY(hipMalloc(scratch, need * 2));
+  HIP_TRY(kprn_dev_malloc(scratch, need * 2));
   *bytes = need * 2;
 }
 

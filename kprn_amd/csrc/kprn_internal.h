@@ -1,5 +1,6 @@
 // Internal declarations of libkprn.so (gfx950 only).  Public boundary: include/kprn.h.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <functional>
@@ -396,6 +397,17 @@ void release(kprn_handle* h);
 }  // namespace bf16p
 
 // ---- host side of the streaming feed (host_feed.hip) -------------------------------------------------
+// Every device allocation goes through here.  KPRN_POISON_ALLOC=1 fills new memory with 0xFF bytes (NaN as float, -1 as int): nothing
+// may depend on what hipMalloc returns (fresh pages are zero, recycled blocks are not) -- tests/test_gpu_parity.py runs a step that way.
+inline hipError_t kprn_dev_malloc(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) {
+    static const bool poison = getenv("KPRN_POISON_ALLOC") != nullptr;
+    if (poison) { e = hipMemset(*p, 0xFF, bytes); if (e == hipSuccess) e = hipDeviceSynchronize(); }  // (hipMemset may return before it has run)
+  }
+  return e;
+}
+
 namespace hostfeed {
 struct Shape { int B, P, T, F, nT, Vt, Ve, Vr; };
 typedef kprn_batch::HostResult Result;

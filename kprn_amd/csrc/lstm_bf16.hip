@@ -470,7 +470,7 @@ static State* st(kprn_handle* h) {
 }
 template <typename Tp> static Tp* dal(int64_t n) {
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, (size_t)std::max<int64_t>(n, 1) * sizeof(Tp));
+  hipError_t e = kprn_dev_malloc(&p, (size_t)std::max<int64_t>(n, 1) * sizeof(Tp));
   if (e != hipSuccess) throw KprnError{KPRN_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e)};
   return (Tp*)p;
 }

@@ -543,7 +543,7 @@ bool transpose_job(kprn_handle* h, kk::TransposeJob* tj) {
   State* s = st(h);
   if (!s->wt_dirty) return false;
   const int L = h->cfg.L;
-  if (!s->WT) HIP_TRY(hipMalloc((void**)&s->WT, (size_t)2 * 2 * 64 * 256 * sizeof(float)));
+  if (!s->WT) HIP_TRY(kprn_dev_malloc((void**)&s->WT, (size_t)2 * 2 * 64 * 256 * sizeof(float)));
   tj->n = 2 * L;
   for (int m = 0; m < 4; ++m) {
     const int l = (m >> 1) < L ? (m >> 1) : 0;
@@ -578,14 +578,14 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     if (s->DX) hipFree(s->DX);
     const int64_t cn = std::max<int64_t>(N, s->cap_Nb);
     const int ct = std::max(T, s->cap_Tb);
-    HIP_TRY(hipMalloc((void**)&s->DX, (size_t)ct * (cn + 2 * MT) * DH * sizeof(float)));
+    HIP_TRY(kprn_dev_malloc((void**)&s->DX, (size_t)ct * (cn + 2 * MT) * DH * sizeof(float)));
     if (s->DXe) hipFree(s->DXe);
-    HIP_TRY(hipMalloc((void**)&s->DXe, (size_t)(ct * (cn + 2 * MT) + KCAP) * c.de * sizeof(float)));
+    HIP_TRY(kprn_dev_malloc((void**)&s->DXe, (size_t)(ct * (cn + 2 * MT) + KCAP) * c.de * sizeof(float)));
     s->cap_Nb = cn; s->cap_Tb = ct;
   }
-  if (!s->part) HIP_TRY(hipMalloc((void**)&s->part, (size_t)2 * s->num_cu * PART * sizeof(float)));  // one slab set per layer
+  if (!s->part) HIP_TRY(kprn_dev_malloc((void**)&s->part, (size_t)2 * s->num_cu * PART * sizeof(float)));  // one slab set per layer
   static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
-  if (want_timing && !s->timing) HIP_TRY(hipMalloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
+  if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
   if (s->wt_dirty) {  // (normally done already: the transposes ride in the loss-stage launch, transpose_job())
     ProfScope ps(h, "weight_transpose");
     kk::TransposeJob tj;
@@ -669,7 +669,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       if (slabs && (!s->part_small || s->part_small_n < n_small)) {
         HIP_TRY(hipStreamSynchronize(strm));
         if (s->part_small) hipFree(s->part_small);
-        HIP_TRY(hipMalloc((void**)&s->part_small, (size_t)s->num_cu * 8 * n_small * sizeof(float)));
+        HIP_TRY(kprn_dev_malloc((void**)&s->part_small, (size_t)s->num_cu * 8 * n_small * sizeof(float)));
         s->part_small_n = n_small;
       }
       sa.part_small = small_fits ? s->part_small : nullptr;

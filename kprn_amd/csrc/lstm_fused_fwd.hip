@@ -464,7 +464,7 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
       const int64_t cn = std::max<int64_t>(N, s->cap_N);
       const int ct = std::max(b->T, s->cap_T);
       const int64_t mts = (cn + 15) / 16 + 4;
-      HIP_TRY(hipMalloc((void**)&s->save_frag, (size_t)mts * ct * c.L * 4 * NPL * 256 * sizeof(float)));
+      HIP_TRY(kprn_dev_malloc((void**)&s->save_frag, (size_t)mts * ct * c.L * 4 * NPL * 256 * sizeof(float)));
       s->cap_N = cn; s->cap_T = ct;
     }
     a.save_frag = s->save_frag;
@@ -472,7 +472,7 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   const int cus = (!save && h->reserve_cus > 0) ? std::max(1, s->num_cu - h->reserve_cus) : s->num_cu;
   const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)cus);
   static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
-  if (want_timing && !s->timing) HIP_TRY(hipMalloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
+  if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
   a.timing = s->timing;
   ProfScope ps(h, save ? "lstm_fused_fwd_train" : "lstm_fused_fwd");
   if (c.L == 1) { if (save) launch_fwd<1, true>(h, a, grid); else launch_fwd<1, false>(h, a, grid); }

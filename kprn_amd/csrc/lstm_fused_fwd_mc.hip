@@ -576,8 +576,8 @@ void mc_prepare(kprn_handle* h) {
   State* s = st(h);
   const int ns = (c.compute_dtype == 2) ? 3 : (c.compute_dtype == 3) ? 2 : 1;  // format M of McFmt
   if (!s->mc_wsp) {
-    HIP_TRY(hipMalloc((void**)&s->mc_wsp, (size_t)2 * 2 * 4 * 2 * 3 * 4 * 64 * sizeof(uint4)));
-    HIP_TRY(hipMalloc((void**)&s->mc_bias, (size_t)2 * 256 * sizeof(float)));
+    HIP_TRY(kprn_dev_malloc((void**)&s->mc_wsp, (size_t)2 * 2 * 4 * 2 * 3 * 4 * 64 * sizeof(uint4)));
+    HIP_TRY(kprn_dev_malloc((void**)&s->mc_bias, (size_t)2 * 256 * sizeof(float)));
     s->mc_dirty = true;
   }
   const size_t wsp_layer = (size_t)2 * 4 * 2 * 3 * 4 * 64;  // uint4 per layer (room for 3 pieces)
@@ -614,7 +614,7 @@ void forward_mc(kprn_handle* h, const kprn_batch* b, bool save) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (s->mc_hseq[hs]) HIP_TRY(hipFree(s->mc_hseq[hs]));
     s->mc_capN[hs] = std::max<int64_t>(N, s->mc_capN[hs]); s->mc_capT[hs] = std::max(b->T, s->mc_capT[hs]);
-    HIP_TRY(hipMalloc((void**)&s->mc_hseq[hs], (size_t)((s->mc_capN[hs] + MT - 1) / MT + 1) * s->mc_capT[hs] * MT * DH * sizeof(float)));
+    HIP_TRY(kprn_dev_malloc((void**)&s->mc_hseq[hs], (size_t)((s->mc_capN[hs] + MT - 1) / MT + 1) * s->mc_capT[hs] * MT * DH * sizeof(float)));
   }
   if (save) {
     if (N > s->cap_N || b->T > s->cap_T) {
@@ -623,7 +623,7 @@ void forward_mc(kprn_handle* h, const kprn_batch* b, bool save) {
       const int64_t cn = std::max<int64_t>(N, s->cap_N);
       const int ct = std::max(b->T, s->cap_T);
       const int64_t mts = (cn + 15) / 16 + 4;
-      HIP_TRY(hipMalloc((void**)&s->save_frag, (size_t)mts * ct * c.L * 4 * NPL * 256 * sizeof(float)));
+      HIP_TRY(kprn_dev_malloc((void**)&s->save_frag, (size_t)mts * ct * c.L * 4 * NPL * 256 * sizeof(float)));
       s->cap_N = cn; s->cap_T = ct;
     }
   }
@@ -643,7 +643,7 @@ void forward_mc(kprn_handle* h, const kprn_batch* b, bool save) {
     a.save_frag = save ? s->save_frag : nullptr;
     a.n_tiles = n_tiles;
     static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
-    if (want_timing && !s->timing) HIP_TRY(hipMalloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
+    if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
     a.timing = s->timing;
     ProfScope ps(h, save ? "lstm_mc_fwd_train" : "lstm_mc_fwd");
     if (ns == 3) { if (save) launch_mc<3, true>(h, a, grid); else launch_mc<3, false>(h, a, grid); }

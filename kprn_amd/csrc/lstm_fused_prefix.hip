@@ -247,21 +247,24 @@ __global__ __launch_bounds__(256) void k_prefix_bwd(PrefBwdArgs a) {
 }
 
 // ---- host side ----
-static void ensure_prefix_buffers(State* s) {
+static void ensure_prefix_buffers(State* s, hipStream_t stream) {
   if (s->pfb) return;
-  HIP_TRY(hipMalloc((void**)&s->pfb, (size_t)(KCAP + 1) * 2 * PFB * sizeof(float)));
-  HIP_TRY(hipMalloc((void**)&s->pfs, (size_t)KCAP * 2 * NPL * DH * sizeof(float)));
-  HIP_TRY(hipMalloc((void**)&s->pfx, (size_t)DH * sizeof(float)));
-  HIP_TRY(hipMalloc((void**)&s->PG, (size_t)2 * (KCAP + 1) * PFB * sizeof(float)));
-  HIP_TRY(hipMalloc((void**)&s->r1, (size_t)2 * KCAP * R1 * sizeof(float)));
-  HIP_TRY(hipMemset(s->PG, 0, (size_t)2 * (KCAP + 1) * PFB * sizeof(float)));
-  HIP_TRY(hipMemset(s->pfb, 0, (size_t)(KCAP + 1) * 2 * PFB * sizeof(float)));
+  HIP_TRY(kprn_dev_malloc((void**)&s->pfb, (size_t)(KCAP + 1) * 2 * PFB * sizeof(float)));
+  HIP_TRY(kprn_dev_malloc((void**)&s->pfs, (size_t)KCAP * 2 * NPL * DH * sizeof(float)));
+  HIP_TRY(kprn_dev_malloc((void**)&s->pfx, (size_t)DH * sizeof(float)));
+  HIP_TRY(kprn_dev_malloc((void**)&s->PG, (size_t)2 * (KCAP + 1) * PFB * sizeof(float)));
+  HIP_TRY(kprn_dev_malloc((void**)&s->r1, (size_t)2 * KCAP * R1 * sizeof(float)));
+  // ON THE ENGINE'S STREAM: hipMemset on the null stream may run asynchronously to the host, and the engine's stream is
+  // non-blocking -- the zeroing could land AFTER k_prefix_fwd had filled the table (seen as a correct first pass over a new
+  // engine's first batch and a second pass with every padded path 2 % off: tests/test_gpu_fullsize.py scores twice)
+  HIP_TRY(hipMemsetAsync(s->PG, 0, (size_t)2 * (KCAP + 1) * PFB * sizeof(float), stream));
+  HIP_TRY(hipMemsetAsync(s->pfb, 0, (size_t)(KCAP + 1) * 2 * PFB * sizeof(float), stream));
 }
 
 // prefix table for (current parameters, this batch's reference step); cached until either changes
 void prefix_forward(kprn_handle* h, const kprn_batch* b) {
   State* s = st(h);
-  ensure_prefix_buffers(s);
+  ensure_prefix_buffers(s, h->stream);
   if (s->pf_batch == b->serial) return;
   const kprn_config& c = h->cfg;
   PrefFwdArgs a;

@@ -105,6 +105,10 @@ def test_benchmarked_size_fused_matches_the_generic_pipeline(full):
         eng = full.engine(0, impl, impl == "auto")
         b = eng.batch(full.idx, full.labels)
         out = eng.forward(b, 1, want=("probs", "path_scores"))
+        # a second pass over the same batch reuses the cached identical-prefix table: bit-identical scores (this caught the table being
+        # zeroed by a null-stream hipMemset that ran after the prefix kernel of a new engine's first batch had filled it)
+        again = eng.forward(b, 1, want=("path_scores",))["path_scores"]
+        assert np.array_equal(again, out["path_scores"]), (impl, rel_inf(again, full.ps), rel_inf(out["path_scores"], full.ps))
         loss = eng.backward(b, 1)
         g = eng.get_flat_grads()
         res[impl] = (out, loss, g)
@@ -112,7 +116,9 @@ def test_benchmarked_size_fused_matches_the_generic_pipeline(full):
             full.check_grads(eng, loss)
         eng.close()
     (oa, la, ga), (og, lg, gg) = res["auto"], res["generic"]
-    assert rel_inf(oa["path_scores"], og["path_scores"].astype(np.float64)) < 2e-5
+    d_ag = rel_inf(oa["path_scores"], og["path_scores"].astype(np.float64))
+    bad = np.nonzero(np.abs(oa["path_scores"] - full.ps).max(axis=1) > 1e-4 * np.abs(full.ps).max())[0]
+    assert d_ag < 2e-5, (d_ag, rel_inf(oa["path_scores"], full.ps), rel_inf(og["path_scores"], full.ps), len(bad), bad[:40].tolist(), bad[-10:].tolist())
     np.testing.assert_allclose(oa["probs"], og["probs"], rtol=SCORE_RTOL)
     assert abs(la - lg) < 2e-5 * max(1.0, abs(lg))   # (each is within 1e-5 of the oracle's)
     for nm, (off, shp) in full.lay.items():

@@ -581,6 +581,60 @@ def test_embedding_backward_variants_agree(monkeypatch):
             assert np.max(np.abs(res[dbg][nm] - ref)) < 1e-5 * max(1e-30, np.max(np.abs(ref))), (nm, dbg)
 
 
+def test_nothing_depends_on_what_hipmalloc_returns():
+    """KPRN_POISON_ALLOC=1 fills every new device allocation with 0xFF bytes (NaN / -1).  Fresh pages of a new process are zero, recycled
+    blocks of a long-lived one are not: scores, loss, gradients, a few training steps and a fed slot of every pipeline (fused with and
+    without the identical-prefix plan, generic, wide lstm, rnn, gru) must come out the same, twice (the second pass reuses every cache)."""
+    import subprocess, sys, json, textwrap
+    code = textwrap.dedent("""
+        import sys, json
+        sys.path.insert(0, %r)
+        import numpy as np
+        from kprn_amd import _ffi, synth
+        from oracle.oracle import Oracle, make_cfg
+        out = {}
+        def case(name, shape, oshape, n_pairs, **opts):
+            o64 = Oracle(make_cfg(**oshape), np.float64)
+            theta = o64.init_params(3, 0.1).astype(np.float32).astype(np.float64)
+            idx, labels = synth.make_paths(n_pairs, 3, 6, Ve=oshape["Ve"], Vr=oshape["Vr"], seed=5)
+            ps, _, probs = o64.forward(theta, idx)
+            ol, og, _ = o64.forward_backward(theta, idx, labels)
+            eng = _ffi.Engine(*shape, **{k: v for k, v in opts.items() if k not in ("impl", "plan")})
+            eng.set_option("impl", opts.get("impl", "auto")); eng.set_option("prefix_plan", opts.get("plan", "1"))
+            eng.set_flat_params(theta.astype(np.float32))
+            b = eng.batch(idx, labels)
+            r = []
+            for _ in range(2):
+                sc = eng.forward(b, 1, want=("probs", "path_scores"))["path_scores"]
+                loss = eng.backward(b, 1)
+                g = eng.get_flat_grads()
+                r.append([float(np.abs(sc - ps).max() / np.abs(ps).max()), float(abs(loss - ol)), float(np.abs(g - og).max() / np.abs(og).max())])
+            opt = _ffi.make_opt(method=1, lr=1e-2)
+            tl = [eng.train_step(b, opt) for _ in range(3)]
+            slot = eng.feed(idx, labels)
+            fed = eng.forward(slot, 1)["probs"]
+            r.append([float(np.isfinite(tl).all()), float(np.isfinite(fed).all()), float(np.abs(fed - eng.forward(b, 1)["probs"]).max())])
+            out[name] = r
+            eng.close()
+        A = (6, 5000, 9, 16, 32, 16, 64, 2); OA = dict(Vt=6, Ve=5000, Vr=9, dt=16, de=32, dr=16, H=64, L=2)
+        case("fused+plan", A, OA, 3000)
+        case("fused", A, OA, 3000, plan="0")
+        case("generic", A, OA, 3000, impl="generic")
+        W = (6, 700, 9, 24, 40, 24, 72, 1); OW = dict(Vt=6, Ve=700, Vr=9, dt=24, de=40, dr=24, H=72, L=1)
+        case("wide lstm", W, OW, 200)
+        case("rnn", W, dict(OW, rnn_type=1, use_relu=0), 200, rnn_type=1, use_relu=0)
+        case("gru", W, dict(OW, rnn_type=2), 200, rnn_type=2)
+        print(json.dumps(out))
+    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, KPRN_POISON_ALLOC="1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    for name, (first, second, tail) in res.items():
+        for e_sc, e_loss, e_g in (first, second):
+            assert e_sc < 2e-5 and e_loss < 1e-5 and e_g < 2e-4, (name, first, second)
+        assert tail[0] == 1.0 and tail[1] == 1.0 and tail[2] == 0.0, (name, tail)
+
+
 def test_shipped_config_sh_shape_rnn_h250():
     """run_scripts/config.sh as shipped: rnnType rnn, rnnHidSize 250, embedding dims 50/100/50 (D = 200), 1 layer, ReLU,
     identity initialisation, LogSumExp pool, Adam -- odd sizes for every GEMM edge (small vocabulary here)."""
