@@ -6,6 +6,7 @@ The LuaJIT twin of this file is bindings/kprn.lua.
 import ctypes as C
 import os
 import re
+import weakref
 
 import numpy as np
 
@@ -109,14 +110,18 @@ class Batch:
     def __init__(self, engine, idx, labels=None, feed=False):
         """feed=False: kprn_batch_create (ready on return).  feed=True: a slot for Batch.refill -- the upload and the index build
         run on the engine's feed stream, under whatever is queued next (kprn_batch_feed_async)."""
-        self.engine = engine
-        self.ptr = C.c_void_p()
-        self._src = None
+        self._attach(engine)
         if feed:
             self.refill(idx, labels)
             return
         idx, lab = self._check(idx, labels)
         engine._ck(engine.L.kprn_batch_create(engine.h, _fp(idx), _fp(lab), self.B, self.P, self.T, self.F, C.byref(self.ptr)))
+
+    def _attach(self, engine):
+        self.engine = engine
+        self.ptr = C.c_void_p()
+        self._src = None
+        engine._batches.add(self)   # Engine.close() releases the batches still alive before the handle goes
 
     def _check(self, idx, labels):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
@@ -133,7 +138,7 @@ class Batch:
     def reserve(cls, engine, max_pairs, max_paths, T, F, with_labels=True):
         """an empty feed slot sized for the largest minibatch it will hold (kprn_batch_slot_reserve)"""
         self = cls.__new__(cls)
-        self.engine, self.ptr, self._src = engine, C.c_void_p(), None
+        self._attach(engine)
         self.B = self.P = 0
         self.T, self.F, self.has_labels = T, F, with_labels
         engine._ck(engine.L.kprn_batch_slot_reserve(engine.h, C.byref(self.ptr), int(max_pairs), C.c_int64(int(max_paths)), int(T), int(F), int(bool(with_labels))))
@@ -198,6 +203,7 @@ class Engine:
     def __init__(self, Vt, Ve, Vr, dt, de, dr, H, L=1, F=3, num_types=1, C_=46, reducer=2, K=5, rnn_type=0, device_id=0,
                  rank=0, world=1, param_init=0.1, seed=12345, stream=None, use_relu=1, rnn_init=0, compute_dtype=0):
         self.L = lib()
+        self._batches = weakref.WeakSet()
         self.cfg = Config(Vt, Ve, Vr, dt, de, dr, F, num_types, H, L, C_, rnn_type, use_relu, rnn_init, compute_dtype, reducer, K, device_id, rank, world,
                           param_init, seed, stream)
         self.h = C.c_void_p()
@@ -217,6 +223,8 @@ class Engine:
 
     def close(self):
         if self.h:
+            for b in list(self._batches):   # (device blocks, page-locked images and events of batches the caller still holds)
+                b.free()
             for p in getattr(self, "_pinned", []):
                 self.L.kprn_host_free(self.h, p)
             self._pinned = []
@@ -313,7 +321,7 @@ class Engine:
         """the feed for a shuffled order: rows of the file's arrays, gathered inside the engine (Batch.refill_rows)"""
         if slot is None:
             slot = Batch.__new__(Batch)
-            slot.engine, slot.ptr, slot._src = self, C.c_void_p(), None
+            slot._attach(self)
         return slot.refill_rows(data, labels, rows)
 
     def host_array(self, shape, dtype=np.int32):

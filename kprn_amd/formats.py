@@ -248,11 +248,44 @@ def t7_save(path, obj):
 # path-set files ({labels, data, classId}) in any of the three containers
 
 
+def _npz_member_memmap(path, name):
+    """read-only memory map of an uncompressed .npy member of a .npz archive (None when it is compressed or anything looks
+    unusual): a multi-GB path file then costs no load time and no second copy in RAM -- the engine's feed threads read the rows
+    they need straight from the page cache"""
+    import zipfile
+    try:
+        with zipfile.ZipFile(path) as zf:
+            info = zf.getinfo(name + ".npy")
+            if info.compress_type != zipfile.ZIP_STORED:
+                return None
+            with open(path, "rb") as f:
+                f.seek(info.header_offset)
+                hdr = f.read(30)
+                if hdr[:4] != b"PK\x03\x04":
+                    return None
+                n_name, n_extra = int.from_bytes(hdr[26:28], "little"), int.from_bytes(hdr[28:30], "little")
+                start = info.header_offset + 30 + n_name + n_extra
+                f.seek(start)
+                version = np.lib.format.read_magic(f)
+                shape, fortran, dtype = (np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f))
+                if fortran or dtype.hasobject:
+                    return None
+                offset = f.tell()
+            if offset + int(np.prod(shape)) * dtype.itemsize > start + info.file_size:
+                return None
+            return np.memmap(path, dtype=dtype, mode="r", offset=offset, shape=tuple(shape))
+    except Exception:
+        return None
+
+
 def load_path_file(path):
     """-> (labels float32 [N], data int32 [N,P,T,F] 1-based, classId int)."""
     if path.endswith(".npz"):
         z = np.load(path)
-        labels, data, cid = z["labels"], z["data"], int(z["classId"]) if "classId" in z else 1
+        labels, cid = z["labels"], int(z["classId"]) if "classId" in z else 1
+        data = _npz_member_memmap(path, "data")   # (np.savez stores members uncompressed: map the ids instead of copying them)
+        if data is None:
+            data = z["data"]
     elif path.endswith(".int"):
         labels, data = read_int_file(path, add_one=True)
         cid = 1  # movie_data_format.sh:39  insertClassLabels -classLabel 1
