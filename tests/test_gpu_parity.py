@@ -165,9 +165,10 @@ def test_train_steps_match_oracle(impl, method, regularize):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-def test_lazy_entity_update_is_bit_identical_to_dense(impl):
-    """the lazy-exact row update equals optim.adam's dense sweep bit for bit, including rows
-    that are touched once and then coast on momentum for many steps."""
+def test_lazy_entity_update_matches_the_dense_sweep_to_rounding(impl):
+    """the lazy-exact row update against optim.adam's dense sweep over 24 steps, including rows that are touched once and then coast
+    on momentum for many steps: equal to fp32 rounding (2e-6) -- the gradients come from fp32 atomics whose order differs run to run;
+    the BITWISE statement is test_lazy_replay_exactness_without_atomics below."""
     res = []
     for mode in (0, 1):
         eng, o64, theta = mk(L=1, impl="generic", Ve=400)  # deterministic generic path for the bitwise check
