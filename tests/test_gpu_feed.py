@@ -205,5 +205,14 @@ def test_loss_accumulator_sums_the_steps_without_a_sync_per_step():
     eng.close(); ref.close()
 
 
+def test_soak_random_shapes_through_a_slot_ring():
+    """scripts/gpu_feed_soak.py: 300 random minibatches (1 .. 1 500 pairs, P in {1,2,3,5,8}; rows feed / plain feed / label-less) through
+    a 4-slot ring with training and second-stream scoring interleaved, host- and device-built, against an engine fed resident batches"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_feed_soak.py"), "150", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "failures: 0" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
 def ref_uniq(idx):
     return len(np.unique(idx[..., 1]))
