@@ -648,7 +648,8 @@ static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int
     if (h->loss_accumulate) form_loss(h);   // (one single-workgroup launch; otherwise the sum is formed when somebody asks)
   }
   view_step_rows(h, b);
-  join_score(h);
+  // (no join with a scoring pass on the side stream here: the backward writes nothing that pass reads -- gradients, dx, prefix sums --
+  //  and making the main stream wait for the pass's last workgroups cost 3 % of the step; apply_update joins before it writes parameters)
   if (fusedp) fused::backward(h, b, cid);
   else if (bf16p::supported(h, b)) bf16p::backward(h, b, cid);
   else backward_generic(h, b, cid);
