@@ -602,6 +602,41 @@ __global__ void k_adam_rows(float* __restrict__ W, float* __restrict__ g, float*
   if (lane == 0) last[r] = t_now;
 }
 
+// the same for rows of d = 4 G floats handled by G = 8 / 16 / 32 lanes with 16-byte accesses (d = 32: eight rows per wave instead of one
+// half-empty wave per row; the per-element arithmetic is adam_elem's, so the result stays bit-identical to the dense sweep)
+template <int G>
+__global__ void k_adam_rows_v(float* __restrict__ W, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                              int32_t* __restrict__ last, const int32_t* __restrict__ rows, const int32_t* __restrict__ count,
+                              int32_t t_now, int apply_step, const float* __restrict__ step_tab, float b1, float b2, float eps, int64_t pad_row) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int j = threadIdx.x % G;
+  if (slot >= *count) return;
+  const int64_t r = rows[slot];
+  const int32_t l = last[r];
+  const int32_t upto = apply_step ? t_now - 1 : t_now;  // replay (l, upto] with g = 0
+  const int64_t o = r * (4 * G) + 4 * j;
+  const f4 x4 = *(const f4*)(W + o), m4 = *(const f4*)(m + o), v4 = *(const f4*)(v + o);
+  f4 g4 = f4{0.f, 0.f, 0.f, 0.f};
+  if (apply_step) g4 = *(const f4*)(g + o);
+  float x[4] = {x4[0], x4[1], x4[2], x4[3]}, mm[4] = {m4[0], m4[1], m4[2], m4[3]}, vv[4] = {v4[0], v4[1], v4[2], v4[3]};
+  if (l > 0)
+    for (int32_t k = l + 1; k <= upto; ++k) {
+      const float st = step_tab[k];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) adam_elem(x[q], mm[q], vv[q], 0.f, st, b1, b2, eps);
+    }
+  if (apply_step) {
+    const float st = step_tab[t_now];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) adam_elem(x[q], mm[q], vv[q], g4[q], st, b1, b2, eps);
+    *(f4*)(g + o) = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (r == pad_row) { x[0] = x[1] = x[2] = x[3] = 0.f; }  // zeroPadTokens after every step the row lived through (MyOptimizer.lua:219)
+  *(f4*)(W + o) = f4{x[0], x[1], x[2], x[3]}; *(f4*)(m + o) = f4{mm[0], mm[1], mm[2], mm[3]}; *(f4*)(v + o) = f4{vv[0], vv[1], vv[2], vv[3]};
+  if (j == 0) last[r] = t_now;
+}
+
 __global__ void k_adam_flush_all(float* __restrict__ W, float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ last, int64_t V,
                                  int d, int32_t t_now, const float* __restrict__ step_tab, float b1, float b2, float eps, int64_t pad_row) {
   const int lane = threadIdx.x & 63;
@@ -938,8 +973,12 @@ void adagrad_dense(hipStream_t s, float* x, float* g, float* G, int64_t n, float
 void adam_rows(hipStream_t s, float* W, float* g, float* m, float* v, int32_t* last, const int32_t* rows, const int32_t* count, int64_t max_rows,
                int d, int32_t t_now, int apply_step, const float* step_tab, float b1, float b2, float eps, int64_t pad_row) {
   if (max_rows <= 0) return;
-  hipLaunchKernelGGL(k_adam_rows, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, d, t_now, apply_step, step_tab, b1,
-                     b2, eps, pad_row);
+  const bool al = !(((uintptr_t)W | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15);
+  if (al && d == 32) hipLaunchKernelGGL(k_adam_rows_v<8>, dim3(nblocks(max_rows * 8)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, apply_step, step_tab, b1, b2, eps, pad_row);
+  else if (al && d == 64) hipLaunchKernelGGL(k_adam_rows_v<16>, dim3(nblocks(max_rows * 16)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, apply_step, step_tab, b1, b2, eps, pad_row);
+  else if (al && d == 128) hipLaunchKernelGGL(k_adam_rows_v<32>, dim3(nblocks(max_rows * 32)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, apply_step, step_tab, b1, b2, eps, pad_row);
+  else hipLaunchKernelGGL(k_adam_rows, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, d, t_now, apply_step, step_tab, b1,
+                          b2, eps, pad_row);
   CHECK_LAUNCH();
 }
 
