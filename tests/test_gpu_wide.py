@@ -71,10 +71,19 @@ def test_hidden_size_not_a_multiple_of_the_unit_tile():
 
 
 def test_lstm_with_config_sh_dimensions():
-    """FastLSTM at config.sh's sizes (D = 200, H = 250): the 8-byte-vector variant of the step kernel and of the tiled GEMMs"""
+    """FastLSTM at config.sh's sizes (D = 200, H = 250): rows pitched at 8 bytes, fetched with 16-byte vectors at 4-byte granularity"""
     eng, o64, theta = _lstm(50, 100, 50, 250, 1, init=0.05)
     idx, labels = synth.make_paths(150, 2, 6, Ve=700, seed=12)
     _check(eng, o64, theta, idx, labels, steps=2)
+
+
+@pytest.mark.parametrize("H,L", [(29, 1), (23, 2)])
+def test_odd_dimensions_through_the_tiled_kernels(H, L):
+    """D = 23 (5 / 11 / 7), H = 29 (one layer) or 23 (two): every row pitch is odd, so every 16-byte operand vector starts at a mere
+    4-byte boundary and every K / N extent ends inside a vector (element-wise tail masks, gemm_tiled.hip)"""
+    eng, o64, theta = _lstm(5, 11, 7, H, L)
+    idx, labels = synth.make_paths(131, 3, 5, Ve=700, seed=21)   # 393 paths: 3 row tiles + 9 rows
+    _check(eng, o64, theta, idx, labels, steps=3)
 
 
 def test_configs3_shape_d384_h384_at_tiled_size():
@@ -87,8 +96,7 @@ def test_configs3_shape_d384_h384_at_tiled_size():
                                              (0, 2, (32, 32, 32, 96)), (1, 1, (3, 5, 7, 33))])
 def test_rnn_step_kernel(use_relu, L, dims):
     """nn.Recurrence + nn.MaskZero (OneModel.lua:240-266) through the fused step kernel: run_scripts/config.sh exactly (D = 200,
-    H = 250: even leading dimensions -> 8-byte vectors), 16-byte shapes, two layers; odd dimensions (15 / 33) stay on the
-    unfused kernels and must still be right"""
+    H = 250: 8-byte row pitch), 16-byte shapes, two layers, odd dimensions (D = 15, H = 33: 4-byte row pitch)"""
     dt, de, dr, H = dims
     eng = _ffi.Engine(6, 700, 9, dt, de, dr, H, L, rnn_type=1, use_relu=use_relu, param_init=0.05)
     o64 = Oracle(make_cfg(Vt=6, Ve=700, Vr=9, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=1, use_relu=use_relu), np.float64)
