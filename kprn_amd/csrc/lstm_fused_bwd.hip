@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   for (int c = tid; c < (KCAP + 1) * PFB; c += 256) pg[c] = 0.f;  // (first read: after the barriers of a whole tile)
   TPROBE(0)
 
-  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  // A workgroup walks ITS tiles (blockIdx.x + i gridDim.x, the forward's assignment) last one first: the training forward wrote
+  // their saved planes in ascending order, so the most recent ones are the likeliest to still sit in the 256 MB memory-side cache.
+  const int64_t n_mine = (a.n_tiles > (int64_t)blockIdx.x) ? (a.n_tiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+  for (int64_t ti = n_mine - 1; ti >= 0; --ti) {
+    const int64_t tile = (int64_t)blockIdx.x + ti * gridDim.x;
     const int64_t n0 = tile * MT;
     const int k0 = a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tile]) : 0;  // steps below k0 belong to the prefix
     // Everything below counts steps from the tile's first executed one: tt = t - k0 in [0, Te).  The step index enters the
