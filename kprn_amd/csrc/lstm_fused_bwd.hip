@@ -132,10 +132,14 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   for (int c = tid; c < (KCAP + 1) * PFB; c += 256) pg[c] = 0.f;  // (first read: after the barriers of a whole tile)
   TPROBE(0)
 
-  // A workgroup walks ITS tiles (blockIdx.x + i gridDim.x, the forward's assignment) last one first: the training forward wrote
-  // their saved planes in ascending order, so the most recent ones are the likeliest to still sit in the 256 MB memory-side cache.
+  // A workgroup walks ITS tiles (blockIdx.x + i gridDim.x, the forward's assignment) in the order that finds the most in the 256 MB
+  // memory-side cache.  Top layer: last tile first -- the training forward wrote the saved planes in ascending order, so the most
+  // recent ones are the likeliest to still be there.  Bottom layer: first tile first -- by then the top layer's launch has streamed
+  // every plane of ITS layer through the cache, and what is recent is the dx the top layer wrote last, i.e. of its first tiles.
+  // (0.319 -> 0.312 ms per launch.)
   const int64_t n_mine = (a.n_tiles > (int64_t)blockIdx.x) ? (a.n_tiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-  for (int64_t ti = n_mine - 1; ti >= 0; --ti) {
+  for (int64_t tq = 0; tq < n_mine; ++tq) {
+    const int64_t ti = TOP ? n_mine - 1 - tq : tq;
     const int64_t tile = (int64_t)blockIdx.x + ti * gridDim.x;
     const int64_t n0 = tile * MT;
     const int k0 = a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tile]) : 0;  // steps below k0 belong to the prefix
