@@ -755,9 +755,24 @@ def main():
             "value_no_prefix_plan": (extras.get("no_prefix_plan") or {}).get("value"), "no_prefix_plan": extras.get("no_prefix_plan"),
             "dp": dp_info, "alt_f32x6": alt, "kernels": kernels,
         }
-        print(json.dumps(out))
     if world > 1 or a.force_dp:
         dist.destroy_process_group()
+    if rank == 0:
+        emit_last(out)
+
+
+def emit_last(out):
+    """The JSON line is the LAST thing on stdout.  RCCL prints a version banner through C stdio, which a pipe buffers until the process
+    exits -- after Python's own buffer, i.e. behind the line: flush C stdio first, print, and leave without running exit handlers."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

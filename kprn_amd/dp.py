@@ -18,6 +18,8 @@ independent units: model/module/MapReduce.lua:24-47 never mixes them).  Per step
 The collective calls only see an "adapter" that exposes the engine's buffers as torch tensors,
 so the same code is exercised on CPU (gloo, world_size 2) with a numpy-backed adapter.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -45,6 +47,11 @@ class GpuAdapter:
         self.dense = wrap_device(ptr, n, "f32", self.device)
         self.de = engine.cfg.de
         self._cap = 0
+        # Every torch operation of the exchange (the collectives' stream hand-over, copies, timing events) must be ordered with the
+        # engine's kernels: they are issued with the ENGINE's stream as torch's current stream.  (Handing the engine torch's current
+        # stream is not enough: the default stream's handle is 0, which kprn_create reads as "make your own" -- the collectives then
+        # raced the pack / merge kernels: right at step 0 by luck, entity rows off by an optimiser step from step 1 on.)
+        self.stream = torch.cuda.ExternalStream(engine.stream(), device=self.device)
 
     def backward(self, batch, class_id, bce_literal, inv_batch):
         self.e.backward(batch, class_id, bce_literal, inv_batch, want_loss=False)
@@ -104,6 +111,11 @@ class DataParallel:
         self.timing = False   # bench.py: events around the parts of the exchange (GPU adapter only)
         self._ev = []
 
+    def _ctx(self):
+        """torch's current stream := the adapter's stream (GPU adapter), for the duration of the exchange's torch calls"""
+        st = getattr(self.a, "stream", None)
+        return torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
+
     def _dev(self, t):
         if self.collectives and dist.get_backend(self.group) == "nccl":
             return t.to(self.a.device)
@@ -112,10 +124,11 @@ class DataParallel:
     def set_capacity(self, local_max_rows, bound=True):
         """fixed per-rank packing capacity = max over ranks of local_max_rows; bound=True promises that no step of any rank
         touches more distinct rows than that."""
-        t = self._dev(torch.tensor([int(local_max_rows)], dtype=torch.int64))
-        if self.collectives:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        self.capacity = max(1, int(t.item()))
+        with self._ctx():
+            t = self._dev(torch.tensor([int(local_max_rows)], dtype=torch.int64))
+            if self.collectives:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            self.capacity = max(1, int(t.item()))
         self.bounded = bool(bound)
         self._all = None
         return self.capacity
@@ -125,10 +138,11 @@ class DataParallel:
         t = torch.zeros(self.world + 1, dtype=torch.int64)
         t[self.rank] = int(rows)
         t[self.world] = int(pairs)
-        t = self._dev(t)
-        if self.collectives:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        t = t.cpu()
+        with self._ctx():
+            t = self._dev(t)
+            if self.collectives:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t = t.cpu()
         return int(t[:self.world].max().item()), int(t[self.world].item())
 
     def _mark(self):
@@ -156,6 +170,10 @@ class DataParallel:
         """one data-parallel MyOptimizer:trainBatch; `batch` holds THIS rank's pairs.
         overlap: optional callable that ENQUEUES work which does not depend on this step's update (e.g. a scoring pass
         with the pre-update parameters); it runs while the entity-row all-gather is in flight."""
+        with self._ctx():
+            self._train_step(batch, opt, class_id, global_pairs, overlap)
+
+    def _train_step(self, batch, opt, class_id, global_pairs, overlap):
         a = self.a
         need = None
         if global_pairs is None and not self.equal_shards:

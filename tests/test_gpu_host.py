@@ -251,3 +251,52 @@ def test_engine_trained_model_round_trips_through_a_torch7_checkpoint(tmp_path):
     native = os.path.join(root, "model-native")
     eng.save(native)
     assert model.load_checkpoint(eng2, native) == "native"
+
+
+def test_data_parallel_step_at_world_one_equals_the_plain_step(tmp_path):
+    """kprn_amd/dp.py on the GPU with a real process group of size 1 (RCCL: every collective is issued -- the call sequence of the
+    N-GPU run): DataParallel.train_step == Engine.train_step, and MyOptimizer(dp=...) over shuffled files == MyOptimizer without it.
+    The world-size-2 arithmetic (rank-ordered merge, global loss scale, ragged shards) is covered on CPU in tests/test_dp_gloo.py."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from kprn_amd import dp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        shape = (6, 500, 9, 16, 32, 16, 64, 2)
+        stream = torch.cuda.current_stream().cuda_stream
+        a = _ffi.Engine(*shape, seed=4, stream=stream)
+        b = _ffi.Engine(*shape, seed=4)
+        a.zero_pad_tokens(); b.zero_pad_tokens()   # (trainBatch zeroes the pad rows first: the scoring passes below come before / after it)
+        opt = _ffi.make_opt(method=1, lr=1e-2)
+        x = dp.DataParallel(dp.GpuAdapter(a, "cuda:0"))
+        data = [synth.make_paths(200 + 37 * i, 1 + i % 3, 6, Ve=500, seed=60 + i) for i in range(5)]
+        x.set_capacity(max(len(np.unique(i[..., 1])) for i, _ in data) + 8)
+        for idx, lab in data:
+            ba, bb = a.batch(idx, lab), b.batch(idx, lab)
+            x.train_step(ba, opt, 1, overlap=lambda: a.forward_async(ba, 1))
+            pa = a.read_probs(ba.B)
+            pb = b.forward(bb, 1)["probs"]
+            b.train_step(bb, opt)
+            np.testing.assert_allclose(pa, pb, rtol=1e-5, atol=1e-7)
+            assert abs(a.read_loss() - b.read_loss()) < 1e-6 * max(1.0, abs(b.read_loss()))
+        assert np.max(np.abs(a.get_flat_params() - b.get_flat_params())) < 2e-6
+        # the training loop with a DataParallel object: shuffled files, streamed minibatches
+        root = str(tmp_path)
+        _write_dataset(root, ".npz")
+        hists = []
+        for use_dp in (True, False):
+            params = model.parse_flags(FLAGS.split() + ["-dataDir", root])
+            eng = _ffi.Engine(6, 500, 9, 16, 32, 16, 64, 2, seed=9, stream=stream if use_dp else None)
+            fl = batcher.BatcherFileList(root, params.minibatch, True, 100, True, "train.list", seed=3)
+            xx = dp.DataParallel(dp.GpuAdapter(eng, "cuda:0"), equal_shards=False) if use_dp else None
+            mo = optimizer.MyOptimizer(eng, {"numEpochs": 2, "epochHooks": [], "minibatchsize": 16}, model.opt_from_flags(params), dp=xx, out=io.StringIO())
+            hists.append((mo.train(fl), eng.get_flat_params()))
+            eng.close()
+        np.testing.assert_allclose(hists[0][0], hists[1][0], rtol=1e-5)
+        assert np.max(np.abs(hists[0][1] - hists[1][1])) < 5e-6
+        a.close(); b.close()
+    finally:
+        dist.destroy_process_group()
