@@ -463,7 +463,14 @@ struct State {
   bool dense_dirty = true;
   int64_t cap_N = 0; int cap_T = 0;
   bf16 *X16 = nullptr, *XT16 = nullptr, *H16 = nullptr, *HT16 = nullptr, *ACT16 = nullptr, *dA16 = nullptr, *dAT16 = nullptr;
+  void* persist = nullptr;      // lstm_bf16_persist.hip: packed weights + scratch slabs of the persistent layer kernel
+  bool pack_dirty = true;       // its packed weights are stale
 };
+// lstm_bf16_persist.hip: the whole layer (gather + T steps) as one persistent launch
+bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b);
+void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, bool repack, const bf16* Wt16, const bf16* We16, const bf16* Wr16, bf16* H16,
+                     bf16* ACT16);
+void persist_release(void*& st);
 static State* st(kprn_handle* h) {
   if (!h->bf16_state) h->bf16_state = new State();
   return (State*)h->bf16_state;
@@ -490,6 +497,7 @@ void params_changed(kprn_handle* h, bool entity_rows_only) {
   if (!h->bf16_state) return;
   State* s = (State*)h->bf16_state;
   s->dense_dirty = true;
+  s->pack_dirty = true;
   if (!entity_rows_only) s->we_all_dirty = true;
 }
 
@@ -508,6 +516,7 @@ void release(kprn_handle* h) {
   State* s = (State*)h->bf16_state;
   if (!s) return;
   for (bf16* p : {s->We16, s->dense16, s->WT16, s->X16, s->XT16, s->H16, s->HT16, s->ACT16, s->dA16, s->dAT16}) if (p) hipFree(p);
+  persist_release(s->persist);
   delete s;
   h->bf16_state = nullptr;
 }
@@ -564,14 +573,19 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   const int64_t N = (int64_t)b->B * b->P;
   refresh_shadows(h);
   ensure_buffers(h, N, T);
-  {
+  const bool persist = persist_shape_ok(h, b);
+  if (!persist || save) {   // (the persistent kernel gathers for itself; the backward's dW product reads the [T][N][D] plane)
     ProfScope ps(h, "embed_gather_bf16");
     const int64_t work = N * T * (D >> 3);
     hipLaunchKernelGGL(k_gather16, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, strm, b->idx, N, T, b->F, c.num_types, s->dense16 + h->off_Wt, s->We16,
                        s->dense16 + h->off_Wr, c.dt, c.de, c.dr, s->X16);
     HIP_TRY(hipGetLastError());
   }
-  for (int l = 0; l < L; ++l) {
+  if (persist) {
+    persist_forward(h, b, save, s->persist, s->pack_dirty, s->dense16 + h->off_Wt, s->We16, s->dense16 + h->off_Wr, s->H16, s->ACT16);
+    s->pack_dirty = false;
+  }
+  for (int l = 0; l < L && !persist; ++l) {
     const int Din = h->layer[l].Din;
     const bf16* in = (l == 0) ? s->X16 : s->H16 + (int64_t)(l - 1) * T * N * H;
     bf16* hs = s->H16 + (int64_t)l * T * N * H;

@@ -1,0 +1,127 @@
+"""-m gpu: the persistent bf16 layer kernel of BASELINE configs[3] (kprn_amd/csrc/lstm_bf16_persist.hip: gather + all T FastLSTM steps of
+D = H = 384 in one launch, v_mfma_f32_32x32x16_bf16) against the float64 oracle, against the per-step bf16 pipeline it replaces
+(KPRN_BF16_PERSIST=0: same rounding points, different accumulation order), at every tile shape it has (96- and 64-row tiles, ragged
+last tile, a lone 32-row unit), at >= 1 024 work tiles, and in training on a 20 M-row table."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from kprn_amd import _ffi, synth
+from oracle.oracle import Oracle, make_cfg, make_opt
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIMS = (128, 128, 128)
+
+
+def rel_inf(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / max(1e-30, np.max(np.abs(b))))
+
+
+def _case(pairs, P, T, Ve=700, Vr=100, seed=4, init=0.05):
+    dt, de, dr = DIMS
+    eng = _ffi.Engine(6, Ve, Vr, dt, de, dr, 384, 1, compute_dtype=1)
+    o64 = Oracle(make_cfg(Vt=6, Ve=Ve, Vr=Vr, dt=dt, de=de, dr=dr, H=384, L=1), np.float64)
+    theta = o64.init_params(seed, init).astype(np.float32).astype(np.float64)
+    eng.set_flat_params(theta.astype(np.float32))
+    idx, labels = synth.make_paths(pairs, P, T, Ve=Ve, Vr=Vr, seed=seed + 1)
+    return eng, o64, theta, idx, labels
+
+
+def _ran_persistent(eng):
+    return any(k.startswith("lstm_persist_bf16") for k in eng.profile_get())
+
+
+@pytest.mark.parametrize("pairs,P,T,grid", [(150, 2, 6, 0),      # 300 paths: 10 units over 5 workgroups, 64-row tiles
+                                            (333, 3, 6, 3),      # 999 paths: 32 units over 3 workgroups: 96- and 64-row tiles, ragged last unit
+                                            (129, 2, 1, 2),      # T = 1: no recurrent half at all
+                                            (143, 3, 4, 1),      # 429 paths on ONE workgroup: 14 units = 3 + 3 + 3 + 3 + 2, last unit 13 rows
+                                            (86, 3, 8, 7)])      # 258 paths, T = 8 (the id tile's capacity); 9 units over 7 workgroups: lone 32-row units
+def test_scores_and_gradients_against_the_f64_oracle(pairs, P, T, grid, monkeypatch):
+    if grid:
+        monkeypatch.setenv("KPRN_PERSIST_GRID", str(grid))
+    eng, o64, theta, idx, labels = _case(pairs, P, T)
+    eng.profile(True)
+    b = eng.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    ps, _, probs = o64.forward(theta, idx)
+    assert _ran_persistent(eng)
+    e = rel_inf(out["path_scores"], ps)
+    assert e < 3e-2, e
+    np.testing.assert_allclose(out["probs"], probs[:, 0], atol=2e-2)
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 3e-2 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        r = rel_inf(g[off:off + n], og[off:off + n])
+        assert r < 6e-2, (nm, r)
+
+
+_AB = textwrap.dedent("""
+    import sys, json, numpy as np
+    sys.path.insert(0, %r)
+    from kprn_amd import _ffi, synth
+    pairs, P, T, Ve = %d, %d, %d, %d
+    eng = _ffi.Engine(6, Ve, 100, 128, 128, 128, 384, 1, compute_dtype=1, param_init=0.05)
+    idx, labels = synth.make_paths(pairs, P, T, Ve=Ve, Vr=100, seed=11)
+    b = eng.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    loss = eng.backward(b, 1)
+    g = eng.get_flat_grads()
+    res = {"loss": float(loss), "probs": out["probs"].astype(float).tolist(), "ps": out["path_scores"][::7, ::5].astype(float).ravel().tolist()}
+    for nm, (off, shp) in eng.layout().items():
+        if nm == "entity_emb":
+            continue
+        v = g[off:off + int(np.prod(shp))].astype(np.float64)
+        res["g_" + nm] = [float(np.abs(v).max()), float(v.sum()), float((v * np.cos(np.arange(v.size) * 0.37)).sum()), float(np.abs(v).sum())]
+    print(json.dumps(res))
+""")
+
+
+@pytest.mark.parametrize("pairs,P,T", [(2000, 5, 6)])
+def test_agrees_with_the_per_step_bf16_pipeline(pairs, P, T):
+    """Both pipelines round the same values to bf16 (table rows, weights, h_t) and accumulate in fp32; they differ in accumulation order
+    and in nothing else, so scores agree far inside bf16 resolution and the backward (shared) sees the same saves."""
+    res = {}
+    for tag, env in (("persist", {}), ("steps", {"KPRN_BF16_PERSIST": "0"})):
+        r = subprocess.run([sys.executable, "-c", _AB % (ROOT, pairs, P, T, 50000)], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = res["persist"], res["steps"]
+    ps_a, ps_b = np.array(a["ps"]), np.array(b["ps"])
+    assert np.max(np.abs(ps_a - ps_b)) < 2e-3 * np.max(np.abs(ps_b))
+    np.testing.assert_allclose(a["probs"], b["probs"], atol=2e-3)
+    assert abs(a["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(b["loss"]))
+    for nm, ref in b.items():
+        if not nm.startswith("g_"):
+            continue
+        got = a[nm]
+        assert abs(got[0] - ref[0]) < 2e-2 * max(1e-30, ref[0]), (nm, got, ref)
+        tol = 1e-2 * ref[3] + 1e-12
+        assert abs(got[1] - ref[1]) < tol and abs(got[2] - ref[2]) < tol, (nm, got, ref)
+
+
+def test_1024_work_tiles_against_the_f64_oracle():
+    """98 304 paths = 1 024 tiles of 96 rows on 256 workgroups (BASELINE configs[3]'s step is 65 536): every path's 46 scores against
+    the float64 oracle (OpenMP over paths on the host cores), pooled probabilities, and a second pass bit-identical to the first."""
+    pairs, P, T, Ve = 24576, 4, 6, 200000
+    eng, o64, theta, idx, labels = _case(pairs, P, T, Ve=Ve, seed=9)
+    eng.profile(True)
+    b = eng.batch(idx, labels)
+    out = eng.forward(b, 1, want=("probs", "path_scores"))
+    assert _ran_persistent(eng)
+    again = eng.forward(b, 1, want=("probs", "path_scores"))
+    assert np.array_equal(out["path_scores"], again["path_scores"])
+    ps, _, probs = o64.forward(theta, idx)
+    scale = np.max(np.abs(ps))
+    err = np.abs(out["path_scores"].astype(np.float64) - ps)
+    assert err.max() < 3e-2 * scale, err.max() / scale
+    assert np.sqrt(np.mean(err ** 2)) < 4e-3 * scale      # bf16 rounding noise, not a misplaced tile: an rms bound next to the max bound
+    np.testing.assert_allclose(out["probs"], probs[:, 0], atol=2e-2)
