@@ -11,7 +11,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkprn.so")
+LIB_PATH = os.environ.get("KPRN_LIB") or os.path.join(_HERE, "libkprn.so")   # (KPRN_LIB: a measurement build, scripts/build_variants.py)
 HEADER = os.path.join(_HERE, "..", "include", "kprn.h")
 
 

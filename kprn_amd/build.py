@@ -19,6 +19,15 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def file_flags(src):
+    """extra hipcc flags a source asks for in a leading `// hipcc-flags: ...` comment line"""
+    with open(src) as f:
+        for line in f.readlines()[:5]:
+            if line.startswith("// hipcc-flags:"):
+                return [w for w in line[len("// hipcc-flags:"):].split() if w.startswith("-")]
+    return []
+
+
 def stale():
     if not os.path.exists(OUT):
         return True
@@ -40,7 +49,7 @@ def build(force=False, verbose=False):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and all(os.path.getmtime(obj) > os.path.getmtime(h) for h in hdrs)):
             continue
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + file_flags(src) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

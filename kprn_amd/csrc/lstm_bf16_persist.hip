@@ -1,3 +1,4 @@
+// hipcc-flags: -fno-slp-vectorize     (packed fp32 VALU beside MFMAs is slower than the scalar pair it replaces; kprn_amd/build.py reads this line)
 // configs[3] (BASELINE.json: 20 M entities, d = 128 -> D = H = 384, "bf16 MFMA LSTM"): one FastLSTM layer as ONE persistent launch.
 //
 // Stands for   FeatureEmbedding (3 x nn.LookupTable + JoinTable)        release/songPathRnn/net/FeatureEmbedding.lua:112-121
@@ -31,6 +32,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "kprn_internal.h"
 
@@ -46,7 +48,8 @@ namespace pk {
 
 constexpr int MAXPT = 3;     // path tiles (32 rows each) of a work tile
 constexpr int ROWS = 32 * MAXPT;
-constexpr int PF = 12;       // weight fragments in flight per wave (must divide the k-steps of a half)
+constexpr int PF_DEFAULT = 12;   // weight fragments in flight per wave (must divide the k-steps of a half)
+constexpr int LA_DEFAULT = 2;    // k-steps the LDS operand fragments are read ahead
 constexpr int NTH = 256;
 constexpr int MAXT = 8;      // steps whose ids are staged in LDS
 constexpr int MAXSEG = 3;
@@ -65,6 +68,15 @@ struct Args {
   int64_t units;     // ceil(N / 32)
 };
 
+// compile-time loop: the body sees its index as a constant (register arrays stay registers, stage switches fold)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
 
 // One LDS-DMA piece: 64 lanes x 16 bytes, lane l's bytes land at lds_dst + 16 l (lds_dst wave-uniform).  Inline asm so that hipcc
@@ -81,138 +93,205 @@ __device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_
 // every wave's global stores and LDS-DMA pieces have landed, then the barrier
 __device__ __forceinline__ void bar_vm0() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Global accesses go through buffer instructions: descriptor (SGPRs) + wave-uniform byte offset (SGPR) + 32-bit lane offset (VGPR).
+// With ordinary pointers hipcc re-associates (uniform base + constant) + lane offset into per-lane 64-bit pointers, precomputes one VGPR pair
+// for every 4 KB of every weight / scratch stream the unrolled bodies touch, and spills ~200 registers that are then reloaded from
+// scratch inside the MFMA loops; a buffer access keeps everything uniform in scalar registers and steps it with scalar adds.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000); }
+template <class V> __device__ __forceinline__ V ldb(rsrc_t r, unsigned voff, unsigned soff) {
+  static_assert(sizeof(V) == 16, "16-byte pieces");
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return __builtin_bit_cast(V, v);
+}
+template <class V> __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, V v) {
+  if constexpr (sizeof(V) == 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 0);
+  else { static_assert(sizeof(V) == 8, "8- or 16-byte pieces"); __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0); }
+}
+
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f; }
 
-// ---- the cell of one finished chunk, cut into slices that ride behind the next chunk's MFMAs -------------------------------
-template <int NPT, int KH, bool SAVE>
+// ---- the cell of one finished chunk, as a software pipeline that rides behind the next chunk's MFMAs ---------------------------
+// A lane owns NPT x 4 elements (path tile, hidden unit) of the chunk.  One element = 25 VALU operations (10 of them exp2 / rcp),
+// cut into 8 stages of <= 4 operations in which nothing consumes a transcendental issued in the same stage; the product loop
+// calls micro(k) once behind every MFMA (k = 0 .. NSLOT - 1): element e enters the pipeline at slot start(e), two elements are
+// in flight at any time.  hipcc's own interleaving left the cell as one VALU-only stretch between bunched MFMAs (measured:
+// 1.12 ms against 0.77 ms without the cell), so the order is pinned at the call site with sched_barrier.
+template <int NPT, int KH, bool SAVE, int DBG = 0>
 struct Cell {
   static constexpr int H = KH * 16;
-  static constexpr int NSL = NPT * 8;   // slices: per path tile, 4 hidden units x {i, g | f, o, c, h}
+  static constexpr int NE = NPT * 4;     // elements per lane
+  static constexpr int NST = 9;          // stages per element (the last one: the path tile's stores, after its 4th element)
   const Args& a;
   int wave, lane, ln, half;
   int64_t row0; int nvalid;
-  bf16* hs; float* cs;
+  rsrc_t hs, cs;             // this workgroup's scratch slabs (h_t fragments, ping-pong; c_t, scoring)
   int te, ce;                // the chunk being finished: step, chunk
-  f32x16 pre[MAXPT];         // its pre-activations (bias included)
   f32x4 cp[MAXPT];           // c_{t-1} of its elements
-  float ig[4], gg[4], cc[4], hh[4], fg[4], og[4];
+  struct El { float vi, vg, vf, vo, ig, c, t; } el[2];      // the two elements in flight
+  float gi[2][4], gg[2][4], gf[2][4], go[2][4], cc[2][4], hh[2][4];   // finished values of a path tile (two tiles may overlap)
 
-  __device__ __forceinline__ Cell(const Args& a_, int wave_, int lane_, int64_t row0_, int nvalid_, bf16* hs_, float* cs_)
+  __device__ __forceinline__ Cell(const Args& a_, int wave_, int lane_, int64_t row0_, int nvalid_, rsrc_t hs_, rsrc_t cs_)
       : a(a_), wave(wave_), lane(lane_), ln(lane_ & 31), half(lane_ >> 5), row0(row0_), nvalid(nvalid_), hs(hs_), cs(cs_), te(0), ce(0) {}
 
-  __device__ __forceinline__ int u0() const { return 32 * ce + 8 * wave + 4 * half; }   // first of this lane's 4 hidden units
+  // byte offsets of this lane's piece inside (uniform) row-major planes of pitch H / 4H elements: row ln, hidden units 4 half ..
+  __device__ __forceinline__ unsigned lo_row(int pitch_elems, int elt) const { return (unsigned)((ln * pitch_elems + 4 * half) * elt); }
 
   // c_{t-1} of chunk (t, c)'s elements: requested one chunk ahead of the cell that needs it (a dependent load at the head of a
-  // chunk would stall its first slices for an L2 round trip)
+  // chunk would stall its first stages for an L2 round trip)
   __device__ __forceinline__ void request(int t, int c, f32x4 (&cpn)[MAXPT]) const {
-    const int u = 32 * c + 8 * wave + 4 * half;
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt) {
       cpn[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t > 0) {
+      if (t > 0 && !(DBG & 16)) {
         if (SAVE) {
-          const int r = 32 * pt + ln;
-          if (r < nvalid) cpn[pt] = *(const f32x4*)(a.Cs + ((int64_t)(t - 1) * a.N + row0 + r) * H + u);
+          const float* ub = a.Cs + ((int64_t)(t - 1) * a.N + row0 + 32 * pt) * H + 32 * c + 8 * wave;
+          if (32 * pt + ln < nvalid) cpn[pt] = ldb<f32x4>(make_rsrc(ub), lo_row(H, 4), 0);
         } else {
-          cpn[pt] = *(const f32x4*)(cs + ((int64_t)((c * MAXPT + pt) * 4 + wave) * 64 + lane) * 4);
+          cpn[pt] = ldb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((c * MAXPT + pt) * 4 + wave) * 1024u);
         }
       }
     }
   }
-  // take over a finished chunk: its accumulators and the c_{t-1} requested for it
-  __device__ __forceinline__ void take(int t, int c, const f32x16 (&acc)[MAXPT], const f32x4 (&cpn)[MAXPT]) {
+  // take over a finished chunk (its pre-activations stay in the accumulator set they were formed in and are handed to every stage)
+  __device__ __forceinline__ void take(int t, int c, const f32x4 (&cpn)[MAXPT]) {
     te = t; ce = c;
 #pragma unroll
-    for (int pt = 0; pt < NPT; ++pt) { pre[pt] = acc[pt]; cp[pt] = cpn[pt]; }
+    for (int pt = 0; pt < NPT; ++pt) cp[pt] = cpn[pt];
   }
 
   __device__ __forceinline__ void store(int pt) {
-    const int r = 32 * pt + ln;
+    if (DBG & 16) {   // (measurement: the cell's arithmetic without its memory traffic)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(hh[pt & 1][j]), "v"(cc[pt & 1][j]));
+      return;
+    }
+    const int r = 32 * pt + ln, b = pt & 1;
     const bool ok = r < nvalid;
-    const int u = u0();
     bf16x4 hb;
     f32x4 cv, hv;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { hb[j] = (bf16)hh[j]; cv[j] = cc[j]; hv[j] = hh[j]; }
-    // h_t for the next step's recurrent half: B-fragment order, k = hidden unit
-    {
-      const int sh = 2 * ce + (wave >> 1), kg = wave & 1;
-      bf16* dst = hs + (int64_t)(te & 1) * (MAXPT * KH * 512) + ((int64_t)((pt * KH + sh) * 64 + kg * 32 + ln)) * 8 + 4 * half;
-      *(bf16x4*)dst = hb;
-    }
+    for (int j = 0; j < 4; ++j) { hb[j] = (bf16)hh[b][j]; cv[j] = cc[b][j]; hv[j] = hh[b][j]; }
+    // h_t for the next step's recurrent half: B-fragment order, k = hidden unit (32 ce + 8 wave + 4 half + j: k-step 2 ce + (wave >> 1),
+    // k-group wave & 1, element 4 half + j)
+    stb<bf16x4>(hs, (unsigned)(ln * 16 + half * 8), (unsigned)((te & 1) * (MAXPT * KH * 1024) + (pt * KH + 2 * ce + (wave >> 1)) * 1024 + (wave & 1) * 512), hb);
+    const int64_t cu = 32 * ce + 8 * wave;   // first hidden unit of this wave's piece
     if (SAVE) {
       if (ok) {
-        const int64_t row = (int64_t)te * a.N + row0 + r;
-        *(f32x4*)(a.Cs + row * H + u) = cv;
-        *(bf16x4*)(a.H16 + row * H + u) = hb;
-        bf16x4 gi, g2, gf, go;
+        const int64_t row = (int64_t)te * a.N + row0 + 32 * pt;
+        stb<f32x4>(make_rsrc(a.Cs + row * H + cu), lo_row(H, 4), 0, cv);
+        stb<bf16x4>(make_rsrc(a.H16 + row * H + cu), lo_row(H, 2), 0, hb);
+        bf16x4 vi, vg, vf, vo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { gi[j] = (bf16)ig[j]; g2[j] = (bf16)gg[j]; gf[j] = (bf16)fg[j]; go[j] = (bf16)og[j]; }
-        bf16* g = a.ACT16 + row * (4 * H) + u;
-        *(bf16x4*)(g) = gi; *(bf16x4*)(g + H) = g2; *(bf16x4*)(g + 2 * H) = gf; *(bf16x4*)(g + 3 * H) = go;
+        for (int j = 0; j < 4; ++j) { vi[j] = (bf16)gi[b][j]; vg[j] = (bf16)gg[b][j]; vf[j] = (bf16)gf[b][j]; vo[j] = (bf16)go[b][j]; }
+        const rsrc_t g = make_rsrc(a.ACT16 + row * (4 * H) + cu);
+        const unsigned lo = lo_row(4 * H, 2);
+        stb<bf16x4>(g, lo, 0, vi); stb<bf16x4>(g, lo, 2 * H, vg); stb<bf16x4>(g, lo, 4 * H, vf); stb<bf16x4>(g, lo, 6 * H, vo);
       }
     } else {
-      *(f32x4*)(cs + ((int64_t)((ce * MAXPT + pt) * 4 + wave) * 64 + lane) * 4) = cv;
+      stb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((ce * MAXPT + pt) * 4 + wave) * 1024u, cv);
     }
-    if (te == a.T - 1 && ok) *(f32x4*)(a.hT + (row0 + r) * H + u) = hv;
+    if (te == a.T - 1 && ok) stb<f32x4>(make_rsrc(a.hT + (row0 + 32 * pt) * H + cu), lo_row(H, 4), 0, hv);
   }
 
-  // slice sl of NSL (compile-time after unrolling)
-  __device__ __forceinline__ void slice(int sl) {
-    const int pt = sl >> 3, q = sl & 7, j = q >> 1;
-    if ((q & 1) == 0) {
-      ig[j] = sigm(pre[pt][j]);
-      gg[j] = tanh_fast(pre[pt][4 + j]);
-    } else {
-      fg[j] = sigm(pre[pt][8 + j]);
-      og[j] = sigm(pre[pt][12 + j]);
-      cc[j] = fg[j] * cp[pt][j] + ig[j] * gg[j];
-      hh[j] = og[j] * tanh_fast(cc[j]);
-      if (q == 7) store(pt);
+  // stage ST of element E = (path tile pt, hidden unit j)
+  template <int E, int ST>
+  __device__ __forceinline__ void stage(const f32x16 (&pre)[MAXPT]) {
+    constexpr float K1 = -1.4426950408889634f, K2 = -2.8853900817779268f;   // sigmoid(x) = rcp(1 + exp2(K1 x)), tanh(x) = 2 rcp(1 + exp2(K2 x)) - 1
+    constexpr int pt = E >> 2, j = E & 3, b = pt & 1;
+    El& x = el[E & 1];
+    if constexpr (ST == 0) { x.vi = __builtin_amdgcn_exp2f(pre[pt][j] * K1); x.vg = pre[pt][4 + j] * K2; }
+    else if constexpr (ST == 1) { x.vg = __builtin_amdgcn_exp2f(x.vg); x.vf = pre[pt][8 + j] * K1; x.vo = pre[pt][12 + j] * K1; }
+    else if constexpr (ST == 2) { x.vf = __builtin_amdgcn_exp2f(x.vf); x.vo = __builtin_amdgcn_exp2f(x.vo); x.vi += 1.0f; x.vg += 1.0f; }
+    else if constexpr (ST == 3) { x.vi = __builtin_amdgcn_rcpf(x.vi); x.vg = __builtin_amdgcn_rcpf(x.vg); x.vf += 1.0f; x.vo += 1.0f; }
+    else if constexpr (ST == 4) { x.vf = __builtin_amdgcn_rcpf(x.vf); x.vo = __builtin_amdgcn_rcpf(x.vo); x.vg = 2.0f * x.vg - 1.0f; x.ig = x.vi * x.vg; }
+    else if constexpr (ST == 5) { x.c = x.vf * cp[pt][j] + x.ig; x.t = __builtin_amdgcn_exp2f(x.c * K2); }
+    else if constexpr (ST == 6) { x.t = __builtin_amdgcn_rcpf(x.t + 1.0f); }
+    else if constexpr (ST == 7) {
+      x.t = 2.0f * x.t - 1.0f;
+      cc[b][j] = x.c; hh[b][j] = x.vo * x.t;
+      if (SAVE) { gi[b][j] = x.vi; gg[b][j] = x.vg; gf[b][j] = x.vf; go[b][j] = x.vo; }
+    } else if constexpr (j == 3) {
+      store(pt);
     }
   }
-  __device__ __forceinline__ void all() {
-#pragma unroll
-    for (int sl = 0; sl < NSL; ++sl) slice(sl);
+  // slot K of NSLOT behind the MFMAs that carry this cell (one or two product halves): every element whose pipeline covers the slot
+  // advances one stage
+  template <int NSLOT, int K>
+  __device__ __forceinline__ void micro(const f32x16 (&pre)[MAXPT]) {
+    static_assert(NSLOT >= NE + NST, "too few MFMAs to carry the cell");
+    static_for<0, NE>([&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value;
+      constexpr int st = K - (e * (NSLOT - NST)) / (NE - 1);
+      if constexpr (st >= 0 && st < NST) stage<e, st>(pre);
+    });
+  }
+  __device__ __forceinline__ void all(const f32x16 (&pre)[MAXPT]) {
+    static_for<0, NE * NST>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int n = decltype(ic)::value;
+      stage<n / NST, n % NST>(pre);
+    });
   }
 };
 
 // ---- one half of a chunk's product: NK k-steps over one LDS operand tile -----------------------------------------------------
 // ring[s % PF] holds the weight fragment of k-step s; the fragment of step s + PF is requested as soon as step s has been issued
-// (from this half's stream, or from the head of the next half's).  CELL: the finished chunk's cell rides behind the MFMAs.
-template <int NPT, int NK, bool CELL, class CellT>
-__device__ __forceinline__ void half_product(f32x16 (&acc)[MAXPT], bf16x8 (&ring)[PF], const bf16x8* __restrict__ cur, const bf16x8* __restrict__ nxt,
-                                             const char* tile /* LDS operand tile + 16 lane */, CellT& cell) {
+// (from this half's stream, or from the head of the next half's); the LDS operand fragments are read LA k-steps ahead.
+// Issue order, pinned (one wave per SIMD: nothing else fills an MFMA's shadow): behind every MFMA one operand read and one slot
+// of the finished chunk's cell (CELL), the weight request behind the k-step's last.
+// DBG (measurement builds only, KPRN_PERSIST_DBG): 1 no cell, 2 no weight stream, 4 no LDS operand reads, 8 no MFMAs.
+// CSLOTS / COFF: the finished chunk's cell is carried by CSLOTS MFMAs of which this half supplies [COFF, COFF + NK NPT) (CSLOTS = 0: none).
+// INIT: the chunk starts here, its accumulators are formed from the bias image (srcC of the first MFMAs: no copies), which is then
+// reloaded for the next chunk to start (bias_next).
+template <int NPT, int NK, int PF, int LA, bool INIT, int CSLOTS, int COFF, int DBG, class CellT>
+__device__ __forceinline__ void half_product(f32x16 (&acc)[MAXPT], f32x16& bias, rsrc_t rB, unsigned bias_next /* byte offset of the next chunk's image */,
+                                             const f32x16 (&prev)[MAXPT], bf16x8 (&ring)[PF], rsrc_t rW, unsigned cur /* byte offset of this half's weight stream of this wave */,
+                                             unsigned nxt /* ... of the next half's */, const char* tile /* LDS operand tile + 16 lane */, CellT& cell) {
+  const unsigned l16 = (unsigned)cell.lane * 16u;
   static_assert(NK % PF == 0, "the weight ring must keep its phase across halves");
-  bf16x8 xf[2][MAXPT];
+  static_assert(LA >= 1 && LA < NK, "operand fragments are read LA k-steps ahead of their MFMAs");
+  bf16x8 xf[LA + 1][MAXPT];
 #pragma unroll
-  for (int pt = 0; pt < NPT; ++pt) xf[0][pt] = *(const bf16x8*)(tile + (pt * NK) * 1024);
+  for (int q = 0; q < LA; ++q)
 #pragma unroll
-  for (int s = 0; s < NK; ++s) {
-    if (s + 1 < NK) {
+    for (int pt = 0; pt < NPT; ++pt) xf[q][pt] = *(const bf16x8*)(tile + (pt * NK + q) * 1024);
+  static_for<0, NK * NPT>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int k = decltype(ic)::value, s = k / NPT, pt = k % NPT;
+    const bf16x8 xv = xf[(DBG & 4) ? 0 : (s % (LA + 1))][pt];
+    if constexpr ((DBG & 8) != 0) { asm volatile("" :: "v"(ring[s % PF]), "v"(xv)); if (INIT && s == 0) acc[pt] = bias; }
+    else if constexpr (INIT && s == 0) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % PF], xv, bias, 0, 0, 0);
+    else acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % PF], xv, acc[pt], 0, 0, 0);
+    // the k-step's operand reads go out together behind its first MFMA: one lgkmcnt wait per k-step instead of one per MFMA
+    if constexpr (pt == 0 && s + LA < NK && !(DBG & 4)) {
 #pragma unroll
-      for (int pt = 0; pt < NPT; ++pt) xf[(s + 1) & 1][pt] = *(const bf16x8*)(tile + (pt * NK + s + 1) * 1024);
+      for (int q = 0; q < NPT; ++q) xf[(s + LA) % (LA + 1)][q] = *(const bf16x8*)(tile + (q * NK + s + LA) * 1024);
     }
-    const bf16x8 w = ring[s % PF];
-#pragma unroll
-    for (int pt = 0; pt < NPT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xf[s & 1][pt], acc[pt], 0, 0, 0);
-    ring[s % PF] = (s + PF < NK) ? cur[(s + PF) * 64] : nxt[(s + PF - NK) * 64];
-    if (CELL) {
-      constexpr int NSL = CellT::NSL;
-      const int s0 = (s * NSL) / NK, s1 = ((s + 1) * NSL) / NK;
-#pragma unroll
-      for (int sl = s0; sl < s1; ++sl) cell.slice(sl);
+    if constexpr (pt == NPT - 1 && !(DBG & 2)) {   // (1 KiB pieces: three of four requests differ from the one before in the immediate offset only)
+      constexpr int sn = (s + PF < NK) ? s + PF : s + PF - NK;
+      ring[s % PF] = ldb<bf16x8>(rW, l16 + (unsigned)(sn & 3) * 1024u, ((s + PF < NK) ? cur : nxt) + (unsigned)(sn & ~3) * 1024u);
     }
-  }
+    if constexpr (INIT && k == NPT - 1) {   // the bias image has been consumed: request the next chunk's
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = ldb<f32x4>(rB, (unsigned)cell.half * 64u + 16u * q, bias_next);
+        bias[4 * q] = v[0]; bias[4 * q + 1] = v[1]; bias[4 * q + 2] = v[2]; bias[4 * q + 3] = v[3];
+      }
+    }
+    if constexpr (CSLOTS > 0 && !(DBG & 1)) cell.template micro<CSLOTS, COFF + k>(prev);
+    __builtin_amdgcn_sched_barrier(0);
+  });
 }
 
 // ---- a work tile: NPT path tiles, all T steps ---------------------------------------------------------------------------------
-template <int NPT, int KX, int KH, bool SAVE>
-__device__ __forceinline__ void run_tile(const Args& a, char* XB, char* HB, int32_t* IDS, bf16x8 (&ring)[PF], const bf16x8* wbase, bf16* hs, float* cs,
+template <int NPT, int KX, int KH, bool SAVE, int PF, int LA, int DBG>
+__device__ __forceinline__ void run_tile(const Args& a, char* XB, char* HB, int32_t* IDS, bf16x8 (&ring)[PF], rsrc_t rW, rsrc_t rB, const bf16* hs_ptr, rsrc_t hs, rsrc_t cs,
                                          int64_t row0, int nvalid, int wave, int lane) {
   constexpr int H = KH * 16, NCH = H / 32, KS = KX + KH;
-  constexpr int64_t WCH = (int64_t)4 * KS * 64;   // bf16x8 pieces between a wave's fragments of consecutive chunks
+  constexpr unsigned WCH = 4u * KS * 1024u;   // bytes between a wave's fragments of consecutive chunks
+  const unsigned wbase = (unsigned)wave * KS * 1024u;   // this wave's fragments of chunk 0
   const int ln = lane & 31, half = lane >> 5;
   const int T = a.T;
   // ids of the tile: IDS[(t * MAXSEG + seg) * ROWS + r] = table row (0-based) / path (plane segments); rows past the tile repeat its last
@@ -239,71 +318,90 @@ __device__ __forceinline__ void run_tile(const Args& a, char* XB, char* HB, int3
     }
   };
   auto fetch_h = [&](int t_src) {   // h_{t_src} from the scratch slab into the LDS operand tile
-    const bf16* slab = hs + (int64_t)(t_src & 1) * (MAXPT * KH * 512);
+    const char* slab = (const char*)(hs_ptr + (int64_t)(t_src & 1) * (MAXPT * KH * 512));
     for (int f = wave; f < NPT * KH; f += 4)
-      dma16(slab + ((int64_t)f * 64 + lane) * 8, (unsigned)__builtin_amdgcn_readfirstlane((int)(hb_lds + (unsigned)f * 1024u)));
+      dma16(slab + (int64_t)f * 1024 + lane * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)(hb_lds + (unsigned)f * 1024u)));
   };
+  auto BP = [&](int c) -> unsigned { return (unsigned)((c < NCH ? c : c - NCH) * 4 + wave) * 128u; };   // byte offset of chunk c's (mod NCH) bias image: [2 halves][16]
   auto load_bias = [&](int c) -> f32x16 {   // accumulator image of chunk c's bias (the same for every path column)
-    const f32x4* bp = (const f32x4*)(a.Bp + ((int64_t)(c * 4 + wave) * 2 + half) * 16);
     f32x16 b;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 v = bp[q];
+      const f32x4 v = ldb<f32x4>(rB, (unsigned)half * 64u, BP(c) + 16 * q);
       b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3];
     }
     return b;
   };
-  auto wx = [&](int c) -> const bf16x8* { return wbase + (int64_t)c * WCH; };
-
   gather_x(0);
   bar_vm0();
 
-  Cell<NPT, KH, SAVE> cell(a, wave, lane, row0, nvalid, hs, cs);
+  // Two accumulator sets: even chunks form in A, odd chunks in B (NCH is even); while a chunk forms in one set, the cell of the chunk
+  // before it reads the other.  Per set: the c_{t-1} requested for the chunk forming in it, and the bias image it starts from.
+  static_assert(NCH % 2 == 0 && NCH >= 4, "the chunk schedule below alternates two accumulator sets and reorders the first two chunks of a step");
+  constexpr int XS = KX * NPT, HS = KH * NPT;   // MFMAs of an input half / a recurrent half
+  Cell<NPT, KH, SAVE, DBG> cell(a, wave, lane, row0, nvalid, hs, cs);
   const char* xt = XB + lane * 16;
   const char* ht = HB + lane * 16;
-  f32x16 acc[MAXPT];
-  f32x4 cpn[MAXPT];            // c_{t-1} of the chunk in flight (for the cell that will finish it)
-  f32x16 bn = load_bias(0);    // bias image of the next chunk to start
-  // (t = 0, chunk 0): nothing to finish yet
+  f32x16 accA[MAXPT], accB[MAXPT], bn;
+  f32x4 cpn[MAXPT];
+  auto X = [&](int c) -> unsigned { return wbase + (unsigned)c * WCH; };               // weight stream of chunk c's input half (byte offset)
+  auto Hh = [&](int c) -> unsigned { return wbase + (unsigned)c * WCH + KX * 1024u; };   // ... of its recurrent half
+  auto keep = [&](f32x16 (&acc)[MAXPT]) {   // (measurement builds without the cell: the products stay alive)
+    if (DBG & 1) {
 #pragma unroll
-  for (int pt = 0; pt < NPT; ++pt) acc[pt] = bn;
-  bn = load_bias(NCH > 1 ? 1 : 0);
-  cell.request(0, 0, cpn);
-  half_product<NPT, KX, false>(acc, ring, wx(0), wx(NCH > 1 ? 1 : 0), xt, cell);
-  if (NCH == 1 && T > 1) { bar(); gather_x(1); bar_vm0(); }
-  const int Q = T * NCH;
-  for (int lin = 1; lin < Q; ++lin) {
-    const int t = lin / NCH, c = lin - t * NCH;
-    const int tp = (lin - 1) / NCH, cf = (lin - 1) - tp * NCH;
-    const int cn = (c + 1 == NCH) ? 0 : c + 1;
-    cell.take(tp, cf, acc, cpn);
-#pragma unroll
-    for (int pt = 0; pt < NPT; ++pt) acc[pt] = bn;
-    bn = load_bias(cn);
-    cell.request(t, c, cpn);
-    half_product<NPT, KX, true>(acc, ring, wx(c), (t > 0) ? wx(c) + KX * 64 : wx(cn), xt, cell);
-    const bool last_chunk = (c + 1 == NCH);
-    if (last_chunk && t + 1 < T) { bar(); gather_x(t + 1); }   // every wave has read x_t for the last time
-    if (t > 0) {
-      if (c == 0) {
-        // the cell stores of step t - 1 (the last of them rode behind the product above) have landed; every wave is done with h_{t-2}
-        bar_vm0();
-        fetch_h(t - 1);
-        bar_vm0();
-      }
-      half_product<NPT, KH, false>(acc, ring, wx(c) + KX * 64, wx(cn), ht, cell);
+      for (int pt = 0; pt < NPT; ++pt) asm volatile("" :: "v"(acc[pt]));
     }
-    if (last_chunk && t + 1 < T) bar_vm0();   // x_{t+1} is in place
+  };
+  const int T1 = T - 1;
+  // ---- t = 0: input halves only; the cell of chunk c - 1 rides behind chunk c's
+  bn = load_bias(0);
+  cell.request(0, 0, cpn);
+  half_product<NPT, KX, PF, LA, true, 0, 0, DBG>(accA, bn, rB, BP(1), accB, ring, rW, X(0), X(1), xt, cell);
+  for (int c0 = 0; c0 < NCH; c0 += 2) {
+    if (c0 > 0) {
+      cell.take(0, c0 - 1, cpn); keep(accB);
+      cell.request(0, c0, cpn);
+      half_product<NPT, KX, PF, LA, true, XS, 0, DBG>(accA, bn, rB, BP(c0 + 1), accB, ring, rW, X(c0), X(c0 + 1), xt, cell);
+    }
+    cell.take(0, c0, cpn); keep(accA);
+    cell.request(0, c0 + 1, cpn);
+    half_product<NPT, KX, PF, LA, true, XS, 0, DBG>(accB, bn, rB, BP(c0 + 2), accA, ring, rW, X(c0 + 1), X(c0 + 2 < NCH ? c0 + 2 : 0), xt, cell);
   }
-  {
-    const int tp = (Q - 1) / NCH, cl = (Q - 1) - tp * NCH;
-    cell.take(tp, cl, acc, cpn);
-    cell.all();
+  if (T > 1) { bar(); gather_x(1); bar_vm0(); }   // (t = 0 has no recurrent half to hide this gather behind)
+  // ---- t >= 1.  Order of the product halves: X0 X1 H0 H1, then X_c H_c for c >= 2 -- the fetch of h_{t-1} (which has to wait for the last
+  // cell of step t - 1, riding behind X0) lands while X1 runs.
+  for (int t = 1; t < T; ++t) {
+    cell.take(t - 1, NCH - 1, cpn); keep(accB);
+    cell.request(t, 0, cpn);
+    half_product<NPT, KX, PF, LA, true, XS, 0, DBG>(accA, bn, rB, BP(1), accB, ring, rW, X(0), X(1), xt, cell);
+    bar_vm0();        // every wave's cell stores of step t - 1 have landed, and every wave is done with h_{t-2}
+    fetch_h(t - 1);
+    half_product<NPT, KX, PF, LA, true, 0, 0, DBG>(accB, bn, rB, BP(2), accA, ring, rW, X(1), Hh(0), xt, cell);
+    bar_vm0();        // h_{t-1} is in place
+    half_product<NPT, KH, PF, LA, false, 0, 0, DBG>(accA, bn, rB, 0u, accB, ring, rW, Hh(0), Hh(1), ht, cell);
+    cell.take(t, 0, cpn); keep(accA);
+    cell.request(t, 1, cpn);
+    half_product<NPT, KH, PF, LA, false, HS, 0, DBG>(accB, bn, rB, 0u, accA, ring, rW, Hh(1), X(2), ht, cell);
+    for (int c0 = 2; c0 < NCH; c0 += 2) {
+      const bool last = (c0 + 2 == NCH);
+      cell.take(t, c0 - 1, cpn); keep(accB);
+      cell.request(t, c0, cpn);
+      half_product<NPT, KX, PF, LA, true, XS + HS, 0, DBG>(accA, bn, rB, BP(c0 + 1), accB, ring, rW, X(c0), Hh(c0), xt, cell);
+      half_product<NPT, KH, PF, LA, false, XS + HS, XS, DBG>(accA, bn, rB, 0u, accB, ring, rW, Hh(c0), X(c0 + 1), ht, cell);
+      cell.take(t, c0, cpn); keep(accA);
+      cell.request(t, c0 + 1, cpn);
+      half_product<NPT, KX, PF, LA, true, XS + HS, 0, DBG>(accB, bn, rB, BP(c0 + 2), accA, ring, rW, X(c0 + 1), Hh(c0 + 1), xt, cell);
+      if (last && t < T1) { bar(); gather_x(t + 1); }   // every wave has read x_t for the last time
+      half_product<NPT, KH, PF, LA, false, XS + HS, XS, DBG>(accB, bn, rB, 0u, accA, ring, rW, Hh(c0 + 1), X(last ? 0 : c0 + 2), ht, cell);
+      if (last && t < T1) bar_vm0();                    // x_{t+1} is in place
+    }
   }
+  cell.take(T1, NCH - 1, cpn); keep(accB);
+  if (!(DBG & 1)) cell.all(accB);
   bar();   // the operand tiles and the id tile are free for the next work tile
 }
 
-template <int KX, int KH, bool SAVE>
+template <int KX, int KH, bool SAVE, int PF, int LA, int DBG>
 __global__ __launch_bounds__(NTH, 1) void k_lstm16_persist(Args a) {
   constexpr int KS = KX + KH;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -315,19 +413,19 @@ __global__ __launch_bounds__(NTH, 1) void k_lstm16_persist(Args a) {
   const int64_t G = gridDim.x, b = blockIdx.x;
   const int64_t u_beg = a.units * b / G, u_end = a.units * (b + 1) / G;
   if (u_beg >= u_end) return;
-  bf16* hs = a.hscr + b * (int64_t)(2 * MAXPT * KH * 512);
-  float* cs = a.cscr + b * (int64_t)((KH / 2) * MAXPT * 4 * 64 * 4);
-  const bf16x8* wbase = (const bf16x8*)a.Wp + (int64_t)wave * KS * 64 + lane;
+  const bf16* hs_ptr = a.hscr + b * (int64_t)(2 * MAXPT * KH * 512);
+  const rsrc_t hs = make_rsrc(hs_ptr), cs = make_rsrc(a.cscr + b * (int64_t)((KH / 2) * MAXPT * 4 * 64 * 4));
+  const rsrc_t rW = make_rsrc(a.Wp), rB = make_rsrc(a.Bp);
   bf16x8 ring[PF];
 #pragma unroll
-  for (int s = 0; s < PF; ++s) ring[s] = wbase[s * 64];
+  for (int s = 0; s < PF; ++s) ring[s] = ldb<bf16x8>(rW, (unsigned)lane * 16u, (unsigned)(wave * KS + s) * 1024u);
   for (int64_t u = u_beg; u < u_end;) {
     const int64_t rem = u_end - u;
     const int take = rem >= 5 ? 3 : (rem == 4 ? 2 : (int)rem);   // 4 left: 2 + 2 rather than 3 + 1
     const int64_t row0 = u * 32;
     const int nvalid = (int)std::min<int64_t>((int64_t)take * 32, a.N - row0);
-    if (take == 3) run_tile<3, KX, KH, SAVE>(a, XB, HB, IDS, ring, wbase, hs, cs, row0, nvalid, wave, lane);
-    else run_tile<2, KX, KH, SAVE>(a, XB, HB, IDS, ring, wbase, hs, cs, row0, nvalid, wave, lane);
+    if (take == 3) run_tile<3, KX, KH, SAVE, PF, LA, DBG>(a, XB, HB, IDS, ring, rW, rB, hs_ptr, hs, cs, row0, nvalid, wave, lane);
+    else run_tile<2, KX, KH, SAVE, PF, LA, DBG>(a, XB, HB, IDS, ring, rW, rB, hs_ptr, hs, cs, row0, nvalid, wave, lane);
     u += take;
   }
 }
@@ -439,15 +537,25 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
   if (const char* e = getenv("KPRN_PERSIST_GRID"))   // (tests: few workgroups -> 96-row tiles at small N; many -> lone 32-row units)
     grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(p->grid, a.units), atoi(e)));
   const size_t lds_bytes = (size_t)pk::MAXPT * (KX + KH) * 1024 + (size_t)pk::MAXT * pk::MAXSEG * pk::ROWS * sizeof(int32_t);
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[save]) {
-    if (save) HIP_TRY(hipFuncSetAttribute((const void*)pk::k_lstm16_persist<KX, KH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    else HIP_TRY(hipFuncSetAttribute((const void*)pk::k_lstm16_persist<KX, KH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done[save] = true;
+  typedef void (*Kern)(pk::Args);
+  Kern k = save ? (Kern)pk::k_lstm16_persist<KX, KH, true, pk::PF_DEFAULT, pk::LA_DEFAULT, 0> : (Kern)pk::k_lstm16_persist<KX, KH, false, pk::PF_DEFAULT, pk::LA_DEFAULT, 0>;
+#ifdef KPRN_PERSIST_VARIANTS
+  // measurement builds (scripts/gpu_persist_knockouts.py): KPRN_PERSIST_DBG = knock-out mask, KPRN_PERSIST_PF = ring depth, KPRN_PERSIST_LA
+  if (!save) {
+    const int dbg = getenv("KPRN_PERSIST_DBG") ? atoi(getenv("KPRN_PERSIST_DBG")) : 0;
+    const int pf = getenv("KPRN_PERSIST_PF") ? atoi(getenv("KPRN_PERSIST_PF")) : pk::PF_DEFAULT;
+    const int la = getenv("KPRN_PERSIST_LA") ? atoi(getenv("KPRN_PERSIST_LA")) : pk::LA_DEFAULT;
+    bool found = false;
+#define KV(P, A, Dg) if (pf == P && la == A && dbg == Dg) { k = (Kern)pk::k_lstm16_persist<KX, KH, false, P, A, Dg>; found = true; }
+    KV(12, 2, 0) KV(24, 2, 0) KV(12, 1, 0) KV(12, 3, 0) KV(8, 2, 0) KV(24, 3, 0)
+    KV(12, 2, 1) KV(12, 2, 2) KV(12, 2, 4) KV(12, 2, 6) KV(12, 2, 7) KV(12, 2, 9) KV(12, 2, 11) KV(12, 2, 13) KV(12, 2, 15) KV(24, 2, 13) KV(12, 2, 16) KV(12, 2, 22)
+#undef KV
+    KPRN_REQUIRE(found, KPRN_E_ARG, "this variant of the persistent kernel is not compiled in");
   }
+#endif
+  HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   ProfScope ps(h, save ? "lstm_persist_bf16_train" : "lstm_persist_bf16_score");
-  if (save) hipLaunchKernelGGL((pk::k_lstm16_persist<KX, KH, true>), dim3(grid), dim3(pk::NTH), lds_bytes, strm, a);
-  else hipLaunchKernelGGL((pk::k_lstm16_persist<KX, KH, false>), dim3(grid), dim3(pk::NTH), lds_bytes, strm, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(pk::NTH), lds_bytes, strm, a);
   HIP_TRY(hipGetLastError());
 }
 

@@ -1,0 +1,21 @@
+"""Measurement build: kprn_amd/libkprn_variants.so = libkprn.so with the persistent bf16 layer kernel's knock-out / tuning
+variants compiled in (-DKPRN_PERSIST_VARIANTS, lstm_bf16_persist.hip).  Loaded with KPRN_LIB=<path> (kprn_amd/_ffi.py)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from kprn_amd import build as kb  # noqa: E402
+
+kb.build()
+objs = []
+for src in kb.sources():
+    obj = os.path.join(kb.HERE, "build", os.path.basename(src) + ".o")
+    if os.path.basename(src) == "lstm_bf16_persist.hip":
+        obj = os.path.join(kb.HERE, "build", "lstm_bf16_persist.variants.o")
+        subprocess.check_call([kb.HIPCC] + kb.FLAGS + kb.file_flags(src) + ["-DKPRN_PERSIST_VARIANTS", "-c", src, "-o", obj])
+    objs.append(obj)
+out = os.path.join(kb.HERE, "libkprn_variants.so")
+subprocess.check_call([kb.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+print(out)
