@@ -30,6 +30,8 @@ void kprn_destroy(kprn_handle*);
 const char* kprn_last_error(const kprn_handle*);
 int kprn_num_params(kprn_handle*, int64_t*);
 int kprn_get_param(kprn_handle*, const char*, float*, int64_t);
+int kprn_get_param_rows(kprn_handle*, const char*, const int64_t*, int64_t, float*);
+int kprn_set_param_rows(kprn_handle*, const char*, const int64_t*, int64_t, const float*);
 int kprn_set_param(kprn_handle*, const char*, const float*, int64_t);
 int kprn_get_flat_params(kprn_handle*, float*, int64_t);
 int kprn_set_flat_params(kprn_handle*, const float*, int64_t);

@@ -123,6 +123,10 @@ int kprn_num_params(kprn_handle* h, int64_t* n);
 int kprn_get_param(kprn_handle* h, const char* name, float* dst, int64_t n);
 int kprn_set_param(kprn_handle* h, const char* name, const float* src, int64_t n);
 int kprn_get_grad(kprn_handle* h, const char* name, float* dst, int64_t n);
+/* n_rows rows of one tensor by 0-based row index (Lua: lookup.weight[id], id = row + 1; net/FeatureEmbedding.lua:29,41-49,86):
+   what one reads / writes of a 20 M-row nn.LookupTable without moving the table.  dst / src: [n_rows][cols] */
+int kprn_get_param_rows(kprn_handle* h, const char* name, const int64_t* rows, int64_t n_rows, float* dst);
+int kprn_set_param_rows(kprn_handle* h, const char* name, const int64_t* rows, int64_t n_rows, const float* src);
 /* whole flat vector in getParameters() order */
 int kprn_get_flat_params(kprn_handle* h, float* dst, int64_t n);
 int kprn_set_flat_params(kprn_handle* h, const float* src, int64_t n);

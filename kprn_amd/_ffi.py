@@ -279,6 +279,18 @@ class Engine:
         a = np.ascontiguousarray(value, np.float32)
         self._ck(self.L.kprn_set_param(self.h, name.encode(), _fp(a), C.c_int64(a.size)))
 
+    def get_param_rows(self, name, rows):
+        """rows (0-based) of one parameter tensor: [len(rows), cols]"""
+        rows = np.ascontiguousarray(rows, np.int64)
+        out = np.empty((len(rows), self._shape(name)[1] if len(self._shape(name)) > 1 else 1), np.float32)
+        self._ck(self.L.kprn_get_param_rows(self.h, name.encode(), _fp(rows), C.c_int64(len(rows)), _fp(out)))
+        return out
+
+    def set_param_rows(self, name, rows, values):
+        rows = np.ascontiguousarray(rows, np.int64)
+        values = np.ascontiguousarray(values, np.float32)
+        self._ck(self.L.kprn_set_param_rows(self.h, name.encode(), _fp(rows), C.c_int64(len(rows)), _fp(values)))
+
     def get_grad(self, name):
         shp = self._shape(name)
         a = np.empty(shp, np.float32)

@@ -162,6 +162,7 @@ static void flush_lazy(kprn_handle* h) {
   kk::adam_flush_all(h->stream, h->We, h->s1_We, h->s2_We, h->We_last, h->cfg.Ve, h->cfg.de, (int32_t)h->opt_step, h->step_tab,
                      h->last_b1, h->last_b2, h->last_eps, (int64_t)h->cfg.Ve - 1);
   h->lazy_pending = false;
+  bf16p::params_changed(h, false);   // the replay rewrote rows no row list names: the bf16 shadow of the whole table is stale
 }
 
 static void zero_pad_tokens(kprn_handle* h) {
@@ -907,6 +908,37 @@ static int copy_named(kprn_handle* h, const char* name, float* dst, const float*
 int kprn_get_param(kprn_handle* h, const char* name, float* dst, int64_t n) { return copy_named(h, name, dst, nullptr, n, 0); }
 int kprn_set_param(kprn_handle* h, const char* name, const float* src, int64_t n) { return copy_named(h, name, nullptr, src, n, 0); }
 int kprn_get_grad(kprn_handle* h, const char* name, float* dst, int64_t n) { return copy_named(h, name, dst, nullptr, n, 1); }
+
+// rows of one parameter tensor by 0-based row index (a 20 M-row entity table is 10 GB: reading the rows a batch touched must not copy it)
+__global__ void k_rows_copy(float* __restrict__ W, const int64_t* __restrict__ rows, int64_t n, int64_t cols, float* __restrict__ buf, int to_table) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * cols; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows[i / cols], c = i % cols;
+    if (to_table) W[r * cols + c] = buf[i]; else buf[i] = W[r * cols + c];
+  }
+}
+static int copy_rows(kprn_handle* h, const char* name, const int64_t* rows, int64_t n_rows, float* dst, const float* src) {
+  API_BEGIN(h)
+  const ParamInfo* p = find_param(h, name);
+  KPRN_REQUIRE(p, KPRN_E_ARG, std::string("unknown parameter name: ") + (name ? name : "(null)"));
+  KPRN_REQUIRE(n_rows >= 0 && (rows || n_rows == 0) && (dst || src || n_rows == 0), KPRN_E_ARG, "NULL buffer");
+  if (n_rows == 0 || p->rows * p->cols == 0) return KPRN_OK;
+  for (int64_t i = 0; i < n_rows; ++i) KPRN_REQUIRE(rows[i] >= 0 && rows[i] < p->rows, KPRN_E_INDEX, "row index outside the tensor");
+  if (p->where == 1) flush_lazy(h);
+  float* base = (p->where == 1 ? h->We : h->dense) + p->dev_off;
+  int64_t* d_rows = dalloc<int64_t>(n_rows);
+  float* d_buf = dalloc<float>(n_rows * p->cols);
+  HIP_TRY(hipMemcpyAsync(d_rows, rows, (size_t)n_rows * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+  if (src) HIP_TRY(hipMemcpyAsync(d_buf, src, (size_t)(n_rows * p->cols) * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)std::min<int64_t>((n_rows * p->cols + 255) / 256, 8192)), dim3(256), 0, h->stream, base, d_rows, n_rows, p->cols, d_buf,
+                     src ? 1 : 0);
+  if (dst) HIP_TRY(hipMemcpyAsync(dst, d_buf, (size_t)(n_rows * p->cols) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  else params_touched(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  dfree(d_rows); dfree(d_buf);
+  API_END(h)
+}
+int kprn_get_param_rows(kprn_handle* h, const char* name, const int64_t* rows, int64_t n_rows, float* dst) { return copy_rows(h, name, rows, n_rows, dst, nullptr); }
+int kprn_set_param_rows(kprn_handle* h, const char* name, const int64_t* rows, int64_t n_rows, const float* src) { return copy_rows(h, name, rows, n_rows, nullptr, src); }
 
 static int copy_flat(kprn_handle* h, float* dst, const float* src, int64_t n, int which /*0 param,1 grad,2 s1,3 s2*/) {
   API_BEGIN(h)

@@ -387,14 +387,17 @@ __global__ void k_gather16(const int32_t* __restrict__ idx, int64_t N, int T, in
   *(bf16x8*)(X + ((int64_t)t * N + n) * D + col) = v;
 }
 // cell backward of one step on the saved bf16 gate values (kernels_basic.hip k_gates_bwd, with dA written in bf16)
+// interleaved: the persistent layer kernel's gate plane -- per row, groups of [i4 | g4 | f4 | o4] for 4 consecutive hidden units (two
+// 16-byte stores per lane instead of four 8-byte ones); else gate-major rows [i H | g H | f H | o H]
 __global__ void k_gates_bwd16(const bf16* __restrict__ act, const float* __restrict__ c, const float* __restrict__ c_prev, const float* __restrict__ dH_up,
-                              float* __restrict__ dH, float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H) {
+                              float* __restrict__ dH, float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H, int interleaved) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= N * H) return;
   const int jx = (int)(gid % H);
   const int64_t n = gid / H;
   const bf16* a = act + n * 4 * H;
-  const float ig = (float)a[jx], gg = (float)a[H + jx], fg = (float)a[2 * H + jx], og = (float)a[3 * H + jx];
+  const int p0 = interleaved ? (jx >> 2) * 16 + (jx & 3) : jx, ps = interleaved ? 4 : H;
+  const float ig = (float)a[p0], gg = (float)a[p0 + ps], fg = (float)a[p0 + 2 * ps], og = (float)a[p0 + 3 * ps];
   const float tc = tanhf(c[gid]);
   const float dh = dH[gid] + (dH_up ? dH_up[gid] : 0.f);
   const float dO = dh * tc;
@@ -465,6 +468,7 @@ struct State {
   bf16 *X16 = nullptr, *XT16 = nullptr, *H16 = nullptr, *HT16 = nullptr, *ACT16 = nullptr, *dA16 = nullptr, *dAT16 = nullptr;
   void* persist = nullptr;      // lstm_bf16_persist.hip: packed weights + scratch slabs of the persistent layer kernel
   bool pack_dirty = true;       // its packed weights are stale
+  bool act_interleaved = false; // layout of the gate plane the last training forward wrote (k_gates_bwd16)
 };
 // lstm_bf16_persist.hip: the whole layer (gather + T steps) as one persistent launch
 bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b);
@@ -584,7 +588,9 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   if (persist) {
     persist_forward(h, b, save, s->persist, s->pack_dirty, s->dense16 + h->off_Wt, s->We16, s->dense16 + h->off_Wr, s->H16, s->ACT16);
     s->pack_dirty = false;
+    if (save) s->act_interleaved = true;
   }
+  if (!persist && save) s->act_interleaved = false;
   for (int l = 0; l < L && !persist; ++l) {
     const int Din = h->layer[l].Din;
     const bf16* in = (l == 0) ? s->X16 : s->H16 + (int64_t)(l - 1) * T * N * H;
@@ -658,7 +664,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       {
         ProfScope ps(h, "lstm_gates_bwd_bf16");
         hipLaunchKernelGGL(k_gates_bwd16, dim3((unsigned)((N * H + 255) / 256)), dim3(256), 0, strm, act + (int64_t)t * N * G4, cs + (int64_t)t * N * H,
-                           t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr, has_up ? w.dIn + (int64_t)t * N * H : nullptr, w.dH, w.dC, dA_t, N, H);
+                           t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr, has_up ? w.dIn + (int64_t)t * N * H : nullptr, w.dH, w.dC, dA_t, N, H, s->act_interleaved ? 1 : 0);
         HIP_TRY(hipGetLastError());
       }
       if (t > 0) {

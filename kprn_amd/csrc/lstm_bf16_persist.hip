@@ -28,7 +28,8 @@
 //     so the cell writes h_t (packed bf16, fragment order) to a private scratch slab that the next step's DMA brings back:
 //     a round trip through this XCD's L2, 72 KB a step against 2.36 MB of weights.  c_t (fp32) goes the same way
 //     (fragment-order scratch when scoring; the saved [T][N][H] plane when training).
-// Training (SAVE) additionally stores h, c and the four gate activations in the layouts lstm_bf16.hip's backward reads.
+// Training (SAVE) additionally stores h and c row-major and the four gate activations interleaved per 4 hidden units (two 16-byte stores per
+// lane), which is what lstm_bf16.hip's backward reads.
 #include <string.h>
 
 #include <algorithm>
@@ -63,7 +64,7 @@ struct Args {
   const float* Bp;   // packed bias    [H/32][4 waves][2 halves][16]
   bf16* hscr;        // per workgroup: 2 x [MAXPT][H/16][64][8]  h_t in B-fragment order (ping-pong over steps)
   float* cscr;       // per workgroup: [H/32][MAXPT][4][64][4]   c_t in accumulator order (scoring)
-  bf16* H16; float* Cs; bf16* ACT16;   // SAVE: [T][N][H], [T][N][H], [T][N][4H]
+  bf16* H16; float* Cs; bf16* ACT16;   // SAVE: [T][N][H], [T][N][H], [T][N][H/4][i4 g4 f4 o4]
   float* hT;         // [N][H] fp32 h_T (the head's input)
   int64_t units;     // ceil(N / 32)
 };
@@ -184,12 +185,13 @@ struct Cell {
         const int64_t row = (int64_t)te * a.N + row0 + 32 * pt;
         stb<f32x4>(make_rsrc(a.Cs + row * H + cu), lo_row(H, 4), 0, cv);
         stb<bf16x4>(make_rsrc(a.H16 + row * H + cu), lo_row(H, 2), 0, hb);
-        bf16x4 vi, vg, vf, vo;
+        // gate plane, interleaved: per row, groups of [i4 | g4 | f4 | o4] for 4 consecutive hidden units (k_gates_bwd16 reads it so)
+        bf16x8 v0, v1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { vi[j] = (bf16)gi[b][j]; vg[j] = (bf16)gg[b][j]; vf[j] = (bf16)gf[b][j]; vo[j] = (bf16)go[b][j]; }
-        const rsrc_t g = make_rsrc(a.ACT16 + row * (4 * H) + cu);
-        const unsigned lo = lo_row(4 * H, 2);
-        stb<bf16x4>(g, lo, 0, vi); stb<bf16x4>(g, lo, 2 * H, vg); stb<bf16x4>(g, lo, 4 * H, vf); stb<bf16x4>(g, lo, 6 * H, vo);
+        for (int j = 0; j < 4; ++j) { v0[j] = (bf16)gi[b][j]; v0[4 + j] = (bf16)gg[b][j]; v1[j] = (bf16)gf[b][j]; v1[4 + j] = (bf16)go[b][j]; }
+        const rsrc_t g = make_rsrc(a.ACT16 + row * (4 * H) + 4 * cu);
+        const unsigned lo = (unsigned)((ln * 4 * H + 16 * half) * 2);
+        stb<bf16x8>(g, lo, 0, v0); stb<bf16x8>(g, lo, 16, v1);
       }
     } else {
       stb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((ce * MAXPT + pt) * 4 + wave) * 1024u, cv);

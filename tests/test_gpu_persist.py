@@ -125,3 +125,52 @@ def test_1024_work_tiles_against_the_f64_oracle():
     assert err.max() < 3e-2 * scale, err.max() / scale
     assert np.sqrt(np.mean(err ** 2)) < 4e-3 * scale      # bf16 rounding noise, not a misplaced tile: an rms bound next to the max bound
     np.testing.assert_allclose(out["probs"], probs[:, 0], atol=2e-2)
+
+
+def test_training_on_the_20_million_row_table_touched_rows_only():
+    """BASELINE configs[3]'s table: 20 M entities x 128 (10 GB fp32 + gradient + Adam state on the device).  The float64 oracle cannot hold
+    it, and does not need to: lazy-exact Adam leaves every untouched row bit-identical (zero gradient, zero state), so the oracle runs
+    on the COMPACT vocabulary of the rows the batch touches (ids renumbered in ascending order, the pad row last, rows copied from the
+    engine through kprn_get_param_rows), and after several Adam steps the touched rows, the dense parameters and the loss must agree at
+    bf16-pipeline tolerance; a sample of untouched rows must not have moved at all.  Ids reach above 2^24."""
+    Ve, Vr, pairs, P, T = 20_000_000, 100, 256, 3, 6
+    dt, de, dr = DIMS
+    eng = _ffi.Engine(6, Ve, Vr, dt, de, dr, 384, 1, compute_dtype=1, param_init=0.05)
+    idx, labels = synth.make_paths(pairs, P, T, Ve=Ve, Vr=Vr, seed=21)
+    rng = np.random.default_rng(3)
+    ent = idx[..., 1]
+    real = ent != Ve
+    ent[real] = rng.integers(1, Ve - 1, size=int(real.sum()))        # spread the real ids over the whole table (make_paths is Zipf: mostly small ids)
+    assert int(ent.max()) > (1 << 24)
+    ids = np.unique(np.concatenate([ent.ravel(), [Ve]]))             # ascending, the pad row (Ve) last
+    rows0 = eng.get_param_rows("entity_emb", ids - 1)
+    untouched = np.setdiff1d(rng.integers(0, Ve - 1, size=2000), ids - 1)
+    before = eng.get_param_rows("entity_emb", untouched)
+    cidx = idx.copy()
+    cidx[..., 1] = np.searchsorted(ids, ent) + 1                     # compact vocabulary, 1-based
+    o64 = Oracle(make_cfg(Vt=6, Ve=len(ids), Vr=Vr, dt=dt, de=de, dr=dr, H=384, L=1), np.float64)
+    lay = o64.layout()
+    theta = np.zeros(o64.n)
+    for nm, (off, shp) in lay.items():
+        v = rows0 if nm == "entity_emb" else eng.get_param(nm)
+        theta[off:off + int(np.prod(shp))] = np.asarray(v, np.float64).ravel()
+    b = eng.batch(idx, labels)
+    eng.profile(True)
+    opt, oopt = _ffi.make_opt(method=1, lr=2e-3), make_opt(method=1, lr=2e-3)
+    st = o64.new_state()
+    for s in range(4):
+        ol, _ = o64.train_step(theta, st, oopt, cidx, labels)
+        gl = eng.train_step(b, opt)
+        assert abs(gl - ol) < 3e-2 * max(1.0, abs(ol)), (s, gl, ol)
+    assert _ran_persistent(eng)
+    off, shp = lay["entity_emb"]
+    want = theta[off:off + int(np.prod(shp))].reshape(shp)
+    got = eng.get_param_rows("entity_emb", ids - 1)
+    assert np.max(np.abs(got - want)) < 5e-3          # 4 steps of lr 2e-3 move an element by <= 8e-3
+    moved = np.abs(want - rows0).max(axis=1) > 1e-4
+    assert moved.sum() > 0.5 * len(ids)               # ... and most touched rows did move (the comparison above is not vacuous)
+    for nm, (off, shp) in lay.items():
+        if nm != "entity_emb":
+            assert np.max(np.abs(eng.get_param(nm).ravel() - theta[off:off + int(np.prod(shp))])) < 5e-3, nm
+    assert np.array_equal(eng.get_param_rows("entity_emb", untouched), before)
+    eng.close()
