@@ -67,8 +67,13 @@ local function check(h, rc)
   if rc ~= 0 then error(('kprn error %d: %s'):format(rc, ffi.string(C.kprn_last_error(h)))) end
 end
 
+-- kprn_config.stream: nil = the engine creates its own stream; a hipStream_t; or M.STREAM_LEGACY_DEFAULT for the null stream
+-- (cutorch's default stream: its handle is 0, which would otherwise read as "create your own" -- include/kprn.h)
+M.STREAM_LEGACY_DEFAULT = ffi.cast('void*', ffi.cast('intptr_t', -1))
+
 function M.create(o)
   local cfg = ffi.new('kprn_config')
+  cfg.stream = o.stream
   cfg.Vt, cfg.Ve, cfg.Vr = o.Vt, o.Ve, o.Vr
   cfg.dt, cfg.de, cfg.dr = o.dt, o.de, o.dr
   cfg.F, cfg.num_types = o.F or 3, o.num_types or 1

@@ -89,8 +89,13 @@ typedef struct {
   int32_t rank, world;       /* data-parallel position; loss is scaled by the GLOBAL batch       */
   float param_init;          /* -paramInit: uniform(-a, a) over every parameter (OneModel.lua:306-309) */
   uint64_t seed;             /* init RNG seed (the reference leaves it unseeded, OneModel.lua:123) */
-  void* stream;              /* optional caller hipStream_t to queue on; NULL = library-owned    */
+  void* stream;              /* hipStream_t the engine queues on.  NULL = the engine creates its own non-blocking stream (fetch it
+                                with kprn_stream).  NOTE: the legacy default stream's handle is ALSO 0 -- a caller that means "my
+                                default stream" (torch.cuda.current_stream() before any stream is set) must say
+                                KPRN_STREAM_LEGACY_DEFAULT, or its own work is not ordered with the engine's.                    */
 } kprn_config;
+/* kprn_config.stream value for the legacy default (null) stream: the engine then queues on stream 0 instead of creating one */
+#define KPRN_STREAM_LEGACY_DEFAULT ((void*)(intptr_t)-1)
 
 /* mirrors optInfo / optConfig (OneModel.lua:340-384) */
 typedef struct {

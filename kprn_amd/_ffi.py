@@ -197,8 +197,12 @@ class Batch:
             pass
 
 
+STREAM_LEGACY_DEFAULT = C.c_void_p(-1).value   # kprn_config.stream: queue on the legacy default (null) stream (KPRN_STREAM_LEGACY_DEFAULT)
+
+
 class Engine:
-    """Thin object wrapper over one kprn_handle."""
+    """Thin object wrapper over one kprn_handle.  stream: None = the engine creates its own; a hipStream_t handle; or
+    STREAM_LEGACY_DEFAULT for the null stream (whose handle, 0, would otherwise read as "create your own")."""
 
     def __init__(self, Vt, Ve, Vr, dt, de, dr, H, L=1, F=3, num_types=1, C_=46, reducer=2, K=5, rnn_type=0, device_id=0,
                  rank=0, world=1, param_init=0.1, seed=12345, stream=None, use_relu=1, rnn_init=0, compute_dtype=0):

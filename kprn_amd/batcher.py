@@ -17,9 +17,9 @@ from . import formats
 class Batcher:
     """Batcher(filePath, batchSize, shuffle)  -- Batcher.lua:9-32"""
 
-    def __init__(self, filePath, batchSize, shuffle, rng=None):
+    def __init__(self, filePath, batchSize, shuffle, rng=None, check_ids=True):
         self.filePath = filePath
-        self.labels, self.data, self.classId = formats.load_path_file(filePath)
+        self.labels, self.data, self.classId = formats.load_path_file(filePath, check_ids=check_ids)
         self.doShuffle = bool(shuffle)
         self.labelDimension = 1 if self.labels.ndim == 1 else self.labels.shape[1]
         self.numPaths = self.data.shape[1]
@@ -91,7 +91,7 @@ class BatcherFileList:
     each drained completely before the next; `index` is a fresh permutation per epoch when shuffling.
     """
 
-    def __init__(self, dataDir, batchSize, shuffle, maxBatches, useCuda, filelist, seed=None):
+    def __init__(self, dataDir, batchSize, shuffle, maxBatches, useCuda, filelist, seed=None, check_ids=True):
         fileList = os.path.join(dataDir, filelist)
         self.doShuffle = bool(shuffle)
         self.batchSize = int(batchSize)
@@ -102,7 +102,7 @@ class BatcherFileList:
             for line in f:
                 line = line.strip()
                 if line:
-                    self.batchers.append(Batcher(os.path.join(dataDir, line), batchSize, self.doShuffle, self.rng))
+                    self.batchers.append(Batcher(os.path.join(dataDir, line), batchSize, self.doShuffle, self.rng, check_ids=check_ids))
         self.numBatchers = len(self.batchers)
         self.maxBatches = self.numBatchers  # :37 (the maxBatches argument is ignored by the reference too)
         self._new_epoch_order()

@@ -794,8 +794,9 @@ int kprn_create(const kprn_config* cfg, kprn_handle** out) {
     HIP_TRY(hipSetDevice(c.device_id));
     h = new kprn_handle();
     h->cfg = c;
-    if (c.stream) { h->stream = (hipStream_t)c.stream; h->own_stream = false; }
-    else { HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    if (c.stream == KPRN_STREAM_LEGACY_DEFAULT) { h->stream = nullptr; h->own_stream = false; h->stream_known = true; }   // the null stream, by request
+    else if (c.stream) { h->stream = (hipStream_t)c.stream; h->own_stream = false; h->stream_known = true; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; h->stream_known = false; }
     build_layout(h);
     h->dense = dalloc<float>(h->n_dense); h->g_dense = dalloc<float>(h->n_dense);
     h->s1_dense = dalloc<float>(h->n_dense); h->s2_dense = dalloc<float>(h->n_dense);
@@ -1641,6 +1642,9 @@ int kprn_sync(kprn_handle* h) {
 int kprn_dense_grad_buffer(kprn_handle* h, void** dev_ptr, int64_t* n_floats) {
   API_BEGIN(h)
   KPRN_REQUIRE(dev_ptr && n_floats, KPRN_E_ARG, "NULL argument");
+  KPRN_REQUIRE(h->stream_known, KPRN_E_ARG,
+               "data-parallel hooks: the caller's collectives must be ordered with the engine's stream, but kprn_config.stream was NULL (the engine "
+               "made its own) and kprn_stream() was never called -- pass a stream (KPRN_STREAM_LEGACY_DEFAULT for the null stream) or fetch the engine's");
   *dev_ptr = h->g_dense;
   *n_floats = h->n_dense;
   API_END(h)
@@ -1656,6 +1660,9 @@ int kprn_sparse_grad_capacity(kprn_handle* h, int32_t* max_rows) {
 int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int64_t* n_words) {
   API_BEGIN(h)
   KPRN_REQUIRE(dev_buf && n_words, KPRN_E_ARG, "NULL argument");
+  KPRN_REQUIRE(h->stream_known, KPRN_E_ARG,
+               "data-parallel hooks: the caller's collectives must be ordered with the engine's stream, but kprn_config.stream was NULL (the engine "
+               "made its own) and kprn_stream() was never called -- pass a stream (KPRN_STREAM_LEGACY_DEFAULT for the null stream) or fetch the engine's");
   KPRN_REQUIRE(capacity >= h->step_rows_ub && capacity > 0, KPRN_E_ARG, "capacity smaller than this step's touched-row count");
   const int de = h->cfg.de;
   const int64_t words = 4 + (int64_t)capacity * (1 + de);
@@ -1680,6 +1687,9 @@ int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int6
 int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, int32_t capacity) {
   API_BEGIN(h)
   KPRN_REQUIRE(dev_all && world > 0 && capacity > 0, KPRN_E_ARG, "bad argument");
+  KPRN_REQUIRE(h->stream_known, KPRN_E_ARG,
+               "data-parallel hooks: the caller's collectives must be ordered with the engine's stream, but kprn_config.stream was NULL (the engine "
+               "made its own) and kprn_stream() was never called -- pass a stream (KPRN_STREAM_LEGACY_DEFAULT for the null stream) or fetch the engine's");
   KPRN_REQUIRE(capacity == h->pack_cap, KPRN_E_ARG, "capacity differs from the packed buffer's (every rank packs with the same capacity)");
   const int64_t n = (int64_t)world * capacity;
   if (n + 4 > h->step_rows_cap) {
@@ -1716,6 +1726,7 @@ int kprn_stream(kprn_handle* h, void** stream) {
   API_BEGIN(h)
   KPRN_REQUIRE(stream, KPRN_E_ARG, "NULL argument");
   *stream = (void*)h->stream;
+  h->stream_known = true;
   API_END(h)
 }
 

@@ -117,6 +117,7 @@ struct kprn_handle {
   int G = 4;  // rows of the recurrent weights per hidden unit: 4 (FastLSTM gates), 2 (gru r, z) or 1 (rnn)
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  bool stream_known = false;   // the caller chose the stream or has fetched it (kprn_stream): precondition of the data-parallel hooks
   std::string err;
 
   // parameters

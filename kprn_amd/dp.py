@@ -43,6 +43,7 @@ class GpuAdapter:
     def __init__(self, engine, device):
         self.e = engine
         self.device = torch.device(device)
+        sh = engine.stream()   # (first: the engine hands out its exchange buffers only to a caller that knows which stream it queues on)
         ptr, n = engine.dense_grad_buffer()
         self.dense = wrap_device(ptr, n, "f32", self.device)
         self.de = engine.cfg.de
@@ -51,7 +52,8 @@ class GpuAdapter:
         # engine's kernels: they are issued with the ENGINE's stream as torch's current stream.  (Handing the engine torch's current
         # stream is not enough: the default stream's handle is 0, which kprn_create reads as "make your own" -- the collectives then
         # raced the pack / merge kernels: right at step 0 by luck, entity rows off by an optimiser step from step 1 on.)
-        self.stream = torch.cuda.ExternalStream(engine.stream(), device=self.device)
+        # (an engine created with KPRN_STREAM_LEGACY_DEFAULT queues on the null stream = torch's default stream)
+        self.stream = torch.cuda.ExternalStream(sh, device=self.device) if sh else torch.cuda.default_stream(self.device)
 
     def backward(self, batch, class_id, bce_literal, inv_batch):
         self.e.backward(batch, class_id, bce_literal, inv_batch, want_loss=False)

@@ -278,8 +278,10 @@ def _npz_member_memmap(path, name):
         return None
 
 
-def load_path_file(path):
-    """-> (labels float32 [N], data int32 [N,P,T,F] 1-based, classId int)."""
+def load_path_file(path, check_ids=True):
+    """-> (labels float32 [N], data int32 [N,P,T,F] 1-based, classId int).
+    check_ids=False: skip the id >= 1 pass over an int32 file (a memory-mapped .npz is otherwise never read on the host) -- only for
+    callers that hand the ids to the engine, which checks every id against its vocabulary (KPRN_E_INDEX)."""
     if path.endswith(".npz"):
         z = np.load(path)
         labels, cid = z["labels"], int(z["classId"]) if "classId" in z else 1
@@ -305,7 +307,9 @@ def load_path_file(path):
             raise ValueError(f"{path}: non-integer id")
         data = data.astype(np.int64)
     if data.dtype != np.int32 and data.size and (data.min() < 1 or data.max() >= 2 ** 31):
-        raise ValueError(f"{path}: id outside 1..2^31-1")   # (int32 files: the engine checks every id against its vocabulary)
+        raise ValueError(f"{path}: id outside 1..2^31-1")
+    if data.dtype == np.int32 and data.size and check_ids and int(data.min()) < 1:   # (the upper bound is the engine's: it knows the vocabularies)
+        raise ValueError(f"{path}: id < 1")
     return np.asarray(labels, dtype=np.float32).reshape(-1), np.ascontiguousarray(data, dtype=np.int32), cid
 
 

@@ -39,7 +39,7 @@ def flag_parser():
     a("-numLayers", type=int, default=1); a("-useDropout", type=int, default=0); a("-dropout", type=float, default=0.0)
     # engine-side additions (not in the reference)
     a("-seed", type=int, default=12345); a("-entityUpdate", type=int, default=0)
-    a("-checkpointFormat", default="native", choices=["native", "t7", "both"])   # t7: the reference's torch.save{embeddingLayer, predictor_net}
+    a("-checkpointFormat", default="native", choices=["native", "t7", "both"])   # t7 / both: ALSO <path>.t7, the parameters in a Torch7 {embeddingLayer, predictor_net} container
     return p
 
 
@@ -85,8 +85,11 @@ def load_checkpoint(eng, path):
 
 
 def save_checkpoint_t7(eng, path):
-    """the model as the reference writes it: torch.save(path, {embeddingLayer, predictor_net}) (OneModel.lua:392-400), so that the
-    reference's eval/test_from_checkpoint.lua:68 can load a model trained by this engine"""
+    """PARAMETER EXCHANGE in the reference's container: a Torch7 table {embeddingLayer, predictor_net} (OneModel.lua:392-400) whose nn.* objects
+    carry the weight tensors under the reference's field names, in module order -- what formats.checkpoint_params (and a Lua script that walks
+    the tables) reads back.  NOT a runnable checkpoint for eval/test_from_checkpoint.lua: the Element-Research rnn modules in it have no
+    recurrentModule graph, sharedClones or step state, so model:forward would fail; rebuild the model with OneModel.lua's constructor and copy
+    the tensors in."""
     from . import formats
     formats.write_checkpoint(path, {n: eng.get_param(n) for n in eng.layout()}, num_entity_types=eng.cfg.num_types, use_relu=eng.cfg.use_relu)
 

@@ -14,14 +14,16 @@ class OptimizerCallback:  # optimizer/OptimizerCallback.lua
 
 
 class MyOptimizer:
-    FEED_AHEAD = 3
-
     """MyOptimizer(engine, trainingOptions, opt)   (MyOptimizer.lua:13-72)
 
     trainingOptions: dict(numEpochs, epochHooks=[OptimizerCallback], minibatchsize)
     opt:             kprn_opt (model.opt_from_flags)
-    dp:              optional kprn_amd.dp.DataParallel -- every rank then feeds ITS shard of each minibatch
+    dp:              optional kprn_amd.dp.DataParallel -- every rank then feeds ITS shard of each minibatch.  Shards of a file's last
+                     minibatch are ragged (3 and 2 pairs of 5), so the loss scale 1 / (pairs of the GLOBAL minibatch) is agreed per
+                     step: the DataParallel object is switched to equal_shards=False unless trainingOptions["equalShards"] promises
+                     that every rank always holds the same number of pairs.
     """
+    FEED_AHEAD = 3
 
     def __init__(self, engine, trainingOptions, opt, startIteration=1, gradientStepCounter=100, dp=None, out=sys.stdout):
         assert trainingOptions is not None
@@ -32,6 +34,8 @@ class MyOptimizer:
         self.gradientStepCounter = gradientStepCounter
         self.totalError = 0.0
         self.dp = dp
+        if dp is not None and not trainingOptions.get("equalShards", False):
+            dp.equal_shards = False   # (B_local * world is the global pair count only when every shard has the same size)
         self.out = out
         self._cache = {}  # device-resident batches keyed by (file, offset): only when the order is the same every epoch
         # streaming feed (shuffled order): a ring of device slots refilled in turn (BatcherFileList.lua:53-60 preallocates its GPU
@@ -63,8 +67,7 @@ class MyOptimizer:
         assert targets is not None or isinstance(inputs, _ffi.Batch)
         b = inputs if isinstance(inputs, _ffi.Batch) else self._device_batch(inputs, targets, key)
         if self.dp is not None:
-            # ranks may hold shards of different sizes (last batch of a file): the global pair count is agreed per step unless the
-            # DataParallel object was built with equal_shards=True
+            # ranks may hold shards of different sizes (last batch of a file): the global pair count is agreed per step (see __init__)
             self.dp.train_step(b, self.opt, classId)
             err = self.engine.read_loss() if want_loss else None
         else:
@@ -100,6 +103,13 @@ class MyOptimizer:
             self.dp.set_capacity(min(trainBatcher.max_batch_positions() + 8, self.engine.cfg.Ve), bound=True)
         self.engine.set_option("loss_accumulate", "1")
         self.engine.loss_sum(reset=True)
+        try:
+            return self._epochs(trainBatcher, prevTime)
+        finally:   # (an exception out of a step -- a bad id, KPRN_E_INDEX -- must not leave the engine accumulating)
+            self.engine.set_option("loss_accumulate", "0")
+
+    def _epochs(self, trainBatcher, prevTime):
+        numProcessed = 0
         i = self.startIteration
         history = []
         while i <= self.trainingOptions["numEpochs"]:
@@ -156,7 +166,6 @@ class MyOptimizer:
                     hook.hook(i)
             trainBatcher.reset()
             i += 1
-        self.engine.set_option("loss_accumulate", "0")
         return history
 
     def postEpoch(self):  # MyOptimizer.lua:171-173

@@ -25,9 +25,18 @@ def score_batches(engine, batcher, class_id=1):
     label-less feed slot (upload + identical-prefix plan built by the host threads under the previous group's kernels), scored
     asynchronously; the probabilities of group i come back while group i + 1 runs, so the caller's formatting overlaps too."""
     streaming = hasattr(engine, "feed") and hasattr(engine, "forward_async")
-    if streaming:
-        for b in getattr(batcher, "batchers", []):       # chip-sized groups per bucket file
-            b.batchSize = max(b.batchSize, ENGINE_BATCH_PATHS // max(1, b.numPaths))
+    saved = [(b, b.batchSize) for b in getattr(batcher, "batchers", [])]
+    try:
+        if streaming:
+            for b, _ in saved:       # chip-sized groups per bucket file (the caller's batch sizes are put back when the generator ends)
+                b.batchSize = max(b.batchSize, ENGINE_BATCH_PATHS // max(1, b.numPaths))
+        yield from _score_batches(engine, batcher, class_id, streaming)
+    finally:
+        for b, size in saved:
+            b.batchSize = size
+
+
+def _score_batches(engine, batcher, class_id, streaming):
     if not streaming:
         while True:
             got = batcher.getBatch()
@@ -91,7 +100,7 @@ def test_from_checkpoint(engine, input_dir, test_list, out_file, minibatch=512, 
     order = list order and renumbers the global 0-based counter, so that `out_file` is byte-identical to the single-rank file
     (the downstream join with test.list.entity is positional, eval/combine_result.py:24-27)."""
     if world <= 1:
-        batcher = BatcherFileList(input_dir, minibatch, False, 1000, True, test_list)
+        batcher = BatcherFileList(input_dir, minibatch, False, 1000, True, test_list, check_ids=False)   # (the engine validates every id)
         start = time.time()
         n = 0
         with open(out_file, "wb") as f:
@@ -115,7 +124,7 @@ def test_from_checkpoint(engine, input_dir, test_list, out_file, minibatch=512, 
             try:
                 with os.fdopen(fd, "w") as sl:
                     sl.write("\n".join(files[lo:hi]) + "\n")
-                batcher = BatcherFileList(input_dir, minibatch, False, 1000, True, os.path.basename(shard_list))
+                batcher = BatcherFileList(input_dir, minibatch, False, 1000, True, os.path.basename(shard_list), check_ids=False)
                 n = write_scores(engine, batcher, out, 1)
             finally:
                 os.unlink(shard_list)

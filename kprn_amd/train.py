@@ -22,16 +22,15 @@ def main(argv=None):
     eng = model.build_engine(params)
     print(model.REDUCER_NAME[model.reducer_of_train_flag(params.topK)])
     print("Using Adam!" if params.useAdam == 1 else "Using adagrad!")
-    trainBatcher = BatcherFileList(params.dataDir, params.minibatch, True, 100, params.gpuid != -1, "train.list", seed=params.seed)
+    trainBatcher = BatcherFileList(params.dataDir, params.minibatch, True, 100, params.gpuid != -1, "train.list", seed=params.seed, check_ids=False)   # (the engine validates every id)
     callbacks = []
     if params.model:
         def saver(i):
             path = params.model + "-latest"
             print("saving to " + path)
-            if params.checkpointFormat in ("native", "both"):
-                eng.save(path)
+            eng.save(path)   # the native checkpoint is always written: it is the one this package (and its scoring CLI) is tested to load back
             if params.checkpointFormat in ("t7", "both"):
-                model.save_checkpoint_t7(eng, path if params.checkpointFormat == "t7" else path + ".t7")
+                model.save_checkpoint_t7(eng, path + ".t7")
         if params.createExptDir == 1:
             callbacks.append(OptimizerCallback(params.saveFrequency, saver, "saving"))
         else:

@@ -24,6 +24,7 @@ for r in range(WMAX):
     idx, labels = synth.make_paths(paths // 2, 2, 6, Ve=Ve, seed=1000 + 7919 * r)
     batches.append(eng.batch(idx, labels))
 cap = max(b.n_uniq for b in batches)
+eng.stream()   # (the exchange hooks want a caller that knows the engine's stream)
 words = 4 + cap * 33
 out = {"paths_per_rank_per_step": paths, "rows_per_rank": [b.n_uniq for b in batches], "capacity_rows": cap,
        "packed_MB_per_rank": round(words * 4 / 1e6, 2), "worlds": {}}

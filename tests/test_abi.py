@@ -58,3 +58,13 @@ def test_product_code_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "from oracle" not in txt and "import oracle" not in txt and "libkprn_oracle" not in txt, f
+
+
+def test_legacy_default_stream_sentinel_is_declared_everywhere():
+    """kprn_config.stream = NULL means "create a stream"; the null stream is asked for by name (round-2 DP ordering bug)"""
+    root = os.path.dirname(os.path.dirname(__file__))
+    hdr = open(os.path.join(root, "include", "kprn.h")).read()
+    assert "#define KPRN_STREAM_LEGACY_DEFAULT ((void*)(intptr_t)-1)" in hdr
+    assert _ffi.STREAM_LEGACY_DEFAULT == ctypes.c_void_p(-1).value
+    lua = open(os.path.join(root, "bindings", "kprn.lua")).read()
+    assert "STREAM_LEGACY_DEFAULT" in lua and "cfg.stream = o.stream" in lua

@@ -297,6 +297,24 @@ def test_data_parallel_step_at_world_one_equals_the_plain_step(tmp_path):
             eng.close()
         np.testing.assert_allclose(hists[0][0], hists[1][0], rtol=1e-5)
         assert np.max(np.abs(hists[0][1] - hists[1][1])) < 5e-6
+        # kprn_config.stream: NULL = "create a stream" -- the hooks refuse an engine whose stream the caller never saw; the legacy default
+        # stream is asked for by name, and the exchange on it (torch's default stream IS the engine's stream then) equals the plain step
+        blind = _ffi.Engine(*shape, seed=4)
+        with pytest.raises(_ffi.KprnError):
+            blind.dense_grad_buffer()
+        blind.stream()
+        blind.dense_grad_buffer()
+        blind.close()
+        c, d = _ffi.Engine(*shape, seed=4, stream=_ffi.STREAM_LEGACY_DEFAULT), _ffi.Engine(*shape, seed=4)
+        assert c.stream() == 0
+        c.zero_pad_tokens(); d.zero_pad_tokens()
+        y = dp.DataParallel(dp.GpuAdapter(c, "cuda:0"))
+        y.set_capacity(max(len(np.unique(i[..., 1])) for i, _ in data) + 8)
+        for idx, lab in data[:3]:
+            y.train_step(c.batch(idx, lab), opt, 1)
+            d.train_step(d.batch(idx, lab), opt)
+        assert np.max(np.abs(c.get_flat_params() - d.get_flat_params())) < 2e-6
+        c.close(); d.close()
         a.close(); b.close()
     finally:
         dist.destroy_process_group()

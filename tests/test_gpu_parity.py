@@ -273,6 +273,8 @@ def test_two_replicas_exchange_equals_one_big_batch(impl):
     ref, o64, theta = mk(L=2, impl=impl)
     bref = ref.batch(idx, labels)
     reps = [mk(L=2, impl=impl)[0] for _ in range(2)]
+    for e in reps:
+        e.stream()   # (the exchange hooks want a caller that knows the engine's stream; this test orders by full synchronisation)
     halves = [reps[r].batch(idx[r * 12:(r + 1) * 12], labels[r * 12:(r + 1) * 12]) for r in range(2)]
     dev = "cuda:0"
     for step in range(4):
