@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--train-only", action="store_true")
     ap.add_argument("--score-only", action="store_true")
+    ap.add_argument("--no-batch-sweep", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact lines of the other BASELINE configs (each a short run of this script)")
+    ap.add_argument("--cpu-baseline-quick", action="store_true", help="cpu_baseline: the model-only oracle sample only (no literal flavour, no torch-CPU point)")
     ap.add_argument("--reserve-cus", type=int, default=16, help="CUs the scoring pass leaves to the collective in data-parallel runs")
     ap.add_argument("--compute-dtype", type=int, default=0, choices=[0, 1, 2, 3],
                     help="0: fp32 MFMA (default, the headline).  2: f32x6 -- fp32 products formed exactly from bf16 pieces on the matrix "
@@ -274,10 +277,119 @@ def cpu_baseline(a, T, dt, de, dr, H, L, seconds):
     orc.forward(theta, idx)
     t2 = time.perf_counter()
     n = pairs * P
-    return {"value": n / (t2 - t0), "unit": "paths/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic paths (P={P}, T={T}, D=H={H}, L={L}): float64 oracle forward+BCE+backward then scoring "
-                      f"forward, OpenMP over pairs; model-only flavour (no dense Adam sweep over the entity table)",
-            "train_paths_per_s": n / (t1 - t0), "score_paths_per_s": n / (t2 - t1)}
+    out = {"value": n / (t2 - t0), "unit": "paths/s", "cores": cores, "kind": "port",
+           "sample": f"{n} synthetic paths (P={P}, T={T}, D=H={H}, L={L}): float64 oracle forward+BCE+backward then scoring "
+                     f"forward, OpenMP over pairs; model-only flavour (no dense Adam sweep over the entity table)",
+           "train_paths_per_s": n / (t1 - t0), "score_paths_per_s": n / (t2 - t1)}
+    if not a.cpu_baseline_quick:
+        try:
+            out["literal"] = cpu_baseline_literal(a, T, dt, de, dr, H, L, max(5.0, seconds / 2), cores)
+        except MemoryError as e:   # (a small host: the flat float64 vector + Adam state of the KKBox table is ~3 GB)
+            out["literal"] = {"error": f"MemoryError: {e}"}
+        out["torch_cpu_lstm"] = cpu_baseline_torch(T, dt, de, dr, H, L, max(5.0, seconds / 2), cores)
+    return out
+
+
+def cpu_baseline_literal(a, T, dt, de, dr, H, L, seconds, cores):
+    """SURVEY 8d flavour (i): the reference's step AS WRITTEN at its own minibatch -- MyOptimizer.lua:186 zeroGradParameters over the whole
+    flat vector, forward + BCE + backward, :218 optim.adam over every parameter including all of entity_emb (Ve rows, here the
+    KKBox size) -- in the float64 oracle, OpenMP.  What the dense passes cost the reference per minibatch of config.sh:38's 128 pairs."""
+    from oracle.oracle import Oracle, make_cfg, make_opt
+    from kprn_amd import synth
+    Ve = a.entities if a.entities > 0 else 2851220
+    cfg = make_cfg(Vt=6, Ve=Ve, Vr=9, dt=dt, de=de, dr=dr, H=H, L=L)
+    orc = Oracle(cfg, np.float64)
+    theta = orc.init_params(1, 0.1)
+    st = orc.new_state()
+    opt = make_opt(method=1, lr=1e-3)
+    pairs, P = 128, 2
+    idx, labels = synth.make_paths(pairs, P, T, Ve=Ve, seed=11)
+    orc.train_step(theta, st, opt, idx, labels)   # (first touch of 4 x 0.73 GB)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        orc.train_step(theta, st, opt, idx, labels)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 2000:
+            break
+    return {"value": steps * pairs * P / el, "unit": "paths/s", "cores": cores, "kind": "port", "ms_per_step": round(1e3 * el / steps, 3),
+            "steps": steps, "params": int(orc.n),
+            "sample": f"{steps} trainBatch steps of {pairs} pairs x {P} paths (config.sh:38 minibatch), T={T}, D=H={H}, L={L}, Ve={Ve}: dense "
+                      f"zeroGrad + forward + BCE + backward + dense optim.adam over all {orc.n} float64 parameters per step"}
+
+
+def cpu_baseline_torch(T, dt, de, dr, H, L, seconds, cores):
+    """Second, independently implemented CPU point: torch-CPU float64 -- torch.nn.LSTM (its own BLAS-backed kernel; FastLSTM's
+    gate order differs only by a row permutation of the weights, irrelevant to the cost), embedding gathers, Linear(H, 46), LSE pool,
+    BCE, autograd backward; then a scoring forward -- model-only flavour on a bounded sample, like the oracle line above."""
+    import torch
+    # (torch's intra-op pool over all 256 hardware threads of the GPU box ran this model at 98 paths/s: the LSTM's small GEMMs drown in
+    # fork-join overhead; 16 threads is where it stops scaling on this shape)
+    cores = min(cores, 16)
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(5)
+    D, C, Ve = dt + de + dr, 46, 100000
+    emb = [torch.nn.Embedding(6, dt), torch.nn.Embedding(Ve, de), torch.nn.Embedding(9, dr)]
+    lstm = torch.nn.LSTM(D, H, num_layers=L, batch_first=True)
+    head = torch.nn.Linear(H, C)
+    mods = torch.nn.ModuleList(emb + [lstm, head]).double()
+    def fwd(idx, P):
+        x = torch.cat([emb[k](idx[..., k]) for k in range(3)], dim=-1)      # [N, T, D]
+        h, _ = lstm(x)
+        s = head(h[:, -1, :]).view(-1, P, C)
+        return torch.sigmoid(torch.logsumexp(s, dim=1))[:, 0]
+    def sample(pairs, P):
+        idx = torch.stack([torch.randint(0, 6, (pairs * P, T), generator=g), torch.randint(0, Ve, (pairs * P, T), generator=g),
+                           torch.randint(0, 9, (pairs * P, T), generator=g)], dim=-1)
+        return idx, torch.randint(0, 2, (pairs,), generator=g).double()
+    def one(idx, lab, P):
+        mods.zero_grad(set_to_none=True)
+        t0 = time.perf_counter()
+        loss = torch.nn.functional.binary_cross_entropy(fwd(idx, P), lab)
+        loss.backward()
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            fwd(idx, P)
+        return t1 - t0, time.perf_counter() - t1
+    P = 2
+    idx, lab = sample(4096, P)    # pairs per autograd pass (bounded activation memory)
+    one(idx[:512], lab[:256], P)  # (warm-up: thread pool, allocator)
+    n, tt, ts = 0, 0.0, 0.0
+    while tt + ts < seconds:
+        x, y = one(idx, lab, P)
+        tt += x; ts += y; n += idx.shape[0]
+    return {"value": n / (tt + ts), "unit": "paths/s", "cores": cores, "kind": "independent (torch-CPU float64 nn.LSTM)",
+            "train_paths_per_s": n / tt, "score_paths_per_s": n / ts,
+            "sample": f"{n} synthetic paths (P={P}, T={T}, D={D}, H={H}, L={L}) in passes of {idx.shape[0]} paths: forward + BCE + autograd backward, then a "
+                      f"no-grad scoring forward; torch {torch.__version__}, {cores} threads"}
+
+
+def other_configs():
+    """compact {value, ms_per_step, roofline} of configs[4] (inference buckets), "d = 64" reading B, run_scripts/config.sh as shipped and
+    configs[3] (20 M entities, bf16) -- `python bench.py <flags>` each, short, no CPU leg, no extra regions"""
+    import subprocess
+    runs = [("C5_inference_T3to7", ["--workload", "c5", "--steps", "30", "--warmup", "5"]),
+            ("dimsB_D192_H192_L2", ["--dims", "B", "--steps", "6", "--warmup", "2"]),
+            ("shipped_rnn_D200_H250", ["--dims", "shipped", "--steps", "6", "--warmup", "2"]),
+            ("C4_20M_entities_d128_bf16", ["--dims", "C4", "--steps", "6", "--warmup", "2"])]
+    out = {}
+    for name, flags in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-alt", "--no-extra-regions", "--no-other-configs", "--batch-feed", "resident"] + flags
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            d = json.loads(line[-1])
+            rf = d.get("roofline") or {}
+            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d.get("dtype"),
+                         "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
+                         "wall_s": round(time.perf_counter() - t0, 1), "flags": " ".join(flags)}
+            oth = rf.get("other_timed_families")
+            if oth:
+                out[name]["roofline"]["other_timed_families"] = {k: {q: v.get(q) for q in ("frac", "avg_launch_ms")} for k, v in oth.items() if v}
+        except Exception as e:   # a failing side run must not take the headline line with it
+            out[name] = {"error": repr(e)[:300], "flags": " ".join(flags)}
+    return out
 
 
 def run_c5(a):
@@ -597,6 +709,33 @@ def main():
         extras["no_prefix_plan"] = region_line(el, n, a.steps)
         for b in full:
             b.free()
+    if plain and not main_streaming and not a.no_batch_sweep and not a.score_only and not a.train_only:
+        # the reference's own minibatch regime (run_scripts/config.sh:38: 128 pairs ~ 256 paths; test_from_checkpoint.lua:49: 512) up to the
+        # bench's 65 536: same step (scoring forward + trainBatch), batches resident, bucketed by P like the main region
+        sweep = {}
+        for pps in (256, 1024, 4096, 16384, 65536):
+            pool = []
+            for i, P in enumerate(Ps):
+                pairs = max(1, pps // P)
+                idx, labels = synth.make_paths(pairs, P, T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, num_types=nT, seed=4242 + 13 * i)
+                pool.append(eng.batch(idx, labels))
+            npaths = [b.n_paths for b in pool]
+            def st(i, pool=pool, npaths=npaths):
+                run_batch(pool[i % len(pool)])
+                return npaths[i % len(pool)]
+            for i in range(6):
+                st(i)
+            eng.sync()
+            k = int(min(2000, max(12, 0.12 / max(1e-6, (elapsed / a.steps) * max(pps / a.paths_per_step, 0.02)))))
+            k -= k % len(pool)
+            el, n = timed_region(st, 6, k)
+            sweep[str(pps)] = {"value": round(n / el, 1), "ms_per_step": round(1e3 * el / k, 4), "steps": k}
+            for b in pool:
+                b.free()
+        for v in sweep.values():
+            v["ratio_to_65536"] = round(v["value"] / sweep["65536"]["value"], 4)
+        extras["batch_sweep"] = {"unit": "paths/s", "paths_per_step": sweep,
+                                 "what": "scoring forward + trainBatch per step at smaller batches (256 ~ config.sh:38's 128 pairs); resident batches, bucketed by P"}
     # data-parallel runs: the exchange's own time, from a short extra region with events around its parts
     dp_info = None
     if dpx is not None:
@@ -714,6 +853,13 @@ def main():
             b.free()
         eng2.close() if hasattr(eng2, "close") else None
 
+    # ---- the other BASELINE configurations, compact: each a short run of this script in its own process (its own engine, its own
+    #      tables), after everything above has been measured.  Parity-test configs, not the headline.
+    other = None
+    if rank == 0 and world == 1 and a.dims == "A" and a.compute_dtype == 0 and not a.no_other_configs and not a.force_dp and not a.score_only \
+            and not a.train_only and a.impl == "auto" and not a.no_extra_regions:
+        other = other_configs()
+
     if rank == 0:
         fwd_flops = sum(T * 2 * G * H * ((D if l == 0 else H) + H) for l in range(L)) + 2 * H * C
         step_flops = (0 if a.score_only else 3 * fwd_flops) + (0 if a.train_only else fwd_flops)  # nominal: every path, every step
@@ -759,7 +905,8 @@ def main():
             "mfma_frac_end_to_end": round(exec_tflops / ((PEAK_TFLOPS_BF16_MFMA if (c4 and a.compute_dtype == 1) else PEAK_TFLOPS_F32_MFMA) * world), 4),
             "final_loss": round(loss, 6),
             "roofline": roofline, "cpu_baseline": cpu,
-            "streaming": extras.get("streaming"), "long_run": extras.get("long_run"),
+            "streaming": extras.get("streaming"), "long_run": extras.get("long_run"), "batch_sweep": extras.get("batch_sweep"),
+            "other_configs": other,
             "value_no_prefix_plan": (extras.get("no_prefix_plan") or {}).get("value"), "no_prefix_plan": extras.get("no_prefix_plan"),
             "dp": dp_info, "alt_f32x6": alt, "kernels": kernels,
         }

@@ -52,12 +52,15 @@ class Case:
         return eng
 
     def check_forward(self, out):
-        assert rel_inf(out["path_scores"], self.ps) < 2e-5
-        # per element as well: 1e-4 relative, with an absolute floor for the scores that happen to sit near zero
-        np.testing.assert_allclose(out["path_scores"], self.ps, rtol=SCORE_RTOL, atol=2e-5 * float(np.max(np.abs(self.ps))))
+        # measured (scripts/gpu_parity_probe.py, round 3): max |error| = 8e-7 of the largest score for fp32 MFMA / f32x6 -- fp32 rounding of
+        # sums of O(1) terms -- so a score that happens to sit at 1e-6 of the largest carries that ABSOLUTE error too (22 % of itself): the
+        # per-element bar is 1e-4 relative above an absolute floor of 3e-6 of the largest score (round 2: 2e-5), probabilities 1e-5 relative
+        smax = float(np.max(np.abs(self.ps)))
+        assert rel_inf(out["path_scores"], self.ps) < 3e-6
+        np.testing.assert_allclose(out["path_scores"], self.ps, rtol=SCORE_RTOL, atol=3e-6 * smax)
         np.testing.assert_allclose(out["pooled"], self.pooled, rtol=SCORE_RTOL, atol=2e-6)
         np.testing.assert_allclose(out["all_probs"], self.probs, rtol=SCORE_RTOL)
-        np.testing.assert_allclose(out["probs"], self.probs[:, 0], rtol=SCORE_RTOL)
+        np.testing.assert_allclose(out["probs"], self.probs[:, 0], rtol=1e-5)
 
     def check_grads(self, eng, loss):
         assert abs(loss - self.loss) < 1e-5 * max(1.0, abs(self.loss)), (loss, self.loss)
@@ -127,29 +130,51 @@ def test_benchmarked_size_fused_matches_the_generic_pipeline(full):
 
 
 @pytest.mark.parametrize("compute_dtype,plan", [(0, True), (0, False), (2, True)])
-def test_benchmarked_size_five_adam_steps_match_the_f64_oracle(full, compute_dtype, plan):
-    """MyOptimizer:trainBatch x 5 (optim.adam, lazy-exact entity rows) on two alternating 65 536-path batches"""
+def test_benchmarked_size_twenty_adam_steps_match_the_f64_oracle(full, compute_dtype, plan):
+    """MyOptimizer:trainBatch x 20 (optim.adam at the reference's default -learningRate 1e-3, OneModel.lua:342; lazy-exact entity rows) on
+    two alternating 65 536-path batches.  Measured: max |d theta| 4.4e-7 (f32x6: 5.3e-7), loss 1e-6, probabilities of the trained
+    model 1.5e-7 relative; the bars sit an order of magnitude above that (round 2: 5 steps at lr 1e-2, 2e-4 / 2e-4 / 5e-4)."""
     eng = full.engine(compute_dtype, "auto", plan)
     idx2, lab2 = synth.make_paths(PAIRS, P, T, Ve=VE, seed=501)
     batches = [(full.idx, full.labels), (idx2, lab2)]
     gb = [eng.batch(i, l) for i, l in batches]
     th = full.theta.copy()
     st = full.o64.new_state()
-    oopt = make_opt(method=1, lr=1e-2)
-    gopt = _ffi.make_opt(method=1, lr=1e-2)
-    for s in range(5):
+    oopt = make_opt(method=1, lr=1e-3)
+    gopt = _ffi.make_opt(method=1, lr=1e-3)
+    for s in range(20):
         i, l = batches[s & 1]
         ol, _ = full.o64.train_step(th, st, oopt, i, l)
         gl = eng.train_step(gb[s & 1], gopt)
-        assert abs(gl - ol) < 2e-4 * max(1.0, abs(ol)), (s, gl, ol)
+        assert abs(gl - ol) < 1e-5 * max(1.0, abs(ol)), (s, gl, ol)
     got = eng.get_flat_params()
     d = float(np.max(np.abs(got - th)))
-    assert d < 2e-4, d
+    assert d < 5e-6, d
     # and the scores of the trained model
     out = eng.forward(gb[0], 1, want=("probs",))
     _, _, probs = full.o64.forward(th, full.idx)
-    np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=5e-4)
+    np.testing.assert_allclose(out["probs"], probs[:, 0], rtol=1e-5)
     eng.close()
+
+
+def test_host_buffer_entry_point_equals_the_batch_entry_point_bitwise():
+    """kprn_train_step / kprn_forward (host buffers: what bindings/kprn.lua calls, one upload + batch derivation per call) against
+    kprn_batch_create + kprn_train_step_batch / kprn_forward_batch on the same minibatches, ragged sizes included (37 pairs x 3 = 111 paths:
+    one full tile + 47 rows; 1 pair): identical bits in every parameter, loss and probability."""
+    shape = (6, 5000, 9, 16, 32, 16, 64, 2)
+    a, b = _ffi.Engine(*shape, seed=8), _ffi.Engine(*shape, seed=8)
+    opt = _ffi.make_opt(method=1, lr=1e-3)
+    for k, (pairs, Pk) in enumerate([(37, 3), (128, 2), (1, 5), (300, 1), (37, 3)]):
+        idx, labels = synth.make_paths(pairs, Pk, 6, Ve=5000, seed=70 + k)
+        pa, _ = a.forward_host(idx, 1)
+        la = a.train_step_host(idx, labels, opt)
+        bb = b.batch(idx, labels)
+        pb = b.forward(bb, 1)["probs"]
+        lb = b.train_step(bb, opt)
+        assert np.array_equal(pa, pb), k
+        assert la == lb, (k, la, lb)
+    assert np.array_equal(a.get_flat_params(), b.get_flat_params())
+    a.close(); b.close()
 
 
 @pytest.mark.parametrize("compute_dtype", [0, 2])
