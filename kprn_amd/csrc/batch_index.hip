@@ -327,10 +327,10 @@ size_t merge_scratch_bytes(int64_t n, int Ve) {
 // mark: persistent int32 [Ve], all zero on entry and on exit.
 // Out: G rows of the union += sum over ranks (rank order); union_rows (sorted) and *union_count.
 void merge_rows(hipStream_t s, const void* all, int world, int cap, int de, int Ve, float* G, int32_t* union_rows, int32_t* union_count,
-                int32_t* mark, void* scratch, size_t scratch_sz) {
+                int32_t* mark, void* scratch, size_t scratch_sz, int64_t tail_words) {
   const int64_t n = (int64_t)world * cap;
   if (n <= 0) return;
-  const int64_t stride = 4 + (int64_t)cap * (1 + de);
+  const int64_t stride = 4 + (int64_t)cap * (1 + de) + tail_words;   // (tail: the dense gradient arena riding behind the rows, kprn_api.hip)
   for (int r = 0; r < world; ++r) {   // stream order = rank order
     const int32_t* buf = (const int32_t*)all + (int64_t)r * stride;
     if ((de & 3) == 0) {

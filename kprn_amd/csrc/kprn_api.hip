@@ -910,6 +910,20 @@ int kprn_get_param(kprn_handle* h, const char* name, float* dst, int64_t n) { re
 int kprn_set_param(kprn_handle* h, const char* name, const float* src, int64_t n) { return copy_named(h, name, nullptr, src, n, 0); }
 int kprn_get_grad(kprn_handle* h, const char* name, float* dst, int64_t n) { return copy_named(h, name, dst, nullptr, n, 1); }
 
+// data-parallel exchange with the dense gradient arena riding in the packed row buffer (kprn_set_option "dp_dense_in_pack"): one collective
+// per step instead of two.  The arena is copied behind the rows; after the all-gather every rank sums the W copies IN RANK ORDER (the same
+// sequence of additions everywhere: bit-identical dense gradients on every replica by construction).
+__global__ void k_dense_to_pack(const float* __restrict__ g, int64_t n, float* __restrict__ tail) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) tail[i] = g[i];
+}
+__global__ void k_dense_from_all(const float* __restrict__ all, int world, int64_t stride_words, int64_t tail_off, int64_t n, float* __restrict__ g) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = all[tail_off + i];
+    for (int r = 1; r < world; ++r) acc += all[(int64_t)r * stride_words + tail_off + i];
+    g[i] = acc;
+  }
+}
+
 // rows of one parameter tensor by 0-based row index (a 20 M-row entity table is 10 GB: reading the rows a batch touched must not copy it)
 __global__ void k_rows_copy(float* __restrict__ W, const int64_t* __restrict__ rows, int64_t n, int64_t cols, float* __restrict__ buf, int to_table) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * cols; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1665,7 +1679,7 @@ int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int6
                "made its own) and kprn_stream() was never called -- pass a stream (KPRN_STREAM_LEGACY_DEFAULT for the null stream) or fetch the engine's");
   KPRN_REQUIRE(capacity >= h->step_rows_ub && capacity > 0, KPRN_E_ARG, "capacity smaller than this step's touched-row count");
   const int de = h->cfg.de;
-  const int64_t words = 4 + (int64_t)capacity * (1 + de);
+  const int64_t words = 4 + (int64_t)capacity * (1 + de) + (h->dp_dense_in_pack ? h->n_dense : 0);
   if (words > h->pack_words) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     dfree(h->pack_buf);
@@ -1678,6 +1692,10 @@ int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int6
     ProfScope ps(h, "dp_pack_rows");
     kk::pack_rows(h->stream, h->g_We, h->rows_view, h->count_view, h->step_rows_ub, de, h->pack_buf + 4, (float*)(h->pack_buf + 4 + capacity),
                   h->pack_buf);
+    if (h->dp_dense_in_pack)
+      hipLaunchKernelGGL(k_dense_to_pack, dim3((unsigned)std::min<int64_t>((h->n_dense + 255) / 256, 512)), dim3(256), 0, h->stream, h->g_dense, h->n_dense,
+                         (float*)(h->pack_buf + 4 + (int64_t)capacity * (1 + de)));
+    HIP_TRY(hipGetLastError());
   }
   *dev_buf = h->pack_buf;
   *n_words = words;
@@ -1712,7 +1730,13 @@ int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, i
   {
     ProfScope ps(h, "dp_merge_rows");
     bidx::merge_rows(h->stream, dev_all, world, capacity, h->cfg.de, h->cfg.Ve, h->g_We, h->step_rows, h->step_count, h->dp_mark, h->bidx_scratch,
-                     h->bidx_scratch_bytes);
+                     h->bidx_scratch_bytes, h->dp_dense_in_pack ? h->n_dense : 0);
+    if (h->dp_dense_in_pack) {
+      const int64_t row_words = 4 + (int64_t)capacity * (1 + h->cfg.de);
+      hipLaunchKernelGGL(k_dense_from_all, dim3((unsigned)std::min<int64_t>((h->n_dense + 255) / 256, 512)), dim3(256), 0, h->stream, (const float*)dev_all, (int)world,
+                         row_words + h->n_dense, row_words, h->n_dense, h->g_dense);
+      HIP_TRY(hipGetLastError());
+    }
   }
   // the optimiser now walks the union of all ranks' rows (sorted); exact count on the device, upper bound here
   h->view_batch = nullptr; h->rows_view = h->step_rows; h->count_view = h->step_count;
@@ -1872,6 +1896,10 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     h->feed_workers = v;
   } else if (strcmp(key, "profile_filter") == 0) {
     h->prof_filter = value;  // "" = every kernel family; else only families whose name starts with this
+  } else if (strcmp(key, "dp_dense_in_pack") == 0) {
+    // data-parallel exchange: the dense gradient arena travels behind the packed entity rows (one all-gather, no all-reduce); the merge sums
+    // the ranks' copies in rank order
+    h->dp_dense_in_pack = atoi(value) != 0;
   } else if (strcmp(key, "reserve_cus") == 0) {
     // the fused SCORING forward is a persistent one-workgroup-per-CU kernel that fills the register file of every CU it runs
     // on; leaving a few CUs free lets the copy kernels of a concurrently running collective (RCCL) make progress beside it

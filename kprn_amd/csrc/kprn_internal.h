@@ -158,6 +158,7 @@ struct kprn_handle {
   float* loss_partial = nullptr; int64_t loss_partial_cap = 0; int loss_pending = 0;  // >0: d_loss = sum of that many partials, not formed yet
   // packing buffers for the data-parallel exchange
   int32_t* dp_mark = nullptr;   // [Ve] flags of the exchange's union (all zero between steps)
+  bool dp_dense_in_pack = false; // option: the dense gradient arena rides in the packed buffer (one collective per step)
   int32_t* pack_buf = nullptr; int64_t pack_cap = 0, pack_words = 0;  // {count,-,-,-, ids[cap], rows[cap*de]} 32-bit words; cap of the last pack, allocated words
 
   // scalars on device
@@ -384,7 +385,7 @@ void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* 
                  int T, int D, int dt, int de, int Ve, float* gWe, const SlabReduce* red = nullptr, const SmallGrad* sg = nullptr);
 size_t merge_scratch_bytes(int64_t n, int Ve);
 void merge_rows(hipStream_t s, const void* all, int world, int cap, int de, int Ve, float* G, int32_t* union_rows, int32_t* union_count,
-                int32_t* mark /*persistent [Ve], zero on entry and exit*/, void* scratch, size_t scratch_sz);
+                int32_t* mark /*persistent [Ve], zero on entry and exit*/, void* scratch, size_t scratch_sz, int64_t tail_words = 0);
 }  // namespace bidx
 
 // ---- bf16 pipeline (lstm_bf16.hip): compute_dtype 1 with bf16 storage, FastLSTM, 8-element rows, >= 256 paths ----------------

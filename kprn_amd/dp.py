@@ -8,7 +8,8 @@ independent units: model/module/MapReduce.lua:24-47 never mixes them).  Per step
   1. every rank runs zeroGrad + forward + BCE + backward on ITS pairs, with the loss scaled by
      1/B_global (the mean over the global minibatch, nn.BCECriterion sizeAverage);
   2. dense gradients (type/relation tables, LSTM, head: ONE contiguous device buffer, ~0.3 MB
-     for D=H=64,L=2) -> one all-reduce(sum);
+     for D=H=64,L=2) ride behind the rows of 3. (adapter.dense_in_pack, the default) and are summed
+     in rank order by the merge; or (dense_in_pack=False) one all-reduce(sum);
   3. entity-table gradients are row-sparse -> each rank packs {count, row ids, grad rows} of the rows it
      touched into ONE fixed-capacity buffer, ONE all-gather, then every rank merges all ranks' rows:
      union of the ids by a stable sort, sums in rank order (identical addition order everywhere =>
@@ -40,7 +41,7 @@ def wrap_device(ptr, n, kind, device):
 class GpuAdapter:
     """Exposes one kprn Engine's gradient buffers as CUDA tensors (zero-copy)."""
 
-    def __init__(self, engine, device):
+    def __init__(self, engine, device, dense_in_pack=True):
         self.e = engine
         self.device = torch.device(device)
         sh = engine.stream()   # (first: the engine hands out its exchange buffers only to a caller that knows which stream it queues on)
@@ -54,6 +55,11 @@ class GpuAdapter:
         # raced the pack / merge kernels: right at step 0 by luck, entity rows off by an optimiser step from step 1 on.)
         # (an engine created with KPRN_STREAM_LEGACY_DEFAULT queues on the null stream = torch's default stream)
         self.stream = torch.cuda.ExternalStream(sh, device=self.device) if sh else torch.cuda.default_stream(self.device)
+        # ONE collective per step: the dense gradient arena (0.27 MB at D = H = 64) rides behind the packed entity rows in the all-gather and
+        # every rank sums the W copies in rank order inside the merge -- no all-reduce, two stream hand-overs less, and dense gradients that
+        # are bit-identical on every replica by construction
+        self.dense_in_pack = bool(dense_in_pack)
+        engine.set_option("dp_dense_in_pack", "1" if self.dense_in_pack else "0")
 
     def backward(self, batch, class_id, bce_literal, inv_batch):
         self.e.backward(batch, class_id, bce_literal, inv_batch, want_loss=False)
@@ -186,7 +192,7 @@ class DataParallel:
         if self.timing:
             self._ev.append([])
         self._mark()
-        if self.collectives:
+        if self.collectives and not getattr(a, "dense_in_pack", False):
             dist.all_reduce(a.dense_grads(), op=dist.ReduceOp.SUM, group=self.group)
         self._mark()
         if not self.bounded:

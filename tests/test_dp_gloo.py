@@ -28,7 +28,8 @@ class _Batch:
 class OracleAdapter:
     """numpy stand-in for dp.GpuAdapter: same methods, gradients from the oracle."""
 
-    def __init__(self, cfg, theta):
+    def __init__(self, cfg, theta, dense_in_pack=False):
+        self.dense_in_pack = dense_in_pack
         self.o = Oracle(cfg, np.float64)
         self.cfg = cfg
         self.theta = theta.copy()
@@ -67,7 +68,10 @@ class OracleAdapter:
     def pack(self, capacity):
         """one packed float64 tensor {count, ids[cap], rows[cap*de]} (the GPU adapter packs 32-bit words)"""
         ge = self.g[self.e0:self.e1].reshape(-1, self.de)
-        buf = torch.zeros(1 + capacity * (1 + self.de), dtype=torch.float64)
+        nd = self._dense.numel() if self.dense_in_pack else 0
+        buf = torch.zeros(1 + capacity * (1 + self.de) + nd, dtype=torch.float64)
+        if nd:
+            buf[1 + capacity * (1 + self.de):] = self._dense   # the dense arena rides behind the rows
         n = len(self.rows)
         buf[0] = n
         buf[1:1 + n] = torch.from_numpy(self.rows.astype(np.float64))
@@ -77,7 +81,14 @@ class OracleAdapter:
 
     def merge(self, all_buf, world, capacity):
         ge = self.g[self.e0:self.e1].reshape(-1, self.de)
-        stride = 1 + capacity * (1 + self.de)
+        nd = self._dense.numel() if self.dense_in_pack else 0
+        stride = 1 + capacity * (1 + self.de) + nd
+        if nd:
+            tails = [all_buf[r * stride + stride - nd:(r + 1) * stride].clone() for r in range(world)]
+            acc = tails[0]
+            for t in tails[1:]:   # rank order
+                acc = acc + t
+            self._dense = acc
         for r in range(world):  # rank order => same addition order on every replica
             b = all_buf[r * stride:(r + 1) * stride].numpy()
             n = int(b[0])
@@ -111,7 +122,7 @@ def _worker(rank, world, port, out_dir):
         theta = Oracle(cfg).init_params(3, 0.3)
         idx, labels = synth.make_paths(12, 3, 4, Ve=80, seed=7)
         lo, hi = dp.shard_pairs(12, rank, world)
-        a = OracleAdapter(cfg, theta)
+        a = OracleAdapter(cfg, theta, dense_in_pack=True)   # (the GPU adapter's default: one collective per step; the ragged test below runs the all-reduce form)
         d = dp.DataParallel(a)
         opt = make_opt(method=1, lr=1e-2)
         for _ in range(3):

@@ -157,23 +157,28 @@ def test_benchmarked_size_twenty_adam_steps_match_the_f64_oracle(full, compute_d
     eng.close()
 
 
-def test_host_buffer_entry_point_equals_the_batch_entry_point_bitwise():
+def test_host_buffer_entry_point_equals_the_batch_entry_point():
     """kprn_train_step / kprn_forward (host buffers: what bindings/kprn.lua calls, one upload + batch derivation per call) against
     kprn_batch_create + kprn_train_step_batch / kprn_forward_batch on the same minibatches, ragged sizes included (37 pairs x 3 = 111 paths:
-    one full tile + 47 rows; 1 pair): identical bits in every parameter, loss and probability."""
+    one full tile + 47 rows; 1 pair).  The FORWARD of both entry points is bit-identical (same kernels, same plan, same tiles).  A training
+    step is reproducible to rounding only -- the weight-gradient slab reduce and the entity runs that straddle segments add fp32 partials
+    with atomics, whose order differs from launch to launch (measured: 1 ulp differences, 1.5e-8 after four steps) -- so the parameters are
+    held to 1e-7 and, given the SAME parameters, the two entry points must again score bit-identically."""
     shape = (6, 5000, 9, 16, 32, 16, 64, 2)
     a, b = _ffi.Engine(*shape, seed=8), _ffi.Engine(*shape, seed=8)
     opt = _ffi.make_opt(method=1, lr=1e-3)
     for k, (pairs, Pk) in enumerate([(37, 3), (128, 2), (1, 5), (300, 1), (37, 3)]):
         idx, labels = synth.make_paths(pairs, Pk, 6, Ve=5000, seed=70 + k)
-        pa, _ = a.forward_host(idx, 1)
-        la = a.train_step_host(idx, labels, opt)
         bb = b.batch(idx, labels)
+        ph, _ = b.forward_host(idx, 1)
         pb = b.forward(bb, 1)["probs"]
+        assert np.array_equal(ph, pb), k                       # same engine, same parameters: bit-identical
+        pa, _ = a.forward_host(idx, 1)
+        np.testing.assert_allclose(pa, pb, rtol=1e-6)          # the other engine's parameters differ by accumulated rounding
+        la = a.train_step_host(idx, labels, opt)
         lb = b.train_step(bb, opt)
-        assert np.array_equal(pa, pb), k
-        assert la == lb, (k, la, lb)
-    assert np.array_equal(a.get_flat_params(), b.get_flat_params())
+        assert abs(la - lb) < 1e-6 * max(1.0, abs(lb)), (k, la, lb)
+    assert np.max(np.abs(a.get_flat_params() - b.get_flat_params())) < 1e-7
     a.close(); b.close()
 
 
