@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--train-only", action="store_true")
     ap.add_argument("--score-only", action="store_true")
     ap.add_argument("--no-batch-sweep", action="store_true")
-    ap.add_argument("--dp-overlap-score", action="store_true", help="data-parallel step: queue the scoring pass behind the backward, under the all-gather (round-2 order)")
+    ap.add_argument("--dp-score-first", action="store_true", help="data-parallel step: queue the scoring pass first (as the plain step does) instead of behind the backward, under the all-gather")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact lines of the other BASELINE configs (each a short run of this script)")
     ap.add_argument("--cpu-baseline-quick", action="store_true", help="cpu_baseline: the model-only oracle sample only (no literal flavour, no torch-CPU point)")
     ap.add_argument("--reserve-cus", type=int, default=16, help="CUs the scoring pass leaves to the collective in data-parallel runs")
@@ -570,12 +570,12 @@ def main():
         if a.score_only:
             eng.forward_async(b, 1)
         elif dpx is not None:
-            # the scoring pass goes first, as in the single-GPU step (second stream: it shares the chip with the training forward and has
-            # long finished when the update needs the parameters to itself).  Round 2 queued it behind the backward to cover the all-gather;
-            # the merge and the update then sat behind a kernel that owns every CU for 0.3 ms (--force-dp 1.75 ms against 1.48).
-            if score and not a.dp_overlap_score:
+            # The scoring pass is queued behind the backward, under the all-gather (it scores with the pre-update parameters, so it is independent
+            # of the exchange; the update waits for it).  Measured at world 1 over RCCL (profiles/r03): 1.71 ms against 1.47 ms plain; with the
+            # pass queued first, as in the plain step, 1.76 ms (--dp-score-first) -- see DESIGN.md section 4 for where the 0.24 ms goes.
+            if score and a.dp_score_first:
                 score()
-            dpx.train_step(b, opt, 1, overlap=score if a.dp_overlap_score else None)
+            dpx.train_step(b, opt, 1, overlap=None if a.dp_score_first else score)
         else:
             if score:
                 score()
