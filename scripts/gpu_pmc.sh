@@ -11,7 +11,7 @@ rocprofv3 -L 2>/dev/null | grep -i -E "mfma|^.*SQ_BUSY_CU|SQ_WAVE_CYCLES|SQ_ACTI
 pass() {  # name, counters...
   local name="$1"; shift
   timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d "$OUT/raw_$name" -o p --output-format csv -- \
-      python "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-alt --no-extra-regions --batch-feed resident --no-kernel-events "${EXTRA[@]}" > "$OUT/$name.log" 2>&1
+      python "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-alt --no-extra-regions --batch-feed resident --no-kernel-events --no-other-configs --no-batch-sweep "${EXTRA[@]}" > "$OUT/$name.log" 2>&1
   echo "rocprof exit: $?" >> "$OUT/$name.log"
   find "$OUT/raw_$name" -name "*counter_collection.csv" -exec cp {} "$OUT/$name.csv" \;
   rm -rf "$OUT/raw_$name"
@@ -19,7 +19,7 @@ pass() {  # name, counters...
 EXTRA=("$@")
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
-pass sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
+pass sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES ${MOPS:-SQ_INSTS_VALU_MFMA_MOPS_F32}
 python "$REPO/scripts/pmc_summary.py" "$OUT" > "$OUT/kernels.json"
 python - "$OUT" "$@" <<PY > "$OUT/summary.json"
 import json, sys

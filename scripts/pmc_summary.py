@@ -30,6 +30,8 @@ def load(path):
 
 def short(name):
     """kernel family as bench.py's profiler names it"""
+    if "k_lstm16_persist" in name:   # persistent bf16 layer kernel: <KX, KH, SAVE, ...>
+        return "lstm_persist_bf16_train" if "24, 24, true" in name.replace("(bool)1", "true") else "lstm_persist_bf16_score"
     if "k_lstm_fwd_mc" in name:
         return "lstm_mc_fwd_train" if "true>" in name else "lstm_mc_fwd"
     if "k_lstm_fwd" in name:
