@@ -919,12 +919,13 @@ def main():
     if world > 1 or a.force_dp:
         dist.destroy_process_group()
     if rank == 0:
-        emit_last(out)
+        emit_last(out, hard_exit=(world > 1 or a.force_dp))
 
 
-def emit_last(out):
+def emit_last(out, hard_exit=False):
     """The JSON line is the LAST thing on stdout.  RCCL prints a version banner through C stdio, which a pipe buffers until the process
-    exits -- after Python's own buffer, i.e. behind the line: flush C stdio first, print, and leave without running exit handlers."""
+    exits -- after Python's own buffer, i.e. behind the line: flush C stdio first, print, and (runs that initialised RCCL only) leave without
+    running exit handlers.  Other runs exit normally: rocprofv3 writes its tables from an exit handler."""
     import ctypes
     try:
         ctypes.CDLL(None).fflush(None)
@@ -933,7 +934,8 @@ def emit_last(out):
     sys.stdout.write(json.dumps(out) + "\n")
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)
+    if hard_exit:
+        os._exit(0)
 
 
 if __name__ == "__main__":
