@@ -263,14 +263,15 @@ def cpu_baseline(a, T, dt, de, dr, H, L, seconds):
     orc = Oracle(cfg, np.float64)
     theta = orc.init_params(1, 0.1)
     P = 2
-    pairs = 256
+    pairs = 2048
     idx, labels = synth.make_paths(pairs, P, T, Ve=Ve, seed=9)
+    orc.forward_backward(theta, idx[:256], labels[:256])   # (warm-up: the OpenMP team, first touch of the buffers)
     t0 = time.perf_counter()
     orc.forward_backward(theta, idx, labels)
     orc.forward(theta, idx)
     dt0 = time.perf_counter() - t0
     rate = pairs * P / max(dt0, 1e-6)
-    pairs = int(max(256, min(200000, rate * seconds / P)))
+    pairs = int(max(256, min(2000000, rate * seconds / P)))   # the timed sample: ~`seconds` of host work
     idx, labels = synth.make_paths(pairs, P, T, Ve=Ve, seed=10)
     t0 = time.perf_counter()
     orc.forward_backward(theta, idx, labels)
