@@ -49,9 +49,9 @@ namespace pk {
 
 constexpr int MAXPT = 3;     // path tiles (32 rows each) of a work tile
 constexpr int ROWS = 32 * MAXPT;
-constexpr int PF_DEFAULT = 12;   // weight fragments in flight per wave (must divide the k-steps of a half)
-constexpr int LA_DEFAULT = 2;    // k-steps the LDS operand fragments are read ahead
-constexpr int NTH = 256;
+constexpr int PF_DEFAULT = 8;    // weight fragments in flight per wave (must divide the k-steps of a half)
+constexpr int LA_DEFAULT = 1;    // k-steps the LDS operand fragments are read ahead
+constexpr int NW_DEFAULT = 8;     // waves per workgroup: 8 = two per SIMD (a wave's VMEM / LDS / VALU issue fills the other's MFMA time)
 constexpr int MAXT = 8;      // steps whose ids are staged in LDS
 constexpr int MAXSEG = 3;
 
@@ -121,9 +121,10 @@ __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __builtin_am
 // calls micro(k) once behind every MFMA (k = 0 .. NSLOT - 1): element e enters the pipeline at slot start(e), two elements are
 // in flight at any time.  hipcc's own interleaving left the cell as one VALU-only stretch between bunched MFMAs (measured:
 // 1.12 ms against 0.77 ms without the cell), so the order is pinned at the call site with sched_barrier.
-template <int NPT, int KH, bool SAVE, int DBG = 0>
+template <int NPT, int KH, bool SAVE, int NW, int DBG = 0>
 struct Cell {
   static constexpr int H = KH * 16;
+  static constexpr int HC = 8 * NW;      // hidden units per chunk (8 per wave)
   static constexpr int NE = NPT * 4;     // elements per lane
   static constexpr int NST = 9;          // stages per element (the last one: the path tile's stores, after its 4th element)
   const Args& a;
@@ -133,7 +134,7 @@ struct Cell {
   int te, ce;                // the chunk being finished: step, chunk
   f32x4 cp[MAXPT];           // c_{t-1} of its elements
   struct El { float vi, vg, vf, vo, ig, c, t; } el[2];      // the two elements in flight
-  float gi[2][4], gg[2][4], gf[2][4], go[2][4], cc[2][4], hh[2][4];   // finished values of a path tile (two tiles may overlap)
+  float gi[4], gg[4], gf[4], go[4], cc[4], hh[4];   // finished values of a path tile (its stores are issued before the next tile's first element finishes)
 
   __device__ __forceinline__ Cell(const Args& a_, int wave_, int lane_, int64_t row0_, int nvalid_, rsrc_t hs_, rsrc_t cs_)
       : a(a_), wave(wave_), lane(lane_), ln(lane_ & 31), half(lane_ >> 5), row0(row0_), nvalid(nvalid_), hs(hs_), cs(cs_), te(0), ce(0) {}
@@ -149,10 +150,10 @@ struct Cell {
       cpn[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t > 0 && !(DBG & 16)) {
         if (SAVE) {
-          const float* ub = a.Cs + ((int64_t)(t - 1) * a.N + row0 + 32 * pt) * H + 32 * c + 8 * wave;
+          const float* ub = a.Cs + ((int64_t)(t - 1) * a.N + row0 + 32 * pt) * H + HC * c + 8 * wave;
           if (32 * pt + ln < nvalid) cpn[pt] = ldb<f32x4>(make_rsrc(ub), lo_row(H, 4), 0);
         } else {
-          cpn[pt] = ldb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((c * MAXPT + pt) * 4 + wave) * 1024u);
+          cpn[pt] = ldb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((c * MAXPT + pt) * NW + wave) * 1024u);
         }
       }
     }
@@ -167,19 +168,19 @@ struct Cell {
   __device__ __forceinline__ void store(int pt) {
     if (DBG & 16) {   // (measurement: the cell's arithmetic without its memory traffic)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(hh[pt & 1][j]), "v"(cc[pt & 1][j]));
+      for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(hh[j]), "v"(cc[j]));
       return;
     }
-    const int r = 32 * pt + ln, b = pt & 1;
+    const int r = 32 * pt + ln;
     const bool ok = r < nvalid;
     bf16x4 hb;
     f32x4 cv, hv;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { hb[j] = (bf16)hh[b][j]; cv[j] = cc[b][j]; hv[j] = hh[b][j]; }
-    // h_t for the next step's recurrent half: B-fragment order, k = hidden unit (32 ce + 8 wave + 4 half + j: k-step 2 ce + (wave >> 1),
+    for (int j = 0; j < 4; ++j) { hb[j] = (bf16)hh[j]; cv[j] = cc[j]; hv[j] = hh[j]; }
+    // h_t for the next step's recurrent half: B-fragment order, k = hidden unit (HC ce + 8 wave + 4 half + j: k-step (HC / 16) ce + (wave >> 1),
     // k-group wave & 1, element 4 half + j)
-    stb<bf16x4>(hs, (unsigned)(ln * 16 + half * 8), (unsigned)((te & 1) * (MAXPT * KH * 1024) + (pt * KH + 2 * ce + (wave >> 1)) * 1024 + (wave & 1) * 512), hb);
-    const int64_t cu = 32 * ce + 8 * wave;   // first hidden unit of this wave's piece
+    stb<bf16x4>(hs, (unsigned)(ln * 16 + half * 8), (unsigned)((te & 1) * (MAXPT * KH * 1024) + (pt * KH + (HC / 16) * ce + (wave >> 1)) * 1024 + (wave & 1) * 512), hb);
+    const int64_t cu = HC * ce + 8 * wave;   // first hidden unit of this wave's piece
     if (SAVE) {
       if (ok) {
         const int64_t row = (int64_t)te * a.N + row0 + 32 * pt;
@@ -188,13 +189,13 @@ struct Cell {
         // gate plane, interleaved: per row, groups of [i4 | g4 | f4 | o4] for 4 consecutive hidden units (k_gates_bwd16 reads it so)
         bf16x8 v0, v1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v0[j] = (bf16)gi[b][j]; v0[4 + j] = (bf16)gg[b][j]; v1[j] = (bf16)gf[b][j]; v1[4 + j] = (bf16)go[b][j]; }
+        for (int j = 0; j < 4; ++j) { v0[j] = (bf16)gi[j]; v0[4 + j] = (bf16)gg[j]; v1[j] = (bf16)gf[j]; v1[4 + j] = (bf16)go[j]; }
         const rsrc_t g = make_rsrc(a.ACT16 + row * (4 * H) + 4 * cu);
         const unsigned lo = (unsigned)((ln * 4 * H + 16 * half) * 2);
         stb<bf16x8>(g, lo, 0, v0); stb<bf16x8>(g, lo, 16, v1);
       }
     } else {
-      stb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((ce * MAXPT + pt) * 4 + wave) * 1024u, cv);
+      stb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((ce * MAXPT + pt) * NW + wave) * 1024u, cv);
     }
     if (te == a.T - 1 && ok) stb<f32x4>(make_rsrc(a.hT + (row0 + 32 * pt) * H + cu), lo_row(H, 4), 0, hv);
   }
@@ -203,7 +204,7 @@ struct Cell {
   template <int E, int ST>
   __device__ __forceinline__ void stage(const f32x16 (&pre)[MAXPT]) {
     constexpr float K1 = -1.4426950408889634f, K2 = -2.8853900817779268f;   // sigmoid(x) = rcp(1 + exp2(K1 x)), tanh(x) = 2 rcp(1 + exp2(K2 x)) - 1
-    constexpr int pt = E >> 2, j = E & 3, b = pt & 1;
+    constexpr int pt = E >> 2, j = E & 3;
     El& x = el[E & 1];
     if constexpr (ST == 0) { x.vi = __builtin_amdgcn_exp2f(pre[pt][j] * K1); x.vg = pre[pt][4 + j] * K2; }
     else if constexpr (ST == 1) { x.vg = __builtin_amdgcn_exp2f(x.vg); x.vf = pre[pt][8 + j] * K1; x.vo = pre[pt][12 + j] * K1; }
@@ -214,8 +215,8 @@ struct Cell {
     else if constexpr (ST == 6) { x.t = __builtin_amdgcn_rcpf(x.t + 1.0f); }
     else if constexpr (ST == 7) {
       x.t = 2.0f * x.t - 1.0f;
-      cc[b][j] = x.c; hh[b][j] = x.vo * x.t;
-      if (SAVE) { gi[b][j] = x.vi; gg[b][j] = x.vg; gf[b][j] = x.vf; go[b][j] = x.vo; }
+      cc[j] = x.c; hh[j] = x.vo * x.t;
+      if (SAVE) { gi[j] = x.vi; gg[j] = x.vg; gf[j] = x.vf; go[j] = x.vo; }
     } else if constexpr (j == 3) {
       store(pt);
     }
@@ -288,16 +289,17 @@ __device__ __forceinline__ void half_product(f32x16 (&acc)[MAXPT], f32x16& bias,
 }
 
 // ---- a work tile: NPT path tiles, all T steps ---------------------------------------------------------------------------------
-template <int NPT, int KX, int KH, bool SAVE, int PF, int LA, int DBG>
+template <int NPT, int KX, int KH, bool SAVE, int NW, int PF, int LA, int DBG>
 __device__ __forceinline__ void run_tile(const Args& a, char* XB, char* HB, int32_t* IDS, bf16x8 (&ring)[PF], rsrc_t rW, rsrc_t rB, const bf16* hs_ptr, rsrc_t hs, rsrc_t cs,
                                          int64_t row0, int nvalid, int wave, int lane) {
-  constexpr int H = KH * 16, NCH = H / 32, KS = KX + KH;
-  constexpr unsigned WCH = 4u * KS * 1024u;   // bytes between a wave's fragments of consecutive chunks
+  constexpr int H = KH * 16, HC = 8 * NW, NCH = H / HC, KS = KX + KH, NTHR = 64 * NW;
+  static_assert(H % HC == 0, "whole chunks");
+  constexpr unsigned WCH = (unsigned)NW * KS * 1024u;   // bytes between a wave's fragments of consecutive chunks
   const unsigned wbase = (unsigned)wave * KS * 1024u;   // this wave's fragments of chunk 0
   const int ln = lane & 31, half = lane >> 5;
   const int T = a.T;
   // ids of the tile: IDS[(t * MAXSEG + seg) * ROWS + r] = table row (0-based) / path (plane segments); rows past the tile repeat its last
-  for (int i = threadIdx.x; i < T * a.nseg * ROWS; i += NTH) {
+  for (int i = threadIdx.x; i < T * a.nseg * ROWS; i += NTHR) {
     const int r = i % ROWS, sg = (i / ROWS) % a.nseg, t = i / (ROWS * a.nseg);
     const int64_t n = row0 + (r < nvalid ? r : nvalid - 1);
     IDS[(t * MAXSEG + sg) * ROWS + r] = (a.seg_col[sg] >= 0) ? a.idx[(n * T + t) * a.F + a.seg_col[sg]] - 1 : (int32_t)n;
@@ -307,7 +309,7 @@ __device__ __forceinline__ void run_tile(const Args& a, char* XB, char* HB, int3
   const unsigned xb_lds = lds_off(XB), hb_lds = lds_off(HB);
   auto gather_x = [&](int t) {
     const int k0l = 8 * half;
-    for (int f = wave; f < NPT * KX; f += 4) {
+    for (int f = wave; f < NPT * KX; f += NW) {
       const int pt = f / KX, s = f - pt * KX;
       const int k0 = 16 * s + k0l;
       int sg = 0;
@@ -321,10 +323,10 @@ __device__ __forceinline__ void run_tile(const Args& a, char* XB, char* HB, int3
   };
   auto fetch_h = [&](int t_src) {   // h_{t_src} from the scratch slab into the LDS operand tile
     const char* slab = (const char*)(hs_ptr + (int64_t)(t_src & 1) * (MAXPT * KH * 512));
-    for (int f = wave; f < NPT * KH; f += 4)
+    for (int f = wave; f < NPT * KH; f += NW)
       dma16(slab + (int64_t)f * 1024 + lane * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)(hb_lds + (unsigned)f * 1024u)));
   };
-  auto BP = [&](int c) -> unsigned { return (unsigned)((c < NCH ? c : c - NCH) * 4 + wave) * 128u; };   // byte offset of chunk c's (mod NCH) bias image: [2 halves][16]
+  auto BP = [&](int c) -> unsigned { return (unsigned)((c < NCH ? c : c - NCH) * NW + wave) * 128u; };   // byte offset of chunk c's (mod NCH) bias image: [2 halves][16]
   auto load_bias = [&](int c) -> f32x16 {   // accumulator image of chunk c's bias (the same for every path column)
     f32x16 b;
 #pragma unroll
@@ -341,7 +343,7 @@ __device__ __forceinline__ void run_tile(const Args& a, char* XB, char* HB, int3
   // before it reads the other.  Per set: the c_{t-1} requested for the chunk forming in it, and the bias image it starts from.
   static_assert(NCH % 2 == 0 && NCH >= 4, "the chunk schedule below alternates two accumulator sets and reorders the first two chunks of a step");
   constexpr int XS = KX * NPT, HS = KH * NPT;   // MFMAs of an input half / a recurrent half
-  Cell<NPT, KH, SAVE, DBG> cell(a, wave, lane, row0, nvalid, hs, cs);
+  Cell<NPT, KH, SAVE, NW, DBG> cell(a, wave, lane, row0, nvalid, hs, cs);
   const char* xt = XB + lane * 16;
   const char* ht = HB + lane * 16;
   f32x16 accA[MAXPT], accB[MAXPT], bn;
@@ -403,8 +405,8 @@ __device__ __forceinline__ void run_tile(const Args& a, char* XB, char* HB, int3
   bar();   // the operand tiles and the id tile are free for the next work tile
 }
 
-template <int KX, int KH, bool SAVE, int PF, int LA, int DBG>
-__global__ __launch_bounds__(NTH, 1) void k_lstm16_persist(Args a) {
+template <int KX, int KH, bool SAVE, int NW, int PF, int LA, int DBG>
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_lstm16_persist(Args a) {
   constexpr int KS = KX + KH;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* XB = smem;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(NTH, 1) void k_lstm16_persist(Args a) {
   const int64_t u_beg = a.units * b / G, u_end = a.units * (b + 1) / G;
   if (u_beg >= u_end) return;
   const bf16* hs_ptr = a.hscr + b * (int64_t)(2 * MAXPT * KH * 512);
-  const rsrc_t hs = make_rsrc(hs_ptr), cs = make_rsrc(a.cscr + b * (int64_t)((KH / 2) * MAXPT * 4 * 64 * 4));
+  const rsrc_t hs = make_rsrc(hs_ptr), cs = make_rsrc(a.cscr + b * (int64_t)(KH * 16 * ROWS));   // c_t: [H][96 rows] floats per workgroup
   const rsrc_t rW = make_rsrc(a.Wp), rB = make_rsrc(a.Bp);
   bf16x8 ring[PF];
 #pragma unroll
@@ -426,28 +428,28 @@ __global__ __launch_bounds__(NTH, 1) void k_lstm16_persist(Args a) {
     const int take = rem >= 5 ? 3 : (rem == 4 ? 2 : (int)rem);   // 4 left: 2 + 2 rather than 3 + 1
     const int64_t row0 = u * 32;
     const int nvalid = (int)std::min<int64_t>((int64_t)take * 32, a.N - row0);
-    if (take == 3) run_tile<3, KX, KH, SAVE, PF, LA, DBG>(a, XB, HB, IDS, ring, rW, rB, hs_ptr, hs, cs, row0, nvalid, wave, lane);
-    else run_tile<2, KX, KH, SAVE, PF, LA, DBG>(a, XB, HB, IDS, ring, rW, rB, hs_ptr, hs, cs, row0, nvalid, wave, lane);
+    if (take == 3) run_tile<3, KX, KH, SAVE, NW, PF, LA, DBG>(a, XB, HB, IDS, ring, rW, rB, hs_ptr, hs, cs, row0, nvalid, wave, lane);
+    else run_tile<2, KX, KH, SAVE, NW, PF, LA, DBG>(a, XB, HB, IDS, ring, rW, rB, hs_ptr, hs, cs, row0, nvalid, wave, lane);
     u += take;
   }
 }
 
 // ---- weight / bias packing (whenever the dense parameters change) ----------------------------------------------------------
-// Wp[((c * 4 + w) * KS + s) * 64 + lane][j]: A fragment of k-step s for wave w of chunk c; lane = (m, kg), row m = gate (m >> 3) of
-// hidden unit 32 c + 8 w + (m & 7), k = 16 s + 8 kg + j over [x | h].  From the fp32 masters (rounded once, as the shadow is).
-__global__ void k_pack_w(const float* __restrict__ Wi, const float* __restrict__ Wo, const float* __restrict__ bi, int D, int H, bf16* __restrict__ Wp,
+// Wp[((c * NW + w) * KS + s) * 64 + lane][j]: A fragment of k-step s for wave w of chunk c (HC = 8 NW hidden units); lane = (m, kg), row m =
+// gate (m >> 3) of hidden unit HC c + 8 w + (m & 7), k = 16 s + 8 kg + j over [x | h].  From the fp32 masters (rounded once, as the shadow is).
+__global__ void k_pack_w(const float* __restrict__ Wi, const float* __restrict__ Wo, const float* __restrict__ bi, int D, int H, int NW, bf16* __restrict__ Wp,
                          float* __restrict__ Bp) {
-  const int KS = (D + H) / 16;
-  const int64_t total = (int64_t)(H / 32) * 4 * KS * 64;
+  const int KS = (D + H) / 16, HC = 8 * NW;
+  const int64_t total = (int64_t)(H / HC) * NW * KS * 64;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) {
     const int lane = (int)(i & 63);
     const int64_t f = i >> 6;
     const int s = (int)(f % KS);
-    const int w = (int)((f / KS) & 3);
-    const int c = (int)(f / ((int64_t)KS * 4));
+    const int w = (int)((f / KS) % NW);
+    const int c = (int)(f / ((int64_t)KS * NW));
     const int m = lane & 31, kg = lane >> 5;
-    const int row = (m >> 3) * H + 32 * c + 8 * w + (m & 7);
+    const int row = (m >> 3) * H + HC * c + 8 * w + (m & 7);
     const int k0 = 16 * s + 8 * kg;
     bf16x8 o;
 #pragma unroll
@@ -457,9 +459,9 @@ __global__ void k_pack_w(const float* __restrict__ Wi, const float* __restrict__
     }
     *(bf16x8*)(Wp + i * 8) = o;
   }
-  if (i < (int64_t)(H / 32) * 4 * 2 * 16) {   // Bp[((c * 4 + w) * 2 + half) * 16 + r]: accumulator register r of a lane in that half
-    const int r = (int)(i & 15), half = (int)((i >> 4) & 1), w = (int)((i >> 5) & 3), c = (int)(i >> 7);
-    Bp[i] = bi[(r >> 2) * H + 32 * c + 8 * w + 4 * half + (r & 3)];
+  if (i < (int64_t)(H / HC) * NW * 2 * 16) {   // Bp[((c * NW + w) * 2 + half) * 16 + r]: accumulator register r of a lane in that half
+    const int r = (int)(i & 15), half = (int)((i >> 4) & 1), w = (int)((i >> 5) % NW), c = (int)((i >> 5) / NW);
+    Bp[i] = bi[(r >> 2) * H + HC * c + 8 * w + 4 * half + (r & 3)];
   }
 }
 
@@ -469,6 +471,7 @@ __global__ void k_pack_w(const float* __restrict__ Wi, const float* __restrict__
 struct PersistState {
   bf16* Wp = nullptr; float* Bp = nullptr; bf16* hscr = nullptr; float* cscr = nullptr;
   int grid = 0;
+  int packed_nw = 0;   // waves per workgroup the packed weights are laid out for
 };
 
 bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b) {
@@ -513,14 +516,25 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
     p->Wp = pal<bf16>((int64_t)4 * H * (D + H) + 64);
     p->Bp = pal<float>((int64_t)4 * H);
     p->hscr = pal<bf16>((int64_t)ncu * 2 * pk::MAXPT * KH * 512);
-    p->cscr = pal<float>((int64_t)ncu * (KH / 2) * pk::MAXPT * 4 * 64 * 4);
+    p->cscr = pal<float>((int64_t)ncu * H * pk::ROWS);
     repack = true;
   }
-  if (repack) {
-    const int64_t total = (int64_t)(H / 32) * 4 * ((D + H) / 16) * 64;
+  int nw = pk::NW_DEFAULT, dbg = 0, pf = pk::PF_DEFAULT, la = pk::LA_DEFAULT;
+#ifdef KPRN_PERSIST_VARIANTS
+  // measurement builds (scripts/gpu_persist_knockouts.py): KPRN_PERSIST_NW = waves per workgroup, _DBG = knock-out mask, _PF = ring depth, _LA
+  if (!save) {
+    if (const char* e = getenv("KPRN_PERSIST_NW")) nw = atoi(e);
+    if (const char* e = getenv("KPRN_PERSIST_DBG")) dbg = atoi(e);
+    if (const char* e = getenv("KPRN_PERSIST_PF")) pf = atoi(e);
+    if (const char* e = getenv("KPRN_PERSIST_LA")) la = atoi(e);
+  }
+#endif
+  if (repack || p->packed_nw != nw) {
+    const int64_t total = (int64_t)4 * H * ((D + H) / 16) * 8;   // 16-byte pieces of the packed weights
     hipLaunchKernelGGL(pk::k_pack_w, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, strm, h->dense + h->layer[0].Wi, h->dense + h->layer[0].Wo,
-                       h->dense + h->layer[0].bi, D, H, p->Wp, p->Bp);
+                       h->dense + h->layer[0].bi, D, H, nw, p->Wp, p->Bp);
     HIP_TRY(hipGetLastError());
+    p->packed_nw = nw;
   }
   pk::Args a;
   memset(&a, 0, sizeof(a));
@@ -540,24 +554,21 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
     grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(p->grid, a.units), atoi(e)));
   const size_t lds_bytes = (size_t)pk::MAXPT * (KX + KH) * 1024 + (size_t)pk::MAXT * pk::MAXSEG * pk::ROWS * sizeof(int32_t);
   typedef void (*Kern)(pk::Args);
-  Kern k = save ? (Kern)pk::k_lstm16_persist<KX, KH, true, pk::PF_DEFAULT, pk::LA_DEFAULT, 0> : (Kern)pk::k_lstm16_persist<KX, KH, false, pk::PF_DEFAULT, pk::LA_DEFAULT, 0>;
+  Kern k = save ? (Kern)pk::k_lstm16_persist<KX, KH, true, pk::NW_DEFAULT, pk::PF_DEFAULT, pk::LA_DEFAULT, 0>
+                : (Kern)pk::k_lstm16_persist<KX, KH, false, pk::NW_DEFAULT, pk::PF_DEFAULT, pk::LA_DEFAULT, 0>;
 #ifdef KPRN_PERSIST_VARIANTS
-  // measurement builds (scripts/gpu_persist_knockouts.py): KPRN_PERSIST_DBG = knock-out mask, KPRN_PERSIST_PF = ring depth, KPRN_PERSIST_LA
   if (!save) {
-    const int dbg = getenv("KPRN_PERSIST_DBG") ? atoi(getenv("KPRN_PERSIST_DBG")) : 0;
-    const int pf = getenv("KPRN_PERSIST_PF") ? atoi(getenv("KPRN_PERSIST_PF")) : pk::PF_DEFAULT;
-    const int la = getenv("KPRN_PERSIST_LA") ? atoi(getenv("KPRN_PERSIST_LA")) : pk::LA_DEFAULT;
     bool found = false;
-#define KV(P, A, Dg) if (pf == P && la == A && dbg == Dg) { k = (Kern)pk::k_lstm16_persist<KX, KH, false, P, A, Dg>; found = true; }
-    KV(12, 2, 0) KV(24, 2, 0) KV(12, 1, 0) KV(12, 3, 0) KV(8, 2, 0) KV(24, 3, 0)
-    KV(12, 2, 1) KV(12, 2, 2) KV(12, 2, 4) KV(12, 2, 6) KV(12, 2, 7) KV(12, 2, 9) KV(12, 2, 11) KV(12, 2, 13) KV(12, 2, 15) KV(24, 2, 13) KV(12, 2, 16) KV(12, 2, 22)
+#define KV(W, P, A, Dg) if (nw == W && pf == P && la == A && dbg == Dg) { k = (Kern)pk::k_lstm16_persist<KX, KH, false, W, P, A, Dg>; found = true; }
+    KV(8, 8, 1, 0) KV(8, 12, 1, 0) KV(8, 8, 2, 0) KV(8, 12, 2, 0) KV(4, 12, 2, 0) KV(4, 24, 2, 0)
+    KV(8, 8, 1, 1) KV(8, 8, 1, 2) KV(8, 8, 1, 4) KV(8, 8, 1, 6) KV(8, 8, 1, 7) KV(8, 8, 1, 9) KV(8, 8, 1, 13) KV(8, 8, 1, 15) KV(8, 8, 1, 16)
 #undef KV
     KPRN_REQUIRE(found, KPRN_E_ARG, "this variant of the persistent kernel is not compiled in");
   }
 #endif
   HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   ProfScope ps(h, save ? "lstm_persist_bf16_train" : "lstm_persist_bf16_score");
-  hipLaunchKernelGGL(k, dim3(grid), dim3(pk::NTH), lds_bytes, strm, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64 * nw), lds_bytes, strm, a);
   HIP_TRY(hipGetLastError());
 }
 

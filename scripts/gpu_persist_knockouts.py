@@ -16,17 +16,18 @@ idx, labels = synth.make_paths(16384, 4, 6, Ve=Ve, Vr=100, seed=3)
 b = eng.batch(idx, labels)
 N, T, D, H = 65536, 6, 384, 384
 flops = N * 2 * 4 * H * (T * D + (T - 1) * H)
-variants = [("pf12 la2 (default)", {}), ("pf24 la2", {"KPRN_PERSIST_PF": "24"}), ("cell math without its loads / stores", {"KPRN_PERSIST_DBG": "16"}),
-            ("cell math only + MFMA", {"KPRN_PERSIST_DBG": "22"}),
-            ("no cell", {"KPRN_PERSIST_DBG": "1"}), ("no weight stream", {"KPRN_PERSIST_DBG": "2"}),
-            ("no LDS reads", {"KPRN_PERSIST_DBG": "4"}), ("no weights, no LDS", {"KPRN_PERSIST_DBG": "6"}), ("MFMA only", {"KPRN_PERSIST_DBG": "7"}),
-            ("no cell, no MFMA", {"KPRN_PERSIST_DBG": "9"}), ("LDS reads only", {"KPRN_PERSIST_DBG": "11"}), ("weight stream only", {"KPRN_PERSIST_DBG": "13"}),
-            ("weight stream only pf24", {"KPRN_PERSIST_DBG": "13", "KPRN_PERSIST_PF": "24"}), ("skeleton (barriers, DMA, ids)", {"KPRN_PERSIST_DBG": "15"})]
+variants = [("8 waves pf8 la1 (default)", {}), ("8 waves pf12 la1", {"KPRN_PERSIST_PF": "12"}), ("8 waves pf8 la2", {"KPRN_PERSIST_LA": "2"}), ("8 waves pf12 la2", {"KPRN_PERSIST_PF": "12", "KPRN_PERSIST_LA": "2"}),
+            ("4 waves pf12 la2", {"KPRN_PERSIST_NW": "4", "KPRN_PERSIST_PF": "12", "KPRN_PERSIST_LA": "2"}), ("4 waves pf24 la2", {"KPRN_PERSIST_NW": "4", "KPRN_PERSIST_PF": "24", "KPRN_PERSIST_LA": "2"}),
+            ("no cell", {"KPRN_PERSIST_DBG": "1"}), ("no weight stream", {"KPRN_PERSIST_DBG": "2"}), ("no LDS reads", {"KPRN_PERSIST_DBG": "4"}),
+            ("cell math without its loads / stores", {"KPRN_PERSIST_DBG": "16"}),
+            ("no weights, no LDS", {"KPRN_PERSIST_DBG": "6"}), ("MFMA only", {"KPRN_PERSIST_DBG": "7"}),
+            ("no cell, no MFMA", {"KPRN_PERSIST_DBG": "9"}), ("weight stream only", {"KPRN_PERSIST_DBG": "13"}),
+            ("skeleton (barriers, DMA, ids)", {"KPRN_PERSIST_DBG": "15"})]
 ROUNDS = 3
 res = {name: [] for name, _ in variants}
 for rnd in range(ROUNDS):          # interleaved rounds: a drift of the box (clocks, temperature) hits every variant alike
     for name, env in variants:
-        for k in ("KPRN_PERSIST_DBG", "KPRN_PERSIST_PF", "KPRN_PERSIST_LA"):
+        for k in ("KPRN_PERSIST_DBG", "KPRN_PERSIST_PF", "KPRN_PERSIST_LA", "KPRN_PERSIST_NW"):
             os.environ.pop(k, None)
         os.environ.update(env)
         eng.forward(b, 1)
