@@ -387,17 +387,14 @@ __global__ void k_gather16(const int32_t* __restrict__ idx, int64_t N, int T, in
   *(bf16x8*)(X + ((int64_t)t * N + n) * D + col) = v;
 }
 // cell backward of one step on the saved bf16 gate values (kernels_basic.hip k_gates_bwd, with dA written in bf16)
-// interleaved: the persistent layer kernel's gate plane -- per row, groups of [i4 | g4 | f4 | o4] for 4 consecutive hidden units (two
-// 16-byte stores per lane instead of four 8-byte ones); else gate-major rows [i H | g H | f H | o H]
 __global__ void k_gates_bwd16(const bf16* __restrict__ act, const float* __restrict__ c, const float* __restrict__ c_prev, const float* __restrict__ dH_up,
-                              float* __restrict__ dH, float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H, int interleaved) {
+                              float* __restrict__ dH, float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= N * H) return;
   const int jx = (int)(gid % H);
   const int64_t n = gid / H;
   const bf16* a = act + n * 4 * H;
-  const int p0 = interleaved ? (jx >> 2) * 16 + (jx & 3) : jx, ps = interleaved ? 4 : H;
-  const float ig = (float)a[p0], gg = (float)a[p0 + ps], fg = (float)a[p0 + 2 * ps], og = (float)a[p0 + 3 * ps];
+  const float ig = (float)a[jx], gg = (float)a[H + jx], fg = (float)a[2 * H + jx], og = (float)a[3 * H + jx];
   const float tc = tanhf(c[gid]);
   const float dh = dH[gid] + (dH_up ? dH_up[gid] : 0.f);
   const float dO = dh * tc;
@@ -411,6 +408,71 @@ __global__ void k_gates_bwd16(const bf16* __restrict__ act, const float* __restr
   dC[gid] = dc * fg;
   dH[gid] = 0.f;
 }
+// The same cell backward on the persistent layer kernel's FRAGMENT-order saves (lstm_bf16_persist.hip Cell::store): record ((unit NCH + chunk) NW + wave) 64 +
+// lane holds, for path 32 unit + (lane & 31) and hidden units HC chunk + 8 wave + 4 (lane >> 5) .. + 3, c (4 floats) and the gates as [i4 g4] / [f4 o4].
+// One workgroup = one (unit, chunk): 32 rows x HC hidden units.  The records are read coalesced; everything row-major (dH, dC in / out, dA out) goes
+// through LDS tiles so that global accesses are whole 128 / 256-byte row segments.
+template <int NW>
+__global__ __launch_bounds__(256) void k_gates_bwd16_frag(const bf16x8* __restrict__ A0, const bf16x8* __restrict__ A1, const f32x4* __restrict__ cF,
+                                                          const f32x4* __restrict__ cprevF, const float* __restrict__ dH_up, float* __restrict__ dH,
+                                                          float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H) {
+  constexpr int HC = 8 * NW, Q = HC / 4;
+  __shared__ __attribute__((aligned(16))) float sH[32][HC + 4];
+  __shared__ __attribute__((aligned(16))) float sC[32][HC + 4];
+  __shared__ __attribute__((aligned(16))) bf16 sA[32][4][HC + 8];
+  const int tid = threadIdx.x;
+  const int64_t unit = blockIdx.x, row0 = unit * 32;
+  const int c = blockIdx.y, NCH = gridDim.y, ub = HC * c;
+  for (int i = tid; i < 32 * Q; i += 256) {
+    const int r = i / Q, q = i - r * Q;
+    const int64_t n = row0 + r;
+    f32x4 vh = f32x4{0.f, 0.f, 0.f, 0.f}, vc = vh;
+    if (n < N) {
+      vh = *(const f32x4*)(dH + n * H + ub + 4 * q);
+      vc = *(const f32x4*)(dC + n * H + ub + 4 * q);
+      if (dH_up) { const f32x4 u = *(const f32x4*)(dH_up + n * H + ub + 4 * q); vh += u; }
+    }
+    *(f32x4*)&sH[r][4 * q] = vh;
+    *(f32x4*)&sC[r][4 * q] = vc;
+  }
+  __syncthreads();
+  for (int rl = tid; rl < NW * 64; rl += 256) {
+    const int w = rl >> 6, lane = rl & 63, ln = lane & 31, ul = 8 * w + 4 * (lane >> 5);
+    const int64_t rec = ((unit * NCH + c) * NW + w) * 64 + lane;
+    const bf16x8 a0 = A0[rec], a1 = A1[rec];
+    const f32x4 cc = cF[rec];
+    const f32x4 cp = cprevF ? cprevF[rec] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ig = (float)a0[j], gg = (float)a0[4 + j], fg = (float)a1[j], og = (float)a1[4 + j];
+      const float tc = tanhf(cc[j]);
+      const float dh = sH[ln][ul + j];
+      const float dO = dh * tc;
+      const float dc = sC[ln][ul + j] + dh * og * (1.f - tc * tc);
+      sA[ln][0][ul + j] = tobf(dc * gg * ig * (1.f - ig));
+      sA[ln][1][ul + j] = tobf(dc * ig * (1.f - gg * gg));
+      sA[ln][2][ul + j] = tobf(dc * cp[j] * fg * (1.f - fg));
+      sA[ln][3][ul + j] = tobf(dO * og * (1.f - og));
+      sC[ln][ul + j] = dc * fg;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 32 * Q; i += 256) {
+    const int r = i / Q, q = i - r * Q;
+    const int64_t n = row0 + r;
+    if (n < N) {
+      *(f32x4*)(dC + n * H + ub + 4 * q) = *(const f32x4*)&sC[r][4 * q];
+      *(f32x4*)(dH + n * H + ub + 4 * q) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  constexpr int P8 = HC / 8;   // 16-byte pieces of a (row, gate) segment
+  for (int i = tid; i < 32 * 4 * P8; i += 256) {
+    const int p = i % P8, g = (i / P8) & 3, r = i / (4 * P8);
+    const int64_t n = row0 + r;
+    if (n < N) *(bf16x8*)(dA + n * (int64_t)4 * H + (int64_t)g * H + ub + 8 * p) = *(const bf16x8*)&sA[r][g][8 * p];
+  }
+}
+
 // y[c][r] = x[r][c] for r < R, 0 for R <= r < Rp (the padded row count: 16-byte rows of y); x bf16 [R][C] (C a multiple of 8), y pitch
 // ldy (a multiple of 8); 64 x 64 tiles through LDS, 16-byte global accesses on both sides
 __global__ __launch_bounds__(256) void k_transpose16(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t R, int64_t Rp, int64_t Cc, int64_t ldy) {
@@ -459,6 +521,9 @@ __global__ __launch_bounds__(256) void k_rowsum16(const bf16* __restrict__ x, in
 }
 
 // ---- state + orchestration --------------------------------------------------------------------------------------------------
+// lstm_bf16_persist.hip: fragment-order saves of the persistent layer kernel's training launch
+struct PersistSaves { const float* CsF; const bf16* ActF0; const bf16* ActF1; int64_t NU, step_recs; int NW; };
+
 struct State {
   bf16* We16 = nullptr; bool we_all_dirty = true;
   bf16* dense16 = nullptr;      // bf16 image of the dense arena (same offsets)
@@ -468,12 +533,13 @@ struct State {
   bf16 *X16 = nullptr, *XT16 = nullptr, *H16 = nullptr, *HT16 = nullptr, *ACT16 = nullptr, *dA16 = nullptr, *dAT16 = nullptr;
   void* persist = nullptr;      // lstm_bf16_persist.hip: packed weights + scratch slabs of the persistent layer kernel
   bool pack_dirty = true;       // its packed weights are stale
-  bool act_interleaved = false; // layout of the gate plane the last training forward wrote (k_gates_bwd16)
+  bool act_frag = false;        // the last training forward wrote c and the gate planes in fragment order (persistent kernel; k_gates_bwd16_frag)
+  PersistSaves sv{};
 };
 // lstm_bf16_persist.hip: the whole layer (gather + T steps) as one persistent launch
 bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b);
 void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, bool repack, const bf16* Wt16, const bf16* We16, const bf16* Wr16, bf16* H16,
-                     bf16* ACT16);
+                     PersistSaves* sv);
 void persist_release(void*& st);
 static State* st(kprn_handle* h) {
   if (!h->bf16_state) h->bf16_state = new State();
@@ -586,11 +652,11 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
     HIP_TRY(hipGetLastError());
   }
   if (persist) {
-    persist_forward(h, b, save, s->persist, s->pack_dirty, s->dense16 + h->off_Wt, s->We16, s->dense16 + h->off_Wr, s->H16, s->ACT16);
+    persist_forward(h, b, save, s->persist, s->pack_dirty, s->dense16 + h->off_Wt, s->We16, s->dense16 + h->off_Wr, s->H16, &s->sv);
     s->pack_dirty = false;
-    if (save) s->act_interleaved = true;
+    if (save) s->act_frag = true;
   }
-  if (!persist && save) s->act_interleaved = false;
+  if (!persist && save) s->act_frag = false;
   for (int l = 0; l < L && !persist; ++l) {
     const int Din = h->layer[l].Din;
     const bf16* in = (l == 0) ? s->X16 : s->H16 + (int64_t)(l - 1) * T * N * H;
@@ -663,8 +729,20 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       bf16* dA_t = s->dA16 + (int64_t)t * N * G4;
       {
         ProfScope ps(h, "lstm_gates_bwd_bf16");
-        hipLaunchKernelGGL(k_gates_bwd16, dim3((unsigned)((N * H + 255) / 256)), dim3(256), 0, strm, act + (int64_t)t * N * G4, cs + (int64_t)t * N * H,
-                           t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr, has_up ? w.dIn + (int64_t)t * N * H : nullptr, w.dH, w.dC, dA_t, N, H, s->act_interleaved ? 1 : 0);
+        if (s->act_frag && l == 0) {   // the persistent layer kernel's fragment-order saves
+          const PersistSaves& v = s->sv;
+          const int NCH = H / (8 * v.NW);
+          const bf16x8* a0 = (const bf16x8*)v.ActF0 + (int64_t)t * v.step_recs;
+          const bf16x8* a1 = (const bf16x8*)v.ActF1 + (int64_t)t * v.step_recs;
+          const f32x4* cf = (const f32x4*)v.CsF + (int64_t)t * v.step_recs;
+          const f32x4* cpf = t > 0 ? (const f32x4*)v.CsF + (int64_t)(t - 1) * v.step_recs : nullptr;
+          const float* up = has_up ? w.dIn + (int64_t)t * N * H : nullptr;
+          if (v.NW == 8) hipLaunchKernelGGL((k_gates_bwd16_frag<8>), dim3((unsigned)v.NU, (unsigned)NCH), dim3(256), 0, strm, a0, a1, cf, cpf, up, w.dH, w.dC, dA_t, N, H);
+          else hipLaunchKernelGGL((k_gates_bwd16_frag<4>), dim3((unsigned)v.NU, (unsigned)NCH), dim3(256), 0, strm, a0, a1, cf, cpf, up, w.dH, w.dC, dA_t, N, H);
+        } else {
+          hipLaunchKernelGGL(k_gates_bwd16, dim3((unsigned)((N * H + 255) / 256)), dim3(256), 0, strm, act + (int64_t)t * N * G4, cs + (int64_t)t * N * H,
+                             t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr, has_up ? w.dIn + (int64_t)t * N * H : nullptr, w.dH, w.dC, dA_t, N, H);
+        }
         HIP_TRY(hipGetLastError());
       }
       if (t > 0) {

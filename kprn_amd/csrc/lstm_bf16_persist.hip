@@ -28,8 +28,8 @@
 //     so the cell writes h_t (packed bf16, fragment order) to a private scratch slab that the next step's DMA brings back:
 //     a round trip through this XCD's L2, 72 KB a step against 2.36 MB of weights.  c_t (fp32) goes the same way
 //     (fragment-order scratch when scoring; the saved [T][N][H] plane when training).
-// Training (SAVE) additionally stores h and c row-major and the four gate activations interleaved per 4 hidden units (two 16-byte stores per
-// lane), which is what lstm_bf16.hip's backward reads.
+// Training (SAVE) additionally stores h row-major and c and the four gate activations in fragment order (one contiguous KiB per wave store);
+// lstm_bf16.hip's k_gates_bwd16_frag re-lays them out through LDS.
 #include <string.h>
 
 #include <algorithm>
@@ -64,7 +64,8 @@ struct Args {
   const float* Bp;   // packed bias    [H/32][4 waves][2 halves][16]
   bf16* hscr;        // per workgroup: 2 x [MAXPT][H/16][64][8]  h_t in B-fragment order (ping-pong over steps)
   float* cscr;       // per workgroup: [H/32][MAXPT][4][64][4]   c_t in accumulator order (scoring)
-  bf16* H16; float* Cs; bf16* ACT16;   // SAVE: [T][N][H], [T][N][H], [T][N][H/4][i4 g4 f4 o4]
+  bf16* H16;         // SAVE: h_t row-major [T][N][H] (the backward's dW product reads it)
+  float* CsF; bf16* ActF0; bf16* ActF1; int64_t NU;   // SAVE: c_t and the gate activations in FRAGMENT order (see Cell::store), NU = units of 32 rows
   float* hT;         // [N][H] fp32 h_T (the head's input)
   int64_t units;     // ceil(N / 32)
 };
@@ -149,9 +150,8 @@ struct Cell {
     for (int pt = 0; pt < NPT; ++pt) {
       cpn[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t > 0 && !(DBG & 16)) {
-        if (SAVE) {
-          const float* ub = a.Cs + ((int64_t)(t - 1) * a.N + row0 + 32 * pt) * H + HC * c + 8 * wave;
-          if (32 * pt + ln < nvalid) cpn[pt] = ldb<f32x4>(make_rsrc(ub), lo_row(H, 4), 0);
+        if (SAVE) {   // the saved plane of step t - 1, fragment order: [t][unit][chunk][wave][lane] x 4 floats -- one contiguous KiB per wave
+          cpn[pt] = ldb<f32x4>(make_rsrc(a.CsF + (((((int64_t)(t - 1) * a.NU + row0 / 32 + pt) * (H / HC) + c) * NW + wave) * 64) * 4), (unsigned)lane * 16u, 0);
         } else {
           cpn[pt] = ldb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((c * MAXPT + pt) * NW + wave) * 1024u);
         }
@@ -182,18 +182,18 @@ struct Cell {
     stb<bf16x4>(hs, (unsigned)(ln * 16 + half * 8), (unsigned)((te & 1) * (MAXPT * KH * 1024) + (pt * KH + (HC / 16) * ce + (wave >> 1)) * 1024 + (wave & 1) * 512), hb);
     const int64_t cu = HC * ce + 8 * wave;   // first hidden unit of this wave's piece
     if (SAVE) {
-      if (ok) {
-        const int64_t row = (int64_t)te * a.N + row0 + 32 * pt;
-        stb<f32x4>(make_rsrc(a.Cs + row * H + cu), lo_row(H, 4), 0, cv);
-        stb<bf16x4>(make_rsrc(a.H16 + row * H + cu), lo_row(H, 2), 0, hb);
-        // gate plane, interleaved: per row, groups of [i4 | g4 | f4 | o4] for 4 consecutive hidden units (k_gates_bwd16 reads it so)
-        bf16x8 v0, v1;
+      // c_t and the four gate activations in FRAGMENT order -- record ((((t NU + unit) NCH + chunk) NW + wave) 64 + lane): c 4 floats, gates [i4 g4] and
+      // [f4 o4] as two bf16x8 planes -- every store one contiguous KiB per wave (row-major planes cost this kernel five scattered 8 / 16-byte
+      // stores per lane and chunk: 1.27 ms against 0.76 ms for the scoring launch); lstm_bf16.hip's k_gates_bwd16_frag reads them back coalesced
+      // and does the re-layout to row-major through LDS on its own side.  Rows past N land in the padded tail of their unit.
+      const int64_t rec = ((((int64_t)te * a.NU + row0 / 32 + pt) * (H / HC) + ce) * NW + wave) * 64;
+      stb<f32x4>(make_rsrc(a.CsF + rec * 4), (unsigned)lane * 16u, 0, cv);
+      bf16x8 v0, v1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v0[j] = (bf16)gi[j]; v0[4 + j] = (bf16)gg[j]; v1[j] = (bf16)gf[j]; v1[4 + j] = (bf16)go[j]; }
-        const rsrc_t g = make_rsrc(a.ACT16 + row * (4 * H) + 4 * cu);
-        const unsigned lo = (unsigned)((ln * 4 * H + 16 * half) * 2);
-        stb<bf16x8>(g, lo, 0, v0); stb<bf16x8>(g, lo, 16, v1);
-      }
+      for (int j = 0; j < 4; ++j) { v0[j] = (bf16)gi[j]; v0[4 + j] = (bf16)gg[j]; v1[j] = (bf16)gf[j]; v1[4 + j] = (bf16)go[j]; }
+      stb<bf16x8>(make_rsrc(a.ActF0 + rec * 8), (unsigned)lane * 16u, 0, v0);
+      stb<bf16x8>(make_rsrc(a.ActF1 + rec * 8), (unsigned)lane * 16u, 0, v1);
+      if (ok) stb<bf16x4>(make_rsrc(a.H16 + ((int64_t)te * a.N + row0 + 32 * pt) * H + cu), lo_row(H, 2), 0, hb);
     } else {
       stb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((ce * MAXPT + pt) * NW + wave) * 1024u, cv);
     }
@@ -468,10 +468,12 @@ __global__ void k_pack_w(const float* __restrict__ Wi, const float* __restrict__
 }  // namespace pk
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
+struct PersistSaves { const float* CsF; const bf16* ActF0; const bf16* ActF1; int64_t NU, step_recs; int NW; };   // (also declared in lstm_bf16.hip)
 struct PersistState {
   bf16* Wp = nullptr; float* Bp = nullptr; bf16* hscr = nullptr; float* cscr = nullptr;
   int grid = 0;
   int packed_nw = 0;   // waves per workgroup the packed weights are laid out for
+  float* CsF = nullptr; bf16* ActF0 = nullptr; bf16* ActF1 = nullptr; int64_t save_recs = 0;   // training saves, fragment order
 };
 
 bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b) {
@@ -485,7 +487,7 @@ bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b) {
 void persist_release(void*& st) {
   PersistState* p = (PersistState*)st;
   if (!p) return;
-  for (void* q : {(void*)p->Wp, (void*)p->Bp, (void*)p->hscr, (void*)p->cscr}) if (q) hipFree(q);
+  for (void* q : {(void*)p->Wp, (void*)p->Bp, (void*)p->hscr, (void*)p->cscr, (void*)p->CsF, (void*)p->ActF0, (void*)p->ActF1}) if (q) hipFree(q);
   delete p;
   st = nullptr;
 }
@@ -499,7 +501,7 @@ template <typename Tp> static Tp* pal(int64_t n) {
 
 // repack: true when the dense parameters changed since the last call
 void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, bool repack, const bf16* Wt16, const bf16* We16, const bf16* Wr16, bf16* H16,
-                     bf16* ACT16) {
+                     PersistSaves* sv) {
   constexpr int KX = 24, KH = 24;
   const kprn_config& c = h->cfg;
   const int H = c.H, D = h->D, T = b->T;
@@ -544,7 +546,19 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
   a.seg_base[1] = We16; a.seg_w[1] = c.de; a.seg_col[1] = b->F - 2; a.seg_off[1] = c.dt;
   a.seg_base[2] = Wr16; a.seg_w[2] = c.dr; a.seg_col[2] = b->F - 1; a.seg_off[2] = c.dt + c.de;
   a.Wp = p->Wp; a.Bp = p->Bp; a.hscr = p->hscr; a.cscr = p->cscr;
-  a.H16 = H16; a.Cs = h->ws.Cs; a.ACT16 = ACT16;
+  a.H16 = H16; a.NU = (N + 31) / 32;
+  if (save) {
+    PersistState* q = p;
+    const int64_t recs = (int64_t)T * a.NU * 32 * H / 4;   // 4-element records of one plane
+    if (recs > q->save_recs) {
+      HIP_TRY(hipStreamSynchronize(strm));
+      for (void* x : {(void*)q->CsF, (void*)q->ActF0, (void*)q->ActF1}) if (x) hipFree(x);
+      q->CsF = pal<float>(recs * 4); q->ActF0 = pal<bf16>(recs * 8); q->ActF1 = pal<bf16>(recs * 8);
+      q->save_recs = recs;
+    }
+    a.CsF = q->CsF; a.ActF0 = q->ActF0; a.ActF1 = q->ActF1;
+    sv->CsF = q->CsF; sv->ActF0 = q->ActF0; sv->ActF1 = q->ActF1; sv->NU = a.NU; sv->NW = nw; sv->step_recs = a.NU * 32 * H / 4;
+  }
   a.hT = h->ws.Hs + (int64_t)(T - 1) * N * H;   // (L = 1: layer 0's last step)
   a.units = (N + 31) / 32;
   int grid = p->grid;
