@@ -1839,6 +1839,10 @@ int kprn_debug_gemm(kprn_handle* h, int32_t what, int64_t M, int32_t N, int64_t 
   API_BEGIN(h)
   KPRN_REQUIRE(ms && M > 0 && N > 0 && K > 0 && iters > 0, KPRN_E_ARG, "bad argument");
   hipStream_t s = h->stream;
+  if (what == 5 || what == 6) {   // the bf16 pipeline's product (lstm_bf16.hip): 5 = C = A B^T, 6 = split-K accumulate
+    *ms = bf16p::debug_gemm16(s, M, N, K, what == 6 ? 1024 : 1, iters);
+    return KPRN_OK;
+  }
   float *A = nullptr, *B = nullptr, *C = nullptr, *X = nullptr, *Z = nullptr;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));

@@ -295,8 +295,24 @@ static bool big_tiles(int64_t M, int64_t N) {
 }
 
 // C[M][N] (fp32) = or += A[M][K] B[N][K]^T; K, lda, ldb multiples of 8 elements, 16-byte aligned pointers
+static const bf16* zero16() {   // 16 zero bytes on the device: the source of every out-of-range DMA piece
+  static bf16* z = nullptr;
+  if (!z) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+      throw KprnError{KPRN_E_NOMEM, "hipMalloc failed (zero block)"};
+    z = (bf16*)p;
+  }
+  return z;
+}
+namespace gx { struct XArgs; template <bool ACCUM> __global__ void k_gemm16x(XArgs a); }
+static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K, bool accumulate,
+                    int split_k);
+
+// C[M][N] (fp32) = or += A[M][K] B[N][K]^T; K, lda, ldb multiples of 8 elements, 16-byte aligned pointers
 static void gemm16(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K,
                    bool accumulate, const float* bias, int split_k) {
+  if (!bias && gemm16x(s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, split_k)) return;   // the LDS-DMA kernel (large products without a bias)
   GArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.K = K; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.bias = bias;
@@ -314,6 +330,161 @@ static void gemm16(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int
   a.kchunk = kchunk; a.use_atomic = split_k > 1 ? 1 : 0;
   if (big) { if (accumulate) launch16<EPI_ACCUM, 1>(s, a, 1); else launch16<EPI_STORE, 1>(s, a, 1); }
   else if (accumulate) launch16<EPI_ACCUM, 0>(s, a, split_k); else launch16<EPI_STORE, 0>(s, a, split_k);
+}
+
+// ---- the same product on 256 x 128 x 64 tiles with LDS-DMA operand staging (round 3) ------------------------------------------------------
+// k_gemm16 above moves its operands global -> registers -> LDS (8 ds_write_b128 per thread and chunk) on 128 x 128 tiles and reaches 0.22 of the
+// bf16 peak on the backward's products (dx, dh, split-K dW: 3.3 ms of configs[3]'s 8.6 ms step).  Here: 8 waves (4 x 2, 64 x 64 each on
+// v_mfma_f32_32x32x16_bf16), three LDS stages of 48 KB filled by global_load_lds_dwordx4 two chunks ahead (counted vmcnt, one barrier per chunk,
+// no staging registers, no ds_write), and a third fewer operand bytes per flop through the 64 B/clk L1 path, which is what bounds a 128 x 128 tile.
+// LDS image: rows of 128 bytes (64 k); the DMA writes lane l at +16 l, i.e. 8 rows x 8 pieces per instruction, so the XOR swizzle that keeps
+// ds_read_b128 of a 32-row fragment conflict-free is applied to the SOURCE piece (piece = slot ^ ((row >> 1) & 7)) and again to the read address.
+namespace gx {
+constexpr int BM = 256, BN = 128, BK = 64, NSTAGE = 3, NTHR = 512;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+struct XArgs {
+  const bf16* A; int64_t lda; const bf16* B; int64_t ldb; float* C; int64_t ldc; int64_t M; int N; int64_t K;
+  int64_t kchunk; int nsplit; int64_t mtiles; int ntiles; const bf16* zero;   // zero: 16 zero bytes in global memory (source of every out-of-range piece)
+};
+__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool ACCUM>
+__global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kg = lane >> 5;
+  const int64_t id = blockIdx.x;
+  const int xcd = (int)(id & 7);
+  const int64_t j = id >> 3;
+  int nt_idx; int64_t mt_idx, split_idx = 0;
+  if (a.nsplit > 1) {   // all tiles of one K range on one XCD
+    const int64_t tiles = a.mtiles * a.ntiles;
+    split_idx = (j / tiles) * 8 + xcd;
+    const int64_t tl = j % tiles;
+    mt_idx = tl / a.ntiles; nt_idx = (int)(tl % a.ntiles);
+    if (split_idx >= a.nsplit) return;
+  } else {              // the n-tiles of one m-tile back to back on one XCD: its A rows are fetched into that L2 once
+    nt_idx = (int)(j % a.ntiles);
+    mt_idx = (j / a.ntiles) * 8 + xcd;
+    if (mt_idx >= a.mtiles) return;
+  }
+  const int64_t m0 = mt_idx * BM;
+  const int n0 = nt_idx * BN;
+  const int64_t k_beg = split_idx * a.kchunk;
+  const int64_t k_end = (k_beg + a.kchunk < a.K) ? k_beg + a.kchunk : a.K;
+  const int nch = (k_end > k_beg) ? (int)((k_end - k_beg + BK - 1) / BK) : 0;
+  if (nch == 0) return;
+  // this lane's share of a chunk's 48 DMA instructions (8 rows x 128 bytes each): instruction q = wave + 8 i covers tile rows 8 q .. 8 q + 7
+  // (A: q < 32, B: q >= 32); the lane fetches piece (slot ^ key(row)) of row 8 q + (lane >> 3)
+  const bf16* rowp[6]; int piece[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int q = wave + 8 * i;
+    const bool isA = q < BM / 8;
+    const int row = 8 * (isA ? q : q - BM / 8) + (lane >> 3);
+    const int64_t gr = (isA ? m0 : (int64_t)n0) + row;
+    const bool ok = gr < (isA ? a.M : (int64_t)a.N);
+    rowp[i] = ok ? (isA ? a.A + gr * a.lda : a.B + gr * a.ldb) : nullptr;
+    piece[i] = (lane & 7) ^ ((row >> 1) & 7);
+  }
+  const unsigned lds0 = lds_off(smem);
+  auto issue = [&](int c) {
+    const int64_t k0 = k_beg + (int64_t)c * BK;
+    const unsigned st = lds0 + (unsigned)(c % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int64_t k = k0 + 8 * piece[i];
+      const bf16* src = (rowp[i] && k < k_end) ? rowp[i] + k : a.zero;
+      dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + (unsigned)(wave + 8 * i) * 1024u)));
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
+  issue(0);
+  if (nch > 1) issue(1);
+  const int key = (r >> 1) & 7;
+  const int arow = (wm * 64 + r) * 128, brow = BM * 128 + (wn * 64 + r) * 128;
+  for (int c = 0; c < nch; ++c) {
+    // chunk c has landed for this wave (its own 6 pieces; the 6 most recent ones belong to chunk c + 1), then for every wave; and every wave has
+    // finished reading the stage chunk c + 2 is about to overwrite (it held chunk c - 1)
+    if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (c + 2 < nch) issue(c + 2);
+    const char* st = smem + (c % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int po = ((2 * kk + kg) ^ key) << 4;
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(st + arow + i * 32 * 128 + po);
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) fb[jn] = *(const bf16x8*)(st + brow + jn * 32 * 128 + po);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+    }
+  }
+  // D[m][n]: lane (n = lane & 31, kg), register q <-> row (q & 3) + 8 (q >> 2) + 4 kg: 32 consecutive columns per store instruction
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+      const int n = n0 + wn * 64 + jn * 32 + r;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+        if (m >= a.M) continue;
+        float* dst = a.C + m * a.ldc + n;
+        if (ACCUM) unsafeAtomicAdd(dst, acc[i][jn][q]); else *dst = acc[i][jn][q];
+      }
+    }
+}
+}  // namespace gx
+
+static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K, bool accumulate,
+                    int split_k) {
+  static const bool off = getenv("KPRN_BF16_GEMM") && getenv("KPRN_BF16_GEMM")[0] == 'o';   // "old": k_gemm16 everywhere (A/B measurements, tests)
+  if (off || M < gx::BM || N < gx::BN || (K & 7) || (lda & 7) || (ldb & 7)) return false;
+  gx::XArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero = zero16();
+  a.mtiles = (M + gx::BM - 1) / gx::BM; a.ntiles = (N + gx::BN - 1) / gx::BN;
+  if (split_k < 1 || !accumulate) split_k = 1;
+  if (split_k > 1) {
+    const int64_t tiles = a.mtiles * a.ntiles;
+    split_k = (int)std::max<int64_t>(1, std::min<int64_t>(split_k, (3 * 256 + tiles - 1) / tiles));
+  }
+  int64_t kchunk = (K + split_k - 1) / split_k;
+  kchunk = ((kchunk + gx::BK - 1) / gx::BK) * gx::BK;
+  split_k = (int)((K + kchunk - 1) / kchunk);
+  a.kchunk = kchunk; a.nsplit = split_k;
+  const size_t lds_bytes = (size_t)gx::NSTAGE * gx::STAGE_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(((a.mtiles + 7) / 8) * 8 * a.ntiles));
+  if (split_k > 1) grid = dim3((unsigned)(((split_k + 7) / 8) * 8 * a.mtiles * a.ntiles));
+  if (accumulate) hipLaunchKernelGGL((gx::k_gemm16x<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
+  else hipLaunchKernelGGL((gx::k_gemm16x<false>), grid, dim3(gx::NTHR), lds_bytes, s, a);
+  HIP_TRY(hipGetLastError());
+  return true;
 }
 
 // ---- element-wise / layout kernels --------------------------------------------------------------------------------------
@@ -415,7 +586,8 @@ __global__ void k_gates_bwd16(const bf16* __restrict__ act, const float* __restr
 template <int NW>
 __global__ __launch_bounds__(256) void k_gates_bwd16_frag(const bf16x8* __restrict__ A0, const bf16x8* __restrict__ A1, const f32x4* __restrict__ cF,
                                                           const f32x4* __restrict__ cprevF, const float* __restrict__ dH_up, float* __restrict__ dH,
-                                                          float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H) {
+                                                          float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H, bf16* __restrict__ dAT /* nullable: this
+                                                          step's column block of dA^T [4H][T Np] */, int64_t ldT, int64_t Np) {
   constexpr int HC = 8 * NW, Q = HC / 4;
   __shared__ __attribute__((aligned(16))) float sH[32][HC + 4];
   __shared__ __attribute__((aligned(16))) float sC[32][HC + 4];
@@ -470,6 +642,17 @@ __global__ __launch_bounds__(256) void k_gates_bwd16_frag(const bf16x8* __restri
     const int p = i % P8, g = (i / P8) & 3, r = i / (4 * P8);
     const int64_t n = row0 + r;
     if (n < N) *(bf16x8*)(dA + n * (int64_t)4 * H + (int64_t)g * H + ub + 8 * p) = *(const bf16x8*)&sA[r][g][8 * p];
+  }
+  if (dAT) {   // the transposed image the dW products contract over (k-contiguous operands): this tile's 4 HC gate rows x 32 paths, pad columns zero
+    for (int i = tid; i < 4 * HC * 4; i += 256) {
+      const int r8 = i & 3, u = (i >> 2) % HC, g = i / (4 * HC);
+      const int64_t n0 = row0 + 8 * r8;
+      if (n0 >= Np) continue;
+      bf16x8 v;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = (n0 + q < N) ? sA[8 * r8 + q][g][u] : (bf16)0.f;
+      *(bf16x8*)(dAT + ((int64_t)g * H + ub + u) * ldT + n0) = v;
+    }
   }
 }
 
@@ -737,8 +920,10 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
           const f32x4* cf = (const f32x4*)v.CsF + (int64_t)t * v.step_recs;
           const f32x4* cpf = t > 0 ? (const f32x4*)v.CsF + (int64_t)(t - 1) * v.step_recs : nullptr;
           const float* up = has_up ? w.dIn + (int64_t)t * N * H : nullptr;
-          if (v.NW == 8) hipLaunchKernelGGL((k_gates_bwd16_frag<8>), dim3((unsigned)v.NU, (unsigned)NCH), dim3(256), 0, strm, a0, a1, cf, cpf, up, w.dH, w.dC, dA_t, N, H);
-          else hipLaunchKernelGGL((k_gates_bwd16_frag<4>), dim3((unsigned)v.NU, (unsigned)NCH), dim3(256), 0, strm, a0, a1, cf, cpf, up, w.dH, w.dC, dA_t, N, H);
+          const int64_t Np_ = (N + 7) & ~(int64_t)7;
+          bf16* dat = s->dAT16 + (int64_t)t * Np_;   // (this kernel has the tile in LDS: it writes the transposed image too, no transpose pass for dA)
+          if (v.NW == 8) hipLaunchKernelGGL((k_gates_bwd16_frag<8>), dim3((unsigned)v.NU, (unsigned)NCH), dim3(256), 0, strm, a0, a1, cf, cpf, up, w.dH, w.dC, dA_t, N, H, dat, (int64_t)T * Np_, Np_);
+          else hipLaunchKernelGGL((k_gates_bwd16_frag<4>), dim3((unsigned)v.NU, (unsigned)NCH), dim3(256), 0, strm, a0, a1, cf, cpf, up, w.dH, w.dC, dA_t, N, H, dat, (int64_t)T * Np_, Np_);
         } else {
           hipLaunchKernelGGL(k_gates_bwd16, dim3((unsigned)((N * H + 255) / 256)), dim3(256), 0, strm, act + (int64_t)t * N * G4, cs + (int64_t)t * N * H,
                              t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr, has_up ? w.dIn + (int64_t)t * N * H : nullptr, w.dH, w.dC, dA_t, N, H);
@@ -753,7 +938,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     const int64_t Np = (N + 7) & ~(int64_t)7, TNp = (int64_t)T * Np;   // padded step blocks of the transposed images (pads are zero)
     {
       ProfScope ps(h, "bf16_transposes");
-      transpose_steps(strm, s->dA16, s->dAT16, T, N, Np, G4);                                                    // dA^T [4H][T][Np]
+      if (!(s->act_frag && l == 0)) transpose_steps(strm, s->dA16, s->dAT16, T, N, Np, G4);                       // dA^T [4H][T][Np] (the fragment-order gate backward wrote it)
       transpose_steps(strm, (l == 0) ? s->X16 : s->H16 + (int64_t)(l - 1) * TN * H, s->XT16, T, N, Np, Din);      // in^T [Din][T][Np]
       if (T > 1) transpose_steps(strm, hs, s->HT16, T, N, Np, H);                                                // h^T  [H][T][Np]
     }
@@ -782,6 +967,31 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     kk::embed_scatter(strm, b->idx, N, T, b->F, c.num_types, w.dIn, c.dt, c.de, c.dr, c.Vt, c.Vr, gd + h->off_Wt, h->g_We, gd + h->off_Wr, have_index);
     if (have_index) bidx::entity_grad(strm, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, b->n_index, N, T, D, c.dt, c.de, c.Ve, h->g_We);
   }
+}
+
+// measurement hook (kprn_debug_gemm what = 5 / 6): C[M][N] = A[M][K] B[N][K]^T on random bf16 operands; split_k > 1: the split-K accumulate form
+float debug_gemm16(hipStream_t strm, int64_t M, int N, int64_t K, int split_k, int iters) {
+  float* f = dal<float>(std::max<int64_t>(M * K, (int64_t)N * K));
+  bf16 *A = dal<bf16>(M * K), *B = dal<bf16>((int64_t)N * K);
+  float* C = dal<float>(M * N);
+  kk::fill_uniform(strm, f, M * K, 0.1f, 1, 0);
+  hipLaunchKernelGGL(k_cvt, dim3((unsigned)((M * K / 4 + 256) / 256)), dim3(256), 0, strm, f, A, M * K);
+  kk::fill_uniform(strm, f, (int64_t)N * K, 0.1f, 2, 0);
+  hipLaunchKernelGGL(k_cvt, dim3((unsigned)(((int64_t)N * K / 4 + 256) / 256)), dim3(256), 0, strm, f, B, (int64_t)N * K);
+  hipMemsetAsync(C, 0, (size_t)(M * N) * sizeof(float), strm);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int it = -2; it < iters; ++it) {
+    if (it == 0) hipEventRecord(e0, strm);
+    gemm16(strm, A, K, B, K, C, N, M, N, K, split_k > 1, nullptr, split_k);
+  }
+  hipEventRecord(e1, strm);
+  hipEventSynchronize(e1);
+  float t = 0.f;
+  hipEventElapsedTime(&t, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipFree(f); hipFree(A); hipFree(B); hipFree(C);
+  return t / (float)iters;
 }
 
 }  // namespace bf16p
