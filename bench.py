@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--train-only", action="store_true")
     ap.add_argument("--score-only", action="store_true")
     ap.add_argument("--no-batch-sweep", action="store_true")
-    ap.add_argument("--dp-overlap-score", action="store_true", help="data-parallel step: queue the scoring pass behind the backward, under the all-gather (round-2 order), instead of deferring it to the training forward")
+    ap.add_argument("--dp-score-first", action="store_true", help="data-parallel step: queue the scoring pass first (as the plain step does) instead of behind the backward, under the all-gather")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact lines of the other BASELINE configs (each a short run of this script)")
     ap.add_argument("--cpu-baseline-quick", action="store_true", help="cpu_baseline: the model-only oracle sample only (no literal flavour, no torch-CPU point)")
     ap.add_argument("--reserve-cus", type=int, default=16, help="CUs the scoring pass leaves to the collective in data-parallel runs")
@@ -565,21 +565,18 @@ def main():
     # a few CUs left free for the collective's copy kernels.
     if dpx is not None:
         eng.set_option("reserve_cus", str(a.reserve_cus))
-        eng.set_option("score_defer", "0" if a.dp_overlap_score else "1")
 
     def run_batch(b):
         score = (lambda: eng.forward_async(b, 1)) if not a.train_only else None
         if a.score_only:
             eng.forward_async(b, 1)
         elif dpx is not None:
-            # The scoring pass is REQUESTED first and issued by the engine around the training forward of the step's backward
-            # (kprn_set_option "score_defer"): the order the single-call train step produces by itself -- pass and training forward share
-            # the chip, the pass has long finished when the update needs the parameters to itself.  Queued from outside it either sat
-            # between the backward and the update (round 2: 1.71 ms against 1.47 plain) or ran alone in front of the step (1.76 ms).
-            # --dp-overlap-score: the round-2 order (the pass under the all-gather).
-            if score and not a.dp_overlap_score:
+            # The scoring pass is queued behind the backward, under the all-gather (it scores with the pre-update parameters, so it is independent
+            # of the exchange; the update waits for it).  Measured at world 1 over RCCL (profiles/r03): 1.71 ms against 1.47 ms plain; with the
+            # pass queued first, as in the plain step, 1.76 ms (--dp-score-first) -- see DESIGN.md section 4 for where the 0.24 ms goes.
+            if score and a.dp_score_first:
                 score()
-            dpx.train_step(b, opt, 1, overlap=score if a.dp_overlap_score else None)
+            dpx.train_step(b, opt, 1, overlap=None if a.dp_score_first else score)
         else:
             if score:
                 score()

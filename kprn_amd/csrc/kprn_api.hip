@@ -148,11 +148,7 @@ static void step_tab_reserve(kprn_handle* h, int64_t need) {
 
 // scoring overlap: the main stream waits for the pass running on the side stream (before anything that changes what that pass
 // reads -- parameters, the prefix table -- and before the backward kernels, which want the chip to themselves)
-static void flush_deferred_score(kprn_handle* h);
-static void score_pass_begin(kprn_handle* h, const kprn_batch* b, int class_id);
-static void score_pass_launch(kprn_handle* h, const kprn_batch* b, int class_id);
 void join_score(kprn_handle* h) {
-  flush_deferred_score(h);   // (a deferred pass that nobody issued yet must run before what it reads changes)
   if (!h->score_pending) return;
   HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_score_done, 0));
   h->score_pending = false;
@@ -633,15 +629,7 @@ static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int
   const kprn_config& c = h->cfg;
   zero_grads(h);
   h->dense_grads_clean = false;
-  // A deferred scoring pass (kprn_set_option "score_defer") is issued HERE: its fork point in front of the training forward, its launch right
-  // behind it -- the order the single-call train step produces by itself (pass and training forward share the chip, the pass has long
-  // finished when the update needs the parameters), which a caller that puts an exchange between backward and update cannot produce from
-  // outside (the data-parallel step: the pass then sat between the backward and the update).
-  const kprn_batch* db = h->deferred_b;
-  const int dcid = h->deferred_class;
-  if (db) { h->deferred_b = nullptr; score_pass_begin(h, db, dcid); }
   forward_impl(h, b, class_id, true, /*do_pool=*/false);
-  if (db) score_pass_launch(h, db, dcid);
   Workspace& w = h->ws;
   const int cid = class_id - 1;
   float invB = inv_batch > 0.f ? inv_batch : 1.0f / (float)b->B;
@@ -1366,7 +1354,6 @@ static void feed_impl(kprn_handle* h, kprn_batch** slot, const int32_t* idx, con
 
 int kprn_batch_feed_async(kprn_handle* h, kprn_batch** slot, const int32_t* idx, const float* labels, int32_t B, int32_t P, int32_t T, int32_t F) {
   API_BEGIN(h)
-  if (slot && *slot && h->deferred_b == *slot) flush_deferred_score(h);   // (the slot's contents are about to change)
   feed_impl(h, slot, idx, labels, nullptr, B, P, T, F);
   API_END(h)
 }
@@ -1376,7 +1363,6 @@ int kprn_batch_feed_rows_async(kprn_handle* h, kprn_batch** slot, const int32_t*
   API_BEGIN(h)
   KPRN_REQUIRE(rows, KPRN_E_ARG, "rows is NULL");
   for (int32_t i = 0; i < B; ++i) KPRN_REQUIRE(rows[i] >= 0 && rows[i] < n_rows, KPRN_E_ARG, "a row index is outside 0..n_rows-1");
-  if (slot && *slot && h->deferred_b == *slot) flush_deferred_score(h);
   feed_impl(h, slot, data, labels, rows, B, P, T, F);
   API_END(h)
 }
@@ -1448,7 +1434,6 @@ void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
   if (!b) return;
   if (h) {
     hipSetDevice(h->cfg.device_id);
-    if (h->deferred_b == b) { try { flush_deferred_score(h); } catch (...) { h->deferred_b = nullptr; } }
     if (h->view_batch == b) { try { materialize_step_rows(h); } catch (...) { h->view_batch = nullptr; h->rows_view = nullptr; h->step_rows_ub = 0; } }
     if (h->caught_serial == b->serial) h->caught_serial = -1;
     if (b->job.valid()) { try { b->job.get(); } catch (...) {} }
@@ -1476,68 +1461,44 @@ int kprn_batch_executed_steps(kprn_handle* h, const kprn_batch* b, int64_t* step
   API_END(h)
 }
 
-// The scoring pass on the side stream, in two halves.  begin: everything the pass reads is made final on the MAIN stream (row catch-up, prefix
-// table, derived weights) and the fork point is recorded; launch: the side stream waits for the fork point and runs the pass into its own buffers.
-static void score_pass_begin(kprn_handle* h, const kprn_batch* b, int class_id) {
-  check_batch(h, b, class_id);
-  const int64_t N = (int64_t)b->B * b->P;
-  catch_up(h, b);
-  ensure_ws_common(h, N, b->B);
-  if (!h->score_stream) {
-    HIP_TRY(hipStreamCreateWithFlags(&h->score_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_score_done, hipEventDisableTiming));
-  }
-  if (N > h->cap_N2 || b->B > h->cap_B2) {
-    HIP_TRY(hipStreamSynchronize(h->score_stream));
-    dfree(h->S2); dfree(h->sel2);
-    h->cap_N2 = std::max(N, h->cap_N2); h->cap_B2 = std::max<int64_t>(b->B, h->cap_B2);
-    h->S2 = dalloc<float>(h->cap_N2 * h->cfg.C);
-    h->sel2 = dalloc<float>(h->cap_B2);
-  }
-  fused::prefix_forward(h, b);  // (main stream; cached for the pass and for the training forward of the same batch)
-  fused::mc_prepare(h);         // (likewise: the split weights of the matrix-core forward)
-  HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
-}
-static void score_pass_launch(kprn_handle* h, const kprn_batch* b, int class_id) {
-  HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_fork, 0));
-  Workspace& w = h->ws;
-  hipStream_t main_stream = h->stream;
-  float* S0 = w.S; float* sel0 = w.sel;
-  h->stream = h->score_stream; w.S = h->S2; w.sel = h->sel2;
-  try {
-    fused::forward(h, b, false);
-    pool_stage(h, b, class_id - 1, false);
-  } catch (...) { h->stream = main_stream; w.S = S0; w.sel = sel0; throw; }
-  h->stream = main_stream; w.S = S0; w.sel = sel0;
-  HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
-  h->score_pending = true;
-}
-// a pass requested with "score_defer" on and not yet issued: issue it now (somebody needs its result, or is about to change what it reads)
-static void flush_deferred_score(kprn_handle* h) {
-  if (!h->deferred_b) return;
-  const kprn_batch* b = h->deferred_b;
-  const int cid = h->deferred_class;
-  h->deferred_b = nullptr;
-  score_pass_begin(h, b, cid);
-  score_pass_launch(h, b, cid);
-}
-
 int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id) {
   API_BEGIN(h)
-  flush_deferred_score(h);
   h->last_forward_side = false;
   if (h->score_overlap && b && use_fused(h, b, false)) {
     // the pass goes to the side stream with its own output buffers; everything it reads is final on the main stream first
     check_batch(h, b, class_id);
+    const int64_t N = (int64_t)b->B * b->P;
+    catch_up(h, b);
+    ensure_ws_common(h, N, b->B);
+    if (!h->score_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->score_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_score_done, hipEventDisableTiming));
+    }
+    if (N > h->cap_N2 || b->B > h->cap_B2) {
+      HIP_TRY(hipStreamSynchronize(h->score_stream));
+      dfree(h->S2); dfree(h->sel2);
+      h->cap_N2 = std::max(N, h->cap_N2); h->cap_B2 = std::max<int64_t>(b->B, h->cap_B2);
+      h->S2 = dalloc<float>(h->cap_N2 * h->cfg.C);
+      h->sel2 = dalloc<float>(h->cap_B2);
+    }
+    fused::prefix_forward(h, b);  // (main stream; cached for the pass below and for the training forward of the same batch)
+    fused::mc_prepare(h);         // (likewise: the split weights of the matrix-core forward)
+    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_fork, 0));
+    Workspace& w = h->ws;
+    hipStream_t main_stream = h->stream;
+    float* S0 = w.S; float* sel0 = w.sel;
+    h->stream = h->score_stream; w.S = h->S2; w.sel = h->sel2;
+    try {
+      fused::forward(h, b, false);
+      pool_stage(h, b, class_id - 1, false);
+    } catch (...) { h->stream = main_stream; w.S = S0; w.sel = sel0; throw; }
+    h->stream = main_stream; w.S = S0; w.sel = sel0;
+    HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
+    h->score_pending = true;
     h->last_forward_side = true;
     h->last_B = b->B;
-    if (h->score_defer) {   // issued by the next backward, right behind its training forward (kprn_set_option "score_defer")
-      h->deferred_b = b; h->deferred_class = class_id;
-      return KPRN_OK;
-    }
-    score_pass_begin(h, b, class_id);
-    score_pass_launch(h, b, class_id);
     return KPRN_OK;
   }
   forward_impl(h, b, class_id, false, true, /*every_class=*/false);  // kprn_read_probs hands out the selected class
@@ -1547,7 +1508,6 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
 int kprn_read_probs(kprn_handle* h, float* probs, int32_t B) {
   API_BEGIN(h)
   KPRN_REQUIRE(probs && B > 0 && B <= h->last_B, KPRN_E_ARG, "bad probs buffer / B");
-  flush_deferred_score(h);
   if (h->last_forward_side) {
     HIP_TRY(hipMemcpyAsync(probs, h->sel2, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->score_stream));
     HIP_TRY(hipStreamSynchronize(h->score_stream));
@@ -1944,10 +1904,6 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     h->feed_workers = v;
   } else if (strcmp(key, "profile_filter") == 0) {
     h->prof_filter = value;  // "" = every kernel family; else only families whose name starts with this
-  } else if (strcmp(key, "score_defer") == 0) {
-    // kprn_forward_batch_async only records the request; the next backward issues the pass around its training forward (see backward_impl)
-    flush_deferred_score(h);
-    h->score_defer = atoi(value) != 0;
   } else if (strcmp(key, "dp_dense_in_pack") == 0) {
     // data-parallel exchange: the dense gradient arena travels behind the packed entity rows (one all-gather, no all-reduce); the merge sums
     // the ranks' copies in rank order

@@ -187,8 +187,6 @@ struct kprn_handle {
   // of the same step: neither depends on the other); every operation that would change what the pass reads waits for it
   int prefix_plan = 1;            // kprn_set_option "prefix_plan": build identical-prefix plans for new batches (fused path)
   int score_overlap = 0;
-  int score_defer = 0;            // kprn_set_option "score_defer": a requested pass is issued by the next backward (around its training forward)
-  const kprn_batch* deferred_b = nullptr; int deferred_class = 1;   // the request not yet issued
   hipStream_t score_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_score_done = nullptr;
   bool score_pending = false;     // a pass is (possibly) still running on score_stream

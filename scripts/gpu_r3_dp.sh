@@ -8,6 +8,6 @@ run() { name=$1; shift; timeout 600 python bench.py --no-cpu-baseline --no-alt -
 import json; d=json.load(open('gpurun_out/dp_${TAG}_$name.json')); print('$name', d['value'], d['ms_per_step'], json.dumps(d.get('dp'))[:700])" || tail -5 gpurun_out/dp_${TAG}_$name.log; }
 run plain --steps 60 --warmup 10
 run force_dp --force-dp --steps 60 --warmup 10
-run force_dp_r2order --force-dp --dp-overlap-score --steps 60 --warmup 10
+run force_dp_score_first --force-dp --dp-score-first --steps 60 --warmup 10
 run plain2 --steps 60 --warmup 10
 timeout 300 python scripts/gpu_dp_sim.py > gpurun_out/dp_sim_$TAG.json 2> gpurun_out/dp_sim_$TAG.log; tail -c 1200 gpurun_out/dp_sim_$TAG.json
