@@ -71,7 +71,10 @@ def parse():
     ap.add_argument("--train-only", action="store_true")
     ap.add_argument("--score-only", action="store_true")
     ap.add_argument("--no-batch-sweep", action="store_true")
-    ap.add_argument("--dp-score-first", action="store_true", help="data-parallel step: queue the scoring pass first (as the plain step does) instead of behind the backward, under the all-gather")
+    ap.add_argument("--dp-unfused", action="store_true", help="data-parallel step: separate marking merge + row update instead of the union inside the row update (A/B)")
+    ap.add_argument("--dp-score-first", action="store_true", help="data-parallel step: queue the scoring pass first (as the plain step does: it shares the chip with the training forward); default at world 1, where no collective needs hiding")
+    ap.add_argument("--dp-score-under-gather", action="store_true", help="data-parallel step: queue the scoring pass behind the backward, while the all-gather is in flight; default at world > 1")
+    ap.add_argument("--dp-torch-collectives", action="store_true", help="data-parallel step: the collectives through torch.distributed (hooks kprn_sparse_grad_pack / _merge) instead of the engine's own RCCL exchange")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact lines of the other BASELINE configs (each a short run of this script)")
     ap.add_argument("--cpu-baseline-quick", action="store_true", help="cpu_baseline: the model-only oracle sample only (no literal flavour, no torch-CPU point)")
     ap.add_argument("--reserve-cus", type=int, default=16, help="CUs the scoring pass leaves to the collective in data-parallel runs")
@@ -555,7 +558,14 @@ def main():
 
     dpx = None
     if world > 1 or a.force_dp:
-        dpx = dp.DataParallel(dp.GpuAdapter(eng, dev))
+        if a.dp_torch_collectives or a.dp_unfused:
+            os.environ["KPRN_DP_NATIVE"] = "0"
+        dpx = dp.DataParallel(dp.GpuAdapter(eng, dev, fused_update=not a.dp_unfused))
+        # where the scoring pass goes: first (beside the training forward, as in the plain step) when no collective needs hiding, else behind
+        # the backward while the all-gather is in flight (the engine's exchange then runs the collective on a stream of its own)
+        dp_score_first = a.dp_score_first or (world == 1 and not a.dp_score_under_gather)
+        if dpx.native and not dp_score_first:
+            eng.set_option("dp_comm_stream", "1")
         # packing capacity = largest distinct-row count of any batch on any rank (known from the batch index)
         dpx.set_capacity(max(b.n_uniq for b in batches))
 
@@ -563,7 +573,7 @@ def main():
     # BEFORE this step's update ("score the batch, then learn from it"), so it does not depend on the step's gradient
     # exchange: in data-parallel runs it is enqueued while the entity-row all-gather is in flight (kprn_amd/dp.py), with
     # a few CUs left free for the collective's copy kernels.
-    if dpx is not None:
+    if dpx is not None and not dp_score_first:   # (a pass queued first shares the chip with the training forward, not with a collective)
         eng.set_option("reserve_cus", str(a.reserve_cus))
 
     def run_batch(b):
@@ -571,12 +581,12 @@ def main():
         if a.score_only:
             eng.forward_async(b, 1)
         elif dpx is not None:
-            # The scoring pass is queued behind the backward, under the all-gather (it scores with the pre-update parameters, so it is independent
-            # of the exchange; the update waits for it).  Measured at world 1 over RCCL (profiles/r03): 1.71 ms against 1.47 ms plain; with the
-            # pass queued first, as in the plain step, 1.76 ms (--dp-score-first) -- see DESIGN.md section 4 for where the 0.24 ms goes.
-            if score and a.dp_score_first:
+            # The scoring pass scores with the pre-update parameters, so it is independent of the exchange and the update waits for it.  It is
+            # queued FIRST (beside the training forward, exactly as in the plain step) when no collective needs hiding (world 1), else behind
+            # the backward while the all-gather is in flight.  profiles/r03 + DESIGN.md section 4 have the measured timelines of both.
+            if score and dp_score_first:
                 score()
-            dpx.train_step(b, opt, 1, overlap=None if a.dp_score_first else score)
+            dpx.train_step(b, opt, 1, overlap=None if dp_score_first else score)
         else:
             if score:
                 score()
@@ -763,6 +773,9 @@ def main():
         if world > 1:
             dist.all_reduce(tr)
         dp_info["ranks_reporting"] = int(tr.item())
+        dp_info["exchange"] = ("engine: in-place RCCL all-gather on the engine's stream, union inside the row update" if dpx.native else
+                               "torch.distributed collectives around the pack / merge hooks" + ("" if a.dp_unfused else ", union inside the row update"))
+        dp_info["scoring_pass"] = "first, beside the training forward" if dp_score_first else "behind the backward, under the all-gather"
 
     loss = eng.read_loss()
     assert np.isfinite(loss), "training diverged"
@@ -935,7 +948,7 @@ def emit_last(out, hard_exit=False):
     sys.stdout.write(json.dumps(out) + "\n")
     sys.stdout.flush()
     sys.stderr.flush()
-    if hard_exit:
+    if hard_exit and os.environ.get("KPRN_BENCH_SOFT_EXIT") != "1":   # (a profiler wants its exit handler: scripts/gpu_timeline.sh)
         os._exit(0)
 
 

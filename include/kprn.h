@@ -237,12 +237,34 @@ int kprn_sparse_grad_capacity(kprn_handle* h, int32_t* max_rows_per_step);
  *   { int32 count, 3 x pad, int32 ids[capacity] (sorted, 0-based), float rows[capacity][d_entity] }
  * and clears them from the local accumulator; *n_words = 4 + capacity (1 + d_entity): the unit of the all-gather. */
 int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int64_t* n_words);
-/* dev_all = the `world` packed buffers back to back (all-gather output, THIS rank's included).  Builds the union
- * of the rows and their sum in rank order (one stable sort + one gather-reduce; identical bits on every rank) in
- * the accumulator; the next kprn_apply_update walks that union.                                              */
+/* dev_all = the `world` packed buffers back to back (all-gather output, THIS rank's included).  The union of the rows with
+ * their sums in rank order (identical bits on every rank) is what the next kprn_apply_update walks: built here in the
+ * accumulator (a marking pass per rank + one compaction), or -- kprn_set_option(h, "dp_fused_update", "1") -- only recorded
+ * and formed inside the optimiser's row kernel (lazy-exact Adam without clip / L2; anything else builds it first): the
+ * caller then keeps dev_all alive and unchanged until kprn_apply_update has been queued.  With "dp_dense_in_pack" = 1 the
+ * dense gradient buffer rides behind the rows (n_words grows by its length rounded up to 4) and is summed here too.       */
 int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, int32_t capacity);
 /* the stream everything is queued on (hipStream_t), so the caller can order collectives  */
 int kprn_stream(kprn_handle* h, void** stream);
+
+/* ---- the exchange issued by the engine (new design, SURVEY 8e: RCCL over xGMI) --------
+ * Instead of handing buffers to the caller's collectives, the engine holds an RCCL communicator and queues
+ *   pack (straight into its slot of the gathered buffer) -> ncclAllGather IN PLACE -> dense sum -> optimiser step on the union
+ * on its own stream from two C calls; nothing of the host program sits between the kernels.  librccl is dlopen'ed
+ * (rccl_path, or NULL = "librccl.so" as the process already has it); the caller's control plane carries the bootstrap:
+ *   rank 0: kprn_dp_unique_id(path, id) -> broadcast the 128 bytes -> every rank: kprn_dp_init(h, path, id, rank, world)
+ * (collective).  Per step, after kprn_backward_batch with inv_batch = 1 / (pairs of the GLOBAL minibatch):
+ *   kprn_dp_exchange_begin(h, capacity)   capacity = the same multiple of 4 on every rank, >= every rank's touched rows
+ *   ... work that does not depend on the update (a scoring pass) may be queued here ...
+ *   kprn_dp_exchange_finish(h, opt)       = kprn_sparse_grad_merge + kprn_apply_update on the gathered buffer
+ * kprn_set_option(h, "dp_comm_stream", "1") puts the collective on a stream of its own so that the work queued in between
+ * overlaps it (world > 1).  Replicas stay bit-identical (rank-ordered sums).                                             */
+int kprn_dp_available(const char* rccl_path);   /* KPRN_OK when librccl loads and has the entry points (no handle, no GPU work) */
+int kprn_dp_unique_id(const char* rccl_path, void* id128 /* out: 128 bytes */);
+int kprn_dp_init(kprn_handle* h, const char* rccl_path, const void* id128, int32_t rank, int32_t world);
+int kprn_dp_exchange_begin(kprn_handle* h, int32_t capacity);
+int kprn_dp_exchange_finish(kprn_handle* h, const kprn_opt* opt);
+int kprn_dp_shutdown(kprn_handle* h);   /* destroys the communicator (kprn_destroy does it too) */
 
 /* ---- checkpoints (OneModel.lua:392-408 torch.save{embeddingLayer,predictor_net}) ------
  * native format: header + flat fp32 vector in getParameters() order (optimizer state is

@@ -47,6 +47,30 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(kprn_[a-z_0-9]+)\s*\(", txt)))
 
 
+def dp_unique_id(rccl_path=None):
+    """128 bytes from ncclGetUniqueId (rank 0 draws it; the caller broadcasts it to every rank's Engine.dp_init)"""
+    L = lib()
+    buf = (C.c_char * 128)()
+    rc = L.kprn_dp_unique_id(rccl_path.encode() if rccl_path else None, buf)
+    if rc != 0:
+        raise KprnError(rc, L.kprn_last_error(None).decode())
+    return bytes(buf.raw)
+
+
+def dp_available(rccl_path=None):
+    return lib().kprn_dp_available(rccl_path.encode() if rccl_path else None) == 0
+
+
+def torch_rccl_path():
+    """the librccl.so the running torch build ships (the copy torch.distributed's "nccl" backend has loaded), or None"""
+    try:
+        import torch
+        p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return p if os.path.exists(p) else None
+    except Exception:
+        return None
+
+
 def format_score_lines(counter0, probs, labels):
     """bytes of the scoring writer's lines for pairs counter0 .. (kprn_format_score_lines; host-only)"""
     L = lib()
@@ -446,6 +470,20 @@ class Engine:
 
     def sparse_grad_merge(self, all_ptr, world, capacity):
         self._ck(self.L.kprn_sparse_grad_merge(self.h, C.c_void_p(all_ptr), int(world), int(capacity)))
+
+    # ---- the exchange issued by the engine over RCCL (kprn_dp_*) ----
+    def dp_init(self, id128, rank, world, rccl_path=None):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        self._ck(self.L.kprn_dp_init(self.h, rccl_path.encode() if rccl_path else None, buf, int(rank), int(world)))
+
+    def dp_exchange_begin(self, capacity):
+        self._ck(self.L.kprn_dp_exchange_begin(self.h, int(capacity)))
+
+    def dp_exchange_finish(self, opt):
+        self._ck(self.L.kprn_dp_exchange_finish(self.h, C.byref(opt)))
+
+    def dp_shutdown(self):
+        self._ck(self.L.kprn_dp_shutdown(self.h))
 
     def stream(self):
         p = C.c_void_p()

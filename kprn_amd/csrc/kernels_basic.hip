@@ -637,6 +637,64 @@ __global__ void k_adam_rows_v(float* __restrict__ W, float* __restrict__ g, floa
   if (j == 0) last[r] = t_now;
 }
 
+// Data-parallel exchange, union + update in ONE launch (lazy-exact Adam, no clip / L2).  `all` = the all-gathered packed buffers
+// [world][stride] of kprn_sparse_grad_pack: {count, -, -, -, ids[cap] ASCENDING (the batch index's run-length-encoded sorted keys, each
+// row once), rows[cap][d]}.  One G-lane group per (rank, entry); lane j finds the row in rank j's list by binary search (world <= G), the
+// positions are shared through the group; the entry of the LOWEST rank that touched the row owns it: it adds the other ranks'
+// contributions in RANK ORDER (the same addition order on every replica, and the order k_add_rank's launches used), replays the row's
+// skipped steps and applies this one.  No flag array over the table, no compaction, no gradient accumulator round trip.
+template <int G>
+__global__ void k_union_adam(const int32_t* __restrict__ all, int world, int cap, int64_t stride, float* __restrict__ W, float* __restrict__ m,
+                             float* __restrict__ v, int32_t* __restrict__ last, int32_t t_now, const float* __restrict__ step_tab, float b1, float b2,
+                             float eps, int64_t pad_row) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int j = threadIdx.x % G;
+  const int base = (threadIdx.x & 63) & ~(G - 1);
+  const int r = (int)(slot / cap), k = (int)(slot - (int64_t)r * cap);
+  const bool in_range = r < world;
+  const int32_t* mine = all + (int64_t)(in_range ? r : 0) * stride;
+  const bool live = in_range && k < mine[0];
+  const int32_t row = live ? mine[4 + k] : 0;
+  int pos = -1;
+  if (live && j < world && j != r) {
+    const int32_t* o = all + (int64_t)j * stride;
+    const int n = o[0];
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (o[4 + mid] < row) lo = mid + 1; else hi = mid;
+    }
+    if (lo < n && o[4 + lo] == row) pos = lo;
+  }
+  f4 g4 = f4{0.f, 0.f, 0.f, 0.f};
+  if (live) g4 = *(const f4*)((const float*)(mine + 4 + cap) + (int64_t)k * (4 * G) + 4 * j);
+  bool owner = live;
+  for (int q = 0; q < world; ++q) {   // every lane of the wave takes every shuffle (the groups of one wave may belong to two ranks)
+    const int p = __shfl(pos, base + q, 64);
+    if (p < 0 || !live || q == r) continue;
+    if (q < r) owner = false;
+    else if (owner) g4 = g4 + *(const f4*)((const float*)(all + (int64_t)q * stride + 4 + cap) + (int64_t)p * (4 * G) + 4 * j);
+  }
+  if (!owner) return;
+  const int32_t l = last[row];
+  const int64_t o = (int64_t)row * (4 * G) + 4 * j;
+  const f4 x4 = *(const f4*)(W + o), m4 = *(const f4*)(m + o), v4 = *(const f4*)(v + o);
+  float x[4] = {x4[0], x4[1], x4[2], x4[3]}, mm[4] = {m4[0], m4[1], m4[2], m4[3]}, vv[4] = {v4[0], v4[1], v4[2], v4[3]};
+  if (l > 0)
+    for (int32_t kk = l + 1; kk <= t_now - 1; ++kk) {
+      const float st = step_tab[kk];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) adam_elem(x[q], mm[q], vv[q], 0.f, st, b1, b2, eps);
+    }
+  const float st = step_tab[t_now];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) adam_elem(x[q], mm[q], vv[q], g4[q], st, b1, b2, eps);
+  if (row == pad_row) { x[0] = x[1] = x[2] = x[3] = 0.f; }  // zeroPadTokens (MyOptimizer.lua:219)
+  *(f4*)(W + o) = f4{x[0], x[1], x[2], x[3]}; *(f4*)(m + o) = f4{mm[0], mm[1], mm[2], mm[3]}; *(f4*)(v + o) = f4{vv[0], vv[1], vv[2], vv[3]};
+  if (j == 0) last[row] = t_now;
+}
+
 __global__ void k_adam_flush_all(float* __restrict__ W, float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ last, int64_t V,
                                  int d, int32_t t_now, const float* __restrict__ step_tab, float b1, float b2, float eps, int64_t pad_row) {
   const int lane = threadIdx.x & 63;
@@ -703,6 +761,29 @@ __global__ void k_pack_rows(float* __restrict__ G, const int32_t* __restrict__ r
     rows_out[wave * d + e] = G[r * d + e];
     G[r * d + e] = 0.f;
   }
+}
+// the same for d = 4 LG floats with LG lanes per row and 16-byte accesses; the workgroups behind the row part copy `n_tail` floats (the
+// dense gradient arena riding behind the rows, kprn_api.hip dp_dense_in_pack) -- one launch for the whole packed buffer
+template <int LG>
+__global__ void k_pack_rows_v(float* __restrict__ G, const int32_t* __restrict__ rows, const int32_t* __restrict__ count, int32_t* __restrict__ ids_out,
+                              float* __restrict__ rows_out, int32_t* __restrict__ count_out, int row_blocks, const float* __restrict__ tail_src,
+                              int64_t n_tail, float* __restrict__ tail_dst) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  if ((int)blockIdx.x >= row_blocks) {
+    for (int64_t i = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x; i < n_tail; i += (int64_t)(gridDim.x - row_blocks) * blockDim.x)
+      tail_dst[i] = tail_src[i];
+    return;
+  }
+  const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LG;
+  const int j = threadIdx.x % LG;
+  const int32_t n = *count;
+  if (slot == 0 && j == 0) *count_out = n;
+  if (slot >= n) return;
+  const int64_t r = rows[slot];
+  if (j == 0) ids_out[slot] = (int32_t)r;
+  f4* src = (f4*)(G + r * (4 * LG) + 4 * j);
+  *(f4*)(rows_out + slot * (4 * LG) + 4 * j) = *src;
+  *src = f4{0.f, 0.f, 0.f, 0.f};
 }
 
 __global__ void k_clear_rows(float* __restrict__ G, const int32_t* __restrict__ rows, const int32_t* __restrict__ count, int d) {
@@ -1007,10 +1088,40 @@ void zero_rows(hipStream_t s, float* W, int64_t row, int d) {
 }
 
 void pack_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, int32_t* ids_out, float* rows_out,
-               int32_t* count_out) {
+               int32_t* count_out, const float* tail_src, int64_t n_tail, float* tail_dst) {
   int64_t waves = max_rows > 0 ? max_rows : 1;
-  hipLaunchKernelGGL(k_pack_rows, dim3(nblocks(waves * 64)), dim3(TPB), 0, s, G, rows, count, d, ids_out, rows_out, count_out);
+  const bool al = !(((uintptr_t)G | (uintptr_t)rows_out | (uintptr_t)tail_dst) & 15);
+  const int tail_blocks = n_tail > 0 ? (int)std::min<int64_t>((n_tail + 255) / 256, 256) : 0;
+#define KPRN_PACK_V(LG)                                                                                                                      \
+  {                                                                                                                                          \
+    const int rb = (int)nblocks(waves * LG);                                                                                                 \
+    hipLaunchKernelGGL(k_pack_rows_v<LG>, dim3((unsigned)(rb + tail_blocks)), dim3(TPB), 0, s, G, rows, count, ids_out, rows_out, count_out, rb, \
+                       tail_src, n_tail, tail_dst);                                                                                          \
+  }
+  if (al && d == 32) KPRN_PACK_V(8)
+  else if (al && d == 64) KPRN_PACK_V(16)
+  else if (al && d == 128) KPRN_PACK_V(32)
+  else {
+    hipLaunchKernelGGL(k_pack_rows, dim3(nblocks(waves * 64)), dim3(TPB), 0, s, G, rows, count, d, ids_out, rows_out, count_out);
+    if (n_tail > 0) HIP_TRY(hipMemcpyAsync(tail_dst, tail_src, (size_t)n_tail * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+#undef KPRN_PACK_V
   CHECK_LAUNCH();
+}
+
+// union of all ranks' packed rows + the lazy-exact Adam step on it (k_union_adam); false = shape not covered (the caller materialises
+// the union with bidx::merge_rows and takes the ordinary row update)
+bool union_adam(hipStream_t s, const void* all, int world, int cap, int64_t stride, int d, float* W, float* m, float* v, int32_t* last, int32_t t_now,
+                const float* step_tab, float b1, float b2, float eps, int64_t pad_row) {
+  const bool al = !(((uintptr_t)W | (uintptr_t)m | (uintptr_t)v | (uintptr_t)all) & 15) && (stride & 3) == 0 && (cap & 3) == 0;
+  const int lg = d >> 2;
+  if (!al || !(d == 32 || d == 64 || d == 128) || world > lg || world <= 0 || cap <= 0) return false;
+  const int64_t n = (int64_t)world * cap;
+  if (d == 32) hipLaunchKernelGGL(k_union_adam<8>, dim3(nblocks(n * 8)), dim3(TPB), 0, s, (const int32_t*)all, world, cap, stride, W, m, v, last, t_now, step_tab, b1, b2, eps, pad_row);
+  else if (d == 64) hipLaunchKernelGGL(k_union_adam<16>, dim3(nblocks(n * 16)), dim3(TPB), 0, s, (const int32_t*)all, world, cap, stride, W, m, v, last, t_now, step_tab, b1, b2, eps, pad_row);
+  else hipLaunchKernelGGL(k_union_adam<32>, dim3(nblocks(n * 32)), dim3(TPB), 0, s, (const int32_t*)all, world, cap, stride, W, m, v, last, t_now, step_tab, b1, b2, eps, pad_row);
+  CHECK_LAUNCH();
+  return true;
 }
 
 

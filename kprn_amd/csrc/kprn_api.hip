@@ -3,6 +3,7 @@
 // One handle = the reference's training_net (MapReduce(predictor_net, reducer) + Sigmoid,
 // release/songPathRnn/model/OneModel.lua:204-294) plus MyOptimizer's state
 // (model/optimizer/MyOptimizer.lua:13-72), resident in HBM.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -441,8 +442,40 @@ static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool
   h->last_B = b->B;
 }
 
+static void scratch_reserve(void** scratch, size_t* bytes, size_t need);
+static void dp_release(kprn_handle* h);
+// words of the dense gradient arena riding behind the packed rows (padded so that every rank's slice of the gathered buffer keeps
+// 16-byte alignment)
+static inline int64_t dp_tail_words(const kprn_handle* h) { return h->dp_dense_in_pack ? ((h->n_dense + 3) & ~(int64_t)3) : 0; }
+
+// a union recorded by kprn_sparse_grad_merge (dp_fused_update) -> the summed rows in g_We + the sorted union list, as the unfused merge
+// leaves them
+static void materialize_union(kprn_handle* h) {
+  if (!h->dp_union_pending) return;
+  h->dp_union_pending = false;
+  const int64_t n = (int64_t)h->dp_world * h->dp_cap;
+  const size_t need = bidx::merge_scratch_bytes(n, h->cfg.Ve);
+  if (need > h->bidx_scratch_bytes) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    scratch_reserve(&h->bidx_scratch, &h->bidx_scratch_bytes, need);
+  }
+  if (!h->dp_mark) {
+    h->dp_mark = dalloc<int32_t>(h->cfg.Ve);
+    HIP_TRY(hipMemsetAsync(h->dp_mark, 0, (size_t)h->cfg.Ve * sizeof(int32_t), h->stream));
+  }
+  ProfScope ps(h, "dp_merge_rows");
+  bidx::merge_rows(h->stream, h->dp_all, h->dp_world, h->dp_cap, h->cfg.de, h->cfg.Ve, h->g_We, h->step_rows, h->step_count, h->dp_mark, h->bidx_scratch,
+                   h->bidx_scratch_bytes, dp_tail_words(h));
+  h->view_batch = nullptr; h->rows_view = h->step_rows; h->count_view = h->step_count;
+  h->step_rows_ub = std::min<int64_t>(n, h->cfg.Ve);
+  h->ent_grads_dirty = true;
+}
+
 // zeroGradParameters (MyOptimizer.lua:186): dense arena memset; entity rows cleared by list
 static void zero_grads(kprn_handle* h) {
+  if (h->dp_union_pending) {   // a gathered gradient nobody applied: the pack moved the rows out of g_We, so there is nothing to clear
+    h->dp_union_pending = false; h->ent_grads_dirty = false; h->step_rows_ub = 0;
+  }
   if (!h->dense_grads_clean) HIP_TRY(hipMemsetAsync(h->g_dense, 0, (size_t)h->n_dense * sizeof(float), h->stream));
   if (!h->view_batch) { h->rows_view = h->step_rows; h->count_view = h->step_count; }
   if (h->ent_grads_dirty && h->step_rows_ub > 0 && h->rows_view)
@@ -666,9 +699,13 @@ static void apply_update_impl(kprn_handle* h, const kprn_opt* o) {
   hipStream_t s = h->stream;
   const bool reg = (o->regularize == 1);
   const bool dense_ent = reg || o->entity_update == 1;
+  // the exchange's union: walked in place by the row update (lazy-exact Adam, fp32 table only) or materialised first
+  bool fuse_union = h->dp_union_pending && o->method == 1 && !dense_ent && !h->bf16_state && h->dp_world <= (c.de >> 2) &&
+                    (c.de == 32 || c.de == 64 || c.de == 128) && (h->dp_cap & 3) == 0;
+  if (h->dp_union_pending && !fuse_union) materialize_union(h);
   if (!h->view_batch) { h->rows_view = h->step_rows; h->count_view = h->step_count; }  // (the exchange may have re-allocated the list)
   const int32_t* rows = h->rows_view;
-  const int32_t* rcount = h->count_view;
+  const int32_t* rcount = h->count_view;   // (re-read below if a union is materialised late)
   const float* norm2 = nullptr;
   if (reg && o->use_grad_clip) {
     ProfScope ps(h, "grad_norm");
@@ -708,8 +745,16 @@ static void apply_update_impl(kprn_handle* h, const kprn_opt* o) {
       pad_done = true;
     } else {
       ProfScope ps(h, "adam_entity_rows");
-      kk::adam_rows(s, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, rows, rcount, h->step_rows_ub, c.de, (int32_t)t, 1,
-                    h->step_tab, o->beta1, o->beta2, o->eps, pad_row);
+      if (fuse_union) {
+        const int64_t stride = 4 + (int64_t)h->dp_cap * (1 + c.de) + dp_tail_words(h);
+        const bool ok = kk::union_adam(s, h->dp_all, h->dp_world, h->dp_cap, stride, c.de, h->We, h->s1_We, h->s2_We, h->We_last, (int32_t)t, h->step_tab,
+                                       o->beta1, o->beta2, o->eps, pad_row);
+        if (ok) { h->dp_union_pending = false; h->step_rows_ub = 0; h->rows_view = h->step_rows; h->count_view = h->step_count; h->view_batch = nullptr; }
+        else { fuse_union = false; materialize_union(h); rows = h->rows_view; rcount = h->count_view; }
+      }
+      if (!fuse_union)
+        kk::adam_rows(s, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, rows, rcount, h->step_rows_ub, c.de, (int32_t)t, 1,
+                      h->step_tab, o->beta1, o->beta2, o->eps, pad_row);
       h->lazy_pending = true;
       pad_done = h->pad_clean;  // the pad row is re-zeroed whenever the row update touches it; untouched it stays what it was
     }
@@ -859,6 +904,7 @@ void kprn_destroy(kprn_handle* h) {
   if (h->upload_stream) { hipStreamSynchronize(h->upload_stream); hipStreamDestroy(h->upload_stream); h->upload_stream = nullptr; }
   if (h->feed_stream) { hipStreamSynchronize(h->feed_stream); hipStreamDestroy(h->feed_stream); hipEventDestroy(h->ev_feed_fork); }
   if (h->feed_scratch) { hipFree(h->feed_scratch); h->feed_scratch = nullptr; }
+  dp_release(h);
   dfree(h->S2); dfree(h->sel2);
   fused::release(h);
   bf16p::release(h);
@@ -892,6 +938,7 @@ static int copy_named(kprn_handle* h, const char* name, float* dst, const float*
   if (n == 0) return KPRN_OK;   // (a table that is not part of the model: -includeEntity 0 / -includeEntityTypes 0)
   KPRN_REQUIRE(dst || src, KPRN_E_ARG, "NULL buffer");
   if (p->where == 1 && which == 0) flush_lazy(h);
+  if (which == 1) materialize_union(h);
   float* base;
   if (which == 0) base = (p->where == 1 ? h->We : h->dense);
   else base = (p->where == 1 ? h->g_We : h->g_dense);
@@ -960,6 +1007,7 @@ static int copy_flat(kprn_handle* h, float* dst, const float* src, int64_t n, in
   KPRN_REQUIRE(n == h->n_params, KPRN_E_ARG, "n must equal kprn_num_params");
   KPRN_REQUIRE(dst || src, KPRN_E_ARG, "NULL buffer");
   if (which != 1) flush_lazy(h);
+  else materialize_union(h);
   for (auto& p : h->params) {
     float* base;
     switch (which) {
@@ -1461,6 +1509,54 @@ int kprn_batch_executed_steps(kprn_handle* h, const kprn_batch* b, int64_t* step
   API_END(h)
 }
 
+// ---- a side stream that really runs beside the main stream ---------------------------------------------------------------------
+// HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default; assigned round-robin as streams are made),
+// and two streams that land on the same queue execute IN ORDER.  In a process that also holds torch's and RCCL's streams the scoring
+// pass's stream shared the main stream's queue in about every other run: the pass then ran strictly before the training forward
+// (profiles/r03: 0.41 + 0.41 ms instead of 0.74 ms for the overlapped pair).  So the stream is probed: a kernel on the main stream
+// waits (bounded, 200 us) for a flag that a kernel on the candidate sets; if the flag never arrives the two share a queue and the
+// next candidate is tried (every new stream advances the round-robin).
+__global__ void k_probe_wait(int* flag, int* seen, long long max_ticks) {
+  const long long t0 = wall_clock64();   // (100 MHz)
+  int f = 0;
+  while (!(f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(32);
+  *seen = f;
+}
+__global__ void k_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+static hipStream_t make_concurrent_stream(kprn_handle* h) {
+  const int kTries = 8;
+  hipStream_t cand[kTries] = {};
+  int32_t* d = dalloc<int32_t>(2);   // {flag, seen}
+  hipStream_t pick = nullptr;
+  int made = 0;
+  try {
+    for (int i = 0; i < kTries && !pick; ++i) {
+      HIP_TRY(hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));
+      made = i + 1;
+      HIP_TRY(hipMemsetAsync(d, 0, 2 * sizeof(int32_t), h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, h->stream, d, d + 1, (long long)20000);
+      hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, cand[i], d);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(hipStreamSynchronize(cand[i]));
+      int32_t seen = 0;
+      HIP_TRY(hipMemcpy(&seen, d + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (seen) pick = cand[i];
+    }
+  } catch (...) {
+    for (int i = 0; i < made; ++i) if (cand[i]) hipStreamDestroy(cand[i]);
+    dfree(d);
+    throw;
+  }
+  h->side_stream_probes = made;
+  if (!pick) pick = cand[0];   // (every candidate shares the main stream's queue: correct anyway, just not concurrent)
+  for (int i = 0; i < made; ++i) if (cand[i] && cand[i] != pick) hipStreamDestroy(cand[i]);
+  dfree(d);
+  return pick;
+}
+
 int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id) {
   API_BEGIN(h)
   h->last_forward_side = false;
@@ -1471,7 +1567,7 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
     catch_up(h, b);
     ensure_ws_common(h, N, b->B);
     if (!h->score_stream) {
-      HIP_TRY(hipStreamCreateWithFlags(&h->score_stream, hipStreamNonBlocking));
+      h->score_stream = make_concurrent_stream(h);
       HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&h->ev_score_done, hipEventDisableTiming));
     }
@@ -1675,6 +1771,17 @@ int kprn_sparse_grad_capacity(kprn_handle* h, int32_t* max_rows) {
   API_END(h)
 }
 
+// this step's touched entity rows (+ the dense arena behind them, dp_dense_in_pack) -> dst[words], cleared from the accumulator
+static void pack_into(kprn_handle* h, int32_t capacity, int32_t* dst) {
+  const int de = h->cfg.de;
+  h->pack_cap = capacity;  // the capacity THIS buffer is laid out with (ids at +4, rows at +4+capacity): merge checks against it
+  if (!h->view_batch) { h->rows_view = h->step_rows; h->count_view = h->step_count; }
+  ProfScope ps(h, "dp_pack_rows");   // rows moved out of g_We (zeroed behind) + the dense arena behind them, one launch
+  float* tail = (float*)(dst + 4 + (int64_t)capacity * (1 + de));
+  kk::pack_rows(h->stream, h->g_We, h->rows_view, h->count_view, h->step_rows_ub, de, dst + 4, (float*)(dst + 4 + capacity), dst, h->g_dense,
+                h->dp_dense_in_pack ? h->n_dense : 0, tail);
+}
+
 int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int64_t* n_words) {
   API_BEGIN(h)
   KPRN_REQUIRE(dev_buf && n_words, KPRN_E_ARG, "NULL argument");
@@ -1682,36 +1789,21 @@ int kprn_sparse_grad_pack(kprn_handle* h, int32_t capacity, void** dev_buf, int6
                "data-parallel hooks: the caller's collectives must be ordered with the engine's stream, but kprn_config.stream was NULL (the engine "
                "made its own) and kprn_stream() was never called -- pass a stream (KPRN_STREAM_LEGACY_DEFAULT for the null stream) or fetch the engine's");
   KPRN_REQUIRE(capacity >= h->step_rows_ub && capacity > 0, KPRN_E_ARG, "capacity smaller than this step's touched-row count");
-  const int de = h->cfg.de;
-  const int64_t words = 4 + (int64_t)capacity * (1 + de) + (h->dp_dense_in_pack ? h->n_dense : 0);
+  materialize_union(h);   // (a gathered gradient still pending: make it what the unfused merge would have left before packing again)
+  const int64_t words = 4 + (int64_t)capacity * (1 + h->cfg.de) + dp_tail_words(h);
   if (words > h->pack_words) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     dfree(h->pack_buf);
     h->pack_buf = dalloc<int32_t>(words);
     h->pack_words = words;
   }
-  h->pack_cap = capacity;  // the capacity THIS buffer is laid out with (ids at +4, rows at +4+capacity): merge checks against it
-  if (!h->view_batch) { h->rows_view = h->step_rows; h->count_view = h->step_count; }
-  {
-    ProfScope ps(h, "dp_pack_rows");
-    kk::pack_rows(h->stream, h->g_We, h->rows_view, h->count_view, h->step_rows_ub, de, h->pack_buf + 4, (float*)(h->pack_buf + 4 + capacity),
-                  h->pack_buf);
-    if (h->dp_dense_in_pack)
-      hipLaunchKernelGGL(k_dense_to_pack, dim3((unsigned)std::min<int64_t>((h->n_dense + 255) / 256, 512)), dim3(256), 0, h->stream, h->g_dense, h->n_dense,
-                         (float*)(h->pack_buf + 4 + (int64_t)capacity * (1 + de)));
-    HIP_TRY(hipGetLastError());
-  }
+  pack_into(h, capacity, h->pack_buf);
   *dev_buf = h->pack_buf;
   *n_words = words;
   API_END(h)
 }
 
-int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, int32_t capacity) {
-  API_BEGIN(h)
-  KPRN_REQUIRE(dev_all && world > 0 && capacity > 0, KPRN_E_ARG, "bad argument");
-  KPRN_REQUIRE(h->stream_known, KPRN_E_ARG,
-               "data-parallel hooks: the caller's collectives must be ordered with the engine's stream, but kprn_config.stream was NULL (the engine "
-               "made its own) and kprn_stream() was never called -- pass a stream (KPRN_STREAM_LEGACY_DEFAULT for the null stream) or fetch the engine's");
+static void merge_impl(kprn_handle* h, const void* dev_all, int32_t world, int32_t capacity) {
   KPRN_REQUIRE(capacity == h->pack_cap, KPRN_E_ARG, "capacity differs from the packed buffer's (every rank packs with the same capacity)");
   const int64_t n = (int64_t)world * capacity;
   if (n + 4 > h->step_rows_cap) {
@@ -1720,32 +1812,173 @@ int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, i
     h->step_rows_cap = (n + 4) * 2;
     h->step_rows = dalloc<int32_t>(h->step_rows_cap);
   }
-  {
-    const size_t need = bidx::merge_scratch_bytes(n, h->cfg.Ve);
-    if (need > h->bidx_scratch_bytes) {
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      scratch_reserve(&h->bidx_scratch, &h->bidx_scratch_bytes, need);
-    }
+  // the dense arena: sum of the W copies in rank order, now (the dense update and the norm read g_dense)
+  if (h->dp_dense_in_pack) {
+    ProfScope ps(h, "dp_dense_sum");
+    const int64_t row_words = 4 + (int64_t)capacity * (1 + h->cfg.de);
+    hipLaunchKernelGGL(k_dense_from_all, dim3((unsigned)std::min<int64_t>((h->n_dense + 255) / 256, 512)), dim3(256), 0, h->stream, (const float*)dev_all, (int)world,
+                       row_words + dp_tail_words(h), row_words, h->n_dense, h->g_dense);
+    HIP_TRY(hipGetLastError());
   }
-  if (!h->dp_mark) {
-    h->dp_mark = dalloc<int32_t>(h->cfg.Ve);
-    HIP_TRY(hipMemsetAsync(h->dp_mark, 0, (size_t)h->cfg.Ve * sizeof(int32_t), h->stream));
-  }
-  {
-    ProfScope ps(h, "dp_merge_rows");
-    bidx::merge_rows(h->stream, dev_all, world, capacity, h->cfg.de, h->cfg.Ve, h->g_We, h->step_rows, h->step_count, h->dp_mark, h->bidx_scratch,
-                     h->bidx_scratch_bytes, h->dp_dense_in_pack ? h->n_dense : 0);
-    if (h->dp_dense_in_pack) {
-      const int64_t row_words = 4 + (int64_t)capacity * (1 + h->cfg.de);
-      hipLaunchKernelGGL(k_dense_from_all, dim3((unsigned)std::min<int64_t>((h->n_dense + 255) / 256, 512)), dim3(256), 0, h->stream, (const float*)dev_all, (int)world,
-                         row_words + h->n_dense, row_words, h->n_dense, h->g_dense);
-      HIP_TRY(hipGetLastError());
-    }
-  }
-  // the optimiser now walks the union of all ranks' rows (sorted); exact count on the device, upper bound here
+  // the rows: recorded; the optimiser walks the gathered buffer itself (dp_fused_update: the caller keeps dev_all alive and unchanged until
+  // kprn_apply_update returns) or the union is built here -- the optimiser then walks the union of all ranks' rows (sorted); exact count on the
+  // device, upper bound on the host
+  h->dp_all = dev_all; h->dp_world = world; h->dp_cap = capacity; h->dp_union_pending = true;
   h->view_batch = nullptr; h->rows_view = h->step_rows; h->count_view = h->step_count;
   h->step_rows_ub = std::min<int64_t>(n, h->cfg.Ve);
   h->ent_grads_dirty = true;
+  if (!h->dp_fused_update) materialize_union(h);
+}
+
+int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, int32_t capacity) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(dev_all && world > 0 && capacity > 0, KPRN_E_ARG, "bad argument");
+  KPRN_REQUIRE(h->stream_known, KPRN_E_ARG,
+               "data-parallel hooks: the caller's collectives must be ordered with the engine's stream, but kprn_config.stream was NULL (the engine "
+               "made its own) and kprn_stream() was never called -- pass a stream (KPRN_STREAM_LEGACY_DEFAULT for the null stream) or fetch the engine's");
+  merge_impl(h, dev_all, world, capacity);
+  API_END(h)
+}
+
+// ---- the exchange issued by the engine itself: RCCL on the engine's stream(s) ------------------------------------------------------
+// The hooks above leave the collective to the caller (torch.distributed: its own stream, two cross-stream hand-overs of ~20 us each and
+// ~0.3 ms of Python per step between pack and update).  Here the engine holds a communicator of its own and queues
+// pack -> ncclAllGather (IN PLACE: every rank packs straight into its slot of the gathered buffer) -> dense sum -> optimiser step (the
+// union of the rows inside the row kernel) back to back from one C call.  librccl is dlopen'ed (the copy the host process already
+// uses -- torch ships one -- so the library has no link-time dependency on it); the communicator is bootstrapped by the caller's own
+// control plane: rank 0 draws the 128-byte id (kprn_dp_unique_id), the caller broadcasts it, every rank calls kprn_dp_init.
+namespace {
+struct Id128 { char b[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES), passed BY VALUE to ncclCommInitRank
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::string g_rccl_err;
+bool rccl_load(const char* path) {
+  if (g_rccl.lib) return true;
+  const char* names[] = {path && path[0] ? path : nullptr, "librccl.so", "librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* n : names) {
+    if (!n) continue;
+    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+    const char* e = dlerror();
+    g_rccl_err = e ? e : "dlopen failed";
+  }
+  if (!lib) return false;
+  Rccl r;
+  r.lib = lib;
+  *(void**)&r.GetUniqueId = dlsym(lib, "ncclGetUniqueId");
+  *(void**)&r.CommInitRank = dlsym(lib, "ncclCommInitRank");
+  *(void**)&r.AllGather = dlsym(lib, "ncclAllGather");
+  *(void**)&r.CommDestroy = dlsym(lib, "ncclCommDestroy");
+  *(void**)&r.GetErrorString = dlsym(lib, "ncclGetErrorString");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { g_rccl_err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy"; return false; }
+  g_rccl = r;
+  return true;
+}
+std::string rccl_msg(const char* what, int rc) {
+  return std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?") + " (" + std::to_string(rc) + ")";
+}
+const int kNcclInt32 = 2;   // ncclDataType_t (rccl.h)
+}  // namespace
+
+static void dp_release(kprn_handle* h) {
+  if (h->dp_comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->dp_comm); }
+  h->dp_comm = nullptr;
+  if (h->dp_comm_stream) { hipStreamSynchronize(h->dp_comm_stream); hipStreamDestroy(h->dp_comm_stream); h->dp_comm_stream = nullptr; }
+  if (h->ev_dp_packed) { hipEventDestroy(h->ev_dp_packed); h->ev_dp_packed = nullptr; }
+  if (h->ev_dp_gathered) { hipEventDestroy(h->ev_dp_gathered); h->ev_dp_gathered = nullptr; }
+  dfree(h->dp_gather); h->dp_gather_words = 0;
+}
+
+int kprn_dp_available(const char* rccl_path) {
+  if (!rccl_load(rccl_path)) { g_create_error = "cannot load librccl: " + g_rccl_err; return KPRN_E_DEVICE; }
+  return KPRN_OK;
+}
+
+int kprn_dp_unique_id(const char* rccl_path, void* id128) {
+  if (!id128) return KPRN_E_ARG;
+  if (!rccl_load(rccl_path)) { g_create_error = "kprn_dp_unique_id: cannot load librccl: " + g_rccl_err; return KPRN_E_DEVICE; }
+  const int rc = g_rccl.GetUniqueId(id128);
+  if (rc != 0) { g_create_error = rccl_msg("ncclGetUniqueId", rc); return KPRN_E_DEVICE; }
+  return KPRN_OK;
+}
+
+int kprn_dp_init(kprn_handle* h, const char* rccl_path, const void* id128, int32_t rank, int32_t world) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(id128 && world >= 1 && rank >= 0 && rank < world, KPRN_E_ARG, "bad id / rank / world");
+  KPRN_REQUIRE(!h->dp_comm, KPRN_E_ARG, "kprn_dp_init: this handle already holds a communicator");
+  KPRN_REQUIRE(rccl_load(rccl_path), KPRN_E_DEVICE, "cannot load librccl: " + g_rccl_err);
+  Id128 id;
+  memcpy(id.b, id128, 128);
+  void* comm = nullptr;
+  const int rc = g_rccl.CommInitRank(&comm, world, id, rank);   // (collective: every rank of the job is in this call)
+  KPRN_REQUIRE(rc == 0 && comm, KPRN_E_DEVICE, rccl_msg("ncclCommInitRank", rc));
+  h->dp_comm = comm; h->dp_rank = rank; h->dp_nranks = world;
+  h->dp_dense_in_pack = true;    // one collective per step
+  h->dp_fused_update = true;     // union of the rows inside the row update
+  h->stream_known = true;        // (the collective is queued by the engine: nobody else has to know the stream)
+  API_END(h)
+}
+
+int kprn_dp_shutdown(kprn_handle* h) {
+  API_BEGIN(h)
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  dp_release(h);
+  API_END(h)
+}
+
+int kprn_dp_exchange_begin(kprn_handle* h, int32_t capacity) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(h->dp_comm, KPRN_E_ARG, "kprn_dp_exchange_begin before kprn_dp_init");
+  KPRN_REQUIRE(capacity >= h->step_rows_ub && capacity > 0, KPRN_E_ARG, "capacity smaller than this step's touched-row count");
+  KPRN_REQUIRE((capacity & 3) == 0, KPRN_E_ARG, "capacity must be a multiple of 4 rows (every rank's slot of the gathered buffer stays 16-byte aligned)");
+  materialize_union(h);
+  const int W = h->dp_nranks;
+  const int64_t words = 4 + (int64_t)capacity * (1 + h->cfg.de) + dp_tail_words(h);
+  if (words * W > h->dp_gather_words) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->dp_comm_stream) HIP_TRY(hipStreamSynchronize(h->dp_comm_stream));
+    dfree(h->dp_gather);
+    h->dp_gather = dalloc<int32_t>(words * W);
+    h->dp_gather_words = words * W;
+  }
+  int32_t* mine = h->dp_gather + (int64_t)h->dp_rank * words;
+  pack_into(h, capacity, mine);
+  hipStream_t cs = h->stream;
+  if (h->dp_comm_stream_on && W > 1) {
+    if (!h->dp_comm_stream) {
+      h->dp_comm_stream = make_concurrent_stream(h);
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_dp_packed, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_dp_gathered, hipEventDisableTiming));
+    }
+    cs = h->dp_comm_stream;
+    HIP_TRY(hipEventRecord(h->ev_dp_packed, h->stream));
+    HIP_TRY(hipStreamWaitEvent(cs, h->ev_dp_packed, 0));
+  }
+  if (W > 1) {
+    ProfScope ps(h, "dp_allgather");
+    const int rc = g_rccl.AllGather(mine, h->dp_gather, (size_t)words, kNcclInt32, h->dp_comm, cs);   // in place: sendbuff = recvbuff + rank * count
+    KPRN_REQUIRE(rc == 0, KPRN_E_DEVICE, rccl_msg("ncclAllGather", rc));
+  }
+  if (cs != h->stream) HIP_TRY(hipEventRecord(h->ev_dp_gathered, cs));
+  h->dp_begun = true;
+  API_END(h)
+}
+
+int kprn_dp_exchange_finish(kprn_handle* h, const kprn_opt* opt) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(h->dp_comm && h->dp_begun, KPRN_E_ARG, "kprn_dp_exchange_finish without kprn_dp_exchange_begin");
+  h->dp_begun = false;
+  if (h->dp_comm_stream_on && h->dp_nranks > 1 && h->dp_comm_stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_dp_gathered, 0));
+  merge_impl(h, h->dp_gather, h->dp_nranks, (int32_t)h->pack_cap);
+  apply_update_impl(h, opt);
   API_END(h)
 }
 
@@ -1904,6 +2137,12 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     h->feed_workers = v;
   } else if (strcmp(key, "profile_filter") == 0) {
     h->prof_filter = value;  // "" = every kernel family; else only families whose name starts with this
+  } else if (strcmp(key, "dp_comm_stream") == 0) {
+    // kprn_dp_exchange_begin queues the all-gather on a stream of its own (1) or on the main stream (0, default): with 1, work queued on the
+    // main stream between _begin and _finish (a scoring pass on the side stream forks from there) runs while the collective is in flight
+    h->dp_comm_stream_on = atoi(value) != 0;
+  } else if (strcmp(key, "dp_fused_update") == 0) {
+    h->dp_fused_update = atoi(value) != 0;
   } else if (strcmp(key, "dp_dense_in_pack") == 0) {
     // data-parallel exchange: the dense gradient arena travels behind the packed entity rows (one all-gather, no all-reduce); the merge sums
     // the ranks' copies in rank order

@@ -158,6 +158,17 @@ struct kprn_handle {
   float* loss_partial = nullptr; int64_t loss_partial_cap = 0; int loss_pending = 0;  // >0: d_loss = sum of that many partials, not formed yet
   // packing buffers for the data-parallel exchange
   int32_t* dp_mark = nullptr;   // [Ve] flags of the exchange's union (all zero between steps)
+  // union + update fused (option "dp_fused_update"): kprn_sparse_grad_merge only records the gathered buffer; the update walks it directly
+  // (kk::union_adam) or, where that does not apply (clip / L2, Adagrad, dense entity sweeps, bf16 shadows), materialises the union first
+  bool dp_fused_update = false, dp_union_pending = false;
+  const void* dp_all = nullptr; int dp_world = 0, dp_cap = 0;
+  // the exchange issued by the engine itself (kprn_dp_init / kprn_dp_exchange_begin / _finish): RCCL communicator (ncclComm_t), the
+  // in-place all-gather buffer [world][words], and -- dp_comm_stream -- a stream of its own for the collective so that work queued on
+  // the main stream after _begin (a scoring pass forks from there) does not wait for it
+  void* dp_comm = nullptr; int dp_rank = 0, dp_nranks = 0;
+  int32_t* dp_gather = nullptr; int64_t dp_gather_words = 0;
+  bool dp_comm_stream_on = false, dp_begun = false;
+  hipStream_t dp_comm_stream = nullptr; hipEvent_t ev_dp_packed = nullptr, ev_dp_gathered = nullptr;
   bool dp_dense_in_pack = false; // option: the dense gradient arena rides in the packed buffer (one collective per step)
   int32_t* pack_buf = nullptr; int64_t pack_cap = 0, pack_words = 0;  // {count,-,-,-, ids[cap], rows[cap*de]} 32-bit words; cap of the last pack, allocated words
 
@@ -188,6 +199,7 @@ struct kprn_handle {
   int prefix_plan = 1;            // kprn_set_option "prefix_plan": build identical-prefix plans for new batches (fused path)
   int score_overlap = 0;
   hipStream_t score_stream = nullptr;
+  int side_stream_probes = 0;     // candidates tried before one ran beside the main stream (kprn_api.hip make_concurrent_stream)
   hipEvent_t ev_fork = nullptr, ev_score_done = nullptr;
   bool score_pending = false;     // a pass is (possibly) still running on score_stream
   bool last_forward_side = false; // kprn_read_probs reads the side buffers
@@ -259,7 +271,10 @@ void adam_rows(hipStream_t s, float* W, float* g, float* m, float* v, int32_t* l
 void adam_flush_all(hipStream_t s, float* W, float* m, float* v, int32_t* last, int64_t V, int d, int32_t t_now, const float* step_tab, float b1, float b2, float eps, int64_t pad_row);
 void adagrad_rows(hipStream_t s, float* W, float* g, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, float clr, int64_t pad_row);
 void zero_rows(hipStream_t s, float* W, int64_t row, int d);
-void pack_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, int32_t* ids_out, float* rows_out, int32_t* count_out);
+void pack_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, int32_t* ids_out, float* rows_out, int32_t* count_out,
+               const float* tail_src = nullptr, int64_t n_tail = 0, float* tail_dst = nullptr);
+bool union_adam(hipStream_t s, const void* all, int world, int cap, int64_t stride, int d, float* W, float* m, float* v, int32_t* last, int32_t t_now,
+                const float* step_tab, float b1, float b2, float eps, int64_t pad_row);
 void fill_uniform(hipStream_t s, float* x, int64_t n, float a, uint64_t seed, uint64_t offset);
 void fill_i32(hipStream_t s, int32_t* x, int64_t n, int32_t v);
 void clear_rows(hipStream_t s, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d);

@@ -10,16 +10,19 @@ independent units: model/module/MapReduce.lua:24-47 never mixes them).  Per step
   2. dense gradients (type/relation tables, LSTM, head: ONE contiguous device buffer, ~0.3 MB
      for D=H=64,L=2) ride behind the rows of 3. (adapter.dense_in_pack, the default) and are summed
      in rank order by the merge; or (dense_in_pack=False) one all-reduce(sum);
-  3. entity-table gradients are row-sparse -> each rank packs {count, row ids, grad rows} of the rows it
-     touched into ONE fixed-capacity buffer, ONE all-gather, then every rank merges all ranks' rows:
-     union of the ids by a stable sort, sums in rank order (identical addition order everywhere =>
-     replicas stay bit-identical);
+  3. entity-table gradients are row-sparse -> each rank packs {count, row ids (ascending), grad rows} of the
+     rows it touched into ONE fixed-capacity buffer, ONE all-gather, then every rank forms the union of all
+     ranks' rows with sums in rank order (identical addition order everywhere => replicas stay
+     bit-identical): inside the optimiser's row kernel (adapter.fused_update, the default: the entry of the
+     lowest rank that touched a row owns it and looks the other ranks' lists up by binary search) or as a
+     separate merge pass;
   4. the optimiser step runs locally on the summed gradient (MyOptimizer.lua:196-219).
 
 The collective calls only see an "adapter" that exposes the engine's buffers as torch tensors,
 so the same code is exercised on CPU (gloo, world_size 2) with a numpy-backed adapter.
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -33,6 +36,10 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 3, "strides": None}
 
 
+def _round4(n):
+    return (int(n) + 3) // 4 * 4
+
+
 def wrap_device(ptr, n, kind, device):
     typestr = {"f32": "<f4", "i32": "<i4"}[kind]
     return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
@@ -41,7 +48,7 @@ def wrap_device(ptr, n, kind, device):
 class GpuAdapter:
     """Exposes one kprn Engine's gradient buffers as CUDA tensors (zero-copy)."""
 
-    def __init__(self, engine, device, dense_in_pack=True):
+    def __init__(self, engine, device, dense_in_pack=True, fused_update=True):
         self.e = engine
         self.device = torch.device(device)
         sh = engine.stream()   # (first: the engine hands out its exchange buffers only to a caller that knows which stream it queues on)
@@ -60,6 +67,57 @@ class GpuAdapter:
         # are bit-identical on every replica by construction
         self.dense_in_pack = bool(dense_in_pack)
         engine.set_option("dp_dense_in_pack", "1" if self.dense_in_pack else "0")
+        # union + optimiser step in one launch: the merge only records the gathered buffer, the lazy-exact Adam row update walks it in place
+        # (kprn_api.hip dp_fused_update; DataParallel keeps that buffer alive and untouched until the update has been queued)
+        self.fused_update = bool(fused_update)
+        engine.set_option("dp_fused_update", "1" if self.fused_update else "0")
+
+    # ---- the exchange issued by the engine itself (kprn_dp_*, include/kprn.h): RCCL on the engine's stream ----
+    def native_setup(self, group, rank, world):
+        """Bootstraps the engine's own RCCL communicator over the torch process group (which only carries the 128-byte id) -> True, or
+        False when every rank agrees it cannot be had (then the collectives stay with torch.distributed).  Collective."""
+        from . import _ffi
+        if dist.get_backend(group) != "nccl":
+            return False
+        path = _ffi.torch_rccl_path()
+        idb, ok = bytes(128), 1
+        try:
+            if rank == 0:
+                idb = _ffi.dp_unique_id(path)
+            elif not _ffi.dp_available(path):
+                ok = 0
+        except Exception:
+            ok = 0
+        with torch.cuda.stream(self.stream):
+            t = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            if int(t.item()) == 0:
+                return False
+            idt = torch.tensor(list(idb), dtype=torch.uint8, device=self.device)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast(idt, src=src, group=group)
+            idb = bytes(idt.cpu().tolist())
+            try:
+                self.e.dp_init(idb, rank, world, path)   # ncclCommInitRank: every rank is in here
+            except Exception:
+                ok = 0
+            t = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            if int(t.item()) == 0:
+                if ok:
+                    self.e.dp_shutdown()
+                self.e.set_option("dp_dense_in_pack", "1" if self.dense_in_pack else "0")
+                self.e.set_option("dp_fused_update", "1" if self.fused_update else "0")
+                return False
+        self.dense_in_pack = True
+        self.fused_update = True
+        return True
+
+    def exchange_begin(self, capacity):
+        self.e.dp_exchange_begin(capacity)
+
+    def exchange_finish(self, opt):
+        self.e.dp_exchange_finish(opt)
 
     def backward(self, batch, class_id, bce_literal, inv_batch):
         self.e.backward(batch, class_id, bce_literal, inv_batch, want_loss=False)
@@ -118,6 +176,11 @@ class DataParallel:
         self._all = None
         self.timing = False   # bench.py: events around the parts of the exchange (GPU adapter only)
         self._ev = []
+        # The engine's own exchange (one RCCL all-gather in place on the engine's stream, queued from C between pack and update) when the
+        # adapter can set it up -- GPU adapter over the "nccl" backend; KPRN_DP_NATIVE=0 keeps the collectives with torch.distributed
+        self.native = False
+        if self.collectives and hasattr(adapter, "native_setup") and os.environ.get("KPRN_DP_NATIVE", "1") != "0":
+            self.native = bool(adapter.native_setup(group, self.rank, self.world))
 
     def _ctx(self):
         """torch's current stream := the adapter's stream (GPU adapter), for the duration of the exchange's torch calls"""
@@ -136,7 +199,7 @@ class DataParallel:
             t = self._dev(torch.tensor([int(local_max_rows)], dtype=torch.int64))
             if self.collectives:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            self.capacity = max(1, int(t.item()))
+            self.capacity = _round4(max(1, int(t.item())))   # (multiple of 4 rows: every rank's slice of the gathered buffer stays 16-byte aligned)
         self.bounded = bool(bound)
         self._all = None
         return self.capacity
@@ -199,12 +262,22 @@ class DataParallel:
             if need is None:
                 need, _ = self._agree(a.local_rows(), batch.B)
             if need > self.capacity:
-                self.capacity = int(need * 1.25) + 16   # the same number on every rank
+                self.capacity = _round4(int(need * 1.25) + 16)   # the same number on every rank
                 self._all = None
         elif a.local_rows() > self.capacity:
             raise RuntimeError(f"rank {self.rank}: this step touches {a.local_rows()} entity rows, more than the capacity "
                                f"{self.capacity} promised to set_capacity(bound=True)")
         cap = self.capacity
+        if self.native:
+            a.exchange_begin(cap)   # pack into this rank's slot of the gathered buffer + the all-gather, in place
+            self._mark()            # ("pack" = pack + the collective's launch)
+            if overlap is not None:
+                overlap()
+            self._mark()
+            self._mark()            # (no separate merge)
+            a.exchange_finish(opt)  # dense sum + optimiser step with the union of the rows inside the row kernel
+            self._mark()
+            return
         buf = a.pack(cap)  # one packed tensor per rank, same length everywhere
         if self._all is None or self._all.numel() != buf.numel() * self.world or self._all.dtype != buf.dtype:
             self._all = torch.empty(buf.numel() * self.world, dtype=buf.dtype, device=buf.device)

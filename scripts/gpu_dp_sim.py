@@ -4,7 +4,7 @@ the real N-GPU bench).  Every simulated rank is a batch of its own: backward + p
 device copy stands in for the all-gather's arrival), then merge + optimiser step run on the full buffer.  pack / merge / update are timed
 by the engine's HIP events (kernel families dp_pack_rows, dp_merge_rows, adam_*), the gather stand-in by torch events; the real
 all-gather's time is bounded from the payload: every rank receives (W - 1) packed buffers over its xGMI links.
-  python scripts/gpu_dp_sim.py > profiles/r02/dp_exchange_sim.json"""
+  FUSED=1 python scripts/gpu_dp_sim.py > profiles/r03/dp_exchange_sim_fused.json   (FUSED=0: the separate merge)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,10 +23,12 @@ batches = []
 for r in range(WMAX):
     idx, labels = synth.make_paths(paths // 2, 2, 6, Ve=Ve, seed=1000 + 7919 * r)
     batches.append(eng.batch(idx, labels))
-cap = max(b.n_uniq for b in batches)
+cap = (max(b.n_uniq for b in batches) + 3) // 4 * 4
+FUSED = os.environ.get("FUSED", "1")   # union inside the row update (dp_fused_update) or the separate marking merge
+eng.set_option("dp_fused_update", FUSED)
 eng.stream()   # (the exchange hooks want a caller that knows the engine's stream)
 words = 4 + cap * 33
-out = {"paths_per_rank_per_step": paths, "rows_per_rank": [b.n_uniq for b in batches], "capacity_rows": cap,
+out = {"dp_fused_update": int(FUSED), "paths_per_rank_per_step": paths, "rows_per_rank": [b.n_uniq for b in batches], "capacity_rows": cap,
        "packed_MB_per_rank": round(words * 4 / 1e6, 2), "worlds": {}}
 XGMI_GBS = 153.0   # per link, MI355X_MICROARCH.md; a rank receives from each peer over its own link
 for W in (1, 2, 4, 8):

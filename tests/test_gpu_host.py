@@ -272,17 +272,45 @@ def test_data_parallel_step_at_world_one_equals_the_plain_step(tmp_path):
         a.zero_pad_tokens(); b.zero_pad_tokens()   # (trainBatch zeroes the pad rows first: the scoring passes below come before / after it)
         opt = _ffi.make_opt(method=1, lr=1e-2)
         x = dp.DataParallel(dp.GpuAdapter(a, "cuda:0"))
+        assert x.native   # the engine's own exchange: communicator bootstrapped over the process group, in-place all-gather on the engine's stream
+        # ... and the same step with the collectives left to torch.distributed (the pack / merge hooks)
+        t = _ffi.Engine(*shape, seed=4, stream=stream)
+        t.zero_pad_tokens()
+        os.environ["KPRN_DP_NATIVE"] = "0"
+        try:
+            xt = dp.DataParallel(dp.GpuAdapter(t, "cuda:0"))
+        finally:
+            del os.environ["KPRN_DP_NATIVE"]
+        assert not xt.native
         data = [synth.make_paths(200 + 37 * i, 1 + i % 3, 6, Ve=500, seed=60 + i) for i in range(5)]
-        x.set_capacity(max(len(np.unique(i[..., 1])) for i, _ in data) + 8)
-        for idx, lab in data:
-            ba, bb = a.batch(idx, lab), b.batch(idx, lab)
-            x.train_step(ba, opt, 1, overlap=lambda: a.forward_async(ba, 1))
+        for d_ in (x, xt):
+            d_.set_capacity(max(len(np.unique(i[..., 1])) for i, _ in data) + 8)
+        assert x.capacity % 4 == 0
+        for k, (idx, lab) in enumerate(data):
+            ba, bb, bt = a.batch(idx, lab), b.batch(idx, lab), t.batch(idx, lab)
+            if k % 2:   # the scoring pass queued first (beside the training forward) ...
+                a.forward_async(ba, 1)
+                x.train_step(ba, opt, 1)
+            else:       # ... or between the exchange's two halves
+                x.train_step(ba, opt, 1, overlap=lambda: a.forward_async(ba, 1))
             pa = a.read_probs(ba.B)
+            xt.train_step(bt, opt, 1, overlap=lambda: t.forward_async(bt, 1))
+            pt = t.read_probs(bt.B)
             pb = b.forward(bb, 1)["probs"]
             b.train_step(bb, opt)
             np.testing.assert_allclose(pa, pb, rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(pt, pb, rtol=1e-5, atol=1e-7)
             assert abs(a.read_loss() - b.read_loss()) < 1e-6 * max(1.0, abs(b.read_loss()))
         assert np.max(np.abs(a.get_flat_params() - b.get_flat_params())) < 2e-6
+        assert np.max(np.abs(t.get_flat_params() - b.get_flat_params())) < 2e-6
+        # the collective on a stream of its own (what a world > 1 run with the pass under the all-gather uses; at world 1 it degenerates)
+        a.set_option("dp_comm_stream", "1")
+        idx, lab = data[0]
+        ba, bb = a.batch(idx, lab), b.batch(idx, lab)
+        x.train_step(ba, opt, 1, overlap=lambda: a.forward_async(ba, 1))
+        b.train_step(bb, opt)
+        assert np.max(np.abs(a.get_flat_params() - b.get_flat_params())) < 2e-6
+        t.close()
         # the training loop with a DataParallel object: shuffled files, streamed minibatches
         root = str(tmp_path)
         _write_dataset(root, ".npz")

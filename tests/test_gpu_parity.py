@@ -312,6 +312,129 @@ def test_two_replicas_exchange_equals_one_big_batch(impl):
     assert float(np.max(np.abs(a - b))) < 2e-5
 
 
+def _exchange_steps(world, steps, de=32, dense_in_pack=True, **mkkw):
+    """Two groups of `world` replicas on ONE GPU -- group A updates with the union inside the row kernel (dp_fused_update), group B with the
+    separate marking merge -- in lockstep: every replica runs its own backward on its slice of the pairs (two alternating sets of
+    slices, so rows skip steps and the lazy replay runs) and packs; BOTH groups then merge the buffer gathered from group A (a backward is
+    reproducible only to rounding -- fp32 atomics in the weight-gradient reduce -- so the comparison hands both paths the same bits)."""
+    import torch
+    from kprn_amd import dp
+    per = 6
+    sets = [synth.make_paths(per * world, 3, 6, Ve=300, seed=21 + k) for k in range(2)]
+    opt = _ffi.make_opt(method=1, lr=1e-2)
+    groups = []
+    for fused in (True, False):
+        reps = [mk(de=de, **mkkw)[0] for _ in range(world)]
+        for e in reps:
+            e.stream()
+            e.set_option("dp_dense_in_pack", "1" if dense_in_pack else "0")
+            e.set_option("dp_fused_update", "1" if fused else "0")
+        batches = [[reps[r].batch(idx[r * per:(r + 1) * per], lab[r * per:(r + 1) * per]) for r in range(world)] for idx, lab in sets]
+        groups.append((reps, batches))
+    dev = "cuda:0"
+    for step in range(steps):
+        which = 0 if step % 3 != 1 else 1
+        cap = 0
+        for reps, batches in groups:
+            for r in range(world):
+                reps[r].zero_pad_tokens()
+                reps[r].backward(batches[which][r], 1, False, 1.0 / (per * world), want_loss=False)
+                cap = max(cap, reps[r].sparse_grad_capacity())
+        cap = (cap + 3) // 4 * 4
+        if not dense_in_pack:   # the dense all-reduce by hand: group A's sum, handed to everybody
+            dens = []
+            for reps, _ in groups:
+                for r in range(world):
+                    reps[r].sync()
+                    ptr, n = reps[r].dense_grad_buffer()
+                    dens.append(dp.wrap_device(ptr, n, "f32", dev))
+            tot = dens[0].clone()
+            for r in range(1, world):
+                tot += dens[r]
+            for d in dens:
+                d.copy_(tot)
+            torch.cuda.synchronize()
+        gathered = None
+        for reps, _ in groups:
+            packed = []
+            for r in range(world):
+                ptr, n_words = reps[r].sparse_grad_pack(cap)
+                reps[r].sync()
+                packed.append(dp.wrap_device(ptr, n_words, "i32", dev).clone())
+            torch.cuda.synchronize()
+            if gathered is None:
+                gathered = torch.cat(packed)   # what the all-gather delivers; alive until every update has run (the fused update reads it)
+        torch.cuda.synchronize()
+        for reps, _ in groups:
+            for r in range(world):
+                reps[r].sparse_grad_merge(gathered.data_ptr(), world, cap)
+                reps[r].apply_update(opt)
+                reps[r].sync()
+    return [[e.get_flat_params() for e in reps] for reps, _ in groups]
+
+
+@pytest.mark.parametrize("world,de,kw", [(2, 32, dict(L=2)), (3, 32, dict(L=2)), (8, 32, dict(L=2, impl="generic")),
+                                         (3, 64, dict(dt=16, dr=16, H=64, L=1)), (5, 32, dict(L=2, dense_in_pack=False))])
+def test_union_inside_the_row_update_equals_the_separate_merge_bitwise(world, de, kw):
+    """kprn_set_option("dp_fused_update"): the lowest rank's entry owns a row, finds the other ranks' contributions by binary search in their
+    ascending id lists and adds them in rank order -- the same additions in the same order as the marking merge + row update, so the
+    parameters (entity rows, Adam state through the lazy replay, dense arena) must agree BIT FOR BIT, on every replica."""
+    kw = dict(kw)
+    dip = kw.pop("dense_in_pack", True)
+    a, b = _exchange_steps(world, 5, de=de, dense_in_pack=dip, **kw)
+    for r in range(world):
+        assert np.array_equal(a[r], a[0]) and np.array_equal(b[r], b[0])     # replicas identical
+    assert np.array_equal(a[0], b[0])          # fused == separate merge
+    assert np.all(np.isfinite(a[0]))
+    theta0 = mk(de=de, **kw)[2].astype(np.float32)
+    assert float(np.max(np.abs(a[0] - theta0))) > 1e-3   # (and they trained)
+
+
+def test_a_gathered_gradient_can_still_be_read_or_dropped_before_the_update():
+    """the fused path only RECORDS the union; a caller that reads the gradient (kprn_get_grad) or starts another step instead of updating
+    must see what the separate merge would have left"""
+    import torch
+    from kprn_amd import dp
+    outs = []
+    for fused in (True, False):
+        eng = mk(L=2)[0]
+        eng.stream()
+        eng.set_option("dp_dense_in_pack", "1")
+        eng.set_option("dp_fused_update", "1" if fused else "0")
+        idx, lab = synth.make_paths(12, 3, 6, Ve=300, seed=31)
+        b = eng.batch(idx, lab)
+        eng.backward(b, 1, False, 1.0 / 24.0, want_loss=False)
+        cap = (eng.sparse_grad_capacity() + 3) // 4 * 4
+        ptr, n_words = eng.sparse_grad_pack(cap)
+        eng.sync()
+        one = dp.wrap_device(ptr, n_words, "i32", "cuda:0").clone()
+        allbuf = torch.cat([one, one])    # "two ranks" with the same rows: the union doubles every gradient
+        torch.cuda.synchronize()
+        eng.sparse_grad_merge(allbuf.data_ptr(), 2, cap)
+        g = eng.get_flat_grads()
+        # dropped: the next backward starts from clean accumulators
+        eng.backward(b, 1, False, 1.0 / 24.0, want_loss=False)
+        g2 = eng.get_flat_grads()
+        # gathered again and dropped WITHOUT anybody reading it
+        ptr, n_words = eng.sparse_grad_pack(cap)
+        eng.sync()
+        one = dp.wrap_device(ptr, n_words, "i32", "cuda:0").clone()
+        allbuf = torch.cat([one, one])
+        torch.cuda.synchronize()
+        eng.sparse_grad_merge(allbuf.data_ptr(), 2, cap)
+        eng.backward(b, 1, False, 1.0 / 24.0, want_loss=False)
+        g3 = eng.get_flat_grads()
+        outs.append((g, g2, g3))
+    # (a backward is reproducible to rounding only -- fp32 atomics in the weight-gradient reduce -- hence tolerances, not bits)
+    close = lambda x, y: np.allclose(x, y, rtol=1e-4, atol=1e-9)
+    assert close(outs[0][0], outs[1][0]) and close(outs[0][1], outs[1][1])
+    assert close(outs[0][2], outs[0][1]) and close(outs[1][2], outs[1][1])
+    for g, g2, _ in outs:
+        ent = slice(6 * 16, 6 * 16 + 300 * 32)   # entity rows: doubled by the two-rank union; (the dense arena too, dp_dense_in_pack)
+        assert np.any(g2[ent] != 0) and close(g[ent], 2.0 * g2[ent])
+        assert close(g, 2.0 * g2)
+
+
 def test_large_batch_properties():
     """BASELINE-size shapes (T=6, D=H=64, L=2, KKBox-size entity table), checked through
     size-independent properties: (1) scoring a pair does not depend on which other pairs share
