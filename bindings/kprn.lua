@@ -56,6 +56,13 @@ int kprn_read_loss(kprn_handle*, float*);
 int kprn_read_loss_sum(kprn_handle*, float*, int32_t*, int32_t);
 int kprn_set_option(kprn_handle*, const char*, const char*);
 int kprn_sync(kprn_handle*);
+int kprn_backward_batch(kprn_handle*, const kprn_batch*, int32_t, int32_t, float, float*);
+int kprn_sparse_grad_capacity(kprn_handle*, int32_t*);
+int kprn_dp_unique_id(const char*, void*);
+int kprn_dp_init(kprn_handle*, const char*, const void*, int32_t, int32_t);
+int kprn_dp_exchange_begin(kprn_handle*, int32_t);
+int kprn_dp_exchange_finish(kprn_handle*, const kprn_opt*);
+int kprn_dp_shutdown(kprn_handle*);
 ]]
 
 local C = ffi.load('kprn')
@@ -166,6 +173,26 @@ function Net:lossSum(reset)  -- -> totalError, steps since the last reset (MyOpt
   local s, n = ffi.new('float[1]'), ffi.new('int32_t[1]')
   check(self.h, C.kprn_read_loss_sum(self.h, s, n, reset and 1 or 0))
   return s[0], n[0]
+end
+
+-- ---- one process per GPU (the reference is single-device; include/kprn.h "the exchange issued by the engine") ---------------
+-- The Lua program only carries 128 bytes: rank 0 draws the id, whatever control plane the job has (a file, a socket, MPI) hands
+-- it to every rank, and every rank joins.  After that a data-parallel trainBatch is three calls; the engine queues pack ->
+-- in-place RCCL all-gather -> optimiser step on the union of all ranks' rows on its own stream.
+function M.dpUniqueId(rcclPath)
+  local id = ffi.new('char[128]')
+  local rc = C.kprn_dp_unique_id(rcclPath, id)
+  if rc ~= 0 then error(('kprn error %d: %s'):format(rc, ffi.string(C.kprn_last_error(nil)))) end
+  return ffi.string(id, 128)
+end
+function Net:dpInit(id, rank, world, rcclPath) check(self.h, C.kprn_dp_init(self.h, rcclPath, id, rank, world)) end
+-- slot: THIS rank's pairs of the global minibatch; globalPairs: pairs of all ranks (the BCE mean is over the global minibatch);
+-- capacity: the same multiple of 4 on every rank, >= the entity rows any rank touches in a step (minibatch * P * T is a bound)
+function Net:trainBatchSlotDP(slot, classId, optConfig, optInfo, globalPairs, capacity)
+  check(self.h, C.kprn_zero_pad_tokens(self.h))                                                     -- MyOptimizer.lua:181
+  check(self.h, C.kprn_backward_batch(self.h, slot[0], classId or 1, 0, 1.0 / globalPairs, nil))   -- MyOptimizer.lua:186-195
+  check(self.h, C.kprn_dp_exchange_begin(self.h, capacity))
+  check(self.h, C.kprn_dp_exchange_finish(self.h, fill_opt(optConfig, optInfo)))                    -- MyOptimizer.lua:196-219
 end
 
 function Net:zeroPadTokens() check(self.h, C.kprn_zero_pad_tokens(self.h)) end
