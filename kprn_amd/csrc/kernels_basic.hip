@@ -75,6 +75,48 @@ __global__ void k_embed(const int32_t* __restrict__ idx, int64_t N, int T, int F
   for (int q = 0; q < VEC; ++q) dst[q] = out[q];
 }
 
+// The same, one wave per (n, t) row: no 64-bit divisions per element (they were most of k_embed's time at D = 200), VEC-wide accesses
+// for any dims divisible by VEC (the shipped config's 50 / 100 / 50 take VEC = 2), and -- mask != nullptr -- MaskZero's row mask
+// (the row is not all zeros, k_row_nonzero) written by the same pass instead of a second sweep over X.
+template <int VEC>
+__global__ void k_embed_rows(const int32_t* __restrict__ idx, int64_t NT, int64_t N, int T, int F, int nT, const float* __restrict__ Wt,
+                             const float* __restrict__ We, const float* __restrict__ Wr, int dt, int de, int dr, float* __restrict__ X,
+                             int time_major, float* __restrict__ mask) {
+  typedef float vf __attribute__((ext_vector_type(VEC)));
+  const int lane = threadIdx.x & 63;
+  const int64_t nt = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // = n*T + t (input order)
+  if (nt >= NT) return;
+  const int64_t n = nt / T;
+  const int t = (int)(nt - n * T);
+  const int32_t* f = idx + nt * F;
+  const int64_t orow = time_major ? (int64_t)t * N + n : nt;
+  float* dst = X + orow * (dt + de + dr);
+  const float* we = We + (int64_t)(f[F - 2] - 1) * de;
+  const float* wr = Wr + (int64_t)(f[F - 1] - 1) * dr;
+  const float* wt0 = Wt + (int64_t)(f[F - nT - 2] - 1) * dt;
+  const int DV = (dt + de + dr) / VEC;
+  int nz = 0;
+  for (int jv = lane; jv < DV; jv += 64) {
+    const int j = jv * VEC;
+    vf v;
+    if (j < dt) {
+      v = *(const vf*)(wt0 + j);
+      for (int k = 1; k < nT; ++k) v = v + *(const vf*)(Wt + (int64_t)(f[F - nT - 2 + k] - 1) * dt + j);
+    } else if (j < dt + de) {
+      v = *(const vf*)(we + (j - dt));
+    } else {
+      v = *(const vf*)(wr + (j - dt - de));
+    }
+    *(vf*)(dst + j) = v;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) nz |= (v[q] != 0.f) ? 1 : 0;
+  }
+  if (mask) {
+    nz = __any(nz);
+    if (lane == 0) mask[orow] = nz ? 1.f : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // nn.FastLSTM gate math (Element-Research rnn): chunks [i, g, f, o]
 __global__ void k_gates_fwd(float* __restrict__ act, const float* __restrict__ c_prev, float* __restrict__ c, float* __restrict__ h,
@@ -132,8 +174,18 @@ __global__ void k_colsum(const float* __restrict__ A, int64_t rows, int cols, in
   int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float acc = 0.f;
-  if (c < cols)
-    for (int64_t r = r0 + sub; r < r1; r += 4) acc += A[r * ld + c];
+  if (c < cols) {
+    // eight rows in flight per lane (one 4-byte load each: the dependent add chain of a rolled loop left the kernel at 1.3 TB/s)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    int64_t r = r0 + sub;
+    const float* p = A + r * ld + c;
+    const int64_t st = 4 * ld;
+    for (; r + 28 < r1; r += 32, p += 8 * st) {
+      a0 += p[0]; a1 += p[st]; a2 += p[2 * st]; a3 += p[3 * st]; a4 += p[4 * st]; a5 += p[5 * st]; a6 += p[6 * st]; a7 += p[7 * st];
+    }
+    for (; r < r1; r += 4, p += st) a0 += *p;
+    acc = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  }
   __shared__ float red[4][64];
   red[sub][threadIdx.x & 63] = acc;
   __syncthreads();
@@ -822,16 +874,18 @@ void validate_indices(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, 
 
 
 void embed_gather(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* Wt, const float* We, const float* Wr,
-                  int dt, int de, int dr, float* X, bool time_major) {
+                  int dt, int de, int dr, float* X, bool time_major, float* mask) {
   if (N <= 0) return;
-  const int D = dt + de + dr;
-  if ((dt % 4 == 0) && (de % 4 == 0) && (dr % 4 == 0)) {
-    int64_t total = N * T * (D / 4);
-    hipLaunchKernelGGL((k_embed<4>), dim3(nblocks(total)), dim3(TPB), 0, s, idx, N, T, F, nT, Wt, We, Wr, dt, de, dr, X, time_major ? 1 : 0);
-  } else {
-    int64_t total = N * T * D;
-    hipLaunchKernelGGL((k_embed<1>), dim3(nblocks(total)), dim3(TPB), 0, s, idx, N, T, F, nT, Wt, We, Wr, dt, de, dr, X, time_major ? 1 : 0);
-  }
+  const int64_t NT = N * T;
+  const unsigned blocks = nblocks(NT * 64);
+  const int all = dt | de | dr;
+  const uintptr_t pall = (uintptr_t)Wt | (uintptr_t)We | (uintptr_t)Wr | (uintptr_t)X;
+  if ((all % 4 == 0) && !(pall & 15))
+    hipLaunchKernelGGL((k_embed_rows<4>), dim3(blocks), dim3(TPB), 0, s, idx, NT, N, T, F, nT, Wt, We, Wr, dt, de, dr, X, time_major ? 1 : 0, mask);
+  else if ((all % 2 == 0) && !(pall & 7))
+    hipLaunchKernelGGL((k_embed_rows<2>), dim3(blocks), dim3(TPB), 0, s, idx, NT, N, T, F, nT, Wt, We, Wr, dt, de, dr, X, time_major ? 1 : 0, mask);
+  else
+    hipLaunchKernelGGL((k_embed_rows<1>), dim3(blocks), dim3(TPB), 0, s, idx, NT, N, T, F, nT, Wt, We, Wr, dt, de, dr, X, time_major ? 1 : 0, mask);
   CHECK_LAUNCH();
 }
 

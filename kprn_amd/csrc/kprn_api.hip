@@ -283,7 +283,9 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b, bool save) {
   hipStream_t s = h->stream;
   {
     ProfScope ps(h, "embed_gather");
-    kk::embed_gather(s, b->idx, N, T, b->F, c.num_types, h->dense + h->off_Wt, h->We, h->dense + h->off_Wr, c.dt, c.de, c.dr, w.X, true);
+    // (rnnType rnn: MaskZero's mask of the bottom layer's input rows comes out of the same pass)
+    kk::embed_gather(s, b->idx, N, T, b->F, c.num_types, h->dense + h->off_Wt, h->We, h->dense + h->off_Wr, c.dt, c.de, c.dr, w.X, true,
+                     c.rnn_type == 1 ? w.mask : nullptr);
   }
   if (c.rnn_type == 2) {
     // nn.Sequencer(nn.GRU(D, H)) x L (OneModel.lua:237-238,268-273); step record a[n][4H] = [r | z | n | r*h']
@@ -331,7 +333,7 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b, bool save) {
         ProfScope ps(h, "gemm_i2g_fwd");
         gemm::run(s, in, Din, 1, h->dense + h->layer[l].Wi, 1, Din, pre, H, (int64_t)T * N, H, Din, false, h->dense + h->layer[l].bi, 1, bf);
       }
-      {
+      if (l > 0) {
         ProfScope ps(h, "rnn_mask");
         kk::row_nonzero(s, in, (int64_t)T * N, Din, mask);  // layer l > 1: the mask follows the ACTUAL input rows (h^{l-1}_t), as MaskZero does
       }

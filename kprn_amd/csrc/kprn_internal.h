@@ -230,7 +230,7 @@ void join_score(kprn_handle* h);  // main stream waits for the scoring pass on t
 namespace kk {
 void validate_indices(hipStream_t s, const int32_t* idx, int64_t nsteps, int F, int nT, int Vt, int Ve, int Vr, int32_t* flag);
 void embed_gather(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* Wt, const float* We,
-                  const float* Wr, int dt, int de, int dr, float* X, bool time_major);
+                  const float* Wr, int dt, int de, int dr, float* X, bool time_major, float* mask = nullptr /* MaskZero's row mask of X, same pass */);
 void lstm_gates_fwd(hipStream_t s, float* act /*[N][4H] in: pre-act, out: gates*/, const float* c_prev, float* c, float* h, int64_t N, int H);
 void lstm_gates_bwd(hipStream_t s, const float* act, const float* c, const float* c_prev, const float* dH_up /*nullable*/,
                     float* dH, float* dC, float* dA, int64_t N, int H);
