@@ -229,8 +229,10 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4, NT=None):
         return "mfma", tbl[name]
     if name == "embed_gather":
         return "hbm", N * T * ((nT * dt + de + dr) * 4 + F * 4)
-    if name == "embed_scatter":
-        return "hbm", N * T * (D * 4 + F * 4)
+    if name == "embed_scatter":   # the type / relation tables' gradients
+        return "hbm", N * T * ((dt + dr) * 4 + F * 4)
+    if name == "entity_grad":
+        return "hbm", N * T * (de * 4 + 8)
     return None
 
 

@@ -1049,19 +1049,108 @@ __global__ __launch_bounds__(256) void k_small_table_grad(const int32_t* __restr
   }
 }
 
+// nn.LookupTable backward for a table that fits LDS (V * dcols floats <= 64 KB: the type / relation tables of every config, up to the 100
+// relations x 128 of configs[3]) from time-major dX [T][N][D].  A WAVE owns a position: its lanes are the slice's columns, so the LDS adds of
+// one instruction never collide, the id is wave-uniform, the row's slice is read with coalesced loads (eight positions in flight), and the
+// only 64-bit division is one per workgroup (positions of a block are consecutive: (t, n) is carried along).  One flush of non-zero
+// accumulators per workgroup.  Used for tables of more than 16 rows (configs[3]'s 100 relations) instead of the element-indexed
+// k_embed_scatter (four 64-bit divisions per ELEMENT); tiny tables keep the 16-register one-hot kernel, which is faster (no LDS atomics).
+// Knock-outs on configs[3] (KPRN_TABLE_GRAD_DBG): reads alone 0.11 ms, + id loads 0.21, + LDS adds 0.55: ds_add_f32 is the cost.
+__global__ __launch_bounds__(256) void k_table_grad_lds(const int32_t* __restrict__ idx, int64_t N, int T, int F, int idcol, int slots,
+                                                         const float* __restrict__ dX, int D, int col0, int dcols, int V, float* __restrict__ gW,
+                                                         int pos_per_block, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < V * dcols; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const int64_t total = N * T;
+  const int64_t p0 = (int64_t)blockIdx.x * pos_per_block;
+  const int np = (int)((p0 + pos_per_block < total ? p0 + pos_per_block : total) - p0);
+  const int t0 = (int)(p0 / N);
+  const int64_t n0 = p0 - (int64_t)t0 * N;
+  constexpr int UN = 8;
+  for (int qb = wv; qb < np; qb += 4 * UN) {
+    float x[UN][2];
+    int id[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int q = qb + 4 * u;
+      const bool live = q < np;
+      int t = t0;
+      int64_t n = n0 + (live ? q : 0);
+      while (n >= N) { n -= N; ++t; }
+      const float* src = dX + (p0 + (live ? q : 0)) * D + col0;
+      x[u][0] = (live && lane < dcols) ? src[lane] : 0.f;
+      x[u][1] = (live && lane + 64 < dcols) ? src[lane + 64] : 0.f;
+      id[u] = live ? ((dbg & 4) ? (int)(q % V) : idx[(n * T + t) * F + idcol] - 1) : -1;
+      if (slots > 1 && live) {   // CAddTable over the type slots (FeatureEmbedding.lua:55): the same value goes to every slot's row
+        for (int k = 1; k < slots; ++k) {
+          const int r = idx[(n * T + t) * F + idcol + k] - 1;
+          if (lane < dcols) lds_atomic_add(&acc[r * dcols + lane], x[u][0]);
+          if (lane + 64 < dcols) lds_atomic_add(&acc[r * dcols + lane + 64], x[u][1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (id[u] < 0) continue;
+      if (dbg & 1) { if (x[u][0] + x[u][1] == 12345.f) acc[0] = 1.f; continue; }
+      if (lane < dcols) lds_atomic_add(&acc[id[u] * dcols + lane], x[u][0]);
+      if (lane + 64 < dcols) lds_atomic_add(&acc[id[u] * dcols + lane + 64], x[u][1]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < V * dcols; i += 256) {
+    const float v = acc[i];
+    if (v != 0.f && !(dbg & 2)) unsafeAtomicAdd(gW + i, v);
+  }
+}
+
+static bool table_grad_lds(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int idcol, int slots, const float* dX, int D, int col0, int dcols,
+                           int V, float* gW) {
+  const size_t bytes = (size_t)V * dcols * sizeof(float);
+  if (dcols <= 0 || dcols > 128 || bytes > 64 * 1024) return false;
+  static bool attr_set = false;
+  if (bytes > 48 * 1024 && !attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_table_grad_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_set = true;
+  }
+  // positions per workgroup: enough that the flush (V * dcols atomics) stays small beside the reads, few enough to fill the chip
+  const int64_t total = N * T;
+  int ppb = 512;   // (128 .. 512 measure alike; 1 024 and up lose parallelism)
+  while (ppb < 8192 && (int64_t)V * dcols * 8 > (int64_t)ppb * dcols) ppb *= 2;
+  static const int ppb_env = getenv("KPRN_TABLE_GRAD_PPB") ? atoi(getenv("KPRN_TABLE_GRAD_PPB")) : 0;   // (measurement)
+  if (ppb_env > 0) ppb = ppb_env;
+  static const int dbg_env = getenv("KPRN_TABLE_GRAD_DBG") ? atoi(getenv("KPRN_TABLE_GRAD_DBG")) : 0;   // (knock-outs: 1 no LDS adds, 2 no flush, 4 no id loads)
+  hipLaunchKernelGGL(k_table_grad_lds, dim3((unsigned)((total + ppb - 1) / ppb)), dim3(256), bytes, s, idx, N, T, F, idcol, slots, dX, D, col0, dcols, V, gW, ppb, dbg_env);
+  return true;
+}
+
 void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* dX, int dt, int de, int dr, int Vt, int Vr,
                    float* gWt, float* gWe, float* gWr, bool skip_entity) {
   if (N <= 0) return;
-  // tiny tables (<= 16 rows): register accumulators instead of atomics on a handful of addresses
+  // tables that fit LDS (every type / relation table of the named configs): one wave per position, LDS accumulators (k_table_grad_lds);
+  // KPRN_TABLE_GRAD=old keeps the 16-register one-hot kernel for tiny tables and the element-indexed scatter for the rest
   const int D_ = dt + de + dr;
-  const bool type_small = dt > 0 && Vt <= 16, rel_small = dr > 0 && Vr <= 16;
+  static const bool old_path = getenv("KPRN_TABLE_GRAD") && strcmp(getenv("KPRN_TABLE_GRAD"), "old") == 0;
+  bool type_small = false, rel_small = false;   // (= handled here)
+  // (measured, configs[3] / shipped / dims B: up to 16 rows the one-hot register kernel wins -- 0.20 against 0.24-0.28 ms; above, the LDS kernel
+  //  beats the element-indexed scatter 0.54 : 0.60 ms, and 0.35 ms of its 0.54 are the ds_add_f32 themselves: ~120 cycles per wave instruction)
+  if (!old_path) {
+    if (dt > 0 && Vt > 16) type_small = table_grad_lds(s, idx, N, T, F, F - nT - 2, nT, dX, D_, 0, dt, Vt, gWt);
+    if (dr > 0 && Vr > 16) rel_small = table_grad_lds(s, idx, N, T, F, F - 1, 1, dX, D_, dt + de, dr, Vr, gWr);
+  }
   const int ppb = 512;
-  if (type_small)
+  if (!type_small && dt > 0 && Vt <= 16) {
     hipLaunchKernelGGL(k_small_table_grad, dim3((unsigned)((N * T + ppb - 1) / ppb), (unsigned)((dt + 63) / 64)), dim3(256), 0, s, idx, N, T, F, F - nT - 2, nT,
                        dX, D_, 0, dt, Vt, gWt, ppb);
-  if (rel_small)
+    type_small = true;
+  }
+  if (!rel_small && dr > 0 && Vr <= 16) {
     hipLaunchKernelGGL(k_small_table_grad, dim3((unsigned)((N * T + ppb - 1) / ppb), (unsigned)((dr + 63) / 64)), dim3(256), 0, s, idx, N, T, F, F - 1, 1, dX,
                        D_, dt + de, dr, Vr, gWr, ppb);
+    rel_small = true;
+  }
   if ((type_small || dt == 0) && (rel_small || dr == 0) && (skip_entity || de == 0)) { CHECK_LAUNCH(); return; }
   if (type_small) { Vt = 0; }   // (their LDS share is not needed)
   size_t small = (size_t)((int64_t)(type_small ? 0 : Vt) * dt + (int64_t)(rel_small ? 0 : Vr) * dr) * sizeof(float);

@@ -965,7 +965,10 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     ProfScope ps(h, "embed_scatter");
     const bool have_index = b->key_sorted != nullptr && !b->tile_k;
     kk::embed_scatter(strm, b->idx, N, T, b->F, c.num_types, w.dIn, c.dt, c.de, c.dr, c.Vt, c.Vr, gd + h->off_Wt, h->g_We, gd + h->off_Wr, have_index);
-    if (have_index) bidx::entity_grad(strm, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, b->n_index, N, T, D, c.dt, c.de, c.Ve, h->g_We);
+  }
+  if (b->key_sorted != nullptr && !b->tile_k) {
+    ProfScope ps(h, "entity_grad");
+    bidx::entity_grad(strm, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, b->n_index, N, T, D, c.dt, c.de, c.Ve, h->g_We);
   }
 }
 
