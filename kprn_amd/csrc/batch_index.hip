@@ -185,16 +185,31 @@ template <int FRAG>
 __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ DX, const int32_t* __restrict__ key_sorted,
                                                      const int32_t* __restrict__ pos_sorted, int64_t nsteps, int64_t N, int T, int D, int dt, int de,
                                                      int sentinel, float* __restrict__ gWe, int n_ent_blocks, int n_red_blocks, SlabReduce red,
-                                                     SmallGrad sg) {
-  if ((int)blockIdx.x >= n_ent_blocks) {  // (workgroup-uniform) the passenger jobs: weight-gradient slab reduce, small-table gradients
-    const int rb = blockIdx.x - n_ent_blocks;
-    if (rb >= n_red_blocks) { small_grad_block(sg, rb - n_red_blocks); return; }
+                                                     SmallGrad sg, int dbg) {
+  // Which workgroup does what (workgroup-uniform).  The passenger jobs (weight-gradient slab reduce, small-table gradients) stream
+  // coalesced data and start at once; a gather-reduce workgroup first walks key -> position -> row (three dependent round trips) with
+  // little in flight.  order 1 dispatches the passengers FIRST so that their traffic fills the time the gathers spend waiting
+  // (order 0: entity workgroups first, as before; 2: alternating while both kinds last).
+  const int order = (dbg >> 4) & 3;
+  const int n_pass = gridDim.x - n_ent_blocks;
+  int bid = blockIdx.x, rb = -1;   // entity workgroup bid, or passenger workgroup rb
+  if (order == 1) { if (bid < n_pass) { rb = bid; } else bid -= n_pass; }
+  else if (order == 2) {
+    const int both = 2 * (n_pass < n_ent_blocks ? n_pass : n_ent_blocks);
+    if (bid < both) { if (bid & 1) rb = bid >> 1; else bid >>= 1; }
+    else if (n_pass > n_ent_blocks) rb = bid - n_ent_blocks;
+    else bid -= n_pass;
+  } else if (bid >= n_ent_blocks) rb = bid - n_ent_blocks;
+  if (rb >= 0) {
+    if (dbg & 2) return;
+    if (rb >= n_red_blocks) { if (!(dbg & 8)) small_grad_block(sg, rb - n_red_blocks); return; }
+    if (dbg & 4) return;
     const int nbx = (red.n_elem + 255) / 256;
     slab_reduce_block(red, rb % nbx, (rb / nbx) % red.ny, rb / (nbx * red.ny));
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t seg = (int64_t)bid * 4 + (threadIdx.x >> 6);
   const int64_t base = seg * 64;
   if (base >= nsteps) return;
   const int cnt = (int)((nsteps - base < 64) ? (nsteps - base) : 64);
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
           const bool whole = opened_here && (knext != k);  // every occurrence of row k was in this segment
           if (act && k != sentinel) {
             float* dst = gWe + (int64_t)k * de + ecol;
-            if (whole) *dst = acc; else unsafeAtomicAdd(dst, acc);
+            if (whole) *dst = acc; else if (!(dbg & 1)) unsafeAtomicAdd(dst, acc);
           }
           acc = 0.f;
           opened_here = true;
@@ -261,10 +276,11 @@ void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* 
   int n_red = 0, n_sg = 0;
   if (red) { r = *red; n_red = ((r.n_elem + 255) / 256) * r.ny * r.L; }
   if (sg) { g = *sg; n_sg = g.nblocks; }
+  static const int dbg = getenv("KPRN_EGRAD_DBG") ? atoi(getenv("KPRN_EGRAD_DBG")) : 0;   // (measurement: 1 no atomics, 2 no passenger work; 16 x workgroup order)
   const dim3 grid((unsigned)(n_ent + n_red + n_sg));
-  if (frag_order == 1) hipLaunchKernelGGL(k_entity_grad<1>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g);
-  else if (frag_order == 2) hipLaunchKernelGGL(k_entity_grad<2>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g);
-  else hipLaunchKernelGGL(k_entity_grad<0>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g);
+  if (frag_order == 1) hipLaunchKernelGGL(k_entity_grad<1>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g, dbg);
+  else if (frag_order == 2) hipLaunchKernelGGL(k_entity_grad<2>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g, dbg);
+  else hipLaunchKernelGGL(k_entity_grad<0>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g, dbg);
   HIP_TRY(hipGetLastError());
 }
 }  // namespace bidx

@@ -302,9 +302,16 @@ __device__ __forceinline__ void slab_reduce_block(const SlabReduce& a, int bx, i
   if (i >= a.n_elem) return;
   const float* __restrict__ part = a.part[l];
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int s = by * 4; s < a.nslab; s += a.ny * 4) {
+  // sixteen slabs in flight per lane (four left the job latency-bound: 19 us for 68 MB, profiles/r03)
+  for (int s = by * 4; s < a.nslab; s += a.ny * 16) {
+    float x[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (s + u < a.nslab) acc[u] += part[(int64_t)(s + u) * a.n_elem + i];
+    for (int u = 0; u < 16; ++u) {
+      const int sl = s + (u >> 2) * a.ny * 4 + (u & 3);
+      x[u] = (sl < a.nslab) ? part[(int64_t)sl * a.n_elem + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u & 3] += x[u];
   }
   float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   const int GH = a.G * a.H, nW = GH * a.H;
@@ -340,9 +347,12 @@ __device__ __forceinline__ void small_grad_block(const SmallGrad& a, int bx) {
   const int wave_of_block = is_type ? cb : ((a.dt + a.de) >> 4) + (cb - ncb_t);   // 16-column block inside the D = 64 row
   const int idcol = is_type ? (a.F - a.nT - 2) : (a.F - 1);
   const int V = is_type ? a.Vt : a.Vr;
-  float acc[16];
-#pragma unroll
-  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  // One-hot product on the matrix cores: grad[v][col] = sum_rows [id(row) == v] dx[row][col] is D += A B with A = one-hot [16 v x 4 k],
+  // B = dx [4 k x 16 col] (v_mfma_f32_16x16x4_f32; 1.0 x is exact, fp32 accumulate).  MFMA r contracts over the rows {4 ag + r}: lane
+  // (ag, arow) then holds exactly its B element (register r of its own fragment) and its A element (the id of its own row 4 ag + r
+  // against v = arow) -- no shuffles, one compare per MFMA where the select form spent 16 compare-select-adds per element (which made
+  // this job VALU-bound: 39 us of the 84 us launch).  D: lane (g, col) holds rows v = 4 g + i.
+  f32x4_ acc = f32x4_{0.f, 0.f, 0.f, 0.f};
   const int64_t items = a.n_mtiles * a.T;
   // latency-bound (one 1 KiB block + 4 ids per item): the next item's loads are in flight while this one is accumulated
   auto fetch = [&](int64_t it, f32x4_& x, int (&id)[4]) -> bool {
@@ -371,18 +381,14 @@ __device__ __forceinline__ void small_grad_block(const SmallGrad& a, int bx) {
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] += (id[d][r] == v) ? x[d][r] : 0.f;
+        const float onehot = (id[d][r] == arow) ? 1.f : 0.f;
+        const float xv = (id[d][r] >= 0) ? x[d][r] : 0.f;   // (rows nobody owns may hold anything, and 0 x NaN is NaN)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(onehot, xv, acc, 0, 0, 0);
       }
   }
   __shared__ float sg_red[4][16][16];
 #pragma unroll
-  for (int v = 0; v < 16; ++v) {
-    float s = acc[v];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    if (ag == 0) sg_red[wv][v][arow] = s;
-  }
+  for (int i = 0; i < 4; ++i) sg_red[wv][4 * ag + i][arow] = acc[i];
   __syncthreads();
   {
     const int v = threadIdx.x >> 4, c = threadIdx.x & 15;   // 256 threads = 16 table rows x 16 columns

@@ -657,6 +657,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       bidx::SmallGrad sg;
       sg.DX = s->DX; sg.idx = b->idx_s ? b->idx_s : b->idx; sg.tile_k = b->tile_k; sg.N = N; sg.n_mtiles = n_tiles * 4; sg.T = T; sg.F = b->F;
       sg.nT = c.num_types; sg.dt = c.dt; sg.de = c.de; sg.dr = c.dr; sg.Vt = c.Vt; sg.Vr = c.Vr; sg.gWt = a.gWt; sg.gWr = a.gWr; sg.nblocks = 4 * s->num_cu;
+      { static const int sgb = getenv("KPRN_SG_BLOCKS") ? atoi(getenv("KPRN_SG_BLOCKS")) : 0; if (sgb > 0) sg.nblocks = sgb; }   // (measurement)
       bidx::entity_grad(strm, s->DXe, /*compact entity slice=*/2, b->key_sorted, b->pos_sorted, b->n_index, N, T, DH, c.dt, c.de, c.Ve, a.gWe, &ra,
                         small_job ? &sg : nullptr);
       reduced = true;
