@@ -1106,6 +1106,93 @@ __global__ __launch_bounds__(256) void k_table_grad_lds(const int32_t* __restric
   }
 }
 
+// The same gradient as a one-hot product on the matrix cores (the form the fused path's passenger job takes, kprn_internal.h
+// small_grad_block), for row-major time-major dX and tables of up to 128 rows x 128 columns:
+//   gW[v][c] += sum_pos [id(pos) == v] dX[pos][col0 + c]  =  D += A B,  A = one-hot [16 v x 4 pos], B = dX [4 pos x 16 c]
+// on v_mfma_f32_16x16x4_f32 (1.0 x is exact, fp32 accumulate).  A workgroup walks pos_per_block consecutive positions, four at a time;
+// wave w owns the 16-column blocks w and w + 4 and keeps one accumulator tile per (row tile, column block).  Lane (k, n) loads its B
+// element dX[pos + k][16 cb + n] and the id of position pos + k (its A element for row tile rt is [id == 16 rt + n]); a row tile none of
+// the four ids falls into is skipped (wave-uniform).  No LDS atomics (0.35 of 0.55 ms on configs[3]), no 16 compare-selects per element.
+template <int RT>
+__global__ __launch_bounds__(256) void k_table_grad_mfma(const int32_t* __restrict__ idx, int64_t N, int T, int F, int idcol, int slots,
+                                                          const float* __restrict__ dX, int D, int col0, int dcols, int V, float* __restrict__ gW,
+                                                          int pos_per_block) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kk = lane >> 4, n16 = lane & 15;
+  const int ncb = (dcols + 15) >> 4;
+  f4 acc[RT][2];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) { acc[r][0] = f4{0.f, 0.f, 0.f, 0.f}; acc[r][1] = f4{0.f, 0.f, 0.f, 0.f}; }
+  const int64_t total = N * T;
+  const int64_t p0 = (int64_t)blockIdx.x * pos_per_block;
+  const int np = (int)((p0 + pos_per_block < total ? p0 + pos_per_block : total) - p0);
+  const int t0 = (int)(p0 / N);
+  const int64_t n0 = p0 - (int64_t)t0 * N;
+  if (wv >= ncb) return;   // (a slice of fewer than four column blocks: this wave owns none)
+  const int c_a = 16 * wv + n16, c_b = 16 * (wv + 4) + n16;          // this lane's columns inside the slice
+  const bool has_a = wv < ncb && c_a < dcols, has_b = wv + 4 < ncb && c_b < dcols;
+  constexpr int UN = 4;   // k-steps (of four positions) in flight
+  for (int q0 = 0; q0 < np; q0 += 4 * UN) {
+    float xa[UN], xb[UN];
+    int id[UN];
+    int64_t ioff[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int q = q0 + 4 * u + kk;
+      const bool live = q < np;
+      int t = t0;
+      int64_t n = n0 + (live ? q : 0);
+      while (n >= N) { n -= N; ++t; }
+      const float* src = dX + (p0 + (live ? q : 0)) * D + col0;
+      xa[u] = (live && has_a) ? src[c_a] : 0.f;
+      xb[u] = (live && has_b) ? src[c_b] : 0.f;
+      ioff[u] = (n * T + t) * F + idcol;
+      id[u] = live ? idx[ioff[u]] - 1 : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      for (int sl = 0; sl < slots; ++sl) {   // CAddTable over the type slots (FeatureEmbedding.lua:55): the same dx goes to every slot's row
+        const int idv = (sl == 0) ? id[u] : ((id[u] >= 0) ? idx[ioff[u] + sl] - 1 : -1);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          if (RT > 1 && __ballot((idv >> 4) == r) == 0) continue;   // (wave-uniform) nobody's id lies in this row tile
+          const float onehot = (idv == 16 * r + n16) ? 1.f : 0.f;
+          acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(onehot, xa[u], acc[r][0], 0, 0, 0);
+          if (wv + 4 < ncb) acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(onehot, xb[u], acc[r][1], 0, 0, 0);   // (wave-uniform)
+        }
+      }
+    }
+  }
+  // D: lane (g, n) holds rows v = 16 rt + 4 g + i of column 16 cb + n
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = 16 * r + 4 * kk + i;
+      if (v < V) {
+        if (has_a && acc[r][0][i] != 0.f) unsafeAtomicAdd(gW + (int64_t)v * dcols + c_a, acc[r][0][i]);
+        if (has_b && acc[r][1][i] != 0.f) unsafeAtomicAdd(gW + (int64_t)v * dcols + c_b, acc[r][1][i]);
+      }
+    }
+}
+
+static bool table_grad_mfma(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int idcol, int slots, const float* dX, int D, int col0, int dcols,
+                            int V, float* gW) {
+  if (dcols <= 0 || dcols > 128 || V <= 0 || V > 128) return false;
+  static const int ppb_env = getenv("KPRN_TABLE_GRAD_PPB") ? atoi(getenv("KPRN_TABLE_GRAD_PPB")) : 0;   // (measurement)
+  const int ppb = ppb_env > 0 ? ppb_env : 256;   // (256 and 512 measure alike on configs[3] and the shipped shape, 256 wins at D = 192; 1 024 loses parallelism)
+  const int64_t total = N * T;
+  const dim3 grid((unsigned)((total + ppb - 1) / ppb));
+#define KPRN_TG(RT_) hipLaunchKernelGGL(k_table_grad_mfma<RT_>, grid, dim3(256), 0, s, idx, N, T, F, idcol, slots, dX, D, col0, dcols, V, gW, ppb)
+  if (V <= 16) KPRN_TG(1);
+  else if (V <= 32) KPRN_TG(2);
+  else if (V <= 64) KPRN_TG(4);
+  else KPRN_TG(8);
+#undef KPRN_TG
+  return true;
+}
+
 static bool table_grad_lds(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int idcol, int slots, const float* dX, int D, int col0, int dcols,
                            int V, float* gW) {
   const size_t bytes = (size_t)V * dcols * sizeof(float);
@@ -1134,9 +1221,13 @@ void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, i
   const int D_ = dt + de + dr;
   static const bool old_path = getenv("KPRN_TABLE_GRAD") && strcmp(getenv("KPRN_TABLE_GRAD"), "old") == 0;
   bool type_small = false, rel_small = false;   // (= handled here)
-  // (measured, configs[3] / shipped / dims B: up to 16 rows the one-hot register kernel wins -- 0.20 against 0.24-0.28 ms; above, the LDS kernel
-  //  beats the element-indexed scatter 0.54 : 0.60 ms, and 0.35 ms of its 0.54 are the ds_add_f32 themselves: ~120 cycles per wave instruction)
-  if (!old_path) {
+  // KPRN_TABLE_GRAD: mfma (default) = the one-hot product on the matrix cores for tables up to 128 x 128; lds = LDS accumulators above 16 rows
+  // (0.54 ms on configs[3], 0.35 of it ds_add_f32) + the 16-register one-hot kernel below; old = that kernel + the element-indexed scatter
+  static const bool lds_path = getenv("KPRN_TABLE_GRAD") && strcmp(getenv("KPRN_TABLE_GRAD"), "lds") == 0;
+  if (!old_path && !lds_path) {
+    if (dt > 0) type_small = table_grad_mfma(s, idx, N, T, F, F - nT - 2, nT, dX, D_, 0, dt, Vt, gWt);
+    if (dr > 0) rel_small = table_grad_mfma(s, idx, N, T, F, F - 1, 1, dX, D_, dt + de, dr, Vr, gWr);
+  } else if (lds_path) {
     if (dt > 0 && Vt > 16) type_small = table_grad_lds(s, idx, N, T, F, F - nT - 2, nT, dX, D_, 0, dt, Vt, gWt);
     if (dr > 0 && Vr > 16) rel_small = table_grad_lds(s, idx, N, T, F, F - 1, 1, dX, D_, dt + de, dr, Vr, gWr);
   }
