@@ -465,8 +465,20 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   a.mtiles = (M + gx::BM - 1) / gx::BM; a.ntiles = (N + gx::BN - 1) / gx::BN;
   if (split_k < 1 || !accumulate) split_k = 1;
   if (split_k > 1) {
+    // K ranges are dealt to the XCDs (range r on XCD r % 8, all its tiles there), one workgroup per CU (147 KB of LDS), 32 CUs per XCD:
+    // with s ranges per XCD the launch takes ceil(tiles s / 32) rounds of 1 / (8 s) of K each.  Pick the s <= 8 with the least
+    // rounds / s (configs[3]'s dW: 18 tiles -> s = 7: 126 workgroups = 3.94 rounds per XCD; the old "3 x 256 workgroups" rule gave 43
+    // ranges = 6 on three XCDs, 4 rounds of 1 / 43: a quarter more time)
     const int64_t tiles = a.mtiles * a.ntiles;
-    split_k = (int)std::max<int64_t>(1, std::min<int64_t>(split_k, (3 * 256 + tiles - 1) / tiles));
+    static const int s_env = getenv("KPRN_GEMM16_SX") ? atoi(getenv("KPRN_GEMM16_SX")) : 0;   // (measurement)
+    int best = 1;
+    double best_t = 1e30;
+    for (int sx = 1; sx <= 8 && sx * 8 <= std::max(split_k, 8); ++sx) {
+      const double t = (double)((tiles * sx + 31) / 32) / sx;
+      if (t < best_t - 1e-9) { best_t = t; best = sx; }
+    }
+    if (s_env > 0) best = s_env;
+    split_k = best * 8;
   }
   int64_t kchunk = (K + split_k - 1) / split_k;
   kchunk = ((kchunk + gx::BK - 1) / gx::BK) * gx::BK;
