@@ -597,75 +597,90 @@ __global__ void k_gates_bwd16(const bf16* __restrict__ act, const float* __restr
 // through LDS tiles so that global accesses are whole 128 / 256-byte row segments.
 template <int NW>
 __global__ __launch_bounds__(256) void k_gates_bwd16_frag(const bf16x8* __restrict__ A0, const bf16x8* __restrict__ A1, const f32x4* __restrict__ cF,
-                                                          const f32x4* __restrict__ cprevF, const float* __restrict__ dH_up, float* __restrict__ dH,
+                                                          const f32x4* __restrict__ cprevF, const float* __restrict__ dH_up, const float* __restrict__ dH,
                                                           float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H, bf16* __restrict__ dAT /* nullable: this
-                                                          step's column block of dA^T [4H][T Np] */, int64_t ldT, int64_t Np) {
+                                                          step's column block of dA^T [4H][T Np] */, int64_t ldT, int64_t Np, int64_t NU, int units_per_wg,
+                                                          float* __restrict__ gbias /* nullable: [4H] += column sums of dA (the bias gradient) */) {
   constexpr int HC = 8 * NW, Q = HC / 4;
   __shared__ __attribute__((aligned(16))) float sH[32][HC + 4];
   __shared__ __attribute__((aligned(16))) float sC[32][HC + 4];
   __shared__ __attribute__((aligned(16))) bf16 sA[32][4][HC + 8];
   const int tid = threadIdx.x;
-  const int64_t unit = blockIdx.x, row0 = unit * 32;
   const int c = blockIdx.y, NCH = gridDim.y, ub = HC * c;
-  for (int i = tid; i < 32 * Q; i += 256) {
-    const int r = i / Q, q = i - r * Q;
-    const int64_t n = row0 + r;
-    f32x4 vh = f32x4{0.f, 0.f, 0.f, 0.f}, vc = vh;
-    if (n < N) {
-      vh = *(const f32x4*)(dH + n * H + ub + 4 * q);
-      vc = *(const f32x4*)(dC + n * H + ub + 4 * q);
-      if (dH_up) { const f32x4 u = *(const f32x4*)(dH_up + n * H + ub + 4 * q); vh += u; }
+  // A workgroup walks units_per_wg 32-row units of its chunk: the bias gradient (column sums of dA, formerly a second sweep over dA^T: 1.2 GB
+  // per step) is summed per thread -- thread (g, u) owns gate row g H + ub + u -- across the units and leaves as ONE atomic per thread.
+  float bsum = 0.f;
+  const int bg = tid / HC, bu = tid - bg * HC;   // (tid < 4 HC)
+  for (int ui = 0; ui < units_per_wg; ++ui) {
+    const int64_t unit = (int64_t)blockIdx.x * units_per_wg + ui;
+    if (unit >= NU) break;   // (workgroup-uniform)
+    const int64_t row0 = unit * 32;
+    if (ui > 0) __syncthreads();   // (the previous unit's tiles have been read)
+    for (int i = tid; i < 32 * Q; i += 256) {
+      const int r = i / Q, q = i - r * Q;
+      const int64_t n = row0 + r;
+      f32x4 vh = f32x4{0.f, 0.f, 0.f, 0.f}, vc = vh;
+      if (n < N) {
+        vh = *(const f32x4*)(dH + n * H + ub + 4 * q);
+        vc = *(const f32x4*)(dC + n * H + ub + 4 * q);
+        if (dH_up) { const f32x4 u = *(const f32x4*)(dH_up + n * H + ub + 4 * q); vh += u; }
+      }
+      *(f32x4*)&sH[r][4 * q] = vh;
+      *(f32x4*)&sC[r][4 * q] = vc;
     }
-    *(f32x4*)&sH[r][4 * q] = vh;
-    *(f32x4*)&sC[r][4 * q] = vc;
-  }
-  __syncthreads();
-  for (int rl = tid; rl < NW * 64; rl += 256) {
-    const int w = rl >> 6, lane = rl & 63, ln = lane & 31, ul = 8 * w + 4 * (lane >> 5);
-    const int64_t rec = ((unit * NCH + c) * NW + w) * 64 + lane;
-    const bf16x8 a0 = A0[rec], a1 = A1[rec];
-    const f32x4 cc = cF[rec];
-    const f32x4 cp = cprevF ? cprevF[rec] : f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int rl = tid; rl < NW * 64; rl += 256) {
+      const int w = rl >> 6, lane = rl & 63, ln = lane & 31, ul = 8 * w + 4 * (lane >> 5);
+      const int64_t rec = ((unit * NCH + c) * NW + w) * 64 + lane;
+      const bf16x8 a0 = A0[rec], a1 = A1[rec];
+      const f32x4 cc = cF[rec];
+      const f32x4 cp = cprevF ? cprevF[rec] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float ig = (float)a0[j], gg = (float)a0[4 + j], fg = (float)a1[j], og = (float)a1[4 + j];
-      const float tc = tanhf(cc[j]);
-      const float dh = sH[ln][ul + j];
-      const float dO = dh * tc;
-      const float dc = sC[ln][ul + j] + dh * og * (1.f - tc * tc);
-      sA[ln][0][ul + j] = tobf(dc * gg * ig * (1.f - ig));
-      sA[ln][1][ul + j] = tobf(dc * ig * (1.f - gg * gg));
-      sA[ln][2][ul + j] = tobf(dc * cp[j] * fg * (1.f - fg));
-      sA[ln][3][ul + j] = tobf(dO * og * (1.f - og));
-      sC[ln][ul + j] = dc * fg;
+      for (int j = 0; j < 4; ++j) {
+        const float ig = (float)a0[j], gg = (float)a0[4 + j], fg = (float)a1[j], og = (float)a1[4 + j];
+        const float tc = tanhf(cc[j]);
+        const float dh = sH[ln][ul + j];
+        const float dO = dh * tc;
+        const float dc = sC[ln][ul + j] + dh * og * (1.f - tc * tc);
+        sA[ln][0][ul + j] = tobf(dc * gg * ig * (1.f - ig));
+        sA[ln][1][ul + j] = tobf(dc * ig * (1.f - gg * gg));
+        sA[ln][2][ul + j] = tobf(dc * cp[j] * fg * (1.f - fg));
+        sA[ln][3][ul + j] = tobf(dO * og * (1.f - og));
+        sC[ln][ul + j] = dc * fg;
+      }
     }
-  }
-  __syncthreads();
-  for (int i = tid; i < 32 * Q; i += 256) {
-    const int r = i / Q, q = i - r * Q;
-    const int64_t n = row0 + r;
-    if (n < N) {
-      *(f32x4*)(dC + n * H + ub + 4 * q) = *(const f32x4*)&sC[r][4 * q];
-      *(f32x4*)(dH + n * H + ub + 4 * q) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    // (dH is not cleared: the recurrent product of this step -- dh_{t-1} = dA_t W_o2g, plain stores -- or the next head backward overwrites it)
+    for (int i = tid; i < 32 * Q; i += 256) {
+      const int r = i / Q, q = i - r * Q;
+      const int64_t n = row0 + r;
+      if (n < N) *(f32x4*)(dC + n * H + ub + 4 * q) = *(const f32x4*)&sC[r][4 * q];
     }
-  }
-  constexpr int P8 = HC / 8;   // 16-byte pieces of a (row, gate) segment
-  for (int i = tid; i < 32 * 4 * P8; i += 256) {
-    const int p = i % P8, g = (i / P8) & 3, r = i / (4 * P8);
-    const int64_t n = row0 + r;
-    if (n < N) *(bf16x8*)(dA + n * (int64_t)4 * H + (int64_t)g * H + ub + 8 * p) = *(const bf16x8*)&sA[r][g][8 * p];
-  }
-  if (dAT) {   // the transposed image the dW products contract over (k-contiguous operands): this tile's 4 HC gate rows x 32 paths, pad columns zero
-    for (int i = tid; i < 4 * HC * 4; i += 256) {
-      const int r8 = i & 3, u = (i >> 2) % HC, g = i / (4 * HC);
-      const int64_t n0 = row0 + 8 * r8;
-      if (n0 >= Np) continue;
-      bf16x8 v;
+    constexpr int P8 = HC / 8;   // 16-byte pieces of a (row, gate) segment
+    for (int i = tid; i < 32 * 4 * P8; i += 256) {
+      const int p = i % P8, g = (i / P8) & 3, r = i / (4 * P8);
+      const int64_t n = row0 + r;
+      if (n < N) *(bf16x8*)(dA + n * (int64_t)4 * H + (int64_t)g * H + ub + 8 * p) = *(const bf16x8*)&sA[r][g][8 * p];
+    }
+    if (dAT) {   // the transposed image the dW products contract over (k-contiguous operands): this tile's 4 HC gate rows x 32 paths, pad columns zero
+      for (int i = tid; i < 4 * HC * 4; i += 256) {
+        const int r8 = i & 3, u = (i >> 2) % HC, g = i / (4 * HC);
+        const int64_t n0 = row0 + 8 * r8;
+        if (n0 >= Np) continue;
+        bf16x8 v;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = (n0 + q < N) ? sA[8 * r8 + q][g][u] : (bf16)0.f;
-      *(bf16x8*)(dAT + ((int64_t)g * H + ub + u) * ldT + n0) = v;
+        for (int q = 0; q < 8; ++q) v[q] = (n0 + q < N) ? sA[8 * r8 + q][g][u] : (bf16)0.f;
+        *(bf16x8*)(dAT + ((int64_t)g * H + ub + u) * ldT + n0) = v;
+      }
+    }
+    if (gbias && tid < 4 * HC) {   // the bf16-rounded values, as the separate row sum over dA^T read them
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) sacc += (row0 + r < N) ? (float)sA[r][bg][bu] : 0.f;
+      bsum += sacc;
     }
   }
+  if (gbias && tid < 4 * HC && bsum != 0.f) unsafeAtomicAdd(gbias + (int64_t)bg * H + ub + bu, bsum);
 }
 
 // y[c][r] = x[r][c] for r < R, 0 for R <= r < Rp (the padded row count: 16-byte rows of y); x bf16 [R][C] (C a multiple of 8), y pitch
@@ -728,6 +743,7 @@ struct State {
   bf16 *X16 = nullptr, *XT16 = nullptr, *H16 = nullptr, *HT16 = nullptr, *ACT16 = nullptr, *dA16 = nullptr, *dAT16 = nullptr;
   void* persist = nullptr;      // lstm_bf16_persist.hip: packed weights + scratch slabs of the persistent layer kernel
   bool pack_dirty = true;       // its packed weights are stale
+  bool bias_in_gates = false;   // k_gates_bwd16_frag also summed the bias gradient (measurement switch)
   bool act_frag = false;        // the last training forward wrote c and the gate planes in fragment order (persistent kernel; k_gates_bwd16_frag)
   PersistSaves sv{};
 };
@@ -934,8 +950,16 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
           const float* up = has_up ? w.dIn + (int64_t)t * N * H : nullptr;
           const int64_t Np_ = (N + 7) & ~(int64_t)7;
           bf16* dat = s->dAT16 + (int64_t)t * Np_;   // (this kernel has the tile in LDS: it writes the transposed image too, no transpose pass for dA)
-          if (v.NW == 8) hipLaunchKernelGGL((k_gates_bwd16_frag<8>), dim3((unsigned)v.NU, (unsigned)NCH), dim3(256), 0, strm, a0, a1, cf, cpf, up, w.dH, w.dC, dA_t, N, H, dat, (int64_t)T * Np_, Np_);
-          else hipLaunchKernelGGL((k_gates_bwd16_frag<4>), dim3((unsigned)v.NU, (unsigned)NCH), dim3(256), 0, strm, a0, a1, cf, cpf, up, w.dH, w.dC, dA_t, N, H, dat, (int64_t)T * Np_, Np_);
+          // Measured (configs[3], ms per launch): one unit per workgroup, bias sums left to k_rowsum16 0.224; the bias gradient summed here
+          // 0.26-0.29 (units per workgroup 4 / 2 / 1 / 8) -- 6 x 0.04-0.06 costs what the separate sweep over dA^T costs (0.20 ms), so it stays
+          // a separate launch; KPRN_GATES_FUSED_BIAS=<units per workgroup> switches the fused form on.
+          static const int fb_env = getenv("KPRN_GATES_FUSED_BIAS") ? atoi(getenv("KPRN_GATES_FUSED_BIAS")) : 0;
+          s->bias_in_gates = fb_env > 0;
+          const int upw = fb_env > 0 ? fb_env : 1;
+          const dim3 grid((unsigned)((v.NU + upw - 1) / upw), (unsigned)NCH);
+          float* gb = fb_env > 0 ? gd + h->layer[l].bi : nullptr;
+          if (v.NW == 8) hipLaunchKernelGGL((k_gates_bwd16_frag<8>), grid, dim3(256), 0, strm, a0, a1, cf, cpf, up, w.dH, w.dC, dA_t, N, H, dat, (int64_t)T * Np_, Np_, (int64_t)v.NU, upw, gb);
+          else hipLaunchKernelGGL((k_gates_bwd16_frag<4>), grid, dim3(256), 0, strm, a0, a1, cf, cpf, up, w.dH, w.dC, dA_t, N, H, dat, (int64_t)T * Np_, Np_, (int64_t)v.NU, upw, gb);
         } else {
           hipLaunchKernelGGL(k_gates_bwd16, dim3((unsigned)((N * H + 255) / 256)), dim3(256), 0, strm, act + (int64_t)t * N * G4, cs + (int64_t)t * N * H,
                              t > 0 ? cs + (int64_t)(t - 1) * N * H : nullptr, has_up ? w.dIn + (int64_t)t * N * H : nullptr, w.dH, w.dC, dA_t, N, H);
@@ -963,7 +987,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       ProfScope ps(h, "gemm_o2g_bwd_dw");   // gW_o2g [4H][H] += dA[1..T-1]^T h[0..T-2]
       gemm16(strm, s->dAT16 + Np, TNp, s->HT16, TNp, gd + h->layer[l].Wo, H, G4, H, (int64_t)(T - 1) * Np, true, nullptr, split);
     }
-    {
+    if (!(s->act_frag && l == 0 && s->bias_in_gates)) {   // (else the fragment-order gate backward summed the bias gradient as it produced dA)
       ProfScope ps(h, "bias_colsum");
       hipLaunchKernelGGL(k_rowsum16, dim3((unsigned)G4), dim3(256), 0, strm, s->dAT16, TNp, gd + h->layer[l].bi);
       HIP_TRY(hipGetLastError());
