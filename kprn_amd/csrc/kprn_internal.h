@@ -358,13 +358,18 @@ __device__ __forceinline__ void small_grad_block(const SmallGrad& a, int bx) {
   auto fetch = [&](int64_t it, f32x4_& x, int (&id)[4]) -> bool {
     const int64_t mtile = it / a.T;
     const int t = (int)(it - mtile * a.T);
-    const bool live = !(a.tile_k && t < a.tile_k[mtile >> 2]);   // (wave-uniform) the prefix backward owns the skipped positions
+    // (the ids are requested before tile_k is known -- both loads in one round trip -- and discarded afterwards if the position is skipped)
+    const int tk = a.tile_k ? a.tile_k[mtile >> 2] : 0;
     x = *(const f32x4_*)(a.DX + ((mtile * a.T + t) * 4 + wave_of_block) * 256 + lane * 4);
+    int raw[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t n = mtile * 16 + ag * 4 + r;
-      id[r] = (live && n < a.N) ? a.idx[(n * a.T + t) * a.F + idcol] - 1 : -1;
+      raw[r] = (n < a.N) ? a.idx[(n * a.T + t) * a.F + idcol] : 0;
     }
+    const bool live = !(t < tk);   // (wave-uniform) the prefix backward owns the skipped positions
+#pragma unroll
+    for (int r = 0; r < 4; ++r) id[r] = live ? raw[r] - 1 : -1;
     return live;
   };
   constexpr int DEPTH = 6;   // items in flight per wave

@@ -569,6 +569,62 @@ __global__ void k_gather16(const int32_t* __restrict__ idx, int64_t N, int T, in
   }
   *(bf16x8*)(X + ((int64_t)t * N + n) * D + col) = v;
 }
+// The same gather written TRANSPOSED: XT[d][t][n] (pitch ldy = T Np, pad columns n >= N zero) -- the k-contiguous operand of the dW product.
+// When the persistent layer kernel ran the training forward (it gathers for itself) the row-major plane X16 has no other reader, so the
+// backward builds the transposed image straight from the shadow tables: 64 positions x 64 columns per workgroup through LDS, 16-byte accesses
+// on both sides (k_gather16 + k_transpose16 of X: 0.13 + 0.16 ms on configs[3]).
+__global__ __launch_bounds__(256) void k_gather16_T(const int32_t* __restrict__ idx, int64_t N, int64_t Np, int T, int F, int nT, const bf16* __restrict__ Wt,
+                                                    const bf16* __restrict__ We, const bf16* __restrict__ Wr, int dt, int de, int dr, bf16* __restrict__ XT,
+                                                    int64_t ldy) {
+  __shared__ __attribute__((aligned(16))) bf16 tl[64][72];
+  const int D = dt + de + dr;
+  const int64_t n0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64, t = blockIdx.z;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int f = threadIdx.x + 256 * e;
+    const int rr = f >> 3, col = c0 + (f & 7) * 8;
+    const int64_t n = n0 + rr;
+    bf16x8 v;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (bf16)0.f;
+    if (n < N && col < D) {
+      const int32_t* id = idx + (n * T + t) * F;
+      if (col < dt) {
+        v = *(const bf16x8*)(Wt + (int64_t)(id[F - nT - 2] - 1) * dt + col);
+        if (nT > 1) {
+          float acc[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[q] = (float)v[q];
+          for (int k = 1; k < nT; ++k) {
+            const bf16x8 w = *(const bf16x8*)(Wt + (int64_t)(id[F - nT - 2 + k] - 1) * dt + col);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += (float)w[q];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = tobf(acc[q]);
+        }
+      } else if (col < dt + de) {
+        v = *(const bf16x8*)(We + (int64_t)(id[F - 2] - 1) * de + (col - dt));
+      } else {
+        v = *(const bf16x8*)(Wr + (int64_t)(id[F - 1] - 1) * dr + (col - dt - de));
+      }
+    }
+    *(bf16x8*)(&tl[rr][(f & 7) * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int f = threadIdx.x + 256 * e;
+    const int cc = f >> 3, rq = (f & 7) * 8;
+    if (c0 + cc < D && n0 + rq < Np) {
+      bf16x8 v;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = tl[rq + q][cc];
+      *(bf16x8*)(XT + (int64_t)(c0 + cc) * ldy + (int64_t)t * Np + n0 + rq) = v;
+    }
+  }
+}
 // cell backward of one step on the saved bf16 gate values (kernels_basic.hip k_gates_bwd, with dA written in bf16)
 __global__ void k_gates_bwd16(const bf16* __restrict__ act, const float* __restrict__ c, const float* __restrict__ c_prev, const float* __restrict__ dH_up,
                               float* __restrict__ dH, float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H) {
@@ -855,7 +911,7 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   refresh_shadows(h);
   ensure_buffers(h, N, T);
   const bool persist = persist_shape_ok(h, b);
-  if (!persist || save) {   // (the persistent kernel gathers for itself; the backward's dW product reads the [T][N][D] plane)
+  if (!persist) {   // (the persistent kernel gathers for itself, and the backward then builds the dW product's operand X^T from the tables: k_gather16_T)
     ProfScope ps(h, "embed_gather_bf16");
     const int64_t work = N * T * (D >> 3);
     hipLaunchKernelGGL(k_gather16, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, strm, b->idx, N, T, b->F, c.num_types, s->dense16 + h->off_Wt, s->We16,
@@ -975,7 +1031,11 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     {
       ProfScope ps(h, "bf16_transposes");
       if (!(s->act_frag && l == 0)) transpose_steps(strm, s->dA16, s->dAT16, T, N, Np, G4);                       // dA^T [4H][T][Np] (the fragment-order gate backward wrote it)
-      transpose_steps(strm, (l == 0) ? s->X16 : s->H16 + (int64_t)(l - 1) * TN * H, s->XT16, T, N, Np, Din);      // in^T [Din][T][Np]
+      if (l == 0 && s->act_frag) {   // in^T gathered straight into the transposed layout (the forward was the persistent kernel: no X16 plane)
+        hipLaunchKernelGGL(k_gather16_T, dim3((unsigned)((Np + 63) / 64), (unsigned)((Din + 63) / 64), (unsigned)T), dim3(256), 0, strm, b->idx, N, Np, T, b->F,
+                           c.num_types, s->dense16 + h->off_Wt, s->We16, s->dense16 + h->off_Wr, c.dt, c.de, c.dr, s->XT16, (int64_t)T * Np);
+        HIP_TRY(hipGetLastError());
+      } else transpose_steps(strm, (l == 0) ? s->X16 : s->H16 + (int64_t)(l - 1) * TN * H, s->XT16, T, N, Np, Din);      // in^T [Din][T][Np]
       if (T > 1) transpose_steps(strm, hs, s->HT16, T, N, Np, H);                                                // h^T  [H][T][Np]
     }
     const int split = (int)std::min<int64_t>(1024, std::max<int64_t>(1, TN / 4096));

@@ -166,11 +166,21 @@ def test_training_on_the_20_million_row_table_touched_rows_only():
     off, shp = lay["entity_emb"]
     want = theta[off:off + int(np.prod(shp))].reshape(shp)
     got = eng.get_param_rows("entity_emb", ids - 1)
-    assert np.max(np.abs(got - want)) < 5e-3          # 4 steps of lr 2e-3 move an element by <= 8e-3
+
+    def close(a, b, nm):
+        # Adam normalises: 4 steps of lr 2e-3 move an element by <= 8e-3 whatever its gradient, so an element whose gradient is at the
+        # bf16 pipeline's noise level may step the other way (measured: one element in 590 k off by 8.1e-3, the split-K atomics order
+        # changes which).  Bars: nearly all elements within 5e-3, the rms far inside it, nobody further than opposite walks allow.
+        d = np.abs(np.asarray(a, np.float64).ravel() - np.asarray(b, np.float64).ravel())
+        assert d.max() < 2 * 8e-3 + 1e-4, (nm, d.max())
+        assert np.mean(d > 5e-3) < 1e-4, (nm, float(np.mean(d > 5e-3)))
+        assert np.sqrt(np.mean(d ** 2)) < 1e-3, (nm, float(np.sqrt(np.mean(d ** 2))))
+
+    close(got, want, "entity_emb")
     moved = np.abs(want - rows0).max(axis=1) > 1e-4
     assert moved.sum() > 0.5 * len(ids)               # ... and most touched rows did move (the comparison above is not vacuous)
     for nm, (off, shp) in lay.items():
         if nm != "entity_emb":
-            assert np.max(np.abs(eng.get_param(nm).ravel() - theta[off:off + int(np.prod(shp))])) < 5e-3, nm
+            close(eng.get_param(nm), theta[off:off + int(np.prod(shp))], nm)
     assert np.array_equal(eng.get_param_rows("entity_emb", untouched), before)
     eng.close()
