@@ -1957,7 +1957,7 @@ int kprn_dp_exchange_begin(kprn_handle* h, int32_t capacity) {
   int32_t* mine = h->dp_gather + (int64_t)h->dp_rank * words;
   pack_into(h, capacity, mine);
   hipStream_t cs = h->stream;
-  if (h->dp_comm_stream_on && W > 1) {
+  if (h->dp_comm_stream_on) {   // (also at world 1, where the collective is empty: the hand-over is the same code a world-8 run takes)
     if (!h->dp_comm_stream) {
       h->dp_comm_stream = make_concurrent_stream(h);
       HIP_TRY(hipEventCreateWithFlags(&h->ev_dp_packed, hipEventDisableTiming));
@@ -1967,9 +1967,10 @@ int kprn_dp_exchange_begin(kprn_handle* h, int32_t capacity) {
     HIP_TRY(hipEventRecord(h->ev_dp_packed, h->stream));
     HIP_TRY(hipStreamWaitEvent(cs, h->ev_dp_packed, 0));
   }
-  if (W > 1) {
+  {
     ProfScope ps(h, "dp_allgather");
-    const int rc = g_rccl.AllGather(mine, h->dp_gather, (size_t)words, kNcclInt32, h->dp_comm, cs);   // in place: sendbuff = recvbuff + rank * count
+    // in place: sendbuff = recvbuff + rank * count (no staging copy; with one rank RCCL returns at once)
+    const int rc = g_rccl.AllGather(mine, h->dp_gather, (size_t)words, kNcclInt32, h->dp_comm, cs);
     KPRN_REQUIRE(rc == 0, KPRN_E_DEVICE, rccl_msg("ncclAllGather", rc));
   }
   if (cs != h->stream) HIP_TRY(hipEventRecord(h->ev_dp_gathered, cs));
@@ -1981,7 +1982,7 @@ int kprn_dp_exchange_finish(kprn_handle* h, const kprn_opt* opt) {
   API_BEGIN(h)
   KPRN_REQUIRE(h->dp_comm && h->dp_begun, KPRN_E_ARG, "kprn_dp_exchange_finish without kprn_dp_exchange_begin");
   h->dp_begun = false;
-  if (h->dp_comm_stream_on && h->dp_nranks > 1 && h->dp_comm_stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_dp_gathered, 0));
+  if (h->dp_comm_stream_on && h->dp_comm_stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_dp_gathered, 0));
   merge_impl(h, h->dp_gather, h->dp_nranks, (int32_t)h->pack_cap);
   apply_update_impl(h, opt);
   API_END(h)
