@@ -108,9 +108,13 @@ template <class V> __device__ __forceinline__ V ldb(rsrc_t r, unsigned voff, uns
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
   return __builtin_bit_cast(V, v);
 }
-template <class V> __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, V v) {
-  if constexpr (sizeof(V) == 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 0);
-  else { static_assert(sizeof(V) == 8, "8- or 16-byte pieces"); __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0); }
+// AUX: cache policy bits of the store (0 default; 2 = nt, a streaming store -- the training saves are not read again by this launch)
+#ifndef KPRN_SAVE_AUX
+#define KPRN_SAVE_AUX 0
+#endif
+template <class V, int AUX = 0> __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, V v) {
+  if constexpr (sizeof(V) == 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, AUX);
+  else { static_assert(sizeof(V) == 8, "8- or 16-byte pieces"); __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, AUX); }
 }
 
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
@@ -187,13 +191,13 @@ struct Cell {
       // stores per lane and chunk: 1.27 ms against 0.76 ms for the scoring launch); lstm_bf16.hip's k_gates_bwd16_frag reads them back coalesced
       // and does the re-layout to row-major through LDS on its own side.  Rows past N land in the padded tail of their unit.
       const int64_t rec = ((((int64_t)te * a.NU + row0 / 32 + pt) * (H / HC) + ce) * NW + wave) * 64;
-      stb<f32x4>(make_rsrc(a.CsF + rec * 4), (unsigned)lane * 16u, 0, cv);
+      stb<f32x4, KPRN_SAVE_AUX>(make_rsrc(a.CsF + rec * 4), (unsigned)lane * 16u, 0, cv);
       bf16x8 v0, v1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v0[j] = (bf16)gi[j]; v0[4 + j] = (bf16)gg[j]; v1[j] = (bf16)gf[j]; v1[4 + j] = (bf16)go[j]; }
-      stb<bf16x8>(make_rsrc(a.ActF0 + rec * 8), (unsigned)lane * 16u, 0, v0);
-      stb<bf16x8>(make_rsrc(a.ActF1 + rec * 8), (unsigned)lane * 16u, 0, v1);
-      if (ok) stb<bf16x4>(make_rsrc(a.H16 + ((int64_t)te * a.N + row0 + 32 * pt) * H + cu), lo_row(H, 2), 0, hb);
+      stb<bf16x8, KPRN_SAVE_AUX>(make_rsrc(a.ActF0 + rec * 8), (unsigned)lane * 16u, 0, v0);
+      stb<bf16x8, KPRN_SAVE_AUX>(make_rsrc(a.ActF1 + rec * 8), (unsigned)lane * 16u, 0, v1);
+      if (ok) stb<bf16x4, KPRN_SAVE_AUX>(make_rsrc(a.H16 + ((int64_t)te * a.N + row0 + 32 * pt) * H + cu), lo_row(H, 2), 0, hb);
     } else {
       stb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((ce * MAXPT + pt) * NW + wave) * 1024u, cv);
     }

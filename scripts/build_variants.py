@@ -14,8 +14,8 @@ for src in kb.sources():
     obj = os.path.join(kb.HERE, "build", os.path.basename(src) + ".o")
     if os.path.basename(src) == "lstm_bf16_persist.hip":
         obj = os.path.join(kb.HERE, "build", "lstm_bf16_persist.variants.o")
-        subprocess.check_call([kb.HIPCC] + kb.FLAGS + kb.file_flags(src) + ["-DKPRN_PERSIST_VARIANTS", "-c", src, "-o", obj])
+        subprocess.check_call([kb.HIPCC] + kb.FLAGS + kb.file_flags(src) + ["-DKPRN_PERSIST_VARIANTS"] + os.environ.get("KPRN_VARIANT_DEFS", "").split() + ["-c", src, "-o", obj])
     objs.append(obj)
-out = os.path.join(kb.HERE, "libkprn_variants.so")
+out = os.path.join(kb.HERE, os.environ.get("KPRN_VARIANT_NAME", "libkprn_variants.so"))
 subprocess.check_call([kb.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
 print(out)
