@@ -224,39 +224,47 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
     const bool act = ecol < de;
     const int col = dt + ecol;        // column of dx
     const int coff = (col >> 4) * 256 + (col & 15) * 4;
-    float v[64];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      const int p = __builtin_amdgcn_readlane(my_pos, i);
-      const int n = p / T, t = p - n * T;
-      int64_t off;
-      if (FRAG == 1) {
-        const int rr = n & 15;
-        off = ((int64_t)(n >> 4) * T + t) * ((int64_t)waves_per_group * 256) + (rr >> 2) * 64 + (rr & 3) + coff;
-      } else if (FRAG == 2) {
-        off = (int64_t)p * de + ecol;   // compact entity slice: 4 de contiguous bytes per position
-      } else {
-        off = ((int64_t)t * N + n) * D + col;
-      }
-      v[i] = (act && i < cnt && __builtin_amdgcn_readlane(my_key, i) != sentinel) ? DX[off] : 0.f;
-    }
+    // the segment's 64 positions in two halves of 32: 32 gathers in flight per lane instead of 64 keeps the kernel at <= 64 VGPRs (8 waves
+    // per SIMD instead of 5 -- the launch's 6 688 workgroups, passengers included, need 3.3 rounds of resident slots instead of 5.2)
     float acc = 0.f;
     bool opened_here = __builtin_amdgcn_readlane(my_key, 0) != key_before;  // the first run starts in this segment
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      if (i < cnt) {  // wave-uniform
-        acc += v[i];
-        const int k = __builtin_amdgcn_readlane(my_key, i);
-        const bool more = (i < 63) && (i + 1 < cnt);
-        const int knext = more ? __builtin_amdgcn_readlane(my_key, (i + 1) & 63) : key_after;
-        if (!more || knext != k) {  // the run ends, or the segment does
-          const bool whole = opened_here && (knext != k);  // every occurrence of row k was in this segment
-          if (act && k != sentinel) {
-            float* dst = gWe + (int64_t)k * de + ecol;
-            if (whole) *dst = acc; else if (!(dbg & 1)) unsafeAtomicAdd(dst, acc);
+    for (int hf = 0; hf < 2; ++hf) {
+      if (hf * 32 >= cnt) break;   // (wave-uniform)
+      float v[32];
+#pragma unroll
+      for (int i2 = 0; i2 < 32; ++i2) {
+        const int i = 32 * hf + i2;
+        const int p = __builtin_amdgcn_readlane(my_pos, i);
+        const int n = p / T, t = p - n * T;
+        int64_t off;
+        if (FRAG == 1) {
+          const int rr = n & 15;
+          off = ((int64_t)(n >> 4) * T + t) * ((int64_t)waves_per_group * 256) + (rr >> 2) * 64 + (rr & 3) + coff;
+        } else if (FRAG == 2) {
+          off = (int64_t)p * de + ecol;   // compact entity slice: 4 de contiguous bytes per position
+        } else {
+          off = ((int64_t)t * N + n) * D + col;
+        }
+        v[i2] = (act && i < cnt && __builtin_amdgcn_readlane(my_key, i) != sentinel) ? DX[off] : 0.f;
+      }
+#pragma unroll
+      for (int i2 = 0; i2 < 32; ++i2) {
+        const int i = 32 * hf + i2;
+        if (i < cnt) {  // wave-uniform
+          acc += v[i2];
+          const int k = __builtin_amdgcn_readlane(my_key, i);
+          const bool more = (i < 63) && (i + 1 < cnt);
+          const int knext = more ? __builtin_amdgcn_readlane(my_key, (i + 1) & 63) : key_after;
+          if (!more || knext != k) {  // the run ends, or the segment does
+            const bool whole = opened_here && (knext != k);  // every occurrence of row k was in this segment
+            if (act && k != sentinel) {
+              float* dst = gWe + (int64_t)k * de + ecol;
+              if (whole) *dst = acc; else if (!(dbg & 1)) unsafeAtomicAdd(dst, acc);
+            }
+            acc = 0.f;
+            opened_here = true;
           }
-          acc = 0.f;
-          opened_here = true;
         }
       }
     }

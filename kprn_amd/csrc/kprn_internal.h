@@ -372,7 +372,7 @@ __device__ __forceinline__ void small_grad_block(const SmallGrad& a, int bx) {
     for (int r = 0; r < 4; ++r) id[r] = live ? raw[r] - 1 : -1;
     return live;
   };
-  constexpr int DEPTH = 6;   // items in flight per wave
+  constexpr int DEPTH = 4;   // items in flight per wave (6 cost the whole launch two waves per SIMD of occupancy: the kernel is one register allocation)
   for (int64_t it0 = part; it0 < items; it0 += (int64_t)nparts * DEPTH) {
     f32x4_ x[DEPTH];
     int id[DEPTH][4];
