@@ -118,6 +118,31 @@ def test_backward_matches_oracle(impl, L, P, nT, F):
     assert rel_inf(g3, g2.astype(np.float64)) < 1e-5
 
 
+@pytest.mark.parametrize("Vt,Vr,nT,F,dt,de,dr,H", [(40, 70, 2, 4, 16, 32, 16, 64), (100, 9, 1, 3, 48, 32, 16, 96), (6, 128, 3, 5, 20, 40, 36, 96)])
+def test_table_gradients_on_the_matrix_cores_for_larger_tables_and_several_type_slots(Vt, Vr, nT, F, dt, de, dr, H):
+    """kk::k_table_grad_mfma (generic pipelines): tables of more than 16 rows take several 16-row tiles (tiles nobody's id falls into are
+    skipped), several type slots send the same dx to every slot's row, slices that are not a multiple of 16 columns mask their tail lanes --
+    type_emb / relation_emb gradients against the f64 oracle (the named configs only exercise <= 16 rows or one slot)."""
+    eng, o64, theta = mk(Vt=Vt, Vr=Vr, dt=dt, de=de, dr=dr, H=H, L=1, F=F, nT=nT, impl="generic")
+    idx, labels = synth.make_paths(300, 3, 6, F=F, Vt=Vt, Ve=300, Vr=Vr, num_types=nT, seed=17)
+    b = eng.batch(idx, labels)
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels, class_id=1)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], og[off:off + n]) < GRAD_RTOL, nm
+    # row by row: a misplaced row tile would hide in a matrix norm
+    for nm in ("type_emb", "relation_emb"):
+        off, shp = eng.layout()[nm]
+        ge = g[off:off + int(np.prod(shp))].reshape(shp).astype(np.float64)
+        go = og[off:off + int(np.prod(shp))].reshape(shp)
+        scale = np.abs(go).max()
+        assert np.max(np.abs(ge - go)) < 2e-5 * scale, nm
+        assert np.count_nonzero(np.abs(go).sum(axis=1)) >= min(shp[0], 8) - 2  # (several rows really received gradient; the last id of a vocabulary is unused by the generator)
+
+
 @pytest.mark.parametrize("impl", IMPLS)
 def test_odd_sizes_shipped_config_shape(impl):
     """run_scripts/config.sh: d = 50/100/50, H = 250 (not a multiple of 16), L = 1."""
