@@ -453,6 +453,119 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
       }
     }
 }
+
+// ---- 256 x 192 x 32 tiles for N = a multiple of 192 (configs[3]: N = 384); opt-in (KPRN_BF16_GEMM=y), a measured non-improvement ------------------
+// The idea: k_gemm16x is balanced on the LDS pipe: a 64 x 64 per-wave tile reads 1 KiB of LDS per v_mfma_f32_32x32x16_bf16 and the CU's 128 B/clk feed exactly
+// four SIMDs at 32 cycles per MFMA.  Here a wave owns 64 x 96 (2 x 3 MFMA tiles: 0.83 KiB per MFMA), N = 384 is two column tiles instead of three (A is
+// fetched twice, not three times), and four 28 KB stages of 32 k keep three chunks in flight.  LDS rows are 64 bytes (4 pieces of 16): one DMA
+// instruction covers 16 rows x 4 pieces, lane l -> row l >> 2, slot l & 3, and fetches piece slot ^ ((row >> 1) & 3) -- eight consecutive rows then
+// occupy the eight 16-byte granules of a 128-byte LDS phase exactly once for any piece, which is what a ds_read_b128 of a 32-row fragment touches.
+// A stage is 28 instructions: waves 0-3 issue four of them (q = w, w + 8, w + 16, w + 24), waves 4-7 three -- the counted vmcnt differs by wave.
+constexpr int YBM = 256, YBN = 192, YBK = 32, YSTAGE = 4;
+constexpr int YSTAGE_BYTES = (YBM + YBN) * YBK * 2;
+template <bool ACCUM>
+__global__ __launch_bounds__(NTHR, 2) void k_gemm16y(XArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kg = lane >> 5;
+  const int64_t id = blockIdx.x;
+  const int xcd = (int)(id & 7);
+  const int64_t j = id >> 3;
+  int nt_idx; int64_t mt_idx, split_idx = 0;
+  if (a.nsplit > 1) {   // all tiles of one K range on one XCD
+    const int64_t tiles = a.mtiles * a.ntiles;
+    split_idx = (j / tiles) * 8 + xcd;
+    const int64_t tl = j % tiles;
+    mt_idx = tl / a.ntiles; nt_idx = (int)(tl % a.ntiles);
+    if (split_idx >= a.nsplit) return;
+  } else {              // the n-tiles of one m-tile back to back on one XCD: its A rows are fetched into that L2 once
+    nt_idx = (int)(j % a.ntiles);
+    mt_idx = (j / a.ntiles) * 8 + xcd;
+    if (mt_idx >= a.mtiles) return;
+  }
+  const int64_t m0 = mt_idx * YBM;
+  const int n0 = nt_idx * YBN;
+  const int64_t k_beg = split_idx * a.kchunk;
+  const int64_t k_end = (k_beg + a.kchunk < a.K) ? k_beg + a.kchunk : a.K;
+  const int nch = (k_end > k_beg) ? (int)((k_end - k_beg + YBK - 1) / YBK) : 0;
+  if (nch == 0) return;
+  const int nq = wave < 4 ? 4 : 3;   // (wave-uniform) DMA instructions of this wave per chunk
+  const bf16* rowp[4]; int piece[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = wave + 8 * i;              // instruction q covers tile rows 16 q .. 16 q + 15 (A: q < 16, B: 16 <= q < 28)
+    const bool isA = q < YBM / 16;
+    const int row = 16 * (isA ? q : q - YBM / 16) + (lane >> 2);
+    const int64_t gr = (isA ? m0 : (int64_t)n0) + row;
+    const bool ok = q < (YBM + YBN) / 16 && gr < (isA ? a.M : (int64_t)a.N);
+    rowp[i] = ok ? (isA ? a.A + gr * a.lda : a.B + gr * a.ldb) : nullptr;
+    piece[i] = (lane & 3) ^ ((row >> 1) & 3);
+  }
+  const unsigned lds0 = lds_off(smem);
+  auto issue = [&](int c) {
+    const int64_t k0 = k_beg + (int64_t)c * YBK;
+    const unsigned st = lds0 + (unsigned)(c % YSTAGE) * YSTAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i == 3 && wave >= 4) break;   // (wave-uniform)
+      const int64_t k = k0 + 8 * piece[i];
+      const bf16* src = (rowp[i] && k < k_end) ? rowp[i] + k : a.zero;
+      dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + (unsigned)(wave + 8 * i) * 1024u)));
+    }
+  };
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 3; ++jn)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
+  issue(0);
+  if (nch > 1) issue(1);
+  if (nch > 2) issue(2);
+  const int key = (r >> 1) & 3;
+  const int arow = (wm * 64 + r) * 64, brow = YBM * 64 + (wn * 96 + r) * 64;
+  for (int c = 0; c < nch; ++c) {
+    // chunk c has landed for this wave: at most the pieces of the chunks behind it (up to two) may still be in flight
+    const int behind = (nch - 1 - c) < 2 ? (nch - 1 - c) : 2;
+    if (nq == 4) {
+      if (behind == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (behind == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (behind == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... for every wave; and every wave is done reading the stage chunk c + 3 overwrites
+    if (c + 3 < nch) issue(c + 3);
+    const char* st = smem + (c % YSTAGE) * YSTAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int po = ((2 * kk + kg) ^ key) << 4;
+      bf16x8 fa[2], fb[3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(st + arow + i * 32 * 64 + po);
+#pragma unroll
+      for (int jn = 0; jn < 3; ++jn) fb[jn] = *(const bf16x8*)(st + brow + jn * 32 * 64 + po);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 3; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 3; ++jn) {
+      const int n = n0 + wn * 96 + jn * 32 + r;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+        if (m >= a.M) continue;
+        float* dst = a.C + m * a.ldc + n;
+        if (ACCUM) unsafeAtomicAdd(dst, acc[i][jn][q]); else *dst = acc[i][jn][q];
+      }
+    }
+}
 }  // namespace gx
 
 static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K, bool accumulate,
@@ -462,7 +575,12 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   gx::XArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero = zero16();
-  a.mtiles = (M + gx::BM - 1) / gx::BM; a.ntiles = (N + gx::BN - 1) / gx::BN;
+  // KPRN_BF16_GEMM=y: 256 x 192 tiles where they divide N (configs[3]: N = 384).  Measured equal to the 256 x 128 kernel on dx / dh (0.743 : 0.750,
+  // 0.110 : 0.107 ms) and slower on the split-K dW (12 tiles deal worse over 8 XCDs than 18): opt-in, kept as the record of that measurement
+  static const bool want_y = getenv("KPRN_BF16_GEMM") && getenv("KPRN_BF16_GEMM")[0] == 'y';
+  const bool y = want_y && (N % gx::YBN) == 0;
+  const int bn = y ? gx::YBN : gx::BN, bk = y ? gx::YBK : gx::BK;
+  a.mtiles = (M + gx::BM - 1) / gx::BM; a.ntiles = (N + bn - 1) / bn;
   if (split_k < 1 || !accumulate) split_k = 1;
   if (split_k > 1) {
     // K ranges are dealt to the XCDs (range r on XCD r % 8, all its tiles there), one workgroup per CU (147 KB of LDS), 32 CUs per XCD:
@@ -481,19 +599,24 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
     split_k = best * 8;
   }
   int64_t kchunk = (K + split_k - 1) / split_k;
-  kchunk = ((kchunk + gx::BK - 1) / gx::BK) * gx::BK;
+  kchunk = ((kchunk + bk - 1) / bk) * bk;
   split_k = (int)((K + kchunk - 1) / kchunk);
   a.kchunk = kchunk; a.nsplit = split_k;
-  const size_t lds_bytes = (size_t)gx::NSTAGE * gx::STAGE_BYTES;
+  const size_t lds_bytes = y ? (size_t)gx::YSTAGE * gx::YSTAGE_BYTES : (size_t)gx::NSTAGE * gx::STAGE_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::NSTAGE * gx::STAGE_BYTES)));
+    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::NSTAGE * gx::STAGE_BYTES)));
+    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16y<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::YSTAGE * gx::YSTAGE_BYTES)));
+    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16y<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::YSTAGE * gx::YSTAGE_BYTES)));
     attr_done = true;
   }
   dim3 grid((unsigned)(((a.mtiles + 7) / 8) * 8 * a.ntiles));
   if (split_k > 1) grid = dim3((unsigned)(((split_k + 7) / 8) * 8 * a.mtiles * a.ntiles));
-  if (accumulate) hipLaunchKernelGGL((gx::k_gemm16x<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
+  if (y) {
+    if (accumulate) hipLaunchKernelGGL((gx::k_gemm16y<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
+    else hipLaunchKernelGGL((gx::k_gemm16y<false>), grid, dim3(gx::NTHR), lds_bytes, s, a);
+  } else if (accumulate) hipLaunchKernelGGL((gx::k_gemm16x<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
   else hipLaunchKernelGGL((gx::k_gemm16x<false>), grid, dim3(gx::NTHR), lds_bytes, s, a);
   HIP_TRY(hipGetLastError());
   return true;
