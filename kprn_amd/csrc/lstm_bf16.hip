@@ -771,12 +771,12 @@ __global__ void k_gates_bwd16(const bf16* __restrict__ act, const float* __restr
   dH[gid] = 0.f;
 }
 // The same cell backward on the persistent layer kernel's FRAGMENT-order saves (lstm_bf16_persist.hip Cell::store): record ((unit NCH + chunk) NW + wave) 64 +
-// lane holds, for path 32 unit + (lane & 31) and hidden units HC chunk + 8 wave + 4 (lane >> 5) .. + 3, c (4 floats) and the gates as [i4 g4] / [f4 o4].
+// lane holds, for path 32 unit + (lane & 31) and hidden units HC chunk + 8 wave + 4 (lane >> 5) .. + 3, c (4 bf16: a copy of the fp32 cell state the recurrence itself runs on) and the gates as [i4 g4] / [f4 o4].
 // One workgroup = one (unit, chunk): 32 rows x HC hidden units.  The records are read coalesced; everything row-major (dH, dC in / out, dA out) goes
 // through LDS tiles so that global accesses are whole 128 / 256-byte row segments.
 template <int NW>
-__global__ __launch_bounds__(256) void k_gates_bwd16_frag(const bf16x8* __restrict__ A0, const bf16x8* __restrict__ A1, const f32x4* __restrict__ cF,
-                                                          const f32x4* __restrict__ cprevF, const float* __restrict__ dH_up, const float* __restrict__ dH,
+__global__ __launch_bounds__(256) void k_gates_bwd16_frag(const bf16x8* __restrict__ A0, const bf16x8* __restrict__ A1, const bf16x4* __restrict__ cF,
+                                                          const bf16x4* __restrict__ cprevF, const float* __restrict__ dH_up, const float* __restrict__ dH,
                                                           float* __restrict__ dC, bf16* __restrict__ dA, int64_t N, int H, bf16* __restrict__ dAT /* nullable: this
                                                           step's column block of dA^T [4H][T Np] */, int64_t ldT, int64_t Np, int64_t NU, int units_per_wg,
                                                           float* __restrict__ gbias /* nullable: [4H] += column sums of dA (the bias gradient) */) {
@@ -812,8 +812,14 @@ __global__ __launch_bounds__(256) void k_gates_bwd16_frag(const bf16x8* __restri
       const int w = rl >> 6, lane = rl & 63, ln = lane & 31, ul = 8 * w + 4 * (lane >> 5);
       const int64_t rec = ((unit * NCH + c) * NW + w) * 64 + lane;
       const bf16x8 a0 = A0[rec], a1 = A1[rec];
-      const f32x4 cc = cF[rec];
-      const f32x4 cp = cprevF ? cprevF[rec] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bf16x4 cc16 = cF[rec];
+      bf16x4 cp16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cp16[j] = (bf16)0.f;
+      if (cprevF) cp16 = cprevF[rec];
+      f32x4 cc, cp;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { cc[j] = (float)cc16[j]; cp[j] = (float)cp16[j]; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float ig = (float)a0[j], gg = (float)a0[4 + j], fg = (float)a1[j], og = (float)a1[4 + j];
@@ -911,7 +917,7 @@ __global__ __launch_bounds__(256) void k_rowsum16(const bf16* __restrict__ x, in
 
 // ---- state + orchestration --------------------------------------------------------------------------------------------------
 // lstm_bf16_persist.hip: fragment-order saves of the persistent layer kernel's training launch
-struct PersistSaves { const float* CsF; const bf16* ActF0; const bf16* ActF1; int64_t NU, step_recs; int NW; };
+struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; int64_t NU, step_recs; int NW; };
 
 struct State {
   bf16* We16 = nullptr; bool we_all_dirty = true;
@@ -1124,8 +1130,8 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
           const int NCH = H / (8 * v.NW);
           const bf16x8* a0 = (const bf16x8*)v.ActF0 + (int64_t)t * v.step_recs;
           const bf16x8* a1 = (const bf16x8*)v.ActF1 + (int64_t)t * v.step_recs;
-          const f32x4* cf = (const f32x4*)v.CsF + (int64_t)t * v.step_recs;
-          const f32x4* cpf = t > 0 ? (const f32x4*)v.CsF + (int64_t)(t - 1) * v.step_recs : nullptr;
+          const bf16x4* cf = (const bf16x4*)v.CsF + (int64_t)t * v.step_recs;
+          const bf16x4* cpf = t > 0 ? (const bf16x4*)v.CsF + (int64_t)(t - 1) * v.step_recs : nullptr;
           const float* up = has_up ? w.dIn + (int64_t)t * N * H : nullptr;
           const int64_t Np_ = (N + 7) & ~(int64_t)7;
           bf16* dat = s->dAT16 + (int64_t)t * Np_;   // (this kernel has the tile in LDS: it writes the transposed image too, no transpose pass for dA)

@@ -65,7 +65,7 @@ struct Args {
   bf16* hscr;        // per workgroup: 2 x [MAXPT][H/16][64][8]  h_t in B-fragment order (ping-pong over steps)
   float* cscr;       // per workgroup: [H/32][MAXPT][4][64][4]   c_t in accumulator order (scoring)
   bf16* H16;         // SAVE: h_t row-major [T][N][H] (the backward's dW product reads it)
-  float* CsF; bf16* ActF0; bf16* ActF1; int64_t NU;   // SAVE: c_t and the gate activations in FRAGMENT order (see Cell::store), NU = units of 32 rows
+  bf16* CsF; bf16* ActF0; bf16* ActF1; int64_t NU;   // SAVE: c_t (bf16) and the gate activations in FRAGMENT order (see Cell::store), NU = units of 32 rows
   float* hT;         // [N][H] fp32 h_T (the head's input)
   int64_t units;     // ceil(N / 32)
 };
@@ -154,11 +154,9 @@ struct Cell {
     for (int pt = 0; pt < NPT; ++pt) {
       cpn[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t > 0 && !(DBG & 16)) {
-        if (SAVE) {   // the saved plane of step t - 1, fragment order: [t][unit][chunk][wave][lane] x 4 floats -- one contiguous KiB per wave
-          cpn[pt] = ldb<f32x4>(make_rsrc(a.CsF + (((((int64_t)(t - 1) * a.NU + row0 / 32 + pt) * (H / HC) + c) * NW + wave) * 64) * 4), (unsigned)lane * 16u, 0);
-        } else {
-          cpn[pt] = ldb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((c * MAXPT + pt) * NW + wave) * 1024u);
-        }
+        // (scoring and training alike: the recurrence runs on the fp32 c of this workgroup's L2-resident slab, so the two launches compute the same
+        //  forward; the training launch's saved plane is a bf16 copy for the backward)
+        cpn[pt] = ldb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((c * MAXPT + pt) * NW + wave) * 1024u);
       }
     }
   }
@@ -191,16 +189,18 @@ struct Cell {
       // stores per lane and chunk: 1.27 ms against 0.76 ms for the scoring launch); lstm_bf16.hip's k_gates_bwd16_frag reads them back coalesced
       // and does the re-layout to row-major through LDS on its own side.  Rows past N land in the padded tail of their unit.
       const int64_t rec = ((((int64_t)te * a.NU + row0 / 32 + pt) * (H / HC) + ce) * NW + wave) * 64;
-      stb<f32x4, KPRN_SAVE_AUX>(make_rsrc(a.CsF + rec * 4), (unsigned)lane * 16u, 0, cv);
+      bf16x4 cb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cb[j] = (bf16)cc[j];
+      stb<bf16x4, KPRN_SAVE_AUX>(make_rsrc(a.CsF + rec * 4), (unsigned)lane * 8u, 0, cb);   // (bf16: 0.3 GB less to HBM per launch; the backward's tanh(c), c_{t-1} f (1 - f) take it)
       bf16x8 v0, v1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v0[j] = (bf16)gi[j]; v0[4 + j] = (bf16)gg[j]; v1[j] = (bf16)gf[j]; v1[4 + j] = (bf16)go[j]; }
       stb<bf16x8, KPRN_SAVE_AUX>(make_rsrc(a.ActF0 + rec * 8), (unsigned)lane * 16u, 0, v0);
       stb<bf16x8, KPRN_SAVE_AUX>(make_rsrc(a.ActF1 + rec * 8), (unsigned)lane * 16u, 0, v1);
       if (ok) stb<bf16x4, KPRN_SAVE_AUX>(make_rsrc(a.H16 + ((int64_t)te * a.N + row0 + 32 * pt) * H + cu), lo_row(H, 2), 0, hb);
-    } else {
-      stb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((ce * MAXPT + pt) * NW + wave) * 1024u, cv);
     }
+    stb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((ce * MAXPT + pt) * NW + wave) * 1024u, cv);
     if (te == a.T - 1 && ok) stb<f32x4>(make_rsrc(a.hT + (row0 + 32 * pt) * H + cu), lo_row(H, 4), 0, hv);
   }
 
@@ -472,12 +472,12 @@ __global__ void k_pack_w(const float* __restrict__ Wi, const float* __restrict__
 }  // namespace pk
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-struct PersistSaves { const float* CsF; const bf16* ActF0; const bf16* ActF1; int64_t NU, step_recs; int NW; };   // (also declared in lstm_bf16.hip)
+struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; int64_t NU, step_recs; int NW; };   // (also declared in lstm_bf16.hip)
 struct PersistState {
   bf16* Wp = nullptr; float* Bp = nullptr; bf16* hscr = nullptr; float* cscr = nullptr;
   int grid = 0;
   int packed_nw = 0;   // waves per workgroup the packed weights are laid out for
-  float* CsF = nullptr; bf16* ActF0 = nullptr; bf16* ActF1 = nullptr; int64_t save_recs = 0;   // training saves, fragment order
+  bf16* CsF = nullptr; bf16* ActF0 = nullptr; bf16* ActF1 = nullptr; int64_t save_recs = 0;   // training saves, fragment order
 };
 
 bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b) {
@@ -557,7 +557,7 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
     if (recs > q->save_recs) {
       HIP_TRY(hipStreamSynchronize(strm));
       for (void* x : {(void*)q->CsF, (void*)q->ActF0, (void*)q->ActF1}) if (x) hipFree(x);
-      q->CsF = pal<float>(recs * 4); q->ActF0 = pal<bf16>(recs * 8); q->ActF1 = pal<bf16>(recs * 8);
+      q->CsF = pal<bf16>(recs * 4); q->ActF0 = pal<bf16>(recs * 8); q->ActF1 = pal<bf16>(recs * 8);
       q->save_recs = recs;
     }
     a.CsF = q->CsF; a.ActF0 = q->ActF0; a.ActF1 = q->ActF1;
