@@ -498,7 +498,7 @@ __global__ void k_head_bwd(const float* __restrict__ dS, const float* __restrict
     for (int64_t n = r0; n < r1; ++n) {
       float d = dS[n];
       acc += d * hT[n * H + j];
-      dH[n * H + j] = d * w;
+      if (dH) dH[n * H + j] = d * w;
     }
     unsafeAtomicAdd(gWout + (int64_t)cid * H + j, acc);
   }

@@ -928,6 +928,8 @@ struct State {
   bf16 *X16 = nullptr, *XT16 = nullptr, *H16 = nullptr, *HT16 = nullptr, *ACT16 = nullptr, *dA16 = nullptr, *dAT16 = nullptr;
   void* persist = nullptr;      // lstm_bf16_persist.hip: packed weights + scratch slabs of the persistent layer kernel
   bool pack_dirty = true;       // its packed weights are stale
+  void* persist_bwd = nullptr;  // lstm_bf16_bwd_persist.hip: packed W_o2g^T fragments of the persistent BPTT kernel
+  bool packb_dirty = true;
   bool bias_in_gates = false;   // k_gates_bwd16_frag also summed the bias gradient (measurement switch)
   bool act_frag = false;        // the last training forward wrote c and the gate planes in fragment order (persistent kernel; k_gates_bwd16_frag)
   PersistSaves sv{};
@@ -937,6 +939,10 @@ bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b);
 void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, bool repack, const bf16* Wt16, const bf16* We16, const bf16* Wr16, bf16* H16,
                      PersistSaves* sv);
 void persist_release(void*& st);
+// lstm_bf16_bwd_persist.hip: BPTT through the layer (cell backward + recurrent product of all T steps) as one persistent launch
+bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv);
+void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16, bf16* dAT16, int64_t Np);
+void persist_bwd_release(void*& st);
 static State* st(kprn_handle* h) {
   if (!h->bf16_state) h->bf16_state = new State();
   return (State*)h->bf16_state;
@@ -964,6 +970,7 @@ void params_changed(kprn_handle* h, bool entity_rows_only) {
   State* s = (State*)h->bf16_state;
   s->dense_dirty = true;
   s->pack_dirty = true;
+  s->packb_dirty = true;
   if (!entity_rows_only) s->we_all_dirty = true;
 }
 
@@ -983,6 +990,7 @@ void release(kprn_handle* h) {
   if (!s) return;
   for (bf16* p : {s->We16, s->dense16, s->WT16, s->X16, s->XT16, s->H16, s->HT16, s->ACT16, s->dA16, s->dAT16}) if (p) hipFree(p);
   persist_release(s->persist);
+  persist_bwd_release(s->persist_bwd);
   delete s;
   h->bf16_state = nullptr;
 }
@@ -1104,12 +1112,14 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   const int H = c.H, L = c.L, T = b->T, D = h->D, G4 = 4 * c.H;
   const int64_t N = (int64_t)b->B * b->P, TN = (int64_t)T * N;
   float* gd = h->g_dense;
+  // the persistent BPTT launch forms dh_T = dS W_out[cid] itself and keeps dh / dc on the chip: no dH plane, no dC plane
+  const bool bptt_persist = s->act_frag && L == 1 && persist_bwd_shape_ok(h, s->sv);
   {
     ProfScope ps(h, "head_bwd");
     const float* hT = w.Hs + ((int64_t)(L - 1) * T + (T - 1)) * N * H;
-    kk::head_bwd(strm, w.dS, hT, h->dense + h->off_outW, N, H, cid, w.dH, gd + h->off_outW, gd + h->off_outb);
+    kk::head_bwd(strm, w.dS, hT, h->dense + h->off_outW, N, H, cid, bptt_persist ? nullptr : w.dH, gd + h->off_outW, gd + h->off_outb);
   }
-  HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), strm));
+  if (!bptt_persist) HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), strm));
   for (int l = L - 1; l >= 0; --l) {
     const int Din = h->layer[l].Din;
     const bf16* act = s->ACT16 + (int64_t)l * TN * G4;
@@ -1121,7 +1131,13 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), strm));
       HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), strm));
     }
-    for (int t = T - 1; t >= 0; --t) {
+    if (bptt_persist) {
+      const int64_t Np_ = (N + 7) & ~(int64_t)7;
+      persist_backward(h, N, T, cid, s->sv, s->persist_bwd, s->packb_dirty, s->dA16, s->dAT16, Np_);
+      s->packb_dirty = false;
+      s->bias_in_gates = true;   // (the launch sums the bias gradient from the dA^T pieces it writes)
+    }
+    for (int t = T - 1; t >= 0 && !bptt_persist; --t) {
       bf16* dA_t = s->dA16 + (int64_t)t * N * G4;
       {
         ProfScope ps(h, "lstm_gates_bwd_bf16");

@@ -1,0 +1,394 @@
+// hipcc-flags: -fno-slp-vectorize
+// configs[3] (BASELINE.json: 20 M entities, d = 128 -> D = H = 384, "bf16 MFMA LSTM"): BPTT through the FastLSTM layer as ONE persistent launch.
+//
+// Stands for the backward of   nn.Sequencer(nn.FastLSTM(D, H)), all T steps     release/songPathRnn/model/OneModel.lua:236,268-274
+// (gradInput of the T cells + the recurrent gradient dh_{t-1} = dA_t W_o2g) at the bf16 pipeline's precision, replacing per step one
+// k_gates_bwd16_frag launch (1.2 GB of HBM traffic each: saves in, dH / dC in and out, dA and dA^T out) and one dh GEMM launch
+// (lstm_bf16.hip backward(): 6 + 5 launches, 1.8 ms of the 6.6 ms step).  What those launches paid for was state through HBM: dH and dC
+// (fp32, [N][H]) round-tripped every step, dA re-read by the recurrent product.  Here a workgroup owns a 64-path tile for t = T-1 .. 0:
+//   * dc_t and the accumulators of dh_{t-1} never leave registers (2 x 96 per lane: one wave per SIMD, the 512-entry file); the finished
+//     dh_t waits in LDS in lane-private 16-byte slots (96 KB: written once per step, read back quad by quad -- no barrier, no conflicts).
+//   * The recurrent product is taken TRANSPOSED on v_mfma_f32_32x32x16_bf16, as in the forward (lstm_bf16_persist.hip): the weight
+//     fragment (W_o2g^T: 32 hidden units x 16 gate columns) is the A operand, dA_t (16 gate columns x 32 paths) the B operand.  In the
+//     C/D layout a lane then holds dh_{t-1} of FOUR CONSECUTIVE HIDDEN UNITS of one path per register quad -- exactly the (path, 4 units)
+//     quad whose saved gates the forward wrote as one record of its fragment-order planes (Cell::store): the cell backward is lane-local
+//     on the accumulators and every save is read with one coalesced 1 KiB wave load.
+//   * K (the 4H = 1536 gate columns) is walked in 12 chunks of 32 hidden units x 4 gates.  Wave w's three 32-row result tiles are
+//     composed so that register quad q of tile j is this lane's quad of chunk 4 j + q (rows 8 q + 4 half + r <-> hidden unit
+//     32 (4 j + q) + 8 w + 4 half + r): per chunk EVERY lane of EVERY wave owns exactly one quad per path tile, so the cell backward of
+//     chunk c + 1 is spread evenly over the four SIMDs' VALUs while the matrix cores run chunk c's product.
+//   * dA of a chunk goes to LDS in B-FRAGMENT order (a lane's [di4 dg4] / [df4 do4] are two 16-byte pieces of k-step 2 w + half:
+//     the store is one ds_write_b128 into the lane's own slot, the product's operand read one ds_read_b128), double buffered:
+//     2 x 16 KB.  Each weight fragment (1 KiB, packed by k_pack_wb in exactly the order it is read) is fetched L2 -> registers by
+//     exactly ONE wave and used for both path tiles.
+//   * Outputs per chunk: dA row-major (the dx product's operand), dA^T in 16-byte pieces of 8 consecutive paths (the split-K dW
+//     products' k-contiguous operand) gathered from the LDS tile, and the bias gradient = row sums of dA^T, kept in an LDS table for
+//     the whole launch and flushed with one atomic per gate column per workgroup.
+// HBM-bound by construction: per (path, step) it reads 4.6 KB of saves and writes 6 KB (dA + dA^T); the product and the cell ride under that.
+// Index algebra replayed lane by lane in numpy: tests/test_persist_layout.py (backward model).
+#include <string.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "kprn_internal.h"
+
+namespace bf16p {
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace pb {
+
+constexpr int H = 384;          // hidden units (instantiated shape)
+constexpr int NPT = 2;          // path tiles (32 rows) of a work tile
+constexpr int NW = 4;           // waves per workgroup, one per SIMD
+constexpr int MJ = 3;           // 32-row result tiles per wave: NW * MJ * 32 = H
+constexpr int NCH = 12;         // K chunks: 32 hidden units x 4 gates = 128 gate columns = 8 k-steps
+constexpr int KSC = 8;          // k-steps per chunk
+constexpr int FR = NCH * KSC * MJ;   // weight fragments per wave and step (288 KiB)
+constexpr int PF = 12;          // fragments in flight per wave (4 k-steps ahead; divides the fragments of a chunk)
+constexpr int UREC = H / 4 * 32;     // records (quads) of one unit of 32 rows and one step: [forward chunk 6][forward wave 8][lane 64]
+constexpr int BUF = NPT * KSC * 1024;   // bytes of one dA chunk tile in LDS
+static_assert(NW * MJ * 32 == H && NCH * 32 == H && MJ * 4 == NCH && (KSC * MJ) % PF == 0, "shape algebra of the backward tile");
+
+struct BArgs {
+  const bf16x8* A0; const bf16x8* A1; const bf16x4* cF;   // the forward's fragment-order saves: [i4 g4], [f4 o4], c (records of 4 hidden units)
+  int64_t NU, step_recs;     // units of 32 rows; records per step (= NU UREC)
+  const float* dS;           // [N] d loss / d S[n][cid]
+  const float* Wc;           // [H] row cid of out.weight: dh_T[n] = dS[n] Wc
+  const bf16* WpB;           // packed W_o2g^T fragments [NW][FR][64 lanes][8]
+  bf16* dA;                  // [T][N][4H] row-major
+  bf16* dAT;                 // [4H][ldT], this step's block at column t Np
+  float* gbias;              // [4H] += column sums of dA (the bf16-rounded values)
+  int64_t N, Np, ldT; int T;
+  int64_t tiles;             // ceil(N / 64)
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// workgroup barrier ordering LDS traffic only (the save prefetches, the weight ring and the dA stores stay in flight across it)
+__device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000); }
+template <class V> __device__ __forceinline__ V ldb(rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(V) == 16) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+  else { static_assert(sizeof(V) == 8, "8- or 16-byte pieces"); return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0)); }
+}
+template <class V> __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, V v) {
+  static_assert(sizeof(V) == 8, "8-byte pieces");
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
+}
+
+__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f; }
+
+// the saves of this lane's quad of one chunk, per path tile
+struct Sv { bf16x8 a0[NPT], a1[NPT]; bf16x4 c[NPT], cp[NPT]; };
+
+__global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* const buf = smem;                          // 2 x BUF: dA chunk tiles [pt][k-step][slot][16 B]
+  float* const sdb = (float*)(smem + 2 * BUF);     // [4H] bias-gradient sums of this workgroup
+  char* const dhl = smem + 2 * BUF + 4 * H * 4 + threadIdx.x * 16;   // dh_t of the tile: [(j NPT + pt) 4 + q][thread][16 B], this thread's slots
+  const int tid = threadIdx.x, lane = tid & 63, ln = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t G = gridDim.x, b = blockIdx.x;
+  const int64_t t_beg = a.tiles * b / G, t_end = a.tiles * (b + 1) / G;
+  if (t_beg >= t_end) return;
+  for (int i = tid; i < 4 * H; i += 64 * NW) sdb[i] = 0.f;
+  const int T = a.T;
+  const rsrc_t rW = make_rsrc(a.WpB + (int64_t)w * FR * 512);
+  const unsigned l16 = (unsigned)lane * 16u, l8 = (unsigned)lane * 8u;
+  bf16x8 ring[PF];
+  if (T > 1) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) ring[s] = ldb<bf16x8>(rW, l16, (unsigned)s * 1024u);
+  }
+  // the dA^T pass of a chunk: thread -> (octet of 8 consecutive paths, gate column kc = (tid >> 3) + 32 i of the chunk's 128)
+  // gate column kc of a chunk: k-step kc >> 4, k-group (kc >> 3) & 1, element kc & 7  ->  LDS piece, and row (gate H + unit) of dA^T / the bias gradient
+  const int oct = tid & 7, kc0 = tid >> 3;
+  int et_src[4];       // byte offset of this thread's first element inside a chunk tile
+  int64_t et_row[4];   // its row of dA^T, without the chunk's 32 c
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kc = kc0 + 32 * i, ks = kc >> 4, kg = (kc >> 3) & 1, e = kc & 7;
+    et_src[i] = (((oct >> 2) * KSC + ks) * 64 + 32 * kg + 8 * (oct & 3)) * 16 + 2 * e;
+    et_row[i] = (2 * kg + (e >> 2)) * H + 8 * (ks >> 1) + 4 * (ks & 1) + (e & 3);
+  }
+  bar();
+
+  for (int64_t tile = t_beg; tile < t_end; ++tile) {
+    const int64_t row0 = tile * 64;
+    // units of 32 rows of the tile (the second may lie past the end: its lanes are masked, its loads stay in range)
+    const int64_t u0 = tile * NPT;
+    const unsigned d1_16 = (u0 + 1 < a.NU) ? (unsigned)UREC * 16u : 0u;   // byte distance of path tile 1's records (16-byte planes)
+    bool valid[NPT];
+    float ds[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+      const int64_t n = row0 + 32 * pt + ln;
+      valid[pt] = n < a.N;
+      ds[pt] = valid[pt] ? a.dS[n] : 0.f;
+    }
+    // saves of (step t, chunk c): forward group of 8 hidden units G8 = 4 c + w = (forward chunk G8 >> 3, forward wave G8 & 7), record
+    // ((unit NCHF + chunk) 8 + wave) 64 + lane  ->  byte offset (4 c + w) 1024 (+ 16 lane) inside the unit's block of a 16-byte plane
+    auto request = [&](int t, auto cc, Sv& s) {
+      constexpr int c = decltype(cc)::value;
+      const int64_t r0 = (int64_t)t * a.step_recs + u0 * UREC;
+      const rsrc_t r_a0 = make_rsrc(a.A0 + r0), r_a1 = make_rsrc(a.A1 + r0), r_c = make_rsrc(a.cF + r0);
+      const unsigned so = (unsigned)(4 * c + w) * 1024u;
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) {
+        const unsigned sp = so + (pt ? d1_16 : 0u);
+        s.a0[pt] = ldb<bf16x8>(r_a0, l16, sp);
+        s.a1[pt] = ldb<bf16x8>(r_a1, l16, sp);
+        s.c[pt] = ldb<bf16x4>(r_c, l8, sp >> 1);
+      }
+      if (t > 0) {
+        const rsrc_t r_p = make_rsrc(a.cF + (r0 - a.step_recs));
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) s.cp[pt] = ldb<bf16x4>(r_p, l8, (so + (pt ? d1_16 : 0u)) >> 1);
+      } else {
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s.cp[pt][q] = (bf16)0.f;
+      }
+    };
+
+    // ---- state of the tile: dc_t and the accumulators of dh_{t-1} (register 4 q + r of tile j <-> chunk 4 j + q, unit r of the lane's quad);
+    // dh_t in LDS.  dh_T = dS[n] W_out[cid] (nn.Linear backward on the selected column), this lane's slice Wc[32 c + 8 w + 4 half + r]
+    f32x16 acc[MJ][NPT], dcs[MJ][NPT];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const f32x4 wq = *(const f32x4*)(a.Wc + 32 * c + 8 * w + 4 * half);
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) *(f32x4*)(dhl + (((c >> 2) * NPT + pt) * 4 + (c & 3)) * 4096) = wq * ds[pt];
+    }
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dcs[j][pt][r] = 0.f; acc[j][pt][r] = 0.f; }
+
+    Sv sv[2];
+    request(T - 1, std::integral_constant<int, 0>{}, sv[0]);
+    request(T - 1, std::integral_constant<int, 1>{}, sv[1]);
+
+    for (int t = T - 1; t >= 0; --t) {
+      const rsrc_t r_dA = make_rsrc(a.dA + ((int64_t)t * a.N + row0) * (4 * H));
+      bf16* const dat_t = a.dAT + (int64_t)t * a.Np + row0;
+      const bool et_ok = row0 + 8 * oct < a.Np;
+
+      // cell backward of chunk c on this lane's quads -> dA pieces to LDS tile (c & 1) and to the row-major plane
+      auto gate = [&](auto cc, const Sv& s) {
+        constexpr int c = decltype(cc)::value, j = c >> 2, q = c & 3;
+        char* const dst = buf + (c & 1) * BUF;
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+          bf16x8 p0, p1;
+          bf16x4 vi, vg, vf, vo;
+          const f32x4 dh4 = *(const f32x4*)(dhl + ((j * NPT + pt) * 4 + q) * 4096);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ig = (float)s.a0[pt][r], gg = (float)s.a0[pt][4 + r], fg = (float)s.a1[pt][r], og = (float)s.a1[pt][4 + r];
+            const float tc = tanh_fast((float)s.c[pt][r]);
+            const float cp = (float)s.cp[pt][r];
+            const float dh = dh4[r];
+            const float dO = dh * tc;
+            const float dc = dcs[j][pt][4 * q + r] + dh * og * (1.f - tc * tc);
+            const bf16 di = (bf16)(dc * gg * ig * (1.f - ig));
+            const bf16 dg = (bf16)(dc * ig * (1.f - gg * gg));
+            const bf16 df = (bf16)(dc * cp * fg * (1.f - fg));
+            const bf16 dov = (bf16)(dO * og * (1.f - og));
+            dcs[j][pt][4 * q + r] = dc * fg;
+            p0[r] = di; p0[4 + r] = dg; p1[r] = df; p1[4 + r] = dov;
+            vi[r] = di; vg[r] = dg; vf[r] = df; vo[r] = dov;
+          }
+          // B-fragment order: k-step 2 w + half, k-group ab (piece [di dg] -> 0, [df do] -> 1), slot ln + 32 ab
+          *(bf16x8*)(dst + ((pt * KSC + 2 * w + half) * 64 + ln) * 16) = p0;
+          *(bf16x8*)(dst + ((pt * KSC + 2 * w + half) * 64 + 32 + ln) * 16) = p1;
+          if (valid[pt]) {
+            const unsigned vo_ = (unsigned)(((32 * pt + ln) * (4 * H) + 4 * half) * 2);
+            const unsigned so_ = (unsigned)((32 * c + 8 * w) * 2);
+            stb<bf16x4>(r_dA, vo_, so_, vi);
+            stb<bf16x4>(r_dA, vo_, so_ + (unsigned)(H * 2), vg);
+            stb<bf16x4>(r_dA, vo_, so_ + (unsigned)(2 * H * 2), vf);
+            stb<bf16x4>(r_dA, vo_, so_ + (unsigned)(3 * H * 2), vo);
+          }
+        }
+      };
+      // dA^T pieces and the bias sums of chunk c from its LDS tile
+      auto emit_T = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const char* const src = buf + (c & 1) * BUF;
+        // (the chunk's row block of dA^T as an opaque scalar: otherwise hipcc precomputes the 48 (chunk, i) row offsets of the whole step
+        //  as 64-bit VGPR pairs outside the step loop and spills a hundred registers for them)
+        int64_t cofs = (int64_t)(32 * c) * a.ldT;
+        asm volatile("" : "+s"(cofs));
+        bf16* const dat_c = dat_t + cofs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const char* p = src + et_src[i];
+          bf16x8 v;
+          float sum = 0.f;
+#pragma unroll
+          for (int x = 0; x < 8; ++x) { v[x] = *(const bf16*)(p + 16 * x); sum += (float)v[x]; }
+          if (et_ok) *(bf16x8*)(dat_c + et_row[i] * a.ldT + 8 * oct) = v;
+          sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+          if (oct == 0) sdb[et_row[i] + 32 * c] += sum;   // (one owner thread per gate column: no atomics)
+        }
+      };
+      // dh_{t-1} += W_o2g^T[:, chunk c] dA_t[chunk c]: 8 k-steps x 3 result tiles x 2 path tiles
+      auto product = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const char* const src = buf + (c & 1) * BUF + lane * 16;
+        static_for<0, KSC>([&](auto kk) __attribute__((always_inline)) {
+          constexpr int ks = decltype(kk)::value;
+          bf16x8 bf[NPT];
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt) bf[pt] = *(const bf16x8*)(src + (pt * KSC + ks) * 1024);
+          static_for<0, MJ>([&](auto jj) __attribute__((always_inline)) {
+            constexpr int j = decltype(jj)::value;
+            constexpr int f = (c * KSC + ks) * MJ + j, slot = f % PF;
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[j][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot], bf[pt], acc[j][pt], 0, 0, 0);
+            constexpr int fn = (f + PF) % FR;   // (the next step walks the same fragments again)
+            ring[slot] = ldb<bf16x8>(rW, l16, (unsigned)fn * 1024u);
+          });
+        });
+      };
+
+      gate(std::integral_constant<int, 0>{}, sv[0]);
+      request(t, std::integral_constant<int, 2>{}, sv[0]);
+      bar();
+      static_for<0, NCH>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        if (t > 0) product(cc);
+        emit_T(cc);
+        if constexpr (c + 1 < NCH) {
+          gate(std::integral_constant<int, c + 1>{}, sv[(c + 1) & 1]);
+          if constexpr (c + 3 < NCH) request(t, std::integral_constant<int, c + 3>{}, sv[(c + 1) & 1]);
+          else if (t > 0) request(t - 1, std::integral_constant<int, c + 3 - NCH>{}, sv[(c + 1) & 1]);
+        }
+        bar();
+      });
+      // dh_{t-1} is complete: it becomes the step's dh (lane-private LDS slots), the accumulators start again from zero
+      if (t > 0) {
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *(f32x4*)(dhl + ((j * NPT + pt) * 4 + q) * 4096) = f32x4{acc[j][pt][4 * q], acc[j][pt][4 * q + 1], acc[j][pt][4 * q + 2], acc[j][pt][4 * q + 3]};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][pt][r] = 0.f;
+          }
+      }
+    }
+  }
+  bar();
+  for (int i = tid; i < 4 * H; i += 64 * NW) {
+    const float v = sdb[i];
+    if (v != 0.f) unsafeAtomicAdd(a.gbias + i, v);
+  }
+}
+
+// ---- weight packing (whenever the dense parameters change) -----------------------------------------------------------------------
+// WpB[((w FR + f) 64 + lane)][e], f = (c KSC + ks) MJ + j: A fragment of result tile j of wave w for k-step ks of chunk c.  Lane = (m, kg):
+// row m <-> hidden unit 32 (4 j + (m >> 3)) + 8 w + (m & 7); element e <-> gate column k = 16 ks + 8 kg + e of the chunk = gate
+// 2 kg + (e >> 2) of hidden unit 32 c + 8 (ks >> 1) + 4 (ks & 1) + (e & 3) (the order the cell backward writes its pieces in).
+// Value: W_o2g[gate H + unit_k][unit_m]  (dh_{t-1}[m] = sum_k dA_t[k] W_o2g[k][m]).  From the fp32 master, rounded once.
+__global__ void k_pack_wb(const float* __restrict__ Wo, bf16* __restrict__ WpB) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)NW * FR * 64) return;
+  const int lane = (int)(i & 63);
+  const int f = (int)((i >> 6) % FR), w = (int)((i >> 6) / FR);
+  const int j = f % MJ, ks = (f / MJ) % KSC, c = f / (MJ * KSC);
+  const int m = lane & 31, kg = lane >> 5;
+  const int um = 32 * (4 * j + (m >> 3)) + 8 * w + (m & 7);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int gate = 2 * kg + (e >> 2), uk = 32 * c + 8 * (ks >> 1) + 4 * (ks & 1) + (e & 3);
+    o[e] = (bf16)Wo[(int64_t)(gate * H + uk) * H + um];
+  }
+  *(bf16x8*)(WpB + i * 8) = o;
+}
+
+}  // namespace pb
+
+// ---- host side --------------------------------------------------------------------------------------------------------------
+struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; int64_t NU, step_recs; int NW; };   // (also declared in lstm_bf16.hip)
+struct PersistBwdState { bf16* WpB = nullptr; int grid = 0; };
+
+bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv) {
+  static const bool off = getenv("KPRN_BF16_BWD_PERSIST") && getenv("KPRN_BF16_BWD_PERSIST")[0] == '0';
+  return !off && h->cfg.L == 1 && h->cfg.H == pb::H && sv.NW == 8;
+}
+
+void persist_bwd_release(void*& st) {
+  PersistBwdState* p = (PersistBwdState*)st;
+  if (!p) return;
+  if (p->WpB) (void)hipFree(p->WpB);
+  delete p;
+  st = nullptr;
+}
+
+// dA_t (row-major and transposed) for all steps + the bias gradient, from the persistent forward's saves; ws.dS holds d loss / d S[:, cid]
+void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16, bf16* dAT16, int64_t Np) {
+  hipStream_t strm = h->stream;
+  PersistBwdState* p = (PersistBwdState*)st;
+  if (!p) {
+    p = new PersistBwdState();
+    st = p;
+    int dev = 0, ncu = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    p->grid = ncu;
+    void* q = nullptr;
+    hipError_t e = kprn_dev_malloc(&q, (size_t)pb::NW * pb::FR * 1024 + 64);
+    if (e != hipSuccess) throw KprnError{KPRN_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e)};
+    p->WpB = (bf16*)q;
+    repack = true;
+  }
+  if (repack) {
+    const int64_t total = (int64_t)pb::NW * pb::FR * 64;
+    hipLaunchKernelGGL(pb::k_pack_wb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, strm, h->dense + h->layer[0].Wo, p->WpB);
+    HIP_TRY(hipGetLastError());
+  }
+  pb::BArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A0 = (const bf16x8*)sv.ActF0; a.A1 = (const bf16x8*)sv.ActF1; a.cF = (const bf16x4*)sv.CsF;
+  a.NU = sv.NU; a.step_recs = sv.step_recs;
+  a.dS = h->ws.dS; a.Wc = h->dense + h->off_outW + (int64_t)cid * pb::H;
+  a.WpB = p->WpB; a.dA = dA16; a.dAT = dAT16; a.gbias = h->g_dense + h->layer[0].bi;
+  a.N = N; a.Np = Np; a.ldT = (int64_t)T * Np; a.T = T;
+  a.tiles = (N + 63) / 64;
+  int grid = (int)std::min<int64_t>(p->grid, a.tiles);
+  if (const char* e = getenv("KPRN_PERSIST_BWD_GRID")) grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, atoi(e)));   // (tests: several tiles per workgroup at small N)
+  const size_t lds_bytes = (size_t)2 * pb::BUF + (size_t)4 * pb::H * sizeof(float) + (size_t)pb::MJ * pb::NPT * 4 * 4096;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute((const void*)pb::k_lstm16_bwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  ProfScope ps(h, "lstm_persist_bf16_bwd");
+  hipLaunchKernelGGL(pb::k_lstm16_bwd_persist, dim3(grid), dim3(64 * pb::NW), lds_bytes, strm, a);
+  HIP_TRY(hipGetLastError());
+}
+
+}  // namespace bf16p

@@ -130,3 +130,141 @@ def test_persistent_kernel_index_algebra():
     hr, cr = reference(x, Wi, Wo, bi, H)
     assert np.max(np.abs(hT - hr)) < 1e-12
     assert np.max(np.abs(cT - cr)) < 1e-12
+
+
+# ---- the persistent BPTT kernel (kprn_amd/csrc/lstm_bf16_bwd_persist.hip) ------------------------------------------------------------
+# Formulas under test: k_pack_wb's fragment order, the forward-record addressing (4 c + w = forward chunk * 8 + forward wave), the
+# B-fragment placement of the cell backward's [di dg] / [df do] pieces, the (tile j, register 4 q + r) <-> (chunk 4 j + q, unit r)
+# composition of the result tiles, the dA^T gather from the LDS tile and the bias-gradient rows.
+
+def pack_wb(Wo, H, MJ):
+    NW, KSC, NCH = 4, 8, H // 32
+    FR = NCH * KSC * MJ
+    WpB = np.zeros((NW, FR, 64, 8))
+    for w in range(NW):
+        for f in range(FR):
+            j, ks, c = f % MJ, (f // MJ) % KSC, f // (MJ * KSC)
+            for lane in range(64):
+                m, kg = lane & 31, lane >> 5
+                um = 32 * (4 * j + (m >> 3)) + 8 * w + (m & 7)
+                for e in range(8):
+                    gate, uk = 2 * kg + (e >> 2), 32 * c + 8 * (ks >> 1) + 4 * (ks & 1) + (e & 3)
+                    WpB[w, f, lane, e] = Wo[gate * H + uk, um]
+    return WpB
+
+
+def forward_records(i, g, f, o, c, H):
+    """[T][N][H] planes -> the forward's fragment-order saves (Cell::store): rec = (((t NU + unit) NCHF + cf) 8 + wf) 64 + lane"""
+    T, N, _ = i.shape
+    NU, NCHF = N // 32, H // 64
+    A0 = np.zeros((T * NU * NCHF * 8 * 64, 8)); A1 = np.zeros_like(A0); CF = np.zeros((A0.shape[0], 4))
+    for t in range(T):
+        for u in range(NU):
+            for cf in range(NCHF):
+                for wf in range(8):
+                    for lane in range(64):
+                        ln, half = lane & 31, lane >> 5
+                        rec = (((t * NU + u) * NCHF + cf) * 8 + wf) * 64 + lane
+                        n, u0 = 32 * u + ln, 64 * cf + 8 * wf + 4 * half
+                        A0[rec, :4], A0[rec, 4:] = i[t, n, u0:u0 + 4], g[t, n, u0:u0 + 4]
+                        A1[rec, :4], A1[rec, 4:] = f[t, n, u0:u0 + 4], o[t, n, u0:u0 + 4]
+                        CF[rec] = c[t, n, u0:u0 + 4]
+    return A0, A1, CF
+
+
+def run_bwd_model(A0, A1, CF, dS, Wc, Wo, T, N, H, MJ):
+    NW, NPT, KSC, NCH, NCHF = 4, 2, 8, H // 32, H // 64
+    NU, UREC = N // 32, H // 4 * 32
+    FR = NCH * KSC * MJ
+    WpB = pack_wb(Wo, H, MJ)
+    dA = np.zeros((T, N, 4 * H)); dAT = np.zeros((4 * H, T, N)); db = np.zeros(4 * H)
+    for tile in range(N // 64):
+        dh = np.zeros((NW, MJ, NPT, 64, 16)); dc = np.zeros_like(dh)
+        for w in range(NW):
+            for c in range(NCH):
+                for pt in range(NPT):
+                    for lane in range(64):
+                        ln, half = lane & 31, lane >> 5
+                        wq = Wc[32 * c + 8 * w + 4 * half:32 * c + 8 * w + 4 * half + 4]
+                        dh[w, c >> 2, pt, lane, 4 * (c & 3):4 * (c & 3) + 4] = wq * dS[tile * 64 + 32 * pt + ln]
+        for t in range(T - 1, -1, -1):
+            acc = np.zeros((NW, MJ, NPT, 64, 16))
+            for c in range(NCH):
+                buf = np.zeros((NPT, KSC, 64, 8))
+                j, q = c >> 2, c & 3
+                for w in range(NW):
+                    for pt in range(NPT):
+                        for lane in range(64):
+                            ln, half = lane & 31, lane >> 5
+                            rec = (t * NU + tile * NPT + pt) * UREC + (4 * c + w) * 64 + lane
+                            ig, gg, fg, og = A0[rec, :4], A0[rec, 4:], A1[rec, :4], A1[rec, 4:]
+                            cc = CF[rec]
+                            cp = CF[rec - NU * UREC] if t > 0 else np.zeros(4)
+                            tc = np.tanh(cc)
+                            d_h = dh[w, j, pt, lane, 4 * q:4 * q + 4]
+                            dO = d_h * tc
+                            d_c = dc[w, j, pt, lane, 4 * q:4 * q + 4] + d_h * og * (1 - tc * tc)
+                            di, dg, df, do = d_c * gg * ig * (1 - ig), d_c * ig * (1 - gg * gg), d_c * cp * fg * (1 - fg), dO * og * (1 - og)
+                            dc[w, j, pt, lane, 4 * q:4 * q + 4] = d_c * fg
+                            buf[pt, 2 * w + half, ln] = np.concatenate([di, dg])
+                            buf[pt, 2 * w + half, 32 + ln] = np.concatenate([df, do])
+                            n, u0 = tile * 64 + 32 * pt + ln, 32 * c + 8 * w + 4 * half
+                            for gt, v in enumerate((di, dg, df, do)):
+                                dA[t, n, gt * H + u0:gt * H + u0 + 4] = v
+                # emit_T: thread (oct, kc0), i
+                for tid in range(256):
+                    oct_, kc0 = tid & 7, tid >> 3
+                    for i4 in range(4):
+                        kc = kc0 + 32 * i4
+                        ks, kg, e = kc >> 4, (kc >> 3) & 1, kc & 7
+                        row = (2 * kg + (e >> 2)) * H + 8 * (ks >> 1) + 4 * (ks & 1) + (e & 3) + 32 * c
+                        pt, lb = oct_ >> 2, 8 * (oct_ & 3)
+                        v = np.array([buf[pt, ks, 32 * kg + lb + x, e] for x in range(8)])
+                        dAT[row, t, tile * 64 + 8 * oct_:tile * 64 + 8 * oct_ + 8] = v
+                        db[row] += v.sum()
+                if t > 0:
+                    for w in range(NW):
+                        for ks in range(KSC):
+                            for jj in range(MJ):
+                                fidx = (c * KSC + ks) * MJ + jj
+                                for pt in range(NPT):
+                                    acc[w, jj, pt] = mfma_32x32x16(WpB[w, fidx], buf[pt, ks], acc[w, jj, pt])
+            dh = acc
+    return dA, dAT, db
+
+
+def reference_bwd(i, g, f, o, c, dS, Wc, Wo, H):
+    T, N, _ = i.shape
+    dh = np.outer(dS, Wc); dc = np.zeros((N, H))
+    dA = np.zeros((T, N, 4 * H))
+    for t in range(T - 1, -1, -1):
+        tc = np.tanh(c[t]); cp = c[t - 1] if t > 0 else np.zeros((N, H))
+        dO = dh * tc
+        d_c = dc + dh * o[t] * (1 - tc * tc)
+        dA[t] = np.concatenate([d_c * g[t] * i[t] * (1 - i[t]), d_c * i[t] * (1 - g[t] ** 2), d_c * cp * f[t] * (1 - f[t]), dO * o[t] * (1 - o[t])], axis=1)
+        dc = d_c * f[t]
+        dh = dA[t] @ Wo
+    return dA
+
+
+def _bwd_case(H, MJ, T, N, seed):
+    rng = np.random.default_rng(seed)
+    i, f, o = (1 / (1 + np.exp(-rng.normal(size=(T, N, H)))) for _ in range(3))
+    g = np.tanh(rng.normal(size=(T, N, H)))
+    c = rng.normal(size=(T, N, H))
+    dS, Wc = rng.normal(size=N), rng.normal(size=H)
+    Wo = rng.normal(size=(4 * H, H)) * 0.2
+    A0, A1, CF = forward_records(i, g, f, o, c, H)
+    dA, dAT, db = run_bwd_model(A0, A1, CF, dS, Wc, Wo, T, N, H, MJ)
+    ref = reference_bwd(i, g, f, o, c, dS, Wc, Wo, H)
+    assert np.max(np.abs(dA - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref)))
+    assert np.max(np.abs(dAT - ref.transpose(2, 0, 1))) < 1e-10 * max(1.0, np.max(np.abs(ref)))
+    assert np.max(np.abs(db - ref.sum(axis=(0, 1)))) < 1e-9 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_persistent_bptt_index_algebra_small():
+    _bwd_case(H=128, MJ=1, T=3, N=128, seed=7)     # two tiles, NCH = 4: every formula with the same code path as the instantiated shape
+
+
+def test_persistent_bptt_index_algebra_instantiated_shape():
+    _bwd_case(H=384, MJ=3, T=2, N=64, seed=8)      # H = 384: three result tiles per wave, twelve chunks, six forward chunks
