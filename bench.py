@@ -130,6 +130,16 @@ def launch_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
+MIN_PATHS_PER_RANK_STEP = 32768
+
+
+def strong_steps(total_paths, world, steps):
+    """--total-paths (strong scaling: a FIXED total divided over ranks and steps): the step count is lowered until a rank's step holds
+    >= 32 768 paths -- below ~8 k paths a step is the latency of one tile through four persistent kernels, which would
+    measure that floor, not the scaling.  1 M paths on 8 GPUs -> 3 steps of 41 666 paths per rank instead of 20 steps of 6 250."""
+    return max(1, min(steps, total_paths // (world * MIN_PATHS_PER_RANK_STEP)))
+
+
 def dry_run(a):
     """No GPU, no engine: the ranks rendezvous over gloo, run K placeholder steps through the same barrier / max-over-ranks
     timing as the real run and rank 0 prints a JSON line marked dry_run.  Checks the launcher and the rank plumbing only."""
@@ -141,6 +151,8 @@ def dry_run(a):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.total_paths:
+        a.steps = strong_steps(a.total_paths, world, a.steps)
     pps = a.paths_per_step if not a.total_paths else max(64, a.total_paths // (world * max(1, a.steps)))
     g = torch.ones(1024)
     def step():
@@ -371,24 +383,66 @@ def cpu_baseline_torch(T, dt, de, dr, H, L, seconds, cores):
                       f"no-grad scoring forward; torch {torch.__version__}, {cores} threads"}
 
 
+def dropin_minibatch(eng, opt, T, F, Vt, Ve, Vr, nT, seconds=0.4):
+    """The calls bindings/kprn.lua makes in place of MyOptimizer:trainBatch (MyOptimizer.lua:177-221) and test_from_checkpoint.lua:109, at the
+    reference's own sizes: kprn_train_step from HOST buffers with 128 pairs (run_scripts/config.sh:38), the loss returned to the host every
+    step; then kprn_forward from host buffers with 512 pairs (test_from_checkpoint.lua:49), the probabilities returned.  A minibatch comes from
+    one bucket file (constant P: movie_data_format.py:311-314); P is drawn per minibatch from the fixture's distribution (SURVEY 8d:
+    min(Geom(0.57), 28), mean 1.75).  Synchronous by construction -- every call ends with a device-to-host copy the caller waits for."""
+    from kprn_amd import synth
+    rng = np.random.default_rng(99)
+    def pool(pairs, n, seed0):
+        out = []
+        for i in range(n):
+            P = int(min(rng.geometric(0.57), 28))
+            idx, labels = synth.make_paths(pairs, P, T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, num_types=nT, seed=seed0 + i)
+            out.append((np.ascontiguousarray(idx, np.int32), np.ascontiguousarray(labels, np.float32)))
+        return out
+    train, score = pool(128, 32, 9100), pool(512, 16, 9300)
+    def run(fn, items, seconds):
+        for it in items[:6]:
+            fn(it)
+        eng.sync()
+        k, n, t0 = 0, 0, time.perf_counter()
+        while True:
+            idx, _ = items[k % len(items)]
+            fn(items[k % len(items)])
+            n += idx.shape[0] * idx.shape[1]
+            k += 1
+            if k % 8 == 0 and time.perf_counter() - t0 >= seconds:
+                break
+        el = time.perf_counter() - t0
+        return {"steps": k, "steps_per_s": round(k / el, 1), "paths_per_s": round(n / el, 1), "ms_per_step": round(1e3 * el / k, 4),
+                "mean_paths_per_step": round(n / k, 1)}
+    losses = []
+    tr = run(lambda it: losses.append(eng.train_step_host(it[0], it[1], opt)), train, seconds)
+    sc = run(lambda it: eng.forward_host(it[0]), score, seconds)
+    assert np.all(np.isfinite(losses))
+    return {"train_128_pairs": tr, "score_512_pairs": sc,
+            "what": "kprn_train_step / kprn_forward from host buffers at the reference's minibatch sizes (config.sh:38, test_from_checkpoint.lua:49), "
+                    "P per minibatch ~ min(Geom(0.57), 28); loss / probabilities returned to the host every call"}
+
+
 def other_configs():
     """compact {value, ms_per_step, roofline} of configs[4] (inference buckets), "d = 64" reading B, run_scripts/config.sh as shipped and
     configs[3] (20 M entities, bf16) -- `python bench.py <flags>` each, short, no CPU leg, no extra regions"""
     import subprocess
-    runs = [("C5_inference_T3to7", ["--workload", "c5", "--steps", "30", "--warmup", "5"]),
-            ("dimsB_D192_H192_L2", ["--dims", "B", "--steps", "6", "--warmup", "2"]),
-            ("shipped_rnn_D200_H250", ["--dims", "shipped", "--steps", "6", "--warmup", "2"]),
-            ("C4_20M_entities_d128_bf16", ["--dims", "C4", "--steps", "6", "--warmup", "2"])]
+    # step counts chosen for a timed region of >= 0.3 s each (C5 0.35 ms, dims B 20 ms, shipped 5.5 ms, configs[3] 5-7 ms per step)
+    runs = [("C5_inference_T3to7", ["--workload", "c5", "--steps", "1000", "--warmup", "10"]),
+            ("dimsB_D192_H192_L2", ["--dims", "B", "--steps", "18", "--warmup", "2"]),
+            ("shipped_rnn_D200_H250", ["--dims", "shipped", "--steps", "64", "--warmup", "3"]),
+            ("C4_20M_entities_d128_bf16", ["--dims", "C4", "--steps", "60", "--warmup", "3"])]
     out = {}
     for name, flags in runs:
-        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-alt", "--no-extra-regions", "--no-other-configs", "--batch-feed", "resident"] + flags
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-alt", "--no-extra-regions", "--no-other-configs", "--no-batch-sweep", "--batch-feed", "resident"] + flags
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             d = json.loads(line[-1])
             rf = d.get("roofline") or {}
-            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d.get("dtype"),
+            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d.get("dtype"), "steps": d.get("steps"),
+                         "timed_region_s": round(d["ms_per_step"] * d.get("steps", 0) / 1e3, 3), "mfma_frac_end_to_end": d.get("mfma_frac_end_to_end"),
                          "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
                          "wall_s": round(time.perf_counter() - t0, 1), "flags": " ".join(flags)}
             oth = rf.get("other_timed_families")
@@ -519,6 +573,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(dev))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if a.total_paths:
+        a.steps = strong_steps(a.total_paths, world, a.steps)
         a.paths_per_step = max(64, a.total_paths // (world * max(1, a.steps)))
 
     from kprn_amd import _ffi, synth, dp
@@ -631,6 +686,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    last_local = [0.0]   # this rank's own seconds of the last timed region (before the max over ranks)
+
     def timed_region(step, first, k):
         """exactly k steps between barriers; returns (max-over-ranks seconds, paths of all ranks)"""
         barrier()
@@ -640,6 +697,7 @@ def main():
             n += step(first + i)
         barrier()
         el = time.perf_counter() - t0
+        last_local[0] = el
         if world > 1:
             tt = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -679,6 +737,7 @@ def main():
         dominant = "lstm_persist_bf16"
     eng.set_option("profile_filter", dominant)
     elapsed, npaths_total = timed_region(step, a.warmup, a.steps)
+    elapsed_local = last_local[0]
     eng.profile(False)
     fams = eng.profile_get() if prof else {}
     value = npaths_total / elapsed
@@ -755,6 +814,8 @@ def main():
             v["ratio_to_65536"] = round(v["value"] / sweep["65536"]["value"], 4)
         extras["batch_sweep"] = {"unit": "paths/s", "paths_per_step": sweep,
                                  "what": "scoring forward + trainBatch per step at smaller batches (256 ~ config.sh:38's 128 pairs); resident batches, bucketed by P"}
+    if plain and not main_streaming and not a.no_batch_sweep and not a.score_only and not a.train_only:
+        extras["dropin_minibatch"] = dropin_minibatch(eng, opt, T, F, Vt, Ve, Vr, nT)
     # data-parallel runs: the exchange's own time, from a short extra region with events around its parts
     dp_info = None
     if dpx is not None:
@@ -775,6 +836,15 @@ def main():
         if world > 1:
             dist.all_reduce(tr)
         dp_info["ranks_reporting"] = int(tr.item())
+        # self-check of a scaling run: the communicator's size as RCCL reports it, and every rank's own wall time per step of the timed region
+        dp_info["rccl_nranks"] = int(eng.dp_comm_size()) if dpx.native else int(dist.get_world_size())   # ncclCommCount of the engine's own communicator
+        mine = torch.tensor([1e3 * elapsed_local / a.steps], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        dp_info["per_rank_ms_per_step"] = [round(float(x.item()), 4) for x in allr]
         dp_info["exchange"] = ("engine: in-place RCCL all-gather on the engine's stream, union inside the row update" if dpx.native else
                                "torch.distributed collectives around the pack / merge hooks" + ("" if a.dp_unfused else ", union inside the row update"))
         dp_info["scoring_pass"] = "first, beside the training forward" if dp_score_first else "behind the backward, under the all-gather"
@@ -928,6 +998,7 @@ def main():
             "final_loss": round(loss, 6),
             "roofline": roofline, "cpu_baseline": cpu,
             "streaming": extras.get("streaming"), "long_run": extras.get("long_run"), "batch_sweep": extras.get("batch_sweep"),
+            "dropin_minibatch": extras.get("dropin_minibatch"),
             "other_configs": other,
             "value_no_prefix_plan": (extras.get("no_prefix_plan") or {}).get("value"), "no_prefix_plan": extras.get("no_prefix_plan"),
             "dp": dp_info, "alt_f32x6": alt, "kernels": kernels,

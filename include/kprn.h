@@ -264,7 +264,8 @@ int kprn_dp_unique_id(const char* rccl_path, void* id128 /* out: 128 bytes */);
 int kprn_dp_init(kprn_handle* h, const char* rccl_path, const void* id128, int32_t rank, int32_t world);
 int kprn_dp_exchange_begin(kprn_handle* h, int32_t capacity);
 int kprn_dp_exchange_finish(kprn_handle* h, const kprn_opt* opt);
-int kprn_dp_shutdown(kprn_handle* h);   /* destroys the communicator (kprn_destroy does it too) */
+int kprn_dp_comm_size(kprn_handle* h, int32_t* nranks);   /* the communicator's rank count as RCCL reports it (ncclCommCount) */
+int kprn_dp_shutdown(kprn_handle* h);   /* destroys the communicator (kprn_destroy does it too); restores the two options kprn_dp_init forced on */
 
 /* ---- checkpoints (OneModel.lua:392-408 torch.save{embeddingLayer,predictor_net}) ------
  * native format: header + flat fp32 vector in getParameters() order (optimizer state is

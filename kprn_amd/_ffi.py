@@ -482,6 +482,11 @@ class Engine:
     def dp_exchange_finish(self, opt):
         self._ck(self.L.kprn_dp_exchange_finish(self.h, C.byref(opt)))
 
+    def dp_comm_size(self):
+        n = C.c_int32()
+        self._ck(self.L.kprn_dp_comm_size(self.h, C.byref(n)))
+        return n.value
+
     def dp_shutdown(self):
         self._ck(self.L.kprn_dp_shutdown(self.h))
 

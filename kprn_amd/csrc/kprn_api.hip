@@ -1860,6 +1860,7 @@ struct Rccl {
   int (*CommInitRank)(void**, int, Id128, int) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -1882,6 +1883,7 @@ bool rccl_load(const char* path) {
   *(void**)&r.CommInitRank = dlsym(lib, "ncclCommInitRank");
   *(void**)&r.AllGather = dlsym(lib, "ncclAllGather");
   *(void**)&r.CommDestroy = dlsym(lib, "ncclCommDestroy");
+  *(void**)&r.CommCount = dlsym(lib, "ncclCommCount");
   *(void**)&r.GetErrorString = dlsym(lib, "ncclGetErrorString");
   if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { g_rccl_err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy"; return false; }
   g_rccl = r;
@@ -1894,8 +1896,16 @@ const int kNcclInt32 = 2;   // ncclDataType_t (rccl.h)
 }  // namespace
 
 static void dp_release(kprn_handle* h) {
-  if (h->dp_comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->dp_comm); }
+  if (h->dp_comm && g_rccl.CommDestroy) {
+    g_rccl.CommDestroy(h->dp_comm);
+    h->dp_dense_in_pack = h->dp_saved_dense_in_pack;   // (kprn_dp_init forced both on)
+    h->dp_fused_update = h->dp_saved_fused_update;
+  }
   h->dp_comm = nullptr;
+  // an exchange in flight dies with the communicator: nothing may point into the gathered buffer freed below (a later materialize_union /
+  // kprn_get_grad / kprn_sparse_grad_pack would read it).  The rows a begun exchange had moved out of g_We are lost with it -- the caller
+  // shut the exchange down between begin and finish.
+  h->dp_begun = false; h->dp_union_pending = false; h->dp_all = nullptr; h->dp_world = 0; h->dp_cap = 0;
   if (h->dp_comm_stream) { hipStreamSynchronize(h->dp_comm_stream); hipStreamDestroy(h->dp_comm_stream); h->dp_comm_stream = nullptr; }
   if (h->ev_dp_packed) { hipEventDestroy(h->ev_dp_packed); h->ev_dp_packed = nullptr; }
   if (h->ev_dp_gathered) { hipEventDestroy(h->ev_dp_gathered); h->ev_dp_gathered = nullptr; }
@@ -1926,9 +1936,23 @@ int kprn_dp_init(kprn_handle* h, const char* rccl_path, const void* id128, int32
   const int rc = g_rccl.CommInitRank(&comm, world, id, rank);   // (collective: every rank of the job is in this call)
   KPRN_REQUIRE(rc == 0 && comm, KPRN_E_DEVICE, rccl_msg("ncclCommInitRank", rc));
   h->dp_comm = comm; h->dp_rank = rank; h->dp_nranks = world;
+  h->dp_saved_dense_in_pack = h->dp_dense_in_pack; h->dp_saved_fused_update = h->dp_fused_update;
   h->dp_dense_in_pack = true;    // one collective per step
   h->dp_fused_update = true;     // union of the rows inside the row update
   h->stream_known = true;        // (the collective is queued by the engine: nobody else has to know the stream)
+  API_END(h)
+}
+
+int kprn_dp_comm_size(kprn_handle* h, int32_t* nranks) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(nranks, KPRN_E_ARG, "NULL argument");
+  KPRN_REQUIRE(h->dp_comm, KPRN_E_ARG, "kprn_dp_comm_size before kprn_dp_init");
+  int n = h->dp_nranks;
+  if (g_rccl.CommCount) {   // RCCL's own count of the communicator's ranks (a self-check for scaling runs: must equal the launcher's world size)
+    const int rc = g_rccl.CommCount(h->dp_comm, &n);
+    KPRN_REQUIRE(rc == 0, KPRN_E_DEVICE, rccl_msg("ncclCommCount", rc));
+  }
+  *nranks = n;
   API_END(h)
 }
 

@@ -170,6 +170,7 @@ struct kprn_handle {
   bool dp_comm_stream_on = false, dp_begun = false;
   hipStream_t dp_comm_stream = nullptr; hipEvent_t ev_dp_packed = nullptr, ev_dp_gathered = nullptr;
   bool dp_dense_in_pack = false; // option: the dense gradient arena rides in the packed buffer (one collective per step)
+  bool dp_saved_dense_in_pack = false, dp_saved_fused_update = false;  // the two options as the caller had set them before kprn_dp_init forced them on (restored by kprn_dp_shutdown)
   int32_t* pack_buf = nullptr; int64_t pack_cap = 0, pack_words = 0;  // {count,-,-,-, ids[cap], rows[cap*de]} 32-bit words; cap of the last pack, allocated words
 
   // scalars on device

@@ -183,7 +183,7 @@ struct Cell {
     // k-group wave & 1, element 4 half + j)
     stb<bf16x4>(hs, (unsigned)(ln * 16 + half * 8), (unsigned)((te & 1) * (MAXPT * KH * 1024) + (pt * KH + (HC / 16) * ce + (wave >> 1)) * 1024 + (wave & 1) * 512), hb);
     const int64_t cu = HC * ce + 8 * wave;   // first hidden unit of this wave's piece
-    if (SAVE) {
+    if (SAVE && 32 * pt < nvalid) {   // (wave-uniform: a workgroup left with a lone 32-row unit runs the two-unit body, whose second unit's records belong to another workgroup -- or lie past the planes)
       // c_t and the four gate activations in FRAGMENT order -- record ((((t NU + unit) NCH + chunk) NW + wave) 64 + lane): c 4 floats, gates [i4 g4] and
       // [f4 o4] as two bf16x8 planes -- every store one contiguous KiB per wave (row-major planes cost this kernel five scattered 8 / 16-byte
       // stores per lane and chunk: 1.27 ms against 0.76 ms for the scoring launch); lstm_bf16.hip's k_gates_bwd16_frag reads them back coalesced

@@ -41,7 +41,9 @@ def _ran_persistent(eng):
                                             (333, 3, 6, 3),      # 999 paths: 32 units over 3 workgroups: 96- and 64-row tiles, ragged last unit
                                             (129, 2, 1, 2),      # T = 1: no recurrent half at all
                                             (143, 3, 4, 1),      # 429 paths on ONE workgroup: 14 units = 3 + 3 + 3 + 3 + 2, last unit 13 rows
-                                            (86, 3, 8, 7)])      # 258 paths, T = 8 (the id tile's capacity); 9 units over 7 workgroups: lone 32-row units
+                                            (86, 3, 8, 7),       # 258 paths, T = 8 (the id tile's capacity); 9 units over 7 workgroups: lone 32-row units
+                                            (86, 3, 6, 9)])      # 9 units over 9 workgroups: EVERY workgroup owns a lone unit, the last one 2 rows of the batch's last unit
+                                                                 # (the two-unit body must not write a second unit's save records: ADVICE r3)
 def test_scores_and_gradients_against_the_f64_oracle(pairs, P, T, grid, monkeypatch):
     if grid:
         monkeypatch.setenv("KPRN_PERSIST_GRID", str(grid))
