@@ -21,9 +21,11 @@
 //     the store is one ds_write_b128 into the lane's own slot, the product's operand read one ds_read_b128), double buffered:
 //     2 x 16 KB.  Each weight fragment (1 KiB, packed by k_pack_wb in exactly the order it is read) is fetched L2 -> registers by
 //     exactly ONE wave and used for both path tiles.
-//   * Outputs per chunk: dA row-major (the dx product's operand), dA^T in 16-byte pieces of 8 consecutive paths (the split-K dW
-//     products' k-contiguous operand) gathered from the LDS tile, and the bias gradient = row sums of dA^T, kept in an LDS table for
-//     the whole launch and flushed with one atomic per gate column per workgroup.
+//   * Outputs per chunk: dA row-major (the dx product's operand; v_permlane32_swap pairs the two lanes of a path into 16-byte stores), dA^T
+//     in 16-byte pieces of 8 consecutive paths (the split-K dW products' k-contiguous operand) read from a second, TRANSPOSED LDS tile
+//     that the lanes fill with two-byte writes (fire and forget; the first version gathered the pieces with 32 ds_read_u16 per thread and
+//     chunk, each a round trip the single wave per SIMD waited for: 2.0 ms per launch), and the bias gradient = row sums of dA^T, kept in
+//     an LDS table for the whole launch and flushed with one atomic per gate column per workgroup.
 // HBM-bound by construction: per (path, step) it reads 4.6 KB of saves and writes 6 KB (dA + dA^T); the product and the cell ride under that.
 // Index algebra replayed lane by lane in numpy: tests/test_persist_layout.py (backward model).
 #include <string.h>
@@ -53,6 +55,8 @@ constexpr int FR = NCH * KSC * MJ;   // weight fragments per wave and step (288 
 constexpr int PF = 12;          // fragments in flight per wave (4 k-steps ahead; divides the fragments of a chunk)
 constexpr int UREC = H / 4 * 32;     // records (quads) of one unit of 32 rows and one step: [forward chunk 6][forward wave 8][lane 64]
 constexpr int BUF = NPT * KSC * 1024;   // bytes of one dA chunk tile in LDS
+constexpr int TP = 64 * 2 + 16;         // row pitch of the transposed chunk tile (bytes): 64 paths + 16 (the two halves of a wave write rows 4 apart: 576 bytes = other banks)
+constexpr int TT = 128 * TP;            // bytes of the transposed chunk tile: 4 gates x 32 hidden units rows
 static_assert(NW * MJ * 32 == H && NCH * 32 == H && MJ * 4 == NCH && (KSC * MJ) % PF == 0, "shape algebra of the backward tile");
 
 struct BArgs {
@@ -96,11 +100,14 @@ __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __builtin_am
 // the saves of this lane's quad of one chunk, per path tile
 struct Sv { bf16x8 a0[NPT], a1[NPT]; bf16x4 c[NPT], cp[NPT]; };
 
+// DBG (measurement builds, KPRN_PERSIST_VARIANTS + KPRN_PERSIST_BWD_DBG): 1 no dA^T / bias pass, 2 no row-major dA stores, 4 no product, 8 no save loads
+template <int DBG>
 __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  char* const buf = smem;                          // 2 x BUF: dA chunk tiles [pt][k-step][slot][16 B]
-  float* const sdb = (float*)(smem + 2 * BUF);     // [4H] bias-gradient sums of this workgroup
-  char* const dhl = smem + 2 * BUF + 4 * H * 4 + threadIdx.x * 16;   // dh_t of the tile: [(j NPT + pt) 4 + q][thread][16 B], this thread's slots
+  char* const buf = smem;                                   // 2 x BUF: dA chunk tiles in B-fragment order [pt][k-step][slot][16 B]
+  char* const tt = smem + 2 * BUF;                          // dA chunk tile TRANSPOSED: [gate 4][unit 32] rows of 64 paths (pitch TP bytes)
+  float* const sdb = (float*)(smem + 2 * BUF + TT);         // [4H] bias-gradient sums of this workgroup
+  char* const dhl = smem + 2 * BUF + TT + 4 * H * 4 + threadIdx.x * 16;   // dh_t of the tile: [(j NPT + pt) 4 + q][thread][16 B], this thread's slots
   const int tid = threadIdx.x, lane = tid & 63, ln = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t G = gridDim.x, b = blockIdx.x;
@@ -115,17 +122,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
 #pragma unroll
     for (int s = 0; s < PF; ++s) ring[s] = ldb<bf16x8>(rW, l16, (unsigned)s * 1024u);
   }
-  // the dA^T pass of a chunk: thread -> (octet of 8 consecutive paths, gate column kc = (tid >> 3) + 32 i of the chunk's 128)
-  // gate column kc of a chunk: k-step kc >> 4, k-group (kc >> 3) & 1, element kc & 7  ->  LDS piece, and row (gate H + unit) of dA^T / the bias gradient
+  // the dA^T pass of a chunk: thread -> (octet of 8 consecutive paths, row kc0 + 32 i of the transposed tile = gate i, unit kc0 of the chunk)
   const int oct = tid & 7, kc0 = tid >> 3;
-  int et_src[4];       // byte offset of this thread's first element inside a chunk tile
-  int64_t et_row[4];   // its row of dA^T, without the chunk's 32 c
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int kc = kc0 + 32 * i, ks = kc >> 4, kg = (kc >> 3) & 1, e = kc & 7;
-    et_src[i] = (((oct >> 2) * KSC + ks) * 64 + 32 * kg + 8 * (oct & 3)) * 16 + 2 * e;
-    et_row[i] = (2 * kg + (e >> 2)) * H + 8 * (ks >> 1) + 4 * (ks & 1) + (e & 3);
-  }
   bar();
 
   for (int64_t tile = t_beg; tile < t_end; ++tile) {
@@ -145,6 +143,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
     // ((unit NCHF + chunk) 8 + wave) 64 + lane  ->  byte offset (4 c + w) 1024 (+ 16 lane) inside the unit's block of a 16-byte plane
     auto request = [&](int t, auto cc, Sv& s) {
       constexpr int c = decltype(cc)::value;
+      if constexpr ((DBG & 8) != 0) {
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { s.a0[pt][q] = (bf16)0.5f; s.a1[pt][q] = (bf16)0.5f; s.c[pt][q & 3] = (bf16)0.25f; s.cp[pt][q & 3] = (bf16)0.25f; }
+        return;
+      }
       const int64_t r0 = (int64_t)t * a.step_recs + u0 * UREC;
       const rsrc_t r_a0 = make_rsrc(a.A0 + r0), r_a1 = make_rsrc(a.A1 + r0), r_c = make_rsrc(a.cF + r0);
       const unsigned so = (unsigned)(4 * c + w) * 1024u;
@@ -191,15 +196,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
       const rsrc_t r_dA = make_rsrc(a.dA + ((int64_t)t * a.N + row0) * (4 * H));
       bf16* const dat_t = a.dAT + (int64_t)t * a.Np + row0;
       const bool et_ok = row0 + 8 * oct < a.Np;
+      bf16x8 pc[NPT][2];    // the chunk's pieces [di4 dg4] / [df4 do4] of this lane, kept for the transposed tile (written behind the barrier)
 
-      // cell backward of chunk c on this lane's quads -> dA pieces to LDS tile (c & 1) and to the row-major plane
+      // cell backward of chunk c on this lane's quads -> dA pieces to the B-fragment tile (c & 1) and to the row-major plane
       auto gate = [&](auto cc, const Sv& s) {
         constexpr int c = decltype(cc)::value, j = c >> 2, q = c & 3;
         char* const dst = buf + (c & 1) * BUF;
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
           bf16x8 p0, p1;
-          bf16x4 vi, vg, vf, vo;
           const f32x4 dh4 = *(const f32x4*)(dhl + ((j * NPT + pt) * 4 + q) * 4096);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -209,51 +214,77 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
             const float dh = dh4[r];
             const float dO = dh * tc;
             const float dc = dcs[j][pt][4 * q + r] + dh * og * (1.f - tc * tc);
-            const bf16 di = (bf16)(dc * gg * ig * (1.f - ig));
-            const bf16 dg = (bf16)(dc * ig * (1.f - gg * gg));
-            const bf16 df = (bf16)(dc * cp * fg * (1.f - fg));
-            const bf16 dov = (bf16)(dO * og * (1.f - og));
+            p0[r] = (bf16)(dc * gg * ig * (1.f - ig));
+            p0[4 + r] = (bf16)(dc * ig * (1.f - gg * gg));
+            p1[r] = (bf16)(dc * cp * fg * (1.f - fg));
+            p1[4 + r] = (bf16)(dO * og * (1.f - og));
             dcs[j][pt][4 * q + r] = dc * fg;
-            p0[r] = di; p0[4 + r] = dg; p1[r] = df; p1[4 + r] = dov;
-            vi[r] = di; vg[r] = dg; vf[r] = df; vo[r] = dov;
           }
           // B-fragment order: k-step 2 w + half, k-group ab (piece [di dg] -> 0, [df do] -> 1), slot ln + 32 ab
           *(bf16x8*)(dst + ((pt * KSC + 2 * w + half) * 64 + ln) * 16) = p0;
           *(bf16x8*)(dst + ((pt * KSC + 2 * w + half) * 64 + 32 + ln) * 16) = p1;
-          if (valid[pt]) {
-            const unsigned vo_ = (unsigned)(((32 * pt + ln) * (4 * H) + 4 * half) * 2);
-            const unsigned so_ = (unsigned)((32 * c + 8 * w) * 2);
-            stb<bf16x4>(r_dA, vo_, so_, vi);
-            stb<bf16x4>(r_dA, vo_, so_ + (unsigned)(H * 2), vg);
-            stb<bf16x4>(r_dA, vo_, so_ + (unsigned)(2 * H * 2), vf);
-            stb<bf16x4>(r_dA, vo_, so_ + (unsigned)(3 * H * 2), vo);
+          pc[pt][0] = p0; pc[pt][1] = p1;
+          if constexpr ((DBG & 2) == 0) {
+            // row-major plane: the two lanes of a path (half 0 / 1) hold units 8 w .. + 3 / + 4 .. + 7 of every gate; one v_permlane32_swap per dword
+            // hands lane half 0 the 16 bytes of gate i (f) and lane half 1 those of gate g (o): two 16-byte stores per lane instead of four of 8
+            const u32x4 x0 = __builtin_bit_cast(u32x4, p0), x1 = __builtin_bit_cast(u32x4, p1);
+            u32x4 s0, s1;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const auto r0 = __builtin_amdgcn_permlane32_swap(x0[d], x0[2 + d], false, false);   // (di dword d, dg dword d)
+              s0[d] = r0[0]; s0[2 + d] = r0[1];
+              const auto r1 = __builtin_amdgcn_permlane32_swap(x1[d], x1[2 + d], false, false);   // (df, do)
+              s1[d] = r1[0]; s1[2 + d] = r1[1];
+            }
+            if (valid[pt]) {
+              const unsigned vo_ = (unsigned)(((32 * pt + ln) * (4 * H) + half * H) * 2);
+              const unsigned so_ = (unsigned)((32 * c + 8 * w) * 2);
+              __builtin_amdgcn_raw_buffer_store_b128(s0, r_dA, (int)vo_, (int)so_, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(s1, r_dA, (int)vo_, (int)(so_ + (unsigned)(2 * H * 2)), 0);
+            }
           }
         }
       };
-      // dA^T pieces and the bias sums of chunk c from its LDS tile
+      // the chunk's pieces into the transposed tile: row gate 32 + 8 w + 4 half + r, column = path (16 two-byte LDS writes per path tile: fire and forget)
+      auto write_T = [&]() {
+        if constexpr ((DBG & 1) != 0) return;
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *(bf16*)(tt + (g4 * 32 + 8 * w + 4 * half + r) * TP + (32 * pt + ln) * 2) = pc[pt][g4 >> 1][4 * (g4 & 1) + r];
+      };
+      // dA^T pieces and the bias sums of chunk c from the transposed tile: thread (oct, kc0) owns 8 consecutive paths of rows kc0 + 32 i (gate i, unit kc0)
       auto emit_T = [&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        const char* const src = buf + (c & 1) * BUF;
+        if constexpr ((DBG & 1) != 0) return;
         // (the chunk's row block of dA^T as an opaque scalar: otherwise hipcc precomputes the 48 (chunk, i) row offsets of the whole step
         //  as 64-bit VGPR pairs outside the step loop and spills a hundred registers for them)
-        int64_t cofs = (int64_t)(32 * c) * a.ldT;
-        asm volatile("" : "+s"(cofs));
-        bf16* const dat_c = dat_t + cofs;
+        int64_t cofs = (int64_t)(32 * c + kc0) * a.ldT;
+        asm volatile("" : "+v"(cofs));
+        bf16* const dat_c = dat_t + cofs + 8 * oct;
+        bf16x8 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *(const bf16x8*)(tt + (32 * i + kc0) * TP + oct * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const char* p = src + et_src[i];
-          bf16x8 v;
+          if (et_ok) *(bf16x8*)(dat_c + (int64_t)(i * H) * a.ldT) = v[i];
           float sum = 0.f;
 #pragma unroll
-          for (int x = 0; x < 8; ++x) { v[x] = *(const bf16*)(p + 16 * x); sum += (float)v[x]; }
-          if (et_ok) *(bf16x8*)(dat_c + et_row[i] * a.ldT + 8 * oct) = v;
-          sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-          if (oct == 0) sdb[et_row[i] + 32 * c] += sum;   // (one owner thread per gate column: no atomics)
+          for (int x = 0; x < 8; ++x) sum += (float)v[i][x];
+          // sum over the 8 lanes of the octet group (DPP: quad xor 1, quad xor 2, mirror of the half row)
+          sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, true));
+          sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, true));
+          sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, true));
+          if (oct == 0) sdb[i * H + 32 * c + kc0] += sum;   // (one owner thread per gate column: no atomics)
         }
       };
       // dh_{t-1} += W_o2g^T[:, chunk c] dA_t[chunk c]: 8 k-steps x 3 result tiles x 2 path tiles
       auto product = [&](auto cc) {
         constexpr int c = decltype(cc)::value;
+        if constexpr ((DBG & 4) != 0) return;
         const char* const src = buf + (c & 1) * BUF + lane * 16;
         static_for<0, KSC>([&](auto kk) __attribute__((always_inline)) {
           constexpr int ks = decltype(kk)::value;
@@ -271,8 +302,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
         });
       };
 
+      // Per chunk two regions: A = product(c) + dA^T pass(c) + cell backward(c + 1) [writes the OTHER B-fragment tile], barrier, B = the
+      // transposed tile of chunk c + 1 from the pieces kept in registers (every wave has finished reading chunk c's), barrier.
       gate(std::integral_constant<int, 0>{}, sv[0]);
       request(t, std::integral_constant<int, 2>{}, sv[0]);
+      bar();
+      write_T();
       bar();
       static_for<0, NCH>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
@@ -282,6 +317,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
           gate(std::integral_constant<int, c + 1>{}, sv[(c + 1) & 1]);
           if constexpr (c + 3 < NCH) request(t, std::integral_constant<int, c + 3>{}, sv[(c + 1) & 1]);
           else if (t > 0) request(t - 1, std::integral_constant<int, c + 3 - NCH>{}, sv[(c + 1) & 1]);
+          bar();
+          write_T();
         }
         bar();
       });
@@ -380,14 +417,23 @@ void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSa
   a.tiles = (N + 63) / 64;
   int grid = (int)std::min<int64_t>(p->grid, a.tiles);
   if (const char* e = getenv("KPRN_PERSIST_BWD_GRID")) grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, atoi(e)));   // (tests: several tiles per workgroup at small N)
-  const size_t lds_bytes = (size_t)2 * pb::BUF + (size_t)4 * pb::H * sizeof(float) + (size_t)pb::MJ * pb::NPT * 4 * 4096;
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute((const void*)pb::k_lstm16_bwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
+  const size_t lds_bytes = (size_t)2 * pb::BUF + (size_t)pb::TT + (size_t)4 * pb::H * sizeof(float) + (size_t)pb::MJ * pb::NPT * 4 * 4096;
+  typedef void (*Kern)(pb::BArgs);
+  Kern k = (Kern)pb::k_lstm16_bwd_persist<0>;
+#ifdef KPRN_PERSIST_VARIANTS
+  // measurement builds (scripts/gpu_persist_knockouts.py bwd): KPRN_PERSIST_BWD_DBG = knock-out mask
+  if (const char* e = getenv("KPRN_PERSIST_BWD_DBG")) {
+    const int dbg = atoi(e);
+    bool found = dbg == 0;
+#define KV(D) if (dbg == D) { k = (Kern)pb::k_lstm16_bwd_persist<D>; found = true; }
+    KV(1) KV(2) KV(3) KV(4) KV(7) KV(8) KV(15)
+#undef KV
+    KPRN_REQUIRE(found, KPRN_E_ARG, "this variant of the persistent BPTT kernel is not compiled in");
   }
+#endif
+  HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   ProfScope ps(h, "lstm_persist_bf16_bwd");
-  hipLaunchKernelGGL(pb::k_lstm16_bwd_persist, dim3(grid), dim3(64 * pb::NW), lds_bytes, strm, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64 * pb::NW), lds_bytes, strm, a);
   HIP_TRY(hipGetLastError());
 }
 

@@ -1,5 +1,5 @@
 """Measurement build: kprn_amd/libkprn_variants.so = libkprn.so with the persistent bf16 layer kernel's knock-out / tuning
-variants compiled in (-DKPRN_PERSIST_VARIANTS, lstm_bf16_persist.hip).  Loaded with KPRN_LIB=<path> (kprn_amd/_ffi.py)."""
+variants compiled in (-DKPRN_PERSIST_VARIANTS: lstm_bf16_persist.hip, lstm_bf16_bwd_persist.hip).  Loaded with KPRN_LIB=<path> (kprn_amd/_ffi.py)."""
 import os
 import subprocess
 import sys
@@ -12,8 +12,8 @@ kb.build()
 objs = []
 for src in kb.sources():
     obj = os.path.join(kb.HERE, "build", os.path.basename(src) + ".o")
-    if os.path.basename(src) == "lstm_bf16_persist.hip":
-        obj = os.path.join(kb.HERE, "build", "lstm_bf16_persist.variants.o")
+    if os.path.basename(src) in ("lstm_bf16_persist.hip", "lstm_bf16_bwd_persist.hip"):
+        obj = os.path.join(kb.HERE, "build", os.path.basename(src)[:-4] + ".variants.o")
         subprocess.check_call([kb.HIPCC] + kb.FLAGS + kb.file_flags(src) + ["-DKPRN_PERSIST_VARIANTS"] + os.environ.get("KPRN_VARIANT_DEFS", "").split() + ["-c", src, "-o", obj])
     objs.append(obj)
 out = os.path.join(kb.HERE, os.environ.get("KPRN_VARIANT_NAME", "libkprn_variants.so"))

@@ -211,15 +211,21 @@ def run_bwd_model(A0, A1, CF, dS, Wc, Wo, T, N, H, MJ):
                             n, u0 = tile * 64 + 32 * pt + ln, 32 * c + 8 * w + 4 * half
                             for gt, v in enumerate((di, dg, df, do)):
                                 dA[t, n, gt * H + u0:gt * H + u0 + 4] = v
-                # emit_T: thread (oct, kc0), i
+                # write_T (lane pieces -> transposed tile rows gate 32 + 8 w + 4 half + r) and emit_T (thread (oct, kc0): rows kc0 + 32 i)
+                tt = np.zeros((128, 64))
+                for w in range(NW):
+                    for pt in range(NPT):
+                        for lane in range(64):
+                            ln, half = lane & 31, lane >> 5
+                            pcs = (buf[pt, 2 * w + half, ln], buf[pt, 2 * w + half, 32 + ln])
+                            for g4 in range(4):
+                                for r in range(4):
+                                    tt[g4 * 32 + 8 * w + 4 * half + r, 32 * pt + ln] = pcs[g4 >> 1][4 * (g4 & 1) + r]
                 for tid in range(256):
                     oct_, kc0 = tid & 7, tid >> 3
                     for i4 in range(4):
-                        kc = kc0 + 32 * i4
-                        ks, kg, e = kc >> 4, (kc >> 3) & 1, kc & 7
-                        row = (2 * kg + (e >> 2)) * H + 8 * (ks >> 1) + 4 * (ks & 1) + (e & 3) + 32 * c
-                        pt, lb = oct_ >> 2, 8 * (oct_ & 3)
-                        v = np.array([buf[pt, ks, 32 * kg + lb + x, e] for x in range(8)])
+                        v = tt[32 * i4 + kc0, 8 * oct_:8 * oct_ + 8]
+                        row = i4 * H + 32 * c + kc0
                         dAT[row, t, tile * 64 + 8 * oct_:tile * 64 + 8 * oct_ + 8] = v
                         db[row] += v.sum()
                 if t > 0:
