@@ -118,12 +118,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
   const rsrc_t rW = make_rsrc(a.WpB + (int64_t)w * FR * 512);
   const unsigned l16 = (unsigned)lane * 16u, l8 = (unsigned)lane * 8u;
   bf16x8 ring[PF];
-  if (T > 1) {
 #pragma unroll
-    for (int s = 0; s < PF; ++s) ring[s] = ldb<bf16x8>(rW, l16, (unsigned)s * 1024u);
-  }
+  for (int s = 0; s < PF; ++s) ring[s] = ldb<bf16x8>(rW, l16, (unsigned)s * 1024u);
   // the dA^T pass of a chunk: thread -> (octet of 8 consecutive paths, row kc0 + 32 i of the transposed tile = gate i, unit kc0 of the chunk)
   const int oct = tid & 7, kc0 = tid >> 3;
+  const unsigned et_voff = (unsigned)(((int64_t)kc0 * a.ldT + 8 * oct) * 2);   // (host: 32 rows of dA^T span < 4 GB)
   bar();
 
   for (int64_t tile = t_beg; tile < t_end; ++tile) {
@@ -197,37 +196,43 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
       bf16* const dat_t = a.dAT + (int64_t)t * a.Np + row0;
       const bool et_ok = row0 + 8 * oct < a.Np;
       bf16x8 pc[NPT][2];    // the chunk's pieces [di4 dg4] / [df4 do4] of this lane, kept for the transposed tile (written behind the barrier)
+      f32x4 dh4[NPT];       // dh_t of the quads about to be processed
+      bf16x8 ev;            // the dA^T piece in flight
 
-      // cell backward of chunk c on this lane's quads -> dA pieces to the B-fragment tile (c & 1) and to the row-major plane
-      auto gate = [&](auto cc, const Sv& s) {
-        constexpr int c = decltype(cc)::value, j = c >> 2, q = c & 3;
-        char* const dst = buf + (c & 1) * BUF;
+      auto read_dh = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
 #pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) {
-          bf16x8 p0, p1;
-          const f32x4 dh4 = *(const f32x4*)(dhl + ((j * NPT + pt) * 4 + q) * 4096);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float ig = (float)s.a0[pt][r], gg = (float)s.a0[pt][4 + r], fg = (float)s.a1[pt][r], og = (float)s.a1[pt][4 + r];
-            const float tc = tanh_fast((float)s.c[pt][r]);
-            const float cp = (float)s.cp[pt][r];
-            const float dh = dh4[r];
-            const float dO = dh * tc;
-            const float dc = dcs[j][pt][4 * q + r] + dh * og * (1.f - tc * tc);
-            p0[r] = (bf16)(dc * gg * ig * (1.f - ig));
-            p0[4 + r] = (bf16)(dc * ig * (1.f - gg * gg));
-            p1[r] = (bf16)(dc * cp * fg * (1.f - fg));
-            p1[4 + r] = (bf16)(dO * og * (1.f - og));
-            dcs[j][pt][4 * q + r] = dc * fg;
-          }
+        for (int pt = 0; pt < NPT; ++pt) dh4[pt] = *(const f32x4*)(dhl + (((c >> 2) * NPT + pt) * 4 + (c & 3)) * 4096);
+      };
+      // ---- the cell backward of chunk c, cut into slices that ride behind the product's MFMAs (one wave per SIMD: nothing else fills an
+      // MFMA's shadow, and hipcc, left alone, sinks every prefetch load down to its use: the first version waited vmcnt(0) in front of most MFMAs).
+      // G = 0 .. 7: element (pt = G >> 2, r = G & 3);  8, 9: the path tile's pieces -> B-fragment tile (c & 1) + row-major plane;
+      // 10: the saves of chunk c + 2 (or of the next step's first chunks) and dh of chunk c + 1 are requested.
+      auto gslice = [&](auto cc, auto gg, Sv& s) {
+        constexpr int c = decltype(cc)::value, Gs = decltype(gg)::value, j = c >> 2, q = c & 3;
+        if constexpr (Gs < 8) {
+          constexpr int pt = Gs >> 2, r = Gs & 3;
+          const float ig = (float)s.a0[pt][r], gv = (float)s.a0[pt][4 + r], fg = (float)s.a1[pt][r], og = (float)s.a1[pt][4 + r];
+          const float tc = tanh_fast((float)s.c[pt][r]);
+          const float cp = (float)s.cp[pt][r];
+          const float dh = dh4[pt][r];
+          const float dO = dh * tc;
+          const float dc = dcs[j][pt][4 * q + r] + dh * og * (1.f - tc * tc);
+          pc[pt][0][r] = (bf16)(dc * gv * ig * (1.f - ig));
+          pc[pt][0][4 + r] = (bf16)(dc * ig * (1.f - gv * gv));
+          pc[pt][1][r] = (bf16)(dc * cp * fg * (1.f - fg));
+          pc[pt][1][4 + r] = (bf16)(dO * og * (1.f - og));
+          dcs[j][pt][4 * q + r] = dc * fg;
+        } else if constexpr (Gs < 10) {
+          constexpr int pt = Gs - 8;
+          char* const dst = buf + (c & 1) * BUF;
           // B-fragment order: k-step 2 w + half, k-group ab (piece [di dg] -> 0, [df do] -> 1), slot ln + 32 ab
-          *(bf16x8*)(dst + ((pt * KSC + 2 * w + half) * 64 + ln) * 16) = p0;
-          *(bf16x8*)(dst + ((pt * KSC + 2 * w + half) * 64 + 32 + ln) * 16) = p1;
-          pc[pt][0] = p0; pc[pt][1] = p1;
+          *(bf16x8*)(dst + ((pt * KSC + 2 * w + half) * 64 + ln) * 16) = pc[pt][0];
+          *(bf16x8*)(dst + ((pt * KSC + 2 * w + half) * 64 + 32 + ln) * 16) = pc[pt][1];
           if constexpr ((DBG & 2) == 0) {
             // row-major plane: the two lanes of a path (half 0 / 1) hold units 8 w .. + 3 / + 4 .. + 7 of every gate; one v_permlane32_swap per dword
             // hands lane half 0 the 16 bytes of gate i (f) and lane half 1 those of gate g (o): two 16-byte stores per lane instead of four of 8
-            const u32x4 x0 = __builtin_bit_cast(u32x4, p0), x1 = __builtin_bit_cast(u32x4, p1);
+            const u32x4 x0 = __builtin_bit_cast(u32x4, pc[pt][0]), x1 = __builtin_bit_cast(u32x4, pc[pt][1]);
             u32x4 s0, s1;
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
@@ -243,6 +248,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
               __builtin_amdgcn_raw_buffer_store_b128(s1, r_dA, (int)vo_, (int)(so_ + (unsigned)(2 * H * 2)), 0);
             }
           }
+        } else if constexpr (Gs == 10) {
+          if constexpr (c + 2 < NCH) request(t, std::integral_constant<int, c + 2>{}, s);
+          else if (t > 0) request(t - 1, std::integral_constant<int, c + 2 - NCH>{}, s);
+          if constexpr (c + 1 < NCH) read_dh(std::integral_constant<int, c + 1>{});
         }
       };
       // the chunk's pieces into the transposed tile: row gate 32 + 8 w + 4 half + r, column = path (16 two-byte LDS writes per path tile: fire and forget)
@@ -256,74 +265,83 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
             for (int r = 0; r < 4; ++r)
               *(bf16*)(tt + (g4 * 32 + 8 * w + 4 * half + r) * TP + (32 * pt + ln) * 2) = pc[pt][g4 >> 1][4 * (g4 & 1) + r];
       };
-      // dA^T pieces and the bias sums of chunk c from the transposed tile: thread (oct, kc0) owns 8 consecutive paths of rows kc0 + 32 i (gate i, unit kc0)
-      auto emit_T = [&](auto cc) {
-        constexpr int c = decltype(cc)::value;
+      // ---- dA^T pieces and the bias sums of chunk c from the transposed tile, in slices G = 11 .. 15: thread (oct, kc0) owns 8 consecutive paths of
+      // rows kc0 + 32 i (gate i, unit kc0); piece i is read in slice 11 + i and leaves in slice 12 + i
+      auto eslice = [&](auto cc, auto gg) {
+        constexpr int c = decltype(cc)::value, Gs = decltype(gg)::value;
         if constexpr ((DBG & 1) != 0) return;
-        // (the chunk's row block of dA^T as an opaque scalar: otherwise hipcc precomputes the 48 (chunk, i) row offsets of the whole step
-        //  as 64-bit VGPR pairs outside the step loop and spills a hundred registers for them)
-        int64_t cofs = (int64_t)(32 * c + kc0) * a.ldT;
-        asm volatile("" : "+v"(cofs));
-        bf16* const dat_c = dat_t + cofs + 8 * oct;
-        bf16x8 v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = *(const bf16x8*)(tt + (32 * i + kc0) * TP + oct * 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (et_ok) *(bf16x8*)(dat_c + (int64_t)(i * H) * a.ldT) = v[i];
+        if constexpr (Gs >= 12 && Gs <= 15) {
+          constexpr int i = Gs - 12;
+          // address = uniform 64-bit base (scalar registers: plane + step block + row block of (gate i, chunk c)) + this thread's 32-bit byte offset
+          // (row kc0 of the block, octet).  The row block is made opaque: otherwise hipcc precomputes the 48 (chunk, i) offsets of the whole
+          // step outside the step loop and spills registers for them.
+          int64_t sofs = (int64_t)(i * H + 32 * c) * a.ldT;
+          asm volatile("" : "+s"(sofs));
+          if (et_ok) *(bf16x8*)((char*)(dat_t + sofs) + et_voff) = ev;
           float sum = 0.f;
 #pragma unroll
-          for (int x = 0; x < 8; ++x) sum += (float)v[i][x];
+          for (int x = 0; x < 8; ++x) sum += (float)ev[x];
           // sum over the 8 lanes of the octet group (DPP: quad xor 1, quad xor 2, mirror of the half row)
           sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, true));
           sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, true));
           sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, true));
           if (oct == 0) sdb[i * H + 32 * c + kc0] += sum;   // (one owner thread per gate column: no atomics)
         }
-      };
-      // dh_{t-1} += W_o2g^T[:, chunk c] dA_t[chunk c]: 8 k-steps x 3 result tiles x 2 path tiles
-      auto product = [&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        if constexpr ((DBG & 4) != 0) return;
-        const char* const src = buf + (c & 1) * BUF + lane * 16;
-        static_for<0, KSC>([&](auto kk) __attribute__((always_inline)) {
-          constexpr int ks = decltype(kk)::value;
-          bf16x8 bf[NPT];
-#pragma unroll
-          for (int pt = 0; pt < NPT; ++pt) bf[pt] = *(const bf16x8*)(src + (pt * KSC + ks) * 1024);
-          static_for<0, MJ>([&](auto jj) __attribute__((always_inline)) {
-            constexpr int j = decltype(jj)::value;
-            constexpr int f = (c * KSC + ks) * MJ + j, slot = f % PF;
-#pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) acc[j][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot], bf[pt], acc[j][pt], 0, 0, 0);
-            constexpr int fn = (f + PF) % FR;   // (the next step walks the same fragments again)
-            ring[slot] = ldb<bf16x8>(rW, l16, (unsigned)fn * 1024u);
-          });
-        });
+        if constexpr (Gs >= 11 && Gs <= 14) ev = *(const bf16x8*)(tt + (32 * (Gs - 11) + kc0) * TP + oct * 16);
       };
 
-      // Per chunk two regions: A = product(c) + dA^T pass(c) + cell backward(c + 1) [writes the OTHER B-fragment tile], barrier, B = the
-      // transposed tile of chunk c + 1 from the pieces kept in registers (every wave has finished reading chunk c's), barrier.
-      gate(std::integral_constant<int, 0>{}, sv[0]);
+      // first chunk of the step: nothing to ride behind
+      read_dh(std::integral_constant<int, 0>{});
+      static_for<0, 10>([&](auto gg) __attribute__((always_inline)) { gslice(std::integral_constant<int, 0>{}, gg, sv[0]); });
       request(t, std::integral_constant<int, 2>{}, sv[0]);
+      read_dh(std::integral_constant<int, 1>{});
       bar();
       write_T();
       bar();
-      static_for<0, NCH>([&](auto cc) __attribute__((always_inline)) {
-        constexpr int c = decltype(cc)::value;
-        if (t > 0) product(cc);
-        emit_T(cc);
-        if constexpr (c + 1 < NCH) {
-          gate(std::integral_constant<int, c + 1>{}, sv[(c + 1) & 1]);
-          if constexpr (c + 3 < NCH) request(t, std::integral_constant<int, c + 3>{}, sv[(c + 1) & 1]);
-          else if (t > 0) request(t - 1, std::integral_constant<int, c + 3 - NCH>{}, sv[(c + 1) & 1]);
+      // Per chunk two regions: A = product(c): 8 k-steps x 3 result tiles x 2 path tiles (dh_{t-1} += W_o2g^T[:, chunk c] dA_t[chunk c]) with the
+      // dA^T pass of chunk c and the cell backward of chunk c + 1 [writes the OTHER B-fragment tile] in its shadow, barrier, B = the transposed
+      // tile of chunk c + 1 from the pieces kept in registers (every wave has finished reading chunk c's), barrier.
+      // (no run-time branch around the MFMA groups: at every join hipcc's wait-count bookkeeping assumes that none of the later ring loads were
+      //  issued -- it then waits vmcnt(0) in front of every MFMA and the prefetch ring is gone)
+      auto chunks = [&](auto hp) __attribute__((always_inline)) {
+        constexpr bool HP = decltype(hp)::value && !(DBG & 4);
+        static_for<0, NCH>([&](auto cc) __attribute__((always_inline)) {
+          constexpr int c = decltype(cc)::value;
+          const char* const src = buf + (c & 1) * BUF + lane * 16;
+          bf16x8 bfr[2][NPT];
+          if constexpr (HP) {
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) bfr[0][pt] = *(const bf16x8*)(src + (pt * KSC) * 1024);
+          }
+          static_for<0, KSC * MJ>([&](auto gg) __attribute__((always_inline)) {
+            constexpr int g = decltype(gg)::value, ks = g / MJ, j = g % MJ;
+            if constexpr (HP) {
+              constexpr int f = c * KSC * MJ + g, slot = f % PF;
+#pragma unroll
+              for (int pt = 0; pt < NPT; ++pt) acc[j][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot], bfr[ks & 1][pt], acc[j][pt], 0, 0, 0);
+              if constexpr (j == 0 && ks + 1 < KSC) {
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) bfr[(ks + 1) & 1][pt] = *(const bf16x8*)(src + (pt * KSC + ks + 1) * 1024);
+              }
+              constexpr int fn = (f + PF) % FR;   // (the next step walks the same fragments again)
+              ring[slot] = ldb<bf16x8>(rW, l16, (unsigned)fn * 1024u);
+            }
+            if constexpr (c + 1 < NCH && g <= 10) gslice(std::integral_constant<int, c + 1>{}, gg, sv[(c + 1) & 1]);
+            eslice(cc, gg);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+          if constexpr (c + 1 < NCH) {
+            bar();
+            write_T();
+          }
           bar();
-          write_T();
-        }
-        bar();
-      });
+        });
+      };
+      // The product runs at t = 0 as well (its result, "dh_{-1}", is dropped): one sixth more MFMA work -- the matrix cores are not what bounds this
+      // launch -- for ONE copy of the step body with no branches in it.  (Two copies, with and without, cost 500 spilled registers.)
+      chunks(std::true_type{});
       // dh_{t-1} is complete: it becomes the step's dh (lane-private LDS slots), the accumulators start again from zero
-      if (t > 0) {
+      {
 #pragma unroll
         for (int j = 0; j < MJ; ++j)
 #pragma unroll
@@ -415,6 +433,7 @@ void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSa
   a.WpB = p->WpB; a.dA = dA16; a.dAT = dAT16; a.gbias = h->g_dense + h->layer[0].bi;
   a.N = N; a.Np = Np; a.ldT = (int64_t)T * Np; a.T = T;
   a.tiles = (N + 63) / 64;
+  KPRN_REQUIRE(a.ldT * 64 < ((int64_t)1 << 32), KPRN_E_ARG, "persistent BPTT: T x N too large for 32-bit row-block offsets of dA^T");
   int grid = (int)std::min<int64_t>(p->grid, a.tiles);
   if (const char* e = getenv("KPRN_PERSIST_BWD_GRID")) grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, atoi(e)));   // (tests: several tiles per workgroup at small N)
   const size_t lds_bytes = (size_t)2 * pb::BUF + (size_t)pb::TT + (size_t)4 * pb::H * sizeof(float) + (size_t)pb::MJ * pb::NPT * 4 * 4096;

@@ -194,3 +194,31 @@ def test_ragged_last_tile_many_tiles_per_workgroup(compute_dtype):
     loss = eng.backward(b, 1)
     case.check_grads(eng, loss)
     eng.close()
+
+
+def test_reference_minibatch_regime_through_the_host_buffer_entry_points():
+    """What bindings/kprn.lua calls at the reference's own sizes: kprn_train_step from host buffers with 128 pairs (run_scripts/config.sh:38),
+    P per minibatch from the fixture distribution (one bucket file per minibatch: movie_data_format.py:311-314), the loss returned every
+    step (MyOptimizer.lua:177-221), then kprn_forward with 512 pairs (test_from_checkpoint.lua:49,109) -- every step's loss, the final
+    parameters and the scores against the float64 oracle at the fp32 bars of this file."""
+    Ve = 20000
+    shape = dict(SHAPE, Ve=Ve)
+    o64 = Oracle(make_cfg(**shape), np.float64)
+    th = o64.init_params(31, 0.1).astype(np.float32).astype(np.float64)
+    eng = _ffi.Engine(6, Ve, 9, 16, 32, 16, 64, 2)
+    eng.set_flat_params(th.astype(np.float32))
+    rng = np.random.default_rng(99)
+    opt, oopt, st = _ffi.make_opt(method=1, lr=1e-3), make_opt(method=1, lr=1e-3), o64.new_state()
+    for k in range(12):
+        Pk = int(min(rng.geometric(0.57), 28))
+        idx, labels = synth.make_paths(128, Pk, T, Ve=Ve, seed=900 + k)
+        ol, _ = o64.train_step(th, st, oopt, idx, labels)
+        gl = eng.train_step_host(idx, labels, opt)
+        assert abs(gl - ol) < 1e-5 * max(1.0, abs(ol)), (k, Pk, gl, ol)
+    assert float(np.max(np.abs(eng.get_flat_params() - th))) < 5e-6
+    for k, Pk in enumerate((1, 3, 28)):
+        idx, _ = synth.make_paths(512, Pk, T, Ve=Ve, seed=950 + k)
+        probs, allp = eng.forward_host(idx, 1)
+        _, _, want = o64.forward(th, idx)
+        np.testing.assert_allclose(probs, want[:, 0], rtol=1e-5)
+    eng.close()

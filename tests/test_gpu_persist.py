@@ -37,6 +37,8 @@ def direction(got, want, floor=0.05):
     """(cosine, share of the elements above `floor` x the largest |want| whose sign agrees): what a misplaced tile or a transposed operand
     cannot pass, whatever the rounding noise"""
     got, want = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
+    if not np.any(want):   # (a gradient that is identically zero -- W_o2g at T = 1 -- has no direction: it must BE zero)
+        return (1.0, 1.0) if not np.any(got) else (0.0, 0.0)
     big = np.abs(want) > floor * np.max(np.abs(want))
     cos = float(got @ want / max(1e-300, np.linalg.norm(got) * np.linalg.norm(want)))
     return cos, float(np.mean(np.sign(got[big]) == np.sign(want[big]))) if big.any() else 1.0
