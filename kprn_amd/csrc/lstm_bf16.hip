@@ -454,6 +454,133 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
     }
 }
 
+// ---- the same tiles with the A operand handed over K-MAJOR: C[m][n] = sum_k AT[k][m] B[n][k]  (round 4) ----------------------------------------------
+// dx = dA W_i2g with dA as the persistent BPTT launch leaves it for the dW products anyway: TRANSPOSED, [gate column][step][path] (lstm_bf16_bwd_persist.hip).
+// Reading it here saves that launch its second, row-major copy of dA (1.2 GB per step of configs[3], written in 16-byte pieces scattered over 64 rows per
+// wave instruction: 0.46 ms of its 1.35).  The A stage is the k-major image itself: 64 k-rows of 256 paths (512 bytes), filled by the same LDS-DMA
+// (one instruction = two k-rows), and the fragment of v_mfma_f32_32x32x16_bf16 -- lane (m, kg) holds A[m][8 kg .. + 7] -- is formed by two
+// ds_read_b64_tr_b16 per lane: inside a 16-lane group, lane p points at 4 consecutive paths of k-row (p >> 2) and gets back the 4 k-rows of ITS path
+// (probed: scripts/ubench/tr16_probe.hip).  Bank conflicts: the 32 lanes of a phase touch 4 k-rows x 64 bytes, and 512-byte rows put those on the
+// same banks; the 64-byte unit a piece lands in is therefore XORed with (k & 3) -- on the SOURCE side (the DMA writes LDS linearly) and again in the
+// read address.  Column m' of AT is (step, path) with Np >= N paths per step (pad columns): the epilogue maps it to row step N + path of C.
+struct XTArgs {
+  const bf16* AT; int64_t ldat; const bf16* B; int64_t ldb; float* C; int64_t ldc; int64_t Mp; int N; int64_t K;
+  int64_t mtiles; int ntiles; int64_t Np, Nv; const bf16* zero;
+};
+__global__ __launch_bounds__(NTHR, 2) void k_gemm16xt(XTArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kg = lane >> 5;
+  const int64_t id = blockIdx.x;
+  const int xcd = (int)(id & 7);
+  const int64_t j = id >> 3;
+  const int nt_idx = (int)(j % a.ntiles);              // the n-tiles of one m-tile back to back on one XCD: its A columns are fetched into that L2 once
+  const int64_t mt_idx = (j / a.ntiles) * 8 + xcd;
+  if (mt_idx >= a.mtiles) return;
+  const int64_t m0 = mt_idx * BM;
+  const int n0 = nt_idx * BN;
+  const int nch = (int)((a.K + BK - 1) / BK);
+  // this lane's share of a chunk's 48 DMA instructions.  A (q < 32): instruction q = k-rows 2 q, 2 q + 1; the lane fills physical slot lane & 31 of
+  // k-row 2 q + (lane >> 5) with the piece (8 paths) whose 64-byte unit is (slot >> 2) ^ (k & 3).  B (q >= 32): 8 rows x 128 bytes, as k_gemm16x.
+  const bf16* src0[6]; int64_t step[6]; int kofs[6]; bool isa[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int q = wave + 8 * i;
+    isa[i] = q < 32;
+    if (isa[i]) {
+      const int krow = 2 * q + (lane >> 5), ps = lane & 31;
+      const int ls = ((((ps >> 2) ^ (krow & 3))) << 2) | (ps & 3);
+      const int64_t m = m0 + 8 * ls;
+      kofs[i] = krow;
+      src0[i] = (m < a.Mp) ? a.AT + (int64_t)krow * a.ldat + m : nullptr;
+      step[i] = (int64_t)BK * a.ldat;
+    } else {
+      const int row = 8 * (q - 32) + (lane >> 3);
+      const int piece = (lane & 7) ^ ((row >> 1) & 7);
+      kofs[i] = 8 * piece;
+      src0[i] = (n0 + row < a.N) ? a.B + (int64_t)(n0 + row) * a.ldb + 8 * piece : nullptr;
+      step[i] = BK;
+    }
+  }
+  const unsigned lds0 = lds_off(smem);
+  auto issue = [&](int c) {
+    const unsigned st = lds0 + (unsigned)(c % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const bf16* src = (src0[i] && (int64_t)c * BK + kofs[i] < a.K) ? src0[i] + (int64_t)c * step[i] : a.zero;
+      dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + (unsigned)(wave + 8 * i) * 1024u)));
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
+  issue(0);
+  if (nch > 1) issue(1);
+  // A fragment addresses: lane p of a 16-lane group -> k-row (p >> 2) of the read's four, paths mb + 4 (p & 3) .. + 3 of the wave's 32-row fragment i
+  const int p16 = lane & 15, mb = r & 16;
+  int aoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ml = wm * 64 + i * 32 + mb + 4 * (p16 & 3);
+    const int ls = ml >> 3, ps = ((((ls >> 2) ^ (p16 >> 2))) << 2) | (ls & 3);
+    aoff[i] = (8 * kg + (p16 >> 2)) * 512 + ps * 16 + (ml & 7) * 2;
+  }
+  const int key = (r >> 1) & 7;
+  const int brow = BM * 128 + (wn * 64 + r) * 128;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (c + 2 < nch) issue(c + 2);
+    const char* st = smem + (c % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int po = ((2 * kk + kg) ^ key) << 4;
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + aoff[i] + (16 * kk) * 512));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + aoff[i] + (16 * kk + 4) * 512));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fa[i] = __builtin_bit_cast(bf16x8, both);
+      }
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) fb[jn] = *(const bf16x8*)(st + brow + jn * 32 * 128 + po);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+    }
+  }
+  const bool same = a.Np == a.Nv;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+      const int n = n0 + wn * 64 + jn * 32 + r;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t mp = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+        if (mp >= a.Mp) continue;
+        int64_t row = mp;
+        if (!same) {   // pad columns between the steps (N not a multiple of 8): 32-bit arithmetic (host: Mp < 2^32)
+          const unsigned tq = (unsigned)mp / (unsigned)a.Np, path = (unsigned)mp - tq * (unsigned)a.Np;
+          if ((int64_t)path >= a.Nv) continue;
+          row = (int64_t)tq * a.Nv + path;
+        }
+        a.C[row * a.ldc + n] = acc[i][jn][q];
+      }
+    }
+}
+
 // ---- 256 x 192 x 32 tiles for N = a multiple of 192 (configs[3]: N = 384); opt-in (KPRN_BF16_GEMM=y), a measured non-improvement ------------------
 // The idea: k_gemm16x is balanced on the LDS pipe: a 64 x 64 per-wave tile reads 1 KiB of LDS per v_mfma_f32_32x32x16_bf16 and the CU's 128 B/clk feed exactly
 // four SIMDs at 32 cycles per MFMA.  Here a wave owns 64 x 96 (2 x 3 MFMA tiles: 0.83 KiB per MFMA), N = 384 is two column tiles instead of three (A is
@@ -620,6 +747,29 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   else hipLaunchKernelGGL((gx::k_gemm16x<false>), grid, dim3(gx::NTHR), lds_bytes, s, a);
   HIP_TRY(hipGetLastError());
   return true;
+}
+
+// C[(step, path)][N] (fp32) = sum_k AT[k][step Np + path] B[n][k]: the k-major A operand (gx::k_gemm16xt); false = shape not covered
+static bool gemm16xt(hipStream_t s, const bf16* AT, int64_t ldat, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t Mp, int N, int64_t K, int64_t Np, int64_t Nv) {
+  static const bool off = getenv("KPRN_BF16_DX_T") && getenv("KPRN_BF16_DX_T")[0] == '0';
+  if (off || Mp < gx::BM || Mp >= ((int64_t)1 << 32) || N < gx::BN || (K & 7) || (ldat & 7) || (ldb & 7) || (Np & 7)) return false;
+  gx::XTArgs a;
+  memset(&a, 0, sizeof(a));
+  a.AT = AT; a.ldat = ldat; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.Mp = Mp; a.N = N; a.K = K; a.Np = Np; a.Nv = Nv; a.zero = zero16();
+  a.mtiles = (Mp + gx::BM - 1) / gx::BM; a.ntiles = (N + gx::BN - 1) / gx::BN;
+  const size_t lds_bytes = (size_t)gx::NSTAGE * gx::STAGE_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16xt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gx::k_gemm16xt, dim3((unsigned)(((a.mtiles + 7) / 8) * 8 * a.ntiles)), dim3(gx::NTHR), lds_bytes, s, a);
+  HIP_TRY(hipGetLastError());
+  return true;
+}
+bool dx_from_transposed_ok(int64_t Mp, int N, int64_t K, int64_t Np) {   // (the BPTT launch asks before it drops its row-major copy of dA)
+  static const bool off = getenv("KPRN_BF16_DX_T") && getenv("KPRN_BF16_DX_T")[0] == '0';
+  return !off && Mp >= gx::BM && Mp < ((int64_t)1 << 32) && N >= gx::BN && !(K & 7) && !(Np & 7);
 }
 
 // ---- element-wise / layout kernels --------------------------------------------------------------------------------------
@@ -941,7 +1091,7 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
 void persist_release(void*& st);
 // lstm_bf16_bwd_persist.hip: BPTT through the layer (cell backward + recurrent product of all T steps) as one persistent launch
 bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv);
-void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16, bf16* dAT16, int64_t Np);
+void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16 /* nullable: no row-major copy */, bf16* dAT16, int64_t Np);
 void persist_bwd_release(void*& st);
 static State* st(kprn_handle* h) {
   if (!h->bf16_state) h->bf16_state = new State();
@@ -1131,9 +1281,11 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), strm));
       HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), strm));
     }
+    // dx straight from the transposed dA the BPTT launch writes for the dW products (gx::k_gemm16xt): that launch then writes no row-major copy
+    const int64_t Np_ = (N + 7) & ~(int64_t)7;
+    const bool dx_t = bptt_persist && dx_from_transposed_ok((int64_t)T * Np_, Din, G4, Np_);
     if (bptt_persist) {
-      const int64_t Np_ = (N + 7) & ~(int64_t)7;
-      persist_backward(h, N, T, cid, s->sv, s->persist_bwd, s->packb_dirty, s->dA16, s->dAT16, Np_);
+      persist_backward(h, N, T, cid, s->sv, s->persist_bwd, s->packb_dirty, dx_t ? nullptr : s->dA16, s->dAT16, Np_);
       s->packb_dirty = false;
       s->bias_in_gates = true;   // (the launch sums the bias gradient from the dA^T pieces it writes)
     }
@@ -1199,7 +1351,8 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     }
     {
       ProfScope ps(h, "gemm_i2g_bwd_dx");   // dx [T N][Din] = dA W_i2g
-      gemm16(strm, s->dA16, G4, wt, G4, w.dIn, Din, TN, Din, G4, false, nullptr, 1);
+      if (!(dx_t && gemm16xt(strm, s->dAT16, TNp, wt, G4, w.dIn, Din, TNp, Din, G4, Np, N)))
+        gemm16(strm, s->dA16, G4, wt, G4, w.dIn, Din, TN, Din, G4, false, nullptr, 1);
     }
   }
   {

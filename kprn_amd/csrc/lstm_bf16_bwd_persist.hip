@@ -100,7 +100,8 @@ __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __builtin_am
 // the saves of this lane's quad of one chunk, per path tile
 struct Sv { bf16x8 a0[NPT], a1[NPT]; bf16x4 c[NPT], cp[NPT]; };
 
-// DBG (measurement builds, KPRN_PERSIST_VARIANTS + KPRN_PERSIST_BWD_DBG): 1 no dA^T / bias pass, 2 no row-major dA stores, 4 no product, 8 no save loads
+// DBG: 2 = no row-major copy of dA (the product default: dx reads the transposed image, lstm_bf16.hip gx::k_gemm16xt; 0 keeps it for the row-major
+// dx product).  Measurement builds (KPRN_PERSIST_VARIANTS + KPRN_PERSIST_BWD_DBG) add: 1 no dA^T / bias pass, 4 no product, 8 no save loads
 template <int DBG>
 __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -404,7 +405,7 @@ void persist_bwd_release(void*& st) {
 }
 
 // dA_t (row-major and transposed) for all steps + the bias gradient, from the persistent forward's saves; ws.dS holds d loss / d S[:, cid]
-void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16, bf16* dAT16, int64_t Np) {
+void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16 /* nullable: no row-major copy */, bf16* dAT16, int64_t Np) {
   hipStream_t strm = h->stream;
   PersistBwdState* p = (PersistBwdState*)st;
   if (!p) {
@@ -438,12 +439,12 @@ void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSa
   if (const char* e = getenv("KPRN_PERSIST_BWD_GRID")) grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, atoi(e)));   // (tests: several tiles per workgroup at small N)
   const size_t lds_bytes = (size_t)2 * pb::BUF + (size_t)pb::TT + (size_t)4 * pb::H * sizeof(float) + (size_t)pb::MJ * pb::NPT * 4 * 4096;
   typedef void (*Kern)(pb::BArgs);
-  Kern k = (Kern)pb::k_lstm16_bwd_persist<0>;
+  Kern k = dA16 ? (Kern)pb::k_lstm16_bwd_persist<0> : (Kern)pb::k_lstm16_bwd_persist<2>;   // (2: no row-major copy -- dx reads the transposed image)
 #ifdef KPRN_PERSIST_VARIANTS
   // measurement builds (scripts/gpu_persist_knockouts.py bwd): KPRN_PERSIST_BWD_DBG = knock-out mask
   if (const char* e = getenv("KPRN_PERSIST_BWD_DBG")) {
-    const int dbg = atoi(e);
-    bool found = dbg == 0;
+    const int dbg = atoi(e) | (dA16 ? 0 : 2);
+    bool found = dbg == 0 || dbg == 2;
 #define KV(D) if (dbg == D) { k = (Kern)pb::k_lstm16_bwd_persist<D>; found = true; }
     KV(1) KV(2) KV(3) KV(4) KV(7) KV(8) KV(15)
 #undef KV

@@ -120,7 +120,8 @@ def test_agrees_with_the_per_step_bf16_pipeline(pairs, P, T):
     """Both pipelines round the same values to bf16 (table rows, weights, h_t) and accumulate in fp32; they differ in accumulation order
     and in nothing else, so scores agree far inside bf16 resolution and the backward (shared) sees the same saves."""
     res = {}
-    for tag, env in (("persist", {}), ("steps", {"KPRN_BF16_PERSIST": "0"}), ("bwd_steps", {"KPRN_BF16_BWD_PERSIST": "0"})):
+    for tag, env in (("persist", {}), ("steps", {"KPRN_BF16_PERSIST": "0"}), ("bwd_steps", {"KPRN_BF16_BWD_PERSIST": "0"}),
+                     ("dx_rowmajor", {"KPRN_BF16_DX_T": "0"})):
         r = subprocess.run([sys.executable, "-c", _AB % (ROOT, pairs, P, T, 50000)], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr[-1500:]
         res[tag] = json.loads(r.stdout.strip().splitlines()[-1])
@@ -133,6 +134,16 @@ def test_agrees_with_the_per_step_bf16_pipeline(pairs, P, T):
             got = a[nm]
             assert abs(got[0] - ref[0]) < 4e-3 * max(1e-30, ref[0]), (nm, got, ref)
             tol = 2e-3 * ref[3] + 1e-12
+            assert abs(got[1] - ref[1]) < tol and abs(got[2] - ref[2]) < tol, (nm, got, ref)
+    # dx = dA W_i2g from the TRANSPOSED dA (ds_read_b64_tr_b16 operand loads, gx::k_gemm16xt) against the row-major product on the same dA:
+    # the same bf16 products in another accumulation order -- the table gradients (everything downstream of dx) agree to fp32 rounding
+    a, b = res["persist"], res["dx_rowmajor"]
+    assert a["ps"] == b["ps"] and a["loss"] == b["loss"]
+    for nm, ref in b.items():
+        if nm.startswith("g_"):
+            got = a[nm]
+            assert abs(got[0] - ref[0]) < 1e-4 * max(1e-30, ref[0]), (nm, got, ref)
+            tol = 1e-4 * ref[3] + 1e-12
             assert abs(got[1] - ref[1]) < tol and abs(got[2] - ref[2]) < tol, (nm, got, ref)
     a, b = res["persist"], res["steps"]
     ps_a, ps_b = np.array(a["ps"]), np.array(b["ps"])
