@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--dp-unfused", action="store_true", help="data-parallel step: separate marking merge + row update instead of the union inside the row update (A/B)")
     ap.add_argument("--dp-score-first", action="store_true", help="data-parallel step: queue the scoring pass first (as the plain step does: it shares the chip with the training forward); default at world 1, where no collective needs hiding")
     ap.add_argument("--dp-score-under-gather", action="store_true", help="data-parallel step: queue the scoring pass behind the backward, while the all-gather is in flight; default at world > 1")
+    ap.add_argument("--dp-score-split", type=float, default=-1.0, help="data-parallel step: this fraction of the scoring pass's tiles runs behind the backward, under the all-gather; the rest is queued first, beside the training forward (default at world > 1: 0.5; 0 = the whole pass first, 1 = the whole pass under the gather)")
     ap.add_argument("--dp-torch-collectives", action="store_true", help="data-parallel step: the collectives through torch.distributed (hooks kprn_sparse_grad_pack / _merge) instead of the engine's own RCCL exchange")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact lines of the other BASELINE configs (each a short run of this script)")
     ap.add_argument("--cpu-baseline-quick", action="store_true", help="cpu_baseline: the model-only oracle sample only (no literal flavour, no torch-CPU point)")
@@ -620,7 +621,14 @@ def main():
         dpx = dp.DataParallel(dp.GpuAdapter(eng, dev, fused_update=not a.dp_unfused))
         # where the scoring pass goes: first (beside the training forward, as in the plain step) when no collective needs hiding, else behind
         # the backward while the all-gather is in flight (the engine's exchange then runs the collective on a stream of its own)
-        dp_score_first = a.dp_score_first or (world == 1 and not a.dp_score_under_gather)
+        dp_score_first = a.dp_score_first or (world == 1 and not a.dp_score_under_gather and a.dp_score_split < 0)
+        # the scoring pass split around the collective: most of it shares the chip with the training forward (as in the plain step), the
+        # rest gives the all-gather something to hide under
+        dp_split = 0.0
+        if not dp_score_first and not a.dp_score_under_gather and a.compute_dtype == 0:
+            dp_split = 0.5 if a.dp_score_split < 0 else a.dp_score_split
+        if 0.0 < dp_split < 1.0:
+            eng.set_option("score_split", str(dp_split))
         if dpx.native and not dp_score_first:
             eng.set_option("dp_comm_stream", "1")
         # packing capacity = largest distinct-row count of any batch on any rank (known from the batch index)
@@ -643,7 +651,12 @@ def main():
             # the backward while the all-gather is in flight.  profiles/r03 + DESIGN.md section 4 have the measured timelines of both.
             if score and dp_score_first:
                 score()
-            dpx.train_step(b, opt, 1, overlap=None if dp_score_first else score)
+                dpx.train_step(b, opt, 1, overlap=None)
+            elif score and 0.0 < dp_split < 1.0:
+                score()                                                       # first part: beside the training forward
+                dpx.train_step(b, opt, 1, overlap=eng.forward_async_rest)     # the rest: under the all-gather
+            else:
+                dpx.train_step(b, opt, 1, overlap=score)
         else:
             if score:
                 score()
@@ -847,7 +860,9 @@ def main():
         dp_info["per_rank_ms_per_step"] = [round(float(x.item()), 4) for x in allr]
         dp_info["exchange"] = ("engine: in-place RCCL all-gather on the engine's stream, union inside the row update" if dpx.native else
                                "torch.distributed collectives around the pack / merge hooks" + ("" if a.dp_unfused else ", union inside the row update"))
-        dp_info["scoring_pass"] = "first, beside the training forward" if dp_score_first else "behind the backward, under the all-gather"
+        dp_info["scoring_pass"] = ("first, beside the training forward" if dp_score_first else
+                                   (f"split: {1 - dp_split:.2f} of its tiles first (beside the training forward), {dp_split:.2f} behind the backward, under the all-gather"
+                                    if 0.0 < dp_split < 1.0 else "behind the backward, under the all-gather"))
 
     loss = eng.read_loss()
     assert np.isfinite(loss), "training diverged"

@@ -62,6 +62,7 @@ int kprn_dp_unique_id(const char*, void*);
 int kprn_dp_init(kprn_handle*, const char*, const void*, int32_t, int32_t);
 int kprn_dp_exchange_begin(kprn_handle*, int32_t);
 int kprn_dp_exchange_finish(kprn_handle*, const kprn_opt*);
+int kprn_forward_batch_async_rest(kprn_handle*);
 int kprn_dp_comm_size(kprn_handle*, int32_t*);
 int kprn_dp_shutdown(kprn_handle*);
 ]]

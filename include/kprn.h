@@ -195,6 +195,11 @@ int kprn_forward_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id,
                        float* probs, float* all_probs, float* pooled, float* path_scores);
 /* async variant for throughput loops: results stay on the device until kprn_read_probs  */
 int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id);
+/* kprn_set_option(h, "score_split", "f"): kprn_forward_batch_async queues the first (1 - f) of the batch's 64-path tiles only; this call queues
+ * the rest + the pooling stage behind everything queued so far (a data-parallel step: between kprn_dp_exchange_begin and _finish, so that the
+ * collective has compute to hide under while most of the pass shared the chip with the training forward).  Whatever waits for the pass
+ * (the optimiser step, kprn_read_probs) places a forgotten second part itself. */
+int kprn_forward_batch_async_rest(kprn_handle* h);
 int kprn_read_probs(kprn_handle* h, float* probs, int32_t B);
 /* embedding sub-net output x[N,T,D] (FeatureEmbedding.lua:112-121), for bit-exact checks */
 int kprn_embed(kprn_handle* h, const int32_t* idx, int64_t N, int32_t T, int32_t F, float* x);

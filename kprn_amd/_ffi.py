@@ -401,6 +401,10 @@ class Engine:
     def forward_async(self, batch, class_id=1):
         self._ck(self.L.kprn_forward_batch_async(self.h, batch.ptr, int(class_id)))
 
+    def forward_async_rest(self):
+        """second part of a split scoring pass (set_option("score_split", f))"""
+        self._ck(self.L.kprn_forward_batch_async_rest(self.h))
+
     def read_probs(self, B):
         a = np.empty(B, np.float32)
         self._ck(self.L.kprn_read_probs(self.h, _fp(a), int(B)))

@@ -17,7 +17,7 @@
 
 namespace fused {
 bool fwd_supported(const kprn_handle* h, int T);
-void forward(kprn_handle* h, const kprn_batch* b, bool save);
+void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin = 0, int64_t tile_end = -1, bool ignore_reserve = false);
 bool bwd_supported(const kprn_handle* h, int T);
 void backward(kprn_handle* h, const kprn_batch* b, int cid);
 void params_changed(kprn_handle* h);
@@ -149,7 +149,9 @@ static void step_tab_reserve(kprn_handle* h, int64_t need) {
 
 // scoring overlap: the main stream waits for the pass running on the side stream (before anything that changes what that pass
 // reads -- parameters, the prefix table -- and before the backward kernels, which want the chip to themselves)
+static void launch_score_rest(kprn_handle* h);
 void join_score(kprn_handle* h) {
+  if (h->score_rest_batch) launch_score_rest(h);   // (a split pass whose second part nobody placed: it goes now)
   if (!h->score_pending) return;
   HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_score_done, 0));
   h->score_pending = false;
@@ -1492,6 +1494,7 @@ void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
     if (b->job.valid()) { try { b->job.get(); } catch (...) {} }
     if (h->upload_stream) hipStreamSynchronize(h->upload_stream);
     if (h->feed_stream) hipStreamSynchronize(h->feed_stream);
+    if (h->score_rest_batch == b) { try { launch_score_rest(h); } catch (...) { h->score_rest_batch = nullptr; } }   // (the deferred part of a split pass reads the batch)
     if (h->score_stream) hipStreamSynchronize(h->score_stream);  // a scoring pass on the second stream may still read the batch
     hipStreamSynchronize(h->stream);
   }
@@ -1591,12 +1594,18 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
     hipStream_t main_stream = h->stream;
     float* S0 = w.S; float* sel0 = w.sel;
     h->stream = h->score_stream; w.S = h->S2; w.sel = h->sel2;
+    // "score_split" f: the last f of the batch's tiles wait for kprn_forward_batch_async_rest (a data-parallel step places them under its
+    // collective); the first part runs now, beside whatever is queued next, on the whole chip
+    const int64_t n_tiles = (N + 63) / 64;
+    const int64_t t_split = (h->score_split > 0.f && h->cfg.compute_dtype == 0 && n_tiles >= 64)
+                                ? std::max<int64_t>(1, std::min<int64_t>(n_tiles - 1, (int64_t)((1.0 - h->score_split) * n_tiles + 0.5))) : n_tiles;
     try {
-      fused::forward(h, b, false);
-      pool_stage(h, b, class_id - 1, false);
+      fused::forward(h, b, false, 0, t_split < n_tiles ? t_split : -1, t_split < n_tiles);
+      if (t_split == n_tiles) pool_stage(h, b, class_id - 1, false);
     } catch (...) { h->stream = main_stream; w.S = S0; w.sel = sel0; throw; }
     h->stream = main_stream; w.S = S0; w.sel = sel0;
-    HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
+    if (t_split < n_tiles) { h->score_rest_batch = b; h->score_rest_cid = class_id; h->score_rest_tile0 = t_split; }
+    else HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
     h->score_pending = true;
     h->last_forward_side = true;
     h->last_B = b->B;
@@ -1606,10 +1615,37 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
   API_END(h)
 }
 
+// the second part of a split scoring pass (kprn_set_option "score_split"): the remaining tiles + the pooling stage, behind everything queued
+// on the main stream so far
+static void launch_score_rest(kprn_handle* h) {
+  const kprn_batch* b = h->score_rest_batch;
+  h->score_rest_batch = nullptr;
+  if (!b) return;
+  HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+  HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_fork, 0));
+  Workspace& w = h->ws;
+  hipStream_t main_stream = h->stream;
+  float* S0 = w.S; float* sel0 = w.sel;
+  h->stream = h->score_stream; w.S = h->S2; w.sel = h->sel2;
+  try {
+    fused::forward(h, b, false, h->score_rest_tile0, -1);
+    pool_stage(h, b, h->score_rest_cid - 1, false);
+  } catch (...) { h->stream = main_stream; w.S = S0; w.sel = sel0; throw; }
+  h->stream = main_stream; w.S = S0; w.sel = sel0;
+  HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
+}
+
+int kprn_forward_batch_async_rest(kprn_handle* h) {
+  API_BEGIN(h)
+  launch_score_rest(h);
+  API_END(h)
+}
+
 int kprn_read_probs(kprn_handle* h, float* probs, int32_t B) {
   API_BEGIN(h)
   KPRN_REQUIRE(probs && B > 0 && B <= h->last_B, KPRN_E_ARG, "bad probs buffer / B");
   if (h->last_forward_side) {
+    if (h->score_rest_batch) launch_score_rest(h);
     HIP_TRY(hipMemcpyAsync(probs, h->sel2, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->score_stream));
     HIP_TRY(hipStreamSynchronize(h->score_stream));
   } else {
@@ -2147,6 +2183,12 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     else throw KprnError{KPRN_E_ARG, "impl must be auto or generic"};
   } else if (strcmp(key, "prefix_plan") == 0) {
     h->prefix_plan = atoi(value) ? 1 : 0;  // batches created from now on (an existing batch keeps what it was built with)
+  } else if (strcmp(key, "score_split") == 0) {
+    // kprn_forward_batch_async queues only the first (1 - f) of the batch's tiles; kprn_forward_batch_async_rest the others + the pooling
+    join_score(h);
+    const double f = atof(value);
+    KPRN_REQUIRE(f >= 0.0 && f < 1.0, KPRN_E_ARG, "score_split: a fraction in [0, 1)");
+    h->score_split = (float)f;
   } else if (strcmp(key, "score_overlap") == 0) {
     // kprn_forward_batch_async on a second stream (fused path): the scoring pass shares the chip with the work enqueued after it
     join_score(h);

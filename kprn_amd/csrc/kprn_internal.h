@@ -203,6 +203,8 @@ struct kprn_handle {
   int side_stream_probes = 0;     // candidates tried before one ran beside the main stream (kprn_api.hip make_concurrent_stream)
   hipEvent_t ev_fork = nullptr, ev_score_done = nullptr;
   bool score_pending = false;     // a pass is (possibly) still running on score_stream
+  float score_split = 0.f;        // option: fraction of a scoring pass's tiles deferred to kprn_forward_batch_async_rest
+  const kprn_batch* score_rest_batch = nullptr; int score_rest_cid = 1; int64_t score_rest_tile0 = 0;   // the deferred part of a split pass
   bool last_forward_side = false; // kprn_read_probs reads the side buffers
   float* S2 = nullptr; float* sel2 = nullptr; int64_t cap_N2 = 0, cap_B2 = 0;
   int reserve_cus = 0;          // CUs the SCORING forward leaves free (a collective's copy kernels run beside it; kprn_set_option)

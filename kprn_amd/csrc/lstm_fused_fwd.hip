@@ -438,7 +438,10 @@ static void launch_fwd(kprn_handle* h, const FwdArgs& a, int grid) {
   HIP_TRY(hipGetLastError());
 }
 
-void forward(kprn_handle* h, const kprn_batch* b, bool save) {
+// tile_begin / tile_end (scoring only, tile_end < 0 = all): the pass restricted to a range of the batch's 64-path tiles -- a scoring pass split
+// in two around a data-parallel step's collective (kprn_set_option "score_split").  The kernel sees a shorter batch: the per-tile arrays are
+// handed over shifted, scores still land at their path's own row of S.
+void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin, int64_t tile_end, bool ignore_reserve) {
   const kprn_config& c = h->cfg;
   if (c.compute_dtype != 0) { forward_mc(h, b, save); return; }  // bf16 / f32x6: the matrix-core forward (lstm_fused_fwd_mc.hip)
   State* s = st(h);
@@ -456,6 +459,15 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   a.Wout = h->dense + h->off_outW; a.bout = h->dense + h->off_outb; a.C = c.C;
   a.S = h->ws.S;
   a.n_tiles = (N + MT - 1) / MT;
+  if (!save && (tile_begin > 0 || tile_end >= 0)) {
+    const int64_t t0 = std::min<int64_t>(tile_begin, a.n_tiles), t1 = tile_end < 0 ? a.n_tiles : std::min<int64_t>(tile_end, a.n_tiles);
+    if (t1 <= t0) return;
+    a.idx += t0 * MT * a.T * a.F;
+    if (a.perm) a.perm += t0 * MT; else a.S += t0 * MT * (int64_t)c.C;
+    if (a.tile_k) a.tile_k += t0;
+    a.N = std::min<int64_t>(N, t1 * MT) - t0 * MT;
+    a.n_tiles = t1 - t0;
+  }
   a.save_frag = nullptr;
   if (save) {
     if (N > s->cap_N || b->T > s->cap_T) {
@@ -469,7 +481,7 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
     }
     a.save_frag = s->save_frag;
   }
-  const int cus = (!save && h->reserve_cus > 0) ? std::max(1, s->num_cu - h->reserve_cus) : s->num_cu;
+  const int cus = (!save && h->reserve_cus > 0 && !ignore_reserve) ? std::max(1, s->num_cu - h->reserve_cus) : s->num_cu;
   const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)cus);
   static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
   if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));

@@ -222,3 +222,29 @@ def test_reference_minibatch_regime_through_the_host_buffer_entry_points():
         _, _, want = o64.forward(th, idx)
         np.testing.assert_allclose(probs, want[:, 0], rtol=1e-5)
     eng.close()
+
+
+@pytest.mark.parametrize("plan", [True, False])
+def test_split_scoring_pass_is_bit_identical(plan):
+    """kprn_set_option("score_split", f): the scoring pass as two launches over disjoint tile ranges (the second one placed by the caller -- a
+    data-parallel step puts it under its collective -- or, when forgotten, by whoever waits for the pass): the same bits as the single launch,
+    with and without the identical-prefix plan, ragged last tile included."""
+    case = Case(16389, 29)
+    eng = case.engine(0, "auto", plan)
+    eng.set_option("score_overlap", "1")
+    b = eng.batch(case.idx, case.labels)
+    eng.forward_async(b, 1)
+    ref = eng.read_probs(b.B).copy()
+    np.testing.assert_allclose(ref, case.probs[:, 0], rtol=1e-5)
+    for f in ("0.4", "0.75"):
+        eng.set_option("score_split", f)
+        eng.forward_async(b, 1)
+        eng.forward_async_rest()
+        assert np.array_equal(eng.read_probs(b.B), ref), f
+        eng.forward_async(b, 1)                      # the second part never placed: read_probs places it
+        assert np.array_equal(eng.read_probs(b.B), ref), f
+        eng.forward_async(b, 1)                      # ... or the optimiser step, which waits for the pass
+        eng.train_step(b, _ffi.make_opt(method=1, lr=0.0), 1, want_loss=False)
+        assert np.array_equal(eng.read_probs(b.B), ref), f
+    eng.set_option("score_split", "0")
+    eng.close()
