@@ -251,7 +251,7 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4, NT=None):
 
 def pmc_traffic(name, paths_per_step):
     """HBM bytes per launch of kernel family `name` from the rocprofv3 PMC passes of this very command
-    (scripts/gpu_pmc.sh -> profiles/<round>/pmc_summary.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
+    (scripts/gpu_profile.sh -> profiles/<round>/pmc_summary_<tag>.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
     passes).  bench.py cannot collect counters on itself; None when no summary for this workload size is committed."""
     import glob
     best = None

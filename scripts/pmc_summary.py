@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel averages of the rocprofv3 PMC passes written by scripts/gpu_pmc.sh.
+"""Per-kernel averages of the rocprofv3 PMC passes written by scripts/gpu_profile.sh.
 
 Units / gfx950 corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
 FETCH_SIZE and WRITE_SIZE are reported in KiB-like units of the TCC_EA request counters; on gfx950
@@ -30,6 +30,8 @@ def load(path):
 
 def short(name):
     """kernel family as bench.py's profiler names it"""
+    if "k_lstm16_bwd_persist" in name:   # persistent bf16 BPTT kernel
+        return "lstm_persist_bf16_bwd"
     if "k_lstm16_persist" in name:   # persistent bf16 layer kernel: <KX, KH, SAVE, ...>
         return "lstm_persist_bf16_train" if "24, 24, true" in name.replace("(bool)1", "true") else "lstm_persist_bf16_score"
     if "k_lstm_fwd_mc" in name:
@@ -69,7 +71,7 @@ def main(d):
     for k, o in out.items():
         if "fetch_bytes_corrected" in o or "write_bytes_raw" in o:
             o["hbm_bytes_per_launch"] = o.get("fetch_bytes_corrected", 0.0) + o.get("write_bytes_raw", 0.0)
-    keep = {k: v for k, v in out.items() if "lstm" in k or "entity_grad" in k or "adam" in k or "loss" in k}
+    keep = {k: v for k, v in out.items() if "lstm" in k or "entity_grad" in k or "adam" in k or "loss" in k or "gemm16" in k}
     print(json.dumps(keep, indent=1, sort_keys=True))
 
 
