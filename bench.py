@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--dp-unfused", action="store_true", help="data-parallel step: separate marking merge + row update instead of the union inside the row update (A/B)")
     ap.add_argument("--dp-score-first", action="store_true", help="data-parallel step: queue the scoring pass first (as the plain step does: it shares the chip with the training forward); default at world 1, where no collective needs hiding")
     ap.add_argument("--dp-score-under-gather", action="store_true", help="data-parallel step: queue the scoring pass behind the backward, while the all-gather is in flight; default at world > 1")
-    ap.add_argument("--dp-score-split", type=float, default=-1.0, help="data-parallel step: this fraction of the scoring pass's tiles runs behind the backward, under the all-gather; the rest is queued first, beside the training forward (default at world > 1: 0.5; 0 = the whole pass first, 1 = the whole pass under the gather)")
+    ap.add_argument("--dp-score-split", type=float, default=-1.0, help="data-parallel step: this fraction of the scoring pass's tiles runs behind the backward, under the all-gather; the rest is queued first, beside the training forward (opt-in; default at world > 1: the whole pass under the gather)")
     ap.add_argument("--dp-torch-collectives", action="store_true", help="data-parallel step: the collectives through torch.distributed (hooks kprn_sparse_grad_pack / _merge) instead of the engine's own RCCL exchange")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact lines of the other BASELINE configs (each a short run of this script)")
     ap.add_argument("--cpu-baseline-quick", action="store_true", help="cpu_baseline: the model-only oracle sample only (no literal flavour, no torch-CPU point)")
@@ -621,12 +621,14 @@ def main():
         dpx = dp.DataParallel(dp.GpuAdapter(eng, dev, fused_update=not a.dp_unfused))
         # where the scoring pass goes: first (beside the training forward, as in the plain step) when no collective needs hiding, else behind
         # the backward while the all-gather is in flight (the engine's exchange then runs the collective on a stream of its own)
-        dp_score_first = a.dp_score_first or (world == 1 and not a.dp_score_under_gather and a.dp_score_split < 0)
+        dp_score_first = a.dp_score_first or (world == 1 and not a.dp_score_under_gather and a.dp_score_split <= 0)
         # the scoring pass split around the collective: most of it shares the chip with the training forward (as in the plain step), the
         # rest gives the all-gather something to hide under
         dp_split = 0.0
-        if not dp_score_first and not a.dp_score_under_gather and a.compute_dtype == 0:
-            dp_split = 0.5 if a.dp_score_split < 0 else a.dp_score_split
+        # (measured at world 1, profiles/r04: plain 1.461 ms, pass first 1.509, all of it under the gather 1.672, split 0.5 / 0.3: 1.612 / 1.624 --
+        #  work placed under the gather runs alone on 240 CUs in whole rounds of tiles, so the split buys 0.05 ms; opt-in)
+        if not dp_score_first and not a.dp_score_under_gather and a.compute_dtype == 0 and a.dp_score_split > 0:
+            dp_split = a.dp_score_split
         if 0.0 < dp_split < 1.0:
             eng.set_option("score_split", str(dp_split))
         if dpx.native and not dp_score_first:
