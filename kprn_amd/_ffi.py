@@ -243,6 +243,8 @@ class Engine:
         self._ck(self.L.kprn_num_params(self.h, C.byref(n)))
         self.n_params = int(n.value)
         self.D = dt + de + dr
+        if os.environ.get("KPRN_SMALL_TILES") is not None:   # (tests: the 64-path tiles + identical-prefix plan at small sizes too)
+            self.set_option("small_tiles", os.environ["KPRN_SMALL_TILES"])
 
     # -- plumbing ------------------------------------------------------------------------
     def _ck(self, rc):

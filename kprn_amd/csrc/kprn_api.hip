@@ -18,6 +18,7 @@
 namespace fused {
 bool fwd_supported(const kprn_handle* h, int T);
 void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin = 0, int64_t tile_end = -1, bool ignore_reserve = false);
+bool small_tiles(const kprn_handle* h, int64_t N, bool has_plan);
 bool bwd_supported(const kprn_handle* h, int T);
 void backward(kprn_handle* h, const kprn_batch* b, int cid);
 void params_changed(kprn_handle* h);
@@ -1103,6 +1104,8 @@ static void batch_release(kprn_batch* b) {
 
 static bool batch_wants_plan(kprn_handle* h, const kprn_batch* b) {
   static const char* dbg_env = getenv("KPRN_DBG");
+  // (small batches run on tiles of one 16-row m-tile, which have no per-tile prefix classes: lstm_fused_fwd.hip small_tiles)
+  if (fused::small_tiles(h, (int64_t)b->B * b->P, false)) return false;
   return h->prefix_plan && use_fused(h, b, true) && b->F <= 16 && !(dbg_env && (atoi(dbg_env) & 64));
 }
 
@@ -1623,7 +1626,7 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
     // "score_split" f: the last f of the batch's tiles wait for kprn_forward_batch_async_rest (a data-parallel step places them under its
     // collective); the first part runs now, beside whatever is queued next, on the whole chip
     const int64_t n_tiles = (N + 63) / 64;
-    const int64_t t_split = (h->score_split > 0.f && h->cfg.compute_dtype == 0 && n_tiles >= 64)
+    const int64_t t_split = (h->score_split > 0.f && h->cfg.compute_dtype == 0 && n_tiles >= 64 && !fused::small_tiles(h, N, b->tile_k != nullptr))
                                 ? std::max<int64_t>(1, std::min<int64_t>(n_tiles - 1, (int64_t)((1.0 - h->score_split) * n_tiles + 0.5))) : n_tiles;
     try {
       fused::forward(h, b, false, 0, t_split < n_tiles ? t_split : -1, t_split < n_tiles);
@@ -2227,6 +2230,10 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     else throw KprnError{KPRN_E_ARG, "impl must be auto or generic"};
   } else if (strcmp(key, "prefix_plan") == 0) {
     h->prefix_plan = atoi(value) ? 1 : 0;  // batches created from now on (an existing batch keeps what it was built with)
+  } else if (strcmp(key, "small_tiles") == 0) {
+    // batches created / fed from now on: <= 8 192 paths on tiles of one 16-row m-tile and no identical-prefix plan ("1", default), or the
+    // 64-path tiles at every size ("0")
+    h->small_tiles_on = atoi(value) != 0;
   } else if (strcmp(key, "score_split") == 0) {
     // kprn_forward_batch_async queues only the first (1 - f) of the batch's tiles; kprn_forward_batch_async_rest the others + the pooling
     join_score(h);

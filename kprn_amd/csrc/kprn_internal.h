@@ -205,6 +205,7 @@ struct kprn_handle {
   kprn_batch* dropin_slot[4] = {nullptr, nullptr, nullptr, nullptr};   // feed slots of the host-buffer entry points (kprn_train_step: 0 / 1, kprn_forward: 2 / 3)
   int dropin_next_train = 0, dropin_next_score = 0, dropin_last = 0;
   bool score_pending = false;     // a pass is (possibly) still running on score_stream
+  bool small_tiles_on = true;     // option "small_tiles": batches of <= 8 192 paths run on tiles of one 16-row m-tile (no identical-prefix plan)
   float score_split = 0.f;        // option: fraction of a scoring pass's tiles deferred to kprn_forward_batch_async_rest
   const kprn_batch* score_rest_batch = nullptr; int score_rest_cid = 1; int64_t score_rest_tile0 = 0;   // the deferred part of a split pass
   bool last_forward_side = false; // kprn_read_probs reads the side buffers

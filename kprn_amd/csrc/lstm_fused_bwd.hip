@@ -79,8 +79,10 @@ struct Pre {
   f32x4 bhp[4];  // B operands of dW_o2g: h^l_{t-1}, same layout
 };
 
-template <bool BOTTOM, bool TOP>
+// NMT: 16-row m-tiles of a tile -- 4, or 1 for small batches (fused::small_tiles; no identical-prefix plan there)
+template <bool BOTTOM, bool TOP, int NMT>
 __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
+  constexpr int MTR = 16 * NMT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = (KPRN_PROBES_ON && a.timing) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -141,21 +143,21 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   for (int64_t tq = 0; tq < n_mine; ++tq) {
     const int64_t ti = TOP ? n_mine - 1 - tq : tq;
     const int64_t tile = (int64_t)blockIdx.x + ti * gridDim.x;
-    const int64_t n0 = tile * MT;
+    const int64_t n0 = tile * MTR;
     const int k0 = a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tile]) : 0;  // steps below k0 belong to the prefix
     // Everything below counts steps from the tile's first executed one: tt = t - k0 in [0, Te).  The step index enters the
     // addresses only through these per-tile bases, so the step bodies see the same (compile-time 0 for the last step)
     // offsets whether or not the tile sits behind a prefix.
     const int Te = T - k0;
-    const float* frag_tile = a.save_frag + tile * 4 * frag_mt_stride + (int64_t)k0 * L * 4 * frag_unit + lane * 4;
-    float* dx_tile = a.DX + (((tile * 4) * T + k0) * 4 + j) * 256 + lane * 4;  // + (mt * T + tt) * 1024
+    const float* frag_tile = a.save_frag + tile * NMT * frag_mt_stride + (int64_t)k0 * L * 4 * frag_unit + lane * 4;
+    float* dx_tile = a.DX + (((tile * NMT) * T + k0) * 4 + j) * 256 + lane * 4;  // + (mt * T + tt) * 1024
     const int32_t* idk = ids + k0 * 4;                                           // [(row * T + tt) * 4 + slot]
     auto frag_ptr = [&](int mt, int t, int l, int w, int plane) -> const float* {
       return frag_tile + mt * frag_mt_stride + ((int64_t)(t * L + l) * 4 + w) * frag_unit + plane * 256;
     };
-    f32x4 dc[4], dh[4];
+    f32x4 dc[NMT], dh[NMT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < NMT; ++m) {
       dc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       dh[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (TOP) {
@@ -174,11 +176,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     }
     if (BOTTOM) {
       lds_barrier();  // previous tile's id tile / x tile fully consumed
-      ids_stage<256>(a.idx, a.N, T, a.F, a.nT, tile, ids);
+      ids_stage<256, MTR>(a.idx, a.N, T, a.F, a.nT, tile, ids);
       lds_barrier();
-      f32x4 nin[4];
-      gather_load<256>(a, gsrc, tile, Te - 1, idk, nin, T - 1);
-      gather_store<256>(in_t, nin);
+      f32x4 nin[MTR * 16 / 256];
+      gather_load<256, MTR>(a, gsrc, tile, Te - 1, idk, nin, T - 1);
+      gather_store<256, MTR>(in_t, nin);
       lds_barrier();
     }
     TPROBE(1)  // tile prologue
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         for (int nt = 0; nt < 4; ++nt) load_bin_lds(nt, 0);
       }
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int mt = 0; mt < NMT; ++mt) {
         // cell backward on the saved factors (elementwise on float4: register r <-> row 4 ag + r)
         f32x4 dhv = dh[mt];
         if (!TOP) dhv += up;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         TPROBE(7)  // stage C, VALU part (incl. waiting for the factors)
         // the factors are dead: request the next m-tile's (first m-tile of step t-1 after the last one)
-        if (mt < 3) load_P(mt + 1, t);
+        if (mt < NMT - 1) load_P(mt + 1, t);
         else if (REC) load_P(0, t - 1);
         // dW += dA^T [in | h_prev]: MFMA (nt, r, q) uses k-slot ag <-> row mt*16 + 4ag + r
 #pragma unroll
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
               if (REC) KPRN_MFMA_ACC_A(dwo[q][nt], dA[q][r], bhp[nt][r]);
             }
           __builtin_amdgcn_sched_barrier(0);
-          if (mt < 3) { load_B(nt, mt + 1, t, REC); if (BOTTOM) load_bin_lds(nt, mt + 1); }
+          if (mt < NMT - 1) { load_B(nt, mt + 1, t, REC); if (BOTTOM) load_bin_lds(nt, mt + 1); }
           else if (REC) load_B(nt, 0, t - 1, t > 1);
         }
         TPROBE(2)  // stage C, dW MFMAs (incl. waiting for the B fragments)
@@ -259,16 +261,20 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         // h_prefix).  Column sums of the dA tile, thread = column; kept out of the registers of the hot loop on purpose.
         float cs0 = 0.f, cs1 = 0.f;
 #pragma unroll 8
-        for (int row = 0; row < MT; row += 2) { cs0 += dA_t[row * LDD + tid]; cs1 += dA_t[(row + 1) * LDD + tid]; }
+        for (int row = 0; row < MTR; row += 2) { cs0 += dA_t[row * LDD + tid]; cs1 += dA_t[(row + 1) * LDD + tid]; }
         pg[k0 * PFB + tid] += cs0 + cs1;  // one owner thread per entry
       }
       TPROBE(3)  // mid barrier wait
       // bottom layer: x_{t-1} is requested here (latency hides under stage E) and lands after it
-      f32x4 nin[4];
-      if (BOTTOM && REC) gather_load<256>(a, gsrc, tile, t - 1, idk, nin, k0 + t - 1);
+      f32x4 nin[MTR * 16 / 256];
+      if (BOTTOM && REC) gather_load<256, MTR>(a, gsrc, tile, t - 1, idk, nin, k0 + t - 1);
 
       // ---- E. [dx | dh_prev] = dA * [W_i2g | W_o2g]; this wave: columns 16j..16j+15 of each ----------
       f32x4 ax[4], ah[4];
+      if constexpr (NMT < 4) {   // (the pins below name all four)
+#pragma unroll
+        for (int q = NMT; q < 4; ++q) { ax[q] = f32x4{0.f, 0.f, 0.f, 0.f}; ah[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
       {
         const float* abase = dA_t + arow * LDD + ag * 4;
         if (REC) {
@@ -277,16 +283,30 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
 #pragma unroll
           for (int S = 0; S < 16; ++S) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < NMT; ++mt) {
               const f32x4 a4 = apre;
-              const int gn = S * 4 + mt + 1;  // next group
+              const int gn = S * NMT + mt + 1;  // next group
               if (S == 0) { KPRN_MFMA_Z(ax[mt], a4[0], wiT[S][0]); KPRN_MFMA_Z(ah[mt], a4[0], woT[S][0]); }
               else { KPRN_MFMA(ax[mt], a4[0], wiT[S][0]); KPRN_MFMA(ah[mt], a4[0], woT[S][0]); }
               KPRN_MFMA(ax[mt], a4[1], wiT[S][1]); KPRN_MFMA(ah[mt], a4[1], woT[S][1]);
-              if (gn < 64) apre = *(const f32x4*)(abase + (gn & 3) * 16 * LDD + (gn >> 2) * 16);
+              if (gn < 16 * NMT) apre = *(const f32x4*)(abase + (gn % NMT) * 16 * LDD + (gn / NMT) * 16);
               KPRN_MFMA(ax[mt], a4[2], wiT[S][2]); KPRN_MFMA(ah[mt], a4[2], woT[S][2]);
               KPRN_MFMA(ax[mt], a4[3], wiT[S][3]); KPRN_MFMA(ah[mt], a4[3], woT[S][3]);
             }
+          }
+        } else if constexpr (NMT == 1) {
+          // t = 0, one m-tile: the k range is split over two accumulators (even / odd k-groups) so that consecutive MFMAs never chain on
+          // one accumulator; they are added behind the drain below
+          f32x4 ap0 = *(const f32x4*)(abase), ap1 = *(const f32x4*)(abase + 16);
+#pragma unroll
+          for (int S = 0; S < 16; S += 2) {
+            const f32x4 a0 = ap0, a1 = ap1;
+            if (S == 0) { KPRN_MFMA_Z(ax[0], a0[0], wiT[S][0]); KPRN_MFMA_Z(ax[1], a1[0], wiT[S + 1][0]); }
+            else { KPRN_MFMA(ax[0], a0[0], wiT[S][0]); KPRN_MFMA(ax[1], a1[0], wiT[S + 1][0]); }
+            KPRN_MFMA(ax[0], a0[1], wiT[S][1]); KPRN_MFMA(ax[1], a1[1], wiT[S + 1][1]);
+            if (S + 2 < 16) { ap0 = *(const f32x4*)(abase + (S + 2) * 16); ap1 = *(const f32x4*)(abase + (S + 3) * 16); }
+            KPRN_MFMA(ax[0], a0[2], wiT[S][2]); KPRN_MFMA(ax[1], a1[2], wiT[S + 1][2]);
+            KPRN_MFMA(ax[0], a0[3], wiT[S][3]); KPRN_MFMA(ax[1], a1[3], wiT[S + 1][3]);
           }
         } else {
           // t = 0: no dh; two m-tiles share a group so that consecutive MFMAs never chain on one accumulator
@@ -313,10 +333,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       KPRN_MFMA_DRAIN();  // ax / ah are read by VALU and stores below
       KPRN_PIN_V4(ax);
       if (REC) KPRN_PIN_V4(ah);
-      if (BOTTOM && REC) gather_store<256>(in_t, nin);
+      if constexpr (NMT == 1) { if (!REC) ax[0] += ax[1]; }
+      if (BOTTOM && REC) gather_store<256, MTR>(in_t, nin);
       const bool compact = BOTTOM && a.DXe != nullptr && wcls == 1;   // (wave-uniform)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int mt = 0; mt < NMT; ++mt) {
         if (REC) dh[mt] = ah[mt];  // already in the layout stage C of step t-1 reads
         // dx in fragment order: the layer below (or, bottom layer, the small-table gradient job) reloads it the same way,
         // 1 KiB per instruction; in place -- this thread read this very slot as `up` at the start of the step.
@@ -327,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         // entity columns of the bottom layer: row-major for the gather-reduce over the occurrence index (16 lanes = 64 contiguous bytes)
         float* de_row = a.DXe + ((n0 + ag * 4) * T + k0 + t) * (int64_t)a.de + (j * 16 + arow - a.dt);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) de_row[(int64_t)(mt * 16 + r) * T * a.de] = ax[mt][r];
       }
@@ -341,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       // ... and dc_{k0-1} = sum over rows of the dc this step hands down
       float cs = 0.f;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) cs += (dc[m][0] + dc[m][1]) + (dc[m][2] + dc[m][3]);
+      for (int m = 0; m < NMT; ++m) cs += (dc[m][0] + dc[m][1]) + (dc[m][2] + dc[m][3]);
       cs += __shfl_xor(cs, 16, 64);
       cs += __shfl_xor(cs, 32, 64);
       if (ag == 0) pg[k0 * PFB + 4 * DH + j * 16 + arow] += cs;  // one owner lane per entry
@@ -564,13 +585,13 @@ bool transpose_job(kprn_handle* h, kk::TransposeJob* tj) {
 
 bool bwd_supported(const kprn_handle* h, int T) { return fwd_supported(h, T); }
 
-template <bool BOTTOM, bool TOP>
+template <bool BOTTOM, bool TOP, int NMT = 4>
 static void launch_bwd(kprn_handle* h, const BwdArgs& a, int grid) {
   size_t lds_bytes = (size_t)MT * LDD * sizeof(float);
   if (BOTTOM) lds_bytes += (size_t)MT * LDA * sizeof(float) + (MT * MAXT_LDS * 4) * sizeof(int32_t);
   lds_bytes += (size_t)(KCAP + 1) * PFB * sizeof(float);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP, NMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP, NMT>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());
 }
 
@@ -604,7 +625,12 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     HIP_TRY(hipGetLastError());
   }
   float* gd = h->g_dense;
-  const int64_t n_tiles = (N + MT - 1) / MT;
+  // small batches ran the forward on tiles of one 16-row m-tile (fused::small_tiles): the same here -- the saves and dx are laid out per
+  // 16-row block either way
+  const bool small = small_tiles(h, N, b->tile_k != nullptr);
+  const int64_t n_tiles64 = (N + MT - 1) / MT;
+  const int64_t n_tiles = small ? (N + 15) / 16 : n_tiles64;
+  const int nmt = small ? 1 : 4;
   const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)s->num_cu);
   bool have_r1 = false, reduced = false;
   std::unique_ptr<ProfScope> bwd_scope;
@@ -618,7 +644,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     a.L = L; a.layer = l;
     a.WiT = s->WT + (size_t)(l * 2 + 0) * 64 * 256; a.WoT = s->WT + (size_t)(l * 2 + 1) * 64 * 256;
     a.save_frag = s->save_frag; a.dS = h->ws.dS; a.wout_row = h->dense + h->off_outW + (int64_t)cid * DH; a.DX = s->DX;
-    a.gWout_row = gd + h->off_outW + (int64_t)cid * DH; a.gbout_c = gd + h->off_outb + cid; a.Npad = n_tiles * MT;
+    a.gWout_row = gd + h->off_outW + (int64_t)cid * DH; a.gbout_c = gd + h->off_outb + cid; a.Npad = n_tiles64 * MT;
     a.gWi = gd + h->layer[l].Wi; a.gbi = gd + h->layer[l].bi; a.gWo = gd + h->layer[l].Wo;
     a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
     a.n_tiles = n_tiles;
@@ -635,13 +661,14 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     {
       // one event pair around the L back-to-back launches of the family (an event pair costs ~4 us of stream time)
       if (top) { bwd_scope.reset(new ProfScope(h, "lstm_fused_bwd")); bwd_scope->launches = L; }
-      if (bottom && top) launch_bwd<true, true>(h, a, grid);
+      if (small) { if (bottom) launch_bwd<true, false, 1>(h, a, grid); else launch_bwd<false, true, 1>(h, a, grid); }   // (L == 2)
+      else if (bottom && top) launch_bwd<true, true>(h, a, grid);
       else if (bottom) launch_bwd<true, false>(h, a, grid);
       else if (top) launch_bwd<false, true>(h, a, grid);
       else launch_bwd<false, false>(h, a, grid);
       if (bottom || s->timing) bwd_scope.reset();
     }
-    if (bottom) have_r1 = prefix_backward(h, b, n_tiles);  // the skipped steps of every layer; leaves their dx sums in DX's virtual tile
+    if (bottom) have_r1 = prefix_backward(h, b, n_tiles64);  // the skipped steps of every layer; leaves their dx sums in DX's virtual tile
     if (bottom) {
       for (int q = 0; q < 2; ++q) {
         const int ll = q < L ? q : 0;
@@ -655,7 +682,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       // the weight-gradient slab reduce and the small-table gradients ride along: independent, latency-bound jobs in one launch
       ProfScope ps(h, "entity_grad+dw_reduce");
       bidx::SmallGrad sg;
-      sg.DX = s->DX; sg.idx = b->idx_s ? b->idx_s : b->idx; sg.tile_k = b->tile_k; sg.N = N; sg.n_mtiles = n_tiles * 4; sg.T = T; sg.F = b->F;
+      sg.DX = s->DX; sg.idx = b->idx_s ? b->idx_s : b->idx; sg.tile_k = b->tile_k; sg.N = N; sg.n_mtiles = n_tiles * nmt; sg.T = T; sg.F = b->F;
       sg.nT = c.num_types; sg.dt = c.dt; sg.de = c.de; sg.dr = c.dr; sg.Vt = c.Vt; sg.Vr = c.Vr; sg.gWt = a.gWt; sg.gWr = a.gWr; sg.nblocks = 4 * s->num_cu;
       { static const int sgb = getenv("KPRN_SG_BLOCKS") ? atoi(getenv("KPRN_SG_BLOCKS")) : 0; if (sgb > 0) sg.nblocks = sgb; }   // (measurement)
       bidx::entity_grad(strm, s->DXe, /*compact entity slice=*/2, b->key_sorted, b->pos_sorted, b->n_index, N, T, DH, c.dt, c.de, c.Ve, a.gWe, &ra,
@@ -668,12 +695,12 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       ScatArgs sa;
       sa.idx = b->idx_s ? b->idx_s : b->idx; sa.tile_k = b->tile_k; sa.N = N; sa.T = T; sa.F = b->F; sa.nT = c.num_types;
       sa.dt = c.dt; sa.de = c.de; sa.dr = c.dr; sa.Vt = c.Vt; sa.Vr = c.Vr;
-      sa.DX = s->DX; sa.gWt = a.gWt; sa.gWe = a.gWe; sa.gWr = a.gWr; sa.n_tiles = n_tiles;
+      sa.DX = s->DX; sa.gWt = a.gWt; sa.gWe = a.gWe; sa.gWr = a.gWr; sa.n_tiles = n_tiles64;
       sa.do_small = small_in_kernel ? 0 : 1; sa.do_entity = have_index ? 0 : 1;
       const int n_small = c.Vt * c.dt + c.Vr * c.dr;
       const bool small_fits = n_small <= 4096;
       const size_t lds_b = (size_t)MT * LDA * sizeof(float) + MT * 4 * sizeof(int32_t) + (size_t)(small_fits ? n_small : 0) * sizeof(float);
-      const int sgrid = (int)std::min<int64_t>(n_tiles * T, (int64_t)s->num_cu * 8);
+      const int sgrid = (int)std::min<int64_t>(n_tiles64 * T, (int64_t)s->num_cu * 8);
       const bool slabs = small_fits && sa.do_small;
       if (slabs && (!s->part_small || s->part_small_n < n_small)) {
         HIP_TRY(hipStreamSynchronize(strm));

@@ -67,11 +67,12 @@ constexpr int PFB = 4 * DH + DH; // floats per (class, layer) of the prefix tabl
 // all the tile's ids -> LDS: ids[(row*T + t)*4 + {0: first type, 1: entity, 2: relation}] (0-based).
 // Rows past N repeat row N-1 (their results are never stored).  Removes the dependent id -> row load
 // chain from every step's gather.
-template <int NTHREADS>
+// MTR: path rows of a tile -- MT (64), or 16 in the small-batch instantiations (one 16-row m-tile per tile: lstm_fused_fwd.hip NMT)
+template <int NTHREADS, int MTR = MT>
 __device__ __forceinline__ void ids_stage(const int32_t* idx, int64_t N, int T, int F, int nT, int64_t tile, int32_t* ids) {
-  for (int c = threadIdx.x; c < MT * T; c += NTHREADS) {
+  for (int c = threadIdx.x; c < MTR * T; c += NTHREADS) {
     const int row = c / T, t = c - row * T;
-    int64_t n = tile * MT + row;
+    int64_t n = tile * MTR + row;
     if (n >= N) n = N - 1;
     const int32_t* f = idx + (n * T + t) * F;
     ids[c * 4 + 0] = f[F - nT - 2] - 1;
@@ -99,11 +100,11 @@ __device__ __forceinline__ GatherSrc gather_src(const Args& a) {
 }
 
 // gather this thread's share of one step's x rows for `tile` into registers (ids from the LDS id tile)
-template <int NTHREADS, class Args>
+template <int NTHREADS, int MTR = MT, class Args>
 // t indexes the LDS id tile handed in; tg = the step's index in the batch (differs when `ids` points behind a skipped prefix)
-__device__ __forceinline__ void gather_load(const Args& a, const GatherSrc& g, int64_t tile, int t, const int32_t* ids, f32x4 (&v)[1024 / NTHREADS],
+__device__ __forceinline__ void gather_load(const Args& a, const GatherSrc& g, int64_t tile, int t, const int32_t* ids, f32x4 (&v)[MTR * 16 / NTHREADS],
                                             int tg = -1) {
-  constexpr int PER = 1024 / NTHREADS;  // 64 rows x 16 float4 chunks
+  constexpr int PER = MTR * 16 / NTHREADS;  // MTR rows x 16 float4 chunks
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int row = (threadIdx.x >> 4) + k * (NTHREADS >> 4);
@@ -114,7 +115,7 @@ __device__ __forceinline__ void gather_load(const Args& a, const GatherSrc& g, i
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int row = (threadIdx.x >> 4) + k * (NTHREADS >> 4);
-      int64_t n = tile * MT + row;
+      int64_t n = tile * MTR + row;
       if (n >= a.N) n = a.N - 1;
       const int32_t* f = a.idx + (n * a.T + (tg >= 0 ? tg : t)) * a.F;
       for (int q = 1; q < a.nT; ++q) v[k] += *(const f32x4*)(g.base + (int64_t)(f[a.F - a.nT - 2 + q] - 1) * g.width);
@@ -122,9 +123,9 @@ __device__ __forceinline__ void gather_load(const Args& a, const GatherSrc& g, i
   }
 }
 
-template <int NTHREADS>
-__device__ __forceinline__ void gather_store(float* xbuf, const f32x4 (&v)[1024 / NTHREADS]) {
-  constexpr int PER = 1024 / NTHREADS;
+template <int NTHREADS, int MTR = MT>
+__device__ __forceinline__ void gather_store(float* xbuf, const f32x4 (&v)[MTR * 16 / NTHREADS]) {
+  constexpr int PER = MTR * 16 / NTHREADS;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int c = threadIdx.x + k * NTHREADS;
@@ -213,6 +214,9 @@ static inline State* st(kprn_handle* h) {
 }
 
 bool fwd_supported(const kprn_handle* h, int T);
+// small batches: tiles of ONE 16-row m-tile (four times as many workgroups, a quarter of the latency per tile); no identical-prefix plan
+constexpr int64_t SMALL_TILES_MAX_PATHS = 8192;
+bool small_tiles(const kprn_handle* h, int64_t N, bool has_plan);
 void prefix_forward(kprn_handle* h, const kprn_batch* b);
 void forward_mc(kprn_handle* h, const kprn_batch* b, bool save);
 void mc_prepare(kprn_handle* h);

@@ -142,6 +142,7 @@ __device__ __forceinline__ void cell_all(const f32x4 (&pacc)[4], float (&pc)[4],
 }
 
 // nn.Linear(H, C) on the tile's h_T (LDS) -> S[n][0..C)
+template <int NMT>
 __device__ __forceinline__ void head_tile(const FwdArgs& a, const float* hbuf, int64_t tile, int j, int lane) {
   const int ntiles = (a.C + 15) >> 4;
   const int arow = lane & 15, ag = lane >> 4;
@@ -153,7 +154,7 @@ __device__ __forceinline__ void head_tile(const FwdArgs& a, const float* hbuf, i
 #pragma unroll
     for (int S = 0; S < 4; ++S) w4[S] = cv ? *(const f32x4*)(a.Wout + (int64_t)col * DH + S * 16 + ag * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < NMT; ++mt) {
       f32x4 acc = f32x4{b, b, b, b};
 #pragma unroll
       for (int S = 0; S < 4; ++S) {
@@ -164,7 +165,7 @@ __device__ __forceinline__ void head_tile(const FwdArgs& a, const float* hbuf, i
       if (cv) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t n = tile * MT + mt * 16 + ag * 4 + r;
+          const int64_t n = tile * (16 * NMT) + mt * 16 + ag * 4 + r;
           if (n < a.N) a.S[(a.perm ? (int64_t)a.perm[n] : n) * a.C + col] = acc[r];
         }
       }
@@ -172,9 +173,12 @@ __device__ __forceinline__ void head_tile(const FwdArgs& a, const float* hbuf, i
   }
 }
 
-template <int L, bool SAVE>
+// NMT: 16-row m-tiles of a tile -- 4 (64-path tiles), or 1 for small batches (fused::small_tiles: four times as many workgroups, each a quarter
+// of the latency; the unit pipeline below is the same, a slot is then the chain of L units (layer l, m-tile 0))
+template <int L, bool SAVE, int NMT>
 __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
-  constexpr int NT = 256;
+  constexpr int NT = 256, MTR = 16 * NMT;
+  static_assert(NMT == 4 || (NMT == 1 && L == 2), "the accumulator ping-pong needs an even number of units per slot");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // LDS carve (floats): x double buffer | h(layer l) double buffer, l = 0..L-1
   auto xbuf = [&](int i) -> float* { return lds + i * (MT * LDA); };
@@ -227,11 +231,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
         asm volatile("" : "+a"(wi[l][q][S]));
         asm volatile("" : "+a"(wo[l][q][S]));
       }
-  float c[L][4][4];
+  float c[L][NMT][4];
 #pragma unroll
   for (int l = 0; l < L; ++l)
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < NMT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[l][m][r] = 0.f;
 
@@ -239,17 +243,17 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   if ((int64_t)blockIdx.x >= a.n_tiles) return;
   auto tile_k0 = [&](int64_t tl) -> int { return a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tl]) : 0; };
 
-  f32x4 gv[1024 / NT];
+  f32x4 gv[MTR * 16 / NT];
   const GatherSrc gsrc = gather_src(a);
-  ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, blockIdx.x, idbuf(0));
+  ids_stage<NT, MTR>(a.idx, a.N, T, a.F, a.nT, blockIdx.x, idbuf(0));
   if (a.tile_k) {  // classes 1 .. longest prefix of the batch (class 0 = no prefix: nothing to look up)
     const int n_cls = __builtin_amdgcn_readfirstlane(a.pmeta[0]) + 1;
     for (int c = L * PFB + threadIdx.x; c < n_cls * L * PFB; c += NT) ((float*)pft)[c] = a.pfb[c];
   }
   lds_barrier();
   int k0 = tile_k0(blockIdx.x);  // the tile runs steps k0 .. T-1 (k0 <= T-2)
-  gather_load<NT>(a, gsrc, blockIdx.x, k0, idbuf(0), gv);
-  gather_store<NT>(xbuf(0), gv);
+  gather_load<NT, MTR>(a, gsrc, blockIdx.x, k0, idbuf(0), gv);
+  gather_store<NT, MTR>(xbuf(0), gv);
 
   // The work of a slot (one step t of one tile) is a chain of units u = (layer l, 16-row m-tile mt).  Unit u:
   //   [recurrent half: 64 MFMAs over h^l_{t-1}, with the CELL of unit u-1 interleaved]  (skipped at t == 0)
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 
   auto save_unit = [&](int64_t p_tile, int p_t, int pl, int pm) {
     if (!SAVE) return;
-    float* fb = a.save_frag + (p_tile * 4 + pm) * frag_mt_stride + ((int64_t)(p_t * L + pl) * 4 + j) * frag_unit + lane * 4;
+    float* fb = a.save_frag + (p_tile * NMT + pm) * frag_mt_stride + ((int64_t)(p_t * L + pl) * 4 + j) * frag_unit + lane * 4;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) *(f32x4*)(fb + k * 256) = sv[k];
   };
@@ -293,8 +297,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
           cinit[l] = pft[(cls * L + l) * PFB + 4 * DH + j * 16 + arow];
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (!(l == L - 1 && m == 3)) {  // c[L-1][3] still belongs to the previous slot's last cell
+        for (int m = 0; m < NMT; ++m)
+          if (!(l == L - 1 && m == NMT - 1)) {  // c[L-1][NMT-1] still belongs to the previous slot's last cell
 #pragma unroll
             for (int r = 0; r < 4; ++r) c[l][m][r] = cinit[l];
           }
@@ -305,22 +309,22 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
       const float* in_buf = (l == 0) ? xbuf(par) : hbuf(l - 1, par);
       const float* hp_buf = hbuf(l, par ^ 1);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int mt = 0; mt < NMT; ++mt) {
         // the unit whose cell is still outstanding
         const int pl = (mt > 0) ? l : ((l > 0) ? l - 1 : L - 1);
-        const int pm = (mt > 0) ? mt - 1 : 3;
+        const int pm = (mt > 0) ? mt - 1 : NMT - 1;
         const bool cross = (l == 0 && mt == 0);             // it belongs to the previous slot
         const int64_t q_tile = cross ? p_tile : tile;
         const int q_t = cross ? p_t : t;
         const int q_par = cross ? (par ^ 1) : par;
         float* pout = hbuf(pl, q_par) + pm * 16 * LDA + o_off;
-        f32x4(&acc)[4] = accs[mt & 1];
-        f32x4(&pacc)[4] = accs[(mt & 1) ^ 1];
+        f32x4(&acc)[4] = accs[(l * NMT + mt) & 1];
+        f32x4(&pacc)[4] = accs[((l * NMT + mt) & 1) ^ 1];
         const float* in_base = in_buf + mt * 16 * LDA + a_off;
         // first A fragment of the unit that follows this one (always a readable LDS address; unused when that
         // unit starts behind a barrier)
         const float* nxt;
-        if (mt < 3) nxt = (FIRST ? in_buf : hp_buf) + (mt + 1) * 16 * LDA + a_off;
+        if (mt < NMT - 1) nxt = (FIRST ? in_buf : hp_buf) + (mt + 1) * 16 * LDA + a_off;
         else if (l + 1 < L) nxt = hbuf(l + 1, par ^ 1) + a_off;
         else nxt = hbuf(0, par) + a_off;
         if (!FIRST) {
@@ -340,10 +344,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
           }
           if (cross) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) c[L - 1][3][r] = cinit[L - 1];
+            for (int r = 0; r < 4; ++r) c[L - 1][NMT - 1][r] = cinit[L - 1];
           }
           lds_barrier();
-          if (cross && has_prev) head_tile(a, hbuf(L - 1, q_par), p_tile, j, lane);
+          if (cross && has_prev) head_tile<NMT>(a, hbuf(L - 1, q_par), p_tile, j, lane);
           apre = *(const f32x4*)(in_base);
           half_unit<SAVE, false, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], pout, sv);
           if (cls > 0) {  // (uniform)
@@ -384,8 +388,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
     }
     const bool have_next = tile_n < a.n_tiles;
     // the next tile's ids are staged while this tile's first step computes (visible after >= 1 barrier: a tile has >= 2 steps)
-    if (t == k0 && tile + gridDim.x < a.n_tiles) ids_stage<NT>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
-    if (have_next) gather_load<NT>(a, gsrc, tile_n, tn, idbuf(tpar_n), gv);
+    if (t == k0 && tile + gridDim.x < a.n_tiles) ids_stage<NT, MTR>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
+    if (have_next) gather_load<NT, MTR>(a, gsrc, tile_n, tn, idbuf(tpar_n), gv);
     FPROBE(1)  // id staging + gather issue
     // (2) the units of this slot
     if (t == k0) { slot(std::true_type{}, tile, t, par, s > 0, p_tile, p_t, k0); FPROBE(2) }
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
     KPRN_MFMA_DRAIN();
     KPRN_PIN_V4(accs[0]);
     KPRN_PIN_V4(accs[1]);
-    if (have_next) gather_store<NT>(xbuf(par ^ 1), gv);
+    if (have_next) gather_store<NT, MTR>(xbuf(par ^ 1), gv);
     FPROBE(4)  // landing the gathered rows (waits for the loads -- and, when saving, for the stores in flight)
     p_tile = tile; p_t = t;
     if (!have_next) break;
@@ -406,11 +410,12 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   // drain: the cell of the very last unit, then the last tile's head
   {
     KPRN_MFMA_DRAIN();
-    KPRN_PIN_V4(accs[1]);
-    cell_all<SAVE>(accs[1], c[L - 1][3], hbuf(L - 1, par) + 3 * 16 * LDA + o_off, sv);
-    save_unit(p_tile, p_t, L - 1, 3);
+    constexpr int LAST = (L * NMT - 1) & 1;   // accumulator set of a slot's last unit
+    KPRN_PIN_V4(accs[LAST]);
+    cell_all<SAVE>(accs[LAST], c[L - 1][NMT - 1], hbuf(L - 1, par) + (NMT - 1) * 16 * LDA + o_off, sv);
+    save_unit(p_tile, p_t, L - 1, NMT - 1);
     lds_barrier();
-    head_tile(a, hbuf(L - 1, par), p_tile, j, lane);
+    head_tile<NMT>(a, hbuf(L - 1, par), p_tile, j, lane);
   }
   FPROBE(5)  // drain
   if (KPRN_PROBES_ON && a.timing && threadIdx.x == 0) {
@@ -421,20 +426,27 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 }
 
 // ---- host side ----
+// Small batches: below ~8 k paths the 64-path tiles leave most CUs idle and a step is the latency of ONE tile through the persistent launches
+// (0.38 ms whatever the size).  Tiles of one 16-row m-tile put 4x the workgroups on the chip at a quarter of the latency each.
+// No identical-prefix plan in this mode (kprn_api.hip batch_wants_plan agrees): its classes are per 64-path tile.
+bool small_tiles(const kprn_handle* h, int64_t N, bool has_plan) {
+  return h->small_tiles_on && !has_plan && h->cfg.compute_dtype == 0 && h->cfg.L == 2 && N <= SMALL_TILES_MAX_PATHS;
+}
+
 bool fwd_supported(const kprn_handle* h, int T) {
   const kprn_config& c = h->cfg;
   return (h->D == DH && c.H == DH && c.L >= 1 && c.L <= 2 && (c.dt % 4) == 0 && (c.de % 4) == 0 && (c.dr % 4) == 0 && T >= 2 && T <= MAXT_LDS);
 }
 
-template <int L, bool SAVE>
+template <int L, bool SAVE, int NMT = 4>
 static void launch_fwd(kprn_handle* h, const FwdArgs& a, int grid) {
   const size_t lds_bytes = (size_t)(2 + 2 * L) * MT * LDA * sizeof(float) + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t) + (size_t)(KCAP + 1) * L * PFB * sizeof(float);
   static bool attr_done = false;  // one per template instantiation
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd<L, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd<L, SAVE, NMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_lstm_fwd<L, SAVE>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
+  hipLaunchKernelGGL((k_lstm_fwd<L, SAVE, NMT>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());
 }
 
@@ -458,8 +470,9 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin,
   }
   a.Wout = h->dense + h->off_outW; a.bout = h->dense + h->off_outb; a.C = c.C;
   a.S = h->ws.S;
-  a.n_tiles = (N + MT - 1) / MT;
-  if (!save && (tile_begin > 0 || tile_end >= 0)) {
+  const bool small = small_tiles(h, N, b->tile_k != nullptr);   // (c.L == 2: the only small-tile instantiation)
+  a.n_tiles = small ? (N + 15) / 16 : (N + MT - 1) / MT;
+  if (!small && !save && (tile_begin > 0 || tile_end >= 0)) {
     const int64_t t0 = std::min<int64_t>(tile_begin, a.n_tiles), t1 = tile_end < 0 ? a.n_tiles : std::min<int64_t>(tile_end, a.n_tiles);
     if (t1 <= t0) return;
     a.idx += t0 * MT * a.T * a.F;
@@ -488,6 +501,7 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin,
   a.timing = s->timing;
   ProfScope ps(h, save ? "lstm_fused_fwd_train" : "lstm_fused_fwd");
   if (c.L == 1) { if (save) launch_fwd<1, true>(h, a, grid); else launch_fwd<1, false>(h, a, grid); }
+  else if (small) { if (save) launch_fwd<2, true, 1>(h, a, grid); else launch_fwd<2, false, 1>(h, a, grid); }
   else { if (save) launch_fwd<2, true>(h, a, grid); else launch_fwd<2, false>(h, a, grid); }
   if (s->timing) {
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -8,6 +8,13 @@ from kprn_amd import _ffi, synth
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _sixty_four_path_tiles(monkeypatch):
+    """This module pins the 64-path tiles and their identical-prefix plan on SMALL shapes (fast, every edge case); left alone the engine runs batches
+    of <= 8 192 paths on tiles of one 16-row m-tile without a plan -- tests/test_gpu_small_tiles.py covers that mode."""
+    monkeypatch.setenv("KPRN_SMALL_TILES", "0")
+
 SHAPE = (6, 5000, 9, 16, 32, 16, 64, 2)
 
 

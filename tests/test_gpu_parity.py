@@ -14,6 +14,13 @@ from oracle.oracle import Oracle, make_cfg, make_opt
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _sixty_four_path_tiles(monkeypatch):
+    """This module pins the 64-path tiles and their identical-prefix plan on SMALL shapes (fast, every edge case); left alone the engine runs batches
+    of <= 8 192 paths on tiles of one 16-row m-tile without a plan -- tests/test_gpu_small_tiles.py covers that mode."""
+    monkeypatch.setenv("KPRN_SMALL_TILES", "0")
+
 SCORE_RTOL = 1e-4   # north_star: fp32 scores within 1e-4 relative
 GRAD_RTOL = 2e-4    # max|g_gpu - g_f64| / max|g_f64| per tensor
 
