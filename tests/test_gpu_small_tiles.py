@@ -27,9 +27,9 @@ def mk(seed=3, small=True):
     return eng, o64, theta
 
 
-@pytest.mark.parametrize("pairs,P", [(1, 1), (5, 3), (16, 1), (17, 1), (50, 2), (333, 3), (2048, 4), (293, 28)])
+@pytest.mark.parametrize("pairs,P", [(1, 1), (5, 3), (16, 1), (17, 1), (50, 2), (333, 3), (2048, 4), (292, 28)])
 def test_scores_and_gradients_against_the_f64_oracle(pairs, P):
-    """1 .. 8 204 paths: one ragged tile, exactly one tile, many tiles per workgroup (8 192 paths = 512 tiles on 256 workgroups), P up to 28;
+    """1 .. 8 192 paths: one ragged tile, exactly one tile, many tiles per workgroup (8 192 paths = 512 tiles on 256 workgroups), P up to 28;
     every path's 46 scores, the pooled probabilities, the loss and every gradient."""
     eng, o64, theta = mk()
     idx, labels = synth.make_paths(pairs, P, T, Ve=SHAPE["Ve"], seed=pairs + P)
