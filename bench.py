@@ -215,6 +215,9 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4, NT=None):
         return "mfma", (fl + N * 2 * H * C) / L
     if name in ("lstm_persist_bf16_score", "lstm_persist_bf16_train"):   # the whole layer in one launch (lstm_bf16_persist.hip); no recurrent half at t = 0
         return "mfma", N * 2 * g * (T * D + (T - 1) * H)
+    if name == "lstm_persist_bf16_bwd":   # BPTT through the layer in one launch (lstm_bf16_bwd_persist.hip), HBM-bound: per (path, step) it reads the saved
+        # gates (i, g, f, o: 8 B per hidden unit), c_t and c_{t-1} (2 + 2 B) and writes dA transposed (2 B per gate column)
+        return "hbm", N * T * (H * 12 + g * 2)
     if name in ("lstm_step_fwd", "lstm_step_bf16", "rnn_step_fwd"):   # one launch per (layer, step): [x_t | h_{t-1}] [W_i | W_o]^T, no recurrent half at t = 0
         fl = 0
         for l in range(L):
@@ -448,7 +451,7 @@ def other_configs():
                          "wall_s": round(time.perf_counter() - t0, 1), "flags": " ".join(flags)}
             oth = rf.get("other_timed_families")
             if oth:
-                out[name]["roofline"]["other_timed_families"] = {k: {q: v.get(q) for q in ("frac", "avg_launch_ms")} for k, v in oth.items() if v}
+                out[name]["roofline"]["other_timed_families"] = {k: {q: v.get(q) for q in ("bound", "frac", "avg_launch_ms")} for k, v in oth.items() if v}
         except Exception as e:   # a failing side run must not take the headline line with it
             out[name] = {"error": repr(e)[:300], "flags": " ".join(flags)}
     return out

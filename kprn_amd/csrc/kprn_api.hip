@@ -995,16 +995,24 @@ static int copy_rows(kprn_handle* h, const char* name, const int64_t* rows, int6
   if (n_rows == 0 || p->rows * p->cols == 0) return KPRN_OK;
   for (int64_t i = 0; i < n_rows; ++i) KPRN_REQUIRE(rows[i] >= 0 && rows[i] < p->rows, KPRN_E_INDEX, "row index outside the tensor");
   if (p->where == 1) flush_lazy(h);
+  if (src) params_touched(h);   // (BEFORE the write is queued: it makes the main stream wait for a scoring pass that may still read these rows)
   float* base = (p->where == 1 ? h->We : h->dense) + p->dev_off;
-  int64_t* d_rows = dalloc<int64_t>(n_rows);
-  float* d_buf = dalloc<float>(n_rows * p->cols);
-  HIP_TRY(hipMemcpyAsync(d_rows, rows, (size_t)n_rows * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-  if (src) HIP_TRY(hipMemcpyAsync(d_buf, src, (size_t)(n_rows * p->cols) * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)std::min<int64_t>((n_rows * p->cols + 255) / 256, 8192)), dim3(256), 0, h->stream, base, d_rows, n_rows, p->cols, d_buf,
-                     src ? 1 : 0);
-  if (dst) HIP_TRY(hipMemcpyAsync(dst, d_buf, (size_t)(n_rows * p->cols) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  else params_touched(h);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  int64_t* d_rows = nullptr;
+  float* d_buf = nullptr;
+  try {
+    d_rows = dalloc<int64_t>(n_rows);
+    d_buf = dalloc<float>(n_rows * p->cols);
+    HIP_TRY(hipMemcpyAsync(d_rows, rows, (size_t)n_rows * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    if (src) HIP_TRY(hipMemcpyAsync(d_buf, src, (size_t)(n_rows * p->cols) * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)std::min<int64_t>((n_rows * p->cols + 255) / 256, 8192)), dim3(256), 0, h->stream, base, d_rows, n_rows, p->cols, d_buf,
+                       src ? 1 : 0);
+    if (dst) HIP_TRY(hipMemcpyAsync(dst, d_buf, (size_t)(n_rows * p->cols) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  } catch (...) {
+    hipStreamSynchronize(h->stream);
+    dfree(d_rows); dfree(d_buf);
+    throw;
+  }
   dfree(d_rows); dfree(d_buf);
   API_END(h)
 }

@@ -79,6 +79,8 @@ class GpuAdapter:
         from . import _ffi
         if dist.get_backend(group) != "nccl":
             return False
+        if not (self.dense_in_pack and self.fused_update):
+            return False   # kprn_dp_init forces both options on: a caller who asked for the all-reduce / the separate merge keeps the hook path
         path = _ffi.torch_rccl_path()
         idb, ok = bytes(128), 1
         try:

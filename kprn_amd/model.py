@@ -39,7 +39,8 @@ def flag_parser():
     a("-numLayers", type=int, default=1); a("-useDropout", type=int, default=0); a("-dropout", type=float, default=0.0)
     # engine-side additions (not in the reference)
     a("-seed", type=int, default=12345); a("-entityUpdate", type=int, default=0)
-    a("-checkpointFormat", default="native", choices=["native", "t7", "both"])   # t7 / both: ALSO <path>.t7, the parameters in a Torch7 {embeddingLayer, predictor_net} container
+    a("-checkpointFormat", default="native", choices=["native", "t7", "both"],
+      help="the native checkpoint is always written at <model>-latest; t7 / both ALSO write <model>-latest.t7, the parameters in a Torch7 {embeddingLayer, predictor_net} container (the reference writes its container at <model>-latest itself)")
     return p
 
 
