@@ -1046,6 +1046,33 @@ __global__ __launch_bounds__(256) void k_transpose16(const bf16* __restrict__ x,
     }
   }
 }
+// h^T [H][T Np] (the dW_o2g product's k-contiguous operand) from the persistent forward's FRAGMENT-order h records (lstm_bf16_persist.hip Cell::store:
+// record (((t NU + unit) NCHF + chunk) 8 + wave) 64 + lane = hidden units 64 chunk + 8 wave + 4 (lane >> 5) .. + 3 of path 32 unit + (lane & 31)).
+// One workgroup = (two units = 64 paths, one chunk of 64 hidden units, one step): 8 KB of records in, coalesced; transposed through LDS by two-byte
+// writes; 128-byte rows out.  Paths past N are written as zeros (their records hold a repeated row).
+__global__ __launch_bounds__(256) void k_hfrag_T(const bf16x4* __restrict__ HsF, bf16* __restrict__ HT, int64_t NU, int64_t step_recs, int64_t N, int64_t Np, int64_t ldT, int H) {
+  constexpr int TP = 64 + 8;   // elements: 144-byte rows (the two lane halves of a record wave write rows 4 apart: other banks)
+  __shared__ __attribute__((aligned(16))) bf16 tl[64][TP];
+  const int tid = threadIdx.x, cf = blockIdx.y, t = blockIdx.z, NCHF = H / 64;
+  const int64_t u0 = (int64_t)blockIdx.x * 2, n0 = u0 * 32;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = tid + 256 * e;              // record of the pair of units: unit r >> 9, wave (r >> 6) & 7, lane r & 63
+    const int uu = r >> 9, wf = (r >> 6) & 7, lane = r & 63, ln = lane & 31, half = lane >> 5;
+    bf16x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (bf16)0.f;
+    if (u0 + uu < NU && n0 + 32 * uu + ln < N) v = HsF[(int64_t)t * step_recs + (((u0 + uu) * NCHF + cf) * 8 + wf) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tl[8 * wf + 4 * half + j][32 * uu + ln] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int pc = tid + 256 * e, hl = pc >> 3, oct = pc & 7;
+    if (n0 + 8 * oct < Np) *(bf16x8*)(HT + (int64_t)(64 * cf + hl) * ldT + (int64_t)t * Np + n0 + 8 * oct) = *(const bf16x8*)&tl[hl][8 * oct];
+  }
+}
 // out[r] += sum of row r of x (bf16 [R][n], n a multiple of 8): the bias gradient from dA^T
 __global__ __launch_bounds__(256) void k_rowsum16(const bf16* __restrict__ x, int64_t n, float* __restrict__ out) {
   __shared__ float red[256];
@@ -1067,7 +1094,7 @@ __global__ __launch_bounds__(256) void k_rowsum16(const bf16* __restrict__ x, in
 
 // ---- state + orchestration --------------------------------------------------------------------------------------------------
 // lstm_bf16_persist.hip: fragment-order saves of the persistent layer kernel's training launch
-struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; int64_t NU, step_recs; int NW; };
+struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; const bf16* HsF; int64_t NU, step_recs; int NW; };
 
 struct State {
   bf16* We16 = nullptr; bool we_all_dirty = true;
@@ -1206,7 +1233,7 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
     HIP_TRY(hipGetLastError());
   }
   if (persist) {
-    persist_forward(h, b, save, s->persist, s->pack_dirty, s->dense16 + h->off_Wt, s->We16, s->dense16 + h->off_Wr, s->H16, &s->sv);
+    persist_forward(h, b, save, s->persist, s->pack_dirty, s->dense16 + h->off_Wt, s->We16, s->dense16 + h->off_Wr, /*row-major h plane: not needed, h^T is built from the fragment-order records*/ nullptr, &s->sv);
     s->pack_dirty = false;
     if (save) s->act_frag = true;
   }
@@ -1333,7 +1360,11 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
                            c.num_types, s->dense16 + h->off_Wt, s->We16, s->dense16 + h->off_Wr, c.dt, c.de, c.dr, s->XT16, (int64_t)T * Np);
         HIP_TRY(hipGetLastError());
       } else transpose_steps(strm, (l == 0) ? s->X16 : s->H16 + (int64_t)(l - 1) * TN * H, s->XT16, T, N, Np, Din);      // in^T [Din][T][Np]
-      if (T > 1) transpose_steps(strm, hs, s->HT16, T, N, Np, H);                                                // h^T  [H][T][Np]
+      if (T > 1 && s->act_frag && l == 0 && s->sv.HsF && s->sv.NW == 8 && (H % 64) == 0) {   // h^T straight from the persistent forward's fragment-order records (steps 0 .. T-2)
+        hipLaunchKernelGGL(k_hfrag_T, dim3((unsigned)((s->sv.NU + 1) / 2), (unsigned)(H / 64), (unsigned)(T - 1)), dim3(256), 0, strm, (const bf16x4*)s->sv.HsF, s->HT16,
+                           (int64_t)s->sv.NU, (int64_t)s->sv.step_recs, N, Np, (int64_t)T * Np, H);
+        HIP_TRY(hipGetLastError());
+      } else if (T > 1) transpose_steps(strm, hs, s->HT16, T, N, Np, H);                                         // h^T  [H][T][Np]
     }
     const int split = (int)std::min<int64_t>(1024, std::max<int64_t>(1, TN / 4096));
     {

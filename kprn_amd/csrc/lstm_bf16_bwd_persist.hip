@@ -388,7 +388,7 @@ __global__ void k_pack_wb(const float* __restrict__ Wo, bf16* __restrict__ WpB) 
 }  // namespace pb
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; int64_t NU, step_recs; int NW; };   // (also declared in lstm_bf16.hip)
+struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; const bf16* HsF; int64_t NU, step_recs; int NW; };   // (also declared in lstm_bf16.hip)
 struct PersistBwdState { bf16* WpB = nullptr; int grid = 0; };
 
 bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv) {

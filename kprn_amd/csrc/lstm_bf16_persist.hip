@@ -66,6 +66,7 @@ struct Args {
   float* cscr;       // per workgroup: [H/32][MAXPT][4][64][4]   c_t in accumulator order (scoring)
   bf16* H16;         // SAVE: h_t row-major [T][N][H] (the backward's dW product reads it)
   bf16* CsF; bf16* ActF0; bf16* ActF1; int64_t NU;   // SAVE: c_t (bf16) and the gate activations in FRAGMENT order (see Cell::store), NU = units of 32 rows
+  bf16* HsF;         // SAVE: h_t in the same fragment order (4 hidden units per record); lstm_bf16.hip k_hfrag_T builds the dW product's h^T from it
   float* hT;         // [N][H] fp32 h_T (the head's input)
   int64_t units;     // ceil(N / 32)
 };
@@ -198,7 +199,10 @@ struct Cell {
       for (int j = 0; j < 4; ++j) { v0[j] = (bf16)gi[j]; v0[4 + j] = (bf16)gg[j]; v1[j] = (bf16)gf[j]; v1[4 + j] = (bf16)go[j]; }
       stb<bf16x8, KPRN_SAVE_AUX>(make_rsrc(a.ActF0 + rec * 8), (unsigned)lane * 16u, 0, v0);
       stb<bf16x8, KPRN_SAVE_AUX>(make_rsrc(a.ActF1 + rec * 8), (unsigned)lane * 16u, 0, v1);
-      if (ok) stb<bf16x4, KPRN_SAVE_AUX>(make_rsrc(a.H16 + ((int64_t)te * a.N + row0 + 32 * pt) * H + cu), lo_row(H, 2), 0, hb);
+      // h_t for the backward's dW product: in fragment order too (one contiguous 512 bytes per wave store).  Row-major, the same 8 bytes per lane land in 32
+      // different rows per wave instruction: measured 0.12 ms of the training launch's 1.09 (profiles/r04: KPRN_DBG_NO_H16 build) for 0.3 GB.
+      stb<bf16x4, KPRN_SAVE_AUX>(make_rsrc(a.HsF + rec * 4), (unsigned)lane * 8u, 0, hb);
+      if (a.H16 && ok) stb<bf16x4, KPRN_SAVE_AUX>(make_rsrc(a.H16 + ((int64_t)te * a.N + row0 + 32 * pt) * H + cu), lo_row(H, 2), 0, hb);   // (the per-step backward's row-major plane: KPRN_BF16_BWD_PERSIST=0)
     }
     stb<f32x4>(cs, (unsigned)lane * 16u, (unsigned)((ce * MAXPT + pt) * NW + wave) * 1024u, cv);
     if (te == a.T - 1 && ok) stb<f32x4>(make_rsrc(a.hT + (row0 + 32 * pt) * H + cu), lo_row(H, 4), 0, hv);
@@ -472,12 +476,12 @@ __global__ void k_pack_w(const float* __restrict__ Wi, const float* __restrict__
 }  // namespace pk
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; int64_t NU, step_recs; int NW; };   // (also declared in lstm_bf16.hip)
+struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; const bf16* HsF; int64_t NU, step_recs; int NW; };   // (also declared in lstm_bf16.hip, lstm_bf16_bwd_persist.hip)
 struct PersistState {
   bf16* Wp = nullptr; float* Bp = nullptr; bf16* hscr = nullptr; float* cscr = nullptr;
   int grid = 0;
   int packed_nw = 0;   // waves per workgroup the packed weights are laid out for
-  bf16* CsF = nullptr; bf16* ActF0 = nullptr; bf16* ActF1 = nullptr; int64_t save_recs = 0;   // training saves, fragment order
+  bf16* CsF = nullptr; bf16* ActF0 = nullptr; bf16* ActF1 = nullptr; bf16* HsF = nullptr; int64_t save_recs = 0;   // training saves, fragment order
 };
 
 bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b) {
@@ -491,7 +495,7 @@ bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b) {
 void persist_release(void*& st) {
   PersistState* p = (PersistState*)st;
   if (!p) return;
-  for (void* q : {(void*)p->Wp, (void*)p->Bp, (void*)p->hscr, (void*)p->cscr, (void*)p->CsF, (void*)p->ActF0, (void*)p->ActF1}) if (q) hipFree(q);
+  for (void* q : {(void*)p->Wp, (void*)p->Bp, (void*)p->hscr, (void*)p->cscr, (void*)p->CsF, (void*)p->ActF0, (void*)p->ActF1, (void*)p->HsF}) if (q) hipFree(q);
   delete p;
   st = nullptr;
 }
@@ -556,12 +560,12 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
     const int64_t recs = (int64_t)T * a.NU * 32 * H / 4;   // 4-element records of one plane
     if (recs > q->save_recs) {
       HIP_TRY(hipStreamSynchronize(strm));
-      for (void* x : {(void*)q->CsF, (void*)q->ActF0, (void*)q->ActF1}) if (x) hipFree(x);
-      q->CsF = pal<bf16>(recs * 4); q->ActF0 = pal<bf16>(recs * 8); q->ActF1 = pal<bf16>(recs * 8);
+      for (void* x : {(void*)q->CsF, (void*)q->ActF0, (void*)q->ActF1, (void*)q->HsF}) if (x) hipFree(x);
+      q->CsF = pal<bf16>(recs * 4); q->ActF0 = pal<bf16>(recs * 8); q->ActF1 = pal<bf16>(recs * 8); q->HsF = pal<bf16>(recs * 4);
       q->save_recs = recs;
     }
-    a.CsF = q->CsF; a.ActF0 = q->ActF0; a.ActF1 = q->ActF1;
-    sv->CsF = q->CsF; sv->ActF0 = q->ActF0; sv->ActF1 = q->ActF1; sv->NU = a.NU; sv->NW = nw; sv->step_recs = a.NU * 32 * H / 4;
+    a.CsF = q->CsF; a.ActF0 = q->ActF0; a.ActF1 = q->ActF1; a.HsF = q->HsF;
+    sv->CsF = q->CsF; sv->ActF0 = q->ActF0; sv->ActF1 = q->ActF1; sv->HsF = q->HsF; sv->NU = a.NU; sv->NW = nw; sv->step_recs = a.NU * 32 * H / 4;
   }
   a.hT = h->ws.Hs + (int64_t)(T - 1) * N * H;   // (L = 1: layer 0's last step)
   a.units = (N + 31) / 32;
