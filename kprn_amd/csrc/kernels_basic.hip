@@ -168,7 +168,7 @@ __global__ void k_add_bias(float* __restrict__ Y, const float* __restrict__ b, i
 }
 
 // out[c] += sum_r A[r][c]; block = 256 threads handles 256 rows x 64-col strip with LDS-free partials
-__global__ void k_colsum(const float* __restrict__ A, int64_t rows, int cols, int64_t ld, float* __restrict__ out, int rows_per_block) {
+__global__ void k_colsum(const float* __restrict__ A, int64_t rows, int cols, int64_t ld, float* __restrict__ out, int rows_per_block, float* __restrict__ out2) {
   int c = blockIdx.y * 64 + (threadIdx.x & 63);
   int sub = threadIdx.x >> 6;  // 4 row-subgroups
   int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -192,6 +192,7 @@ __global__ void k_colsum(const float* __restrict__ A, int64_t rows, int cols, in
   if (sub == 0 && c < cols) {
     float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     unsafeAtomicAdd(out + c, v);
+    if (out2) unsafeAtomicAdd(out2 + c, v);   // (a second vector that sees the same gradient: the rnn cell's h2h.bias next to i2h.bias)
   }
 }
 
@@ -948,12 +949,12 @@ void add_bias_rows(hipStream_t s, float* Y, const float* b, int64_t rows, int co
   CHECK_LAUNCH();
 }
 
-void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out, int64_t ld) {
+void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out, int64_t ld, float* out2) {
   if (rows <= 0) return;
   if (ld <= 0) ld = cols;
   const int rpb = 512;
   dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 63) / 64));
-  hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, A, rows, cols, ld, out, rpb);
+  hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, A, rows, cols, ld, out, rpb, out2);
   CHECK_LAUNCH();
 }
 

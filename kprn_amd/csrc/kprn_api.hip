@@ -594,8 +594,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       }
       {
         ProfScope ps(h, "bias_colsum");  // i2h.bias and h2h.bias see the same gradient (both are added to every pre-activation)
-        kk::col_sum_add(s, w.dA, (int64_t)T * N, H, gd + h->layer[l].bi);
-        kk::col_sum_add(s, w.dA, (int64_t)T * N, H, gd + h->layer[l].bo);
+        kk::col_sum_add(s, w.dA, (int64_t)T * N, H, gd + h->layer[l].bi, 0, gd + h->layer[l].bo);   // (one pass over dA for both)
       }
       {
         ProfScope ps(h, "gemm_i2g_bwd_dx");

@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 // (0.38 ms whatever the size).  Tiles of one 16-row m-tile put 4x the workgroups on the chip at a quarter of the latency each.
 // No identical-prefix plan in this mode (kprn_api.hip batch_wants_plan agrees): its classes are per 64-path tile.
 bool small_tiles(const kprn_handle* h, int64_t N, bool has_plan) {
-  return h->small_tiles_on && !has_plan && h->cfg.compute_dtype == 0 && h->cfg.L == 2 && N <= SMALL_TILES_MAX_PATHS;
+  static const int64_t max_paths = getenv("KPRN_SMALL_TILES_MAX") ? atoll(getenv("KPRN_SMALL_TILES_MAX")) : SMALL_TILES_MAX_PATHS;   // (measurement: the 16-row tiles at any size)
+  return h->small_tiles_on && !has_plan && h->cfg.compute_dtype == 0 && h->cfg.L == 2 && N <= max_paths;
 }
 
 bool fwd_supported(const kprn_handle* h, int T) {
