@@ -52,7 +52,15 @@ constexpr int MJ = 3;           // 32-row result tiles per wave: NW * MJ * 32 = 
 constexpr int NCH = 12;         // K chunks: 32 hidden units x 4 gates = 128 gate columns = 8 k-steps
 constexpr int KSC = 8;          // k-steps per chunk
 constexpr int FR = NCH * KSC * MJ;   // weight fragments per wave and step (288 KiB)
-constexpr int PF = 12;          // fragments in flight per wave (4 k-steps ahead; divides the fragments of a chunk)
+#ifndef KPRN_BPTT_PF
+#define KPRN_BPTT_PF 12
+#endif
+#ifndef KPRN_BPTT_SD
+#define KPRN_BPTT_SD 2
+#endif
+constexpr int PF = KPRN_BPTT_PF;   // fragments in flight per wave (12 = 4 k-steps ahead; divides the fragments of a chunk)
+constexpr int SD = KPRN_BPTT_SD;   // chunks the saves are requested ahead of their cell backward (one register set of 24 per chunk in flight)
+static_assert(NCH % SD == 0, "the save sets keep their phase across steps");
 constexpr int UREC = H / 4 * 32;     // records (quads) of one unit of 32 rows and one step: [forward chunk 6][forward wave 8][lane 64]
 constexpr int BUF = NPT * KSC * 1024;   // bytes of one dA chunk tile in LDS
 constexpr int TP = 64 * 2 + 16;         // row pitch of the transposed chunk tile (bytes): 64 paths + 16 (the two halves of a wave write rows 4 apart: 576 bytes = other banks)
@@ -188,9 +196,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dcs[j][pt][r] = 0.f; acc[j][pt][r] = 0.f; }
 
-    Sv sv[2];
-    request(T - 1, std::integral_constant<int, 0>{}, sv[0]);
-    request(T - 1, std::integral_constant<int, 1>{}, sv[1]);
+    Sv sv[SD];
+    static_for<0, SD>([&](auto cc) __attribute__((always_inline)) { request(T - 1, cc, sv[decltype(cc)::value]); });
 
     for (int t = T - 1; t >= 0; --t) {
       const rsrc_t r_dA = make_rsrc(a.dA + ((int64_t)t * a.N + row0) * (4 * H));
@@ -250,8 +257,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
             }
           }
         } else if constexpr (Gs == 10) {
-          if constexpr (c + 2 < NCH) request(t, std::integral_constant<int, c + 2>{}, s);
-          else if (t > 0) request(t - 1, std::integral_constant<int, c + 2 - NCH>{}, s);
+          if constexpr (c + SD < NCH) request(t, std::integral_constant<int, c + SD>{}, s);
+          else if (t > 0) request(t - 1, std::integral_constant<int, c + SD - NCH>{}, s);
           if constexpr (c + 1 < NCH) read_dh(std::integral_constant<int, c + 1>{});
         }
       };
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
       // first chunk of the step: nothing to ride behind
       read_dh(std::integral_constant<int, 0>{});
       static_for<0, 10>([&](auto gg) __attribute__((always_inline)) { gslice(std::integral_constant<int, 0>{}, gg, sv[0]); });
-      request(t, std::integral_constant<int, 2>{}, sv[0]);
+      request(t, std::integral_constant<int, SD>{}, sv[0]);
       read_dh(std::integral_constant<int, 1>{});
       bar();
       write_T();
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
               constexpr int fn = (f + PF) % FR;   // (the next step walks the same fragments again)
               ring[slot] = ldb<bf16x8>(rW, l16, (unsigned)fn * 1024u);
             }
-            if constexpr (c + 1 < NCH && g <= 10) gslice(std::integral_constant<int, c + 1>{}, gg, sv[(c + 1) & 1]);
+            if constexpr (c + 1 < NCH && g <= 10) gslice(std::integral_constant<int, c + 1>{}, gg, sv[(c + 1) % SD]);
             eslice(cc, gg);
             __builtin_amdgcn_sched_barrier(0);
           });
