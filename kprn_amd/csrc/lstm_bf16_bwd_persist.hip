@@ -46,7 +46,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace pb {
 
 constexpr int H = 384;          // hidden units (instantiated shape)
-constexpr int NPT = 2;          // path tiles (32 rows) of a work tile
 constexpr int NW = 4;           // waves per workgroup, one per SIMD
 constexpr int MJ = 3;           // 32-row result tiles per wave: NW * MJ * 32 = H
 constexpr int NCH = 12;         // K chunks: 32 hidden units x 4 gates = 128 gate columns = 8 k-steps
@@ -62,10 +61,19 @@ constexpr int PF = KPRN_BPTT_PF;   // fragments in flight per wave (12 = 4 k-ste
 constexpr int SD = KPRN_BPTT_SD;   // chunks the saves are requested ahead of their cell backward (one register set of 24 per chunk in flight)
 static_assert(NCH % SD == 0, "the save sets keep their phase across steps");
 constexpr int UREC = H / 4 * 32;     // records (quads) of one unit of 32 rows and one step: [forward chunk 6][forward wave 8][lane 64]
-constexpr int BUF = NPT * KSC * 1024;   // bytes of one dA chunk tile in LDS
-constexpr int TP = 64 * 2 + 16;         // row pitch of the transposed chunk tile (bytes): 64 paths + 16 (the two halves of a wave write rows 4 apart: 576 bytes = other banks)
-constexpr int TT = 128 * TP;            // bytes of the transposed chunk tile: 4 gates x 32 hidden units rows
-static_assert(NW * MJ * 32 == H && NCH * 32 == H && MJ * 4 == NCH && (KSC * MJ) % PF == 0, "shape algebra of the backward tile");
+// geometry of a work tile of NPT path tiles (32 rows each): NPT = 2 (64 rows, one workgroup per CU) or 1 (32 rows, two workgroups per CU)
+template <int NPT> struct Geo {
+  static constexpr int PW = 32 * NPT;             // paths of a tile
+  static constexpr int BUF = NPT * KSC * 1024;    // bytes of one dA chunk tile in LDS
+  static constexpr int TP = PW * 2 + 16;          // row pitch of the transposed chunk tile (bytes): the two halves of a wave write rows 4 apart -> other banks
+  static constexpr int TT = 128 * TP;             // bytes of the transposed chunk tile: 4 gates x 32 hidden units rows
+  static constexpr int NO = PW / 8;               // 16-byte pieces (8 paths) of a row
+  static constexpr int RPP = 256 / NO;            // rows of the transposed tile the 256 threads cover per pass
+  static constexpr int NI = 128 / RPP;            // passes = pieces per thread and chunk
+  static constexpr int DHL = MJ * NPT * 4 * 4096; // bytes of dh_t in LDS
+  static constexpr int LDS = 2 * BUF + TT + 4 * H * 4 + DHL;
+};
+
 
 struct BArgs {
   const bf16x8* A0; const bf16x8* A1; const bf16x4* cF;   // the forward's fragment-order saves: [i4 g4], [f4 o4], c (records of 4 hidden units)
@@ -77,7 +85,7 @@ struct BArgs {
   bf16* dAT;                 // [4H][ldT], this step's block at column t Np
   float* gbias;              // [4H] += column sums of dA (the bf16-rounded values)
   int64_t N, Np, ldT; int T;
-  int64_t tiles;             // ceil(N / 64)
+  int64_t tiles;             // ceil(N / (32 NPT))
 };
 
 template <int I, int N, class F>
@@ -106,12 +114,16 @@ template <class V> __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, 
 __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f; }
 
 // the saves of this lane's quad of one chunk, per path tile
-struct Sv { bf16x8 a0[NPT], a1[NPT]; bf16x4 c[NPT], cp[NPT]; };
+template <int NPT> struct SvT { bf16x8 a0[NPT], a1[NPT]; bf16x4 c[NPT], cp[NPT]; };
 
 // DBG: 2 = no row-major copy of dA (the product default: dx reads the transposed image, lstm_bf16.hip gx::k_gemm16xt; 0 keeps it for the row-major
 // dx product).  Measurement builds (KPRN_PERSIST_VARIANTS + KPRN_PERSIST_BWD_DBG) add: 1 no dA^T / bias pass, 4 no product, 8 no save loads
-template <int DBG>
-__global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
+template <int NPT, int DBG>
+__global__ __launch_bounds__(64 * NW, NPT == 1 ? 2 : 1) void k_lstm16_bwd_persist(BArgs a) {
+  static_assert(NW * MJ * 32 == H && NCH * 32 == H && MJ * 4 == NCH && (KSC * MJ) % PF == 0, "shape algebra of the backward tile");
+  typedef Geo<NPT> GE;
+  typedef SvT<NPT> Sv;
+  constexpr int BUF = GE::BUF, TP = GE::TP, TT = GE::TT, NO = GE::NO, RPP = GE::RPP, NI = GE::NI, PW = GE::PW;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* const buf = smem;                                   // 2 x BUF: dA chunk tiles in B-fragment order [pt][k-step][slot][16 B]
   char* const tt = smem + 2 * BUF;                          // dA chunk tile TRANSPOSED: [gate 4][unit 32] rows of 64 paths (pitch TP bytes)
@@ -130,15 +142,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
 #pragma unroll
   for (int s = 0; s < PF; ++s) ring[s] = ldb<bf16x8>(rW, l16, (unsigned)s * 1024u);
   // the dA^T pass of a chunk: thread -> (octet of 8 consecutive paths, row kc0 + 32 i of the transposed tile = gate i, unit kc0 of the chunk)
-  const int oct = tid & 7, kc0 = tid >> 3;
-  const unsigned et_voff = (unsigned)(((int64_t)kc0 * a.ldT + 8 * oct) * 2);   // (host: 32 rows of dA^T span < 4 GB)
+  const int oct = tid % NO, kc0 = tid / NO;   // row kc0 + RPP i of the transposed tile = gate (RPP i + kc0) / 32, unit (kc0 & 31)
+  const unsigned et_voff = (unsigned)(((int64_t)((kc0 >> 5) * H + (kc0 & 31)) * a.ldT + 8 * oct) * 2);   // (host: H + 32 rows of dA^T span < 4 GB)
   bar();
 
   for (int64_t tile = t_beg; tile < t_end; ++tile) {
-    const int64_t row0 = tile * 64;
+    const int64_t row0 = tile * PW;
     // units of 32 rows of the tile (the second may lie past the end: its lanes are masked, its loads stay in range)
     const int64_t u0 = tile * NPT;
-    const unsigned d1_16 = (u0 + 1 < a.NU) ? (unsigned)UREC * 16u : 0u;   // byte distance of path tile 1's records (16-byte planes)
+    const unsigned d1_16 = (NPT > 1 && u0 + 1 < a.NU) ? (unsigned)UREC * 16u : 0u;   // byte distance of path tile 1's records (16-byte planes)
     bool valid[NPT];
     float ds[NPT];
 #pragma unroll
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
       // 10: the saves of chunk c + 2 (or of the next step's first chunks) and dh of chunk c + 1 are requested.
       auto gslice = [&](auto cc, auto gg, Sv& s) {
         constexpr int c = decltype(cc)::value, Gs = decltype(gg)::value, j = c >> 2, q = c & 3;
-        if constexpr (Gs < 8) {
+        if constexpr (Gs < 8 && (Gs >> 2) < NPT) {
           constexpr int pt = Gs >> 2, r = Gs & 3;
           const float ig = (float)s.a0[pt][r], gv = (float)s.a0[pt][4 + r], fg = (float)s.a1[pt][r], og = (float)s.a1[pt][4 + r];
           const float tc = tanh_fast((float)s.c[pt][r]);
@@ -231,7 +243,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
           pc[pt][1][r] = (bf16)(dc * cp * fg * (1.f - fg));
           pc[pt][1][4 + r] = (bf16)(dO * og * (1.f - og));
           dcs[j][pt][4 * q + r] = dc * fg;
-        } else if constexpr (Gs < 10) {
+        } else if constexpr (Gs >= 8 && Gs < 10 && (Gs - 8) < NPT) {
           constexpr int pt = Gs - 8;
           char* const dst = buf + (c & 1) * BUF;
           // B-fragment order: k-step 2 w + half, k-group ab (piece [di dg] -> 0, [df do] -> 1), slot ln + 32 ab
@@ -278,24 +290,24 @@ __global__ __launch_bounds__(64 * NW, 1) void k_lstm16_bwd_persist(BArgs a) {
       auto eslice = [&](auto cc, auto gg) {
         constexpr int c = decltype(cc)::value, Gs = decltype(gg)::value;
         if constexpr ((DBG & 1) != 0) return;
-        if constexpr (Gs >= 12 && Gs <= 15) {
-          constexpr int i = Gs - 12;
-          // address = uniform 64-bit base (scalar registers: plane + step block + row block of (gate i, chunk c)) + this thread's 32-bit byte offset
-          // (row kc0 of the block, octet).  The row block is made opaque: otherwise hipcc precomputes the 48 (chunk, i) offsets of the whole
+        if constexpr (Gs >= 12 && Gs < 12 + NI) {
+          constexpr int i = Gs - 12, gbase = (RPP * i) / 32;   // this pass's rows: gates gbase (+ kc0 >> 5)
+          // address = uniform 64-bit base (scalar registers: plane + step block + row block of (gate, chunk c)) + this thread's 32-bit byte offset
+          // (its row of the block, octet).  The row block is made opaque: otherwise hipcc precomputes the (chunk, pass) offsets of the whole
           // step outside the step loop and spills registers for them.
-          int64_t sofs = (int64_t)(i * H + 32 * c) * a.ldT;
+          int64_t sofs = (int64_t)(gbase * H + 32 * c) * a.ldT;
           asm volatile("" : "+s"(sofs));
           if (et_ok) *(bf16x8*)((char*)(dat_t + sofs) + et_voff) = ev;
           float sum = 0.f;
 #pragma unroll
           for (int x = 0; x < 8; ++x) sum += (float)ev[x];
-          // sum over the 8 lanes of the octet group (DPP: quad xor 1, quad xor 2, mirror of the half row)
+          // sum over the lanes of the row's pieces (DPP: quad xor 1, quad xor 2, and for 8 pieces the mirror of the half row)
           sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, true));
           sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, true));
-          sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, true));
-          if (oct == 0) sdb[i * H + 32 * c + kc0] += sum;   // (one owner thread per gate column: no atomics)
+          if constexpr (NO == 8) sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, true));
+          if (oct == 0) sdb[(gbase + (kc0 >> 5)) * H + 32 * c + (kc0 & 31)] += sum;   // (one owner thread per gate column: no atomics)
         }
-        if constexpr (Gs >= 11 && Gs <= 14) ev = *(const bf16x8*)(tt + (32 * (Gs - 11) + kc0) * TP + oct * 16);
+        if constexpr (Gs >= 11 && Gs < 11 + NI) ev = *(const bf16x8*)(tt + (RPP * (Gs - 11) + kc0) * TP + oct * 16);
       };
 
       // first chunk of the step: nothing to ride behind
@@ -440,19 +452,24 @@ void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSa
   a.dS = h->ws.dS; a.Wc = h->dense + h->off_outW + (int64_t)cid * pb::H;
   a.WpB = p->WpB; a.dA = dA16; a.dAT = dAT16; a.gbias = h->g_dense + h->layer[0].bi;
   a.N = N; a.Np = Np; a.ldT = (int64_t)T * Np; a.T = T;
-  a.tiles = (N + 63) / 64;
-  KPRN_REQUIRE(a.ldT * 64 < ((int64_t)1 << 32), KPRN_E_ARG, "persistent BPTT: T x N too large for 32-bit row-block offsets of dA^T");
-  int grid = (int)std::min<int64_t>(p->grid, a.tiles);
+  // tile height: 64 rows, one workgroup per CU (default), or 32 rows, two workgroups per CU (KPRN_BPTT_NPT=1: each weight fragment then serves one
+  // path tile only -- twice the weight bytes through the L1 path -- for two independent barrier domains per CU)
+  static const int npt_env = getenv("KPRN_BPTT_NPT") ? atoi(getenv("KPRN_BPTT_NPT")) : 2;
+  const int npt = npt_env == 1 ? 1 : 2;
+  a.tiles = (N + 32 * npt - 1) / (32 * npt);
+  KPRN_REQUIRE(a.ldT * (pb::H + 64) * 2 < ((int64_t)1 << 32), KPRN_E_ARG, "persistent BPTT: T x N too large for 32-bit row-block offsets of dA^T");
+  int grid = (int)std::min<int64_t>((int64_t)p->grid * (npt == 1 ? 2 : 1), a.tiles);
   if (const char* e = getenv("KPRN_PERSIST_BWD_GRID")) grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, atoi(e)));   // (tests: several tiles per workgroup at small N)
-  const size_t lds_bytes = (size_t)2 * pb::BUF + (size_t)pb::TT + (size_t)4 * pb::H * sizeof(float) + (size_t)pb::MJ * pb::NPT * 4 * 4096;
+  const size_t lds_bytes = npt == 1 ? (size_t)pb::Geo<1>::LDS : (size_t)pb::Geo<2>::LDS;
   typedef void (*Kern)(pb::BArgs);
-  Kern k = dA16 ? (Kern)pb::k_lstm16_bwd_persist<0> : (Kern)pb::k_lstm16_bwd_persist<2>;   // (2: no row-major copy -- dx reads the transposed image)
+  Kern k = dA16 ? (Kern)pb::k_lstm16_bwd_persist<2, 0> : (Kern)pb::k_lstm16_bwd_persist<2, 2>;   // (2: no row-major copy -- dx reads the transposed image)
+  if (npt == 1) k = dA16 ? (Kern)pb::k_lstm16_bwd_persist<1, 0> : (Kern)pb::k_lstm16_bwd_persist<1, 2>;
 #ifdef KPRN_PERSIST_VARIANTS
   // measurement builds (scripts/gpu_persist_knockouts.py bwd): KPRN_PERSIST_BWD_DBG = knock-out mask
   if (const char* e = getenv("KPRN_PERSIST_BWD_DBG")) {
     const int dbg = atoi(e) | (dA16 ? 0 : 2);
-    bool found = dbg == 0 || dbg == 2;
-#define KV(D) if (dbg == D) { k = (Kern)pb::k_lstm16_bwd_persist<D>; found = true; }
+    bool found = (dbg == 0 || dbg == 2) && npt == 2;
+#define KV(D) if (dbg == D) { k = (Kern)pb::k_lstm16_bwd_persist<2, D>; found = true; }
     KV(1) KV(2) KV(3) KV(4) KV(7) KV(8) KV(15)
 #undef KV
     KPRN_REQUIRE(found, KPRN_E_ARG, "this variant of the persistent BPTT kernel is not compiled in");
