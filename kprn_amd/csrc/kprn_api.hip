@@ -1388,6 +1388,7 @@ static void feed_impl(kprn_handle* h, kprn_batch** slot, const int32_t* idx, con
   if (fresh) b = new kprn_batch();
   try {
     if (!fresh) {
+      if (h->score_rest_batch == b) launch_score_rest(h);   // (the deferred part of a split scoring pass still reads the slot's old contents)
       // the slot's previous contents: whatever the handle still refers to goes to owned storage; their last readers were
       // enqueued before this call, and the feed stream starts behind them (below)
       if (h->view_batch == b) {
@@ -1467,6 +1468,7 @@ int kprn_batch_slot_reserve(kprn_handle* h, kprn_batch** slot, int32_t max_pairs
   if (fresh) b = new kprn_batch();
   try {
     if (!fresh) {
+      if (h->score_rest_batch == b) launch_score_rest(h);
       if (h->view_batch == b) materialize_step_rows(h);
       if (b->pending && b->host_built && b->job.valid()) { try { b->job.get(); } catch (...) {} }
       b->pending = false; b->bad = true;  // (no contents until the next feed)
@@ -1603,6 +1605,7 @@ static hipStream_t make_concurrent_stream(kprn_handle* h) {
 
 int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id) {
   API_BEGIN(h)
+  if (h->score_rest_batch) launch_score_rest(h);   // (the second part of an earlier split pass that nobody placed: before its buffers are reused)
   h->last_forward_side = false;
   if (h->score_overlap && b && use_fused(h, b, false)) {
     // the pass goes to the side stream with its own output buffers; everything it reads is final on the main stream first
