@@ -75,3 +75,25 @@ def test_register_spills_of_the_persistent_kernels():
         loads_inside = [l for l in ins[first:last] if l.startswith("scratch_load")]
         assert not stores_inside, (km.group(1), stores_inside[:3])
         assert len(loads_inside) <= (16 if "ILb1ELb0E" in km.group(1) else 32), (km.group(1), len(loads_inside))   # (L = 2 bottom | L = 1)
+
+
+def test_persistent_bptt_kernel_keeps_its_state_in_registers():
+    """lstm_bf16_bwd_persist.hip: the accumulators of dh_{t-1} and dc (2 x 96 registers), the weight ring and two save sets live in the 512-entry file of one
+    wave per SIMD; the first builds spilled 309 / 146 registers into the step loop (dh in registers too; the dA^T row offsets precomputed per chunk).  The product
+    instantiations must not spill at all, and their prefetch ring must survive hipcc's scheduling: counted vmcnt waits in front of the MFMAs, not vmcnt(0)."""
+    text = chk.compile_isa(os.path.join(CSRC, "lstm_bf16_bwd_persist.hip"))
+    res = {k: v for k, v in chk.kernel_resources(text).items() if "k_lstm16_bwd_persist" in k}
+    assert len(res) >= 4
+    for k, v in res.items():
+        if "ILi2E" in k:      # 64-row tiles, one workgroup per CU: the product default
+            assert v["vgpr_spill_count"] == 0 and v["vgpr_count"] <= 512, (k, v)
+        else:                 # 32-row tiles, two workgroups per CU (opt-in, measured slower): 256 registers per wave
+            assert v["vgpr_spill_count"] <= 40 and v["vgpr_count"] <= 256, (k, v)
+    km = re.search(r"\n(_ZN5bf16p2pb20k_lstm16_bwd_persistILi2ELi2E\w+):[^\n]*\n(.*?)s_endpgm", text, re.S)
+    ins = [l.split(";")[0].strip() for l in km.group(2).split("\n")]
+    ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
+    mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
+    assert len(mf) == 12 * 8 * 3 * 2       # chunks x k-steps x result tiles x path tiles: ONE copy of the step body
+    waits = [l for l in ins[mf[0]:mf[-1]] if l.startswith("s_waitcnt") and "vmcnt" in l]
+    drained = [l for l in waits if "vmcnt(0)" in l]
+    assert len(drained) <= 4, drained[:5]   # (the first builds: a vmcnt(0) in front of most of the 576 MFMAs)
