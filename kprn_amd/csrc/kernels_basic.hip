@@ -1145,11 +1145,17 @@ __global__ __launch_bounds__(256) void k_table_grad_mfma(const int32_t* __restri
       int t = t0;
       int64_t n = n0 + (live ? q : 0);
       while (n >= N) { n -= N; ++t; }
+      // (every load unconditional, from a clamped position: under `live ? load : 0` hipcc branches around each load and waits for it inside the
+      //  branch -- UN dependent round trips per iteration instead of one: configs[3] 0.267 -> 0.199 ms, dims B 0.156 -> 0.116.  A variant with 16-byte
+      //  loads feeding four accumulator tiles per lane and the waves splitting the positions measured 0.73 / 1.15 ms: its extra position groups
+      //  multiply the epilogue's atomics on the same few table rows, which is what bounds this kernel on small tables)
       const float* src = dX + (p0 + (live ? q : 0)) * D + col0;
-      xa[u] = (live && has_a) ? src[c_a] : 0.f;
-      xb[u] = (live && has_b) ? src[c_b] : 0.f;
+      const float va = src[has_a ? c_a : 0], vb = src[has_b ? c_b : 0];
       ioff[u] = (n * T + t) * F + idcol;
-      id[u] = live ? idx[ioff[u]] - 1 : -1;
+      const int idr = idx[ioff[u]];
+      xa[u] = (live && has_a) ? va : 0.f;
+      xb[u] = (live && has_b) ? vb : 0.f;
+      id[u] = live ? idr - 1 : -1;
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -1178,79 +1184,6 @@ __global__ __launch_bounds__(256) void k_table_grad_mfma(const int32_t* __restri
     }
 }
 
-// The same product with 16-byte loads (round 4).  Above, a lane loads ONE float per position (a wave instruction = 4 rows x 64 bytes) and the id chain
-// idx -> id sits in front of every MFMA group: 0.18 ms for the 200 MB relation slice of configs[3] (1.1 TB/s; its MFMAs alone are 0.04 ms).  Here a lane
-// loads a float4 -- columns 4 n .. 4 n + 3 of its position -- which feeds FOUR accumulator tiles: tile j, lane n <-> real column 64 ch + 4 n + j (any
-// bijection of columns to (tile, lane) works for a one-hot product; the epilogue writes column 64 ch + 4 n + j).  A wave instruction is then 4 rows x 256
-// contiguous bytes; waves split the slice's 64-column halves (ch) and, beyond that, the positions (pg).
-template <int RT>
-__global__ __launch_bounds__(256, 2) void k_table_grad_mfma4(const int32_t* __restrict__ idx, int64_t N, int T, int F, int idcol, int slots,
-                                                           const float* __restrict__ dX, int D, int col0, int dcols, int V, float* __restrict__ gW,
-                                                           int pos_per_block) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int kk = lane >> 4, n16 = lane & 15;
-  const int ncw = (dcols + 63) >> 6;          // column waves (1 or 2)
-  const int npg = 4 / ncw;                    // position groups
-  const int ch = wv % ncw, pg = wv / ncw;
-  f4 acc[RT][4];
-#pragma unroll
-  for (int r = 0; r < RT; ++r)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[r][j] = f4{0.f, 0.f, 0.f, 0.f};
-  const int64_t total = N * T;
-  const int64_t p0 = (int64_t)blockIdx.x * pos_per_block;
-  const int np = (int)((p0 + pos_per_block < total ? p0 + pos_per_block : total) - p0);
-  const int t0 = (int)(p0 / N);
-  const int64_t n0 = p0 - (int64_t)t0 * N;
-  const int c4 = 64 * ch + 4 * n16;           // this lane's first column inside the slice
-  const bool has = c4 + 3 < dcols;            // (dcols is a multiple of 4)
-  constexpr int UN = 4;                       // k-steps (of four positions) in flight per wave
-  for (int q0 = 4 * pg; q0 < np; q0 += 4 * UN * npg) {
-    f4 x[UN];
-    int id[UN];
-    int64_t ioff[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int q = q0 + 4 * npg * u + kk;
-      const bool live = q < np;
-      int t = t0;
-      int64_t n = n0 + (live ? q : 0);
-      while (n >= N) { n -= N; ++t; }
-      x[u] = (live && has) ? *(const f4*)(dX + (p0 + q) * D + col0 + c4) : f4{0.f, 0.f, 0.f, 0.f};
-      ioff[u] = (n * T + t) * F + idcol;
-      id[u] = live ? idx[ioff[u]] - 1 : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      for (int sl = 0; sl < slots; ++sl) {   // CAddTable over the type slots (FeatureEmbedding.lua:55): the same dx goes to every slot's row
-        const int idv = (sl == 0) ? id[u] : ((id[u] >= 0) ? idx[ioff[u] + sl] - 1 : -1);
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          if (RT > 1 && __ballot((idv >> 4) == r) == 0) continue;   // (wave-uniform) nobody's id lies in this row tile
-          const float onehot = (idv == 16 * r + n16) ? 1.f : 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(onehot, x[u][j], acc[r][j], 0, 0, 0);
-        }
-      }
-    }
-  }
-  // D: lane (g, n) holds rows v = 16 rt + 4 g + i of tile j's column n = real column c4 + j
-  if (has) {
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int v = 16 * r + 4 * kk + i;
-        if (v < V) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (acc[r][j][i] != 0.f) unsafeAtomicAdd(gW + (int64_t)v * dcols + c4 + j, acc[r][j][i]);
-        }
-      }
-  }
-}
-
 static bool table_grad_mfma(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int idcol, int slots, const float* dX, int D, int col0, int dcols,
                             int V, float* gW) {
   if (dcols <= 0 || dcols > 128 || V <= 0 || V > 128) return false;
@@ -1258,10 +1191,7 @@ static bool table_grad_mfma(hipStream_t s, const int32_t* idx, int64_t N, int T,
   const int ppb = ppb_env > 0 ? ppb_env : 256;   // (256 and 512 measure alike on configs[3] and the shipped shape, 256 wins at D = 192; 1 024 loses parallelism)
   const int64_t total = N * T;
   const dim3 grid((unsigned)((total + ppb - 1) / ppb));
-  static const bool wide_off = getenv("KPRN_TABLE_GRAD_WIDE") && getenv("KPRN_TABLE_GRAD_WIDE")[0] == '0';   // (A/B: the one-float-per-lane loads)
-  const bool wide = !wide_off && (dcols & 3) == 0 && (col0 & 3) == 0 && (D & 3) == 0;
-#define KPRN_TG(RT_) do { if (wide) hipLaunchKernelGGL(k_table_grad_mfma4<RT_>, grid, dim3(256), 0, s, idx, N, T, F, idcol, slots, dX, D, col0, dcols, V, gW, ppb); \
-                          else hipLaunchKernelGGL(k_table_grad_mfma<RT_>, grid, dim3(256), 0, s, idx, N, T, F, idcol, slots, dX, D, col0, dcols, V, gW, ppb); } while (0)
+#define KPRN_TG(RT_) hipLaunchKernelGGL(k_table_grad_mfma<RT_>, grid, dim3(256), 0, s, idx, N, T, F, idcol, slots, dX, D, col0, dcols, V, gW, ppb)
   if (V <= 16) KPRN_TG(1);
   else if (V <= 32) KPRN_TG(2);
   else if (V <= 64) KPRN_TG(4);
