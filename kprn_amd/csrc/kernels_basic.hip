@@ -1188,7 +1188,8 @@ static bool table_grad_mfma(hipStream_t s, const int32_t* idx, int64_t N, int T,
                             int V, float* gW) {
   if (dcols <= 0 || dcols > 128 || V <= 0 || V > 128) return false;
   static const int ppb_env = getenv("KPRN_TABLE_GRAD_PPB") ? atoi(getenv("KPRN_TABLE_GRAD_PPB")) : 0;   // (measurement)
-  const int ppb = ppb_env > 0 ? ppb_env : 256;   // (256 and 512 measure alike on configs[3] and the shipped shape, 256 wins at D = 192; 1 024 loses parallelism)
+  const int ppb = ppb_env > 0 ? ppb_env : 512;   // (round 4, after the loads went unconditional: 512 beats 256 on configs[3] 0.175 : 0.198 ms, shipped 0.147 : 0.198, D = 192
+                                                 //  0.106 : 0.113 -- half the workgroups = half the epilogue atomics on the same table rows; 1 024 loses parallelism: 0.253)
   const int64_t total = N * T;
   const dim3 grid((unsigned)((total + ppb - 1) / ppb));
 #define KPRN_TG(RT_) hipLaunchKernelGGL(k_table_grad_mfma<RT_>, grid, dim3(256), 0, s, idx, N, T, F, idcol, slots, dX, D, col0, dcols, V, gW, ppb)
