@@ -314,7 +314,9 @@ __device__ __forceinline__ void slab_reduce_block(const SlabReduce& a, int bx, i
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int sl = s + (u >> 2) * a.ny * 4 + (u & 3);
-      x[u] = (sl < a.nslab) ? part[(int64_t)sl * a.n_elem + i] : 0.f;
+      // (unconditional load from a clamped slab, then the select: a load under a condition is a branch with the wait inside it)
+      const float v = part[(int64_t)(sl < a.nslab ? sl : a.nslab - 1) * a.n_elem + i];
+      x[u] = (sl < a.nslab) ? v : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc[u & 3] += x[u];
@@ -371,7 +373,8 @@ __device__ __forceinline__ void small_grad_block(const SmallGrad& a, int bx) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t n = mtile * 16 + ag * 4 + r;
-      raw[r] = (n < a.N) ? a.idx[(n * a.T + t) * a.F + idcol] : 0;
+      const int rv = a.idx[((n < a.N ? n : a.N - 1) * a.T + t) * a.F + idcol];   // (unconditional, clamped: see slab_reduce_block)
+      raw[r] = (n < a.N) ? rv : 0;
     }
     const bool live = !(t < tk);   // (wave-uniform) the prefix backward owns the skipped positions
 #pragma unroll
@@ -385,8 +388,8 @@ __device__ __forceinline__ void small_grad_block(const SmallGrad& a, int bx) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const int64_t it = it0 + (int64_t)d * nparts;
-      if (it < items) fetch(it, x[d], id[d]);
-      else { x[d] = f32x4_{0.f, 0.f, 0.f, 0.f}; id[d][0] = id[d][1] = id[d][2] = id[d][3] = -1; }
+      fetch(it < items ? it : items - 1, x[d], id[d]);   // (every item's loads issued, then the tail masked: no branch around a load)
+      if (!(it < items)) { id[d][0] = id[d][1] = id[d][2] = id[d][3] = -1; }
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
