@@ -213,19 +213,24 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
   const int64_t base = seg * 64;
   if (base >= nsteps) return;
   const int cnt = (int)((nsteps - base < 64) ? (nsteps - base) : 64);
-  const int my_key = (lane < cnt) ? key_sorted[base + lane] : -1;
+  // all four index reads are issued unconditionally from clamped addresses and masked afterwards: hipcc turns `cond ? load : x`
+  // into a branch with the wait inside it, which made these four dependent round trips instead of one
+  const int64_t mine = base + (lane < cnt ? lane : cnt - 1);
+  const int key_ld = key_sorted[mine], pos_ld = pos_sorted[mine];
+  const int kb_ld = key_sorted[base > 0 ? base - 1 : 0], ka_ld = key_sorted[base + cnt < nsteps ? base + cnt : nsteps - 1];
+  const int my_key = (lane < cnt) ? key_ld : -1;
   if (__builtin_amdgcn_readlane(my_key, 0) == sentinel) return;  // sorted last: nothing but skipped positions from here on
-  const int my_pos = (lane < cnt) ? pos_sorted[base + lane] : 0;
-  const int key_before = (base > 0) ? key_sorted[base - 1] : -1;
-  const int key_after = (base + cnt < nsteps) ? key_sorted[base + cnt] : -1;
+  const int my_pos = (lane < cnt) ? pos_ld : 0;
+  const int key_before = (base > 0) ? kb_ld : -1;
+  const int key_after = (base + cnt < nsteps) ? ka_ld : -1;
   const int waves_per_group = D >> 4;  // FRAG: 16-column blocks per (16-row block, t)
   for (int c0 = 0; c0 < de; c0 += 64) {
-    const int ecol = c0 + lane;       // column inside the entity slice
-    const bool act = ecol < de;
+    const bool act = c0 + lane < de;
+    const int ecol = act ? c0 + lane : de - 1;  // column inside the entity slice (idle lanes re-read the last one: loads stay unconditional)
     const int col = dt + ecol;        // column of dx
     const int coff = (col >> 4) * 256 + (col & 15) * 4;
-    // the segment's 64 positions in two halves of 32: 32 gathers in flight per lane instead of 64 keeps the kernel at <= 64 VGPRs (8 waves
-    // per SIMD instead of 5 -- the launch's 6 688 workgroups, passengers included, need 3.3 rounds of resident slots instead of 5.2)
+    // the segment's 64 positions in two halves of 32: 32 gathers in flight per lane (76 VGPRs, 6 waves per SIMD; capping the kernel at 64
+    // VGPRs for 8 waves makes the passenger jobs' code spill and measured 8 us slower)
     float acc = 0.f;
     bool opened_here = __builtin_amdgcn_readlane(my_key, 0) != key_before;  // the first run starts in this segment
 #pragma unroll
@@ -246,13 +251,16 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
         } else {
           off = ((int64_t)t * N + n) * D + col;
         }
-        v[i2] = (act && i < cnt && __builtin_amdgcn_readlane(my_key, i) != sentinel) ? DX[off] : 0.f;
+        // Unconditional, and unconditionally used below: 32 loads in flight.  (`cond ? DX[off] : 0` compiles to a branch per load with
+        // the wait inside it.)  What the guard used to zero is harmless: idle lanes never store, a run of skipped (sentinel) positions is
+        // dropped at its end, and positions past cnt (they re-read position 0) are only added after the segment's last run was written.
+        v[i2] = DX[off];
       }
 #pragma unroll
       for (int i2 = 0; i2 < 32; ++i2) {
         const int i = 32 * hf + i2;
+        acc += v[i2];
         if (i < cnt) {  // wave-uniform
-          acc += v[i2];
           const int k = __builtin_amdgcn_readlane(my_key, i);
           const bool more = (i < 63) && (i + 1 < cnt);
           const int knext = more ? __builtin_amdgcn_readlane(my_key, (i + 1) & 63) : key_after;

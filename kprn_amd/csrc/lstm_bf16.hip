@@ -853,35 +853,46 @@ __global__ __launch_bounds__(256) void k_gather16_T(const int32_t* __restrict__ 
   const int D = dt + de + dr;
   const int64_t n0 = (int64_t)blockIdx.x * 64;
   const int c0 = blockIdx.y * 64, t = blockIdx.z;
+  // Both of a thread's pieces: ids first, then rows, every load unconditional from a clamped address and masked afterwards (written as
+  // `if (in range) load`, hipcc keeps the wait inside the branch: four dependent round trips per thread instead of two).
+  const bf16* src[2]; const int32_t* idp[2]; bool ok[2], summed[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int f = threadIdx.x + 256 * e;
     const int rr = f >> 3, col = c0 + (f & 7) * 8;
     const int64_t n = n0 + rr;
-    bf16x8 v;
+    ok[e] = n < N && col < D;
+    const int cl = col < D ? col : 0;
+    const int32_t* id = idx + ((n < N ? n : N - 1) * T + t) * F;
+    const int which = cl < dt ? 0 : (cl < dt + de ? 1 : 2);
+    idp[e] = id;
+    summed[e] = which == 0 && nT > 1;
+    const int row = id[which == 0 ? F - nT - 2 : (which == 1 ? F - 2 : F - 1)] - 1;
+    src[e] = which == 0 ? Wt + (int64_t)row * dt + cl : (which == 1 ? We + (int64_t)row * de + (cl - dt) : Wr + (int64_t)row * dr + (cl - dt - de));
+  }
+  bf16x8 ld[2];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = (bf16)0.f;
-    if (n < N && col < D) {
-      const int32_t* id = idx + (n * T + t) * F;
-      if (col < dt) {
-        v = *(const bf16x8*)(Wt + (int64_t)(id[F - nT - 2] - 1) * dt + col);
-        if (nT > 1) {
-          float acc[8];
+  for (int e = 0; e < 2; ++e) ld[e] = *(const bf16x8*)src[e];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) acc[q] = (float)v[q];
-          for (int k = 1; k < nT; ++k) {
-            const bf16x8 w = *(const bf16x8*)(Wt + (int64_t)(id[F - nT - 2 + k] - 1) * dt + col);
+  for (int e = 0; e < 2; ++e) {
+    const int f = threadIdx.x + 256 * e;
+    const int rr = f >> 3, col = c0 + (f & 7) * 8;
+    bf16x8 v = ld[e];
+    if (summed[e] && ok[e]) {   // several type slots per step: their rows summed (FeatureEmbedding.lua:55)
+      float acc[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] += (float)w[q];
-          }
+      for (int q = 0; q < 8; ++q) acc[q] = (float)v[q];
+      for (int k = 1; k < nT; ++k) {
+        const bf16x8 w = *(const bf16x8*)(Wt + (int64_t)(idp[e][F - nT - 2 + k] - 1) * dt + col);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = tobf(acc[q]);
-        }
-      } else if (col < dt + de) {
-        v = *(const bf16x8*)(We + (int64_t)(id[F - 2] - 1) * de + (col - dt));
-      } else {
-        v = *(const bf16x8*)(Wr + (int64_t)(id[F - 1] - 1) * dr + (col - dt - de));
+        for (int q = 0; q < 8; ++q) acc[q] += (float)w[q];
       }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = tobf(acc[q]);
+    }
+    if (!ok[e]) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = (bf16)0.f;
     }
     *(bf16x8*)(&tl[rr][(f & 7) * 8]) = v;
   }
