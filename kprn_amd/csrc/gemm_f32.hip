@@ -27,6 +27,15 @@ __device__ __forceinline__ short to_bf16(float x) {
   return (short)(u >> 16);
 }
 
+// x where keep, +0 elsewhere -- as a bit mask the optimiser cannot see through.  The operand tiles' loads are issued unconditionally from clamped
+// (always valid) addresses and masked with this: written as `in range ? load : 0` -- or as a select after the load, which hipcc turns back into
+// the same thing -- every element becomes a branch with the load AND its wait inside: 16 dependent round trips per k-step.
+__device__ __forceinline__ float masked(float x, bool keep) {
+  unsigned m = keep ? 0xffffffffu : 0u;
+  asm("" : "+v"(m));
+  return __uint_as_float(__float_as_uint(x) & m);
+}
+
 constexpr int BM = 64, BN = 64, BK = 32, LDT = 80;  // LDT: k-major tile row stride (2-way = minimal bank sharing for 64 lanes)
 
 template <bool A_KCONTIG, bool B_NCONTIG, bool BF16>
@@ -55,6 +64,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 
   constexpr int PER = BM * BK / 256;  // elements of each tile per thread
   float ra[PER], rb[PER];
+  unsigned keep_a = 0u, keep_b = 0u;   // bit e: element e lies inside the problem (applied when the tile is written to LDS, behind the MFMAs)
   // element e of this thread: the fast thread index runs along the operand's contiguous dimension (coalesced loads)
   auto a_mk = [&](int e, int& m, int& k) {
     if (A_KCONTIG) { k = tid & (BK - 1); m = (tid / BK) + e * (256 / BK); }
@@ -64,13 +74,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     if (B_NCONTIG) { n = tid & 63; k = (tid >> 6) + e * 4; }
     else           { k = tid & (BK - 1); n = (tid / BK) + e * (256 / BK); }
   };
-  auto load_tile = [&](int64_t k0) {  // zero-filled outside the problem
+  // zero-filled outside the problem (masked())
+  auto load_tile = [&](int64_t k0) {
+    keep_a = keep_b = 0u;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
       int m, k;
       a_mk(e, m, k);
       const int64_t gm = m_base + m, gk = k0 + k;
-      ra[e] = (gm < M && gk < k_end) ? A[gm * sAm + gk * sAk] : 0.f;
+      ra[e] = A[(gm < M ? gm : M - 1) * sAm + (gk < K ? gk : K - 1) * sAk];
+      keep_a |= (gm < M && gk < k_end) ? (1u << e) : 0u;
     }
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
@@ -78,7 +91,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
       b_nk(e, n, k);
       const int gn = n_base + n;
       const int64_t gk = k0 + k;
-      rb[e] = (gn < N && gk < k_end) ? B[gk * sBk + (int64_t)gn * sBn] : 0.f;
+      rb[e] = B[(gk < K ? gk : K - 1) * sBk + (int64_t)(gn < N ? gn : N - 1) * sBn];
+      keep_b |= (gn < N && gk < k_end) ? (1u << e) : 0u;
     }
   };
   auto store_tile = [&](int buf) {
@@ -86,13 +100,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     for (int e = 0; e < PER; ++e) {
       int m, k;
       a_mk(e, m, k);
-      As[buf][k][m] = ra[e];
+      As[buf][k][m] = masked(ra[e], (keep_a >> e) & 1u);
     }
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
       int n, k;
       b_nk(e, n, k);
-      Bs[buf][k][n] = rb[e];
+      Bs[buf][k][n] = masked(rb[e], (keep_b >> e) & 1u);
     }
   };
 
@@ -142,6 +156,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     cur ^= 1;
   }
   // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+  float bj[2] = {0.f, 0.f};   // this lane's bias values, fetched once and together (inside the element loop each was a load with its own wait)
+  if (bias && !accumulate && !use_atomic) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n_base + wn * 32 + j * 16 + (lane & 15);
+      bj[j] = bias[col < N ? col : N - 1];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -159,8 +181,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         } else if (accumulate) {
           *dst += v;
         } else {
-          if (bias) v += bias[col];
-          *dst = v;
+          *dst = bias ? v + bj[j] : v;
         }
       }
     }
@@ -196,6 +217,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_big(const float* __restrict__
 
   constexpr int PER = GM * GK / 256;  // 8
   float ra[PER], rb[PER];
+  unsigned keep_a = 0u, keep_b = 0u;   // bit e: element e lies inside the problem (applied when the tile is written to LDS, behind the MFMAs)
   auto a_mk = [&](int e, int& m, int& k) {
     if (A_KCONTIG) { k = tid & (GK - 1); m = (tid / GK) + e * (256 / GK); }
     else           { m = tid & 127; k = (tid >> 7) + e * 2; }
@@ -205,12 +227,14 @@ __global__ __launch_bounds__(256) void gemm_kernel_big(const float* __restrict__
     else           { k = tid & (GK - 1); n = (tid / GK) + e * (256 / GK); }
   };
   auto load_tile = [&](int64_t k0) {
+    keep_a = keep_b = 0u;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
       int m, k;
       a_mk(e, m, k);
       const int64_t gm = m_base + m, gk = k0 + k;
-      ra[e] = (gm < M && gk < k_end) ? A[gm * sAm + gk * sAk] : 0.f;
+      ra[e] = A[(gm < M ? gm : M - 1) * sAm + (gk < K ? gk : K - 1) * sAk];
+      keep_a |= (gm < M && gk < k_end) ? (1u << e) : 0u;
     }
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
@@ -218,14 +242,15 @@ __global__ __launch_bounds__(256) void gemm_kernel_big(const float* __restrict__
       b_nk(e, n, k);
       const int gn = n_base + n;
       const int64_t gk = k0 + k;
-      rb[e] = (gn < N && gk < k_end) ? B[gk * sBk + (int64_t)gn * sBn] : 0.f;
+      rb[e] = B[(gk < K ? gk : K - 1) * sBk + (int64_t)(gn < N ? gn : N - 1) * sBn];
+      keep_b |= (gn < N && gk < k_end) ? (1u << e) : 0u;
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int e = 0; e < PER; ++e) { int m, k; a_mk(e, m, k); As[buf][k][m] = ra[e]; }
+    for (int e = 0; e < PER; ++e) { int m, k; a_mk(e, m, k); As[buf][k][m] = masked(ra[e], (keep_a >> e) & 1u); }
 #pragma unroll
-    for (int e = 0; e < PER; ++e) { int n, k; b_nk(e, n, k); Bs[buf][k][n] = rb[e]; }
+    for (int e = 0; e < PER; ++e) { int n, k; b_nk(e, n, k); Bs[buf][k][n] = masked(rb[e], (keep_b >> e) & 1u); }
   };
 
   load_tile(k_beg);
@@ -269,6 +294,14 @@ __global__ __launch_bounds__(256) void gemm_kernel_big(const float* __restrict__
     __syncthreads();
     cur ^= 1;
   }
+  float bj[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias && !accumulate && !use_atomic) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n_base + wn * 64 + j * 16 + (lane & 15);
+      bj[j] = bias[col < N ? col : N - 1];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -283,7 +316,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_big(const float* __restrict__
         float* dst = C + row * ldc + col;
         if (use_atomic) unsafeAtomicAdd(dst, v);
         else if (accumulate) *dst += v;
-        else { if (bias) v += bias[col]; *dst = v; }
+        else *dst = bias ? v + bj[j] : v;
       }
     }
 }
