@@ -32,7 +32,7 @@ static thread_local std::string g_create_error;
 
 // ---------------------------------------------------------------------------------------
 // profiling scopes
-ProfScope::ProfScope(kprn_handle* h_, const char* n) : h(h_), name(n) {
+ProfScope::ProfScope(kprn_handle* h_, const char* n, hipStream_t on) : h(h_), name(n), strm(on ? on : h_->stream) {
   if (!h->prof_on) return;
   // an event pair costs ~4 us of stream time: a filter keeps the measurement of ONE kernel family from taxing all the others
   if (!h->prof_filter.empty() && strncmp(n, h->prof_filter.c_str(), h->prof_filter.size()) != 0) return;
@@ -43,11 +43,11 @@ ProfScope::ProfScope(kprn_handle* h_, const char* n) : h(h_), name(n) {
     return e;
   };
   a = get(); b = get();
-  if (a) hipEventRecord(a, h->stream);
+  if (a) hipEventRecord(a, strm);
 }
 ProfScope::~ProfScope() {
   if (!h->prof_on || !a || !b) return;
-  hipEventRecord(b, h->stream);
+  hipEventRecord(b, strm);
   h->prof_pending.push_back({name, a, b, launches});
   if (h->prof_pending.size() > 4096) prof_drain(h);
 }
@@ -1570,7 +1570,8 @@ __global__ void k_probe_wait(int* flag, int* seen, long long max_ticks) {
 }
 __global__ void k_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-static hipStream_t make_concurrent_stream(kprn_handle* h) {
+}  // extern "C"
+hipStream_t make_concurrent_stream(kprn_handle* h) {
   const int kTries = 8;
   hipStream_t cand[kTries] = {};
   int32_t* d = dalloc<int32_t>(2);   // {flag, seen}
@@ -1602,6 +1603,7 @@ static hipStream_t make_concurrent_stream(kprn_handle* h) {
   dfree(d);
   return pick;
 }
+extern "C" {
 
 int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id) {
   API_BEGIN(h)

@@ -226,9 +226,11 @@ struct kprn_handle {
 struct ProfScope {
   kprn_handle* h; const char* name; hipEvent_t a = nullptr, b = nullptr;
   int launches = 1;  // launches of the family this scope spans (one event pair around several back-to-back launches)
-  ProfScope(kprn_handle* h_, const char* n);
+  hipStream_t strm;  // the stream the family is launched on (the handle's, unless given)
+  ProfScope(kprn_handle* h_, const char* n, hipStream_t on = nullptr);
   ~ProfScope();
 };
+hipStream_t make_concurrent_stream(kprn_handle* h);   // a stream whose work runs BESIDE the main stream's (kprn_api.hip: probed, not assumed)
 void prof_drain(kprn_handle* h);
 void join_score(kprn_handle* h);  // main stream waits for the scoring pass on the side stream, if any
 

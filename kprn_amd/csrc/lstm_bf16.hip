@@ -1121,6 +1121,8 @@ struct State {
   bool bias_in_gates = false;   // k_gates_bwd16_frag also summed the bias gradient (measurement switch)
   bool act_frag = false;        // the last training forward wrote c and the gate planes in fragment order (persistent kernel; k_gates_bwd16_frag)
   PersistSaves sv{};
+  // the backward's side stream (backward(): the memory-bound helpers run beside the matrix-core launches they do not depend on)
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_operands = nullptr, ev_dx = nullptr, ev_join = nullptr;
 };
 // lstm_bf16_persist.hip: the whole layer (gather + T steps) as one persistent launch
 bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b);
@@ -1179,6 +1181,10 @@ void release(kprn_handle* h) {
   for (bf16* p : {s->We16, s->dense16, s->WT16, s->X16, s->XT16, s->H16, s->HT16, s->ACT16, s->dA16, s->dAT16}) if (p) hipFree(p);
   persist_release(s->persist);
   persist_bwd_release(s->persist_bwd);
+  if (s->side) {
+    hipStreamSynchronize(s->side); hipStreamDestroy(s->side);
+    for (hipEvent_t e : {s->ev_fork, s->ev_operands, s->ev_dx, s->ev_join}) if (e) hipEventDestroy(e);
+  }
   delete s;
   h->bf16_state = nullptr;
 }
@@ -1302,10 +1308,26 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   float* gd = h->g_dense;
   // the persistent BPTT launch forms dh_T = dS W_out[cid] itself and keeps dh / dc on the chip: no dH plane, no dC plane
   const bool bptt_persist = s->act_frag && L == 1 && persist_bwd_shape_ok(h, s->sv);
+  // Side stream (with the persistent BPTT launch): what is left of this backward is a chain of matrix-core launches -- BPTT, the dx product,
+  // the two dW products -- and memory-bound helpers that each depend on only part of it.  The helpers run on a second stream beside the
+  // launches they do not depend on: the head's backward and the two transposed operands of the dW products (in^T gathered from the tables,
+  // h^T from the forward's records) beside BPTT; the three table gradients (they need dx only) beside the dW products.  The main stream
+  // waits for the side stream before this function returns: nothing outside sees two streams.  KPRN_BF16_BWD_OVERLAP=0: one stream.
+  static const bool overlap_env = !(getenv("KPRN_BF16_BWD_OVERLAP") && getenv("KPRN_BF16_BWD_OVERLAP")[0] == '0');
+  const bool overlap = bptt_persist && overlap_env;
+  if (overlap && !s->side) {
+    s->side = make_concurrent_stream(h);
+    for (hipEvent_t* e : {&s->ev_fork, &s->ev_operands, &s->ev_dx, &s->ev_join}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  hipStream_t side = overlap ? s->side : strm;
+  if (overlap) {
+    HIP_TRY(hipEventRecord(s->ev_fork, strm));
+    HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
+  }
   {
-    ProfScope ps(h, "head_bwd");
+    ProfScope ps(h, "head_bwd", side);
     const float* hT = w.Hs + ((int64_t)(L - 1) * T + (T - 1)) * N * H;
-    kk::head_bwd(strm, w.dS, hT, h->dense + h->off_outW, N, H, cid, bptt_persist ? nullptr : w.dH, gd + h->off_outW, gd + h->off_outb);
+    kk::head_bwd(side, w.dS, hT, h->dense + h->off_outW, N, H, cid, bptt_persist ? nullptr : w.dH, gd + h->off_outW, gd + h->off_outb);
   }
   if (!bptt_persist) HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), strm));
   for (int l = L - 1; l >= 0; --l) {
@@ -1364,18 +1386,31 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     }
     const int64_t Np = (N + 7) & ~(int64_t)7, TNp = (int64_t)T * Np;   // padded step blocks of the transposed images (pads are zero)
     {
-      ProfScope ps(h, "bf16_transposes");
+      // (with the side stream: in^T and h^T are built there, beside the BPTT launch queued above -- neither reads anything it writes)
+      ProfScope ps(h, "bf16_transposes", side);
       if (!(s->act_frag && l == 0)) transpose_steps(strm, s->dA16, s->dAT16, T, N, Np, G4);                       // dA^T [4H][T][Np] (the fragment-order gate backward wrote it)
       if (l == 0 && s->act_frag) {   // in^T gathered straight into the transposed layout (the forward was the persistent kernel: no X16 plane)
-        hipLaunchKernelGGL(k_gather16_T, dim3((unsigned)((Np + 63) / 64), (unsigned)((Din + 63) / 64), (unsigned)T), dim3(256), 0, strm, b->idx, N, Np, T, b->F,
+        hipLaunchKernelGGL(k_gather16_T, dim3((unsigned)((Np + 63) / 64), (unsigned)((Din + 63) / 64), (unsigned)T), dim3(256), 0, side, b->idx, N, Np, T, b->F,
                            c.num_types, s->dense16 + h->off_Wt, s->We16, s->dense16 + h->off_Wr, c.dt, c.de, c.dr, s->XT16, (int64_t)T * Np);
         HIP_TRY(hipGetLastError());
       } else transpose_steps(strm, (l == 0) ? s->X16 : s->H16 + (int64_t)(l - 1) * TN * H, s->XT16, T, N, Np, Din);      // in^T [Din][T][Np]
       if (T > 1 && s->act_frag && l == 0 && s->sv.HsF && s->sv.NW == 8 && (H % 64) == 0) {   // h^T straight from the persistent forward's fragment-order records (steps 0 .. T-2)
-        hipLaunchKernelGGL(k_hfrag_T, dim3((unsigned)((s->sv.NU + 1) / 2), (unsigned)(H / 64), (unsigned)(T - 1)), dim3(256), 0, strm, (const bf16x4*)s->sv.HsF, s->HT16,
+        hipLaunchKernelGGL(k_hfrag_T, dim3((unsigned)((s->sv.NU + 1) / 2), (unsigned)(H / 64), (unsigned)(T - 1)), dim3(256), 0, side, (const bf16x4*)s->sv.HsF, s->HT16,
                            (int64_t)s->sv.NU, (int64_t)s->sv.step_recs, N, Np, (int64_t)T * Np, H);
         HIP_TRY(hipGetLastError());
       } else if (T > 1) transpose_steps(strm, hs, s->HT16, T, N, Np, H);                                         // h^T  [H][T][Np]
+    }
+    if (overlap) {
+      HIP_TRY(hipEventRecord(s->ev_operands, side));
+      // dx first: the table gradients (side stream) then run beside the two dW products
+      {
+        ProfScope ps(h, "gemm_i2g_bwd_dx");   // dx [T N][Din] = dA W_i2g
+        if (!(dx_t && gemm16xt(strm, s->dAT16, TNp, wt, G4, w.dIn, Din, TNp, Din, G4, Np, N)))
+          gemm16(strm, s->dA16, G4, wt, G4, w.dIn, Din, TN, Din, G4, false, nullptr, 1);
+      }
+      HIP_TRY(hipEventRecord(s->ev_dx, strm));
+      HIP_TRY(hipStreamWaitEvent(side, s->ev_dx, 0));
+      HIP_TRY(hipStreamWaitEvent(strm, s->ev_operands, 0));
     }
     const int split = (int)std::min<int64_t>(1024, std::max<int64_t>(1, TN / 4096));
     {
@@ -1391,20 +1426,25 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       hipLaunchKernelGGL(k_rowsum16, dim3((unsigned)G4), dim3(256), 0, strm, s->dAT16, TNp, gd + h->layer[l].bi);
       HIP_TRY(hipGetLastError());
     }
-    {
+    if (!overlap) {
       ProfScope ps(h, "gemm_i2g_bwd_dx");   // dx [T N][Din] = dA W_i2g
       if (!(dx_t && gemm16xt(strm, s->dAT16, TNp, wt, G4, w.dIn, Din, TNp, Din, G4, Np, N)))
         gemm16(strm, s->dA16, G4, wt, G4, w.dIn, Din, TN, Din, G4, false, nullptr, 1);
     }
   }
+  // (with the side stream these were queued behind ev_dx, i.e. they run beside the dW products issued above)
   {
-    ProfScope ps(h, "embed_scatter");
+    ProfScope ps(h, "embed_scatter", side);
     const bool have_index = b->key_sorted != nullptr && !b->tile_k;
-    kk::embed_scatter(strm, b->idx, N, T, b->F, c.num_types, w.dIn, c.dt, c.de, c.dr, c.Vt, c.Vr, gd + h->off_Wt, h->g_We, gd + h->off_Wr, have_index);
+    kk::embed_scatter(side, b->idx, N, T, b->F, c.num_types, w.dIn, c.dt, c.de, c.dr, c.Vt, c.Vr, gd + h->off_Wt, h->g_We, gd + h->off_Wr, have_index);
   }
   if (b->key_sorted != nullptr && !b->tile_k) {
-    ProfScope ps(h, "entity_grad");
-    bidx::entity_grad(strm, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, b->n_index, N, T, D, c.dt, c.de, c.Ve, h->g_We);
+    ProfScope ps(h, "entity_grad", side);
+    bidx::entity_grad(side, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, b->n_index, N, T, D, c.dt, c.de, c.Ve, h->g_We);
+  }
+  if (overlap) {
+    HIP_TRY(hipEventRecord(s->ev_join, side));
+    HIP_TRY(hipStreamWaitEvent(strm, s->ev_join, 0));
   }
 }
 
