@@ -1231,6 +1231,89 @@ static void ensure_buffers(kprn_handle* h, int64_t N, int T) {
   s->cap_N = cn; s->cap_T = ct;
 }
 
+// nn.Linear(H, C) on the last step's h for the bf16 pipeline (OneModel.lua:275): S[n][c] = sum_k bf16(h_T[n][k]) bf16(W_out[c][k]) + b[c], fp32 accumulation --
+// the arithmetic the generic product did for this call (fp32 operands rounded to bf16 as fragments are formed), as its own launch: that product
+// spent 0.082 ms per call on configs[3] (twice per step: 100 MB of h_T through 64 x 64 tiles of 4-byte loads); this is one pass over h_T.
+// A wave owns 16 paths x all classes (NT column tiles of v_mfma_f32_16x16x32_bf16); a lane reads 64 contiguous bytes of its path's row per 64-k block
+// -- the MFMA's k index is permuted to make that so (k = 64 j + 16 kg + 8 i + q), and the weights sit in LDS in the same permuted fragment order.
+template <int NT>
+__global__ __launch_bounds__(256) void k_head_fwd16(const float* __restrict__ hT, const bf16* __restrict__ W16, const float* __restrict__ bias, float* __restrict__ S,
+                                                    int64_t N, int H, int C) {
+  extern __shared__ __attribute__((aligned(16))) bf16x8 wf[];   // [H / 64][2][NT][64 lanes]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nj = H >> 6;
+  for (int e = threadIdx.x; e < nj * 2 * NT * 64; e += 256) {
+    const int l = e & 63, nt = (e >> 6) % NT, ji = (e >> 6) / NT;
+    const int cls = nt * 16 + (l & 15);
+    bf16x8 v;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (bf16)0.f;
+    if (cls < C) v = *(const bf16x8*)(W16 + (int64_t)cls * H + 64 * (ji >> 1) + 16 * (l >> 4) + 8 * (ji & 1));
+    wf[e] = v;
+  }
+  float bj[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { const int col = nt * 16 + (lane & 15); bj[nt] = bias[col < C ? col : C - 1]; }
+  __syncthreads();
+  for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk * 16 < N; blk += (int64_t)gridDim.x * 4) {
+    const int64_t row = blk * 16 + (lane & 15);
+    const float* src = hT + (row < N ? row : N - 1) * H + 16 * (lane >> 4);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // two register sets in turn: the next 64-k block's 16 floats of the row are requested before this block's are used (no copies: a
+    // register move would wait for the load it moves)
+    f32x4 x[4], y[4];
+    auto fetch = [&](f32x4 (&v)[4], int j) {
+      const int jc = j < nj ? j : nj - 1;   // (past the end: the last block again -- the loads stay unconditional)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = *(const f32x4*)(src + 64 * jc + 4 * q);
+    };
+    auto block = [&](const f32x4 (&v)[4], int j) {
+      bf16x8 a0, a1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a0[q] = tobf(v[0][q]); a0[4 + q] = tobf(v[1][q]); a1[q] = tobf(v[2][q]); a1[4 + q] = tobf(v[3][q]); }
+      const bf16x8* w0 = wf + (size_t)(j * 2) * NT * 64 + lane;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w0[nt * 64], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w0[(NT + nt) * 64], acc[nt], 0, 0, 0);
+      }
+    };
+    fetch(x, 0);
+    for (int j = 0; j < nj; j += 2) {
+      fetch(y, j + 1);
+      block(x, j);
+      fetch(x, j + 2);
+      if (j + 1 < nj) block(y, j + 1);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = nt * 16 + (lane & 15);
+      if (col >= C) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t ro = blk * 16 + 4 * (lane >> 4) + r;   // D: lane (col, rg) register r <-> row 4 rg + r
+        if (ro < N) S[ro * C + col] = acc[nt][r] + bj[nt];
+      }
+    }
+  }
+}
+// false: a shape this launch does not take (the caller falls back to the generic product).  KPRN_BF16_HEAD=0: always false (A/B)
+static bool head_fwd16(hipStream_t s, const float* hT, const bf16* W16, const float* bias, float* S, int64_t N, int H, int C) {
+  static const bool off = getenv("KPRN_BF16_HEAD") && getenv("KPRN_BF16_HEAD")[0] == '0';
+  const int NT = (C + 15) / 16;
+  const size_t lds = (size_t)(H >> 6) * 2 * NT * 64 * sizeof(bf16x8);
+  if (off || N <= 0 || (H & 63) || C < 1 || NT > 4 || lds > 64 * 1024 || ((uintptr_t)W16 & 15) || ((uintptr_t)hT & 15)) return false;
+  const dim3 grid((unsigned)std::min<int64_t>((N + 63) / 64, 4 * 256));
+  if (NT == 1) hipLaunchKernelGGL((k_head_fwd16<1>), grid, dim3(256), lds, s, hT, W16, bias, S, N, H, C);
+  else if (NT == 2) hipLaunchKernelGGL((k_head_fwd16<2>), grid, dim3(256), lds, s, hT, W16, bias, S, N, H, C);
+  else if (NT == 3) hipLaunchKernelGGL((k_head_fwd16<3>), grid, dim3(256), lds, s, hT, W16, bias, S, N, H, C);
+  else hipLaunchKernelGGL((k_head_fwd16<4>), grid, dim3(256), lds, s, hT, W16, bias, S, N, H, C);
+  HIP_TRY(hipGetLastError());
+  return true;
+}
+
 // forward of the whole stack; the head runs on the fp32 h_T of the top layer (written by its last step) through the generic bf16-product GEMM
 void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   const kprn_config& c = h->cfg;
@@ -1285,7 +1368,8 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save) {
   {
     ProfScope ps(h, "gemm_head_fwd");
     const float* hT = w.Hs + ((int64_t)(L - 1) * T + (T - 1)) * N * H;
-    gemm::run(strm, hT, H, 1, h->dense + h->off_outW, 1, H, w.S, c.C, N, c.C, H, false, h->dense + h->off_outb, 1, true);
+    if (!head_fwd16(strm, hT, s->dense16 + h->off_outW, h->dense + h->off_outb, w.S, N, H, c.C))
+      gemm::run(strm, hT, H, 1, h->dense + h->off_outW, 1, H, w.S, c.C, N, c.C, H, false, h->dense + h->off_outb, 1, true);
   }
 }
 
