@@ -510,6 +510,45 @@ __global__ void k_head_bwd(const float* __restrict__ dS, const float* __restrict
   }
 }
 
+// The same for H <= 512 in one pass at memory speed: a workgroup takes rows_per_block rows, its four waves every fourth row of them, a lane the
+// columns lane + 64 g; the waves' sums meet in LDS and leave as H atomics per workgroup.  (k_head_bwd above: 64 rows per workgroup = 1 024 atomics
+// on each of the H addresses of the selected row at 65 536 paths -- same-address atomics serialise in L2 -- and one load in flight per thread:
+// 0.08-0.09 ms for 100 MB on configs[3] / the shipped shape.)  Loads are unconditional (idle lanes re-read column H - 1 and drop the sum).
+template <int NG, bool HAS_DH>
+__global__ __launch_bounds__(256) void k_head_bwd_w(const float* __restrict__ dS, const float* __restrict__ hT, const float* __restrict__ Wout, int64_t N, int H,
+                                                    int cid, float* __restrict__ dH, float* __restrict__ gWout, float* __restrict__ gbout, int rows_per_block) {
+  __shared__ float red[4][NG * 64 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+  float acc[NG], w[NG];
+  int jc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int j = g * 64 + lane;
+    jc[g] = j < H ? j : H - 1;
+    acc[g] = 0.f;
+    w[g] = Wout[(int64_t)cid * H + jc[g]];
+  }
+  float bsum = 0.f;
+#pragma unroll 4
+  for (int64_t n = r0 + wave; n < r1; n += 4) {
+    const float d = dS[n];
+    bsum += d;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      acc[g] += d * hT[n * H + jc[g]];
+      if (HAS_DH && g * 64 + lane < H) dH[n * H + g * 64 + lane] = d * w[g];
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) red[wave][g * 64 + lane] = acc[g];
+  if (lane == 0) red[wave][NG * 64] = bsum;
+  __syncthreads();
+  for (int j = threadIdx.x; j < H; j += 256) unsafeAtomicAdd(gWout + (int64_t)cid * H + j, red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+  if (threadIdx.x == 0) unsafeAtomicAdd(gbout + cid, red[0][NG * 64] + red[1][NG * 64] + red[2][NG * 64] + red[3][NG * 64]);
+}
+
 // ---------------------------------------------------------------------------------------
 // nn.LookupTable backward = scatter-add (duplicates accumulate).  The two tiny tables (types,
 // relations) are reduced in LDS per block first; entity rows go straight to L2 atomics.
@@ -989,6 +1028,21 @@ void sum_partials(hipStream_t s, const float* partial, int n, float* out, int ac
 
 void head_bwd(hipStream_t s, const float* dS, const float* hT, const float* Wout, int64_t N, int H, int cid, float* dH, float* gWout, float* gbout) {
   if (N <= 0) return;
+  if (H <= 512 && N >= 4096) {   // the wave-per-row form (below that the 64-row workgroups of the plain kernel fill more of the chip)
+    const int rpb = 256;
+    const dim3 grid((unsigned)((N + rpb - 1) / rpb));
+    const int ng = (H + 63) / 64;
+#define KPRN_HB(NG)                                                                                                                        \
+    do {                                                                                                                                   \
+      if (dH) hipLaunchKernelGGL((k_head_bwd_w<NG, true>), grid, dim3(256), 0, s, dS, hT, Wout, N, H, cid, dH, gWout, gbout, rpb);        \
+      else hipLaunchKernelGGL((k_head_bwd_w<NG, false>), grid, dim3(256), 0, s, dS, hT, Wout, N, H, cid, dH, gWout, gbout, rpb);          \
+    } while (0)
+    if (ng <= 1) KPRN_HB(1); else if (ng == 2) KPRN_HB(2); else if (ng == 3) KPRN_HB(3); else if (ng == 4) KPRN_HB(4);
+    else if (ng <= 6) KPRN_HB(6); else KPRN_HB(8);
+#undef KPRN_HB
+    CHECK_LAUNCH();
+    return;
+  }
   const int rpb = 64;
   hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((N + rpb - 1) / rpb)), dim3(H >= 256 ? 256 : (H > 64 ? 128 : 64)), 0, s, dS, hT, Wout, N, H, cid,
                      dH, gWout, gbout, rpb);
