@@ -165,7 +165,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    float oldv[2][4];   // accumulate mode: the 8 old values of this row block, requested together (clamped addresses) before the first is used
+    if (accumulate && !use_atomic) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = n_base + wn * 32 + j * 16 + (lane & 15);
+          const int64_t row = m_base + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+          oldv[j][r] = C[(row < M ? row : M - 1) * ldc + (col < N ? col : N - 1)];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n_base + wn * 32 + j * 16 + (lane & 15);
@@ -179,12 +190,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         if (use_atomic) {
           unsafeAtomicAdd(dst, v);
         } else if (accumulate) {
-          *dst += v;
+          *dst = oldv[j][r] + v;
         } else {
           *dst = bias ? v + bj[j] : v;
         }
       }
     }
+  }
 }
 
 
@@ -303,7 +315,18 @@ __global__ __launch_bounds__(256) void gemm_kernel_big(const float* __restrict__
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
+    float oldv[4][4];
+    if (accumulate && !use_atomic) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = n_base + wn * 64 + j * 16 + (lane & 15);
+          const int64_t row = m_base + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+          oldv[j][r] = C[(row < M ? row : M - 1) * ldc + (col < N ? col : N - 1)];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = n_base + wn * 64 + j * 16 + (lane & 15);
@@ -315,10 +338,11 @@ __global__ __launch_bounds__(256) void gemm_kernel_big(const float* __restrict__
         float v = acc[i][j][r];
         float* dst = C + row * ldc + col;
         if (use_atomic) unsafeAtomicAdd(dst, v);
-        else if (accumulate) *dst += v;
+        else if (accumulate) *dst = oldv[j][r] + v;
         else *dst = bias ? v + bj[j] : v;
       }
     }
+  }
 }
 
 }  // namespace

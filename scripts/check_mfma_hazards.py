@@ -58,6 +58,33 @@ def kernel_resources(text):
     return out
 
 
+
+def serialized_loads(text, kernel_regex):
+    """{kernel symbol: (vector memory loads, loads that are waited for with vmcnt(0) before the next load is issued)} for the kernels whose symbol
+    matches.  hipcc turns `in_range ? p[i] : 0` (or a select right behind an unconditional load) into a branch with the load AND its wait inside:
+    a loop of such loads is a chain of dependent round trips.  A load counts as serialized when, walking forward over at most
+    8 instructions, an `s_waitcnt vmcnt(0)` comes before any other load."""
+    out = {}
+    for km in re.finditer(r"\n(_Z\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S):   # (to the function's end: a kernel with early returns has several s_endpgm)
+        if not re.search(kernel_regex, km.group(1)):
+            continue
+        ins = [l.split(";")[0].strip() for l in km.group(2).split("\n")]
+        ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
+        is_load = lambda l: re.match(r"(global_load|buffer_load)", l) and "lds" not in l
+        loads = serial = 0
+        for i, l in enumerate(ins):
+            if not is_load(l):
+                continue
+            loads += 1
+            for nxt in ins[i + 1:i + 9]:
+                if is_load(nxt):
+                    break
+                if nxt.startswith("s_waitcnt") and "vmcnt(0)" in nxt:
+                    serial += 1
+                    break
+        out[km.group(1)] = (loads, serial)
+    return out
+
 def check(path):
     text = compile_isa(path)
     return check_text(text, os.path.basename(path))

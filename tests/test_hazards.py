@@ -97,3 +97,24 @@ def test_persistent_bptt_kernel_keeps_its_state_in_registers():
     waits = [l for l in ins[mf[0]:mf[-1]] if l.startswith("s_waitcnt") and "vmcnt" in l]
     drained = [l for l in waits if "vmcnt(0)" in l]
     assert len(drained) <= 4, drained[:5]   # (the first builds: a vmcnt(0) in front of most of the 576 MFMAs)
+
+
+def test_operand_loads_are_not_a_chain_of_round_trips():
+    """The conditional-load rule: in the kernels it was found in, a load is no longer followed by its own vmcnt(0).
+    (The last load of a batch always is: the bars are counts, not zero.)"""
+    isa = chk.compile_isa(os.path.join(CSRC, "gemm_f32.hip"))
+    res = chk.serialized_loads(isa, r"gemm_kernel")
+    assert len(res) == 16
+    for k, (loads, serial) in res.items():
+        # prologue + main loop: 16 operand loads each, in flight together; the accumulate epilogue's old values: 8 / 16 per row block, together
+        assert loads >= 50 and serial <= 4, (k, loads, serial)
+    isa = chk.compile_isa(os.path.join(CSRC, "batch_index.hip"))
+    res = chk.serialized_loads(isa, r"k_entity_grad")
+    assert len(res) == 3
+    for k, (loads, serial) in res.items():
+        assert loads >= 64 and serial <= 8, (k, loads, serial)   # 2 x 32 gathers in flight; the index reads and the passenger jobs' tails remain
+    isa = chk.compile_isa(os.path.join(CSRC, "kernels_basic.hip"))
+    res = chk.serialized_loads(isa, r"k_table_grad_mfma")
+    assert res
+    for k, (loads, serial) in res.items():
+        assert serial <= 4, (k, loads, serial)
