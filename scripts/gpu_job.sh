@@ -32,7 +32,7 @@ PY
        ;;
     py) env "${envs[@]}" timeout 1500 python "$@" > "$out.log" 2>&1; tail -${TAILN:-30} "$out.log" ;;
     prof) cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/prof_$name
-       env "${envs[@]}" timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o p -- python "$REPO/bench.py" $QUICK "$@" > "$REPO/$out.log" 2>&1
+       env "${envs[@]}" timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o p --output-format csv -- python "$REPO/bench.py" $QUICK "$@" > "$REPO/$out.log" 2>&1
        f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$REPO/$out.kernel_stats.csv" && head -12 "$f"
        cd "$REPO" ;;
     *) echo "unknown step kind $kind" ;;
