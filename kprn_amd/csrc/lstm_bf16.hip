@@ -1236,20 +1236,33 @@ static void ensure_buffers(kprn_handle* h, int64_t N, int T) {
 // spent 0.082 ms per call on configs[3] (twice per step: 100 MB of h_T through 64 x 64 tiles of 4-byte loads); this is one pass over h_T.
 // A wave owns 16 paths x all classes (NT column tiles of v_mfma_f32_16x16x32_bf16); a lane reads 64 contiguous bytes of its path's row per 64-k block
 // -- the MFMA's k index is permuted to make that so (k = 64 j + 16 kg + 8 i + q), and the weights sit in LDS in the same permuted fragment order.
-template <int NT>
-__global__ __launch_bounds__(256) void k_head_fwd16(const float* __restrict__ hT, const bf16* __restrict__ W16, const float* __restrict__ bias, float* __restrict__ S,
-                                                    int64_t N, int H, int C) {
-  extern __shared__ __attribute__((aligned(16))) bf16x8 wf[];   // [H / 64][2][NT][64 lanes]
+// The launch is a handful of round trips (weight fragments, then per block of 16 paths the row and the stores), so the fragment fill and a block's
+// row are each requested in one go (first build: 9 + 6 dependent round trips, 0.039 ms).
+template <int NT, int NJ>   // NT: 16-class column tiles; NJ = H / 64
+__global__ __launch_bounds__(256) void k_head_fwd16(const float* __restrict__ hT, const bf16* __restrict__ W16, const float* __restrict__ bias,
+                                                       float* __restrict__ S, int64_t N, int C) {
+  constexpr int H = 64 * NJ, E = NJ * 2 * NT * 64, PE = (E + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) bf16x8 wf[];   // [NJ][2][NT][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nj = H >> 6;
-  for (int e = threadIdx.x; e < nj * 2 * NT * 64; e += 256) {
-    const int l = e & 63, nt = (e >> 6) % NT, ji = (e >> 6) / NT;
-    const int cls = nt * 16 + (l & 15);
-    bf16x8 v;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  {
+    // the weight fragments: all of a thread's pieces requested together, from clamped addresses; rows past C are zeroed by a mask the optimiser
+    // cannot see through (a select here would put each load and its wait inside a branch: PE dependent round trips before the first row is read)
+    u32x4 v[PE];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = (bf16)0.f;
-    if (cls < C) v = *(const bf16x8*)(W16 + (int64_t)cls * H + 64 * (ji >> 1) + 16 * (l >> 4) + 8 * (ji & 1));
-    wf[e] = v;
+    for (int i = 0; i < PE; ++i) {
+      const int e0 = threadIdx.x + 256 * i, e = e0 < E ? e0 : E - 1;
+      const int l = e & 63, nt = (e >> 6) % NT, ji = (e >> 6) / NT;
+      const int cls = nt * 16 + (l & 15);
+      v[i] = *(const u32x4*)(W16 + (int64_t)(cls < C ? cls : C - 1) * H + 64 * (ji >> 1) + 16 * (l >> 4) + 8 * (ji & 1));
+    }
+#pragma unroll
+    for (int i = 0; i < PE; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      unsigned m = ((e >> 6) % NT) * 16 + (e & 15) < C ? 0xffffffffu : 0u;
+      asm("" : "+v"(m));
+      if (E % 256 == 0 || e < E) *(u32x4*)(wf + e) = v[i] & m;
+    }
   }
   float bj[NT];
 #pragma unroll
@@ -1258,34 +1271,27 @@ __global__ __launch_bounds__(256) void k_head_fwd16(const float* __restrict__ hT
   for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk * 16 < N; blk += (int64_t)gridDim.x * 4) {
     const int64_t row = blk * 16 + (lane & 15);
     const float* src = hT + (row < N ? row : N - 1) * H + 16 * (lane >> 4);
+    asm volatile("" ::: "memory");   // (keeps the weight fragments in LDS: hoisted out of this loop they take 48 NT registers and the row loads get serialized)
+    f32x4 x[NJ][4];   // this lane's share of its path's row, requested at once: one round trip per 16 paths
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[j][q] = *(const f32x4*)(src + 64 * j + 4 * q);
+    __builtin_amdgcn_sched_barrier(0);   // all 4 NJ requests are issued before the first is used (left alone, hipcc sinks each load down to its MFMA)
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // two register sets in turn: the next 64-k block's 16 floats of the row are requested before this block's are used (no copies: a
-    // register move would wait for the load it moves)
-    f32x4 x[4], y[4];
-    auto fetch = [&](f32x4 (&v)[4], int j) {
-      const int jc = j < nj ? j : nj - 1;   // (past the end: the last block again -- the loads stay unconditional)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = *(const f32x4*)(src + 64 * jc + 4 * q);
-    };
-    auto block = [&](const f32x4 (&v)[4], int j) {
+    for (int j = 0; j < NJ; ++j) {
       bf16x8 a0, a1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { a0[q] = tobf(v[0][q]); a0[4 + q] = tobf(v[1][q]); a1[q] = tobf(v[2][q]); a1[4 + q] = tobf(v[3][q]); }
+      for (int q = 0; q < 4; ++q) { a0[q] = tobf(x[j][0][q]); a0[4 + q] = tobf(x[j][1][q]); a1[q] = tobf(x[j][2][q]); a1[4 + q] = tobf(x[j][3][q]); }
       const bf16x8* w0 = wf + (size_t)(j * 2) * NT * 64 + lane;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w0[nt * 64], acc[nt], 0, 0, 0);
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w0[(NT + nt) * 64], acc[nt], 0, 0, 0);
       }
-    };
-    fetch(x, 0);
-    for (int j = 0; j < nj; j += 2) {
-      fetch(y, j + 1);
-      block(x, j);
-      fetch(x, j + 2);
-      if (j + 1 < nj) block(y, j + 1);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1302,14 +1308,15 @@ __global__ __launch_bounds__(256) void k_head_fwd16(const float* __restrict__ hT
 // false: a shape this launch does not take (the caller falls back to the generic product).  KPRN_BF16_HEAD=0: always false (A/B)
 static bool head_fwd16(hipStream_t s, const float* hT, const bf16* W16, const float* bias, float* S, int64_t N, int H, int C) {
   static const bool off = getenv("KPRN_BF16_HEAD") && getenv("KPRN_BF16_HEAD")[0] == '0';
-  const int NT = (C + 15) / 16;
-  const size_t lds = (size_t)(H >> 6) * 2 * NT * 64 * sizeof(bf16x8);
-  if (off || N <= 0 || (H & 63) || C < 1 || NT > 4 || lds > 64 * 1024 || ((uintptr_t)W16 & 15) || ((uintptr_t)hT & 15)) return false;
-  const dim3 grid((unsigned)std::min<int64_t>((N + 63) / 64, 4 * 256));
-  if (NT == 1) hipLaunchKernelGGL((k_head_fwd16<1>), grid, dim3(256), lds, s, hT, W16, bias, S, N, H, C);
-  else if (NT == 2) hipLaunchKernelGGL((k_head_fwd16<2>), grid, dim3(256), lds, s, hT, W16, bias, S, N, H, C);
-  else if (NT == 3) hipLaunchKernelGGL((k_head_fwd16<3>), grid, dim3(256), lds, s, hT, W16, bias, S, N, H, C);
-  else hipLaunchKernelGGL((k_head_fwd16<4>), grid, dim3(256), lds, s, hT, W16, bias, S, N, H, C);
+  const int NT = (C + 15) / 16, NJ = H >> 6;
+  const size_t lds = (size_t)NJ * 2 * NT * 64 * sizeof(bf16x8);
+  if (off || N <= 0 || (H & 63) || C < 1 || NT > 4 || !(NJ == 2 || NJ == 3 || NJ == 4 || NJ == 6) || ((uintptr_t)W16 & 15) || ((uintptr_t)hT & 15)) return false;
+  const dim3 grid((unsigned)std::min<int64_t>((N + 63) / 64, 2 * 256));   // two workgroups per CU (<= 256 registers per lane), all resident: a wave walks its blocks
+#define KPRN_HF(NTv, NJv) hipLaunchKernelGGL((k_head_fwd16<NTv, NJv>), grid, dim3(256), lds, s, hT, W16, bias, S, N, C)
+#define KPRN_HF_NJ(NTv) do { if (NJ == 2) KPRN_HF(NTv, 2); else if (NJ == 3) KPRN_HF(NTv, 3); else if (NJ == 4) KPRN_HF(NTv, 4); else KPRN_HF(NTv, 6); } while (0)
+  if (NT == 1) KPRN_HF_NJ(1); else if (NT == 2) KPRN_HF_NJ(2); else if (NT == 3) KPRN_HF_NJ(3); else KPRN_HF_NJ(4);
+#undef KPRN_HF_NJ
+#undef KPRN_HF
   HIP_TRY(hipGetLastError());
   return true;
 }
