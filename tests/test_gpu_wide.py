@@ -107,6 +107,25 @@ def test_rnn_step_kernel(use_relu, L, dims):
     _check(eng, o64, theta, idx, labels, steps=3)
 
 
+@pytest.mark.parametrize("kind,dims,L,pairs,P", [("rnn", (50, 100, 50, 250), 1, 1400, 3), ("lstm", (64, 64, 64, 192), 2, 1100, 4)])
+def test_head_backward_wave_per_row_kernel_against_the_oracle(kind, dims, L, pairs, P):
+    """From 4 096 paths up the generic pipelines' head backward is kk::k_head_bwd_w (a wave per row, a lane per column group, dH written
+    in the same pass): run_scripts/config.sh's shape (H = 250: four column groups, the last one ragged) and reading B (H = 192: three),
+    scores, loss and every gradient against the float64 oracle (tests/test_head_layout.py replays the kernel's index algebra on the CPU)."""
+    dt, de, dr, H = dims
+    if kind == "rnn":
+        eng = _ffi.Engine(6, 700, 9, dt, de, dr, H, L, rnn_type=1, use_relu=1, param_init=0.05)
+        o64 = Oracle(make_cfg(Vt=6, Ve=700, Vr=9, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=1, use_relu=1), np.float64)
+        theta = o64.init_params(7, 0.05).astype(np.float32).astype(np.float64)
+        o64.zero_pad(theta)
+        eng.set_flat_params(theta.astype(np.float32))
+    else:
+        eng, o64, theta = _lstm(dt, de, dr, H, L)
+    idx, labels = synth.make_paths(pairs, P, 6, Ve=700, seed=pairs)
+    assert pairs * P >= 4096
+    _check(eng, o64, theta, idx, labels)
+
+
 def test_tiled_kernels_agree_with_the_round1_kernels_at_the_bench_size():
     """16 384 paths, D = H = 192, L = 2: same library with KPRN_NO_TILED_GEMM / KPRN_NO_STEP_KERNEL (plain GEMM + element-wise
     kernels per step) -- two GPU implementations of every GEMM of the step"""
