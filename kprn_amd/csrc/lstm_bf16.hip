@@ -1411,6 +1411,11 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     for (hipEvent_t* e : {&s->ev_fork, &s->ev_operands, &s->ev_dx, &s->ev_join}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
   hipStream_t side = overlap ? s->side : strm;
+  // an error thrown between the fork and the join below must not leave helpers running behind the caller's back: drain the side stream on the way out
+  struct SideGuard {
+    hipStream_t st; bool joined;
+    ~SideGuard() { if (st && !joined) (void)hipStreamSynchronize(st); }
+  } side_guard{overlap ? side : nullptr, false};
   if (overlap) {
     HIP_TRY(hipEventRecord(s->ev_fork, strm));
     HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
@@ -1536,6 +1541,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   if (overlap) {
     HIP_TRY(hipEventRecord(s->ev_join, side));
     HIP_TRY(hipStreamWaitEvent(strm, s->ev_join, 0));
+    side_guard.joined = true;
   }
 }
 
