@@ -102,6 +102,11 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
                     help="c2 (default): BASELINE configs[1], train + score at T = 6.  c5: configs[4] -- inference-only scoring of a path set with "
                          "variable path length <= 7, bucketed by identical T (3..7) as the reference pads per file, d = 64")
+    ap.add_argument("--set-option", action="append", default=[], metavar="KEY=VALUE", help="kprn_set_option(KEY, VALUE) on the engine before the first step (A/B runs), repeatable")
+    ap.add_argument("--uniform-tiles", action="store_true",
+                    help="every path has T real steps (no left padding -> no identical-prefix skipping) and the batch is a whole number of 256 x 64-path "
+                         "tiles: every workgroup of the fused kernels draws the same number of tile-steps.  The dominant kernel's roofline.frac on this "
+                         "line is the kernel's own ceiling, free of the 18-vs-20 tile-step quantisation of the 4 / 6-step mix (DESIGN.md section 7-1)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rank wiring / timing / JSON check without a GPU: gloo backend, the step is a placeholder (CPU tests)")
     return ap.parse_args()
@@ -141,6 +146,24 @@ def strong_steps(total_paths, world, steps):
     return max(1, min(steps, total_paths // (world * MIN_PATHS_PER_RANK_STEP)))
 
 
+def replica_digests(vectors, world, device="cpu"):
+    """Self-check of a data-parallel run: a 64-bit digest (blake2b) of each of this rank's `vectors` (numpy arrays), all-gathered over the
+    default process group -> (per-rank hex digests, all ranks identical?).  Replicas hold the same bits by construction (rank-ordered sums:
+    DESIGN.md section 4); a run whose replicas diverged exits with code 3."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    digs = [int.from_bytes(hashlib.blake2b(np.ascontiguousarray(v).tobytes(), digest_size=8).digest(), "little", signed=True) for v in vectors]
+    mine = torch.tensor(digs, dtype=torch.int64, device=device)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    allr = [[int(v) for v in t.cpu().tolist()] for t in allr]
+    return [[f"{v & 0xffffffffffffffff:016x}" for v in r] for r in allr], bool(all(r == allr[0] for r in allr))
+
+
 def dry_run(a):
     """No GPU, no engine: the ranks rendezvous over gloo, run K placeholder steps through the same barrier / max-over-ranks
     timing as the real run and rank 0 prints a JSON line marked dry_run.  Checks the launcher and the rank plumbing only."""
@@ -155,10 +178,12 @@ def dry_run(a):
     if a.total_paths:
         a.steps = strong_steps(a.total_paths, world, a.steps)
     pps = a.paths_per_step if not a.total_paths else max(64, a.total_paths // (world * max(1, a.steps)))
-    g = torch.ones(1024)
+    g = torch.ones(1024)   # the "replica": every rank applies the same all-reduced update
     def step():
+        upd = torch.full((1024,), 1.0 + rank)
         if world > 1:
-            dist.all_reduce(g.clone())
+            dist.all_reduce(upd)
+        g.add_(upd, alpha=1e-3)
         return pps
     for _ in range(a.warmup):
         step()
@@ -175,15 +200,21 @@ def dry_run(a):
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         el[0] = mx[0]
+    if os.environ.get("KPRN_DRYRUN_DIVERGE") == "1" and rank == world - 1:   # (tests: a replica that went its own way must fail the run)
+        g[7] += 1e-6
+    per_rank, same = replica_digests((g.numpy(),), world)
     if rank == 0:
         print(json.dumps({"metric": "paths/sec (train+score) at path_len=6 d=64", "value": None, "unit": "paths/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * float(el[0]) / max(1, a.steps), 4),
                           "higher_is_better": True, "scaling": "strong" if a.total_paths else "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "none (dry run: placeholder steps, launcher and rank wiring only)", "dry_run": True,
                           "ranks_reporting": int(tot[2]), "paths_counted": int(tot[1]),
+                          "dp": {"replica_digests": {"per_rank": per_rank}, "replicas_bit_identical": same},
                           "config": {"workload": "dry run", "paths_per_step_per_gpu": pps, "parallelism": f"dp{world}" if world > 1 else "single"}}))
     if world > 1:
         dist.destroy_process_group()
+    if not same:
+        sys.exit(3)
 
 
 PEAK_TFLOPS_BF16_MFMA = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
@@ -240,6 +271,8 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4, NT=None):
         "gemm_i2g_fwd": 2 * T * N * g * D, "gemm_o2g_fwd": 2 * N * g * H, "gemm_head_fwd": 2 * N * C * H,
         "gemm_o2g_bwd_dh": 2 * N * g * H, "gemm_o2g_bwd_dw": 2 * (T - 1) * N * g * H,
         "gemm_i2g_bwd_dw": 2 * T * N * g * D, "gemm_i2g_bwd_dx": 2 * T * N * g * D,
+        # configs[3], small tables (lstm_bf16.hip k_onehot_T): dx for the entity slice only; ONE dW product over [x_e^T | S^T (128 one-hot rows) | h^T]
+        "gemm_i2g_bwd_dx_e": 2 * T * N * g * de, "gemm_bwd_dw_merged": 2 * T * N * g * (de + 128 + H),
     }
     if name in tbl:
         return "mfma", tbl[name]
@@ -576,9 +609,12 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    requested_steps = a.steps
     if a.total_paths:
         a.steps = strong_steps(a.total_paths, world, a.steps)
         a.paths_per_step = max(64, a.total_paths // (world * max(1, a.steps)))
+    if a.uniform_tiles:
+        a.paths_per_step = max(256 * 64, (a.paths_per_step // (256 * 64)) * 256 * 64)
 
     from kprn_amd import _ffi, synth, dp
     dt_, de_, dr_, H = dims_of(a)
@@ -600,15 +636,19 @@ def main():
     eng.set_option("feed_build", a.feed_build)
     if a.feed_threads > 0:
         eng.set_option("feed_threads", str(a.feed_threads))
+    for kv in a.set_option:
+        k_, _, v_ = kv.partition("=")
+        eng.set_option(k_, v_)
     opt = _ffi.make_opt(method=1, lr=1e-3, entity_update=a.entity_update)
 
     # bucketed batches (constant P per batch, like the reference's train.txt.<P>.torch files)
-    Ps = [1, 2, 3, 4, 5, 8]
+    Ps = [1, 2, 4, 8] if a.uniform_tiles else [1, 2, 3, 4, 5, 8]   # (uniform tiles: P divides the batch, so every batch is exactly paths_per_step paths)
     host = []      # the path set in host memory (page-locked: what a loader hands the feed)
     batches = []   # ... and resident in HBM
     for i, P in enumerate(Ps):
         pairs = max(1, a.paths_per_step // P)
-        idx, labels = synth.make_paths(pairs, P, T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, num_types=nT, seed=12345 + 97 * i + 7919 * rank)
+        idx, labels = synth.make_paths(pairs, P, T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, num_types=nT, seed=12345 + 97 * i + 7919 * rank,
+                                       real_len=(T if a.uniform_tiles else None))
         hi, hl = eng.host_array(idx.shape, np.int32), eng.host_array(labels.shape, np.float32)
         hi[...] = idx
         hl[...] = labels
@@ -863,6 +903,13 @@ def main():
         else:
             allr = [mine]
         dp_info["per_rank_ms_per_step"] = [round(float(x.item()), 4) for x in allr]
+        # Replicas must hold the same bits after the timed steps: the rows are summed in rank order inside the row update and the dense arena in rank
+        # order inside the merge, so parameters AND Adam state are bit-identical by construction.  A 64-bit digest of the flat
+        # parameter vector and of both Adam moments from every rank; any difference fails the run (exit code 3 below).
+        eng.sync()
+        per_rank, same = replica_digests((eng.get_flat_params(), eng.get_flat_opt_state(0), eng.get_flat_opt_state(1)), world, dev)
+        dp_info["replica_digests"] = {"what": "blake2b-64 of (flat parameters, Adam m, Adam v) per rank", "per_rank": per_rank}
+        dp_info["replicas_bit_identical"] = same
         dp_info["exchange"] = ("engine: in-place RCCL all-gather on the engine's stream, union inside the row update" if dpx.native else
                                "torch.distributed collectives around the pack / merge hooks" + ("" if a.dp_unfused else ", union inside the row update"))
         dp_info["scoring_pass"] = ("first, beside the training forward" if dp_score_first else
@@ -1006,6 +1053,8 @@ def main():
                        "score_overlap": not a.no_score_overlap,
                        "batch_feed": "streaming" if main_streaming else "resident",
                        "total_paths": a.total_paths or None,
+                       "requested_steps": requested_steps, "paths_per_rank_step": a.paths_per_step,   # (--total-paths lowers the step count: strong_steps())
+                       "uniform_tiles": bool(a.uniform_tiles), "set_options": a.set_option or None,
                        "forward_arithmetic": {0: "fp32 MFMA", 1: "bf16 MFMA products, fp32 accumulate",
                                               2: "f32x6: fp32 operands split exactly into 3 bf16 pieces, 6 partial products on the matrix cores, fp32 accumulate",
                                               3: "f32x3: pre-scaled fp32 operands as 2 fp16 pieces, 3 partial products on the matrix cores, fp32 accumulate"}[a.compute_dtype],
@@ -1023,13 +1072,17 @@ def main():
             "value_no_prefix_plan": (extras.get("no_prefix_plan") or {}).get("value"), "no_prefix_plan": extras.get("no_prefix_plan"),
             "dp": dp_info, "alt_f32x6": alt, "kernels": kernels,
         }
+    # a data-parallel run whose replicas diverged is not a measurement: the line is still printed (it says which rank differs), the exit code is 3
+    diverged = bool(dp_info is not None and not dp_info.get("replicas_bit_identical", True))
     if world > 1 or a.force_dp:
         dist.destroy_process_group()
     if rank == 0:
-        emit_last(out, hard_exit=(world > 1 or a.force_dp))
+        emit_last(out, hard_exit=(world > 1 or a.force_dp), rc=3 if diverged else 0)
+    elif diverged:
+        sys.exit(3)
 
 
-def emit_last(out, hard_exit=False):
+def emit_last(out, hard_exit=False, rc=0):
     """The JSON line is the LAST thing on stdout.  RCCL prints a version banner through C stdio, which a pipe buffers until the process
     exits -- after Python's own buffer, i.e. behind the line: flush C stdio first, print, and (runs that initialised RCCL only) leave without
     running exit handlers.  Other runs exit normally: rocprofv3 writes its tables from an exit handler."""
@@ -1042,7 +1095,9 @@ def emit_last(out, hard_exit=False):
     sys.stdout.flush()
     sys.stderr.flush()
     if hard_exit and os.environ.get("KPRN_BENCH_SOFT_EXIT") != "1":   # (a profiler wants its exit handler: scripts/gpu_timeline.sh)
-        os._exit(0)
+        os._exit(rc)
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -292,7 +292,7 @@ void entity_grad(hipStream_t s, const float* DX, int frag_order, const int32_t* 
   int n_red = 0, n_sg = 0;
   if (red) { r = *red; n_red = ((r.n_elem + 255) / 256) * r.ny * r.L; }
   if (sg) { g = *sg; n_sg = g.nblocks; }
-  static const int dbg = getenv("KPRN_EGRAD_DBG") ? atoi(getenv("KPRN_EGRAD_DBG")) : 0;   // (measurement: 1 no atomics, 2 no passenger work; 16 x workgroup order)
+  static const int dbg = KPRN_DEV_ENV("KPRN_EGRAD_DBG") ? atoi(KPRN_DEV_ENV("KPRN_EGRAD_DBG")) : 0;   // (measurement: 1 no atomics, 2 no passenger work; 16 x workgroup order)
   const dim3 grid((unsigned)(n_ent + n_red + n_sg));
   if (frag_order == 1) hipLaunchKernelGGL(k_entity_grad<1>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g, dbg);
   else if (frag_order == 2) hipLaunchKernelGGL(k_entity_grad<2>, grid, dim3(256), 0, s, DX, key_sorted, pos_sorted, n_index, N, T, D, dt, de, Ve, gWe, n_ent, n_red, r, g, dbg);

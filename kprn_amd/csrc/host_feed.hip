@@ -231,7 +231,7 @@ void build(const Shape& g, const int32_t* idx, int kcap, int nth, bool want_inde
   const int B = g.B, P = g.P, T = g.T, F = g.F, nT = g.nT;
   const int64_t N = (int64_t)B * P, nsteps = N * T;
   const int c0 = F - nT - 2;
-  static const bool timing = getenv("KPRN_FEED_TIMING") != nullptr;
+  static const bool timing = KPRN_DEV_ENV("KPRN_FEED_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto tlast = now();
   const auto t_begin = tlast;

@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_table_grad_mfma(const int32_t* __restri
 static bool table_grad_mfma(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int idcol, int slots, const float* dX, int D, int col0, int dcols,
                             int V, float* gW) {
   if (dcols <= 0 || dcols > 128 || V <= 0 || V > 128) return false;
-  static const int ppb_env = getenv("KPRN_TABLE_GRAD_PPB") ? atoi(getenv("KPRN_TABLE_GRAD_PPB")) : 0;   // (measurement)
+  static const int ppb_env = KPRN_DEV_ENV("KPRN_TABLE_GRAD_PPB") ? atoi(KPRN_DEV_ENV("KPRN_TABLE_GRAD_PPB")) : 0;   // (measurement)
   const int ppb = ppb_env > 0 ? ppb_env : 512;   // (round 4, after the loads went unconditional: 512 beats 256 on configs[3] 0.175 : 0.198 ms, shipped 0.147 : 0.198, D = 192
                                                  //  0.106 : 0.113 -- half the workgroups = half the epilogue atomics on the same table rows; 1 024 loses parallelism: 0.253)
   const int64_t total = N * T;
@@ -1268,9 +1268,9 @@ static bool table_grad_lds(hipStream_t s, const int32_t* idx, int64_t N, int T, 
   const int64_t total = N * T;
   int ppb = 512;   // (128 .. 512 measure alike; 1 024 and up lose parallelism)
   while (ppb < 8192 && (int64_t)V * dcols * 8 > (int64_t)ppb * dcols) ppb *= 2;
-  static const int ppb_env = getenv("KPRN_TABLE_GRAD_PPB") ? atoi(getenv("KPRN_TABLE_GRAD_PPB")) : 0;   // (measurement)
+  static const int ppb_env = KPRN_DEV_ENV("KPRN_TABLE_GRAD_PPB") ? atoi(KPRN_DEV_ENV("KPRN_TABLE_GRAD_PPB")) : 0;   // (measurement)
   if (ppb_env > 0) ppb = ppb_env;
-  static const int dbg_env = getenv("KPRN_TABLE_GRAD_DBG") ? atoi(getenv("KPRN_TABLE_GRAD_DBG")) : 0;   // (knock-outs: 1 no LDS adds, 2 no flush, 4 no id loads)
+  static const int dbg_env = KPRN_DEV_ENV("KPRN_TABLE_GRAD_DBG") ? atoi(KPRN_DEV_ENV("KPRN_TABLE_GRAD_DBG")) : 0;   // (knock-outs: 1 no LDS adds, 2 no flush, 4 no id loads)
   hipLaunchKernelGGL(k_table_grad_lds, dim3((unsigned)((total + ppb - 1) / ppb)), dim3(256), bytes, s, idx, N, T, F, idcol, slots, dX, D, col0, dcols, V, gW, ppb, dbg_env);
   return true;
 }
@@ -1281,11 +1281,11 @@ void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, i
   // tables that fit LDS (every type / relation table of the named configs): one wave per position, LDS accumulators (k_table_grad_lds);
   // KPRN_TABLE_GRAD=old keeps the 16-register one-hot kernel for tiny tables and the element-indexed scatter for the rest
   const int D_ = dt + de + dr;
-  static const bool old_path = getenv("KPRN_TABLE_GRAD") && strcmp(getenv("KPRN_TABLE_GRAD"), "old") == 0;
+  static const bool old_path = KPRN_DEV_ENV("KPRN_TABLE_GRAD") && strcmp(KPRN_DEV_ENV("KPRN_TABLE_GRAD"), "old") == 0;
   bool type_small = false, rel_small = false;   // (= handled here)
   // KPRN_TABLE_GRAD: mfma (default) = the one-hot product on the matrix cores for tables up to 128 x 128; lds = LDS accumulators above 16 rows
   // (0.54 ms on configs[3], 0.35 of it ds_add_f32) + the 16-register one-hot kernel below; old = that kernel + the element-indexed scatter
-  static const bool lds_path = getenv("KPRN_TABLE_GRAD") && strcmp(getenv("KPRN_TABLE_GRAD"), "lds") == 0;
+  static const bool lds_path = KPRN_DEV_ENV("KPRN_TABLE_GRAD") && strcmp(KPRN_DEV_ENV("KPRN_TABLE_GRAD"), "lds") == 0;
   if (!old_path && !lds_path) {
     if (dt > 0) type_small = table_grad_mfma(s, idx, N, T, F, F - nT - 2, nT, dX, D_, 0, dt, Vt, gWt);
     if (dr > 0) rel_small = table_grad_mfma(s, idx, N, T, F, F - 1, 1, dX, D_, dt + de, dr, Vr, gWr);

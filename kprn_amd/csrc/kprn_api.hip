@@ -1110,10 +1110,9 @@ static void batch_release(kprn_batch* b) {
 }
 
 static bool batch_wants_plan(kprn_handle* h, const kprn_batch* b) {
-  static const char* dbg_env = getenv("KPRN_DBG");
   // (small batches run on tiles of one 16-row m-tile, which have no per-tile prefix classes: lstm_fused_fwd.hip small_tiles)
   if (fused::small_tiles(h, (int64_t)b->B * b->P, false)) return false;
-  return h->prefix_plan && use_fused(h, b, true) && b->F <= 16 && !(dbg_env && (atoi(dbg_env) & 64));
+  return h->prefix_plan && use_fused(h, b, true) && b->F <= 16 && !(kprn_dbg_mask() & 64);
 }
 
 // buffers for a [B,P,T,F] batch; a refill that fits the slot's capacities allocates nothing.  quiesce(): called before any
@@ -1571,7 +1570,7 @@ __global__ void k_probe_wait(int* flag, int* seen, long long max_ticks) {
 __global__ void k_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 }  // extern "C"
-hipStream_t make_concurrent_stream(kprn_handle* h) {
+hipStream_t make_concurrent_stream(kprn_handle* h, int* probes) {
   const int kTries = 8;
   hipStream_t cand[kTries] = {};
   int32_t* d = dalloc<int32_t>(2);   // {flag, seen}
@@ -1597,7 +1596,7 @@ hipStream_t make_concurrent_stream(kprn_handle* h) {
     dfree(d);
     throw;
   }
-  h->side_stream_probes = made;
+  if (probes) *probes = made; else h->side_stream_probes = made;   // (default: the scoring stream's count, what kprn_get_stat reports)
   if (!pick) pick = cand[0];   // (every candidate shares the main stream's queue: correct anyway, just not concurrent)
   for (int i = 0; i < made; ++i) if (cand[i] && cand[i] != pick) hipStreamDestroy(cand[i]);
   dfree(d);
@@ -1671,7 +1670,13 @@ static void launch_score_rest(kprn_handle* h) {
   try {
     fused::forward(h, b, false, h->score_rest_tile0, -1);
     pool_stage(h, b, h->score_rest_cid - 1, false);
-  } catch (...) { h->stream = main_stream; w.S = S0; w.sel = sel0; throw; }
+  } catch (...) {
+    // the pass cannot finish: nobody may wait for it on a stale event, or hand out its half-filled S2 / sel2 as a finished pass
+    h->stream = main_stream; w.S = S0; w.sel = sel0;
+    h->score_pending = false; h->last_forward_side = false; h->last_B = 0;
+    (void)hipStreamSynchronize(h->score_stream);
+    throw;
+  }
   h->stream = main_stream; w.S = S0; w.sel = sel0;
   HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
 }
@@ -2244,8 +2249,14 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     h->prefix_plan = atoi(value) ? 1 : 0;  // batches created from now on (an existing batch keeps what it was built with)
   } else if (strcmp(key, "small_tiles") == 0) {
     // batches created / fed from now on: <= 8 192 paths on tiles of one 16-row m-tile and no identical-prefix plan ("1", default), or the
-    // 64-path tiles at every size ("0")
+    // 64-path tiles at every size ("0").  (A split scoring pass whose second part is still unplaced is finished first: the rest launch decides
+    // its tiling from this option.)
+    join_score(h);
     h->small_tiles_on = atoi(value) != 0;
+  } else if (strcmp(key, "bf16_small_tables") == 0) {
+    // bf16 pipeline, persistent BPTT: gradients of the type / relation tables (<= 128 rows together) and of their column blocks of W_i2g from one
+    // extra column block of the merged dW product ("1", default) or from the full dx product + the table-gradient launch ("0": the A/B reference)
+    h->bf16_small_tables = atoi(value) != 0;
   } else if (strcmp(key, "score_split") == 0) {
     // kprn_forward_batch_async queues only the first (1 - f) of the batch's tiles; kprn_forward_batch_async_rest the others + the pooling
     join_score(h);

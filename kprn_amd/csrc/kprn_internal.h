@@ -205,6 +205,7 @@ struct kprn_handle {
   kprn_batch* dropin_slot[4] = {nullptr, nullptr, nullptr, nullptr};   // feed slots of the host-buffer entry points (kprn_train_step: 0 / 1, kprn_forward: 2 / 3)
   int dropin_next_train = 0, dropin_next_score = 0, dropin_last = 0;
   bool score_pending = false;     // a pass is (possibly) still running on score_stream
+  bool bf16_small_tables = true;  // option "bf16_small_tables": configs[3] backward forms the type / relation gradients from G = dA^T [S_r | S_t] (lstm_bf16.hip)
   bool small_tiles_on = true;     // option "small_tiles": batches of <= 8 192 paths run on tiles of one 16-row m-tile (no identical-prefix plan)
   float score_split = 0.f;        // option: fraction of a scoring pass's tiles deferred to kprn_forward_batch_async_rest
   const kprn_batch* score_rest_batch = nullptr; int score_rest_cid = 1; int64_t score_rest_tile0 = 0;   // the deferred part of a split pass
@@ -230,7 +231,7 @@ struct ProfScope {
   ProfScope(kprn_handle* h_, const char* n, hipStream_t on = nullptr);
   ~ProfScope();
 };
-hipStream_t make_concurrent_stream(kprn_handle* h);   // a stream whose work runs BESIDE the main stream's (kprn_api.hip: probed, not assumed)
+hipStream_t make_concurrent_stream(kprn_handle* h, int* probes = nullptr);   // a stream whose work runs BESIDE the main stream's (kprn_api.hip: probed, not assumed)
 void prof_drain(kprn_handle* h);
 void join_score(kprn_handle* h);  // main stream waits for the scoring pass on the side stream, if any
 
@@ -435,6 +436,21 @@ void rows_updated(kprn_handle* h, const int32_t* rows, const int32_t* count, int
 void release(kprn_handle* h);
 float debug_gemm16(hipStream_t s, int64_t M, int N, int64_t K, int split_k, int iters);   // ms per launch (kprn_debug_gemm what 5 / 6)
 }  // namespace bf16p
+
+// ---- environment switches ---------------------------------------------------------------------------------
+// The shipped library reads a dozen environment variables, each set by a test that names it (README.md has the list).  Every other
+// A/B and knock-out switch of the measurement rounds exists only in the measurement build (scripts/build_variants.py compiles the
+// sources it lists with -DKPRN_PERSIST_VARIANTS): KPRN_DEV_ENV is nullptr in the shipped library, so those paths fold away.
+#ifdef KPRN_PERSIST_VARIANTS
+#define KPRN_DEV_ENV(name) getenv(name)
+#else
+#define KPRN_DEV_ENV(name) ((const char*)nullptr)
+#endif
+// KPRN_DBG: bit mask of cross-check modes the parity tests switch on (tests/test_gpu_parity.py: 64 = no identical-prefix plan, ...)
+inline int kprn_dbg_mask() {
+  static const int m = [] { const char* e = getenv("KPRN_DBG"); return e ? atoi(e) : 0; }();
+  return m;
+}
 
 // ---- host side of the streaming feed (host_feed.hip) -------------------------------------------------
 // Every device allocation goes through here.  KPRN_POISON_ALLOC=1 fills new memory with 0xFF bytes (NaN as float, -1 as int): nothing

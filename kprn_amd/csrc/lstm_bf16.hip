@@ -697,14 +697,14 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16y(XArgs a) {
 
 static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K, bool accumulate,
                     int split_k) {
-  static const bool off = getenv("KPRN_BF16_GEMM") && getenv("KPRN_BF16_GEMM")[0] == 'o';   // "old": k_gemm16 everywhere (A/B measurements, tests)
+  static const bool off = KPRN_DEV_ENV("KPRN_BF16_GEMM") && KPRN_DEV_ENV("KPRN_BF16_GEMM")[0] == 'o';   // "old": k_gemm16 everywhere (A/B measurements, tests)
   if (off || M < gx::BM || N < gx::BN || (K & 7) || (lda & 7) || (ldb & 7)) return false;
   gx::XArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero = zero16();
   // KPRN_BF16_GEMM=y: 256 x 192 tiles where they divide N (configs[3]: N = 384).  Measured equal to the 256 x 128 kernel on dx / dh (0.743 : 0.750,
   // 0.110 : 0.107 ms) and slower on the split-K dW (12 tiles deal worse over 8 XCDs than 18): opt-in, kept as the record of that measurement
-  static const bool want_y = getenv("KPRN_BF16_GEMM") && getenv("KPRN_BF16_GEMM")[0] == 'y';
+  static const bool want_y = KPRN_DEV_ENV("KPRN_BF16_GEMM") && KPRN_DEV_ENV("KPRN_BF16_GEMM")[0] == 'y';
   const bool y = want_y && (N % gx::YBN) == 0;
   const int bn = y ? gx::YBN : gx::BN, bk = y ? gx::YBK : gx::BK;
   a.mtiles = (M + gx::BM - 1) / gx::BM; a.ntiles = (N + bn - 1) / bn;
@@ -715,7 +715,7 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
     // rounds / s (configs[3]'s dW: 18 tiles -> s = 7: 126 workgroups = 3.94 rounds per XCD; the old "3 x 256 workgroups" rule gave 43
     // ranges = 6 on three XCDs, 4 rounds of 1 / 43: a quarter more time)
     const int64_t tiles = a.mtiles * a.ntiles;
-    static const int s_env = getenv("KPRN_GEMM16_SX") ? atoi(getenv("KPRN_GEMM16_SX")) : 0;   // (measurement)
+    static const int s_env = KPRN_DEV_ENV("KPRN_GEMM16_SX") ? atoi(KPRN_DEV_ENV("KPRN_GEMM16_SX")) : 0;   // (measurement)
     int best = 1;
     double best_t = 1e30;
     for (int sx = 1; sx <= 8 && sx * 8 <= std::max(split_k, 8); ++sx) {
@@ -750,9 +750,16 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
 }
 
 // C[(step, path)][N] (fp32) = sum_k AT[k][step Np + path] B[n][k]: the k-major A operand (gx::k_gemm16xt); false = shape not covered
+static bool dx_t_off() {   // KPRN_BF16_DX_T=0: dx from a row-major dA (tests/test_gpu_persist.py A/B)
+  static const bool off = [] { const char* e = getenv("KPRN_BF16_DX_T"); return e && e[0] == '0'; }();
+  return off;
+}
+// the ONE predicate of the k-major-A product: what gemm16xt takes is what dx_from_transposed_ok promises the BPTT launch
+static bool xt_shape_ok(int64_t Mp, int N, int64_t K, int64_t Np, int64_t ldat, int64_t ldb) {
+  return !dx_t_off() && Mp >= gx::BM && Mp < ((int64_t)1 << 32) && N >= gx::BN && !(K & 7) && !(ldat & 7) && !(ldb & 7) && !(Np & 7);
+}
 static bool gemm16xt(hipStream_t s, const bf16* AT, int64_t ldat, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t Mp, int N, int64_t K, int64_t Np, int64_t Nv) {
-  static const bool off = getenv("KPRN_BF16_DX_T") && getenv("KPRN_BF16_DX_T")[0] == '0';
-  if (off || Mp < gx::BM || Mp >= ((int64_t)1 << 32) || N < gx::BN || (K & 7) || (ldat & 7) || (ldb & 7) || (Np & 7)) return false;
+  if (!xt_shape_ok(Mp, N, K, Np, ldat, ldb)) return false;
   gx::XTArgs a;
   memset(&a, 0, sizeof(a));
   a.AT = AT; a.ldat = ldat; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.Mp = Mp; a.N = N; a.K = K; a.Np = Np; a.Nv = Nv; a.zero = zero16();
@@ -768,8 +775,7 @@ static bool gemm16xt(hipStream_t s, const bf16* AT, int64_t ldat, const bf16* B,
   return true;
 }
 bool dx_from_transposed_ok(int64_t Mp, int N, int64_t K, int64_t Np) {   // (the BPTT launch asks before it drops its row-major copy of dA)
-  static const bool off = getenv("KPRN_BF16_DX_T") && getenv("KPRN_BF16_DX_T")[0] == '0';
-  return !off && Mp >= gx::BM && Mp < ((int64_t)1 << 32) && N >= gx::BN && !(K & 7) && !(Np & 7);
+  return xt_shape_ok(Mp, N, K, Np, /*ldat = the padded (step, path) extent*/ Mp, /*ldb = the gate columns*/ K);
 }
 
 // ---- element-wise / layout kernels --------------------------------------------------------------------------------------
@@ -1103,6 +1109,89 @@ __global__ __launch_bounds__(256) void k_rowsum16(const bf16* __restrict__ x, in
   if (threadIdx.x == 0) out[blockIdx.x] += red[0];
 }
 
+// ---- small tables: their gradients through ONE extra column block of the dW product (round 5) -------------------------------------------------
+// The step input is x = [Wt[type] | We[entity] | Wr[relation]] (FeatureEmbedding.lua:112-121), so with the one-hot selectors S_t, S_r of a batch
+//   x_r = S_r Wr                          =>   dW_i2g[:, relation columns] = dA^T x_r = (dA^T S_r) Wr        = G_r Wr
+//   dWr = S_r^T dx_r = S_r^T (dA W_i2g_r)  =>   dWr                         = (S_r^T dA) W_i2g_r              = G_r^T W_i2g[:, relation columns]
+// and the same for the type table: the relation / type thirds of the dx product and of the dW_i2g product, and both table-gradient launches, collapse
+// into G = dA^T [S_r | S_t] -- 128 more columns of the split-K dW product (Vr + Vt <= 128 one-hot rows, exact in bf16) -- plus two tiny fp32 products.
+// configs[3] (100 relations, 6 types, d = 128): dx shrinks from N = 384 to the entity slice (N = 128: a third of the flops, one column tile, dA^T
+// read once instead of three times), the two dW products become ONE over the operand Z^T = [x_e^T | S^T | h_{t-1}^T] (N = 640 instead of 768, dA^T read
+// by one launch instead of two), the one-hot table-gradient launch (0.27 ms, 400 MB of dx) and two thirds of the X^T gather disappear.
+// G is a sum of bf16 dA values in fp32 and the small products run in fp32 on the same bf16 shadows the big ones read: the same gradient, fewer roundings.
+//
+// S^T rows of the operand: row r < Vr is relation r + 1, row Vr + y is type y + 1 (num_types = 1); [128][T][Np], pad columns zero.
+__global__ __launch_bounds__(256) void k_onehot_T(const int32_t* __restrict__ idx, int64_t N, int64_t Np, int T, int F, int Vr, int Vt, bf16* __restrict__ ST, int64_t ldT) {
+  __shared__ int rid[64], tyid[64];
+  const int64_t n0 = (int64_t)blockIdx.x * 64;
+  const int t = blockIdx.y;
+  if (threadIdx.x < 64) {
+    const int64_t n = n0 + threadIdx.x;
+    const int32_t* id = idx + ((n < N ? n : N - 1) * T + t) * F;
+    const int r = id[F - 1] - 1, y = id[F - 3] - 1;
+    rid[threadIdx.x] = n < N ? r : -1;
+    tyid[threadIdx.x] = n < N ? Vr + y : -1;
+  }
+  __syncthreads();
+  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p0 = 32 * half + 8 * q;
+    if (n0 + p0 >= Np) continue;
+    u16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (rid[p0 + e] == row || tyid[p0 + e] == row) ? (unsigned short)0x3f80 : (unsigned short)0;   // bf16 1.0
+    *(u16x8*)(ST + (int64_t)row * ldT + (int64_t)t * Np + n0 + p0) = v;
+  }
+}
+// What the merged product leaves in Ct [4H][NZ] (NZ = de + 128 + H: entity columns | G | recurrent columns) goes where the optimiser reads it (all +=):
+// workgroups [0, 4H): one gate row each -- gW_i2g[k][:] = [G_t Wt | Ct entity block | G_r Wr], gW_o2g[k][:]; workgroups behind them: one (table row,
+// K slice) each -- gWr[r][:] += sum_k G[k][r] W_i2g[k][relation columns] (atomic over the slices), likewise gWt.
+struct FinArgs {
+  const float* Ct; int NZ, G4, Din, H, dt, de, dr, Vt, Vr;
+  const bf16* Wt16; const bf16* Wr16; const bf16* Wi16;
+  float* gWi; float* gWo; float* gWt; float* gWr;
+  int kslices;
+};
+__global__ __launch_bounds__(256) void k_small_tables_finish(FinArgs a) {
+  __shared__ float g[128];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < a.G4) {
+    const int k = blockIdx.x;
+    const float* row = a.Ct + (int64_t)k * a.NZ;
+    if (tid < 128) g[tid] = row[a.de + tid];
+    __syncthreads();
+    for (int j = tid; j < a.Din; j += 256) {
+      float v = 0.f;
+      if (j < a.dt) {
+        for (int y = 0; y < a.Vt; ++y) v += g[a.Vr + y] * (float)a.Wt16[y * a.dt + j];
+      } else if (j < a.dt + a.de) {
+        v = row[j - a.dt];
+      } else {
+        const int jj = j - a.dt - a.de;
+#pragma unroll 4
+        for (int r = 0; r < a.Vr; ++r) v += g[r] * (float)a.Wr16[r * a.dr + jj];
+      }
+      a.gWi[(int64_t)k * a.Din + j] += v;
+    }
+    for (int j = tid; j < a.H; j += 256) a.gWo[(int64_t)k * a.H + j] += row[a.de + 128 + j];
+    return;
+  }
+  const int bi = (int)blockIdx.x - a.G4;
+  const int r = bi / a.kslices, ks = bi - r * a.kslices;   // one-hot row r: relation r (r < Vr) or type r - Vr
+  const bool rel = r < a.Vr;
+  const int w = rel ? a.dr : a.dt, col0 = rel ? a.dt + a.de : 0;
+  const int kper = (a.G4 + a.kslices - 1) / a.kslices;
+  const int k0 = ks * kper, k1 = k0 + kper < a.G4 ? k0 + kper : a.G4;
+  const int j = tid & 127, sub = tid >> 7;
+  const int jc = j < w ? j : w - 1;   // (w <= 128; idle lanes re-read the last column: loads stay unconditional)
+  float acc = 0.f;
+#pragma unroll 8
+  for (int k = k0 + sub; k < k1; k += 2) acc += a.Ct[(int64_t)k * a.NZ + a.de + r] * (float)a.Wi16[(int64_t)k * a.Din + col0 + jc];
+  if (j < w) unsafeAtomicAdd((rel ? a.gWr + (int64_t)r * a.dr : a.gWt + (int64_t)(r - a.Vr) * a.dt) + j, acc);
+}
+
 // ---- state + orchestration --------------------------------------------------------------------------------------------------
 // lstm_bf16_persist.hip: fragment-order saves of the persistent layer kernel's training launch
 struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; const bf16* HsF; int64_t NU, step_recs; int NW; };
@@ -1114,6 +1203,8 @@ struct State {
   bool dense_dirty = true;
   int64_t cap_N = 0; int cap_T = 0;
   bf16 *X16 = nullptr, *XT16 = nullptr, *H16 = nullptr, *HT16 = nullptr, *ACT16 = nullptr, *dA16 = nullptr, *dAT16 = nullptr;
+  bf16* ZT16 = nullptr; int64_t z_cap = 0;   // small-table backward: the merged dW product's operand [x_e^T | S^T | h_{t-1}^T], [de + 128 + H][T][Np]
+  float* Ctmp = nullptr; int64_t ct_cap = 0; //   ... and its result [4H][de + 128 + H]
   void* persist = nullptr;      // lstm_bf16_persist.hip: packed weights + scratch slabs of the persistent layer kernel
   bool pack_dirty = true;       // its packed weights are stale
   void* persist_bwd = nullptr;  // lstm_bf16_bwd_persist.hip: packed W_o2g^T fragments of the persistent BPTT kernel
@@ -1122,6 +1213,7 @@ struct State {
   bool act_frag = false;        // the last training forward wrote c and the gate planes in fragment order (persistent kernel; k_gates_bwd16_frag)
   PersistSaves sv{};
   // the backward's side stream (backward(): the memory-bound helpers run beside the matrix-core launches they do not depend on)
+  int side_probes = 0;   // candidates make_concurrent_stream tried for it
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_operands = nullptr, ev_dx = nullptr, ev_join = nullptr;
 };
 // lstm_bf16_persist.hip: the whole layer (gather + T steps) as one persistent launch
@@ -1130,7 +1222,7 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
                      PersistSaves* sv);
 void persist_release(void*& st);
 // lstm_bf16_bwd_persist.hip: BPTT through the layer (cell backward + recurrent product of all T steps) as one persistent launch
-bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv);
+bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv, int64_t N, int T);
 void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16 /* nullable: no row-major copy */, bf16* dAT16, int64_t Np);
 void persist_bwd_release(void*& st);
 static State* st(kprn_handle* h) {
@@ -1178,7 +1270,8 @@ void rows_updated(kprn_handle* h, const int32_t* rows, const int32_t* count, int
 void release(kprn_handle* h) {
   State* s = (State*)h->bf16_state;
   if (!s) return;
-  for (bf16* p : {s->We16, s->dense16, s->WT16, s->X16, s->XT16, s->H16, s->HT16, s->ACT16, s->dA16, s->dAT16}) if (p) hipFree(p);
+  for (bf16* p : {s->We16, s->dense16, s->WT16, s->X16, s->XT16, s->H16, s->HT16, s->ACT16, s->dA16, s->dAT16, s->ZT16}) if (p) hipFree(p);
+  if (s->Ctmp) hipFree(s->Ctmp);
   persist_release(s->persist);
   persist_bwd_release(s->persist_bwd);
   if (s->side) {
@@ -1307,7 +1400,7 @@ __global__ __launch_bounds__(256) void k_head_fwd16(const float* __restrict__ hT
 }
 // false: a shape this launch does not take (the caller falls back to the generic product).  KPRN_BF16_HEAD=0: always false (A/B)
 static bool head_fwd16(hipStream_t s, const float* hT, const bf16* W16, const float* bias, float* S, int64_t N, int H, int C) {
-  static const bool off = getenv("KPRN_BF16_HEAD") && getenv("KPRN_BF16_HEAD")[0] == '0';
+  static const bool off = KPRN_DEV_ENV("KPRN_BF16_HEAD") && KPRN_DEV_ENV("KPRN_BF16_HEAD")[0] == '0';
   const int NT = (C + 15) / 16, NJ = H >> 6;
   const size_t lds = (size_t)NJ * 2 * NT * 64 * sizeof(bf16x8);
   if (off || N <= 0 || (H & 63) || C < 1 || NT > 4 || !(NJ == 2 || NJ == 3 || NJ == 4 || NJ == 6) || ((uintptr_t)W16 & 15) || ((uintptr_t)hT & 15)) return false;
@@ -1398,16 +1491,16 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   const int64_t N = (int64_t)b->B * b->P, TN = (int64_t)T * N;
   float* gd = h->g_dense;
   // the persistent BPTT launch forms dh_T = dS W_out[cid] itself and keeps dh / dc on the chip: no dH plane, no dC plane
-  const bool bptt_persist = s->act_frag && L == 1 && persist_bwd_shape_ok(h, s->sv);
+  const bool bptt_persist = s->act_frag && L == 1 && persist_bwd_shape_ok(h, s->sv, N, T);
   // Side stream (with the persistent BPTT launch): what is left of this backward is a chain of matrix-core launches -- BPTT, the dx product,
   // the two dW products -- and memory-bound helpers that each depend on only part of it.  The helpers run on a second stream beside the
   // launches they do not depend on: the head's backward and the two transposed operands of the dW products (in^T gathered from the tables,
   // h^T from the forward's records) beside BPTT; the three table gradients (they need dx only) beside the dW products.  The main stream
   // waits for the side stream before this function returns: nothing outside sees two streams.  KPRN_BF16_BWD_OVERLAP=0: one stream.
-  static const bool overlap_env = !(getenv("KPRN_BF16_BWD_OVERLAP") && getenv("KPRN_BF16_BWD_OVERLAP")[0] == '0');
+  static const bool overlap_env = [] { const char* e = getenv("KPRN_BF16_BWD_OVERLAP"); return !(e && e[0] == '0'); }();
   const bool overlap = bptt_persist && overlap_env;
   if (overlap && !s->side) {
-    s->side = make_concurrent_stream(h);
+    s->side = make_concurrent_stream(h, &s->side_probes);
     for (hipEvent_t* e : {&s->ev_fork, &s->ev_operands, &s->ev_dx, &s->ev_join}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
   hipStream_t side = overlap ? s->side : strm;
@@ -1462,7 +1555,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
           // Measured (configs[3], ms per launch): one unit per workgroup, bias sums left to k_rowsum16 0.224; the bias gradient summed here
           // 0.26-0.29 (units per workgroup 4 / 2 / 1 / 8) -- 6 x 0.04-0.06 costs what the separate sweep over dA^T costs (0.20 ms), so it stays
           // a separate launch; KPRN_GATES_FUSED_BIAS=<units per workgroup> switches the fused form on.
-          static const int fb_env = getenv("KPRN_GATES_FUSED_BIAS") ? atoi(getenv("KPRN_GATES_FUSED_BIAS")) : 0;
+          static const int fb_env = KPRN_DEV_ENV("KPRN_GATES_FUSED_BIAS") ? atoi(KPRN_DEV_ENV("KPRN_GATES_FUSED_BIAS")) : 0;
           s->bias_in_gates = fb_env > 0;
           const int upw = fb_env > 0 ? fb_env : 1;
           const dim3 grid((unsigned)((v.NU + upw - 1) / upw), (unsigned)NCH);
@@ -1481,6 +1574,74 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       }
     }
     const int64_t Np = (N + 7) & ~(int64_t)7, TNp = (int64_t)T * Np;   // padded step blocks of the transposed images (pads are zero)
+    // Small tables (see k_onehot_T): dx for the entity slice only, ONE dW product over [x_e^T | S^T | h_{t-1}^T], the type / relation gradients from G.
+    const bool tabs = bptt_persist && dx_t && l == 0 && h->bf16_small_tables && c.num_types == 1 && c.Vt + c.Vr <= 128 && c.dt <= 128 && c.dr <= 128 &&
+                      c.de >= 128 && T > 1 && b->key_sorted != nullptr && !b->tile_k && s->sv.HsF && (H % 64) == 0;
+    if (tabs) {
+      const int NZ = c.de + 128 + H;
+      if (TNp * NZ > s->z_cap) {
+        HIP_TRY(hipStreamSynchronize(strm));
+        if (overlap) HIP_TRY(hipStreamSynchronize(side));
+        if (s->ZT16) hipFree(s->ZT16);
+        s->ZT16 = nullptr; s->ZT16 = dal<bf16>(TNp * NZ); s->z_cap = TNp * NZ;
+      }
+      if ((int64_t)G4 * NZ > s->ct_cap) {
+        HIP_TRY(hipStreamSynchronize(strm));
+        if (s->Ctmp) hipFree(s->Ctmp);
+        s->Ctmp = nullptr; s->Ctmp = dal<float>((int64_t)G4 * NZ); s->ct_cap = (int64_t)G4 * NZ;
+      }
+      bf16* zt_e = s->ZT16;                              // rows [0, de): x_e^T, the entity slice of the step input
+      bf16* zt_s = s->ZT16 + (int64_t)c.de * TNp;        // rows [de, de + 128): the one-hot selectors
+      bf16* zt_h = s->ZT16 + (int64_t)(c.de + 128) * TNp;   // rows behind them: h_{t-1}^T (step block 0 zero)
+      {
+        ProfScope ps(h, "bf16_transposes", side);   // (side stream: beside the BPTT launch queued above -- nothing here reads what it writes)
+        hipLaunchKernelGGL(k_gather16_T, dim3((unsigned)((Np + 63) / 64), (unsigned)((c.de + 63) / 64), (unsigned)T), dim3(256), 0, side, b->idx, N, Np, T, b->F, 1,
+                           s->We16, s->We16, s->We16, 0, c.de, 0, zt_e, TNp);
+        hipLaunchKernelGGL(k_onehot_T, dim3((unsigned)((Np + 63) / 64), (unsigned)T), dim3(256), 0, side, b->idx, N, Np, T, b->F, c.Vr, c.Vt, zt_s, TNp);
+        HIP_TRY(hipMemset2DAsync(zt_h, (size_t)TNp * sizeof(bf16), 0, (size_t)Np * sizeof(bf16), (size_t)H, side));
+        hipLaunchKernelGGL(k_hfrag_T, dim3((unsigned)((s->sv.NU + 1) / 2), (unsigned)(H / 64), (unsigned)(T - 1)), dim3(256), 0, side, (const bf16x4*)s->sv.HsF, zt_h + Np,
+                           (int64_t)s->sv.NU, (int64_t)s->sv.step_recs, N, Np, TNp, H);
+        HIP_TRY(hipGetLastError());
+      }
+      if (overlap) HIP_TRY(hipEventRecord(s->ev_operands, side));
+      {
+        ProfScope ps(h, "gemm_i2g_bwd_dx_e");   // dx_e [T N][de] = dA W_i2g[:, entity columns] (compact: what the entity gather-reduce reads)
+        const bool ran = gemm16xt(strm, s->dAT16, TNp, wt + (int64_t)c.dt * G4, G4, w.dIn, c.de, TNp, c.de, G4, Np, N);
+        KPRN_REQUIRE(ran, KPRN_E_ARG, "bf16 backward: the transposed-dA dx product does not cover this shape (dx_from_transposed_ok said it would)");
+      }
+      if (overlap) {
+        HIP_TRY(hipEventRecord(s->ev_dx, strm));
+        HIP_TRY(hipStreamWaitEvent(side, s->ev_dx, 0));
+        HIP_TRY(hipStreamWaitEvent(strm, s->ev_operands, 0));
+      }
+      {
+        ProfScope ps(h, "entity_grad", side);   // (beside the merged dW product)
+        bidx::entity_grad(side, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, b->n_index, N, T, c.de, 0, c.de, c.Ve, h->g_We);
+      }
+      {
+        ProfScope ps(h, "gemm_bwd_dw_merged");   // Ct [4H][NZ] = dA^T [x_e^T | S^T | h_{t-1}^T]^T, split-K
+        HIP_TRY(hipMemsetAsync(s->Ctmp, 0, (size_t)G4 * NZ * sizeof(float), strm));
+        const int split = (int)std::min<int64_t>(1024, std::max<int64_t>(1, TN / 4096));
+        gemm16(strm, s->dAT16, TNp, s->ZT16, TNp, s->Ctmp, NZ, G4, NZ, TNp, true, nullptr, split);
+      }
+      {
+        ProfScope ps(h, "small_tables_finish");
+        FinArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.Ct = s->Ctmp; fa.NZ = NZ; fa.G4 = G4; fa.Din = Din; fa.H = H; fa.dt = c.dt; fa.de = c.de; fa.dr = c.dr; fa.Vt = c.Vt; fa.Vr = c.Vr;
+        fa.Wt16 = s->dense16 + h->off_Wt; fa.Wr16 = s->dense16 + h->off_Wr; fa.Wi16 = s->dense16 + h->layer[l].Wi;
+        fa.gWi = gd + h->layer[l].Wi; fa.gWo = gd + h->layer[l].Wo; fa.gWt = gd + h->off_Wt; fa.gWr = gd + h->off_Wr;
+        fa.kslices = 8;
+        hipLaunchKernelGGL(k_small_tables_finish, dim3((unsigned)(G4 + (c.Vr + c.Vt) * fa.kslices)), dim3(256), 0, strm, fa);
+        HIP_TRY(hipGetLastError());
+      }
+      if (overlap) {
+        HIP_TRY(hipEventRecord(s->ev_join, side));
+        HIP_TRY(hipStreamWaitEvent(strm, s->ev_join, 0));
+        side_guard.joined = true;
+      }
+      return;   // (L = 1: nothing below this layer)
+    }
     {
       // (with the side stream: in^T and h^T are built there, beside the BPTT launch queued above -- neither reads anything it writes)
       ProfScope ps(h, "bf16_transposes", side);
@@ -1494,15 +1655,21 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
         hipLaunchKernelGGL(k_hfrag_T, dim3((unsigned)((s->sv.NU + 1) / 2), (unsigned)(H / 64), (unsigned)(T - 1)), dim3(256), 0, side, (const bf16x4*)s->sv.HsF, s->HT16,
                            (int64_t)s->sv.NU, (int64_t)s->sv.step_recs, N, Np, (int64_t)T * Np, H);
         HIP_TRY(hipGetLastError());
-      } else if (T > 1) transpose_steps(strm, hs, s->HT16, T, N, Np, H);                                         // h^T  [H][T][Np]
+      } else if (T > 1) {
+        // (the persistent forward writes no row-major h plane: its records are the only copy, and k_hfrag_T above is their only reader)
+        KPRN_REQUIRE(!(s->act_frag && l == 0), KPRN_E_ARG, "bf16 backward: h^T of a persistent forward needs its fragment-order records (NW = 8, H a multiple of 64)");
+        transpose_steps(strm, hs, s->HT16, T, N, Np, H);                                                        // h^T  [H][T][Np]
+      }
     }
     if (overlap) {
       HIP_TRY(hipEventRecord(s->ev_operands, side));
       // dx first: the table gradients (side stream) then run beside the two dW products
       {
         ProfScope ps(h, "gemm_i2g_bwd_dx");   // dx [T N][Din] = dA W_i2g
-        if (!(dx_t && gemm16xt(strm, s->dAT16, TNp, wt, G4, w.dIn, Din, TNp, Din, G4, Np, N)))
-          gemm16(strm, s->dA16, G4, wt, G4, w.dIn, Din, TN, Din, G4, false, nullptr, 1);
+        if (dx_t) {   // (the BPTT launch wrote no row-major dA: there is nothing to fall back to)
+          const bool ran = gemm16xt(strm, s->dAT16, TNp, wt, G4, w.dIn, Din, TNp, Din, G4, Np, N);
+          KPRN_REQUIRE(ran, KPRN_E_ARG, "bf16 backward: the transposed-dA dx product does not cover this shape (dx_from_transposed_ok said it would)");
+        } else gemm16(strm, s->dA16, G4, wt, G4, w.dIn, Din, TN, Din, G4, false, nullptr, 1);
       }
       HIP_TRY(hipEventRecord(s->ev_dx, strm));
       HIP_TRY(hipStreamWaitEvent(side, s->ev_dx, 0));
@@ -1524,8 +1691,10 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     }
     if (!overlap) {
       ProfScope ps(h, "gemm_i2g_bwd_dx");   // dx [T N][Din] = dA W_i2g
-      if (!(dx_t && gemm16xt(strm, s->dAT16, TNp, wt, G4, w.dIn, Din, TNp, Din, G4, Np, N)))
-        gemm16(strm, s->dA16, G4, wt, G4, w.dIn, Din, TN, Din, G4, false, nullptr, 1);
+      if (dx_t) {
+        const bool ran = gemm16xt(strm, s->dAT16, TNp, wt, G4, w.dIn, Din, TNp, Din, G4, Np, N);
+        KPRN_REQUIRE(ran, KPRN_E_ARG, "bf16 backward: the transposed-dA dx product does not cover this shape (dx_from_transposed_ok said it would)");
+      } else gemm16(strm, s->dA16, G4, wt, G4, w.dIn, Din, TN, Din, G4, false, nullptr, 1);
     }
   }
   // (with the side stream these were queued behind ev_dx, i.e. they run beside the dW products issued above)

@@ -410,9 +410,15 @@ __global__ void k_pack_wb(const float* __restrict__ Wo, bf16* __restrict__ WpB) 
 struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; const bf16* HsF; int64_t NU, step_recs; int NW; };   // (also declared in lstm_bf16.hip)
 struct PersistBwdState { bf16* WpB = nullptr; int grid = 0; };
 
-bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv) {
-  static const bool off = getenv("KPRN_BF16_BWD_PERSIST") && getenv("KPRN_BF16_BWD_PERSIST")[0] == '0';
-  return !off && h->cfg.L == 1 && h->cfg.H == pb::H && sv.NW == 8;
+// Everything persist_backward() requires of a batch is decided HERE, before the backward has accumulated anything: a batch the launch cannot take
+// (T x N beyond the 32-bit row-block offsets of dA^T: about 4.8 M (path, step) positions at H = 384) trains through the per-step loop instead.
+static bool persist_bwd_offsets_ok(int64_t N, int T) {
+  const int64_t Np = (N + 7) & ~(int64_t)7;
+  return (int64_t)T * Np * (pb::H + 64) * 2 < ((int64_t)1 << 32);
+}
+bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv, int64_t N, int T) {
+  static const bool off = [] { const char* e = getenv("KPRN_BF16_BWD_PERSIST"); return e && e[0] == '0'; }();
+  return !off && h->cfg.L == 1 && h->cfg.H == pb::H && sv.NW == 8 && T >= 1 && persist_bwd_offsets_ok(N, T);
 }
 
 void persist_bwd_release(void*& st) {
@@ -454,10 +460,10 @@ void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSa
   a.N = N; a.Np = Np; a.ldT = (int64_t)T * Np; a.T = T;
   // tile height: 64 rows, one workgroup per CU (default), or 32 rows, two workgroups per CU (KPRN_BPTT_NPT=1: each weight fragment then serves one
   // path tile only -- twice the weight bytes through the L1 path -- for two independent barrier domains per CU)
-  static const int npt_env = getenv("KPRN_BPTT_NPT") ? atoi(getenv("KPRN_BPTT_NPT")) : 2;
+  static const int npt_env = KPRN_DEV_ENV("KPRN_BPTT_NPT") ? atoi(KPRN_DEV_ENV("KPRN_BPTT_NPT")) : 2;
   const int npt = npt_env == 1 ? 1 : 2;
   a.tiles = (N + 32 * npt - 1) / (32 * npt);
-  KPRN_REQUIRE(a.ldT * (pb::H + 64) * 2 < ((int64_t)1 << 32), KPRN_E_ARG, "persistent BPTT: T x N too large for 32-bit row-block offsets of dA^T");
+  KPRN_REQUIRE(persist_bwd_offsets_ok(N, T) && Np == ((N + 7) & ~(int64_t)7), KPRN_E_ARG, "persistent BPTT: shape not covered (persist_bwd_shape_ok decides before the backward starts)");
   int grid = (int)std::min<int64_t>((int64_t)p->grid * (npt == 1 ? 2 : 1), a.tiles);
   if (const char* e = getenv("KPRN_PERSIST_BWD_GRID")) grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, atoi(e)));   // (tests: several tiles per workgroup at small N)
   const size_t lds_bytes = npt == 1 ? (size_t)pb::Geo<1>::LDS : (size_t)pb::Geo<2>::LDS;
@@ -466,7 +472,7 @@ void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSa
   if (npt == 1) k = dA16 ? (Kern)pb::k_lstm16_bwd_persist<1, 0> : (Kern)pb::k_lstm16_bwd_persist<1, 2>;
 #ifdef KPRN_PERSIST_VARIANTS
   // measurement builds (scripts/gpu_persist_knockouts.py bwd): KPRN_PERSIST_BWD_DBG = knock-out mask
-  if (const char* e = getenv("KPRN_PERSIST_BWD_DBG")) {
+  if (const char* e = KPRN_DEV_ENV("KPRN_PERSIST_BWD_DBG")) {
     const int dbg = atoi(e) | (dA16 ? 0 : 2);
     bool found = (dbg == 0 || dbg == 2) && npt == 2;
 #define KV(D) if (dbg == D) { k = (Kern)pb::k_lstm16_bwd_persist<2, D>; found = true; }

@@ -486,7 +486,7 @@ struct PersistState {
 
 bool persist_shape_ok(const kprn_handle* h, const kprn_batch* b) {
   const kprn_config& c = h->cfg;
-  static const bool off = getenv("KPRN_BF16_PERSIST") && getenv("KPRN_BF16_PERSIST")[0] == '0';
+  static const bool off = [] { const char* e = getenv("KPRN_BF16_PERSIST"); return e && e[0] == '0'; }();
   if (off) return false;
   // instantiated shape: D = H = 384 (three 128-wide tables), one layer, one type slot
   return c.L == 1 && c.H == 384 && h->D == 384 && c.num_types == 1 && (c.dt % 8) == 0 && (c.de % 8) == 0 && (c.dr % 8) == 0 && b->T >= 1 && b->T <= pk::MAXT;
@@ -533,10 +533,10 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
 #ifdef KPRN_PERSIST_VARIANTS
   // measurement builds (scripts/gpu_persist_knockouts.py): KPRN_PERSIST_NW = waves per workgroup, _DBG = knock-out mask, _PF = ring depth, _LA
   if (!save) {
-    if (const char* e = getenv("KPRN_PERSIST_NW")) nw = atoi(e);
-    if (const char* e = getenv("KPRN_PERSIST_DBG")) dbg = atoi(e);
-    if (const char* e = getenv("KPRN_PERSIST_PF")) pf = atoi(e);
-    if (const char* e = getenv("KPRN_PERSIST_LA")) la = atoi(e);
+    if (const char* e = KPRN_DEV_ENV("KPRN_PERSIST_NW")) nw = atoi(e);
+    if (const char* e = KPRN_DEV_ENV("KPRN_PERSIST_DBG")) dbg = atoi(e);
+    if (const char* e = KPRN_DEV_ENV("KPRN_PERSIST_PF")) pf = atoi(e);
+    if (const char* e = KPRN_DEV_ENV("KPRN_PERSIST_LA")) la = atoi(e);
   }
 #endif
   if (repack || p->packed_nw != nw) {

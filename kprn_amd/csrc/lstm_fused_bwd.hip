@@ -613,7 +613,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     s->cap_Nb = cn; s->cap_Tb = ct;
   }
   if (!s->part) HIP_TRY(kprn_dev_malloc((void**)&s->part, (size_t)2 * s->num_cu * PART * sizeof(float)));  // one slab set per layer
-  static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
+  static const bool want_timing = KPRN_DEV_ENV("KPRN_TIMING") != nullptr;
   if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
   if (s->wt_dirty) {  // (normally done already: the transposes ride in the loss-stage launch, transpose_job())
     ProfScope ps(h, "weight_transpose");
@@ -649,7 +649,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
     a.n_tiles = n_tiles;
     a.part = s->part + (size_t)l * s->num_cu * PART; a.timing = s->timing;
-    { static const char* d = getenv("KPRN_DBG"); a.dbg = d ? atoi(d) : 0; }
+    a.dbg = kprn_dbg_mask();
     const bool bottom = (l == 0), top = (l == L - 1);
     // type / relation gradients: a passenger job of the entity-gradient launch when the shapes allow (one type slot, slices in
     // 16-column blocks, tables of at most 16 rows), else the general scatter kernel
@@ -684,7 +684,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       bidx::SmallGrad sg;
       sg.DX = s->DX; sg.idx = b->idx_s ? b->idx_s : b->idx; sg.tile_k = b->tile_k; sg.N = N; sg.n_mtiles = n_tiles * nmt; sg.T = T; sg.F = b->F;
       sg.nT = c.num_types; sg.dt = c.dt; sg.de = c.de; sg.dr = c.dr; sg.Vt = c.Vt; sg.Vr = c.Vr; sg.gWt = a.gWt; sg.gWr = a.gWr; sg.nblocks = 4 * s->num_cu;
-      { static const int sgb = getenv("KPRN_SG_BLOCKS") ? atoi(getenv("KPRN_SG_BLOCKS")) : 0; if (sgb > 0) sg.nblocks = sgb; }   // (measurement)
+      { static const int sgb = KPRN_DEV_ENV("KPRN_SG_BLOCKS") ? atoi(KPRN_DEV_ENV("KPRN_SG_BLOCKS")) : 0; if (sgb > 0) sg.nblocks = sgb; }   // (measurement)
       bidx::entity_grad(strm, s->DXe, /*compact entity slice=*/2, b->key_sorted, b->pos_sorted, b->n_index, N, T, DH, c.dt, c.de, c.Ve, a.gWe, &ra,
                         small_job ? &sg : nullptr);
       reduced = true;

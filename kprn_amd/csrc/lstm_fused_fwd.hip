@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 // (0.38 ms whatever the size).  Tiles of one 16-row m-tile put 4x the workgroups on the chip at a quarter of the latency each.
 // No identical-prefix plan in this mode (kprn_api.hip batch_wants_plan agrees): its classes are per 64-path tile.
 bool small_tiles(const kprn_handle* h, int64_t N, bool has_plan) {
-  static const int64_t max_paths = getenv("KPRN_SMALL_TILES_MAX") ? atoll(getenv("KPRN_SMALL_TILES_MAX")) : SMALL_TILES_MAX_PATHS;   // (measurement: the 16-row tiles at any size)
+  static const int64_t max_paths = KPRN_DEV_ENV("KPRN_SMALL_TILES_MAX") ? atoll(KPRN_DEV_ENV("KPRN_SMALL_TILES_MAX")) : SMALL_TILES_MAX_PATHS;   // (measurement: the 16-row tiles at any size)
   return h->small_tiles_on && !has_plan && h->cfg.compute_dtype == 0 && h->cfg.L == 2 && N <= max_paths;
 }
 
@@ -497,7 +497,7 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin,
   }
   const int cus = (!save && h->reserve_cus > 0 && !ignore_reserve) ? std::max(1, s->num_cu - h->reserve_cus) : s->num_cu;
   const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)cus);
-  static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
+  static const bool want_timing = KPRN_DEV_ENV("KPRN_TIMING") != nullptr;
   if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
   a.timing = s->timing;
   ProfScope ps(h, save ? "lstm_fused_fwd_train" : "lstm_fused_fwd");

@@ -642,7 +642,7 @@ void forward_mc(kprn_handle* h, const kprn_batch* b, bool save) {
     a.perm = b->perm; a.tile_k = b->tile_k; a.pmeta = b->pmeta; a.pfb = s->pfb;
     a.save_frag = save ? s->save_frag : nullptr;
     a.n_tiles = n_tiles;
-    static const bool want_timing = getenv("KPRN_TIMING") != nullptr;
+    static const bool want_timing = KPRN_DEV_ENV("KPRN_TIMING") != nullptr;
     if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
     a.timing = s->timing;
     ProfScope ps(h, save ? "lstm_mc_fwd_train" : "lstm_mc_fwd");

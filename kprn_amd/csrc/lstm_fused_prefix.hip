@@ -307,8 +307,7 @@ bool prefix_backward(kprn_handle* h, const kprn_batch* b, int64_t n_tiles) {
   a.gWt = gd + h->off_Wt; a.gWe = h->g_We; a.gWr = gd + h->off_Wr;
   a.DXv = s->DX + (size_t)n_tiles * 4 * b->T * 4 * 256;
   a.DXe_v = s->DXe_on ? s->DXe + (size_t)n_tiles * MT * b->T * c.de : nullptr;
-  static const char* d = getenv("KPRN_DBG");
-  a.entity_direct = (d && (atoi(d) & 16)) ? 1 : 0;
+  a.entity_direct = (kprn_dbg_mask() & 16) ? 1 : 0;
   ProfScope ps(h, "prefix_bwd");
   hipLaunchKernelGGL(k_prefix_bwd, dim3(1), dim3(256), 0, h->stream, a);
   HIP_TRY(hipGetLastError());

@@ -54,3 +54,23 @@ def test_started_by_torchrun_it_is_one_of_the_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     assert json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_replica_digests_ride_on_the_line_and_a_diverged_replica_fails_the_run():
+    """round 5: after the timed steps every rank digests its replica (parameters + Adam state in the real run) and the digests are all-gathered;
+    `dp.replicas_bit_identical` is on the line and a run whose replicas differ exits with code 3 (the line still names the digests)."""
+    d = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert d["dp"]["replicas_bit_identical"] is True
+    per = d["dp"]["replica_digests"]["per_rank"]
+    assert len(per) == 2 and per[0] == per[1]
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["KPRN_DRYRUN_DIVERGE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    bad = json.loads(lines[0])
+    assert bad["dp"]["replicas_bit_identical"] is False and bad["dp"]["replica_digests"]["per_rank"][0] != bad["dp"]["replica_digests"]["per_rank"][1]

@@ -281,3 +281,40 @@ def test_twenty_adam_steps_follow_the_oracle_loss_curve():
         cos, sign = direction(got[off:off + n] - th0[off:off + n], th[off:off + n] - th0[off:off + n], floor=0.25)
         assert cos > 0.9995 and sign >= 0.999, (nm, cos, sign)
     eng.close()
+
+
+@pytest.mark.parametrize("pairs,P,T", [(700, 3, 6), (2200, 2, 5)])
+def test_small_table_gradients_from_the_merged_dw_product_match_the_dx_route(pairs, P, T):
+    """Round 5: with <= 128 relation + type rows the backward forms their gradients (and the matching column blocks of W_i2g) from
+    G = dA^T [S_r | S_t], 128 extra columns of ONE merged dW product over [x_e^T | S^T | h_{t-1}^T]; dx is formed for the entity slice only
+    (lstm_bf16.hip k_onehot_T / k_small_tables_finish).  Same engine, same batch, same dA: against the full dx product + one-hot table-gradient
+    route ("bf16_small_tables" = 0) every gradient agrees to fp32 reordering, and against the float64 oracle both stay inside the bf16 bars."""
+    eng, o64, theta, idx, labels = _case(pairs, P, T, Ve=3000, seed=31)
+    eng.profile(True)
+    b = eng.batch(idx, labels)
+    lay = eng.layout()
+    loss1 = eng.backward(b, 1)
+    fam = eng.profile_get()
+    assert "gemm_bwd_dw_merged" in fam and "small_tables_finish" in fam and "gemm_i2g_bwd_dx_e" in fam, sorted(fam)
+    assert "embed_scatter" not in fam and "gemm_i2g_bwd_dw" not in fam
+    g1 = eng.get_flat_grads().astype(np.float64)
+    eng.set_option("bf16_small_tables", "0")
+    eng.profile_reset()
+    eng.profile(True)
+    loss0 = eng.backward(b, 1)
+    fam0 = eng.profile_get()
+    assert "gemm_i2g_bwd_dw" in fam0 and "gemm_bwd_dw_merged" not in fam0
+    g0 = eng.get_flat_grads().astype(np.float64)
+    assert loss1 == loss0
+    for nm, (off, shp) in lay.items():
+        n = int(np.prod(shp))
+        a, r = g1[off:off + n], g0[off:off + n]
+        assert np.max(np.abs(a - r)) < 2e-5 * max(1e-30, np.max(np.abs(r))), (nm, float(np.max(np.abs(a - r))), float(np.max(np.abs(r))))
+    _, og, _ = o64.forward_backward(theta, idx, labels)
+    for nm, (off, shp) in lay.items():
+        n = int(np.prod(shp))
+        got, want = g1[off:off + n], og[off:off + n]
+        cos, sign = direction(got, want)
+        assert rel_inf(got, want) < GRAD_MAX and rel_rms(got, want) < GRAD_RMS, (nm, rel_inf(got, want), rel_rms(got, want))
+        assert cos > GRAD_COS and sign >= GRAD_SIGN, (nm, cos, sign)
+    eng.close()
