@@ -2253,6 +2253,12 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // its tiling from this option.)
     join_score(h);
     h->small_tiles_on = atoi(value) != 0;
+  } else if (strcmp(key, "bf16_bptt_dxe") == 0) {
+    // bf16 pipeline with "bf16_small_tables": the entity slice of dx is formed INSIDE the persistent BPTT launch (a fourth result tile per wave; value =
+    // depth of its weight ring, 8 (default) or 16) or by its own product launch reading dA^T once more ("0")
+    const int v = atoi(value);
+    KPRN_REQUIRE(v == 0 || v == 8 || v == 16, KPRN_E_ARG, "bf16_bptt_dxe must be 0, 8 or 16");
+    h->bf16_bptt_dxe = v;
   } else if (strcmp(key, "bf16_small_tables") == 0) {
     // bf16 pipeline, persistent BPTT: gradients of the type / relation tables (<= 128 rows together) and of their column blocks of W_i2g from one
     // extra column block of the merged dW product ("1", default) or from the full dx product + the table-gradient launch ("0": the A/B reference)

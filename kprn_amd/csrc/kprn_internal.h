@@ -205,6 +205,7 @@ struct kprn_handle {
   kprn_batch* dropin_slot[4] = {nullptr, nullptr, nullptr, nullptr};   // feed slots of the host-buffer entry points (kprn_train_step: 0 / 1, kprn_forward: 2 / 3)
   int dropin_next_train = 0, dropin_next_score = 0, dropin_last = 0;
   bool score_pending = false;     // a pass is (possibly) still running on score_stream
+  int bf16_bptt_dxe = 8;          // option "bf16_bptt_dxe": the persistent BPTT launch also forms dx for the entity slice (weight ring depth 8 | 16; 0: a separate product)
   bool bf16_small_tables = true;  // option "bf16_small_tables": configs[3] backward forms the type / relation gradients from G = dA^T [S_r | S_t] (lstm_bf16.hip)
   bool small_tiles_on = true;     // option "small_tiles": batches of <= 8 192 paths run on tiles of one 16-row m-tile (no identical-prefix plan)
   float score_split = 0.f;        // option: fraction of a scoring pass's tiles deferred to kprn_forward_batch_async_rest

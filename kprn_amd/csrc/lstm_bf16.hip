@@ -1223,7 +1223,9 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
 void persist_release(void*& st);
 // lstm_bf16_bwd_persist.hip: BPTT through the layer (cell backward + recurrent product of all T steps) as one persistent launch
 bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv, int64_t N, int T);
-void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16 /* nullable: no row-major copy */, bf16* dAT16, int64_t Np);
+void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16 /* nullable: no row-major copy */, bf16* dAT16, int64_t Np,
+                      float* dXe /* nullable: the launch also forms the entity slice of dx, [T][N][de] */);
+bool persist_bwd_dxe_ok(const kprn_handle* h);
 void persist_bwd_release(void*& st);
 static State* st(kprn_handle* h) {
   if (!h->bf16_state) h->bf16_state = new State();
@@ -1533,8 +1535,13 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     // dx straight from the transposed dA the BPTT launch writes for the dW products (gx::k_gemm16xt): that launch then writes no row-major copy
     const int64_t Np_ = (N + 7) & ~(int64_t)7;
     const bool dx_t = bptt_persist && dx_from_transposed_ok((int64_t)T * Np_, Din, G4, Np_);
+    // Small tables (see k_onehot_T): dx for the entity slice only, ONE dW product over [x_e^T | S^T | h_{t-1}^T], the type / relation gradients from G.
+    const bool tabs = bptt_persist && dx_t && l == 0 && h->bf16_small_tables && c.num_types == 1 && c.Vt + c.Vr <= 128 && c.dt <= 128 && c.dr <= 128 &&
+                      c.de >= 128 && T > 1 && b->key_sorted != nullptr && !b->tile_k && s->sv.HsF && (H % 64) == 0;
+    // ... and that slice of dx formed inside the BPTT launch itself (a fourth result tile per wave): no dx product launch, dA^T read once less
+    const bool dxe_in_bptt = tabs && h->bf16_bptt_dxe != 0 && persist_bwd_dxe_ok(h);
     if (bptt_persist) {
-      persist_backward(h, N, T, cid, s->sv, s->persist_bwd, s->packb_dirty, dx_t ? nullptr : s->dA16, s->dAT16, Np_);
+      persist_backward(h, N, T, cid, s->sv, s->persist_bwd, s->packb_dirty, dx_t ? nullptr : s->dA16, s->dAT16, Np_, dxe_in_bptt ? w.dIn : nullptr);
       s->packb_dirty = false;
       s->bias_in_gates = true;   // (the launch sums the bias gradient from the dA^T pieces it writes)
     }
@@ -1574,9 +1581,6 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       }
     }
     const int64_t Np = (N + 7) & ~(int64_t)7, TNp = (int64_t)T * Np;   // padded step blocks of the transposed images (pads are zero)
-    // Small tables (see k_onehot_T): dx for the entity slice only, ONE dW product over [x_e^T | S^T | h_{t-1}^T], the type / relation gradients from G.
-    const bool tabs = bptt_persist && dx_t && l == 0 && h->bf16_small_tables && c.num_types == 1 && c.Vt + c.Vr <= 128 && c.dt <= 128 && c.dr <= 128 &&
-                      c.de >= 128 && T > 1 && b->key_sorted != nullptr && !b->tile_k && s->sv.HsF && (H % 64) == 0;
     if (tabs) {
       const int NZ = c.de + 128 + H;
       if (TNp * NZ > s->z_cap) {
@@ -1604,7 +1608,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
         HIP_TRY(hipGetLastError());
       }
       if (overlap) HIP_TRY(hipEventRecord(s->ev_operands, side));
-      {
+      if (!dxe_in_bptt) {
         ProfScope ps(h, "gemm_i2g_bwd_dx_e");   // dx_e [T N][de] = dA W_i2g[:, entity columns] (compact: what the entity gather-reduce reads)
         const bool ran = gemm16xt(strm, s->dAT16, TNp, wt + (int64_t)c.dt * G4, G4, w.dIn, c.de, TNp, c.de, G4, Np, N);
         KPRN_REQUIRE(ran, KPRN_E_ARG, "bf16 backward: the transposed-dA dx product does not cover this shape (dx_from_transposed_ok said it would)");

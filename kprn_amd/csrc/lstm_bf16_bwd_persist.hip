@@ -51,6 +51,13 @@ constexpr int MJ = 3;           // 32-row result tiles per wave: NW * MJ * 32 = 
 constexpr int NCH = 12;         // K chunks: 32 hidden units x 4 gates = 128 gate columns = 8 k-steps
 constexpr int KSC = 8;          // k-steps per chunk
 constexpr int FR = NCH * KSC * MJ;   // weight fragments per wave and step (288 KiB)
+// With the entity slice of dx formed in this launch (DXE, round 5): a FOURTH result tile per wave -- rows = entity columns 32 w .. 32 w + 31 of the step
+// input, dx_e[n][col] = sum_k dA_t[n][k] W_i2g[k][dt + col] -- fed by one more weight fragment per k-step (W_i2g^T entity rows, 96 KiB more per wave and step).
+constexpr int DE = 128;         // entity columns (instantiated shape: 4 waves x 32)
+constexpr int MJX = MJ + 1;
+constexpr int FRX = NCH * KSC * MJX;
+// ring depth of the DXE variant = the template argument itself (8 or 16: divides the 32 fragments of a chunk).  hipcc -S, gfx950: 8 -> 512 registers, 12 spilled
+// dwords, all outside the step loop; 16 -> 34 spilled, 8 reloads inside the loop.
 #ifndef KPRN_BPTT_PF
 #define KPRN_BPTT_PF 12
 #endif
@@ -83,6 +90,7 @@ struct BArgs {
   const bf16* WpB;           // packed W_o2g^T fragments [NW][FR][64 lanes][8]
   bf16* dA;                  // [T][N][4H] row-major
   bf16* dAT;                 // [4H][ldT], this step's block at column t Np
+  float* dXe;                // DXE: [T][N][DE] fp32, the entity slice of dx (what the entity gather-reduce reads)
   float* gbias;              // [4H] += column sums of dA (the bf16-rounded values)
   int64_t N, Np, ldT; int T;
   int64_t tiles;             // ceil(N / (32 NPT))
@@ -118,9 +126,12 @@ template <int NPT> struct SvT { bf16x8 a0[NPT], a1[NPT]; bf16x4 c[NPT], cp[NPT];
 
 // DBG: 2 = no row-major copy of dA (the product default: dx reads the transposed image, lstm_bf16.hip gx::k_gemm16xt; 0 keeps it for the row-major
 // dx product).  Measurement builds (KPRN_PERSIST_VARIANTS + KPRN_PERSIST_BWD_DBG) add: 1 no dA^T / bias pass, 4 no product, 8 no save loads
-template <int NPT, int DBG>
+template <int NPT, int DBG, int DXE = 0>
 __global__ __launch_bounds__(64 * NW, NPT == 1 ? 2 : 1) void k_lstm16_bwd_persist(BArgs a) {
-  static_assert(NW * MJ * 32 == H && NCH * 32 == H && MJ * 4 == NCH && (KSC * MJ) % PF == 0, "shape algebra of the backward tile");
+  static_assert(NW * MJ * 32 == H && NCH * 32 == H && MJ * 4 == NCH && (KSC * MJ) % PF == 0 && (DXE == 0 || (KSC * MJX) % DXE == 0) && NW * 32 == DE, "shape algebra of the backward tile");
+  constexpr int MJP = DXE ? MJX : MJ;      // result tiles per wave in the product
+  constexpr int FRP = DXE ? FRX : FR;      // weight fragments per wave and step
+  constexpr int PFP = DXE ? DXE : PF;      // ring depth
   typedef Geo<NPT> GE;
   typedef SvT<NPT> Sv;
   constexpr int BUF = GE::BUF, TP = GE::TP, TT = GE::TT, NO = GE::NO, RPP = GE::RPP, NI = GE::NI, PW = GE::PW;
@@ -136,11 +147,11 @@ __global__ __launch_bounds__(64 * NW, NPT == 1 ? 2 : 1) void k_lstm16_bwd_persis
   if (t_beg >= t_end) return;
   for (int i = tid; i < 4 * H; i += 64 * NW) sdb[i] = 0.f;
   const int T = a.T;
-  const rsrc_t rW = make_rsrc(a.WpB + (int64_t)w * FR * 512);
+  const rsrc_t rW = make_rsrc(a.WpB + (int64_t)w * FRP * 512);
   const unsigned l16 = (unsigned)lane * 16u, l8 = (unsigned)lane * 8u;
-  bf16x8 ring[PF];
+  bf16x8 ring[PFP];
 #pragma unroll
-  for (int s = 0; s < PF; ++s) ring[s] = ldb<bf16x8>(rW, l16, (unsigned)s * 1024u);
+  for (int s = 0; s < PFP; ++s) ring[s] = ldb<bf16x8>(rW, l16, (unsigned)s * 1024u);
   // the dA^T pass of a chunk: thread -> (octet of 8 consecutive paths, row kc0 + 32 i of the transposed tile = gate i, unit kc0 of the chunk)
   const int oct = tid % NO, kc0 = tid / NO;   // row kc0 + RPP i of the transposed tile = gate (RPP i + kc0) / 32, unit (kc0 & 31)
   const unsigned et_voff = (unsigned)(((int64_t)((kc0 >> 5) * H + (kc0 & 31)) * a.ldT + 8 * oct) * 2);   // (host: H + 32 rows of dA^T span < 4 GB)
@@ -195,6 +206,11 @@ __global__ __launch_bounds__(64 * NW, NPT == 1 ? 2 : 1) void k_lstm16_bwd_persis
     // ---- state of the tile: dc_t and the accumulators of dh_{t-1} (register 4 q + r of tile j <-> chunk 4 j + q, unit r of the lane's quad);
     // dh_t in LDS.  dh_T = dS[n] W_out[cid] (nn.Linear backward on the selected column), this lane's slice Wc[32 c + 8 w + 4 half + r]
     f32x16 acc[MJ][NPT], dcs[MJ][NPT];
+    f32x16 accx[NPT];   // DXE: dx_e of the step being processed (rows = entity columns 32 w + (r & 3) + 8 (r >> 2) + 4 half, column = path)
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accx[pt][r] = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const f32x4 wq = *(const f32x4*)(a.Wc + 32 * c + 8 * w + 4 * half);
@@ -333,17 +349,22 @@ __global__ __launch_bounds__(64 * NW, NPT == 1 ? 2 : 1) void k_lstm16_bwd_persis
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) bfr[0][pt] = *(const bf16x8*)(src + (pt * KSC) * 1024);
           }
-          static_for<0, KSC * MJ>([&](auto gg) __attribute__((always_inline)) {
-            constexpr int g = decltype(gg)::value, ks = g / MJ, j = g % MJ;
+          static_for<0, KSC * MJP>([&](auto gg) __attribute__((always_inline)) {
+            constexpr int g = decltype(gg)::value, ks = g / MJP, j = g % MJP;
             if constexpr (HP) {
-              constexpr int f = c * KSC * MJ + g, slot = f % PF;
+              constexpr int f = c * KSC * MJP + g, slot = f % PFP;
+              if constexpr (j < MJ) {
 #pragma unroll
-              for (int pt = 0; pt < NPT; ++pt) acc[j][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot], bfr[ks & 1][pt], acc[j][pt], 0, 0, 0);
+                for (int pt = 0; pt < NPT; ++pt) acc[j][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot], bfr[ks & 1][pt], acc[j][pt], 0, 0, 0);
+              } else {
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) accx[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot], bfr[ks & 1][pt], accx[pt], 0, 0, 0);
+              }
               if constexpr (j == 0 && ks + 1 < KSC) {
 #pragma unroll
                 for (int pt = 0; pt < NPT; ++pt) bfr[(ks + 1) & 1][pt] = *(const bf16x8*)(src + (pt * KSC + ks + 1) * 1024);
               }
-              constexpr int fn = (f + PF) % FR;   // (the next step walks the same fragments again)
+              constexpr int fn = (f + PFP) % FRP;   // (the next step walks the same fragments again)
               ring[slot] = ldb<bf16x8>(rW, l16, (unsigned)fn * 1024u);
             }
             if constexpr (c + 1 < NCH && g <= 10) gslice(std::integral_constant<int, c + 1>{}, gg, sv[(c + 1) % SD]);
@@ -360,6 +381,19 @@ __global__ __launch_bounds__(64 * NW, NPT == 1 ? 2 : 1) void k_lstm16_bwd_persis
       // The product runs at t = 0 as well (its result, "dh_{-1}", is dropped): one sixth more MFMA work -- the matrix cores are not what bounds this
       // launch -- for ONE copy of the step body with no branches in it.  (Two copies, with and without, cost 500 spilled registers.)
       chunks(std::true_type{});
+      // DXE: dx_e of step t is complete (this one is NOT dropped at t = 0): a lane holds four quads of 4 consecutive entity columns of its path
+      if constexpr (DXE != 0) {
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+          if (valid[pt]) {
+            float* const dst = a.dXe + ((int64_t)t * a.N + row0 + 32 * pt + ln) * DE + 32 * w + 4 * half;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 8 * q) = f32x4{accx[pt][4 * q], accx[pt][4 * q + 1], accx[pt][4 * q + 2], accx[pt][4 * q + 3]};
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accx[pt][r] = 0.f;
+        }
+      }
       // dh_{t-1} is complete: it becomes the step's dh (lane-private LDS slots), the accumulators start again from zero
       {
 #pragma unroll
@@ -387,19 +421,22 @@ __global__ __launch_bounds__(64 * NW, NPT == 1 ? 2 : 1) void k_lstm16_bwd_persis
 // row m <-> hidden unit 32 (4 j + (m >> 3)) + 8 w + (m & 7); element e <-> gate column k = 16 ks + 8 kg + e of the chunk = gate
 // 2 kg + (e >> 2) of hidden unit 32 c + 8 (ks >> 1) + 4 (ks & 1) + (e & 3) (the order the cell backward writes its pieces in).
 // Value: W_o2g[gate H + unit_k][unit_m]  (dh_{t-1}[m] = sum_k dA_t[k] W_o2g[k][m]).  From the fp32 master, rounded once.
-__global__ void k_pack_wb(const float* __restrict__ Wo, bf16* __restrict__ WpB) {
+// mjp = MJ: the recurrent fragments only; mjp = MJX (DXE): fragment j = MJ of every k-step is W_i2g^T's entity slice -- row m <-> entity column 32 w + m,
+// value W_i2g[gate H + unit_k][col0 + 32 w + m]  (dx_e[m] = sum_k dA_t[k] W_i2g[k][col0 + m]; col0 = dt, Din = the row pitch of W_i2g).
+__global__ void k_pack_wb(const float* __restrict__ Wo, const float* __restrict__ Wi, int Din, int col0, int mjp, bf16* __restrict__ WpB) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)NW * FR * 64) return;
+  const int fr = NCH * KSC * mjp;
+  if (i >= (int64_t)NW * fr * 64) return;
   const int lane = (int)(i & 63);
-  const int f = (int)((i >> 6) % FR), w = (int)((i >> 6) / FR);
-  const int j = f % MJ, ks = (f / MJ) % KSC, c = f / (MJ * KSC);
+  const int f = (int)((i >> 6) % fr), w = (int)((i >> 6) / fr);
+  const int j = f % mjp, ks = (f / mjp) % KSC, c = f / (mjp * KSC);
   const int m = lane & 31, kg = lane >> 5;
   const int um = 32 * (4 * j + (m >> 3)) + 8 * w + (m & 7);
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int gate = 2 * kg + (e >> 2), uk = 32 * c + 8 * (ks >> 1) + 4 * (ks & 1) + (e & 3);
-    o[e] = (bf16)Wo[(int64_t)(gate * H + uk) * H + um];
+    o[e] = (bf16)(j < MJ ? Wo[(int64_t)(gate * H + uk) * H + um] : Wi[(int64_t)(gate * H + uk) * Din + col0 + 32 * w + m]);
   }
   *(bf16x8*)(WpB + i * 8) = o;
 }
@@ -408,7 +445,7 @@ __global__ void k_pack_wb(const float* __restrict__ Wo, bf16* __restrict__ WpB) 
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 struct PersistSaves { const bf16* CsF; const bf16* ActF0; const bf16* ActF1; const bf16* HsF; int64_t NU, step_recs; int NW; };   // (also declared in lstm_bf16.hip)
-struct PersistBwdState { bf16* WpB = nullptr; int grid = 0; };
+struct PersistBwdState { bf16* WpB = nullptr; int grid = 0; int packed_mjp = 0; };
 
 // Everything persist_backward() requires of a batch is decided HERE, before the backward has accumulated anything: a batch the launch cannot take
 // (T x N beyond the 32-bit row-block offsets of dA^T: about 4.8 M (path, step) positions at H = 384) trains through the per-step loop instead.
@@ -430,7 +467,10 @@ void persist_bwd_release(void*& st) {
 }
 
 // dA_t (row-major and transposed) for all steps + the bias gradient, from the persistent forward's saves; ws.dS holds d loss / d S[:, cid]
-void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16 /* nullable: no row-major copy */, bf16* dAT16, int64_t Np) {
+// dXe (nullable): the launch also forms the entity slice of dx, [T][N][de] fp32 (de = 128 columns from dt on) -- persist_bwd_dxe_ok() says whether it can
+bool persist_bwd_dxe_ok(const kprn_handle* h) { return h->cfg.de == pb::DE && h->D >= h->cfg.dt + pb::DE; }
+void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16 /* nullable: no row-major copy */, bf16* dAT16, int64_t Np,
+                      float* dXe) {
   hipStream_t strm = h->stream;
   PersistBwdState* p = (PersistBwdState*)st;
   if (!p) {
@@ -441,22 +481,26 @@ void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSa
     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     p->grid = ncu;
     void* q = nullptr;
-    hipError_t e = kprn_dev_malloc(&q, (size_t)pb::NW * pb::FR * 1024 + 64);
+    hipError_t e = kprn_dev_malloc(&q, (size_t)pb::NW * pb::FRX * 1024 + 64);
     if (e != hipSuccess) throw KprnError{KPRN_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e)};
     p->WpB = (bf16*)q;
     repack = true;
   }
-  if (repack) {
-    const int64_t total = (int64_t)pb::NW * pb::FR * 64;
-    hipLaunchKernelGGL(pb::k_pack_wb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, strm, h->dense + h->layer[0].Wo, p->WpB);
+  const bool dxe = dXe != nullptr;
+  KPRN_REQUIRE(!dxe || (persist_bwd_dxe_ok(h) && !dA16), KPRN_E_ARG, "persistent BPTT: dx_e in the launch needs de = 128 and no row-major dA");
+  const int mjp = dxe ? pb::MJX : pb::MJ;
+  if (repack || p->packed_mjp != mjp) {
+    const int64_t total = (int64_t)pb::NW * pb::NCH * pb::KSC * mjp * 64;
+    hipLaunchKernelGGL(pb::k_pack_wb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, strm, h->dense + h->layer[0].Wo, h->dense + h->layer[0].Wi, h->D, h->cfg.dt, mjp, p->WpB);
     HIP_TRY(hipGetLastError());
+    p->packed_mjp = mjp;
   }
   pb::BArgs a;
   memset(&a, 0, sizeof(a));
   a.A0 = (const bf16x8*)sv.ActF0; a.A1 = (const bf16x8*)sv.ActF1; a.cF = (const bf16x4*)sv.CsF;
   a.NU = sv.NU; a.step_recs = sv.step_recs;
   a.dS = h->ws.dS; a.Wc = h->dense + h->off_outW + (int64_t)cid * pb::H;
-  a.WpB = p->WpB; a.dA = dA16; a.dAT = dAT16; a.gbias = h->g_dense + h->layer[0].bi;
+  a.WpB = p->WpB; a.dA = dA16; a.dAT = dAT16; a.dXe = dXe; a.gbias = h->g_dense + h->layer[0].bi;
   a.N = N; a.Np = Np; a.ldT = (int64_t)T * Np; a.T = T;
   // tile height: 64 rows, one workgroup per CU (default), or 32 rows, two workgroups per CU (KPRN_BPTT_NPT=1: each weight fragment then serves one
   // path tile only -- twice the weight bytes through the L1 path -- for two independent barrier domains per CU)
@@ -470,6 +514,7 @@ void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSa
   typedef void (*Kern)(pb::BArgs);
   Kern k = dA16 ? (Kern)pb::k_lstm16_bwd_persist<2, 0> : (Kern)pb::k_lstm16_bwd_persist<2, 2>;   // (2: no row-major copy -- dx reads the transposed image)
   if (npt == 1) k = dA16 ? (Kern)pb::k_lstm16_bwd_persist<1, 0> : (Kern)pb::k_lstm16_bwd_persist<1, 2>;
+  if (dxe) { KPRN_REQUIRE(npt == 2, KPRN_E_ARG, "persistent BPTT: dx_e in the launch is built for 64-row tiles"); k = h->bf16_bptt_dxe == 16 ? (Kern)pb::k_lstm16_bwd_persist<2, 2, 16> : (Kern)pb::k_lstm16_bwd_persist<2, 2, 8>; }
 #ifdef KPRN_PERSIST_VARIANTS
   // measurement builds (scripts/gpu_persist_knockouts.py bwd): KPRN_PERSIST_BWD_DBG = knock-out mask
   if (const char* e = KPRN_DEV_ENV("KPRN_PERSIST_BWD_DBG")) {

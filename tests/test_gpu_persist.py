@@ -295,9 +295,23 @@ def test_small_table_gradients_from_the_merged_dw_product_match_the_dx_route(pai
     lay = eng.layout()
     loss1 = eng.backward(b, 1)
     fam = eng.profile_get()
-    assert "gemm_bwd_dw_merged" in fam and "small_tables_finish" in fam and "gemm_i2g_bwd_dx_e" in fam, sorted(fam)
+    # (default: the entity slice of dx is formed inside the persistent BPTT launch -- a fourth result tile per wave -- so no dx product launch at all)
+    assert "gemm_bwd_dw_merged" in fam and "small_tables_finish" in fam and "gemm_i2g_bwd_dx_e" not in fam and "gemm_i2g_bwd_dx" not in fam, sorted(fam)
     assert "embed_scatter" not in fam and "gemm_i2g_bwd_dw" not in fam
     g1 = eng.get_flat_grads().astype(np.float64)
+    # the other two forms of dx_e: the BPTT launch with the deeper weight ring, and the separate k-major-A product
+    for mode in ("16", "0"):
+        eng.set_option("bf16_bptt_dxe", mode)
+        eng.profile_reset()
+        eng.profile(True)
+        assert eng.backward(b, 1) == loss1
+        assert ("gemm_i2g_bwd_dx_e" in eng.profile_get()) == (mode == "0")
+        gm = eng.get_flat_grads().astype(np.float64)
+        for nm, (off, shp) in lay.items():
+            n = int(np.prod(shp))
+            a, r = gm[off:off + n], g1[off:off + n]
+            assert np.max(np.abs(a - r)) < 2e-5 * max(1e-30, np.max(np.abs(r))), (mode, nm, float(np.max(np.abs(a - r))), float(np.max(np.abs(r))))
+    eng.set_option("bf16_bptt_dxe", "8")
     eng.set_option("bf16_small_tables", "0")
     eng.profile_reset()
     eng.profile(True)
