@@ -307,7 +307,7 @@ static const bf16* zero16() {   // 16 zero bytes on the device: the source of ev
 }
 namespace gx { struct XArgs; template <bool ACCUM> __global__ void k_gemm16x(XArgs a); }
 static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K, bool accumulate,
-                    int split_k);
+                    int split_k, int n_lo = 0, int64_t k_lo = 0, int sx_min = 1);
 
 // C[M][N] (fp32) = or += A[M][K] B[N][K]^T; K, lda, ldb multiples of 8 elements, 16-byte aligned pointers
 static void gemm16(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K,
@@ -345,6 +345,7 @@ constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
 struct XArgs {
   const bf16* A; int64_t lda; const bf16* B; int64_t ldb; float* C; int64_t ldc; int64_t M; int N; int64_t K;
   int64_t kchunk; int nsplit; int64_t mtiles; int ntiles; const bf16* zero;   // zero: 16 zero bytes in global memory (source of every out-of-range piece)
+  int n_lo; int64_t k_lo;   // rows n >= n_lo of B are known to be ZERO for k < k_lo (the merged dW product's h_{t-1}^T block has no step -1): column tiles from n_lo on start at k_lo
 };
 __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
@@ -377,8 +378,9 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
   }
   const int64_t m0 = mt_idx * BM;
   const int n0 = nt_idx * BN;
-  const int64_t k_beg = split_idx * a.kchunk;
+  int64_t k_beg = split_idx * a.kchunk;
   const int64_t k_end = (k_beg + a.kchunk < a.K) ? k_beg + a.kchunk : a.K;
+  if (a.k_lo > 0 && n0 >= a.n_lo && k_beg < a.k_lo) k_beg = a.k_lo;   // (k_lo is a multiple of 8: pieces stay 16-byte aligned)
   const int nch = (k_end > k_beg) ? (int)((k_end - k_beg + BK - 1) / BK) : 0;
   if (nch == 0) return;
   // this lane's share of a chunk's 48 DMA instructions (8 rows x 128 bytes each): instruction q = wave + 8 i covers tile rows 8 q .. 8 q + 7
@@ -696,16 +698,17 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16y(XArgs a) {
 }  // namespace gx
 
 static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K, bool accumulate,
-                    int split_k) {
+                    int split_k, int n_lo, int64_t k_lo, int sx_min) {
   static const bool off = KPRN_DEV_ENV("KPRN_BF16_GEMM") && KPRN_DEV_ENV("KPRN_BF16_GEMM")[0] == 'o';   // "old": k_gemm16 everywhere (A/B measurements, tests)
   if (off || M < gx::BM || N < gx::BN || (K & 7) || (lda & 7) || (ldb & 7)) return false;
   gx::XArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero = zero16();
+  a.n_lo = n_lo; a.k_lo = k_lo;
   // KPRN_BF16_GEMM=y: 256 x 192 tiles where they divide N (configs[3]: N = 384).  Measured equal to the 256 x 128 kernel on dx / dh (0.743 : 0.750,
   // 0.110 : 0.107 ms) and slower on the split-K dW (12 tiles deal worse over 8 XCDs than 18): opt-in, kept as the record of that measurement
   static const bool want_y = KPRN_DEV_ENV("KPRN_BF16_GEMM") && KPRN_DEV_ENV("KPRN_BF16_GEMM")[0] == 'y';
-  const bool y = want_y && (N % gx::YBN) == 0;
+  const bool y = want_y && (N % gx::YBN) == 0 && k_lo == 0;
   const int bn = y ? gx::YBN : gx::BN, bk = y ? gx::YBK : gx::BK;
   a.mtiles = (M + gx::BM - 1) / gx::BM; a.ntiles = (N + bn - 1) / bn;
   if (split_k < 1 || !accumulate) split_k = 1;
@@ -718,7 +721,7 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
     static const int s_env = KPRN_DEV_ENV("KPRN_GEMM16_SX") ? atoi(KPRN_DEV_ENV("KPRN_GEMM16_SX")) : 0;   // (measurement)
     int best = 1;
     double best_t = 1e30;
-    for (int sx = 1; sx <= 8 && sx * 8 <= std::max(split_k, 8); ++sx) {
+    for (int sx = std::max(1, std::min(sx_min, 8)); sx <= 8 && sx * 8 <= std::max(split_k, 8); ++sx) {
       const double t = (double)((tiles * sx + 31) / 32) / sx;
       if (t < best_t - 1e-9) { best_t = t; best = sx; }
     }
@@ -1626,7 +1629,10 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
         ProfScope ps(h, "gemm_bwd_dw_merged");   // Ct [4H][NZ] = dA^T [x_e^T | S^T | h_{t-1}^T]^T, split-K
         HIP_TRY(hipMemsetAsync(s->Ctmp, 0, (size_t)G4 * NZ * sizeof(float), strm));
         const int split = (int)std::min<int64_t>(1024, std::max<int64_t>(1, TN / 4096));
-        gemm16(strm, s->dAT16, TNp, s->ZT16, TNp, s->Ctmp, NZ, G4, NZ, TNp, true, nullptr, split);
+        // (h_{t-1}^T has no step -1: its column tiles skip the K ranges of step block 0 -- a tenth of the launch's workgroups; 8 K ranges per XCD so that
+        //  whole workgroups fall into that block)
+        if (!gemm16x(strm, s->dAT16, TNp, s->ZT16, TNp, s->Ctmp, NZ, G4, NZ, TNp, true, split, c.de + 128, Np, 8))
+          gemm16(strm, s->dAT16, TNp, s->ZT16, TNp, s->Ctmp, NZ, G4, NZ, TNp, true, nullptr, split);
       }
       {
         ProfScope ps(h, "small_tables_finish");
