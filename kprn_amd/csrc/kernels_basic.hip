@@ -1275,6 +1275,78 @@ static bool table_grad_lds(hipStream_t s, const int32_t* idx, int64_t N, int T, 
   return true;
 }
 
+// ---- small tables (kprn_internal.h has the identity) -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_onehot_cols(const int32_t* __restrict__ idx, int64_t NT, int64_t N, int T, int F, int Vr, int Vt, float* __restrict__ X, int64_t ldx,
+                                                     int col0, int ns) {
+  const int nq = ns >> 2;   // 16-byte pieces per position
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= NT * nq) return;
+  const int64_t pos = g / nq;   // time-major position t N + n
+  const int q = (int)(g - pos * nq);
+  const int64_t t = pos / N, n = pos - t * N;
+  const int32_t* id = idx + (n * T + t) * F;
+  const int r = id[F - 1] - 1, y = Vr + id[F - 3] - 1;
+  float4 v;
+  v.x = (4 * q == r || 4 * q == y) ? 1.f : 0.f;
+  v.y = (4 * q + 1 == r || 4 * q + 1 == y) ? 1.f : 0.f;
+  v.z = (4 * q + 2 == r || 4 * q + 2 == y) ? 1.f : 0.f;
+  v.w = (4 * q + 3 == r || 4 * q + 3 == y) ? 1.f : 0.f;
+  float* dst = X + pos * ldx + col0 + 4 * q;
+  dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;   // (col0 need not be 16-byte aligned: dt - ns for any dt)
+}
+void onehot_cols(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int Vr, int Vt, float* X, int64_t ldx, int col0, int ns) {
+  const int64_t work = N * T * (ns >> 2);
+  if (work <= 0) return;
+  hipLaunchKernelGGL(k_onehot_cols, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, idx, N * T, N, T, F, Vr, Vt, X, ldx, col0, ns);
+  HIP_TRY(hipGetLastError());
+}
+// workgroups [0, GH): one gate row each; behind them one (table row, K slice) each (see lstm_bf16.hip k_small_tables_finish: the same kernel on fp32 weights)
+__global__ __launch_bounds__(256) void k_small_tables_finish_f32(const float* __restrict__ Ct, int ns, int GH, int Din, int dt, int de, int dr, int Vt, int Vr,
+                                                                 const float* __restrict__ Wt, const float* __restrict__ Wr, const float* __restrict__ Wi,
+                                                                 float* __restrict__ gWi, float* __restrict__ gWt, float* __restrict__ gWr) {
+  __shared__ float g[128];
+  const int tid = threadIdx.x, NZ = ns + de;
+  if ((int)blockIdx.x < GH) {
+    const int k = blockIdx.x;
+    const float* row = Ct + (int64_t)k * NZ;
+    if (tid < ns) g[tid] = row[tid];
+    __syncthreads();
+    for (int j = tid; j < Din; j += 256) {
+      float v = 0.f;
+      if (j < dt) {
+        for (int y = 0; y < Vt; ++y) v += g[Vr + y] * Wt[y * dt + j];
+      } else if (j < dt + de) {
+        v = row[ns + j - dt];
+      } else {
+        const int jj = j - dt - de;
+        for (int r = 0; r < Vr; ++r) v += g[r] * Wr[r * dr + jj];
+      }
+      gWi[(int64_t)k * Din + j] += v;
+    }
+    return;
+  }
+  // one workgroup per table row, no atomics: two interleaved K sub-sums per column, added in a fixed order (the optimiser tests compare runs BITWISE)
+  __shared__ float red[256];
+  const int r = (int)blockIdx.x - GH;
+  const bool rel = r < Vr;
+  const int w = rel ? dr : dt, col0 = rel ? dt + de : 0;
+  const int j = tid & 127, sb = tid >> 7;
+  for (int j0 = 0; j0 < w; j0 += 128) {
+    const int jj = j0 + j, jc = jj < w ? jj : w - 1;
+    float acc = 0.f;
+    for (int k = sb; k < GH; k += 2) acc += Ct[(int64_t)k * NZ + r] * Wi[(int64_t)k * Din + col0 + jc];
+    red[tid] = acc;
+    __syncthreads();
+    if (sb == 0 && jj < w) (rel ? gWr + (int64_t)r * dr : gWt + (int64_t)(r - Vr) * dt)[jj] += red[tid] + red[tid + 128];
+    __syncthreads();
+  }
+}
+void small_tables_finish(hipStream_t s, const float* Ct, int ns, int GH, int Din, int dt, int de, int dr, int Vt, int Vr, const float* Wt, const float* Wr,
+                         const float* Wi, float* gWi, float* gWt, float* gWr) {
+  hipLaunchKernelGGL(k_small_tables_finish_f32, dim3((unsigned)(GH + Vr + Vt)), dim3(256), 0, s, Ct, ns, GH, Din, dt, de, dr, Vt, Vr, Wt, Wr, Wi, gWi, gWt, gWr);
+  HIP_TRY(hipGetLastError());
+}
+
 void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* dX, int dt, int de, int dr, int Vt, int Vr,
                    float* gWt, float* gWe, float* gWr, bool skip_entity) {
   if (N <= 0) return;

@@ -489,6 +489,53 @@ static void zero_grads(kprn_handle* h) {
   h->dense_grads_clean = true;
 }
 
+// Layer 0 of the generic LSTM / rnn backward through the small-table identity (kprn_internal.h kk::onehot_cols): dx for the entity slice only, ONE dW
+// product over [S | x_e] (the one-hot selectors are written over the last ns type columns of the saved step input, next to the entity columns),
+// the type / relation blocks of gW_i2g and both table gradients from G.  GH = rows of W_i2g (4H FastLSTM, H rnn).  Returns false when the shape is not
+// covered (the caller then takes the dx product + table-gradient route).
+static int small_tables_ns(const kprn_handle* h, const kprn_batch* b) {
+  const kprn_config& c = h->cfg;
+  const int ns = (c.Vr + c.Vt + 3) & ~3;
+  const bool ok = h->small_tables && c.num_types == 1 && c.rnn_type != 2 && ns <= c.dt && ns <= 128 && c.de > 0 && c.dr > 0 && b->key_sorted != nullptr && !b->tile_k &&
+                  b->F >= 3;
+  return ok ? ns : 0;
+}
+static void backward_layer0_small_tables(kprn_handle* h, const kprn_batch* b, int ns, int GH, int split, bool bf) {
+  const kprn_config& c = h->cfg;
+  Workspace& w = h->ws;
+  const int D = h->D, T = b->T;
+  const int64_t N = (int64_t)b->B * b->P, TN = (int64_t)T * N;
+  hipStream_t s = h->stream;
+  float* gd = h->g_dense;
+  const float* Wi = h->dense + h->layer[0].Wi;
+  const int NZ = ns + c.de;
+  if ((int64_t)GH * NZ > h->st_ctmp_cap) {
+    HIP_TRY(hipStreamSynchronize(s));
+    dfree(h->st_ctmp);
+    h->st_ctmp = dalloc<float>((int64_t)GH * NZ);
+    h->st_ctmp_cap = (int64_t)GH * NZ;
+  }
+  {
+    ProfScope ps(h, "gemm_bwd_dw_merged");   // Ct [GH][ns + de] = dA^T [S | x_e]
+    kk::onehot_cols(s, b->idx, N, T, b->F, c.Vr, c.Vt, w.X, D, c.dt - ns, ns);
+    HIP_TRY(hipMemsetAsync(h->st_ctmp, 0, (size_t)GH * NZ * sizeof(float), s));
+    gemm::run(s, w.dA, 1, GH, w.X + (c.dt - ns), D, 1, h->st_ctmp, NZ, GH, NZ, TN, true, nullptr, split, bf);
+  }
+  {
+    ProfScope ps(h, "gemm_i2g_bwd_dx_e");    // dx_e [T N][de] = dA W_i2g[:, entity columns], compact
+    gemm::run(s, w.dA, GH, 1, Wi + c.dt, D, 1, w.dIn, c.de, TN, c.de, GH, false, nullptr, 1, bf);
+  }
+  {
+    ProfScope ps(h, "small_tables_finish");
+    kk::small_tables_finish(s, h->st_ctmp, ns, GH, D, c.dt, c.de, c.dr, c.Vt, c.Vr, h->dense + h->off_Wt, h->dense + h->off_Wr, Wi, gd + h->layer[0].Wi, gd + h->off_Wt,
+                            gd + h->off_Wr);
+  }
+  {
+    ProfScope ps(h, "entity_grad");
+    bidx::entity_grad(s, w.dIn, /*frag_order=*/0, b->key_sorted, b->pos_sorted, b->n_index, N, T, c.de, 0, c.de, c.Ve, h->g_We);
+  }
+}
+
 static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
   const kprn_config& c = h->cfg;
   const bool bf = c.compute_dtype == 1;
@@ -497,6 +544,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
   const int64_t N = (int64_t)b->B * b->P;
   hipStream_t s = h->stream;
   float* gd = h->g_dense;
+  const int st_ns = small_tables_ns(h, b);   // > 0: layer 0's input gradients through the small-table identity
   {
     ProfScope ps(h, "head_bwd");
     const float* hT = w.Hs + ((int64_t)(L - 1) * T + (T - 1)) * N * H;
@@ -589,12 +637,16 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
         gemm::run(s, w.dA + (int64_t)N * H, 1, H, hs, H, 1, gd + h->layer[l].Wo, H, H, H, (int64_t)(T - 1) * N, true, nullptr, split, bf);
       }
       {
-        ProfScope ps(h, "gemm_i2g_bwd_dw");
-        gemm::run(s, w.dA, 1, H, in, Din, 1, gd + h->layer[l].Wi, Din, H, Din, (int64_t)T * N, true, nullptr, split, bf);
-      }
-      {
         ProfScope ps(h, "bias_colsum");  // i2h.bias and h2h.bias see the same gradient (both are added to every pre-activation)
         kk::col_sum_add(s, w.dA, (int64_t)T * N, H, gd + h->layer[l].bi, 0, gd + h->layer[l].bo);   // (one pass over dA for both)
+      }
+      if (l == 0 && st_ns > 0) {
+        backward_layer0_small_tables(h, b, st_ns, H, split, bf);
+        return;
+      }
+      {
+        ProfScope ps(h, "gemm_i2g_bwd_dw");
+        gemm::run(s, w.dA, 1, H, in, Din, 1, gd + h->layer[l].Wi, Din, H, Din, (int64_t)T * N, true, nullptr, split, bf);
       }
       {
         ProfScope ps(h, "gemm_i2g_bwd_dx");
@@ -633,12 +685,16 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       gemm::run(s, w.dA + (int64_t)N * 4 * H, 1, 4 * H, hs, H, 1, gd + h->layer[l].Wo, H, 4 * H, H, (int64_t)(T - 1) * N, true, nullptr, split, bf);
     }
     {
-      ProfScope ps(h, "gemm_i2g_bwd_dw");
-      gemm::run(s, w.dA, 1, 4 * H, in, Din, 1, gd + h->layer[l].Wi, Din, 4 * H, Din, (int64_t)T * N, true, nullptr, split, bf);
-    }
-    {
       ProfScope ps(h, "bias_colsum");
       kk::col_sum_add(s, w.dA, (int64_t)T * N, 4 * H, gd + h->layer[l].bi);
+    }
+    if (l == 0 && st_ns > 0) {
+      backward_layer0_small_tables(h, b, st_ns, 4 * H, split, bf);
+      return;
+    }
+    {
+      ProfScope ps(h, "gemm_i2g_bwd_dw");
+      gemm::run(s, w.dA, 1, 4 * H, in, Din, 1, gd + h->layer[l].Wi, Din, 4 * H, Din, (int64_t)T * N, true, nullptr, split, bf);
     }
     {
       ProfScope ps(h, "gemm_i2g_bwd_dx");
@@ -913,7 +969,7 @@ void kprn_destroy(kprn_handle* h) {
   if (h->feed_stream) { hipStreamSynchronize(h->feed_stream); hipStreamDestroy(h->feed_stream); hipEventDestroy(h->ev_feed_fork); }
   if (h->feed_scratch) { hipFree(h->feed_scratch); h->feed_scratch = nullptr; }
   dp_release(h);
-  dfree(h->S2); dfree(h->sel2);
+  dfree(h->S2); dfree(h->sel2); dfree(h->st_ctmp);
   fused::release(h);
   bf16p::release(h);
   if (h->bidx_scratch) { hipFree(h->bidx_scratch); h->bidx_scratch = nullptr; }
@@ -2253,6 +2309,10 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // its tiling from this option.)
     join_score(h);
     h->small_tiles_on = atoi(value) != 0;
+  } else if (strcmp(key, "small_tables") == 0) {
+    // generic fp32 pipelines: layer 0's type / relation gradients from G = dA^T [S_r | S_t] ("1", default) or from the full dx product + the
+    // table-gradient launch ("0": the A/B reference)
+    h->small_tables = atoi(value) != 0;
   } else if (strcmp(key, "bf16_bptt_dxe") == 0) {
     // bf16 pipeline with "bf16_small_tables": the entity slice of dx is formed INSIDE the persistent BPTT launch (a fourth result tile per wave; value =
     // depth of its weight ring, 8 (default) or 16) or by its own product launch reading dA^T once more ("0")

@@ -206,6 +206,8 @@ struct kprn_handle {
   int dropin_next_train = 0, dropin_next_score = 0, dropin_last = 0;
   bool score_pending = false;     // a pass is (possibly) still running on score_stream
   int bf16_bptt_dxe = 8;          // option "bf16_bptt_dxe": the persistent BPTT launch also forms dx for the entity slice (weight ring depth 8 | 16; 0: a separate product)
+  bool small_tables = true;       // option "small_tables": generic fp32 pipelines (LSTM / rnn cells) form the layer-0 type / relation gradients from G (kprn_api.hip backward_generic)
+  float* st_ctmp = nullptr; int64_t st_ctmp_cap = 0;   //   ... its [GH][ns + de] product result
   bool bf16_small_tables = true;  // option "bf16_small_tables": configs[3] backward forms the type / relation gradients from G = dA^T [S_r | S_t] (lstm_bf16.hip)
   bool small_tiles_on = true;     // option "small_tiles": batches of <= 8 192 paths run on tiles of one 16-row m-tile (no identical-prefix plan)
   float score_split = 0.f;        // option: fraction of a scoring pass's tiles deferred to kprn_forward_batch_async_rest
@@ -267,6 +269,15 @@ void zero_pad3(hipStream_t s, float* a, int na, float* b, int nb, float* c, int 
 void head_bwd(hipStream_t s, const float* dS, const float* hT, const float* Wout, int64_t N, int H, int cid, float* dH, float* gWout, float* gbout);
 void embed_scatter(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int nT, const float* dX /*[T][N][D]*/, int dt, int de, int dr,
                    int Vt, int Vr, float* gWt, float* gWe, float* gWr, bool skip_entity = false);
+// Small tables (generic fp32 pipelines; lstm_bf16.hip has the bf16 twin and the derivation): with x = [Wt[type] | We[entity] | Wr[relation]] the
+// type / relation blocks of dW_i2g and both table gradients follow from G = dA^T [S_r | S_t] (one-hot selectors):
+//   dW_i2g[:, relation cols] = G_r Wr,  dWr = G_r^T W_i2g[:, relation cols]   (likewise for the type table)
+// onehot_cols: X[(t N + n) ldx + col0 + j] = 1 iff j is the position's relation (j < Vr) or Vr + its type; j < ns (the columns [col0, col0 + ns) of the
+// saved step input are overwritten in place: the backward reads X only as the dW product's operand).
+void onehot_cols(hipStream_t s, const int32_t* idx, int64_t N, int T, int F, int Vr, int Vt, float* X, int64_t ldx, int col0, int ns);
+// Ct [GH][ns + de] = dA^T [S | x_e] -> gWi[:, entity cols] += Ct[:, ns:], gWi[:, type / relation cols] += G Wt / G Wr, gWt += G_t^T Wi_t, gWr += G_r^T Wi_r
+void small_tables_finish(hipStream_t s, const float* Ct, int ns, int GH, int Din, int dt, int de, int dr, int Vt, int Vr, const float* Wt, const float* Wr,
+                         const float* Wi, float* gWi, float* gWt, float* gWr);
 void sumsq(hipStream_t s, const float* x, int64_t n, float* out);
 void sumsq_rows(hipStream_t s, const float* G, const int32_t* rows, const int32_t* count, int d, float* out);
 // dense optimiser over a contiguous span; scale_src: device float norm2 -> clip factor computed in-kernel

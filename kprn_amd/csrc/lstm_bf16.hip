@@ -1149,13 +1149,12 @@ __global__ __launch_bounds__(256) void k_onehot_T(const int32_t* __restrict__ id
   }
 }
 // What the merged product leaves in Ct [4H][NZ] (NZ = de + 128 + H: entity columns | G | recurrent columns) goes where the optimiser reads it (all +=):
-// workgroups [0, 4H): one gate row each -- gW_i2g[k][:] = [G_t Wt | Ct entity block | G_r Wr], gW_o2g[k][:]; workgroups behind them: one (table row,
-// K slice) each -- gWr[r][:] += sum_k G[k][r] W_i2g[k][relation columns] (atomic over the slices), likewise gWt.
+// workgroups [0, 4H): one gate row each -- gW_i2g[k][:] = [G_t Wt | Ct entity block | G_r Wr], gW_o2g[k][:]; workgroups behind them: one table row
+// each -- gWr[r][:] += sum_k G[k][r] W_i2g[k][relation columns] (no atomics: a fixed summation order), likewise gWt.
 struct FinArgs {
   const float* Ct; int NZ, G4, Din, H, dt, de, dr, Vt, Vr;
   const bf16* Wt16; const bf16* Wr16; const bf16* Wi16;
   float* gWi; float* gWo; float* gWt; float* gWr;
-  int kslices;
 };
 __global__ __launch_bounds__(256) void k_small_tables_finish(FinArgs a) {
   __shared__ float g[128];
@@ -1181,18 +1180,19 @@ __global__ __launch_bounds__(256) void k_small_tables_finish(FinArgs a) {
     for (int j = tid; j < a.H; j += 256) a.gWo[(int64_t)k * a.H + j] += row[a.de + 128 + j];
     return;
   }
-  const int bi = (int)blockIdx.x - a.G4;
-  const int r = bi / a.kslices, ks = bi - r * a.kslices;   // one-hot row r: relation r (r < Vr) or type r - Vr
+  // one workgroup per one-hot row r (relation r, or type r - Vr), no atomics: two interleaved K sub-sums per column added in a fixed order
+  __shared__ float red[256];
+  const int r = (int)blockIdx.x - a.G4;
   const bool rel = r < a.Vr;
   const int w = rel ? a.dr : a.dt, col0 = rel ? a.dt + a.de : 0;
-  const int kper = (a.G4 + a.kslices - 1) / a.kslices;
-  const int k0 = ks * kper, k1 = k0 + kper < a.G4 ? k0 + kper : a.G4;
-  const int j = tid & 127, sub = tid >> 7;
+  const int j = tid & 127, sb = tid >> 7;
   const int jc = j < w ? j : w - 1;   // (w <= 128; idle lanes re-read the last column: loads stay unconditional)
   float acc = 0.f;
 #pragma unroll 8
-  for (int k = k0 + sub; k < k1; k += 2) acc += a.Ct[(int64_t)k * a.NZ + a.de + r] * (float)a.Wi16[(int64_t)k * a.Din + col0 + jc];
-  if (j < w) unsafeAtomicAdd((rel ? a.gWr + (int64_t)r * a.dr : a.gWt + (int64_t)(r - a.Vr) * a.dt) + j, acc);
+  for (int k = sb; k < a.G4; k += 2) acc += a.Ct[(int64_t)k * a.NZ + a.de + r] * (float)a.Wi16[(int64_t)k * a.Din + col0 + jc];
+  red[tid] = acc;
+  __syncthreads();
+  if (sb == 0 && j < w) (rel ? a.gWr + (int64_t)r * a.dr : a.gWt + (int64_t)(r - a.Vr) * a.dt)[j] += red[tid] + red[tid + 128];
 }
 
 // ---- state + orchestration --------------------------------------------------------------------------------------------------
@@ -1641,8 +1641,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
         fa.Ct = s->Ctmp; fa.NZ = NZ; fa.G4 = G4; fa.Din = Din; fa.H = H; fa.dt = c.dt; fa.de = c.de; fa.dr = c.dr; fa.Vt = c.Vt; fa.Vr = c.Vr;
         fa.Wt16 = s->dense16 + h->off_Wt; fa.Wr16 = s->dense16 + h->off_Wr; fa.Wi16 = s->dense16 + h->layer[l].Wi;
         fa.gWi = gd + h->layer[l].Wi; fa.gWo = gd + h->layer[l].Wo; fa.gWt = gd + h->off_Wt; fa.gWr = gd + h->off_Wr;
-        fa.kslices = 8;
-        hipLaunchKernelGGL(k_small_tables_finish, dim3((unsigned)(G4 + (c.Vr + c.Vt) * fa.kslices)), dim3(256), 0, strm, fa);
+        hipLaunchKernelGGL(k_small_tables_finish, dim3((unsigned)(G4 + c.Vr + c.Vt)), dim3(256), 0, strm, fa);
         HIP_TRY(hipGetLastError());
       }
       if (overlap) {

@@ -234,3 +234,41 @@ def test_ids_beyond_2_pow_24_gather_bit_exact():
     idx2[3, 0, 0, 1] = 1 << 24          # the float32 image of 2^24 + 1
     assert eng.forward(eng.batch(idx2), 1)["probs"][3] != probs[3]
     eng.close()
+
+
+@pytest.mark.parametrize("kind,dims,L,Vr", [("lstm", (64, 64, 64, 192), 2, 9), ("rnn", (50, 100, 50, 250), 1, 9), ("lstm", (128, 128, 128, 384), 1, 100), ("lstm", (16, 32, 16, 64), 2, 9)])
+def test_generic_small_table_gradients_match_the_dx_route(kind, dims, L, Vr):
+    """Round 5, generic fp32 pipelines: layer 0's type / relation gradients (tables and the matching column blocks of W_i2g) from G = dA^T [S_r | S_t]
+    -- the one-hot selectors written over the last type columns of the saved step input, ONE dW product over [S | x_e], dx for the entity slice only
+    (kprn_api.hip backward_layer0_small_tables).  Same engine, same batch: against the full dx product + table-gradient launches
+    ("small_tables" = 0) every gradient agrees to fp32 reordering; against the float64 oracle inside the fp32 bar."""
+    dt, de, dr, H = dims
+    rt = 1 if kind == "rnn" else 0
+    eng = _ffi.Engine(6, 900, Vr, dt, de, dr, H, L, rnn_type=rt, use_relu=1, param_init=0.06)
+    eng.set_option("impl", "generic")
+    o64 = Oracle(make_cfg(Vt=6, Ve=900, Vr=Vr, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=rt, use_relu=1), np.float64)
+    theta = o64.init_params(17, 0.06).astype(np.float32).astype(np.float64)
+    if rt:
+        o64.zero_pad(theta)
+    eng.set_flat_params(theta.astype(np.float32))
+    idx, labels = synth.make_paths(170, 3, 6, Ve=900, Vr=Vr, seed=33)
+    b = eng.batch(idx, labels)
+    eng.profile(True)
+    loss1 = eng.backward(b, 1)
+    fam = eng.profile_get()
+    assert "small_tables_finish" in fam and "gemm_bwd_dw_merged" in fam and "embed_scatter" not in fam, sorted(fam)
+    g1 = eng.get_flat_grads().astype(np.float64)
+    eng.set_option("small_tables", "0")
+    eng.profile_reset()
+    eng.profile(True)
+    loss0 = eng.backward(b, 1)
+    assert "embed_scatter" in eng.profile_get() and "small_tables_finish" not in eng.profile_get()
+    g0 = eng.get_flat_grads().astype(np.float64)
+    assert loss0 == loss1
+    _, og, _ = o64.forward_backward(theta, idx, labels)
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        a, r = g1[off:off + n], g0[off:off + n]
+        assert np.max(np.abs(a - r)) < 2e-5 * max(1e-30, np.max(np.abs(r))), (nm, float(np.max(np.abs(a - r))), float(np.max(np.abs(r))))
+        assert rel_inf(a, og[off:off + n]) < GRAD_RTOL, (nm, rel_inf(a, og[off:off + n]))
+    eng.close()
