@@ -340,6 +340,13 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b, bool save) {
         ProfScope ps(h, "rnn_mask");
         kk::row_nonzero(s, in, (int64_t)T * N, Din, mask);  // layer l > 1: the mask follows the ACTUAL input rows (h^{l-1}_t), as MaskZero does
       }
+      if (stepk && h->persist_layers && lp32::supported(1, N, Din, H, h->persist_layers == 2)) {
+        // all T steps of the layer in ONE persistent launch: h never leaves the CU, weights stream L2 -> LDS by DMA (layer_f32_persist.hip)
+        ProfScope ps(h, "rnn_layer_fwd");
+        lp32::forward_layer(s, 1, in, N, T, Din, H, h->dense + h->layer[l].Wi, h->dense + h->layer[l].Wo, h->dense + h->layer[l].bi, h->dense + h->layer[l].bo, hs,
+                            nullptr, pre, mask, c.use_relu == 1 ? 1 : 0, save, /*write_all_h=*/true);
+        continue;
+      }
       if (stepk) {
         // i2h, h2h, both biases, the activation and MaskZero in one launch per step (gemm_tiled.hip)
         ProfScope ps(h, "rnn_step_fwd");
@@ -371,6 +378,12 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b, bool save) {
     const float* Wi = h->dense + h->layer[l].Wi;
     const float* bi = h->dense + h->layer[l].bi;
     const float* Wo = h->dense + h->layer[l].Wo;
+    if (!bf && !no_step && h->persist_layers && lp32::supported(0, N, Din, H, h->persist_layers == 2)) {
+      // all T steps of the layer in ONE persistent launch: h and c never leave the CU (layer_f32_persist.hip)
+      ProfScope ps(h, "lstm_layer_fwd");
+      lp32::forward_layer(s, 0, in, N, T, Din, H, Wi, Wo, bi, nullptr, hs, cs, act, nullptr, 0, save, /*write_all_h=*/l < L - 1);
+      continue;
+    }
     if (!bf && !no_step && gemm::step_supported(in, Din, Din, hs, H, H, Wi, Wo, N)) {
       // one launch per step: [x_t | h_{t-1}] [W_i2g | W_o2g]^T + b with the FastLSTM cell in the epilogue (gemm_tiled.hip);
       // gate values are written only when a backward follows
@@ -2309,6 +2322,12 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // its tiling from this option.)
     join_score(h);
     h->small_tiles_on = atoi(value) != 0;
+  } else if (strcmp(key, "persist_layers") == 0) {
+    // generic fp32 pipelines: a recurrent layer as ONE persistent launch ("1", default: where layer_f32_persist.hip takes the shape and the batch gives
+    // every CU a tile; "2": at any batch size -- tests) or one launch per step ("0")
+    const int v = atoi(value);
+    KPRN_REQUIRE(v >= 0 && v <= 2, KPRN_E_ARG, "persist_layers must be 0, 1 or 2");
+    h->persist_layers = v;
   } else if (strcmp(key, "small_tables") == 0) {
     // generic fp32 pipelines: layer 0's type / relation gradients from G = dA^T [S_r | S_t] ("1", default) or from the full dx product + the
     // table-gradient launch ("0": the A/B reference)

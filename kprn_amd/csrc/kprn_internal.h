@@ -206,6 +206,7 @@ struct kprn_handle {
   int dropin_next_train = 0, dropin_next_score = 0, dropin_last = 0;
   bool score_pending = false;     // a pass is (possibly) still running on score_stream
   int bf16_bptt_dxe = 8;          // option "bf16_bptt_dxe": the persistent BPTT launch also forms dx for the entity slice (weight ring depth 8 | 16; 0: a separate product)
+  int persist_layers = 1;     // option "persist_layers": generic fp32 LSTM / rnn layers as one persistent launch per layer where the shape allows (layer_f32_persist.hip)
   bool small_tables = true;       // option "small_tables": generic fp32 pipelines (LSTM / rnn cells) form the layer-0 type / relation gradients from G (kprn_api.hip backward_generic)
   float* st_ctmp = nullptr; int64_t st_ctmp_cap = 0;   //   ... its [GH][ns + de] product result
   bool bf16_small_tables = true;  // option "bf16_small_tables": configs[3] backward forms the type / relation gradients from G = dA^T [S_r | S_t] (lstm_bf16.hip)
@@ -490,6 +491,15 @@ void gather_rows(int32_t* dst, const int32_t* src, int64_t row_words, const int6
 void build(const Shape& g, const int32_t* idx, int kcap, int nth, bool want_index, Result* r, int32_t* idx_s, int32_t* perm, int32_t* slot_of, int32_t* tile_k,
            int32_t* pmeta, int32_t* key_sorted, int32_t* pos_sorted, int32_t* uniq, int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3);
 }  // namespace hostfeed
+
+// ---- one recurrent layer, all T steps, as ONE persistent fp32 launch (layer_f32_persist.hip): the wide shapes of the generic pipeline -------------
+namespace lp32 {
+bool supported(int cell /*0 FastLSTM, 1 rnn*/, int64_t N, int Din, int H, bool force /*any N (tests)*/);
+// in [T][N][Din]; hs [T][N][H] (every step when save or write_all_h, else the last one); save: cs + gate values [T][N][4H] (FastLSTM) / pre-activations
+// [T][N][H] (rnn) in the generic backward's layouts; mask [T][N] (rnn: MaskZero)
+void forward_layer(hipStream_t s, int cell, const float* in, int64_t N, int T, int Din, int H, const float* Wi, const float* Wo, const float* bi, const float* bo,
+                   float* hs, float* cs, float* act, const float* mask, int relu, bool save, bool write_all_h);
+}  // namespace lp32
 
 // ---- GEMM (gemm_f32.hip): C[M,N] (+)= A(M,K) * B(K,N), arbitrary strides, fp32 MFMA -----------
 namespace gemm {

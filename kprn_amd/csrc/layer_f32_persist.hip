@@ -1,0 +1,408 @@
+// One recurrent layer of the wide fp32 shapes as ONE persistent launch: "d = 64" reading B (D = H = 192, L = 2: one launch per layer) and
+// run_scripts/config.sh as shipped (rnn, D = 200, H = 250).  gfx950 only.
+//
+// Stands for   nn.Sequencer(nn.FastLSTM(D, H))                                release/songPathRnn/model/OneModel.lua:236,268-274
+//        and   nn.Sequencer(nn.Recurrence(nn.MaskZero(act(i2h x + h2h h))))   release/songPathRnn/model/OneModel.lua:240-266,268-273
+// for all T steps of a 64-path tile, replacing the T per-step launches of gemm_tiled.hip (lstm_step / rnn_step: 0.61 / 0.47 of the fp32-MFMA peak).
+// What those launches spend beside their MFMAs is operand staging -- both operands global -> registers -> masks -> ds_write -> ds_read every 32 k,
+// on VALU slots that fp32 MFMA cannot overlap -- and state through HBM between steps.  Here:
+//   * A workgroup (4 waves, one per SIMD) owns a 64-path tile for t = 0 .. T-1.  [x_t | h_{t-1}] sits in LDS (row pitch KX + KH + 4 floats); h_t is
+//     written there by the cell, c_t stays in registers (FastLSTM), x_{t+1} is fetched into registers under the step's MFMAs.
+//   * The product is taken TRANSPOSED on v_mfma_f32_16x16x4_f32 (weights = first operand): a lane then holds four consecutive hidden units of one
+//     path, all four gates of a unit in the same lane (wave w owns units 64 c + 16 w .. + 15 of chunk c, n-tile q = gate q), so the cell is
+//     lane-local.  rnn: the wave's four n-tiles are four groups of 16 units (64 w + 16 q ..), one chunk covers 256 units.
+//   * Weights never touch the VALU: each wave streams ITS rows L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: a lane's 16 bytes -- four consecutive
+//     k of its weight row -- land in the lane's own slot of a 4 KB group buffer) 2-3 groups of 16 k ahead, and reads them back as B fragments with
+//     one ds_read_b128.  Per group of 16 k a wave issues 4 DMA, 8 ds_read_b128 and 64 MFMAs (2 048 matrix cycles); the fragments of group g + 1 are
+//     read under the MFMAs of group g.  K is padded to whole pairs of groups (pad columns of the LDS tile are zero; a weight row read past its end
+//     delivers the next row's finite values, times zero).
+//   * Saves (training) in the generic backward's own layouts -- gates [T][N][4H], c, h [T][N][H] (rnn: pre-activations [T][N][H]) -- so the
+//     backward of kprn_api.hip runs unchanged.
+#include <string.h>
+
+#include <algorithm>
+
+#include "kprn_internal.h"
+
+namespace lp32 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4u __attribute__((aligned(4)));
+
+constexpr int ROWS = 64, NTHR = 256;
+constexpr int XPMAX = 16;   // 16-byte pieces of a tile row one thread prefetches (Din <= 256)
+constexpr int GB = 4096;    // bytes of one wave's weight group in the DMA ring: 4 n-tiles x 64 lanes x 16 B
+
+struct LArgs {
+  const float* in; int64_t N; int T; int Din; int H;
+  const float* Wi; const float* Wo; const float* bi; const float* bo;
+  float* hs; float* cs; float* act; const float* mask;
+  int relu, write_all_h;
+  int64_t tiles;
+  int KX, KH, PITCH, R;
+};
+
+__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
+// One LDS-DMA instruction: lane l's 16 bytes land at lds_dst + 16 l (lds_dst wave-uniform).  Inline asm: hipcc does not count it (its own counted
+// waits only get stricter); the waits for the ring are written by hand below.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// gate functions at fp32 accuracy (gemm_tiled.hip has the error analysis: absolute error of sigma / tanh <= 1.5e-7)
+__device__ __forceinline__ float exp_fast(float x) {
+  const float t = x * 1.4426950408889634f;
+  const float lo = __builtin_fmaf(x, 1.9259629911e-8f, __builtin_fmaf(x, 1.4426950408889634f, -t));
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, lo * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_fast(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float t = exp_fast(-2.0f * __builtin_fabsf(x));
+  return __builtin_copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+}
+__device__ __forceinline__ void store4(float* __restrict__ p, const f32x4 v, int nv) {
+  if (nv >= 4) *(f32x4u*)p = v;
+  else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) if (r < nv) p[r] = v[r];
+  }
+}
+
+// CELL 0: FastLSTM (gate rows i, g, f, o of W: row q H + u), NCH chunks of 64 hidden units.  CELL 1: rnn, one chunk of 256 units (NCH = 1).
+template <int CELL, int NCH, bool SAVE>
+__global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  float* const At = (float*)smem;                                  // [64][PITCH]: x_t | h_{t-1} (pad columns zero)
+  const int tid = threadIdx.x, lane = tid & 63, arow = lane & 15, ag = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KX = a.KX, KH = a.KH, PITCH = a.PITCH, R = a.R, H = a.H, Din = a.Din, T = a.T;
+  const int ngx = KX >> 4, ngh = KH >> 4;
+  char* const ring = smem + (size_t)ROWS * PITCH * 4 + (size_t)w * R * GB;   // this wave's R group buffers
+  const unsigned ring_lds = lds_off(ring);
+  // (tile range of this workgroup: wave-uniform 32-bit scalars -- the host keeps tiles < 2^31)
+  const int t_beg = __builtin_amdgcn_readfirstlane((int)(a.tiles * (int64_t)blockIdx.x / (int64_t)gridDim.x));
+  const int t_end = __builtin_amdgcn_readfirstlane((int)(a.tiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x));
+  if (t_beg >= t_end) return;
+  for (int i = tid; i < ROWS * PITCH; i += NTHR) At[i] = 0.f;
+  bar();
+
+  // ---- weight rows of this lane's four n-tiles
+  auto wrow = [&](int q, int c) -> int {
+    int u = (CELL == 0) ? 64 * c + 16 * w + arow : 256 * c + 64 * w + 16 * q + arow;
+    if (u >= H) u = H - 1;   // (units past H: any valid row, the result is dropped)
+    return (CELL == 0) ? q * H + u : u;
+  };
+  // ---- the DMA stream: groups in the order they are consumed.  Cursor of the NEXT group to request: (tile, step, chunk, segment, group).
+  int l_tile = t_beg, l_t = 0, l_c = 0, l_seg = 0, l_g = 0;
+  int l_n = 0, l_slot = 0;    // groups requested so far; ring slot of the next request
+  const float* wp[4];         // this lane's source of the next group, per n-tile
+  auto l_setup = [&]() {
+    const float* base = l_seg ? a.Wo : a.Wi;
+    const int ld = l_seg ? H : Din;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wp[q] = base + (int64_t)wrow(q, l_c) * ld + 4 * ag;
+  };
+  l_setup();
+  auto l_issue = [&]() {   // request one group (if any is left) into slot l_n % R
+    if (l_tile >= t_end) return;
+    const unsigned dst = ring_lds + (unsigned)l_slot * GB;
+    l_slot = (l_slot + 1 == R) ? 0 : l_slot + 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dma16(wp[q], (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + q * 1024)));
+      wp[q] += 16;
+    }
+    ++l_n;
+    if (++l_g == (l_seg ? ngh : ngx)) {
+      l_g = 0;
+      if (l_seg == 0 && l_t > 0) l_seg = 1;
+      else {
+        l_seg = 0;
+        if (++l_c == NCH) { l_c = 0; if (++l_t == T) { l_t = 0; ++l_tile; } }
+      }
+      l_setup();
+    }
+  };
+  for (int i = 0; i < R; ++i) l_issue();
+  int c_n = 0, c_slot = 0;   // groups consumed so far; ring slot of group c_n
+
+  // ---- fragment sets (double buffered: group n + 1 is read under the MFMAs of group n)
+  f32x4 fa[2][4], fb[2][4];
+  unsigned a_lane[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_lane[i] = (unsigned)(((16 * i + arow) * PITCH + 4 * ag) * 4);
+  const unsigned b_lane = (unsigned)lane * 16u;
+  auto read_a = [&](int set, int kbase) {   // (PITCH is a multiple of 4 floats: every piece is 16-byte aligned -- one ds_read_b128 each)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[set][i] = *(const f32x4*)__builtin_assume_aligned(smem + a_lane[i] + (unsigned)kbase * 4u, 16);
+  };
+  auto slot_of = [&](int ahead) -> int { int sl = c_slot + ahead; return sl >= R ? sl - R : sl; };   // ring slot of group c_n + ahead (ahead <= 2 <= R)
+  auto read_b = [&](int set, int slot) {
+    const char* src = ring + (size_t)slot * GB + b_lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fb[set][q] = *(const f32x4*)__builtin_assume_aligned(src + q * 1024, 16);
+  };
+  // the weights of group n have landed: at most R - 1 younger groups (4 DMA each) may still be in flight
+  auto wait_w = [&](int n) {
+    const int younger = l_n - 1 - n;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  f32x4 acc[4][4];   // [i: 16-row m-tile][q: n-tile]
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // a quarter of a group's 64 MFMAs (k-slot jj of every fragment): 512 matrix cycles, the shadow one piece of housekeeping issues in.
+  // sched_barrier behind it: the MFMA builtins are plain register operations to hipcc -- left alone it bunches them away from the loads they are meant to cover.
+  auto mfma16 = [&](int set, int jj) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[set][q][jj], fa[set][i][jj], acc[i][q], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- x rows: thread (row = tid >> 2, lane4 = tid & 3) owns the 16-byte pieces (lane4 + 4 j) of its row
+  const int xr = tid >> 2, xl = tid & 3;
+  const int npx = (Din + 15) >> 4;   // pieces per thread (the last one may lie past Din)
+  f32x4 xp[XPMAX];
+  auto x_request = [&](int64_t row0, int t) {
+    int64_t r = row0 + xr;
+    if (r >= a.N) r = a.N - 1;
+    const float* src = a.in + ((int64_t)t * a.N + r) * Din + 4 * xl;
+#pragma unroll
+    for (int j = 0; j < XPMAX; ++j)
+      if (j < npx) xp[j] = *(const f32x4u*)(src + 16 * ((4 * xl + 16 * j + 3 < Din) ? j : 0));   // (a piece past Din re-reads piece 0; it is not stored)
+  };
+  auto x_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < XPMAX; ++j)
+      if (j < npx && 4 * xl + 16 * j + 3 < Din) *(f32x4*)(At + xr * PITCH + 4 * xl + 16 * j) = xp[j];
+  };
+
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    const int64_t row0 = (int64_t)tile * ROWS;
+    f32x4 cst[CELL == 0 ? NCH : 1][4];   // FastLSTM: c_t of this lane's quads
+    f32x4 hn[CELL == 0 ? NCH : 4][4];    // h_t of the step (written to LDS behind the step's last MFMA)
+#pragma unroll
+    for (int c = 0; c < (CELL == 0 ? NCH : 1); ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cst[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    x_request(row0, 0);
+    x_store();
+    bar();
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) x_request(row0, t + 1);
+      float mk[4];
+      if (CELL == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t r = row0 + 16 * i + arow;
+          mk[i] = a.mask[(int64_t)t * a.N + (r < a.N ? r : a.N - 1)];
+        }
+      }
+      const int nseg = t > 0 ? 2 : 1;
+      // prologue of the step: the first group's fragments
+      wait_w(c_n);
+      read_a(0, 0);
+      read_b(0, c_slot);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        zero_acc();
+        for (int seg = 0; seg < nseg; ++seg) {
+          const int ng = seg ? ngh : ngx, k0 = seg ? KX : 0;
+          for (int g = 0; g < ng; g += 2) {
+            // group n = c_n (set 0), then n + 1 (set 1); the group behind the pair: the next pair of this segment, the other segment, the next chunk --
+            // or nothing (the step's last pair: the LDS tile is about to be rewritten)
+            const bool last_pair = (g + 2 == ng) && (seg + 1 == nseg);
+            const bool step_end = last_pair && (c + 1 == NCH);
+            // Each half: the 64 MFMAs of one group in four quarters; behind the first the DMA request of the group R ahead (into the slot this
+            // group's fragments were read from: those reads fed the MFMAs just issued), behind the second the wait for the next group's weights
+            // and its B fragments, behind the third its A fragments.
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(0, 0);
+            l_issue();                                   // group n + R
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(0, 1);
+            wait_w(c_n + 1);
+            read_b(1, slot_of(1));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(0, 2);
+            read_a(1, k0 + 16 * (g + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(0, 3);
+            mfma16(1, 0);
+            l_issue();                                   // group n + 1 + R
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(1, 1);
+            if (!step_end) {
+              wait_w(c_n + 2);
+              read_b(0, slot_of(2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(1, 2);
+            if (!step_end) {
+              int nk;                                    // k of the group behind this pair inside the LDS tile
+              if (g + 2 < ng) nk = k0 + 16 * (g + 2);
+              else if (seg + 1 < nseg) nk = KX;
+              else nk = 0;
+              read_a(0, nk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(1, 3);
+            c_n += 2;
+            c_slot = slot_of(2);
+          }
+        }
+        // ---- the cell of chunk c on the accumulators (lane-local)
+        if constexpr (CELL == 0) {
+          const int u0 = 64 * c + 16 * w + 4 * ag, nv = H - u0;
+          f32x4 bq[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bq[q][r] = (r < nv) ? a.bi[q * H + u0 + r] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + 16 * i + arow;
+            f32x4 ig, gg, fg, og, cc, hh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              ig[r] = sigm(acc[i][0][r] + bq[0][r]);
+              gg[r] = tanh_fast(acc[i][1][r] + bq[1][r]);
+              fg[r] = sigm(acc[i][2][r] + bq[2][r]);
+              og[r] = sigm(acc[i][3][r] + bq[3][r]);
+              cc[r] = fg[r] * cst[c][i][r] + ig[r] * gg[r];
+              hh[r] = og[r] * tanh_fast(cc[r]);
+              if (r >= nv) { cc[r] = 0.f; hh[r] = 0.f; }   // units past H: zero columns of the next step's operand
+            }
+            cst[c][i] = cc;
+            hn[c][i] = hh;
+            if (row < a.N && nv > 0) {
+              const int64_t o = ((int64_t)t * a.N + row) * H + u0;
+              if (SAVE) {
+                store4(a.cs + o, cc, nv);
+                float* gdst = a.act + ((int64_t)t * a.N + row) * (4 * (int64_t)H) + u0;
+                store4(gdst, ig, nv); store4(gdst + H, gg, nv); store4(gdst + 2 * H, fg, nv); store4(gdst + 3 * H, og, nv);
+              }
+              if (a.write_all_h || t == T - 1) store4(a.hs + o, hh, nv);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int u0 = 256 * c + 64 * w + 16 * q + 4 * ag, nv = H - u0;
+            f32x4 bv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (r < nv) ? a.bi[u0 + r] + a.bo[u0 + r] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int64_t row = row0 + 16 * i + arow;
+              const f32x4 pre = acc[i][q] + bv;
+              const bool live = mk[i] != 0.f;
+              f32x4 v;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float x = a.relu ? fmaxf(pre[r], 0.f) : tanh_fast(pre[r]);
+                v[r] = (live && r < nv) ? x : 0.f;
+              }
+              hn[q][i] = v;
+              if (row < a.N && nv > 0) {
+                const int64_t o = ((int64_t)t * a.N + row) * H + u0;
+                if (SAVE) store4(a.act + o, pre, nv);
+                if (a.write_all_h || t == T - 1) store4(a.hs + o, v, nv);
+              }
+            }
+          }
+        }
+      }
+      // ---- every wave has read [x_t | h_{t-1}] for the last time: h_t and x_{t+1} take their place
+      bar();
+      if (t + 1 < T) {
+        x_store();
+        if constexpr (CELL == 0) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int u0 = 64 * c + 16 * w + 4 * ag;
+            if (u0 < KH) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) *(f32x4*)(At + (16 * i + arow) * PITCH + KX + u0) = hn[c][i];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int u0 = 64 * w + 16 * q + 4 * ag;
+            if (u0 < KH) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) *(f32x4*)(At + (16 * i + arow) * PITCH + KX + u0) = hn[q][i];
+            }
+          }
+        }
+      }
+      bar();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------------------------
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+static size_t lds_need(int Din, int H, int R) {
+  const int KX = (Din + 31) & ~31, KH = (H + 31) & ~31;
+  return (size_t)ROWS * (KX + KH + 4) * 4 + (size_t)4 * R * GB;
+}
+// shapes the launch takes: fp32, Din a multiple of 4 up to 256, H up to 256 (FastLSTM: up to 4 chunks of 64 units; rnn: one chunk of 256), enough
+// tiles to give every CU one
+// (a tile per CU at least, unless forced: below ~16 k paths the per-step launches put more workgroups on the chip than N / 64 persistent ones)
+bool supported(int cell, int64_t N, int Din, int H, bool force) {
+  if (cell != 0 && cell != 1) return false;
+  if ((Din & 3) || Din < 16 || Din > 16 * XPMAX || H < 16 || H > 256) return false;
+  if (N < (force ? (int64_t)1 : (int64_t)ROWS * num_cus()) || (N + ROWS - 1) / ROWS >= ((int64_t)1 << 31)) return false;
+  return lds_need(Din, H, 2) <= (size_t)160 * 1024;
+}
+
+void forward_layer(hipStream_t s, int cell, const float* in, int64_t N, int T, int Din, int H, const float* Wi, const float* Wo, const float* bi, const float* bo,
+                   float* hs, float* cs, float* act, const float* mask, int relu, bool save, bool write_all_h) {
+  LArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.N = N; a.T = T; a.Din = Din; a.H = H; a.Wi = Wi; a.Wo = Wo; a.bi = bi; a.bo = bo; a.hs = hs; a.cs = cs; a.act = act; a.mask = mask;
+  a.relu = relu; a.write_all_h = (write_all_h || save) ? 1 : 0;
+  a.tiles = (N + ROWS - 1) / ROWS;
+  a.KX = (Din + 31) & ~31; a.KH = (H + 31) & ~31; a.PITCH = a.KX + a.KH + 4;
+  a.R = lds_need(Din, H, 3) <= (size_t)160 * 1024 ? 3 : 2;
+  const size_t lds = lds_need(Din, H, a.R);
+  const int grid = (int)std::min<int64_t>(a.tiles, num_cus());
+  typedef void (*Kern)(LArgs);
+  Kern k = nullptr;
+  if (cell == 1) k = save ? (Kern)k_layer<1, 1, true> : (Kern)k_layer<1, 1, false>;
+  else {
+    const int nch = (H + 63) / 64;
+    if (nch == 1) k = save ? (Kern)k_layer<0, 1, true> : (Kern)k_layer<0, 1, false>;
+    else if (nch == 2) k = save ? (Kern)k_layer<0, 2, true> : (Kern)k_layer<0, 2, false>;
+    else if (nch == 3) k = save ? (Kern)k_layer<0, 3, true> : (Kern)k_layer<0, 3, false>;
+    else k = save ? (Kern)k_layer<0, 4, true> : (Kern)k_layer<0, 4, false>;
+  }
+  HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), lds, s, a);
+  HIP_TRY(hipGetLastError());
+}
+
+}  // namespace lp32

@@ -1,0 +1,110 @@
+"""-m gpu: one recurrent layer of the wide fp32 shapes as ONE persistent launch (kprn_amd/csrc/layer_f32_persist.hip) -- "d = 64" reading B
+(D = H = 192, L = 2), run_scripts/config.sh as shipped (rnn + MaskZero, D = 200, H = 250), FastLSTM at config.sh's sizes, H not a multiple of 64 --
+against the float64 oracle (scores, every class probability, every gradient through the unchanged generic backward, Adam steps) and against the
+per-step launches it replaces (kprn_set_option "persist_layers" = 0: the same arithmetic in another accumulation order).  "persist_layers" = 2
+takes the launch at any batch size (the default waits for a tile per CU), so ragged last tiles, single-tile workgroups and several tiles per
+workgroup are all reached at sizes the oracle handles."""
+import numpy as np
+import pytest
+
+from kprn_amd import _ffi, synth
+from oracle.oracle import Oracle, make_cfg, make_opt
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_inf(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / max(1e-30, np.max(np.abs(b))))
+
+
+def _mk(kind, dims, L, Vr=9, use_relu=1, init=0.07, seed=5):
+    dt, de, dr, H = dims
+    rt = 1 if kind == "rnn" else 0
+    eng = _ffi.Engine(6, 800, Vr, dt, de, dr, H, L, rnn_type=rt, use_relu=use_relu, param_init=init)
+    eng.set_option("impl", "generic")
+    eng.set_option("persist_layers", "2")
+    o64 = Oracle(make_cfg(Vt=6, Ve=800, Vr=Vr, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=rt, use_relu=use_relu), np.float64)
+    theta = o64.init_params(seed, init).astype(np.float32).astype(np.float64)
+    if rt:
+        o64.zero_pad(theta)   # zero pad embeddings -> MaskZero masks the pad steps
+    eng.set_flat_params(theta.astype(np.float32))
+    return eng, o64, theta
+
+
+CASES = [("lstm", (64, 64, 64, 192), 2, 300, 3, 6),     # reading B: 900 paths = 14 tiles + 4 rows, both layers through the launch
+         ("lstm", (64, 64, 64, 192), 2, 129, 1, 4),     # T = 4, 129 paths: two full tiles + one row
+         ("rnn", (50, 100, 50, 250), 1, 280, 3, 6),     # config.sh as shipped: K padded 200 -> 224, H 250 -> 256, MaskZero
+         ("rnn", (32, 32, 32, 96), 2, 150, 2, 6),       # two rnn layers: the upper layer's mask follows h of the lower one
+         ("lstm", (50, 100, 50, 250), 1, 150, 2, 6),    # FastLSTM at config.sh's sizes: four chunks, the last one 58 units
+         ("lstm", (16, 32, 16, 80), 1, 100, 2, 3),      # H = 80: second chunk a quarter full
+         ("lstm", (64, 64, 64, 192), 1, 40, 1, 1)]      # T = 1: no recurrent half at all
+
+
+@pytest.mark.parametrize("kind,dims,L,pairs,P,T", CASES)
+def test_persistent_layer_against_the_f64_oracle(kind, dims, L, pairs, P, T):
+    eng, o64, theta = _mk(kind, dims, L)
+    idx, labels = synth.make_paths(pairs, P, T, Ve=800, seed=pairs + T)
+    b = eng.batch(idx, labels)
+    eng.profile(True)
+    out = eng.forward(b, 1, want=("probs", "all_probs", "path_scores"))
+    fam = eng.profile_get()
+    assert ("rnn_layer_fwd" if kind == "rnn" else "lstm_layer_fwd") in fam and "lstm_step_fwd" not in fam and "rnn_step_fwd" not in fam, sorted(fam)
+    ps, _, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5, rel_inf(out["path_scores"], ps)
+    np.testing.assert_allclose(out["all_probs"], probs, rtol=1e-4)
+    # training forward (saves in the generic backward's layouts) + the unchanged backward: every gradient
+    loss = eng.backward(b, 1)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], og[off:off + n]) < 2e-4, (nm, rel_inf(g[off:off + n], og[off:off + n]))
+    # ... and against the per-step launches on the same engine
+    eng.set_option("persist_layers", "0")
+    out0 = eng.forward(b, 1, want=("probs", "path_scores"))
+    assert rel_inf(out["path_scores"], out0["path_scores"].astype(np.float64)) < 2e-6
+    eng.backward(b, 1)
+    g0 = eng.get_flat_grads().astype(np.float64)
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], g0[off:off + n]) < 2e-5, (nm, rel_inf(g[off:off + n], g0[off:off + n]))
+    eng.close()
+
+
+@pytest.mark.parametrize("kind,dims,L", [("lstm", (64, 64, 64, 192), 2), ("rnn", (50, 100, 50, 250), 1)])
+def test_adam_steps_through_the_persistent_layers(kind, dims, L):
+    eng, o64, theta = _mk(kind, dims, L)
+    idx, labels = synth.make_paths(200, 3, 6, Ve=800, seed=77)
+    b = eng.batch(idx, labels)
+    th, st = theta.copy(), o64.new_state()
+    opt, oopt = _ffi.make_opt(method=1, lr=5e-3), make_opt(method=1, lr=5e-3)
+    for s in range(3):
+        ol, _ = o64.train_step(th, st, oopt, idx, labels)
+        gl = eng.train_step(b, opt)
+        assert abs(gl - ol) < 2e-4 * max(1, abs(ol)), (s, gl, ol)
+    assert float(np.max(np.abs(eng.get_flat_params() - th))) < 2e-4
+    eng.close()
+
+
+@pytest.mark.parametrize("kind,dims,L,pairs,P", [("lstm", (64, 64, 64, 192), 2, 4400, 4), ("rnn", (50, 100, 50, 250), 1, 5700, 3)])
+def test_a_tile_per_cu_takes_the_launch_by_default(kind, dims, L, pairs, P):
+    """>= 16 384 paths (a 64-path tile for every CU): the default configuration uses the persistent launch; a second pass is bit-identical; scores of a
+    sample of pairs against the float64 oracle"""
+    dt, de, dr, H = dims
+    rt = 1 if kind == "rnn" else 0
+    eng = _ffi.Engine(6, 5000, 9, dt, de, dr, H, L, rnn_type=rt, use_relu=1, param_init=0.06)
+    eng.set_option("impl", "generic")
+    o64 = Oracle(make_cfg(Vt=6, Ve=5000, Vr=9, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=rt, use_relu=1), np.float64)
+    theta = eng.get_flat_params().astype(np.float64)
+    idx, labels = synth.make_paths(pairs, P, 6, Ve=5000, seed=3)
+    b = eng.batch(idx, labels)
+    eng.profile(True)
+    out = eng.forward(b, 1, want=("probs",))
+    assert ("rnn_layer_fwd" if rt else "lstm_layer_fwd") in eng.profile_get()
+    again = eng.forward(b, 1, want=("probs",))
+    assert np.array_equal(out["probs"], again["probs"])
+    sel = np.arange(0, pairs, 37)
+    _, _, probs = o64.forward(theta, idx[sel])
+    np.testing.assert_allclose(out["probs"][sel], probs[:, 0], rtol=1e-4)
+    eng.close()
