@@ -255,6 +255,12 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4, NT=None):
             din = D if l == 0 else H
             fl += N * 2 * g * (T * din + (T - 1) * H)
         return "mfma", fl / (L * T)
+    if name in ("lstm_layer_fwd", "rnn_layer_fwd"):   # one launch per layer, all T steps (layer_f32_persist.hip); no recurrent half at t = 0
+        fl = 0
+        for l in range(L):
+            din = D if l == 0 else H
+            fl += N * 2 * g * (T * din + (T - 1) * H)
+        return "mfma", fl / L
     if name in ("lstm_fused_fwd", "lstm_fused_fwd_train"):
         fl = 0
         for l in range(L):

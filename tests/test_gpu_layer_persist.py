@@ -74,17 +74,30 @@ def test_persistent_layer_against_the_f64_oracle(kind, dims, L, pairs, P, T):
 
 @pytest.mark.parametrize("kind,dims,L", [("lstm", (64, 64, 64, 192), 2), ("rnn", (50, 100, 50, 250), 1)])
 def test_adam_steps_through_the_persistent_layers(kind, dims, L):
+    """Three Adam steps: the loss follows the float64 oracle (measured 1e-7), the parameters equal those of the per-step launches to fp32 reordering
+    (measured 4e-7: scripts/gpu_probe_layer_persist.py), and both sit on the oracle's walk.  Against the oracle a max bar would be vacuous: Adam's first
+    steps move an element by lr whatever its gradient, so the handful of elements whose gradient is at rounding level (here 24 of 80 000 entity
+    elements, the same ones on both paths) may step the other way -- the bar is the rms and the share of elements further than 2e-4."""
     eng, o64, theta = _mk(kind, dims, L)
+    ref, _, _ = _mk(kind, dims, L)
+    ref.set_option("persist_layers", "0")
     idx, labels = synth.make_paths(200, 3, 6, Ve=800, seed=77)
-    b = eng.batch(idx, labels)
+    b, br = eng.batch(idx, labels), ref.batch(idx, labels)
     th, st = theta.copy(), o64.new_state()
     opt, oopt = _ffi.make_opt(method=1, lr=5e-3), make_opt(method=1, lr=5e-3)
     for s in range(3):
         ol, _ = o64.train_step(th, st, oopt, idx, labels)
         gl = eng.train_step(b, opt)
-        assert abs(gl - ol) < 2e-4 * max(1, abs(ol)), (s, gl, ol)
-    assert float(np.max(np.abs(eng.get_flat_params() - th))) < 2e-4
+        ref.train_step(br, opt)
+        assert abs(gl - ol) < 1e-5 * max(1, abs(ol)), (s, gl, ol)
+    got = eng.get_flat_params().astype(np.float64)
+    assert float(np.max(np.abs(got - ref.get_flat_params()))) < 2e-5
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        d = np.abs(got[off:off + n] - th[off:off + n])
+        assert np.sqrt(np.mean(d * d)) < 5e-5 and np.mean(d > 2e-4) < 2e-3, (nm, float(np.sqrt(np.mean(d * d))), float(np.mean(d > 2e-4)))
     eng.close()
+    ref.close()
 
 
 @pytest.mark.parametrize("kind,dims,L,pairs,P", [("lstm", (64, 64, 64, 192), 2, 4400, 4), ("rnn", (50, 100, 50, 250), 1, 5700, 3)])
