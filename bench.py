@@ -261,6 +261,8 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4, NT=None):
             din = D if l == 0 else H
             fl += N * 2 * g * (T * din + (T - 1) * H)
         return "mfma", fl / L
+    if name in ("lstm_layer_bwd", "rnn_layer_bwd"):   # BPTT of one layer in one launch: the recurrent products dh_{t-1} = dA_t W_o2g of steps T-1 .. 1
+        return "mfma", N * 2 * g * (T - 1) * H
     if name in ("lstm_fused_fwd", "lstm_fused_fwd_train"):
         fl = 0
         for l in range(L):

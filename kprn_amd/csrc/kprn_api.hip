@@ -549,6 +549,18 @@ static void backward_layer0_small_tables(kprn_handle* h, const kprn_batch* b, in
   }
 }
 
+// scratch for W_o2g^T of the persistent BPTT launch (grow-only)
+static float* lp_wot_buffer(kprn_handle* h, int H, int GH) {
+  const int64_t need = (int64_t)lp32::bptt_scratch_floats(H, GH);
+  if (need > h->lp_wot_cap) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dfree(h->lp_wot);
+    h->lp_wot = dalloc<float>(need);
+    h->lp_wot_cap = need;
+  }
+  return h->lp_wot;
+}
+
 static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
   const kprn_config& c = h->cfg;
   const bool bf = c.compute_dtype == 1;
@@ -632,8 +644,13 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       const float* Wi = h->dense + h->layer[l].Wi;
       const float* Wo = h->dense + h->layer[l].Wo;
       const bool has_up = (l < L - 1);
-      if (has_up) HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
-      for (int t = T - 1; t >= 0; --t) {
+      const bool bptt1 = !bf && h->persist_layers && lp32::bptt_supported(1, N, H, h->persist_layers == 2);
+      if (bptt1) {
+        // the cell backward of all T steps + the recurrent gradient in ONE persistent launch (layer_f32_persist.hip k_bptt): dh never leaves the CU
+        ProfScope ps(h, "rnn_layer_bwd");
+        lp32::bptt_layer(s, 1, nullptr, nullptr, hs, mask, has_up ? w.dIn : w.dH, has_up, Wo, lp_wot_buffer(h, H, H), w.dA, N, T, H, relu);
+      } else if (has_up) HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
+      for (int t = T - 1; t >= 0 && !bptt1; --t) {
         float* dA_t = w.dA + (int64_t)t * N * H;
         {
           ProfScope ps(h, "rnn_cell_bwd");
@@ -676,11 +693,16 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
     const float* Wi = h->dense + h->layer[l].Wi;
     const float* Wo = h->dense + h->layer[l].Wo;
     const bool has_up = (l < L - 1);
-    if (has_up) {
+    const bool bptt0 = !bf && h->persist_layers && lp32::bptt_supported(0, N, H, h->persist_layers == 2);
+    if (bptt0) {
+      // the cell backward of all T steps + the recurrent gradient in ONE persistent launch (layer_f32_persist.hip k_bptt): dh / dc never leave the CU
+      ProfScope ps(h, "lstm_layer_bwd");
+      lp32::bptt_layer(s, 0, act, cs, nullptr, nullptr, has_up ? w.dIn : w.dH, has_up, Wo, lp_wot_buffer(h, H, 4 * H), w.dA, N, T, H, 0);
+    } else if (has_up) {
       HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
       HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), s));
     }
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t = T - 1; t >= 0 && !bptt0; --t) {
       float* dA_t = w.dA + (int64_t)t * N * 4 * H;
       {
         ProfScope ps(h, "lstm_gates_bwd");
@@ -982,7 +1004,7 @@ void kprn_destroy(kprn_handle* h) {
   if (h->feed_stream) { hipStreamSynchronize(h->feed_stream); hipStreamDestroy(h->feed_stream); hipEventDestroy(h->ev_feed_fork); }
   if (h->feed_scratch) { hipFree(h->feed_scratch); h->feed_scratch = nullptr; }
   dp_release(h);
-  dfree(h->S2); dfree(h->sel2); dfree(h->st_ctmp);
+  dfree(h->S2); dfree(h->sel2); dfree(h->st_ctmp); dfree(h->lp_wot);
   fused::release(h);
   bf16p::release(h);
   if (h->bidx_scratch) { hipFree(h->bidx_scratch); h->bidx_scratch = nullptr; }

@@ -208,6 +208,7 @@ struct kprn_handle {
   int bf16_bptt_dxe = 8;          // option "bf16_bptt_dxe": the persistent BPTT launch also forms dx for the entity slice (weight ring depth 8 | 16; 0: a separate product)
   int persist_layers = 1;     // option "persist_layers": generic fp32 LSTM / rnn layers as one persistent launch per layer where the shape allows (layer_f32_persist.hip)
   bool small_tables = true;       // option "small_tables": generic fp32 pipelines (LSTM / rnn cells) form the layer-0 type / relation gradients from G (kprn_api.hip backward_generic)
+  float* lp_wot = nullptr; int64_t lp_wot_cap = 0;     // layer_f32_persist.hip: W_o2g^T of the layer whose BPTT launch is queued
   float* st_ctmp = nullptr; int64_t st_ctmp_cap = 0;   //   ... its [GH][ns + de] product result
   bool bf16_small_tables = true;  // option "bf16_small_tables": configs[3] backward forms the type / relation gradients from G = dA^T [S_r | S_t] (lstm_bf16.hip)
   bool small_tiles_on = true;     // option "small_tiles": batches of <= 8 192 paths run on tiles of one 16-row m-tile (no identical-prefix plan)
@@ -499,6 +500,11 @@ bool supported(int cell /*0 FastLSTM, 1 rnn*/, int64_t N, int Din, int H, bool f
 // [T][N][H] (rnn) in the generic backward's layouts; mask [T][N] (rnn: MaskZero)
 void forward_layer(hipStream_t s, int cell, const float* in, int64_t N, int T, int Din, int H, const float* Wi, const float* Wo, const float* bi, const float* bo,
                    float* hs, float* cs, float* act, const float* mask, int relu, bool save, bool write_all_h);
+// BPTT through the layer (cell backward of all T steps + dh_{t-1} = dA_t W_o2g) as one persistent launch; dA [T][N][GH] out (GH = 4H FastLSTM, H rnn)
+bool bptt_supported(int cell, int64_t N, int H, bool force);
+size_t bptt_scratch_floats(int H, int GH);
+void bptt_layer(hipStream_t s, int cell, const float* act, const float* cs, const float* hs, const float* mask, const float* dHup, bool up, const float* Wo,
+                float* wot, float* dA, int64_t N, int T, int H, int relu);
 }  // namespace lp32
 
 // ---- GEMM (gemm_f32.hip): C[M,N] (+)= A(M,K) * B(K,N), arbitrary strides, fp32 MFMA -----------

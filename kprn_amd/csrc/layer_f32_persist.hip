@@ -356,6 +356,302 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// =====================================================================================================================================================
+// BPTT through one layer as ONE persistent launch: the cell backward of all T steps + the recurrent gradient dh_{t-1} = dA_t W_o2g, replacing per step one
+// element-wise launch (kk::lstm_gates_bwd / rnn_cell_bwd: saves in, dH / dC in and out, dA out) and one dh product launch (kprn_api.hip backward_generic).
+// dW and dx stay products over the dA this launch writes ([T][N][GH], the generic layout).
+//   * A workgroup owns a 64-path tile for t = T-1 .. 0; dc_t and dh live in registers, in the SAME lane layout as the forward's cell (lane (arow, ag) of wave w:
+//     path 16 i + arow, hidden units 64 c + 16 w + 4 ag .. + 3 -- rnn: 64 w + 16 q + 4 ag), because the product is taken transposed with the weight
+//     fragment (rows of W_o2g^T) as the first MFMA operand and n-tile c of wave w = output units 64 c + 16 w ..: dh_{t-1} lands where the cell backward reads it.
+//   * K (the gate columns) is walked in chunks of 256 = 64 hidden units x 4 gates (rnn: 256 units): the cell backward of a chunk writes its dA quads to
+//     global memory and into an LDS tile [64][256 + 4] (k = gate * 64 + unit of the chunk), barrier, 16 groups of 16 k of product on it, barrier.
+//   * W_o2g^T fragments stream L2 -> LDS by DMA three groups ahead (as in the forward; `global_load_lds_dwordx4 voffset, sbase`: the per-group address
+//     arithmetic is scalar); the saves of the NEXT chunk are requested right behind a chunk's cell backward, so they land under its product.  Those
+//     requests sit between DMA groups in the in-order return stream: the hand-written waits for the first three groups of a product allow for them
+//     (vmcnt(groups + NPF)) instead of draining them.
+struct BPArgs {
+  const float* act;      // FastLSTM: gate values [T][N][4H];  rnn: unused
+  const float* cs;       // FastLSTM: c [T][N][H]
+  const float* hs;       // rnn: h [T][N][H] (the activation's derivative is formed from it)
+  const float* mask;     // rnn: [T][N]
+  const float* dHup;     // UP: [T][N][H] gradient from the layer above;  else [N][H]: the head's gradient, applied at t = T-1
+  const float* WoT;      // [Hp rows][GH] W_o2g^T (row = output unit; zero rows / slack behind H)
+  float* dA;             // [T][N][GH]
+  int64_t N; int T, H, GH, relu;
+  int64_t tiles;
+};
+
+constexpr int BP_LD = 260;      // floats per row of the dA chunk tile
+constexpr int BP_R = 3;         // DMA ring depth (groups)
+
+template <int N_> __device__ __forceinline__ void vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+// DMA with a scalar base: address = sbase + voff (32-bit, unsigned)
+__device__ __forceinline__ void dma16s(const float* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// CELL 0: FastLSTM, NCH chunks (of 64 units) = n-tiles per wave;  CELL 1: rnn, one chunk of 256 units, 4 n-tiles per wave.  UP: a layer above exists.
+template <int CELL, int NCH, bool UP>
+__global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
+  constexpr int NT = (CELL == 0) ? NCH : 4;          // n-tiles (groups of 16 output units) per wave
+  constexpr int KCH = (CELL == 0) ? NCH : 1;         // K chunks per step
+  constexpr int NPF = (CELL == 0) ? 28 : 32;         // 16-byte save requests per lane and chunk
+  constexpr int GBB = NT * 1024;                     // bytes of one wave's weight group
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  float* const Dt = (float*)smem;                    // dA chunk tile [64][BP_LD]
+  const int tid = threadIdx.x, lane = tid & 63, arow = lane & 15, ag = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, GH = a.GH, T = a.T;
+  char* const ring = smem + (size_t)ROWS * BP_LD * 4 + (size_t)w * BP_R * GBB;
+  const unsigned ring_lds = lds_off(ring);
+  const int t_beg = __builtin_amdgcn_readfirstlane((int)(a.tiles * (int64_t)blockIdx.x / (int64_t)gridDim.x));
+  const int t_end = __builtin_amdgcn_readfirstlane((int)(a.tiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x));
+  if (t_beg >= t_end) return;
+
+  // ---- weight stream.  Lane's row of n-tile cc: output unit uo(cc) = 64 cc + 16 w + arow (rnn: 64 w + 16 cc + arow); its byte offset inside W_o2g^T + 16 ag
+  unsigned voff[NT];
+#pragma unroll
+  for (int cc = 0; cc < NT; ++cc) {
+    int uo = (CELL == 0) ? 64 * cc + 16 * w + arow : 64 * w + 16 * cc + arow;
+    if (uo >= H) uo = H - 1;
+    voff[cc] = (unsigned)(((int64_t)uo * GH + 4 * ag) * 4);
+  }
+  // cursor of the next group to request: (tile, step, chunk, group); steps T-1 .. 1 have a product, step 0 has none
+  int l_tile = (T > 1) ? t_beg : t_end, l_t = T - 1, l_c = 0, l_g = 0, l_n = 0, l_slot = 0;
+  auto l_issue = [&]() {
+    if (l_tile >= t_end) return;
+    // k of the group inside the row: FastLSTM gate (g >> 2), units 64 c + 16 (g & 3) ..;  rnn: units 16 g ..
+    const int koff = (CELL == 0) ? (l_g >> 2) * H + 64 * l_c + 16 * (l_g & 3) : 16 * l_g;
+    const float* sb = a.WoT + koff;
+    const unsigned dst = ring_lds + (unsigned)l_slot * GBB;
+    l_slot = (l_slot + 1 == BP_R) ? 0 : l_slot + 1;
+#pragma unroll
+    for (int cc = 0; cc < NT; ++cc) dma16s(sb, voff[cc], (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + cc * 1024)));
+    ++l_n;
+    if (++l_g == 16) {
+      l_g = 0;
+      if (++l_c == KCH) { l_c = 0; if (--l_t == 0) { l_t = T - 1; ++l_tile; } }
+    }
+  };
+  for (int i = 0; i < BP_R; ++i) l_issue();
+  int c_n = 0, c_slot = 0;
+  auto slot_of = [&](int ahead) -> int { int sl = c_slot + ahead; return sl >= BP_R ? sl - BP_R : sl; };
+  // group n has landed; pf: the NPF save requests of this chunk were issued behind it (it is one of the first BP_R groups of the chunk's product)
+  auto wait_w = [&](int n, bool pf) {
+    const int younger = l_n - 1 - n;
+    if (pf) {
+      if (younger >= 2) vmwait<2 * NT + NPF>();
+      else if (younger == 1) vmwait<NT + NPF>();
+      else vmwait<NPF>();
+    } else {
+      if (younger >= 2) vmwait<2 * NT>();
+      else if (younger == 1) vmwait<NT>();
+      else vmwait<0>();
+    }
+  };
+
+  f32x4 fa[2][4], fb[2][NT];
+  unsigned a_lane[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_lane[i] = (unsigned)(((16 * i + arow) * BP_LD + 4 * ag) * 4);
+  const unsigned b_lane = (unsigned)lane * 16u;
+  auto read_a = [&](int set, int g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[set][i] = *(const f32x4*)__builtin_assume_aligned(smem + a_lane[i] + (unsigned)g * 64u, 16);
+  };
+  auto read_b = [&](int set, int slot) {
+    const char* src = ring + (size_t)slot * GBB + b_lane;
+#pragma unroll
+    for (int cc = 0; cc < NT; ++cc) fb[set][cc] = *(const f32x4*)__builtin_assume_aligned(src + cc * 1024, 16);
+  };
+  f32x4 acc[4][NT];   // dh_{t-1} forming: [i][n-tile]
+  auto mfma_q = [&](int set, int jj) {
+#pragma unroll
+    for (int cc = 0; cc < NT; ++cc)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[set][cc][jj], fa[set][i][jj], acc[i][cc], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- saves of one chunk's cell backward (requested a chunk ahead)
+  struct Sv { f32x4 g[CELL == 0 ? 4 : 1][4]; f32x4 c[4], cp[4]; f32x4 up[CELL == 0 ? 1 : 4][4]; f32x4 hq[CELL == 0 ? 1 : 4][4]; };
+  Sv sv;
+  auto request = [&](int64_t row0, int t, int c) {   // unconditional loads from clamped addresses: exactly NPF requests per lane
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t row = row0 + 16 * i + arow;
+      if (row >= a.N) row = a.N - 1;
+      if constexpr (CELL == 0) {
+        int u = 64 * c + 16 * w + 4 * ag;
+        if (u + 4 > H) u = (H >= 4) ? H - 4 : 0;   // (a quad straddling H re-reads the last full quad: its lanes are masked in the cell)
+        const float* ar = a.act + ((int64_t)t * a.N + row) * GH + u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv.g[q][i] = *(const f32x4u*)(ar + q * H);
+        sv.c[i] = *(const f32x4u*)(a.cs + ((int64_t)t * a.N + row) * H + u);
+        sv.cp[i] = *(const f32x4u*)(a.cs + ((int64_t)(t > 0 ? t - 1 : 0) * a.N + row) * H + u);
+        sv.up[0][i] = *(const f32x4u*)(a.dHup + (UP ? ((int64_t)t * a.N + row) * H : row * H) + u);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int u = 64 * w + 16 * q + 4 * ag;
+          if (u + 4 > H) u = (H >= 4) ? H - 4 : 0;
+          sv.hq[q][i] = *(const f32x4u*)(a.hs + ((int64_t)t * a.N + row) * H + u);
+          sv.up[q][i] = *(const f32x4u*)(a.dHup + (UP ? ((int64_t)t * a.N + row) * H : row * H) + u);
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    const int64_t row0 = (int64_t)tile * ROWS;
+    f32x4 dh[4][NT], dc[CELL == 0 ? NCH : 1][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int cc = 0; cc < NT; ++cc) { dh[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int c = 0; c < (CELL == 0 ? NCH : 1); ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    request(row0, T - 1, 0);
+    for (int t = T - 1; t >= 0; --t) {
+      const float upw = (UP || t == T - 1) ? 1.f : 0.f;   // the head's gradient enters at the last step only
+      float mk[4];
+      if (CELL == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t r = row0 + 16 * i + arow;
+          mk[i] = (r < a.N) ? a.mask[(int64_t)t * a.N + r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < KCH; ++c) {
+        // ---- cell backward of chunk c: dA quads -> global + LDS tile
+        if constexpr (CELL == 0) {
+          const int u0 = 64 * c + 16 * w + 4 * ag, nv = H - u0;
+          const int sh = (u0 + 4 > H && H >= 4) ? u0 + 4 - H : 0;   // the quad was read `sh` units early (see request): its valid elements sit at r + sh
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + 16 * i + arow;
+            f32x4 di, dg, df, dO;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int rs = (r + sh < 4) ? r + sh : 3;
+              const float ig = sv.g[0][i][rs], gg = sv.g[1][i][rs], fg = sv.g[2][i][rs], og = sv.g[3][i][rs];
+              const float tc = tanh_fast(sv.c[i][rs]);
+              const float cp = t > 0 ? sv.cp[i][rs] : 0.f;
+              const float dhv = dh[i][c][r] + upw * sv.up[0][i][rs];
+              const float dov = dhv * tc;
+              const float dcv = dc[c][i][r] + dhv * og * (1.f - tc * tc);
+              const bool ok = r < nv && row < a.N;
+              di[r] = ok ? dcv * gg * ig * (1.f - ig) : 0.f;
+              dg[r] = ok ? dcv * ig * (1.f - gg * gg) : 0.f;
+              df[r] = ok ? dcv * cp * fg * (1.f - fg) : 0.f;
+              dO[r] = ok ? dov * og * (1.f - og) : 0.f;
+              dc[c][i][r] = ok ? dcv * fg : 0.f;
+            }
+            float* lrow = Dt + (16 * i + arow) * BP_LD + 16 * w + 4 * ag;
+            *(f32x4*)(lrow) = di; *(f32x4*)(lrow + 64) = dg; *(f32x4*)(lrow + 128) = df; *(f32x4*)(lrow + 192) = dO;
+            if (row < a.N && nv > 0) {
+              float* gdst = a.dA + ((int64_t)t * a.N + row) * GH + u0;
+              store4(gdst, di, nv); store4(gdst + H, dg, nv); store4(gdst + 2 * H, df, nv); store4(gdst + 3 * H, dO, nv);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int u0 = 64 * w + 16 * q + 4 * ag, nv = H - u0;
+            const int sh = (u0 + 4 > H && H >= 4) ? u0 + 4 - H : 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int64_t row = row0 + 16 * i + arow;
+              f32x4 d;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int rs = (r + sh < 4) ? r + sh : 3;
+                const float hv = sv.hq[q][i][rs];
+                const float der = a.relu ? (hv > 0.f ? 1.f : 0.f) : (1.f - hv * hv);
+                const float dhv = dh[i][q][r] + upw * sv.up[q][i][rs];
+                d[r] = (r < nv && mk[i] != 0.f) ? dhv * der : 0.f;
+              }
+              *(f32x4*)(Dt + (16 * i + arow) * BP_LD + 64 * w + 16 * q + 4 * ag) = d;
+              if (row < a.N && nv > 0) store4(a.dA + ((int64_t)t * a.N + row) * GH + u0, d, nv);
+            }
+          }
+        }
+        // ---- the saves of the chunk behind this one (this tile's next chunk / step); the next tile requests its own first chunk
+        const bool more = !(c + 1 == KCH && t == 0);
+        if (more) {
+          if (c + 1 < KCH) request(row0, t, c + 1); else request(row0, t - 1, 0);
+        }
+        if (t == 0) continue;   // (uniform) step 0: no dh_{-1} to form
+        bar();
+        // ---- product of the chunk: 16 groups in 8 pairs; fragments of group n + 1 are read under the MFMAs of group n
+        wait_w(c_n, more);
+        read_a(0, 0);
+        read_b(0, c_slot);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < 16; g += 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(0, 0);
+          l_issue();
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(0, 1);
+          wait_w(c_n + 1, more && g + 1 < BP_R);
+          read_b(1, slot_of(1));
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(0, 2);
+          read_a(1, g + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(0, 3);
+          mfma_q(1, 0);
+          l_issue();
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(1, 1);
+          if (g + 2 < 16) {
+            wait_w(c_n + 2, more && g + 2 < BP_R);
+            read_b(0, slot_of(2));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(1, 2);
+          if (g + 2 < 16) read_a(0, g + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(1, 3);
+          c_n += 2;
+          c_slot = slot_of(2);
+        }
+        bar();   // every wave is done with the tile: the next chunk's cell backward may overwrite it
+      }
+      // dh_{t-1} is complete: it becomes the step's dh, the accumulators start again from zero
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int cc = 0; cc < NT; ++cc) { dh[i][cc] = acc[i][cc]; acc[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// W [R][C] -> WT [C][R] (64 x 64 tiles through LDS)
+__global__ __launch_bounds__(256) void k_transpose_f32(const float* __restrict__ W, float* __restrict__ WT, int R, int C) {
+  __shared__ float t[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    t[r][c] = (r0 + r < R && c0 + c < C) ? W[(int64_t)(r0 + r) * C + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int c = e >> 6, r = e & 63;
+    if (c0 + c < C && r0 + r < R) WT[(int64_t)(c0 + c) * R + r0 + r] = t[r][c];
+  }
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------------------------------
 static int num_cus() {
   static int n = 0;
@@ -400,6 +696,44 @@ void forward_layer(hipStream_t s, int cell, const float* in, int64_t N, int T, i
     else if (nch == 3) k = save ? (Kern)k_layer<0, 3, true> : (Kern)k_layer<0, 3, false>;
     else k = save ? (Kern)k_layer<0, 4, true> : (Kern)k_layer<0, 4, false>;
   }
+  HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), lds, s, a);
+  HIP_TRY(hipGetLastError());
+}
+
+// ---- BPTT host side
+bool bptt_supported(int cell, int64_t N, int H, bool force) {
+  if (cell != 0 && cell != 1) return false;
+  if (H < 16 || H > 256) return false;
+  if (N < (force ? (int64_t)1 : (int64_t)ROWS * num_cus()) || (N + ROWS - 1) / ROWS >= ((int64_t)1 << 31)) return false;
+  return true;
+}
+size_t bptt_scratch_floats(int H, int GH) { return (size_t)(H + 8) * GH + 1024; }   // W_o2g^T + zero slack behind its last row
+
+// act / cs / hs / mask: the forward's saves (generic layouts); dHup: the gradient from above ([T][N][H] when up, else the head's [N][H], applied at
+// t = T-1); Wo [GH][H]; wot: scratch of bptt_scratch_floats(); dA out [T][N][GH]
+void bptt_layer(hipStream_t s, int cell, const float* act, const float* cs, const float* hs, const float* mask, const float* dHup, bool up, const float* Wo,
+                float* wot, float* dA, int64_t N, int T, int H, int relu) {
+  const int GH = cell == 0 ? 4 * H : H;
+  HIP_TRY(hipMemsetAsync(wot, 0, bptt_scratch_floats(H, GH) * sizeof(float), s));
+  hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)((H + 63) / 64), (unsigned)((GH + 63) / 64)), dim3(256), 0, s, Wo, wot, GH, H);
+  BPArgs a;
+  memset(&a, 0, sizeof(a));
+  a.act = act; a.cs = cs; a.hs = hs; a.mask = mask; a.dHup = dHup; a.WoT = wot; a.dA = dA; a.N = N; a.T = T; a.H = H; a.GH = GH; a.relu = relu;
+  a.tiles = (N + ROWS - 1) / ROWS;
+  const int nch = cell == 0 ? (H + 63) / 64 : 1;
+  const int nt = cell == 0 ? nch : 4;
+  const size_t lds = (size_t)ROWS * BP_LD * 4 + (size_t)4 * BP_R * nt * 1024;
+  const int grid = (int)std::min<int64_t>(a.tiles, num_cus());
+  typedef void (*Kern)(BPArgs);
+  Kern k = nullptr;
+#define KPRN_BK(C_, N_) (up ? (Kern)k_bptt<C_, N_, true> : (Kern)k_bptt<C_, N_, false>)
+  if (cell == 1) k = KPRN_BK(1, 1);
+  else if (nch == 1) k = KPRN_BK(0, 1);
+  else if (nch == 2) k = KPRN_BK(0, 2);
+  else if (nch == 3) k = KPRN_BK(0, 3);
+  else k = KPRN_BK(0, 4);
+#undef KPRN_BK
   HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), lds, s, a);
   HIP_TRY(hipGetLastError());

@@ -1,4 +1,4 @@
-"""-m gpu: one recurrent layer of the wide fp32 shapes as ONE persistent launch (kprn_amd/csrc/layer_f32_persist.hip) -- "d = 64" reading B
+"""-m gpu: one recurrent layer of the wide fp32 shapes as ONE persistent launch, forward and BPTT (kprn_amd/csrc/layer_f32_persist.hip k_layer / k_bptt) -- "d = 64" reading B
 (D = H = 192, L = 2), run_scripts/config.sh as shipped (rnn + MaskZero, D = 200, H = 250), FastLSTM at config.sh's sizes, H not a multiple of 64 --
 against the float64 oracle (scores, every class probability, every gradient through the unchanged generic backward, Adam steps) and against the
 per-step launches it replaces (kprn_set_option "persist_layers" = 0: the same arithmetic in another accumulation order).  "persist_layers" = 2
@@ -54,6 +54,9 @@ def test_persistent_layer_against_the_f64_oracle(kind, dims, L, pairs, P, T):
     np.testing.assert_allclose(out["all_probs"], probs, rtol=1e-4)
     # training forward (saves in the generic backward's layouts) + the unchanged backward: every gradient
     loss = eng.backward(b, 1)
+    fam = eng.profile_get()
+    # ... BPTT through the layer is ONE launch too (cell backward + recurrent product of all T steps): no per-step gate-backward / dh launches
+    assert ("rnn_layer_bwd" if kind == "rnn" else "lstm_layer_bwd") in fam and "lstm_gates_bwd" not in fam and "rnn_cell_bwd" not in fam and "gemm_o2g_bwd_dh" not in fam, sorted(fam)
     ol, og, _ = o64.forward_backward(theta, idx, labels)
     assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
     g = eng.get_flat_grads()
