@@ -296,7 +296,19 @@ int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t*
  *                     order on the handle's stream.
  *   "reserve_cus"     CUs the persistent scoring kernel leaves free (a collective's copy kernels run beside it), 0..128
  *   "profile_filter"  kernel-family name prefix: only those families get HIP events while profiling is on ("" = all); an event
- *                     pair costs ~4 us of stream time                                                                            */
+ *                     pair costs ~4 us of stream time
+ *   round 5 (each is the A/B switch of one design choice; the defaults are the fast paths, the tests run both sides in one process):
+ *   "bf16_small_tables" "1" (default): bf16 pipeline (compute_dtype 1, persistent launches): the gradients of the type / relation tables (<= 128
+ *                     rows together) and of their column blocks of W_i2g come from 128 one-hot columns of ONE merged dW product, dx is formed
+ *                     for the entity slice only; "0": full dx product + table-gradient launch
+ *   "bf16_bptt_dxe"   "8" (default) | "16": that slice of dx is formed inside the persistent BPTT launch (value = depth of its weight ring);
+ *                     "0": by its own product launch
+ *   "small_tables"    "1" (default): the same identity on layer 0 of the generic fp32 LSTM / rnn backward; "0": dx product + table-gradient launch
+ *   "persist_layers"  "1" (default): a recurrent layer of the generic fp32 pipeline (FastLSTM / rnn, Din % 4 == 0, Din, H <= 256) runs as ONE
+ *                     persistent launch, forward and BPTT, once the batch gives every CU a 64-path tile; "2": at any batch size; "0": one launch
+ *                     per step
+ *   (also: "small_tiles", "score_split", "loss_accumulate", "feed_build" / "feed_threads" / "feed_workers", "dp_comm_stream",
+ *    "dp_fused_update", "dp_dense_in_pack" -- described at the calls they modify)                                                 */
 int kprn_set_option(kprn_handle* h, const char* key, const char* value);
 /* measurement hook: mean milliseconds per launch of one GEMM shape of the generic pipeline on random data (scripts/gpu_gemm_bench.py).
  * what: 0 C = A B^T, 1 C = A B, 2 C += A^T B (split-K), 3 FastLSTM step kernel (M paths, N = H, K = Din), 4 Recurrence step kernel */
