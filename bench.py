@@ -475,8 +475,8 @@ def other_configs():
     # step counts chosen for a timed region of >= 0.3 s each (C5 0.35 ms, dims B 20 ms, shipped 5.5 ms, configs[3] 5-7 ms per step)
     runs = [("C5_inference_T3to7", ["--workload", "c5", "--steps", "1000", "--warmup", "10"]),
             ("dimsB_D192_H192_L2", ["--dims", "B", "--steps", "18", "--warmup", "2"]),
-            ("shipped_rnn_D200_H250", ["--dims", "shipped", "--steps", "64", "--warmup", "3"]),
-            ("C4_20M_entities_d128_bf16", ["--dims", "C4", "--steps", "60", "--warmup", "3"])]
+            ("shipped_rnn_D200_H250", ["--dims", "shipped", "--steps", "72", "--warmup", "3"]),
+            ("C4_20M_entities_d128_bf16", ["--dims", "C4", "--steps", "75", "--warmup", "3"])]
     out = {}
     for name, flags in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-alt", "--no-extra-regions", "--no-other-configs", "--no-batch-sweep", "--batch-feed", "resident"] + flags

@@ -124,3 +124,42 @@ def test_a_tile_per_cu_takes_the_launch_by_default(kind, dims, L, pairs, P):
     _, _, probs = o64.forward(theta, idx[sel])
     np.testing.assert_allclose(out["probs"][sel], probs[:, 0], rtol=1e-4)
     eng.close()
+
+
+@pytest.mark.parametrize("kind,dims,L", [("lstm", (64, 64, 64, 192), 2), ("rnn", (50, 100, 50, 250), 1)])
+def test_full_batch_agrees_with_the_step_launches(kind, dims, L):
+    """bench.py's own batch (65 536 paths: four tiles per workgroup on every CU, the DMA rings and the counted waits under full load -- the timing regime
+    the small cases cannot reach): probabilities and every gradient of the persistent launches against the per-step launches on the same engine.  The
+    counted `vmcnt` waits assume that loads retire in issue order whether they land in registers or (LDS-DMA) in LDS; a weight group used before it
+    landed would show here as errors of order 1e-2."""
+    dt, de, dr, H = dims
+    rt = 1 if kind == "rnn" else 0
+    eng = _ffi.Engine(6, 200000, 9, dt, de, dr, H, L, rnn_type=rt, use_relu=1, param_init=0.06)
+    eng.set_option("impl", "generic")
+    idx, labels = synth.make_paths(16384, 4, 6, Ve=200000, seed=19)
+    b = eng.batch(idx, labels)
+    res = {}
+    for mode in ("1", "0", "1"):
+        eng.set_option("persist_layers", mode)
+        eng.profile_reset()
+        eng.profile(True)
+        p = eng.forward(b, 1, want=("probs",))["probs"].astype(np.float64)
+        eng.backward(b, 1)
+        fam = eng.profile_get()
+        assert (("lstm_layer_bwd" in fam or "rnn_layer_bwd" in fam) and ("lstm_layer_fwd" in fam or "rnn_layer_fwd" in fam)) == (mode == "1"), sorted(fam)
+        g = eng.get_flat_grads().astype(np.float64)
+        if mode in res:   # a second pass through the persistent launches: the same answer again (to the atomics' reordering in the dW products)
+            assert np.max(np.abs(p - res[mode][0])) < 1e-7
+        res[mode] = (p, g)
+    assert np.max(np.abs(res["1"][0] - res["0"][0])) < 2e-6
+    for nm, (off, shp) in eng.layout().items():
+        if nm == "entity_emb":
+            continue   # (200 000 x d_e: compared through its column sums below)
+        n = int(np.prod(shp))
+        a, r = res["1"][1][off:off + n], res["0"][1][off:off + n]
+        assert np.max(np.abs(a - r)) < 1e-4 * max(1e-30, np.max(np.abs(r))), (nm, float(np.max(np.abs(a - r))), float(np.max(np.abs(r))))
+    off, shp = eng.layout()["entity_emb"]
+    a = res["1"][1][off:off + int(np.prod(shp))].reshape(shp)
+    r = res["0"][1][off:off + int(np.prod(shp))].reshape(shp)
+    assert np.max(np.abs(a - r)) < 1e-4 * np.max(np.abs(r))
+    eng.close()
