@@ -51,17 +51,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0 .. 31 (the instruction takes an immediate)
-__device__ __forceinline__ void vmwait_rt(int n) {
-#define KPRN_VMW(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
-  switch (n) {
-    KPRN_VMW(0) KPRN_VMW(1) KPRN_VMW(2) KPRN_VMW(3) KPRN_VMW(4) KPRN_VMW(5) KPRN_VMW(6) KPRN_VMW(7) KPRN_VMW(8) KPRN_VMW(9) KPRN_VMW(10) KPRN_VMW(11)
-    KPRN_VMW(12) KPRN_VMW(13) KPRN_VMW(14) KPRN_VMW(15) KPRN_VMW(16) KPRN_VMW(17) KPRN_VMW(18) KPRN_VMW(19) KPRN_VMW(20) KPRN_VMW(21) KPRN_VMW(22)
-    KPRN_VMW(23) KPRN_VMW(24) KPRN_VMW(25) KPRN_VMW(26) KPRN_VMW(27) KPRN_VMW(28) KPRN_VMW(29) KPRN_VMW(30) KPRN_VMW(31)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef KPRN_VMW
-}
 
 // gate functions at fp32 accuracy (gemm_tiled.hip has the error analysis: absolute error of sigma / tanh <= 1.5e-7)
 __device__ __forceinline__ float exp_fast(float x) {
@@ -158,14 +147,14 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
     for (int q = 0; q < 4; ++q) fb[set][q] = *(const f32x4*)__builtin_assume_aligned(src + q * 1024, 16);
   };
   // The weights of group n have landed: loads retire in issue order, so it is enough that no more loads are outstanding than were ISSUED behind it --
-  // the younger groups (4 DMA each) and, for the groups requested before this step's x rows (and MaskZero flags), those npx (+ 4) loads, which would
-  // otherwise have to land first (~2 us of HBM latency at the head of every step).  Only loads that are issued unconditionally are counted.
-  int x_mark = 0;            // groups requested before the step's x request
-  const int x_loads = ((Din + 15) >> 4) + (CELL == 1 ? 4 : 0);
+  // the younger groups (4 DMA each).  (The step's x rows and MaskZero flags, requested behind the groups in flight at the head of a step, make the first
+  // waits of a step stricter than they need be; allowing for them -- a run-time count, i.e. a 32-way switch around s_waitcnt's immediate in front of
+  // every wait -- measured 8 % SLOWER on both shapes (profiles/r05/bench_i_*): the fixed three-way form stays.)
   auto wait_w = [&](int n) {
-    int younger = l_n - 1 - n;
-    if (younger > 2) younger = 2;
-    vmwait_rt(4 * (younger > 0 ? younger : 0) + (n < x_mark ? x_loads : 0));
+    const int younger = l_n - 1 - n;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
   f32x4 acc[4][4];   // [i: 16-row m-tile][q: n-tile]
@@ -215,12 +204,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
     x_store();
     bar();
     for (int t = 0; t < T; ++t) {
-      x_mark = 0;
-      if (t + 1 < T) {
-        x_mark = l_n;
-        asm volatile("" ::: "memory");
-        x_request(row0, t + 1);
-      }
+      if (t + 1 < T) x_request(row0, t + 1);
       float mk[4];
       if (CELL == 1) {
 #pragma unroll
