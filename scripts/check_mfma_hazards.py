@@ -37,8 +37,15 @@ def compile_isa(path):
     if path not in _ISA:
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "k.s")
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"),
-                                   "-S", "--cuda-device-only", "-o", out, path])
+            # (with the flags the source asks for in its `// hipcc-flags:` line, as kprn_amd/build.py compiles it: the register allocation the tests pin
+            #  is the shipped one)
+            extra = []
+            with open(path) as f:
+                for line in f.readlines()[:5]:
+                    if line.startswith("// hipcc-flags:"):
+                        extra = [w for w in line[len("// hipcc-flags:"):].split() if w.startswith("-")]
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include")] + extra +
+                                  ["-S", "--cuda-device-only", "-o", out, path])
             _ISA[path] = open(out).read()
     return _ISA[path]
 

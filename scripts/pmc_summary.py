@@ -34,6 +34,11 @@ def short(name):
         return "lstm_persist_bf16_bwd"
     if "k_lstm16_persist" in name:   # persistent bf16 layer kernel: <KX, KH, SAVE, ...>
         return "lstm_persist_bf16_train" if "24, 24, true" in name.replace("(bool)1", "true") else "lstm_persist_bf16_score"
+    if "lp32::k_layer<" in name:      # one wide fp32 layer, all T steps (layer_f32_persist.hip): <CELL, NCH, SAVE>
+        cell = "rnn" if "k_layer<1" in name else "lstm"
+        return cell + ("_layer_fwd_train" if "true>" in name.replace("(bool)1", "true") else "_layer_fwd")
+    if "lp32::k_bptt<" in name:
+        return ("rnn" if "k_bptt<1" in name else "lstm") + "_layer_bwd"
     if "k_lstm_fwd_mc" in name:
         return "lstm_mc_fwd_train" if "true>" in name else "lstm_mc_fwd"
     if "k_lstm_fwd" in name:
@@ -71,7 +76,8 @@ def main(d):
     for k, o in out.items():
         if "fetch_bytes_corrected" in o or "write_bytes_raw" in o:
             o["hbm_bytes_per_launch"] = o.get("fetch_bytes_corrected", 0.0) + o.get("write_bytes_raw", 0.0)
-    keep = {k: v for k, v in out.items() if "lstm" in k or "entity_grad" in k or "adam" in k or "loss" in k or "gemm16" in k}
+    keep = {k: v for k, v in out.items() if "lstm" in k or "rnn_layer" in k or "entity_grad" in k or "adam" in k or "loss" in k or "gemm16" in k or "gemm_tiled" in k
+            or "gemm_kernel" in k}
     print(json.dumps(keep, indent=1, sort_keys=True))
 
 

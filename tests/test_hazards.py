@@ -85,18 +85,24 @@ def test_persistent_bptt_kernel_keeps_its_state_in_registers():
     res = {k: v for k, v in chk.kernel_resources(text).items() if "k_lstm16_bwd_persist" in k}
     assert len(res) >= 4
     for k, v in res.items():
-        if "ILi2E" in k:      # 64-row tiles, one workgroup per CU: the product default
+        if "ILi2E" in k and k.endswith("Li0EEEvNS0_5BArgsE"):      # 64-row tiles, one workgroup per CU, no dx_e tile
             assert v["vgpr_spill_count"] == 0 and v["vgpr_count"] <= 512, (k, v)
+        elif "ILi2ELi2ELi8E" in k:   # round 5, the product default: + the entity slice of dx as a fourth result tile per wave (32 more accumulators), ring of 8
+            assert v["vgpr_spill_count"] <= 16 and v["vgpr_count"] <= 512, (k, v)
+        elif "ILi2ELi2ELi16E" in k:  # ... ring of 16: opt-in, measured slower (reloads inside the step loop)
+            assert v["vgpr_spill_count"] <= 96 and v["vgpr_count"] <= 512, (k, v)
         else:                 # 32-row tiles, two workgroups per CU (opt-in, measured slower): 256 registers per wave
             assert v["vgpr_spill_count"] <= 40 and v["vgpr_count"] <= 256, (k, v)
-    km = re.search(r"\n(_ZN5bf16p2pb20k_lstm16_bwd_persistILi2ELi2E\w+):[^\n]*\n(.*?)s_endpgm", text, re.S)
-    ins = [l.split(";")[0].strip() for l in km.group(2).split("\n")]
-    ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
-    mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
-    assert len(mf) == 12 * 8 * 3 * 2       # chunks x k-steps x result tiles x path tiles: ONE copy of the step body
-    waits = [l for l in ins[mf[0]:mf[-1]] if l.startswith("s_waitcnt") and "vmcnt" in l]
-    drained = [l for l in waits if "vmcnt(0)" in l]
-    assert len(drained) <= 4, drained[:5]   # (the first builds: a vmcnt(0) in front of most of the 576 MFMAs)
+    for sym, n_mfma in (("ILi2ELi2ELi0E", 12 * 8 * 3 * 2), ("ILi2ELi2ELi8E", 12 * 8 * 4 * 2)):   # chunks x k-steps x result tiles x path tiles: ONE copy of the step body
+        km = re.search(r"\n(_ZN5bf16p2pb20k_lstm16_bwd_persist" + sym + r"\w+):[^\n]*\n(.*?)s_endpgm", text, re.S)
+        ins = [l.split(";")[0].strip() for l in km.group(2).split("\n")]
+        ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
+        mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
+        assert len(mf) == n_mfma, (sym, len(mf))
+        waits = [l for l in ins[mf[0]:mf[-1]] if l.startswith("s_waitcnt") and "vmcnt" in l]
+        drained = [l for l in waits if "vmcnt(0)" in l]
+        assert len(drained) <= 4, (sym, drained[:5])   # (the first builds: a vmcnt(0) in front of most of the MFMAs)
+        assert not [l for l in ins[mf[0]:mf[-1]] if l.startswith("scratch_")], sym   # whatever is spilled stays outside the step loop
 
 
 def test_operand_loads_are_not_a_chain_of_round_trips():
