@@ -427,7 +427,7 @@ namespace gemm {
 // the tiled kernel takes a call when both operands are in one of its two layouts with 16-byte granularity; returns false otherwise
 bool run_tiled(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C, int64_t ldc, int64_t M, int N,
                int64_t K, bool accumulate, const float* bias, int split_k) {
-  if (M < 192 || N < 64 || K < 16) return false;   // (M >= 192: the shipped rnn's dW products have M = H = 250 rows -- two row tiles, the second masked)
+  if (M < 256 || N < 64 || K < 16) return false;   // (tried from 192 rows, for the shipped rnn's dW products with M = H = 250: 0.55 -> 1.54 ms, two row tiles leave the split-K launch three quarters empty -- profiles/r05/bench_k_*)
   int LA, LB;
   int64_t lda, ldb;
   if (sAk == 1) { LA = 0; lda = sAm; }        // A contiguous along k, or along m; B along k, or along n
