@@ -183,35 +183,11 @@ __device__ __forceinline__ void frag_read(const float* __restrict__ T, int row_b
   }
 }
 
-// PERMUTED fragments for the dW products (both operands m- / n-contiguous, += epilogue; round 5).  A [k][m] tile used to be read with one ds_read_b32 per
-// (MFMA, operand): 32 reads per 16-k group against 8 for the k-contiguous layout.  But which 16 rows an MFMA tile covers is free: lane arow reads FOUR CONSECUTIVE
-// rows 4 arow .. 4 arow + 3 of one k with a single ds_read_b128 and hands element t to m-tile t, i.e. m-tile t covers rows {4 r + t} of the wave's 64 instead of
-// {16 t + r} -- a relabelling of the output rows that only the epilogue has to know (row of (m-tile i, tile row rho) = 4 rho + i; likewise the columns).
-// 8 reads per group (NTW = 2: the B operand's are ds_read_b64), conflict-free (a k-row's pitch shifts it by 4 banks).
-template <int ROWS, int NT>
-__device__ __forceinline__ void frag_read_perm(const float* __restrict__ T, int row_base, int kg, int arow, int ag, f32x4 (&fr)[NT]) {
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const float* p = T + (kg * 16 + ag * 4 + jj) * (ROWS + 4) + row_base + NT * arow;
-    if constexpr (NT == 4) {
-      const f32x4 v = *(const f32x4*)p;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fr[t][jj] = v[t];
-    } else {
-      static_assert(NT == 2, "two or four tiles per wave");
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      const f32x2 v = *(const f32x2*)p;
-      fr[0][jj] = v[0]; fr[1][jj] = v[1];
-    }
-  }
-}
-
 // NTW: MFMA column tiles per wave: 4 (workgroup tile 128 x 128) or 2 (128 x 64: the last column block of N = 192, 64, ...)
 template <int LA, int LB, int EPI, int NTW>
 __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
   constexpr int TNn = 32 * NTW;
   constexpr bool TR = (EPI != EPI_ACCUM);   // result blocks transposed in the lanes (see the epilogue)
-  constexpr bool PERM = (LA == 1 && LB == 1 && EPI == EPI_ACCUM);   // permuted row / column tiles (frag_read_perm)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   auto As = [&](int i) -> float* { return lds + i * (2 * TILE_F); };              // buffer i: A tile | B tile
   auto Bs = [&](int i) -> float* { return lds + i * (2 * TILE_F) + TILE_F; };
@@ -297,13 +273,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
       f32x4 fa[4], fb[NTW];
-      if constexpr (PERM) {
-        frag_read_perm<TM, 4>(As(cur), wm * 64, kg, arow, ag, fa);
-        frag_read_perm<TNn, NTW>(Bs(cur), wn * (16 * NTW), kg, arow, ag, fb);
-      } else {
-        frag_read<LA, TM, 4>(As(cur), wm * 64, 16, kg, arow, ag, fa);
-        frag_read<LB, TNn, NTW>(Bs(cur), b_base, b_step, kg, arow, ag, fb);
-      }
+      frag_read<LA, TM, 4>(As(cur), wm * 64, 16, kg, arow, ag, fa);
+      frag_read<LB, TNn, NTW>(Bs(cur), b_base, b_step, kg, arow, ag, fb);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -329,11 +300,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tiled(TArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int jn = 0; jn < NTW; ++jn) {
-        const int col = PERM ? n0 + wn * (16 * NTW) + NTW * arow + jn : n0 + wn * (16 * NTW) + jn * 16 + arow;
+        const int col = n0 + wn * (16 * NTW) + jn * 16 + arow;
         if (col >= a.N) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t row = PERM ? m0 + wm * 64 + 4 * (ag * 4 + r) + i : m0 + wm * 64 + i * 16 + ag * 4 + r;
+          const int64_t row = m0 + wm * 64 + i * 16 + ag * 4 + r;
           if (row >= a.M) continue;
           float* dst = a.C + row * a.ldc + col;
           if (a.use_atomic) unsafeAtomicAdd(dst, acc[i][jn][r]);
