@@ -2354,6 +2354,9 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // generic fp32 pipelines: layer 0's type / relation gradients from G = dA^T [S_r | S_t] ("1", default) or from the full dx product + the
     // table-gradient launch ("0": the A/B reference)
     h->small_tables = atoi(value) != 0;
+  } else if (strcmp(key, "bf16_gemm_pingpong") == 0) {
+    // bf16 pipeline: split-K products with >= 256 x 256 outputs on the two-group kernel gx::k_gemm16p ("1", default) or on gx::k_gemm16x ("0").  Process-wide.
+    bf16p::set_gemm_pingpong(atoi(value) != 0);
   } else if (strcmp(key, "bf16_bptt_dxe") == 0) {
     // bf16 pipeline with "bf16_small_tables": the entity slice of dx is formed INSIDE the persistent BPTT launch (a fourth result tile per wave; value =
     // depth of its weight ring, 8 (default) or 16) or by its own product launch reading dA^T once more ("0")

@@ -448,7 +448,8 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid);
 void params_changed(kprn_handle* h, bool entity_rows_only);   // parameters rewritten: shadows are stale (rows only: the dense arena + listed rows)
 void rows_updated(kprn_handle* h, const int32_t* rows, const int32_t* count, int64_t max_rows);
 void release(kprn_handle* h);
-float debug_gemm16(hipStream_t s, int64_t M, int N, int64_t K, int split_k, int iters);   // ms per launch (kprn_debug_gemm what 5 / 6)
+float debug_gemm16(hipStream_t s, int64_t M, int N, int64_t K, int split_k, int iters);
+void set_gemm_pingpong(bool on);   // (process-wide) the split-K bf16 products on the two-group 256 x 256 kernel (default) or on k_gemm16x   // ms per launch (kprn_debug_gemm what 5 / 6)
 }  // namespace bf16p
 
 // ---- environment switches ---------------------------------------------------------------------------------

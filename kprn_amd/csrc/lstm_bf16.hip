@@ -695,7 +695,146 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16y(XArgs a) {
       }
     }
 }
+
+// ---- 256 x 256 x 32 tiles, two wave groups one barrier apart (round 5) --------------------------------------------------------------------------------
+// What k_gemm16x / k_gemm16y share is their lockstep: every wave meets the same barrier, then every wave reads its fragments, then every wave issues its MFMAs --
+// the two waves of a SIMD wait for LDS at the same moment and want the matrix pipe at the same moment (0.28-0.36 of the bf16 peak whatever the tile).  Here the
+// workgroup's eight waves form two groups, G0 = waves 0-3 (rows 0-127 of the tile) and G1 = waves 4-7 (rows 128-255): wave w and w + 4 share a SIMD.  A K tile of
+// 32 is one READ segment (this wave's DMA requests three K tiles ahead, 12 ds_read_b128: 8 A + 4 B fragments of v_mfma_f32_32x32x16_bf16, the counted wait for its
+// own pieces of the next K tile) and one MFMA segment (16 MFMAs = 512 matrix cycles on a 128 x 64 wave tile), each closed by s_barrier -- and G1 runs ONE BARRIER
+// BEHIND G0, so on every SIMD one wave reads while the other multiplies:
+//     barrier index       B0        B1          B2          B3          B4
+//     G0            | R(0) | M(0)     | R(1)     | M(1)      | R(2) ...
+//     G1            |  --  | R(0)     | M(0)     | R(1)      | M(1) ...
+// Four LDS buffers of 32 KB (A 256 x 32 | B 256 x 32 bf16; rows of 64 bytes, the 16-byte piece a lane fetches chosen on the SOURCE side so that a 32-row fragment
+// read is conflict-free: as k_gemm16y).  Hazards: K tile kt + 1 is complete for everybody before G0's R(kt + 1) -- every wave waits for its own pieces of kt + 1 at
+// the end of its R(kt) (G0: interval 2 kt, G1: 2 kt + 1) and a barrier follows both; the buffer DMA(kt + 3) overwrites held K tile kt - 1, last read by G1's R(kt - 1) in
+// interval 2 kt - 1, which ends with lgkmcnt(0) + barrier before G0 requests it in interval 2 kt.
+constexpr int PBM = 256, PBN = 256, PBK = 32, PNBUF = 4, PBUF_BYTES = (PBM + PBN) * PBK * 2;
+template <bool ACCUM>
+__global__ __launch_bounds__(NTHR, 2) void k_gemm16p(XArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wg = wave >> 2, wc = wave & 3, r = lane & 31, kg = lane >> 5;
+  const int64_t id = blockIdx.x;
+  const int xcd = (int)(id & 7);
+  const int64_t j = id >> 3;
+  int nt_idx; int64_t mt_idx, split_idx = 0;
+  if (a.nsplit > 1) {   // all tiles of one K range on one XCD
+    const int64_t tiles = a.mtiles * a.ntiles;
+    split_idx = (j / tiles) * 8 + xcd;
+    const int64_t tl = j % tiles;
+    mt_idx = tl / a.ntiles; nt_idx = (int)(tl % a.ntiles);
+    if (split_idx >= a.nsplit) return;
+  } else {
+    nt_idx = (int)(j % a.ntiles);
+    mt_idx = (j / a.ntiles) * 8 + xcd;
+    if (mt_idx >= a.mtiles) return;
+  }
+  const int64_t m0 = mt_idx * PBM;
+  const int n0 = nt_idx * PBN;
+  int64_t k_beg = split_idx * a.kchunk;
+  const int64_t k_end = (k_beg + a.kchunk < a.K) ? k_beg + a.kchunk : a.K;
+  if (a.k_lo > 0 && n0 >= a.n_lo && k_beg < a.k_lo) k_beg = a.k_lo;
+  const int nkt = (k_end > k_beg) ? (int)((k_end - k_beg + PBK - 1) / PBK) : 0;
+  if (nkt == 0) return;   // (workgroup-uniform: no barrier has been executed)
+  // this lane's share of a K tile's 32 DMA instructions: instruction q = wave + 8 i covers tile rows 16 q .. 16 q + 15 (A: q < 16, B: q >= 16), lane -> row
+  // 16 q' + (lane >> 2), slot lane & 3, piece slot ^ ((row >> 1) & 3)
+  const bf16* rowp[4]; int piece[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = wave + 8 * i;
+    const bool isA = q < PBM / 16;
+    const int row = 16 * (isA ? q : q - PBM / 16) + (lane >> 2);
+    const int64_t gr = (isA ? m0 : (int64_t)n0) + row;
+    const bool ok = gr < (isA ? a.M : (int64_t)a.N);
+    rowp[i] = ok ? (isA ? a.A + gr * a.lda : a.B + gr * a.ldb) : nullptr;
+    piece[i] = (lane & 3) ^ ((row >> 1) & 3);
+  }
+  const unsigned lds0 = lds_off(smem);
+  auto issue = [&](int kt) {
+    const int64_t k0 = k_beg + (int64_t)kt * PBK;
+    const unsigned st = lds0 + (unsigned)(kt & (PNBUF - 1)) * PBUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t k = k0 + 8 * piece[i];
+      const bf16* src = (rowp[i] && k < k_end) ? rowp[i] + k : a.zero;
+      dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + (unsigned)(wave + 8 * i) * 1024u)));
+    }
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
+  const int key = (r >> 1) & 3;
+  const int arow = (wg * 128 + r) * 64, brow = PBM * 64 + (wc * 64 + r) * 64;
+  int po[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) po[s] = ((2 * s + kg) ^ key) << 4;
+  // prologue: three K tiles requested, the first one complete for everybody
+  issue(0);
+  if (nkt > 1) issue(1);
+  if (nkt > 2) issue(2);
+  {
+    const int behind = (nkt - 1) < 2 ? (nkt - 1) : 2;
+    if (behind == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B0
+  if (wg == 1) asm volatile("s_barrier" ::: "memory");               // G1 falls one barrier behind
+  for (int kt = 0; kt < nkt; ++kt) {
+    // ---- READ segment
+    if (kt + 3 < nkt) issue(kt + 3);
+    const char* st = smem + (kt & (PNBUF - 1)) * PBUF_BYTES;
+    bf16x8 fa[4][2], fb[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) fb[jn][s] = *(const bf16x8*)(st + brow + jn * 32 * 64 + po[s]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i][s] = *(const bf16x8*)(st + arow + i * 32 * 64 + po[s]);
+    }
+    {   // this wave's pieces of K tile kt + 1 have landed (the pieces of kt + 2, kt + 3 may still be in flight)
+      const int last = nkt - 1;
+      const int issued = (kt + 3 < last) ? kt + 3 : last;
+      const int behind = issued - (kt + 1);
+      if (behind >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ---- MFMA segment (the partner wave on this SIMD is in its READ segment)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[jn][s], acc[i][jn], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_barrier" ::: "memory");
+  }
+  if (wg == 0) asm volatile("s_barrier" ::: "memory");   // G0 meets G1's last barrier
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+      const int n = n0 + wc * 64 + jn * 32 + r;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t m = m0 + wg * 128 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+        if (m >= a.M) continue;
+        float* dst = a.C + m * a.ldc + n;
+        if (ACCUM) unsafeAtomicAdd(dst, acc[i][jn][q]); else *dst = acc[i][jn][q];
+      }
+    }
+}
 }  // namespace gx
+
+bool g_gemm16_pingpong = true;   // kprn_set_option "bf16_gemm_pingpong": the split-K products of the bf16 backward on k_gemm16p where the shape suits it
+void set_gemm_pingpong(bool on) { g_gemm16_pingpong = on; }
 
 static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K, bool accumulate,
                     int split_k, int n_lo, int64_t k_lo, int sx_min) {
@@ -709,9 +848,12 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   // 0.110 : 0.107 ms) and slower on the split-K dW (12 tiles deal worse over 8 XCDs than 18): opt-in, kept as the record of that measurement
   static const bool want_y = KPRN_DEV_ENV("KPRN_BF16_GEMM") && KPRN_DEV_ENV("KPRN_BF16_GEMM")[0] == 'y';
   const bool y = want_y && (N % gx::YBN) == 0 && k_lo == 0;
-  const int bn = y ? gx::YBN : gx::BN, bk = y ? gx::YBK : gx::BK;
-  a.mtiles = (M + gx::BM - 1) / gx::BM; a.ntiles = (N + bn - 1) / bn;
   if (split_k < 1 || !accumulate) split_k = 1;
+  // the two-group kernel (k_gemm16p) for the split-K products whose output holds whole 256 x 256 tiles' worth of rows and at least one tile of columns
+  // (configs[3]'s merged dW: 1 536 x 640 = 6 x 3 tiles, the last one half empty)
+  const bool p = g_gemm16_pingpong && !y && accumulate && split_k > 1 && M >= gx::PBM && N >= gx::PBN;
+  const int bn = p ? gx::PBN : (y ? gx::YBN : gx::BN), bk = p ? gx::PBK : (y ? gx::YBK : gx::BK), bm = p ? gx::PBM : gx::BM;
+  a.mtiles = (M + bm - 1) / bm; a.ntiles = (N + bn - 1) / bn;
   if (split_k > 1) {
     // K ranges are dealt to the XCDs (range r on XCD r % 8, all its tiles there), one workgroup per CU (147 KB of LDS), 32 CUs per XCD:
     // with s ranges per XCD the launch takes ceil(tiles s / 32) rounds of 1 / (8 s) of K each.  Pick the s <= 8 with the least
@@ -732,9 +874,10 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   kchunk = ((kchunk + bk - 1) / bk) * bk;
   split_k = (int)((K + kchunk - 1) / kchunk);
   a.kchunk = kchunk; a.nsplit = split_k;
-  const size_t lds_bytes = y ? (size_t)gx::YSTAGE * gx::YSTAGE_BYTES : (size_t)gx::NSTAGE * gx::STAGE_BYTES;
+  const size_t lds_bytes = p ? (size_t)gx::PNBUF * gx::PBUF_BYTES : (y ? (size_t)gx::YSTAGE * gx::YSTAGE_BYTES : (size_t)gx::NSTAGE * gx::STAGE_BYTES);
   static bool attr_done = false;
   if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::PNBUF * gx::PBUF_BYTES)));
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::NSTAGE * gx::STAGE_BYTES)));
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::NSTAGE * gx::STAGE_BYTES)));
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16y<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::YSTAGE * gx::YSTAGE_BYTES)));
@@ -743,7 +886,8 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   }
   dim3 grid((unsigned)(((a.mtiles + 7) / 8) * 8 * a.ntiles));
   if (split_k > 1) grid = dim3((unsigned)(((split_k + 7) / 8) * 8 * a.mtiles * a.ntiles));
-  if (y) {
+  if (p) hipLaunchKernelGGL((gx::k_gemm16p<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
+  else if (y) {
     if (accumulate) hipLaunchKernelGGL((gx::k_gemm16y<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
     else hipLaunchKernelGGL((gx::k_gemm16y<false>), grid, dim3(gx::NTHR), lds_bytes, s, a);
   } else if (accumulate) hipLaunchKernelGGL((gx::k_gemm16x<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
