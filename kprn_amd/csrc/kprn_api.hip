@@ -2355,7 +2355,7 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // table-gradient launch ("0": the A/B reference)
     h->small_tables = atoi(value) != 0;
   } else if (strcmp(key, "bf16_gemm_pingpong") == 0) {
-    // bf16 pipeline: split-K products with >= 256 x 256 outputs on the two-group kernel gx::k_gemm16p ("1", default) or on gx::k_gemm16x ("0").  Process-wide.
+    // bf16 pipeline: split-K products with >= 256 x 256 outputs on the two-group kernel gx::k_gemm16p ("1": opt-in, measured slower) or on gx::k_gemm16x ("0", default).  Process-wide.
     bf16p::set_gemm_pingpong(atoi(value) != 0);
   } else if (strcmp(key, "bf16_bptt_dxe") == 0) {
     // bf16 pipeline with "bf16_small_tables": the entity slice of dx is formed INSIDE the persistent BPTT launch (a fourth result tile per wave; value =

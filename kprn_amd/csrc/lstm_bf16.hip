@@ -833,7 +833,11 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16p(XArgs a) {
 }
 }  // namespace gx
 
-bool g_gemm16_pingpong = true;   // kprn_set_option "bf16_gemm_pingpong": the split-K products of the bf16 backward on k_gemm16p where the shape suits it
+// kprn_set_option "bf16_gemm_pingpong" (default off): the split-K products of the bf16 backward on k_gemm16p where the shape suits it.  MEASURED SLOWER than the
+// lockstep kernel (profiles/r05/bench_c4_m_*, bench_c4_n_*: merged dW 1.50 against 1.10 ms at 64 K ranges, 1.62 / 2.05 / 1.97 at 32 / 16 / 8; k_gemm16x 1.08-1.12
+// at every count): neither the SIMD-level phase collision nor the number of atomic passes is what holds these products at 0.28 of the bf16 peak.  Kept as the
+// record of that experiment; tests/test_gpu_persist.py holds it equal to k_gemm16x to fp32 reordering.
+bool g_gemm16_pingpong = false;
 void set_gemm_pingpong(bool on) { g_gemm16_pingpong = on; }
 
 static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K, bool accumulate,

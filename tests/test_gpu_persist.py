@@ -312,12 +312,12 @@ def test_small_table_gradients_from_the_merged_dw_product_match_the_dx_route(pai
             a, r = gm[off:off + n], g1[off:off + n]
             assert np.max(np.abs(a - r)) < 2e-5 * max(1e-30, np.max(np.abs(r))), (mode, nm, float(np.max(np.abs(a - r))), float(np.max(np.abs(r))))
     eng.set_option("bf16_bptt_dxe", "8")
-    # the merged product on the lockstep kernel (gx::k_gemm16x) instead of the two-group one (gx::k_gemm16p): the same sums in another order.  A K tile read
-    # before it had landed (the two groups run one barrier apart) would show as errors of order 1e-2 in whole output tiles.
-    eng.set_option("bf16_gemm_pingpong", "0")
+    # the merged product on the two-group kernel (gx::k_gemm16p: opt-in, a measured non-improvement) instead of the lockstep one (gx::k_gemm16x): the same sums in
+    # another order.  A K tile read before it had landed (the two groups run one barrier apart) would show as errors of order 1e-2 in whole output tiles.
+    eng.set_option("bf16_gemm_pingpong", "1")
     assert eng.backward(b, 1) == loss1
     gx_ = eng.get_flat_grads().astype(np.float64)
-    eng.set_option("bf16_gemm_pingpong", "1")
+    eng.set_option("bf16_gemm_pingpong", "0")
     for nm, (off, shp) in lay.items():
         n = int(np.prod(shp))
         a, r = g1[off:off + n], gx_[off:off + n]
