@@ -305,7 +305,7 @@ static const bf16* zero16() {   // 16 zero bytes on the device: the source of ev
   }
   return z;
 }
-namespace gx { struct XArgs; template <bool ACCUM> __global__ void k_gemm16x(XArgs a); }
+namespace gx { struct XArgs; template <bool ACCUM, int DBG> __global__ void k_gemm16x(XArgs a); }
 static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K, bool accumulate,
                     int split_k, int n_lo = 0, int64_t k_lo = 0, int sx_min = 1);
 
@@ -345,6 +345,7 @@ constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
 struct XArgs {
   const bf16* A; int64_t lda; const bf16* B; int64_t ldb; float* C; int64_t ldc; int64_t M; int N; int64_t K;
   int64_t kchunk; int nsplit; int64_t mtiles; int ntiles; const bf16* zero;   // zero: 16 zero bytes in global memory (source of every out-of-range piece)
+  int touch;                // > 0: every wave touches the cache lines of the chunk `touch` chunks ahead (one dword per tile row: an L2 prefetch; k_gemm16x)
   int n_lo; int64_t k_lo;   // rows n >= n_lo of B are known to be ZERO for k < k_lo (the merged dW product's h_{t-1}^T block has no step -1): column tiles from n_lo on start at k_lo
 };
 __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
@@ -355,7 +356,8 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
 }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool ACCUM>
+// DBG (measurement build only, KPRN_GEMM16_DBG): 1 no MFMAs, 2 no fragment reads either, 4 no DMA (the stages hold whatever they hold), 8 no epilogue
+template <bool ACCUM, int DBG = 0>
 __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -407,6 +409,27 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
       dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + (unsigned)(wave + 8 * i) * 1024u)));
     }
   };
+  // L2 prefetch by touch (round 5).  The knock-outs (scripts/gpu_gemm16_knockouts.py) show this launch bound by its operand staging, not by its MFMAs: DMA + waits +
+  // barriers alone take 0.82 of the 1.06 ms, MFMAs + fragment reads alone 0.39 -- two 48 KB chunks in flight per CU against ~2 us of HBM latency is 20 B/clk per CU.
+  // LDS cannot hold more stages; the L2 can hold the lines: a chunk row is exactly one 128-byte line, so ONE 4-byte load per tile row, `touch` chunks ahead, brings
+  // the chunk into this XCD's L2 long before its DMA asks for it.  Thread L < 384 owns tile row L (A rows, then B rows); the loaded dword is never looked at -- the
+  // load is inline asm so that hipcc emits no wait for it, and it is issued unconditionally (a clamped address): the counted waits below allow for exactly one more
+  // load per chunk in flight for waves 0-5.
+  const int trow = wave * 64 + lane;
+  const bf16* tptr = a.zero;
+  if (a.touch > 0 && trow < BM + BN) {
+    const bool isA = trow < BM;
+    const int64_t gr = isA ? m0 + trow : (int64_t)n0 + (trow - BM);
+    if (gr < (isA ? a.M : (int64_t)a.N)) tptr = (isA ? a.A + gr * a.lda : a.B + gr * a.ldb) + k_beg;
+  }
+  const bool toucher = a.touch > 0 && wave < (BM + BN) / 64;   // (wave-uniform)
+  auto touch = [&](int c) {
+    if (!toucher) return;
+    const int64_t k = k_beg + (int64_t)c * BK;
+    const bf16* p = (tptr != a.zero && k < k_end) ? tptr + (int64_t)c * BK : a.zero;
+    unsigned dummy;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(p) : "memory");
+  };
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -414,30 +437,52 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
-  issue(0);
-  if (nch > 1) issue(1);
+  if (toucher) {   // the lines of the first chunks beyond the two requested below
+    for (int c = 2; c < 2 + a.touch && c < nch; ++c) touch(c);
+  }
+  if (!(DBG & 4)) {
+    issue(0);
+    if (nch > 1) issue(1);
+  }
   const int key = (r >> 1) & 7;
   const int arow = (wm * 64 + r) * 128, brow = BM * 128 + (wn * 64 + r) * 128;
   for (int c = 0; c < nch; ++c) {
-    // chunk c has landed for this wave (its own 6 pieces; the 6 most recent ones belong to chunk c + 1), then for every wave; and every wave has
-    // finished reading the stage chunk c + 2 is about to overwrite (it held chunk c - 1)
-    if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // chunk c has landed for this wave (its own 6 pieces; the 6 most recent ones belong to chunk c + 1 -- plus, for a touching wave, the one touch issued behind
+    // them), then for every wave; and every wave has finished reading the stage chunk c + 2 is about to overwrite (it held chunk c - 1)
+    if (c + 1 < nch) { if (toucher && c > 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (c + 2 < nch) issue(c + 2);
+    touch(c + 2 + a.touch);   // (unconditional for a touching wave: a chunk past the range touches the zero block; BEFORE the DMA, so that exactly this one
+                              //  touch and the next chunk's six pieces are younger than the pieces the next iteration waits for)
+    if (c + 2 < nch && !(DBG & 4)) issue(c + 2);
     const char* st = smem + (c % NSTAGE) * STAGE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int po = ((2 * kk + kg) ^ key) << 4;
       bf16x8 fa[2], fb[2];
+      if constexpr ((DBG & 2) != 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(st + arow + i * 32 * 128 + po);
+        for (int i = 0; i < 2; ++i) { fa[i] = bf16x8{}; fb[i] = bf16x8{}; asm volatile("" : "+v"(fa[i]), "+v"(fb[i])); }
+      } else {
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn) fb[jn] = *(const bf16x8*)(st + brow + jn * 32 * 128 + po);
+        for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(st + arow + i * 32 * 128 + po);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int jn = 0; jn < 2; ++jn) fb[jn] = *(const bf16x8*)(st + brow + jn * 32 * 128 + po);
+      }
+      if constexpr ((DBG & 1) != 0) {
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(fa[i]), "v"(fb[i]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+      }
     }
+  }
+  if constexpr ((DBG & 8) != 0) {
+    if (acc[0][0][0] == 123.456f) a.C[0] = acc[1][1][3];
+    return;
   }
   // D[m][n]: lane (n = lane & 31, kg), register q <-> row (q & 3) + 8 (q >> 2) + 4 kg: 32 consecutive columns per store instruction
 #pragma unroll
@@ -838,6 +883,8 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16p(XArgs a) {
 // at every count): neither the SIMD-level phase collision nor the number of atomic passes is what holds these products at 0.28 of the bf16 peak.  Kept as the
 // record of that experiment; tests/test_gpu_persist.py holds it equal to k_gemm16x to fp32 reordering.
 bool g_gemm16_pingpong = false;
+int g_gemm16_touch = 6;          // kprn_set_option "bf16_gemm_touch": chunks ahead of its DMA k_gemm16x touches a chunk's cache lines (0: off)
+void set_gemm_touch(int n) { g_gemm16_touch = n < 0 ? 0 : (n > 32 ? 32 : n); }
 void set_gemm_pingpong(bool on) { g_gemm16_pingpong = on; }
 
 static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int64_t K, bool accumulate,
@@ -848,6 +895,7 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero = zero16();
   a.n_lo = n_lo; a.k_lo = k_lo;
+  a.touch = g_gemm16_touch;
   // KPRN_BF16_GEMM=y: 256 x 192 tiles where they divide N (configs[3]: N = 384).  Measured equal to the 256 x 128 kernel on dx / dh (0.743 : 0.750,
   // 0.110 : 0.107 ms) and slower on the split-K dW (12 tiles deal worse over 8 XCDs than 18): opt-in, kept as the record of that measurement
   static const bool want_y = KPRN_DEV_ENV("KPRN_BF16_GEMM") && KPRN_DEV_ENV("KPRN_BF16_GEMM")[0] == 'y';
@@ -894,8 +942,23 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   else if (y) {
     if (accumulate) hipLaunchKernelGGL((gx::k_gemm16y<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
     else hipLaunchKernelGGL((gx::k_gemm16y<false>), grid, dim3(gx::NTHR), lds_bytes, s, a);
-  } else if (accumulate) hipLaunchKernelGGL((gx::k_gemm16x<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
-  else hipLaunchKernelGGL((gx::k_gemm16x<false>), grid, dim3(gx::NTHR), lds_bytes, s, a);
+  } else if (accumulate) {
+#ifdef KPRN_PERSIST_VARIANTS
+    // measurement build (scripts/gpu_gemm16_knockouts.py): KPRN_GEMM16_DBG = knock-out mask of the split-K launch
+    if (const char* e = KPRN_DEV_ENV("KPRN_GEMM16_DBG")) {
+      const int dbg = atoi(e);
+      bool found = true;
+#define KV(D) case D: HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+                      hipLaunchKernelGGL((gx::k_gemm16x<true, D>), grid, dim3(gx::NTHR), lds_bytes, s, a); break;
+      switch (dbg) { KV(0) KV(1) KV(3) KV(4) KV(5) KV(7) KV(8) KV(9) KV(12) default: found = false; }
+#undef KV
+      KPRN_REQUIRE(found, KPRN_E_ARG, "this knock-out of k_gemm16x is not compiled in");
+      HIP_TRY(hipGetLastError());
+      return true;
+    }
+#endif
+    hipLaunchKernelGGL((gx::k_gemm16x<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
+  } else hipLaunchKernelGGL((gx::k_gemm16x<false>), grid, dim3(gx::NTHR), lds_bytes, s, a);
   HIP_TRY(hipGetLastError());
   return true;
 }
