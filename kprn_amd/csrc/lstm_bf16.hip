@@ -412,9 +412,10 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
   // L2 prefetch by touch (round 5).  The knock-outs (scripts/gpu_gemm16_knockouts.py) show this launch bound by its operand staging, not by its MFMAs: DMA + waits +
   // barriers alone take 0.82 of the 1.06 ms, MFMAs + fragment reads alone 0.39 -- two 48 KB chunks in flight per CU against ~2 us of HBM latency is 20 B/clk per CU.
   // LDS cannot hold more stages; the L2 can hold the lines: a chunk row is exactly one 128-byte line, so ONE 4-byte load per tile row, `touch` chunks ahead, brings
-  // the chunk into this XCD's L2 long before its DMA asks for it.  Thread L < 384 owns tile row L (A rows, then B rows); the loaded dword is never looked at -- the
-  // load is inline asm so that hipcc emits no wait for it, and it is issued unconditionally (a clamped address): the counted waits below allow for exactly one more
-  // load per chunk in flight for waves 0-5.
+  // the chunk into this XCD's L2 long before its DMA asks for it.  Thread L < 384 owns tile row L (A rows, then B rows); the loaded dword is never looked at and
+  // must not land in a register (an asynchronous load into a VGPR that hipcc believes dead overwrites whatever it put there next -- the first build of this
+  // faulted): it is a 4-byte LDS-DMA into a scratch strip behind the stages.  Issued unconditionally (a clamped address): the counted waits below allow for
+  // exactly one more load per chunk in flight for waves 0-5.
   const int trow = wave * 64 + lane;
   const bf16* tptr = a.zero;
   if (a.touch > 0 && trow < BM + BN) {
@@ -427,8 +428,9 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
     if (!toucher) return;
     const int64_t k = k_beg + (int64_t)c * BK;
     const bf16* p = (tptr != a.zero && k < k_end) ? tptr + (int64_t)c * BK : a.zero;
-    unsigned dummy;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(p) : "memory");
+    unsigned keep;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)NSTAGE * STAGE_BYTES + (unsigned)wave * 256u));
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -926,12 +928,12 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   kchunk = ((kchunk + bk - 1) / bk) * bk;
   split_k = (int)((K + kchunk - 1) / kchunk);
   a.kchunk = kchunk; a.nsplit = split_k;
-  const size_t lds_bytes = p ? (size_t)gx::PNBUF * gx::PBUF_BYTES : (y ? (size_t)gx::YSTAGE * gx::YSTAGE_BYTES : (size_t)gx::NSTAGE * gx::STAGE_BYTES);
+  const size_t lds_bytes = p ? (size_t)gx::PNBUF * gx::PBUF_BYTES : (y ? (size_t)gx::YSTAGE * gx::YSTAGE_BYTES : (size_t)gx::NSTAGE * gx::STAGE_BYTES + 2048 /* touch scratch */);
   static bool attr_done = false;
   if (!attr_done) {
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::PNBUF * gx::PBUF_BYTES)));
-    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::NSTAGE * gx::STAGE_BYTES)));
-    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::NSTAGE * gx::STAGE_BYTES)));
+    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::NSTAGE * gx::STAGE_BYTES + 2048)));
+    HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::NSTAGE * gx::STAGE_BYTES + 2048)));
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16y<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::YSTAGE * gx::YSTAGE_BYTES)));
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16y<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::YSTAGE * gx::YSTAGE_BYTES)));
     attr_done = true;
