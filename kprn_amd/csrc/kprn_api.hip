@@ -2354,6 +2354,9 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // generic fp32 pipelines: layer 0's type / relation gradients from G = dA^T [S_r | S_t] ("1", default) or from the full dx product + the
     // table-gradient launch ("0": the A/B reference)
     h->small_tables = atoi(value) != 0;
+  } else if (strcmp(key, "bf16_gemm_regstage") == 0) {
+    // bf16 split-K products on gx::k_gemm16r ("1", default: operands global -> registers -> LDS, four chunks in flight per thread) or gx::k_gemm16x ("0": LDS-DMA, two)
+    bf16p::set_gemm_regstage(atoi(value) != 0);
   } else if (strcmp(key, "bf16_gemm_touch") == 0) {
     // bf16 products on gx::k_gemm16x: every wave touches (one dword per tile row = one cache line) the chunk this many chunks ahead of its DMA: an L2 prefetch
     // for a launch that is bound by its operand staging ("0": off).  Process-wide.

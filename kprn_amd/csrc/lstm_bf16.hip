@@ -743,6 +743,129 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16y(XArgs a) {
     }
 }
 
+// ---- the x tile with its operands staged through REGISTERS, four chunks in flight (round 5) --------------------------------------------------------------------------
+// Knock-outs of k_gemm16x on the merged dW product (scripts/gpu_gemm16_knockouts.py, profiles/r05/gemm16_knockouts.txt): DMA + waits + barriers alone 0.82 of the
+// 1.06 ms, MFMAs + fragment reads alone 0.39 -- the launch is bound by its operand staging, and that staging by LATENCY: two 48 KB chunks in flight per CU against
+// ~2 us from HBM is 20 bytes per clock and CU, a third of what the L1 path carries.  LDS cannot hold more stages (3 x 48 KB).  Registers can: here every thread fetches
+// its six 16-byte pieces of a chunk into VGPRs THREE chunks before it writes them to LDS (ds_write_b128, the same XOR swizzle applied to the write address), so four
+// chunks = 192 KB per CU are in flight; LDS is a plain double buffer, one barrier per chunk.  No inline-asm loads: hipcc counts its own vmcnt exactly (the chunk loop
+// is unrolled by the ring's period so that the ring is statically indexed), fences keep the loads where they are written.
+constexpr int RRING = 4;   // chunk buffers per thread (3 ahead + the one being written)
+template <bool ACCUM>
+__global__ __launch_bounds__(NTHR, 2) void k_gemm16r(XArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, kg = lane >> 5;
+  const int64_t id = blockIdx.x;
+  const int xcd = (int)(id & 7);
+  const int64_t j = id >> 3;
+  int nt_idx; int64_t mt_idx, split_idx = 0;
+  if (a.nsplit > 1) {
+    const int64_t tiles = a.mtiles * a.ntiles;
+    split_idx = (j / tiles) * 8 + xcd;
+    const int64_t tl = j % tiles;
+    mt_idx = tl / a.ntiles; nt_idx = (int)(tl % a.ntiles);
+    if (split_idx >= a.nsplit) return;
+  } else {
+    nt_idx = (int)(j % a.ntiles);
+    mt_idx = (j / a.ntiles) * 8 + xcd;
+    if (mt_idx >= a.mtiles) return;
+  }
+  const int64_t m0 = mt_idx * BM;
+  const int n0 = nt_idx * BN;
+  int64_t k_beg = split_idx * a.kchunk;
+  const int64_t k_end = (k_beg + a.kchunk < a.K) ? k_beg + a.kchunk : a.K;
+  if (a.k_lo > 0 && n0 >= a.n_lo && k_beg < a.k_lo) k_beg = a.k_lo;
+  const int nch = (k_end > k_beg) ? (int)((k_end - k_beg + BK - 1) / BK) : 0;
+  if (nch == 0) return;
+  // piece i of this thread: tile row 8 q + (lane >> 3) of instruction slot q = wave + 8 i (A: q < 32, B: q >= 32), 16-byte slot lane & 7 of the row's 128 bytes
+  const bf16* src[6]; unsigned wofs[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int q = wave + 8 * i;
+    const bool isA = q < BM / 8;
+    const int row = 8 * (isA ? q : q - BM / 8) + (lane >> 3);
+    const int64_t gr = (isA ? m0 : (int64_t)n0) + row;
+    const bool ok = gr < (isA ? a.M : (int64_t)a.N);
+    src[i] = ok ? (isA ? a.A + gr * a.lda : a.B + gr * a.ldb) + k_beg + 8 * (lane & 7) : nullptr;
+    wofs[i] = (unsigned)((isA ? 0 : BM * 128) + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+  }
+  bf16x8 ring[RRING][6];
+  auto fetch = [&](int c, bf16x8 (&dst)[6]) {   // chunk c of this thread's rows (pieces past the K range / the problem: the zero block)
+    const int64_t kk0 = (int64_t)c * BK;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const bf16* p = (src[i] && c < nch && k_beg + kk0 + 8 * (lane & 7) < k_end) ? src[i] + kk0 : a.zero;
+      dst[i] = *(const bf16x8*)p;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto stash = [&](int stage, const bf16x8 (&v)[6]) {
+    char* st = smem + stage * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *(bf16x8*)(st + wofs[i]) = v[i];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
+  const int key = (r >> 1) & 7;
+  const int arow = (wm * 64 + r) * 128, brow = BM * 128 + (wn * 64 + r) * 128;
+  auto product = [&](int stage) {
+    const char* st = smem + stage * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int po = ((2 * kk + kg) ^ key) << 4;
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(st + arow + i * 32 * 128 + po);
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) fb[jn] = *(const bf16x8*)(st + brow + jn * 32 * 128 + po);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+    }
+  };
+  // prologue: chunks 0 .. 3 requested, chunk 0 written to stage 0
+  fetch(0, ring[0]); fetch(1, ring[1]); fetch(2, ring[2]); fetch(3, ring[3]);
+  stash(0, ring[0]);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // iteration c: chunk c + 4 is requested into the ring slot chunk c just left, chunk c + 1 goes from its registers to the other stage, chunk c is multiplied
+  for (int c0 = 0; c0 < nch; c0 += RRING) {
+#pragma unroll
+    for (int u = 0; u < RRING; ++u) {
+      const int c = c0 + u;
+      if (c < nch) {   // (workgroup-uniform)
+        fetch(c + RRING, ring[u]);
+        stash((c + 1) & 1, ring[(u + 1) % RRING]);
+        __builtin_amdgcn_sched_barrier(0);
+        product(c & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+      const int n = n0 + wn * 64 + jn * 32 + r;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+        if (m >= a.M) continue;
+        float* dst = a.C + m * a.ldc + n;
+        if (ACCUM) unsafeAtomicAdd(dst, acc[i][jn][q]); else *dst = acc[i][jn][q];
+      }
+    }
+}
+
 // ---- 256 x 256 x 32 tiles, two wave groups one barrier apart (round 5) --------------------------------------------------------------------------------
 // What k_gemm16x / k_gemm16y share is their lockstep: every wave meets the same barrier, then every wave reads its fragments, then every wave issues its MFMAs --
 // the two waves of a SIMD wait for LDS at the same moment and want the matrix pipe at the same moment (0.28-0.36 of the bf16 peak whatever the tile).  Here the
@@ -885,7 +1008,12 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16p(XArgs a) {
 // at every count): neither the SIMD-level phase collision nor the number of atomic passes is what holds these products at 0.28 of the bf16 peak.  Kept as the
 // record of that experiment; tests/test_gpu_persist.py holds it equal to k_gemm16x to fp32 reordering.
 bool g_gemm16_pingpong = false;
-int g_gemm16_touch = 6;          // kprn_set_option "bf16_gemm_touch": chunks ahead of its DMA k_gemm16x touches a chunk's cache lines (0: off)
+// kprn_set_option "bf16_gemm_touch" (default 0 = off): chunks ahead of its DMA k_gemm16x touches a chunk's cache lines.  MEASURED SLOWER (merged dW 1.06 -> 1.64 ms
+// at 3 / 6 / 12 chunks: loads retire in issue order, so a touch that misses to HBM holds back the retirement of every DMA piece issued behind it -- the prefetch
+// sits on the critical path it was meant to shorten).  Kept as the record; the test holds it equal to the untouched launch.
+int g_gemm16_touch = 0;
+bool g_gemm16_regstage = true;   // kprn_set_option "bf16_gemm_regstage": the split-K products on k_gemm16r (operands through registers, four chunks in flight)
+void set_gemm_regstage(bool on) { g_gemm16_regstage = on; }
 void set_gemm_touch(int n) { g_gemm16_touch = n < 0 ? 0 : (n > 32 ? 32 : n); }
 void set_gemm_pingpong(bool on) { g_gemm16_pingpong = on; }
 
@@ -940,6 +1068,14 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   }
   dim3 grid((unsigned)(((a.mtiles + 7) / 8) * 8 * a.ntiles));
   if (split_k > 1) grid = dim3((unsigned)(((split_k + 7) / 8) * 8 * a.mtiles * a.ntiles));
+  if (!p && !y && accumulate && split_k > 1 && g_gemm16_regstage) {
+    static bool r_attr = false;
+    const size_t lds_r = (size_t)2 * gx::STAGE_BYTES;
+    if (!r_attr) { HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16r<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r)); r_attr = true; }
+    hipLaunchKernelGGL((gx::k_gemm16r<true>), grid, dim3(gx::NTHR), lds_r, s, a);
+    HIP_TRY(hipGetLastError());
+    return true;
+  }
   if (p) hipLaunchKernelGGL((gx::k_gemm16p<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
   else if (y) {
     if (accumulate) hipLaunchKernelGGL((gx::k_gemm16y<true>), grid, dim3(gx::NTHR), lds_bytes, s, a);
