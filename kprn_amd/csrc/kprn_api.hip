@@ -2354,6 +2354,8 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // generic fp32 pipelines: layer 0's type / relation gradients from G = dA^T [S_r | S_t] ("1", default) or from the full dx product + the
     // table-gradient launch ("0": the A/B reference)
     h->small_tables = atoi(value) != 0;
+  } else if (strcmp(key, "bf16_t_pad") == 0) {
+    bf16p::set_t_pad(atoi(value));   // small-table route: pad (elements) of the row pitch of dA^T / Z^T ("0": rows 2^18-aligned at the bench's size)
   } else if (strcmp(key, "bf16_gemm_regstage") == 0) {
     // bf16 split-K products on gx::k_gemm16r ("1", default: operands global -> registers -> LDS, four chunks in flight per thread) or gx::k_gemm16x ("0": LDS-DMA, two)
     bf16p::set_gemm_regstage(atoi(value) != 0);

@@ -451,6 +451,7 @@ void release(kprn_handle* h);
 float debug_gemm16(hipStream_t s, int64_t M, int N, int64_t K, int split_k, int iters);
 void set_gemm_touch(int chunks);   // (process-wide) L2 prefetch distance of k_gemm16x (0: off)
 void set_gemm_regstage(bool on);   // (process-wide) the split-K bf16 products on gx::k_gemm16r (register-staged operands, four chunks in flight)
+void set_t_pad(int elements);      // (process-wide) pad of the transposed images' row pitch on the small-table route (HBM channel spread)
 void set_gemm_pingpong(bool on);   // (process-wide) the split-K bf16 products on the two-group 256 x 256 kernel (default) or on k_gemm16x   // ms per launch (kprn_debug_gemm what 5 / 6)
 }  // namespace bf16p
 

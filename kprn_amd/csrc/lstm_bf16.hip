@@ -1007,6 +1007,8 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16p(XArgs a) {
 // lockstep kernel (profiles/r05/bench_c4_m_*, bench_c4_n_*: merged dW 1.50 against 1.10 ms at 64 K ranges, 1.62 / 2.05 / 1.97 at 32 / 16 / 8; k_gemm16x 1.08-1.12
 // at every count): neither the SIMD-level phase collision nor the number of atomic passes is what holds these products at 0.28 of the bf16 peak.  Kept as the
 // record of that experiment; tests/test_gpu_persist.py holds it equal to k_gemm16x to fp32 reordering.
+int g_t_pad = 64;                // kprn_set_option "bf16_t_pad": pad (elements, a multiple of 8, <= 512) of the row pitch of dA^T / Z^T on the small-table route
+void set_t_pad(int n) { g_t_pad = n < 0 ? 0 : (n > 512 ? 512 : (n & ~7)); }
 bool g_gemm16_pingpong = false;
 // kprn_set_option "bf16_gemm_touch" (default 0 = off): chunks ahead of its DMA k_gemm16x touches a chunk's cache lines.  MEASURED SLOWER (merged dW 1.06 -> 1.64 ms
 // at 3 / 6 / 12 chunks: loads retire in issue order, so a touch that misses to HBM holds back the retirement of every DMA piece issued behind it -- the prefetch
@@ -1576,7 +1578,7 @@ void persist_release(void*& st);
 // lstm_bf16_bwd_persist.hip: BPTT through the layer (cell backward + recurrent product of all T steps) as one persistent launch
 bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv, int64_t N, int T);
 void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16 /* nullable: no row-major copy */, bf16* dAT16, int64_t Np,
-                      float* dXe /* nullable: the launch also forms the entity slice of dx, [T][N][de] */);
+                      float* dXe /* nullable: the launch also forms the entity slice of dx, [T][N][de] */, int64_t ldT /* row pitch of dA^T, T Np .. T Np + 512 */);
 bool persist_bwd_dxe_ok(const kprn_handle* h);
 void persist_bwd_release(void*& st);
 static State* st(kprn_handle* h) {
@@ -1674,7 +1676,7 @@ static void ensure_buffers(kprn_handle* h, int64_t N, int T) {
   s->X16 = dal<bf16>(rows * h->D); s->XT16 = dal<bf16>(rows_p * Dm);
   s->H16 = dal<bf16>((int64_t)c.L * rows * c.H); s->HT16 = dal<bf16>(rows_p * c.H);
   s->ACT16 = dal<bf16>((int64_t)c.L * rows * 4 * c.H);
-  s->dA16 = dal<bf16>(rows * 4 * c.H); s->dAT16 = dal<bf16>(rows_p * 4 * c.H);
+  s->dA16 = dal<bf16>(rows * 4 * c.H); s->dAT16 = dal<bf16>((rows_p + 512) * 4 * c.H);   // (+ 512: room for a padded row pitch, t_pitch)
   s->cap_N = cn; s->cap_T = ct;
 }
 
@@ -1892,8 +1894,12 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
                       c.de >= 128 && T > 1 && b->key_sorted != nullptr && !b->tile_k && s->sv.HsF && (H % 64) == 0;
     // ... and that slice of dx formed inside the BPTT launch itself (a fourth result tile per wave): no dx product launch, dA^T read once less
     const bool dxe_in_bptt = tabs && h->bf16_bptt_dxe != 0 && persist_bwd_dxe_ok(h);
+    // Row pitch of the transposed images of the small-table route: T Np elements is 3 x 2^18 bytes at the bench's size -- the 1 536 rows of dA^T (and the 640 of the
+    // merged product's other operand) that a K range touches then start at addresses 786 432 bytes apart, i.e. on the same few HBM channels.  A pad of g_t_pad
+    // elements (kprn_set_option "bf16_t_pad", default 64 = one 128-byte line) walks consecutive rows over consecutive channels.
+    const int64_t ldz = (int64_t)T * Np_ + (tabs ? g_t_pad : 0);
     if (bptt_persist) {
-      persist_backward(h, N, T, cid, s->sv, s->persist_bwd, s->packb_dirty, dx_t ? nullptr : s->dA16, s->dAT16, Np_, dxe_in_bptt ? w.dIn : nullptr);
+      persist_backward(h, N, T, cid, s->sv, s->persist_bwd, s->packb_dirty, dx_t ? nullptr : s->dA16, s->dAT16, Np_, dxe_in_bptt ? w.dIn : nullptr, ldz);
       s->packb_dirty = false;
       s->bias_in_gates = true;   // (the launch sums the bias gradient from the dA^T pieces it writes)
     }
@@ -1935,11 +1941,11 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     const int64_t Np = (N + 7) & ~(int64_t)7, TNp = (int64_t)T * Np;   // padded step blocks of the transposed images (pads are zero)
     if (tabs) {
       const int NZ = c.de + 128 + H;
-      if (TNp * NZ > s->z_cap) {
+      if (ldz * NZ > s->z_cap) {
         HIP_TRY(hipStreamSynchronize(strm));
         if (overlap) HIP_TRY(hipStreamSynchronize(side));
         if (s->ZT16) hipFree(s->ZT16);
-        s->ZT16 = nullptr; s->ZT16 = dal<bf16>(TNp * NZ); s->z_cap = TNp * NZ;
+        s->ZT16 = nullptr; s->ZT16 = dal<bf16>(ldz * NZ); s->z_cap = ldz * NZ;
       }
       if ((int64_t)G4 * NZ > s->ct_cap) {
         HIP_TRY(hipStreamSynchronize(strm));
@@ -1947,22 +1953,22 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
         s->Ctmp = nullptr; s->Ctmp = dal<float>((int64_t)G4 * NZ); s->ct_cap = (int64_t)G4 * NZ;
       }
       bf16* zt_e = s->ZT16;                              // rows [0, de): x_e^T, the entity slice of the step input
-      bf16* zt_s = s->ZT16 + (int64_t)c.de * TNp;        // rows [de, de + 128): the one-hot selectors
-      bf16* zt_h = s->ZT16 + (int64_t)(c.de + 128) * TNp;   // rows behind them: h_{t-1}^T (step block 0 zero)
+      bf16* zt_s = s->ZT16 + (int64_t)c.de * ldz;        // rows [de, de + 128): the one-hot selectors
+      bf16* zt_h = s->ZT16 + (int64_t)(c.de + 128) * ldz;   // rows behind them: h_{t-1}^T (step block 0 zero)
       {
         ProfScope ps(h, "bf16_transposes", side);   // (side stream: beside the BPTT launch queued above -- nothing here reads what it writes)
         hipLaunchKernelGGL(k_gather16_T, dim3((unsigned)((Np + 63) / 64), (unsigned)((c.de + 63) / 64), (unsigned)T), dim3(256), 0, side, b->idx, N, Np, T, b->F, 1,
-                           s->We16, s->We16, s->We16, 0, c.de, 0, zt_e, TNp);
-        hipLaunchKernelGGL(k_onehot_T, dim3((unsigned)((Np + 63) / 64), (unsigned)T), dim3(256), 0, side, b->idx, N, Np, T, b->F, c.Vr, c.Vt, zt_s, TNp);
-        HIP_TRY(hipMemset2DAsync(zt_h, (size_t)TNp * sizeof(bf16), 0, (size_t)Np * sizeof(bf16), (size_t)H, side));
+                           s->We16, s->We16, s->We16, 0, c.de, 0, zt_e, ldz);
+        hipLaunchKernelGGL(k_onehot_T, dim3((unsigned)((Np + 63) / 64), (unsigned)T), dim3(256), 0, side, b->idx, N, Np, T, b->F, c.Vr, c.Vt, zt_s, ldz);
+        HIP_TRY(hipMemset2DAsync(zt_h, (size_t)ldz * sizeof(bf16), 0, (size_t)Np * sizeof(bf16), (size_t)H, side));
         hipLaunchKernelGGL(k_hfrag_T, dim3((unsigned)((s->sv.NU + 1) / 2), (unsigned)(H / 64), (unsigned)(T - 1)), dim3(256), 0, side, (const bf16x4*)s->sv.HsF, zt_h + Np,
-                           (int64_t)s->sv.NU, (int64_t)s->sv.step_recs, N, Np, TNp, H);
+                           (int64_t)s->sv.NU, (int64_t)s->sv.step_recs, N, Np, ldz, H);
         HIP_TRY(hipGetLastError());
       }
       if (overlap) HIP_TRY(hipEventRecord(s->ev_operands, side));
       if (!dxe_in_bptt) {
         ProfScope ps(h, "gemm_i2g_bwd_dx_e");   // dx_e [T N][de] = dA W_i2g[:, entity columns] (compact: what the entity gather-reduce reads)
-        const bool ran = gemm16xt(strm, s->dAT16, TNp, wt + (int64_t)c.dt * G4, G4, w.dIn, c.de, TNp, c.de, G4, Np, N);
+        const bool ran = gemm16xt(strm, s->dAT16, ldz, wt + (int64_t)c.dt * G4, G4, w.dIn, c.de, TNp, c.de, G4, Np, N);
         KPRN_REQUIRE(ran, KPRN_E_ARG, "bf16 backward: the transposed-dA dx product does not cover this shape (dx_from_transposed_ok said it would)");
       }
       if (overlap) {
@@ -1980,8 +1986,8 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
         const int split = (int)std::min<int64_t>(1024, std::max<int64_t>(1, TN / 4096));
         // (h_{t-1}^T has no step -1: its column tiles skip the K ranges of step block 0 -- a tenth of the launch's workgroups; 8 K ranges per XCD so that
         //  whole workgroups fall into that block)
-        if (!gemm16x(strm, s->dAT16, TNp, s->ZT16, TNp, s->Ctmp, NZ, G4, NZ, TNp, true, split, c.de + 128, Np, 8))
-          gemm16(strm, s->dAT16, TNp, s->ZT16, TNp, s->Ctmp, NZ, G4, NZ, TNp, true, nullptr, split);
+        if (!gemm16x(strm, s->dAT16, ldz, s->ZT16, ldz, s->Ctmp, NZ, G4, NZ, TNp, true, split, c.de + 128, Np, 8))
+          gemm16(strm, s->dAT16, ldz, s->ZT16, ldz, s->Ctmp, NZ, G4, NZ, TNp, true, nullptr, split);
       }
       {
         ProfScope ps(h, "small_tables_finish");

@@ -451,7 +451,7 @@ struct PersistBwdState { bf16* WpB = nullptr; int grid = 0; int packed_mjp = 0; 
 // (T x N beyond the 32-bit row-block offsets of dA^T: about 4.8 M (path, step) positions at H = 384) trains through the per-step loop instead.
 static bool persist_bwd_offsets_ok(int64_t N, int T) {
   const int64_t Np = (N + 7) & ~(int64_t)7;
-  return (int64_t)T * Np * (pb::H + 64) * 2 < ((int64_t)1 << 32);
+  return ((int64_t)T * Np + 512) * (pb::H + 64) * 2 < ((int64_t)1 << 32);   // (+ 512: the row pitch of dA^T may be padded, lstm_bf16.hip t_pitch)
 }
 bool persist_bwd_shape_ok(const kprn_handle* h, const PersistSaves& sv, int64_t N, int T) {
   static const bool off = [] { const char* e = getenv("KPRN_BF16_BWD_PERSIST"); return e && e[0] == '0'; }();
@@ -470,7 +470,7 @@ void persist_bwd_release(void*& st) {
 // dXe (nullable): the launch also forms the entity slice of dx, [T][N][de] fp32 (de = 128 columns from dt on) -- persist_bwd_dxe_ok() says whether it can
 bool persist_bwd_dxe_ok(const kprn_handle* h) { return h->cfg.de == pb::DE && h->D >= h->cfg.dt + pb::DE; }
 void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSaves& sv, void*& st, bool repack, bf16* dA16 /* nullable: no row-major copy */, bf16* dAT16, int64_t Np,
-                      float* dXe) {
+                      float* dXe, int64_t ldT) {
   hipStream_t strm = h->stream;
   PersistBwdState* p = (PersistBwdState*)st;
   if (!p) {
@@ -501,7 +501,8 @@ void persist_backward(kprn_handle* h, int64_t N, int T, int cid, const PersistSa
   a.NU = sv.NU; a.step_recs = sv.step_recs;
   a.dS = h->ws.dS; a.Wc = h->dense + h->off_outW + (int64_t)cid * pb::H;
   a.WpB = p->WpB; a.dA = dA16; a.dAT = dAT16; a.dXe = dXe; a.gbias = h->g_dense + h->layer[0].bi;
-  a.N = N; a.Np = Np; a.ldT = (int64_t)T * Np; a.T = T;
+  KPRN_REQUIRE(ldT >= (int64_t)T * Np && ldT <= (int64_t)T * Np + 512 && (ldT & 7) == 0, KPRN_E_ARG, "persistent BPTT: bad row pitch of dA^T");
+  a.N = N; a.Np = Np; a.ldT = ldT; a.T = T;
   // tile height: 64 rows, one workgroup per CU (default), or 32 rows, two workgroups per CU (KPRN_BPTT_NPT=1: each weight fragment then serves one
   // path tile only -- twice the weight bytes through the L1 path -- for two independent barrier domains per CU)
   static const int npt_env = KPRN_DEV_ENV("KPRN_BPTT_NPT") ? atoi(KPRN_DEV_ENV("KPRN_BPTT_NPT")) : 2;
