@@ -356,7 +356,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
 }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// DBG (measurement build only, KPRN_GEMM16_DBG): 1 no MFMAs, 2 no fragment reads either, 4 no DMA (the stages hold whatever they hold), 8 no epilogue
+// DBG (measurement build only, KPRN_GEMM16_DBG): 1 no MFMAs, 2 no fragment reads either, 4 no DMA (the stages hold whatever they hold), 8 no epilogue,
+// 16 the DMA pieces come from where a K-blocked layout [K / 64][rows][64] would hold them (tile rows 128 bytes apart instead of a row pitch apart; the same bytes,
+// instructions and reuse between tiles: what the row-major layout costs in address translation / DRAM page locality)
 template <bool ACCUM, int DBG = 0>
 __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -406,6 +408,13 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
     for (int i = 0; i < 6; ++i) {
       const int64_t k = k0 + 8 * piece[i];
       const bf16* src = (rowp[i] && k < k_end) ? rowp[i] + k : a.zero;
+      if constexpr ((DBG & 16) != 0) {   // the K-blocked layout [K / 64][rows][64], emulated inside the same allocations: the same reuse between tiles, rows 128 bytes apart
+        if (rowp[i] && k < k_end) {
+          const bool isA = (wave + 8 * i) < BM / 8;
+          const int64_t gr = isA ? (rowp[i] - a.A) / a.lda : (rowp[i] - a.B) / a.ldb;
+          src = (isA ? a.A + (k0 >> 6) * (a.M * 64) : a.B + (k0 >> 6) * ((int64_t)a.N * 64)) + gr * 64 + 8 * piece[i];
+        }
+      }
       dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + (unsigned)(wave + 8 * i) * 1024u)));
     }
   };
@@ -1014,7 +1023,7 @@ bool g_gemm16_pingpong = false;
 // at 3 / 6 / 12 chunks: loads retire in issue order, so a touch that misses to HBM holds back the retirement of every DMA piece issued behind it -- the prefetch
 // sits on the critical path it was meant to shorten).  Kept as the record; the test holds it equal to the untouched launch.
 int g_gemm16_touch = 0;
-bool g_gemm16_regstage = true;   // kprn_set_option "bf16_gemm_regstage": the split-K products on k_gemm16r (operands through registers, four chunks in flight)
+bool g_gemm16_regstage = false;  // kprn_set_option "bf16_gemm_regstage": the split-K products on k_gemm16r (operands through registers, four chunks in flight); opt-in, measured no faster
 void set_gemm_regstage(bool on) { g_gemm16_regstage = on; }
 void set_gemm_touch(int n) { g_gemm16_touch = n < 0 ? 0 : (n > 32 ? 32 : n); }
 void set_gemm_pingpong(bool on) { g_gemm16_pingpong = on; }
@@ -1090,7 +1099,7 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
       bool found = true;
 #define KV(D) case D: HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
                       hipLaunchKernelGGL((gx::k_gemm16x<true, D>), grid, dim3(gx::NTHR), lds_bytes, s, a); break;
-      switch (dbg) { KV(0) KV(1) KV(3) KV(4) KV(5) KV(7) KV(8) KV(9) KV(12) default: found = false; }
+      switch (dbg) { KV(0) KV(1) KV(3) KV(4) KV(5) KV(7) KV(8) KV(9) KV(12) KV(16) KV(19) KV(27) default: found = false; }
 #undef KV
       KPRN_REQUIRE(found, KPRN_E_ARG, "this knock-out of k_gemm16x is not compiled in");
       HIP_TRY(hipGetLastError());

@@ -19,9 +19,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
     sys.exit(0)
 MASKS = [(0, "full"), (1, "no MFMAs"), (3, "no MFMAs, no fragment reads (DMA + waits + barriers + epilogue)"), (4, "no DMA"), (5, "no DMA, no MFMAs (fragment reads only)"),
-         (7, "skeleton: barriers + epilogue"), (8, "no epilogue"), (9, "no MFMAs, no epilogue"), (12, "no DMA, no epilogue (MFMAs + fragment reads)")]
+         (7, "skeleton: barriers + epilogue"), (8, "no epilogue"), (9, "no MFMAs, no epilogue"), (12, "no DMA, no epilogue (MFMAs + fragment reads)"),
+         (16, "full, sources as a K-blocked layout [K/64][rows][64] would have them"), (19, "DMA + waits + barriers + epilogue, K-blocked sources"),
+         (27, "DMA + waits + barriers, no epilogue, K-blocked sources")]
+ONLY = [int(x) for x in os.environ.get("KPRN_KNOCKOUT_MASKS", "").split(",") if x]
 for rep in range(2):
     for m, what in MASKS:
+        if ONLY and m not in ONLY:
+            continue
         env = dict(os.environ, KPRN_GEMM16_DBG=str(m))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], capture_output=True, text=True, env=env, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]

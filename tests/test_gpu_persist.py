@@ -322,16 +322,13 @@ def test_small_table_gradients_from_the_merged_dw_product_match_the_dx_route(pai
         n = int(np.prod(shp))
         a, r = g1[off:off + n], gx_[off:off + n]
         assert np.max(np.abs(a - r)) < 2e-5 * max(1e-30, np.max(np.abs(r))), ("pingpong", nm, float(np.max(np.abs(a - r))), float(np.max(np.abs(r))))
-    # ... the default split-K product stages its operands through registers (gx::k_gemm16r); against the LDS-DMA kernel (gx::k_gemm16x) with and without the
-    # opt-in L2 prefetch touches (they change the counted waits of its DMA ring: a chunk used one touch too early would show here)
-    for key, val, back in (("bf16_gemm_regstage", "0", "1"), ("bf16_gemm_touch", "6", "0")):
+    # ... the opt-in variants of the split-K product: operands staged through registers (gx::k_gemm16r) instead of the LDS-DMA ring (gx::k_gemm16x), and the
+    # L2 prefetch touches (they change the counted waits of the DMA ring: a chunk used one touch too early would show here)
+    for key, val, back in (("bf16_gemm_regstage", "1", "0"), ("bf16_gemm_touch", "6", "0")):
         eng.set_option(key, val)
-        if key == "bf16_gemm_touch":
-            eng.set_option("bf16_gemm_regstage", "0")
         assert eng.backward(b, 1) == loss1
         gt_ = eng.get_flat_grads().astype(np.float64)
         eng.set_option(key, back)
-        eng.set_option("bf16_gemm_regstage", "1")
         for nm, (off, shp) in lay.items():
             n = int(np.prod(shp))
             a, r = g1[off:off + n], gt_[off:off + n]
