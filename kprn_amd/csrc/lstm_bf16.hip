@@ -358,7 +358,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // DBG (measurement build only, KPRN_GEMM16_DBG): 1 no MFMAs, 2 no fragment reads either, 4 no DMA (the stages hold whatever they hold), 8 no epilogue,
 // 16 the DMA pieces come from where a K-blocked layout [K / 64][rows][64] would hold them (tile rows 128 bytes apart instead of a row pitch apart; the same bytes,
-// instructions and reuse between tiles: what the row-major layout costs in address translation / DRAM page locality)
+// instructions and reuse between tiles: what the row-major layout costs in address translation / DRAM page locality), 32 every chunk re-reads the first 1 KB of
+// its rows (everything an L2 hit: the delivery rate L2 -> LDS of this access shape, no HBM latency in it)
 template <bool ACCUM, int DBG = 0>
 __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -408,6 +409,9 @@ __global__ __launch_bounds__(NTHR, 2) void k_gemm16x(XArgs a) {
     for (int i = 0; i < 6; ++i) {
       const int64_t k = k0 + 8 * piece[i];
       const bf16* src = (rowp[i] && k < k_end) ? rowp[i] + k : a.zero;
+      if constexpr ((DBG & 32) != 0) {   // every chunk from the first 1 KB of its row: 2 176 rows x 1 KB stay in every L2 -- the L2-hit delivery rate of this access shape
+        if (rowp[i] && k < k_end) src = rowp[i] + (k & 511);
+      }
       if constexpr ((DBG & 16) != 0) {   // the K-blocked layout [K / 64][rows][64], emulated inside the same allocations: the same reuse between tiles, rows 128 bytes apart
         if (rowp[i] && k < k_end) {
           const bool isA = (wave + 8 * i) < BM / 8;
@@ -1099,7 +1103,7 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
       bool found = true;
 #define KV(D) case D: HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
                       hipLaunchKernelGGL((gx::k_gemm16x<true, D>), grid, dim3(gx::NTHR), lds_bytes, s, a); break;
-      switch (dbg) { KV(0) KV(1) KV(3) KV(4) KV(5) KV(7) KV(8) KV(9) KV(12) KV(16) KV(19) KV(27) default: found = false; }
+      switch (dbg) { KV(0) KV(1) KV(3) KV(4) KV(5) KV(7) KV(8) KV(9) KV(12) KV(16) KV(19) KV(32) KV(35) default: found = false; }
 #undef KV
       KPRN_REQUIRE(found, KPRN_E_ARG, "this knock-out of k_gemm16x is not compiled in");
       HIP_TRY(hipGetLastError());

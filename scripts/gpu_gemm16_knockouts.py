@@ -21,7 +21,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 MASKS = [(0, "full"), (1, "no MFMAs"), (3, "no MFMAs, no fragment reads (DMA + waits + barriers + epilogue)"), (4, "no DMA"), (5, "no DMA, no MFMAs (fragment reads only)"),
          (7, "skeleton: barriers + epilogue"), (8, "no epilogue"), (9, "no MFMAs, no epilogue"), (12, "no DMA, no epilogue (MFMAs + fragment reads)"),
          (16, "full, sources as a K-blocked layout [K/64][rows][64] would have them"), (19, "DMA + waits + barriers + epilogue, K-blocked sources"),
-         (27, "DMA + waits + barriers, no epilogue, K-blocked sources")]
+         (32, "full, every chunk from the first 1 KB of its rows (all L2 hits)"), (35, "DMA + waits + barriers + epilogue, all L2 hits")]
 ONLY = [int(x) for x in os.environ.get("KPRN_KNOCKOUT_MASKS", "").split(",") if x]
 for rep in range(2):
     for m, what in MASKS:
