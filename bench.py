@@ -1099,6 +1099,10 @@ def main():
             "other_configs": other,
             "value_no_prefix_plan": (extras.get("no_prefix_plan") or {}).get("value"), "no_prefix_plan": extras.get("no_prefix_plan"),
             "dp": dp_info, "alt_f32x6": alt, "kernels": kernels,
+            "kernels_note": ("ms = HIP events around the family's launches, summed over `launches`; 'timed' = inside the timed region, 'warmup' = in the warm-up steps "
+                             "(first steps of the process: lower clocks).  A family queued on a side stream beside a persistent launch that owns every CU "
+                             "(loss_stage / head_bwd / bf16_transposes / entity_grad) reports ELAPSED time including its wait for CUs, not its own run time: "
+                             "the families do not add up to ms_per_step"),
         }
     # a data-parallel run whose replicas diverged is not a measurement: the line is still printed (it says which rank differs), the exit code is 3
     diverged = bool(dp_info is not None and not dp_info.get("replicas_bit_identical", True))
