@@ -307,6 +307,10 @@ int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t*
  *   "persist_layers"  "1" (default): a recurrent layer of the generic fp32 pipeline (FastLSTM / rnn, Din % 4 == 0, Din, H <= 256) runs as ONE
  *                     persistent launch, forward and BPTT, once the batch gives every CU a 64-path tile; "2": at any batch size; "0": one launch
  *                     per step
+ *   "bf16_gemm_pingpong" "0" (default) | "1", "bf16_gemm_regstage" "0" | "1", "bf16_gemm_touch" "0" | chunks ahead, "bf16_t_pad" "64" | 0..512
+ *                     (elements, a multiple of 8): measured alternatives of the bf16 split-K dW product (two wave groups one barrier apart; operands
+ *                     staged through registers; L2 prefetch by touch; row pitch of its transposed operands) -- none faster than the default,
+ *                     kept as the record of DESIGN.md section 7-3 and run against the default by tests/test_gpu_persist.py
  *   (also: "small_tiles", "score_split", "loss_accumulate", "feed_build" / "feed_threads" / "feed_workers", "dp_comm_stream",
  *    "dp_fused_update", "dp_dense_in_pack" -- described at the calls they modify)                                                 */
 int kprn_set_option(kprn_handle* h, const char* key, const char* value);
