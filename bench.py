@@ -433,7 +433,8 @@ def dropin_minibatch(eng, opt, T, F, Vt, Ve, Vr, nT, seconds=0.4):
     reference's own sizes: kprn_train_step from HOST buffers with 128 pairs (run_scripts/config.sh:38), the loss returned to the host every
     step; then kprn_forward from host buffers with 512 pairs (test_from_checkpoint.lua:49), the probabilities returned.  A minibatch comes from
     one bucket file (constant P: movie_data_format.py:311-314); P is drawn per minibatch from the fixture's distribution (SURVEY 8d:
-    min(Geom(0.57), 28), mean 1.75).  Synchronous by construction -- every call ends with a device-to-host copy the caller waits for."""
+    min(Geom(0.57), 28), mean 1.75).  Every call returns its result to the host: kprn_forward after the pass, kprn_train_step as soon as the loss stage
+    has run (the backward and the update follow in stream order while the caller prepares its next minibatch; the region ends with a drain)."""
     from kprn_amd import synth
     rng = np.random.default_rng(99)
     def pool(pairs, n, seed0):
@@ -445,7 +446,10 @@ def dropin_minibatch(eng, opt, T, F, Vt, Ve, Vr, nT, seconds=0.4):
         return out
     train, score = pool(128, 32, 9100), pool(512, 16, 9300)
     def run(fn, items, seconds):
-        for it in items[:6]:
+        # warm-up: every minibatch once through each of the two alternating engine-owned slots, so that both have grown to the largest P before the clock starts
+        # (BatcherFileList.lua:53-60 preallocates its GPU tensors for the largest file the same way; rounds 3-4 warmed six minibatches only and timed the slots'
+        #  re-allocations -- page-locked staging included -- with the steps)
+        for it in items + items[:1] + items:
             fn(it)
         eng.sync()
         k, n, t0 = 0, 0, time.perf_counter()
@@ -456,12 +460,13 @@ def dropin_minibatch(eng, opt, T, F, Vt, Ve, Vr, nT, seconds=0.4):
             k += 1
             if k % 8 == 0 and time.perf_counter() - t0 >= seconds:
                 break
+        eng.sync()   # (kprn_train_step returns with the loss; the last step's backward and update are still part of the region)
         el = time.perf_counter() - t0
         return {"steps": k, "steps_per_s": round(k / el, 1), "paths_per_s": round(n / el, 1), "ms_per_step": round(1e3 * el / k, 4),
                 "mean_paths_per_step": round(n / k, 1)}
     losses = []
     tr = run(lambda it: losses.append(eng.train_step_host(it[0], it[1], opt)), train, seconds)
-    sc = run(lambda it: eng.forward_host(it[0]), score, seconds)
+    sc = run(lambda it: eng.forward_host(it[0], 1, want_all=False), score, seconds)   # (the scorer reads preds[i] only: test_from_checkpoint.lua:82,109)
     assert np.all(np.isfinite(losses))
     return {"train_128_pairs": tr, "score_512_pairs": sc,
             "what": "kprn_train_step / kprn_forward from host buffers at the reference's minibatch sizes (config.sh:38, test_from_checkpoint.lua:49), "

@@ -391,12 +391,13 @@ class Engine:
                                            _fp(bufs["pooled"]), _fp(bufs["path_scores"])))
         return {k: v for k, v in bufs.items() if v is not None}
 
-    def forward_host(self, idx, class_id=1):
-        """the host-pointer entry point kprn_forward (one H2D copy per call)."""
+    def forward_host(self, idx, class_id=1, want_all=True):
+        """the host-pointer entry point kprn_forward (one H2D copy per call).  want_all=False: only the selected class's probabilities come back --
+        what test_from_checkpoint.lua:82,109 reads (its model ends in nn.Select(2, 1)); returns (probs, None)."""
         idx = np.ascontiguousarray(idx, np.int32)
         B, P, T, F = idx.shape
         probs = np.empty(B, np.float32)
-        allp = np.empty((B, self.cfg.C), np.float32)
+        allp = np.empty((B, self.cfg.C), np.float32) if want_all else None
         self._ck(self.L.kprn_forward(self.h, _fp(idx), B, P, T, F, int(class_id), _fp(probs), _fp(allp)))
         return probs, allp
 

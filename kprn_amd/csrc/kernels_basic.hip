@@ -331,7 +331,7 @@ __device__ float reduce_col(const float* s, int P, int C, int reducer, int K) {
 
 // + nn.Select(2, classId) (MyOptimizer.lua:126 / test_from_checkpoint.lua:82): sel[b] = probs[b][cid]
 __global__ void k_pool(const float* __restrict__ S, int B, int P, int C, int reducer, int K, float* __restrict__ pooled, float* __restrict__ probs,
-                       int cid, float* __restrict__ sel) {
+                       int cid, float* __restrict__ sel, float* __restrict__ sel_host) {
   int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (int64_t)B * C) return;
   int c = (int)(gid % C);
@@ -341,13 +341,16 @@ __global__ void k_pool(const float* __restrict__ S, int B, int P, int C, int red
   pooled[gid] = y;
   probs[gid] = pr;
   if (sel && c == cid) sel[b] = pr;
+  if (sel_host && c == cid) sel_host[b] = pr;   // page-locked mirror (kprn_forward_batch hands the probabilities out without a copy operation)
 }
 
 // nn.Select(2, classId) first: only the selected class is reduced (what model:forward hands the caller, test_from_checkpoint.lua:82)
-__global__ void k_pool_sel(const float* __restrict__ S, int B, int P, int C, int reducer, int K, int cid, float* __restrict__ sel) {
+__global__ void k_pool_sel(const float* __restrict__ S, int B, int P, int C, int reducer, int K, int cid, float* __restrict__ sel, float* __restrict__ sel_host) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  sel[b] = sigmoidf_(reduce_col(S + (int64_t)b * P * C + cid, P, C, reducer, K));
+  const float pr = sigmoidf_(reduce_col(S + (int64_t)b * P * C + cid, P, C, reducer, K));
+  sel[b] = pr;
+  if (sel_host) sel_host[b] = pr;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256) void k_loss_stage(const float* __restrict__ S,
                                                     int B, int P, int C, int H, int cid, int reducer, int K, int literal, float invB,
                                                     float* __restrict__ pooled, float* __restrict__ probs, float* __restrict__ sel,
                                                     float* __restrict__ dS, const int32_t* __restrict__ slot_of, float* __restrict__ gW_row,
-                                                    float* __restrict__ gb_c, float* __restrict__ partial, int n_loss_blocks, kk::TransposeJob tj) {
+                                                    float* __restrict__ gb_c, float* __restrict__ partial, int n_loss_blocks, kk::TransposeJob tj, float* __restrict__ partial_host) {
   if ((int)blockIdx.x >= n_loss_blocks) {  // (workgroup-uniform) the passenger job: 256x64 weight transposes
     const int rb = blockIdx.x - n_loss_blocks;
     const int m = rb >> 6, i = (rb & 63) * 256 + threadIdx.x;  // over the 64*256 outputs of matrix m
@@ -465,6 +468,7 @@ __global__ __launch_bounds__(256) void k_loss_stage(const float* __restrict__ S,
     float s = 0.f;
     for (int i = 0; i < LOSS_PPW; ++i) s += lossw[i];
     partial[blockIdx.x] = s;
+    if (partial_host) partial_host[blockIdx.x] = s;   // page-locked mirror: the host adds the partials itself (kprn_train_step's early loss)
   }
 }
 
@@ -997,23 +1001,23 @@ void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* o
   CHECK_LAUNCH();
 }
 
-void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel) {
+void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel, float* sel_host) {
   if (B <= 0) return;
-  if (!pooled) hipLaunchKernelGGL(k_pool_sel, dim3(nblocks((int64_t)B)), dim3(TPB), 0, s, S, B, P, C, reducer, K, cid, sel);
-  else hipLaunchKernelGGL(k_pool, dim3(nblocks((int64_t)B * C)), dim3(TPB), 0, s, S, B, P, C, reducer, K, pooled, probs, cid, sel);
+  if (!pooled) hipLaunchKernelGGL(k_pool_sel, dim3(nblocks((int64_t)B)), dim3(TPB), 0, s, S, B, P, C, reducer, K, cid, sel, sel_host);
+  else hipLaunchKernelGGL(k_pool, dim3(nblocks((int64_t)B * C)), dim3(TPB), 0, s, S, B, P, C, reducer, K, pooled, probs, cid, sel, sel_host);
   CHECK_LAUNCH();
 }
 
 void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
                 int literal, float invB, float* pooled, float* probs, float* sel, float* dS, const int32_t* slot_of, float* gW_row, float* gb_c,
-                float* partial, const TransposeJob* tj) {
+                float* partial, const TransposeJob* tj, float* partial_host) {
   if (B <= 0) return;
   TransposeJob t;
   memset(&t, 0, sizeof(t));
   if (tj) t = *tj;
   const int nlb = (B + LOSS_PPW - 1) / LOSS_PPW;
   hipLaunchKernelGGL(k_loss_stage, dim3((unsigned)(nlb + 64 * t.n)), dim3(256), 0, s, S, labels, hT, B, P, C, H, cid, reducer, K, literal, invB,
-                     pooled, probs, sel, dS, slot_of, gW_row, gb_c, partial, nlb, t);
+                     pooled, probs, sel, dS, slot_of, gW_row, gb_c, partial, nlb, t, partial_host);
   CHECK_LAUNCH();
 }
 

@@ -421,7 +421,7 @@ static void pool_stage(kprn_handle* h, const kprn_batch* b, int cid, bool every_
   const kprn_config& c = h->cfg;
   Workspace& w = h->ws;
   ProfScope ps(h, "pool_sigmoid");
-  kk::pool_sigmoid(h->stream, w.S, b->B, b->P, c.C, c.reducer, c.K, every_class ? w.pooled : nullptr, every_class ? w.probs : nullptr, cid, w.sel);
+  kk::pool_sigmoid(h->stream, w.S, b->B, b->P, c.C, c.reducer, c.K, every_class ? w.pooled : nullptr, every_class ? w.probs : nullptr, cid, w.sel, h->sel_host_armed);
 }
 
 static void batch_ready(kprn_handle* h, const kprn_batch* cb);
@@ -775,8 +775,12 @@ static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int
     const bool have_tj = fusedp && fused::transpose_job(h, &tj);
     kk::loss_stage(h->stream, h->score_buf, b->labels, /*hT=*/nullptr, b->B, b->P, c.C, c.H, cid, c.reducer, c.K, literal,
                    invB, /*pooled=*/nullptr, /*probs=*/nullptr, w.sel, w.dS, fusedp ? b->slot_of : nullptr, gd + h->off_outW + (int64_t)cid * c.H, gd + h->off_outb + cid, h->loss_partial,
-                   have_tj ? &tj : nullptr);
+                   have_tj ? &tj : nullptr, h->loss_early_armed ? h->loss_mirror : nullptr);
     h->loss_pending = kk::loss_partials(b->B);
+    if (h->loss_early_armed) {   // what kprn_train_step_batch waits for instead of the end of the step
+      h->loss_early_n = h->loss_pending;
+      HIP_TRY(hipEventRecord(h->ev_loss, h->stream));
+    }
     if (h->loss_accumulate) form_loss(h);   // (one single-workgroup launch; otherwise the sum is formed when somebody asks)
   }
   view_step_rows(h, b);
@@ -1009,6 +1013,9 @@ void kprn_destroy(kprn_handle* h) {
   bf16p::release(h);
   if (h->bidx_scratch) { hipFree(h->bidx_scratch); h->bidx_scratch = nullptr; }
   dfree(h->loss_partial);
+  if (h->loss_mirror) { hipHostFree(h->loss_mirror); h->loss_mirror = nullptr; }
+  if (h->probs_mirror) { hipHostFree(h->probs_mirror); h->probs_mirror = nullptr; }
+  if (h->ev_loss) { hipEventDestroy(h->ev_loss); h->ev_loss = nullptr; }
   for (auto e : h->event_pool) hipEventDestroy(e);
   Workspace& w = h->ws;
   for (float** p : {&w.X, &w.Hs, &w.Cs, &w.ACT, &w.dA, &w.dIn, &w.dH, &w.dC, &w.S, &w.dS, &w.pooled, &w.probs, &w.sel, &w.dy, &w.mask}) dfree(*p);
@@ -1795,15 +1802,29 @@ int kprn_read_probs(kprn_handle* h, float* probs, int32_t B) {
 
 int kprn_forward_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, float* probs, float* all_probs, float* pooled, float* path_scores) {
   API_BEGIN(h)
-  forward_impl(h, b, class_id, false);
+  KPRN_REQUIRE(b != nullptr, KPRN_E_ARG, "batch is NULL");
+  // the selected class's probabilities (what model:forward hands test_from_checkpoint.lua:109) come back through a page-locked mirror the pool kernel
+  // writes: no copy operation between the pass and the caller; the other outputs are copied as before and cost the all-class reduction only when asked for
+  struct Disarm { kprn_handle* h; ~Disarm() { h->sel_host_armed = nullptr; } } disarm{h};
+  const bool mirror = probs != nullptr && !h->prof_on;
+  if (mirror) {
+    if ((int64_t)b->B > h->probs_mirror_cap) {
+      if (h->probs_mirror) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipHostFree(h->probs_mirror)); h->probs_mirror = nullptr; h->probs_mirror_cap = 0; }
+      HIP_TRY(hipHostMalloc((void**)&h->probs_mirror, (size_t)(2 * (int64_t)b->B + 64) * sizeof(float)));
+      h->probs_mirror_cap = 2 * (int64_t)b->B + 64;
+    }
+    h->sel_host_armed = h->probs_mirror;
+  }
+  forward_impl(h, b, class_id, false, /*do_pool=*/true, /*every_class=*/all_probs != nullptr || pooled != nullptr);
   const int C = h->cfg.C;
   hipStream_t s = h->stream;
-  if (probs) HIP_TRY(hipMemcpyAsync(probs, h->ws.sel, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (probs && !mirror) HIP_TRY(hipMemcpyAsync(probs, h->ws.sel, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost, s));
   if (all_probs) HIP_TRY(hipMemcpyAsync(all_probs, h->ws.probs, (size_t)b->B * C * sizeof(float), hipMemcpyDeviceToHost, s));
   if (pooled) HIP_TRY(hipMemcpyAsync(pooled, h->ws.pooled, (size_t)b->B * C * sizeof(float), hipMemcpyDeviceToHost, s));
   if (path_scores)
     HIP_TRY(hipMemcpyAsync(path_scores, h->score_buf, (size_t)b->B * b->P * C * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (mirror) memcpy(probs, h->probs_mirror, (size_t)b->B * sizeof(float));
   prof_drain(h);
   API_END(h)
 }
@@ -1881,9 +1902,26 @@ int kprn_train_step_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id,
   check_batch(h, b, class_id);
   catch_up(h, b);
   if (!h->pad_clean) { zero_pad_tokens(h); fused::params_changed(h); bf16p::params_changed(h, false); }  // MyOptimizer.lua:181 (a no-op when the last step left them zero)
+  // the loss goes back as soon as the loss stage has run (option "train_step_return" = "loss"); profiling and "drain" wait for the whole step as before
+  struct Disarm { kprn_handle* h; ~Disarm() { h->loss_early_armed = false; } } disarm{h};
+  if (loss && !h->train_step_drain && !h->prof_on) {
+    const int64_t np = kk::loss_partials(b->B);
+    if (np > h->loss_mirror_cap) {
+      if (h->loss_mirror) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipHostFree(h->loss_mirror)); h->loss_mirror = nullptr; h->loss_mirror_cap = 0; }
+      HIP_TRY(hipHostMalloc((void**)&h->loss_mirror, (size_t)(2 * np + 64) * sizeof(float)));
+      h->loss_mirror_cap = 2 * np + 64;
+    }
+    if (!h->ev_loss) HIP_TRY(hipEventCreateWithFlags(&h->ev_loss, hipEventDisableTiming));
+    h->loss_early_armed = true;
+  }
   backward_impl(h, b, class_id, opt->bce_literal, 0.f);
   apply_update_impl(h, opt);
-  if (loss) {
+  if (loss && h->loss_early_armed) {
+    HIP_TRY(hipEventSynchronize(h->ev_loss));
+    float s = 0.f;   // k_sum_partials' order: one running fp32 sum over the partials in index order
+    for (int i = 0; i < h->loss_early_n; ++i) s += h->loss_mirror[i];
+    *loss = s;
+  } else if (loss) {
     form_loss(h);
     HIP_TRY(hipMemcpyAsync(loss, h->d_loss, sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -2388,6 +2426,10 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     h->score_overlap = atoi(value) ? 1 : 0;
   } else if (strcmp(key, "loss_accumulate") == 0) {
     h->loss_accumulate = atoi(value) ? 1 : 0;
+  } else if (strcmp(key, "train_step_return") == 0) {
+    if (strcmp(value, "loss") == 0) h->train_step_drain = 0;
+    else if (strcmp(value, "drain") == 0) h->train_step_drain = 1;
+    else throw KprnError{KPRN_E_ARG, "train_step_return must be loss or drain"};
   } else if (strcmp(key, "feed_build") == 0) {
     if (strcmp(value, "host") == 0) h->feed_build_host = 1;
     else if (strcmp(value, "device") == 0) h->feed_build_host = 0;

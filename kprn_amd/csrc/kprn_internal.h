@@ -156,6 +156,13 @@ struct kprn_handle {
   int64_t next_serial = 1;
   int loss_accumulate = 0;   // option: every backward adds its loss to d_loss[1] (count in d_loss[2]) -- an epoch's error without a host sync per step
   float* loss_partial = nullptr; int64_t loss_partial_cap = 0; int loss_pending = 0;  // >0: d_loss = sum of that many partials, not formed yet
+  // kprn_train_step / kprn_train_step_batch hand the loss back as soon as the loss stage has run (option "train_step_return": "loss", default) instead of after the
+  // whole step ("drain"): the loss stage mirrors its per-workgroup partials into page-locked host memory, an event behind it is what the call waits for, the host adds
+  // the partials in k_sum_partials' order.  The backward and the update run on while the caller prepares its next minibatch (MyOptimizer.lua:184-221 returns the loss of
+  // a step whose update has happened; here it is ordered on the engine's stream before anything a later call can observe).
+  float* loss_mirror = nullptr; int64_t loss_mirror_cap = 0; hipEvent_t ev_loss = nullptr;
+  bool loss_early_armed = false; int loss_early_n = 0; int train_step_drain = 0;
+  float* probs_mirror = nullptr; int64_t probs_mirror_cap = 0; float* sel_host_armed = nullptr;   // kprn_forward_batch: the selected class's probabilities, mirrored by the pool kernel
   // packing buffers for the data-parallel exchange
   int32_t* dp_mark = nullptr;   // [Ve] flags of the exchange's union (all zero between steps)
   // union + update fused (option "dp_fused_update"): kprn_sparse_grad_merge only records the gathered buffer; the update walks it directly
@@ -258,13 +265,14 @@ void gru_gates_fwd(hipStream_t s, float* a, const float* hp, int64_t N, int H);
 void gru_out_fwd(hipStream_t s, float* a, const float* hp, float* h, int64_t N, int H);
 void gru_bwd1(hipStream_t s, const float* a, const float* hp, const float* dH, const float* dH_up, float* dA, float* dHdir, int64_t N, int H);
 void gru_bwd2(hipStream_t s, const float* a, const float* hp, float* dA, const float* dHdir, float* dH, int64_t N, int H);
-void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel);
+void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reducer, int K, float* pooled, float* probs, int cid, float* sel, float* sel_host = nullptr);
 // A second, independent job the loss-stage launch can carry in extra workgroups: WT[m] = W[m]^T for up to four [256][64]
 // matrices (the fused backward's transposed LSTM weights, stale after every update).
 struct TransposeJob { const float* W[4]; float* WT[4]; int n; };
+// (partial_host: optional page-locked mirror of the per-workgroup loss partials)
 void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
                 int literal, float invB, float* pooled, float* probs, float* sel, float* dS, const int32_t* slot_of /*nullable: dS[slot_of[n]]*/,
-                float* gW_row, float* gb_c, float* partial, const TransposeJob* tj = nullptr);
+                float* gW_row, float* gb_c, float* partial, const TransposeJob* tj = nullptr, float* partial_host = nullptr);
 void sum_partials(hipStream_t s, const float* partial, int n, float* out, int accumulate);
 int loss_partials(int B);  // number of per-workgroup loss partials the loss stage writes for B pairs
 void zero_pad3(hipStream_t s, float* a, int na, float* b, int nb, float* c, int nc);

@@ -24,8 +24,8 @@ for i in range(32):
 res = {}
 
 
-def timed(name, fn, k=400):
-    for i in range(16):
+def timed(name, fn, k=640):
+    for i in range(64):   # (two passes over the 32 minibatches: every slot has seen its largest P)
         fn(i)
     eng.sync()
     t0 = time.perf_counter()
@@ -44,6 +44,19 @@ def fed(i):
     eng.train_step(slots[i & 1], opt, 1, want_loss=True)
 timed("feed_async_then_step_ms", fed)
 timed("host_buffer_entry_ms", lambda i: eng.train_step_host(*mb[i % 32], opt))
+for rep in ("", "_again"):
+    eng.set_option("train_step_return", "drain")   # rounds 1-4: the call returns after the whole step
+    timed("host_buffer_entry_drain_ms" + rep, lambda i: eng.train_step_host(*mb[i % 32], opt))
+    timed("resident_loss_every_step_drain_ms" + rep, lambda i: eng.train_step(resident[i % 32], opt, 1, want_loss=True))
+    eng.set_option("train_step_return", "loss")
+    timed("host_buffer_entry_loss_ms" + rep, lambda i: eng.train_step_host(*mb[i % 32], opt))
+    timed("resident_loss_every_step_loss_ms" + rep, lambda i: eng.train_step(resident[i % 32], opt, 1, want_loss=True))
+sc = []
+for i in range(16):
+    P = int(min(rng.geometric(0.57), 28))
+    sc.append(np.ascontiguousarray(synth.make_paths(512, P, T, Ve=Ve, seed=9300 + i)[0], np.int32))
+timed("score_512_probs_only_ms", lambda i: eng.forward_host(sc[i % 16], 1, want_all=False))
+timed("score_512_probs_and_all_classes_ms", lambda i: eng.forward_host(sc[i % 16], 1, want_all=True))
 t0 = time.perf_counter()
 for i in range(2000):
     eng.sync()

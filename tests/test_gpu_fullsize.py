@@ -221,7 +221,47 @@ def test_reference_minibatch_regime_through_the_host_buffer_entry_points():
         probs, allp = eng.forward_host(idx, 1)
         _, _, want = o64.forward(th, idx)
         np.testing.assert_allclose(probs, want[:, 0], rtol=1e-5)
+        np.testing.assert_allclose(allp, want, rtol=1e-5)
+        only, none = eng.forward_host(idx, 1, want_all=False)   # the selected class alone (k_pool_sel + the page-locked mirror): the same bits
+        assert none is None and np.array_equal(only, probs)
     eng.close()
+
+
+def test_train_step_returns_the_loss_before_the_step_has_drained_with_identical_results():
+    """kprn_train_step / kprn_train_step_batch hand the loss back once the loss stage has run (option "train_step_return" = "loss", the default: the partials
+    mirrored into page-locked memory, summed by the host in k_sum_partials' order) while backward and update run on; "drain" waits for the whole step as
+    rounds 1-4 did.  Same minibatches through both: every loss must be the same BITS (the host adds the partials in the device kernel's order) and equal to
+    kprn_read_loss (the device-side sum); parameters and Adam moments agree to the last bits (two runs of the same steps differ in the order of the fp32
+    atomics that join a hub entity's segment sums: 1 ulp).  B = 300 pairs gives 19 partials, B = 7 one."""
+    Ve = 20000
+    engs = []
+    for mode in ("loss", "drain"):
+        e = _ffi.Engine(6, Ve, 9, 16, 32, 16, 64, 2, param_init=0.1, seed=5)
+        e.set_option("train_step_return", mode)
+        engs.append(e)
+    engs[1].set_flat_params(engs[0].get_flat_params())
+    opt = _ffi.make_opt(method=1, lr=1e-3)
+    rng = np.random.default_rng(4)
+    got = [[], []]
+    for k in range(14):
+        B = (128, 300, 7, 64)[k % 4]
+        Pk = int(min(rng.geometric(0.57), 28))
+        idx, labels = synth.make_paths(B, Pk, T, Ve=Ve, seed=700 + k)
+        for j, e in enumerate(engs):
+            if k % 3 == 2:   # the resident-batch entry point
+                b = e.batch(idx, labels)
+                got[j].append(e.train_step(b, opt, 1, want_loss=True))
+                assert e.read_loss() == got[j][-1]
+                b.free()   # (kprn_batch_destroy waits for the step that still reads the batch)
+            else:
+                got[j].append(e.train_step_host(idx, labels, opt))
+    assert got[0] == got[1], (got[0], got[1])
+    assert np.all(np.isfinite(got[0]))
+    np.testing.assert_allclose(engs[0].get_flat_params(), engs[1].get_flat_params(), rtol=0, atol=2e-7)
+    for which in (0, 1):
+        np.testing.assert_allclose(engs[0].get_flat_opt_state(which), engs[1].get_flat_opt_state(which), rtol=1e-4, atol=1e-12)
+    for e in engs:
+        e.close()
 
 
 @pytest.mark.parametrize("plan", [True, False])
