@@ -212,7 +212,12 @@ int kprn_backward_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, i
 /* MyOptimizer.lua:196-219 on the gradients now in the handle: clip/L2 iff regularize==1,
  * optim step, zeroPadTokens.  Async.                                                     */
 int kprn_apply_update(kprn_handle* h, const kprn_opt* opt);
-/* MyOptimizer:trainBatch = zeroPadTokens + kprn_backward_batch + kprn_apply_update        */
+/* MyOptimizer:trainBatch = zeroPadTokens + kprn_backward_batch + kprn_apply_update.
+ * With loss != NULL the call returns as soon as the loss is on the host, i.e. after the forward and the loss stage of this step: the backward and
+ * the optimiser step are queued and complete in stream order BEFORE anything a later call on this handle can observe (parameters, gradients,
+ * scores, the next step) -- the caller's idx / labels have been consumed, and the caller prepares its next minibatch while the device finishes
+ * this one (MyOptimizer.lua:184-221 returns the same number; it just cannot overlap).  A device error raised by the rest of the step surfaces at
+ * the next call.  kprn_set_option(h, "train_step_return", "drain") restores the wait for the whole step; kprn_sync always waits for everything. */
 int kprn_train_step(kprn_handle* h, const int32_t* idx, int32_t B, int32_t P, int32_t T, int32_t F,
                     const float* labels, int32_t class_id, const kprn_opt* opt, float* loss);
 int kprn_train_step_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, const kprn_opt* opt,
@@ -311,6 +316,7 @@ int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t*
  *                     (elements, a multiple of 8): measured alternatives of the bf16 split-K dW product (two wave groups one barrier apart; operands
  *                     staged through registers; L2 prefetch by touch; row pitch of its transposed operands) -- none faster than the default,
  *                     kept as the record of DESIGN.md section 7-3 and run against the default by tests/test_gpu_persist.py
+ *   "train_step_return" "loss" (default) | "drain": see kprn_train_step
  *   (also: "small_tiles", "score_split", "loss_accumulate", "feed_build" / "feed_threads" / "feed_workers", "dp_comm_stream",
  *    "dp_fused_update", "dp_dense_in_pack" -- described at the calls they modify)                                                 */
 int kprn_set_option(kprn_handle* h, const char* key, const char* value);
