@@ -317,6 +317,8 @@ int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t*
  *                     staged through registers; L2 prefetch by touch; row pitch of its transposed operands) -- none faster than the default,
  *                     kept as the record of DESIGN.md section 7-3 and run against the default by tests/test_gpu_persist.py
  *   "train_step_return" "loss" (default) | "drain": see kprn_train_step
+ *   "inline_upload"   "side" (default): kprn_train_step uploads its minibatch on the upload stream, beside the previous step's backward, whenever the previous
+ *                     call waited for its loss (every reader of the slot being refilled is then known to be done); "main": on the engine's stream
  *   (also: "small_tiles", "score_split", "loss_accumulate", "feed_build" / "feed_threads" / "feed_workers", "dp_comm_stream",
  *    "dp_fused_update", "dp_dense_in_pack" -- described at the calls they modify)                                                 */
 int kprn_set_option(kprn_handle* h, const char* key, const char* value);

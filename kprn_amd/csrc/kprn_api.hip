@@ -1408,6 +1408,9 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
   b->job = done->get_future();
   if (inline_now) {
     try {
+      // where the upload runs: beside the step in flight when nothing can still read this slot (kprn_internal.h: dropin_prev_waited), else in stream order
+      const bool side_copy = h->inline_upload_side && labels != nullptr && h->dropin_prev_waited && h->inline_side_ok;
+      hipStream_t cs = h->stream;
       kprn_batch::HostResult* r = &b->hres;
       const int32_t* src = idx;
       const int nth1 = nsteps < 65536 ? 1 : std::max(1, h->feed_threads > 0 ? h->feed_threads : 4);
@@ -1417,11 +1420,17 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
       if (!r->bad) {
         if (want_idx && !rows) memcpy(hs + l.idx, idx, (size_t)(nsteps * F) * sizeof(int32_t));
         hs[l.cnt] = r->n_uniq;
-        if (h->score_pending && h->score_stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_score_done, 0));   // (a pass on the side stream may still read the slot)
+        if (side_copy && !h->upload_stream) {   // (its own hardware queue class: see the worker path above)
+          int lo = 0, hi = 0;
+          HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+          HIP_TRY(hipStreamCreateWithPriority(&h->upload_stream, hipStreamNonBlocking, hi));
+        }
+        cs = side_copy ? h->upload_stream : h->stream;
+        if (h->score_pending && h->score_stream) HIP_TRY(hipStreamWaitEvent(cs, h->ev_score_done, 0));   // (a pass on the side stream may still read the slot)
         const int64_t w0 = want_idx ? 0 : l.idx_s, w1 = want_index ? l.words : l.key;
-        HIP_TRY(hipMemcpyAsync(b->block + w0, hs + w0, (size_t)(w1 - w0) * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(b->block + w0, hs + w0, (size_t)(w1 - w0) * sizeof(int32_t), hipMemcpyHostToDevice, cs));
       }
-      HIP_TRY(hipEventRecord(b->ev_ready, h->stream));
+      HIP_TRY(hipEventRecord(b->ev_ready, cs));   // (batch_ready orders the engine's stream behind it)
       done->set_value();
     } catch (...) { done->set_exception(std::current_exception()); }
     return;
@@ -1483,6 +1492,7 @@ static void feed_impl(kprn_handle* h, kprn_batch** slot, const int32_t* idx, con
   kprn_batch* b = *slot;
   const bool fresh = (b == nullptr);
   if (fresh) b = new kprn_batch();
+  h->inline_side_ok = !fresh && h->score_rest_batch != b && h->view_batch != b;   // (a fresh slot allocates: in stream order)
   try {
     if (!fresh) {
       if (h->score_rest_batch == b) launch_score_rest(h);   // (the deferred part of a split scoring pass still reads the slot's old contents)
@@ -1940,8 +1950,10 @@ int kprn_train_step(kprn_handle* h, const int32_t* idx, int32_t B, int32_t P, in
   // 1.06 ms per 128-pair step against 0.38 ms for the step itself).
   int rc = dropin_feed(h, /*score=*/false, idx, labels, B, P, T, F);
   if (rc != KPRN_OK) return rc;
+  // (the loss is always fetched: waiting for it is what lets the NEXT call's upload run beside this step's backward)
   float l = 0.f;
   rc = kprn_train_step_batch(h, h->dropin_slot[h->dropin_last], class_id, opt, &l);
+  h->dropin_prev_waited = (rc == KPRN_OK);
   if (loss) *loss = l;
   return rc;
 }
@@ -2426,6 +2438,10 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     h->score_overlap = atoi(value) ? 1 : 0;
   } else if (strcmp(key, "loss_accumulate") == 0) {
     h->loss_accumulate = atoi(value) ? 1 : 0;
+  } else if (strcmp(key, "inline_upload") == 0) {
+    if (strcmp(value, "side") == 0) h->inline_upload_side = 1;
+    else if (strcmp(value, "main") == 0) h->inline_upload_side = 0;
+    else throw KprnError{KPRN_E_ARG, "inline_upload must be side or main"};
   } else if (strcmp(key, "train_step_return") == 0) {
     if (strcmp(value, "loss") == 0) h->train_step_drain = 0;
     else if (strcmp(value, "drain") == 0) h->train_step_drain = 1;

@@ -211,6 +211,11 @@ struct kprn_handle {
   hipEvent_t ev_fork = nullptr, ev_score_done = nullptr;
   kprn_batch* dropin_slot[4] = {nullptr, nullptr, nullptr, nullptr};   // feed slots of the host-buffer entry points (kprn_train_step: 0 / 1, kprn_forward: 2 / 3)
   int dropin_next_train = 0, dropin_next_score = 0, dropin_last = 0;
+  // The inline feed of kprn_train_step uploads on the upload stream (beside the previous step's backward) when every reader of the slot it refills is known to be
+  // done: the slot was last read two calls ago, and the previous call WAITED for its own step's loss, i.e. for a kernel ordered behind that reader (option
+  // "inline_upload" = "side", default; "main": on the engine's stream as in round 4).  A previous call that returned without waiting (loss == NULL) clears the flag.
+  bool dropin_prev_waited = false; int inline_upload_side = 1;
+  bool inline_side_ok = true;   // (feed_impl: false when the handle still referred to the slot being refilled -- its rows are copied out in stream order first)
   bool score_pending = false;     // a pass is (possibly) still running on score_stream
   int bf16_bptt_dxe = 8;          // option "bf16_bptt_dxe": the persistent BPTT launch also forms dx for the entity slice (weight ring depth 8 | 16; 0: a separate product)
   int persist_layers = 1;     // option "persist_layers": generic fp32 LSTM / rnn layers as one persistent launch per layer where the shape allows (layer_f32_persist.hip)

@@ -51,6 +51,11 @@ for rep in ("", "_again"):
     eng.set_option("train_step_return", "loss")
     timed("host_buffer_entry_loss_ms" + rep, lambda i: eng.train_step_host(*mb[i % 32], opt))
     timed("resident_loss_every_step_loss_ms" + rep, lambda i: eng.train_step(resident[i % 32], opt, 1, want_loss=True))
+for rep in ("", "_again"):   # the inline feed's upload: on the upload stream beside the previous step's backward (default) or in stream order
+    eng.set_option("inline_upload", "main")
+    timed("host_buffer_entry_upload_in_stream_order_ms" + rep, lambda i: eng.train_step_host(*mb[i % 32], opt))
+    eng.set_option("inline_upload", "side")
+    timed("host_buffer_entry_upload_beside_ms" + rep, lambda i: eng.train_step_host(*mb[i % 32], opt))
 sc = []
 for i in range(16):
     P = int(min(rng.geometric(0.57), 28))

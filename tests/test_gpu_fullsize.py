@@ -239,6 +239,7 @@ def test_train_step_returns_the_loss_before_the_step_has_drained_with_identical_
     for mode in ("loss", "drain"):
         e = _ffi.Engine(6, Ve, 9, 16, 32, 16, 64, 2, param_init=0.1, seed=5)
         e.set_option("train_step_return", mode)
+        e.set_option("inline_upload", "side" if mode == "loss" else "main")   # (the round-4 call: drained, minibatch uploaded in stream order)
         engs.append(e)
     engs[1].set_flat_params(engs[0].get_flat_params())
     opt = _ffi.make_opt(method=1, lr=1e-3)
