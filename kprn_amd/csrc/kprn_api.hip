@@ -1789,6 +1789,10 @@ static void launch_score_rest(kprn_handle* h) {
   HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
 }
 
+static void score_rest_hook(kprn_handle* h) {
+  if (h->score_rest_in_backward && h->score_rest_batch) launch_score_rest(h);
+}
+
 int kprn_forward_batch_async_rest(kprn_handle* h) {
   API_BEGIN(h)
   launch_score_rest(h);
@@ -2426,6 +2430,10 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // bf16 pipeline, persistent BPTT: gradients of the type / relation tables (<= 128 rows together) and of their column blocks of W_i2g from one
     // extra column block of the merged dW product ("1", default) or from the full dx product + the table-gradient launch ("0": the A/B reference)
     h->bf16_small_tables = atoi(value) != 0;
+  } else if (strcmp(key, "score_rest_in_backward") == 0) {
+    join_score(h);
+    h->score_rest_in_backward = atoi(value) ? 1 : 0;
+    h->after_bptt_hook = h->score_rest_in_backward ? score_rest_hook : nullptr;
   } else if (strcmp(key, "score_split") == 0) {
     // kprn_forward_batch_async queues only the first (1 - f) of the batch's tiles; kprn_forward_batch_async_rest the others + the pooling
     join_score(h);

@@ -225,6 +225,10 @@ struct kprn_handle {
   bool bf16_small_tables = true;  // option "bf16_small_tables": configs[3] backward forms the type / relation gradients from G = dA^T [S_r | S_t] (lstm_bf16.hip)
   bool small_tiles_on = true;     // option "small_tiles": batches of <= 8 192 paths run on tiles of one 16-row m-tile (no identical-prefix plan)
   float score_split = 0.f;        // option: fraction of a scoring pass's tiles deferred to kprn_forward_batch_async_rest
+  // option "score_rest_in_backward": the deferred part of a split pass is placed by the fused backward itself, right behind its last BPTT launch -- it runs on the side
+  // stream beside the step's serial tail (prefix backward, gradient gather-reduce, slab reduce), whose latency-bound launches leave most CUs idle; the update joins it
+  int score_rest_in_backward = 0;
+  void (*after_bptt_hook)(kprn_handle*) = nullptr;   // (set by kprn_api.hip: lstm_fused_bwd.hip cannot see launch_score_rest)
   const kprn_batch* score_rest_batch = nullptr; int score_rest_cid = 1; int64_t score_rest_tile0 = 0;   // the deferred part of a split pass
   bool last_forward_side = false; // kprn_read_probs reads the side buffers
   float* S2 = nullptr; float* sel2 = nullptr; int64_t cap_N2 = 0, cap_B2 = 0;

@@ -667,6 +667,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       else if (top) launch_bwd<false, true>(h, a, grid);
       else launch_bwd<false, false>(h, a, grid);
       if (bottom || s->timing) bwd_scope.reset();
+      if (bottom && h->after_bptt_hook) h->after_bptt_hook(h);   // (a deferred part of the scoring pass: beside the tail below, kprn_internal.h score_rest_in_backward)
     }
     if (bottom) have_r1 = prefix_backward(h, b, n_tiles64);  // the skipped steps of every layer; leaves their dx sums in DX's virtual tile
     if (bottom) {

@@ -291,5 +291,10 @@ def test_split_scoring_pass_is_bit_identical(plan):
         eng.forward_async(b, 1)                      # ... or the optimiser step, which waits for the pass
         eng.train_step(b, _ffi.make_opt(method=1, lr=0.0), 1, want_loss=False)
         assert np.array_equal(eng.read_probs(b.B), ref), f
+        eng.set_option("score_rest_in_backward", "1")   # ... or the fused backward, right behind its last BPTT launch (beside the step's serial tail)
+        eng.forward_async(b, 1)
+        eng.train_step(b, _ffi.make_opt(method=1, lr=0.0), 1, want_loss=False)
+        assert np.array_equal(eng.read_probs(b.B), ref), f
+        eng.set_option("score_rest_in_backward", "0")
     eng.set_option("score_split", "0")
     eng.close()
