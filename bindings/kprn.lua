@@ -133,6 +133,8 @@ function Net:trainBatch(inputs, targets, classId, optConfig, optInfo)
   local td = targets:contiguous():data()
   for i = 0, B - 1 do lab[i] = td[i] end
   local loss = ffi.new('float[1]')
+  -- returns once the LOSS is on the host (the int32 copy of `inputs` and `lab` have been consumed by then); the backward and the optimiser step finish in
+  -- stream order while Lua fetches the next minibatch -- Net:sync() waits for everything, e.g. before os.clock() or torch.save
   check(self.h, C.kprn_train_step(self.h, to_int32(inputs), B, P, T, F, lab, classId or 1, opt, loss))
   return loss[0]
 end
@@ -198,6 +200,7 @@ function Net:trainBatchSlotDP(slot, classId, optConfig, optInfo, globalPairs, ca
 end
 
 function Net:zeroPadTokens() check(self.h, C.kprn_zero_pad_tokens(self.h)) end
+function Net:sync() check(self.h, C.kprn_sync(self.h)) end   -- everything queued on the engine has finished (timing, hand-over of the GPU)
 function Net:save(path) check(self.h, C.kprn_save(self.h, path)) end
 function Net:load(path) check(self.h, C.kprn_load(self.h, path)) end
 
