@@ -316,6 +316,8 @@ int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t*
  *                     (elements, a multiple of 8): measured alternatives of the bf16 split-K dW product (two wave groups one barrier apart; operands
  *                     staged through registers; L2 prefetch by touch; row pitch of its transposed operands) -- none faster than the default,
  *                     kept as the record of DESIGN.md section 7-3 and run against the default by tests/test_gpu_persist.py
+ *   "score_rest_before_bptt" "0" (default) | "1": with "score_split" f > 0, the deferred part is queued right behind the loss stage on a stream of the lowest
+ *                     priority: its single-tile workgroups take the CUs the first BPTT launch leaves idle in its tail
  *   "score_rest_in_backward" "0" (default) | "1": with "score_split" f > 0, the fused backward places the deferred part of the scoring pass itself, right behind its
  *                     last BPTT launch (beside the step's serial tail); measured slower than the whole pass first at world 1
  *   "train_step_return" "loss" (default) | "drain": see kprn_train_step

@@ -54,6 +54,7 @@ ProfScope::~ProfScope() {
 void prof_drain(kprn_handle* h) {
   if (h->prof_pending.empty()) return;
   if (h->score_stream) hipStreamSynchronize(h->score_stream);
+  if (h->rest_stream) hipStreamSynchronize(h->rest_stream);
   hipStreamSynchronize(h->stream);
   for (auto& p : h->prof_pending) {
     float ms = 0.f;
@@ -784,6 +785,7 @@ static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int
     if (h->loss_accumulate) form_loss(h);   // (one single-workgroup launch; otherwise the sum is formed when somebody asks)
   }
   view_step_rows(h, b);
+  if (fusedp && h->score_rest_before_bptt && h->score_rest_batch) launch_score_rest(h);   // (kprn_internal.h: into the first BPTT launch's idle tail)
   // (no join with a scoring pass on the side stream here: the backward writes nothing that pass reads -- gradients, dx, prefix sums --
   //  and making the main stream wait for the pass's last workgroups cost 3 % of the step; apply_update joins before it writes parameters)
   if (fusedp) fused::backward(h, b, cid);
@@ -998,6 +1000,7 @@ void kprn_destroy(kprn_handle* h) {
   if (!h) return;
   hipSetDevice(h->cfg.device_id);
   if (h->score_stream) hipStreamSynchronize(h->score_stream);
+  if (h->rest_stream) hipStreamSynchronize(h->rest_stream);
   if (h->stream) hipStreamSynchronize(h->stream);
   prof_drain(h);
   for (kprn_batch*& d : h->dropin_slot) if (d) { kprn_batch* old = d; d = nullptr; kprn_batch_destroy(h, old); }
@@ -1013,6 +1016,8 @@ void kprn_destroy(kprn_handle* h) {
   bf16p::release(h);
   if (h->bidx_scratch) { hipFree(h->bidx_scratch); h->bidx_scratch = nullptr; }
   dfree(h->loss_partial);
+  if (h->rest_stream) { hipStreamSynchronize(h->rest_stream); hipStreamDestroy(h->rest_stream); h->rest_stream = nullptr; }
+  if (h->ev_part1) { hipEventDestroy(h->ev_part1); h->ev_part1 = nullptr; }
   if (h->loss_mirror) { hipHostFree(h->loss_mirror); h->loss_mirror = nullptr; }
   if (h->probs_mirror) { hipHostFree(h->probs_mirror); h->probs_mirror = nullptr; }
   if (h->ev_loss) { hipEventDestroy(h->ev_loss); h->ev_loss = nullptr; }
@@ -1511,6 +1516,7 @@ static void feed_impl(kprn_handle* h, kprn_batch** slot, const int32_t* idx, con
     }
     auto quiesce = [&] {
       if (h->score_stream) HIP_TRY(hipStreamSynchronize(h->score_stream));
+      if (h->rest_stream) HIP_TRY(hipStreamSynchronize(h->rest_stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
       if (h->feed_stream) HIP_TRY(hipStreamSynchronize(h->feed_stream));
       if (h->upload_stream) HIP_TRY(hipStreamSynchronize(h->upload_stream));
@@ -1582,6 +1588,7 @@ int kprn_batch_slot_reserve(kprn_handle* h, kprn_batch** slot, int32_t max_pairs
     }
     auto quiesce = [&] {
       if (h->score_stream) HIP_TRY(hipStreamSynchronize(h->score_stream));
+      if (h->rest_stream) HIP_TRY(hipStreamSynchronize(h->rest_stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
       if (h->feed_stream) HIP_TRY(hipStreamSynchronize(h->feed_stream));
       if (h->upload_stream) HIP_TRY(hipStreamSynchronize(h->upload_stream));
@@ -1640,7 +1647,8 @@ void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
     if (h->upload_stream) hipStreamSynchronize(h->upload_stream);
     if (h->feed_stream) hipStreamSynchronize(h->feed_stream);
     if (h->score_rest_batch == b) { try { launch_score_rest(h); } catch (...) { h->score_rest_batch = nullptr; } }   // (the deferred part of a split pass reads the batch)
-    if (h->score_stream) hipStreamSynchronize(h->score_stream);  // a scoring pass on the second stream may still read the batch
+    if (h->score_stream) hipStreamSynchronize(h->score_stream);
+  if (h->rest_stream) hipStreamSynchronize(h->rest_stream);  // a scoring pass on the second stream may still read the batch
     hipStreamSynchronize(h->stream);
   }
   batch_release(b);
@@ -1729,6 +1737,7 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
     }
     if (N > h->cap_N2 || b->B > h->cap_B2) {
       HIP_TRY(hipStreamSynchronize(h->score_stream));
+      if (h->rest_stream) HIP_TRY(hipStreamSynchronize(h->rest_stream));
       dfree(h->S2); dfree(h->sel2);
       h->cap_N2 = std::max(N, h->cap_N2); h->cap_B2 = std::max<int64_t>(b->B, h->cap_B2);
       h->S2 = dalloc<float>(h->cap_N2 * h->cfg.C);
@@ -1752,8 +1761,13 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
       if (t_split == n_tiles) pool_stage(h, b, class_id - 1, false);
     } catch (...) { h->stream = main_stream; w.S = S0; w.sel = sel0; throw; }
     h->stream = main_stream; w.S = S0; w.sel = sel0;
-    if (t_split < n_tiles) { h->score_rest_batch = b; h->score_rest_cid = class_id; h->score_rest_tile0 = t_split; }
-    else HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
+    if (t_split < n_tiles) {
+      h->score_rest_batch = b; h->score_rest_cid = class_id; h->score_rest_tile0 = t_split;
+      if (h->score_rest_before_bptt) {   // (the rest runs on another stream: its pooling stage reads this part's scores)
+        if (!h->ev_part1) HIP_TRY(hipEventCreateWithFlags(&h->ev_part1, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(h->ev_part1, h->score_stream));
+      }
+    } else HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
     h->score_pending = true;
     h->last_forward_side = true;
     h->last_B = b->B;
@@ -1769,12 +1783,22 @@ static void launch_score_rest(kprn_handle* h) {
   const kprn_batch* b = h->score_rest_batch;
   h->score_rest_batch = nullptr;
   if (!b) return;
+  hipStream_t rs = h->score_stream;
+  if (h->score_rest_before_bptt && h->ev_part1) {
+    if (!h->rest_stream) {
+      int lo = 0, hi = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (lo = the numerically largest value = the LOWEST priority)
+      HIP_TRY(hipStreamCreateWithPriority(&h->rest_stream, hipStreamNonBlocking, lo));
+    }
+    rs = h->rest_stream;
+    HIP_TRY(hipStreamWaitEvent(rs, h->ev_part1, 0));
+  }
   HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
-  HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_fork, 0));
+  HIP_TRY(hipStreamWaitEvent(rs, h->ev_fork, 0));
   Workspace& w = h->ws;
   hipStream_t main_stream = h->stream;
   float* S0 = w.S; float* sel0 = w.sel;
-  h->stream = h->score_stream; w.S = h->S2; w.sel = h->sel2;
+  h->stream = rs; w.S = h->S2; w.sel = h->sel2;
   try {
     fused::forward(h, b, false, h->score_rest_tile0, -1);
     pool_stage(h, b, h->score_rest_cid - 1, false);
@@ -1782,11 +1806,11 @@ static void launch_score_rest(kprn_handle* h) {
     // the pass cannot finish: nobody may wait for it on a stale event, or hand out its half-filled S2 / sel2 as a finished pass
     h->stream = main_stream; w.S = S0; w.sel = sel0;
     h->score_pending = false; h->last_forward_side = false; h->last_B = 0;
-    (void)hipStreamSynchronize(h->score_stream);
+    (void)hipStreamSynchronize(rs);
     throw;
   }
   h->stream = main_stream; w.S = S0; w.sel = sel0;
-  HIP_TRY(hipEventRecord(h->ev_score_done, h->score_stream));
+  HIP_TRY(hipEventRecord(h->ev_score_done, rs));
 }
 
 static void score_rest_hook(kprn_handle* h) {
@@ -1804,6 +1828,7 @@ int kprn_read_probs(kprn_handle* h, float* probs, int32_t B) {
   KPRN_REQUIRE(probs && B > 0 && B <= h->last_B, KPRN_E_ARG, "bad probs buffer / B");
   if (h->last_forward_side) {
     if (h->score_rest_batch) launch_score_rest(h);
+    if (h->score_pending) HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_score_done, 0));   // (the second part of a split pass may have run on the rest stream)
     HIP_TRY(hipMemcpyAsync(probs, h->sel2, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->score_stream));
     HIP_TRY(hipStreamSynchronize(h->score_stream));
   } else {
@@ -1997,6 +2022,7 @@ int kprn_read_loss_sum(kprn_handle* h, float* sum, int32_t* steps, int32_t reset
 int kprn_sync(kprn_handle* h) {
   API_BEGIN(h)
   if (h->score_stream) HIP_TRY(hipStreamSynchronize(h->score_stream));
+      if (h->rest_stream) HIP_TRY(hipStreamSynchronize(h->rest_stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   prof_drain(h);
   API_END(h)
@@ -2430,6 +2456,9 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // bf16 pipeline, persistent BPTT: gradients of the type / relation tables (<= 128 rows together) and of their column blocks of W_i2g from one
     // extra column block of the merged dW product ("1", default) or from the full dx product + the table-gradient launch ("0": the A/B reference)
     h->bf16_small_tables = atoi(value) != 0;
+  } else if (strcmp(key, "score_rest_before_bptt") == 0) {
+    join_score(h);
+    h->score_rest_before_bptt = atoi(value) ? 1 : 0;
   } else if (strcmp(key, "score_rest_in_backward") == 0) {
     join_score(h);
     h->score_rest_in_backward = atoi(value) ? 1 : 0;

@@ -228,6 +228,11 @@ struct kprn_handle {
   // option "score_rest_in_backward": the deferred part of a split pass is placed by the fused backward itself, right behind its last BPTT launch -- it runs on the side
   // stream beside the step's serial tail (prefix backward, gradient gather-reduce, slab reduce), whose latency-bound launches leave most CUs idle; the update joins it
   int score_rest_in_backward = 0;
+  // option "score_rest_before_bptt": the deferred part goes out right behind the loss stage, BEFORE the BPTT launches, on a stream of the LOWEST priority: its
+  // single-tile workgroups only get the CUs the first BPTT launch leaves idle in its tail (235 of 256 workgroups draw 18 tile-steps, 21 draw 20: DESIGN.md 7-1) and
+  // finish inside the second launch's start-up skew -- a quarter of the scoring pass in time the step's schedule wastes anyway (the first part then ends 4 tile-steps earlier)
+  int score_rest_before_bptt = 0;
+  hipStream_t rest_stream = nullptr; hipEvent_t ev_part1 = nullptr;
   void (*after_bptt_hook)(kprn_handle*) = nullptr;   // (set by kprn_api.hip: lstm_fused_bwd.hip cannot see launch_score_rest)
   const kprn_batch* score_rest_batch = nullptr; int score_rest_cid = 1; int64_t score_rest_tile0 = 0;   // the deferred part of a split pass
   bool last_forward_side = false; // kprn_read_probs reads the side buffers

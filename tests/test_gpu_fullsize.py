@@ -296,5 +296,12 @@ def test_split_scoring_pass_is_bit_identical(plan):
         eng.train_step(b, _ffi.make_opt(method=1, lr=0.0), 1, want_loss=False)
         assert np.array_equal(eng.read_probs(b.B), ref), f
         eng.set_option("score_rest_in_backward", "0")
+        eng.set_option("score_rest_before_bptt", "1")   # ... or behind the loss stage on the lowest-priority stream (into the first BPTT launch's idle tail)
+        eng.forward_async(b, 1)
+        eng.train_step(b, _ffi.make_opt(method=1, lr=0.0), 1, want_loss=False)
+        assert np.array_equal(eng.read_probs(b.B), ref), f
+        eng.forward_async(b, 1)                          # (and a pass nobody trains on: read_probs places the rest)
+        assert np.array_equal(eng.read_probs(b.B), ref), f
+        eng.set_option("score_rest_before_bptt", "0")
     eng.set_option("score_split", "0")
     eng.close()
