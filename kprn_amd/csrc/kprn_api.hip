@@ -1828,7 +1828,8 @@ int kprn_read_probs(kprn_handle* h, float* probs, int32_t B) {
   KPRN_REQUIRE(probs && B > 0 && B <= h->last_B, KPRN_E_ARG, "bad probs buffer / B");
   if (h->last_forward_side) {
     if (h->score_rest_batch) launch_score_rest(h);
-    if (h->score_pending) HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_score_done, 0));   // (the second part of a split pass may have run on the rest stream)
+    // (the second part of a split pass may have run on the rest stream, and a join may already have cleared score_pending: the pass's event orders this copy)
+    if (h->ev_score_done) HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_score_done, 0));
     HIP_TRY(hipMemcpyAsync(probs, h->sel2, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->score_stream));
     HIP_TRY(hipStreamSynchronize(h->score_stream));
   } else {
