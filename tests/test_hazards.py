@@ -105,6 +105,40 @@ def test_persistent_bptt_kernel_keeps_its_state_in_registers():
         assert not [l for l in ins[mf[0]:mf[-1]] if l.startswith("scratch_")], sym   # whatever is spilled stays outside the step loop
 
 
+def test_wide_fp32_layer_kernels_keep_state_in_registers_and_their_weight_ring_counted():
+    """layer_f32_persist.hip (round 5): one persistent launch per wide fp32 recurrent layer.  The cell state / dh, dc accumulators live in registers (one wave per
+    SIMD, 512 entries) and the weights arrive through an LDS-DMA ring with COUNTED vmcnt waits.  Pinned here, per instantiation <CELL, NCH, flag>: nothing is spilled
+    (the H = 256 BPTT, NCH = 4, parks a few dozen registers: bounded), no scratch traffic between the MFMAs, the ring is still LDS-DMA, and most of its waits are
+    counted ones -- a build in which hipcc sinks the waits to vmcnt(0) (the first builds did) would pass every parity test and lose the overlap.
+    (These kernels leave early for workgroups without a tile, so their bodies end at .Lfunc_end, not at the first s_endpgm.)"""
+    text = chk.compile_isa(os.path.join(CSRC, "layer_f32_persist.hip"))
+    res = {k: v for k, v in chk.kernel_resources(text).items() if "lp32" in k and ("k_layer" in k or "k_bptt" in k)}
+    assert len(res) == 20, sorted(res)
+    seen = 0
+    for km in re.finditer(r"\n(_ZN4lp32\d+k_(layer|bptt)\w+):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", text, re.S):
+        name, kind = km.group(1), km.group(2)
+        nch4 = "ELi4EL" in name
+        v = res[name]
+        assert v["vgpr_count"] <= 512, (name, v)
+        if kind == "bptt" and nch4:
+            assert v["vgpr_spill_count"] <= 64, (name, v)     # 27 / 51
+        else:
+            assert v["vgpr_spill_count"] == 0, (name, v)
+        ins = [l.split(";")[0].strip() for l in km.group(3).split("\n")]
+        ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
+        mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
+        assert len(mf) >= 128, (name, len(mf))
+        inside = ins[mf[0]:mf[-1]]
+        scratch = [l for l in inside if l.startswith("scratch_")]
+        assert len(scratch) <= (16 if (kind == "bptt" and nch4) else 0), (name, len(scratch))
+        assert [l for l in inside if l.startswith("global_load_lds")], name       # the weight ring
+        waits = [l for l in inside if l.startswith("s_waitcnt") and "vmcnt" in l]
+        drained = [l for l in waits if "vmcnt(0)" in l]
+        assert waits and len(drained) <= (0.45 if kind == "layer" else 0.32) * len(waits), (name, len(drained), len(waits))
+        seen += 1
+    assert seen == 20
+
+
 def test_operand_loads_are_not_a_chain_of_round_trips():
     """The conditional-load rule: in the kernels it was found in, a load is no longer followed by its own vmcnt(0).
     (The last load of a batch always is: the bars are counts, not zero.)"""
