@@ -15,7 +15,7 @@ usage: scripts/check_mfma_hazards.py [file.hip ...]      (default: every fused k
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT = ["lstm_fused_fwd.hip", "lstm_fused_bwd.hip", "lstm_fused_fwd_mc.hip"]
+DEFAULT = ["lstm_fused_fwd.hip", "lstm_fused_bwd.hip", "lstm_fused_fwd_mc.hip", "layer_f32_persist.hip"]   # (the last one: pinned sched_barrier groups around builtin MFMAs)
 
 
 def regs(tok):
@@ -101,7 +101,7 @@ def check_text(text, fname):
     path = fname
     bad = 0
     total = 0
-    for km in re.finditer(r"\n(_Z\w+):[^\n]*\n(.*?)s_endpgm", text, re.S):
+    for km in re.finditer(r"\n(_Z\w+):[^\n]*\n(.*?)(?:\n\.Lfunc_end|s_endpgm(?![\s\S]*?\n\.Lfunc_end))", text, re.S):
         name, body = km.group(1), km.group(2)
         ins = []
         for l in body.split("\n"):
@@ -145,7 +145,7 @@ def check_results(text, fname):
     """(b): MFMA result -> non-MFMA reader closer than NEED issue cycles"""
     bad = 0
     checked = 0
-    for km in re.finditer(r"\n(_Z\w+):[^\n]*\n(.*?)s_endpgm", text, re.S):
+    for km in re.finditer(r"\n(_Z\w+):[^\n]*\n(.*?)(?:\n\.Lfunc_end|s_endpgm(?![\s\S]*?\n\.Lfunc_end))", text, re.S):
         name, body = km.group(1), km.group(2)
         ins = []
         for l in body.split("\n"):
