@@ -29,7 +29,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 128, TN = 128, TK = 32;
 constexpr int LDK = TK + 4;   // row stride of a [rows][k] tile (floats): 16-byte aligned, spreads the b128 fragment reads
-constexpr int LDM = TM + 4;   // row stride of a [k][rows] tile
 constexpr int TILE_F = TM * LDK;  // floats per operand tile (the larger of the two layouts)
 
 enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_LSTM = 2, EPI_RNN = 3 };

@@ -2124,6 +2124,7 @@ int kprn_sparse_grad_merge(kprn_handle* h, const void* dev_all, int32_t world, i
 // union of the rows inside the row kernel) back to back from one C call.  librccl is dlopen'ed (the copy the host process already
 // uses -- torch ships one -- so the library has no link-time dependency on it); the communicator is bootstrapped by the caller's own
 // control plane: rank 0 draws the 128-byte id (kprn_dp_unique_id), the caller broadcasts it, every rank calls kprn_dp_init.
+}  // extern "C"   (the helpers below are C++: they return std::string)
 namespace {
 struct Id128 { char b[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES), passed BY VALUE to ncclCommInitRank
 struct Rccl {
@@ -2166,6 +2167,7 @@ std::string rccl_msg(const char* what, int rc) {
 }
 const int kNcclInt32 = 2;   // ncclDataType_t (rccl.h)
 }  // namespace
+extern "C" {
 
 static void dp_release(kprn_handle* h) {
   if (h->dp_comm && g_rccl.CommDestroy) {

@@ -529,8 +529,9 @@ void persist_forward(kprn_handle* h, const kprn_batch* b, bool save, void*& st, 
     p->cscr = pal<float>((int64_t)ncu * H * pk::ROWS);
     repack = true;
   }
-  int nw = pk::NW_DEFAULT, dbg = 0, pf = pk::PF_DEFAULT, la = pk::LA_DEFAULT;
+  int nw = pk::NW_DEFAULT;
 #ifdef KPRN_PERSIST_VARIANTS
+  int dbg = 0, pf = pk::PF_DEFAULT, la = pk::LA_DEFAULT;
   // measurement builds (scripts/gpu_persist_knockouts.py): KPRN_PERSIST_NW = waves per workgroup, _DBG = knock-out mask, _PF = ring depth, _LA
   if (!save) {
     if (const char* e = KPRN_DEV_ENV("KPRN_PERSIST_NW")) nw = atoi(e);
