@@ -107,6 +107,9 @@ def parse():
                     help="every path has T real steps (no left padding -> no identical-prefix skipping) and the batch is a whole number of 256 x 64-path "
                          "tiles: every workgroup of the fused kernels draws the same number of tile-steps.  The dominant kernel's roofline.frac on this "
                          "line is the kernel's own ceiling, free of the 18-vs-20 tile-step quantisation of the 4 / 6-step mix (DESIGN.md section 7-1)")
+    ap.add_argument("--no-strong-1m", action="store_true",
+                    help="data-parallel runs without --total-paths also time the north_star's strong-scaling experiment (1 000 000 paths split over ranks "
+                         "and steps, and the same total on rank 0 alone) and report it under \"strong_1M\"; this flag skips it")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rank wiring / timing / JSON check without a GPU: gloo backend, the step is a placeholder (CPU tests)")
     return ap.parse_args()
@@ -179,12 +182,26 @@ def dry_run(a):
         a.steps = strong_steps(a.total_paths, world, a.steps)
     pps = a.paths_per_step if not a.total_paths else max(64, a.total_paths // (world * max(1, a.steps)))
     g = torch.ones(1024)   # the "replica": every rank applies the same all-reduced update
+    cur_pps = [pps]
     def step():
         upd = torch.full((1024,), 1.0 + rank)
         if world > 1:
             dist.all_reduce(upd)
         g.add_(upd, alpha=1e-3)
-        return pps
+        return cur_pps[0]
+    # the bootstrap of the engine's own communicator, as a placeholder under the SAME watchdog and agreement as the real one (kprn_amd/dp.py
+    # GpuAdapter.native_setup): a bootstrap that never returns on some rank makes every rank fall back, with the reason on the line
+    from kprn_amd.dp import call_with_watchdog, first_reason
+    def init():
+        if os.environ.get("KPRN_DP_TEST_INIT_HANG") == "1" and rank == world - 1:
+            time.sleep(3600)
+    ok, why = call_with_watchdog(init, float(os.environ.get("KPRN_DP_INIT_TIMEOUT", "60")), "kprn_dp_init (dry-run placeholder)")
+    okt = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    native = bool(int(okt.item()))
+    dp_extra = {"exchange": "engine (placeholder)" if native else "torch.distributed collectives (fallback)",
+                "fallback_reason": None if native else (first_reason(why) or "kprn_dp_init failed on another rank")}
     for _ in range(a.warmup):
         step()
     if world > 1:
@@ -200,6 +217,34 @@ def dry_run(a):
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         el[0] = mx[0]
+    # the strong-scaling experiment beside a weak line (main(): strong_1m): the same total split over ranks and steps, then on rank 0 alone
+    if world > 1 and not a.total_paths and not a.no_strong_1m:
+        ks = strong_steps(STRONG_TOTAL, world, a.steps)
+        cur_pps[0] = max(64, STRONG_TOTAL // (world * ks))
+        dist.barrier()
+        t1 = time.perf_counter()
+        ns = sum(step() for _ in range(ks))
+        dist.barrier()
+        es = torch.tensor([time.perf_counter() - t1, float(ns)], dtype=torch.float64)
+        mx = es.clone(); sm = es.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        k1 = strong_steps(STRONG_TOTAL, 1, a.steps)
+        pps1 = max(64, STRONG_TOTAL // k1)
+        n1 = None
+        dist.barrier()
+        if rank == 0:
+            t2 = time.perf_counter()
+            g1 = torch.ones(1024)
+            for _ in range(k1):
+                g1.add_(torch.full((1024,), 1.0), alpha=1e-3)
+            e1 = max(time.perf_counter() - t2, 1e-9)
+            n1 = {"steps": k1, "paths_per_step": pps1, "value": round(k1 * pps1 / e1, 1), "paths_counted": k1 * pps1}
+        dist.barrier()
+        v = float(sm[1]) / max(float(mx[0]), 1e-9)
+        dp_extra["strong_1M"] = {"total_paths": STRONG_TOTAL, "steps": ks, "paths_per_rank_step": cur_pps[0], "value": round(v, 1), "unit": "paths/s",
+                                 "paths_counted": int(sm[1]), "n1": n1,
+                                 "speedup_vs_n1": round(v / n1["value"], 6) if n1 else None, "efficiency": round(v / n1["value"] / world, 6) if n1 else None}
+        cur_pps[0] = pps
     if os.environ.get("KPRN_DRYRUN_DIVERGE") == "1" and rank == world - 1:   # (tests: a replica that went its own way must fail the run)
         g[7] += 1e-6
     per_rank, same = replica_digests((g.numpy(),), world)
@@ -209,7 +254,7 @@ def dry_run(a):
                           "higher_is_better": True, "scaling": "strong" if a.total_paths else "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "none (dry run: placeholder steps, launcher and rank wiring only)", "dry_run": True,
                           "ranks_reporting": int(tot[2]), "paths_counted": int(tot[1]),
-                          "dp": {"replica_digests": {"per_rank": per_rank}, "replicas_bit_identical": same},
+                          "dp": dict({"replica_digests": {"per_rank": per_rank}, "replicas_bit_identical": same}, **dp_extra),
                           "config": {"workload": "dry run", "paths_per_step_per_gpu": pps, "parallelism": f"dp{world}" if world > 1 else "single"}}))
     if world > 1:
         dist.destroy_process_group()
@@ -785,12 +830,22 @@ def main():
     # dominant family.  Inside the timed region only the dominant family keeps its events (an event pair costs ~4 us of
     # stream time; 13 pairs per step were 6 % of the step), which is what `roofline` is computed from.
     prof = not a.no_kernel_events
-    for i in range(a.warmup):
-        if i == min(1, a.warmup - 1):  # (the very first step carries one-time costs: code load, allocations)
-            eng.sync()
-            eng.profile_reset()
-            eng.profile(prof)
-        step(i)
+    try:
+        for i in range(a.warmup):
+            if i == min(1, a.warmup - 1):  # (the very first step carries one-time costs: code load, allocations)
+                eng.sync()
+                eng.profile_reset()
+                eng.profile(prof)
+            step(i)
+    except dp.DpHang as ex:
+        # the engine's own collective never completed on the device: nothing on this stream can be waited for any more.  Say so and leave
+        # (exit code 4) instead of hanging in the next synchronisation.
+        if rank == 0:
+            emit_last({"metric": "paths/sec (train+score) at path_len=6 d=64", "value": None, "unit": "paths/s", "n_gpus": world, "steps": 0,
+                       "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                       "data": "synthetic", "config": {"workload": "aborted in the warm-up steps", "parallelism": f"dp{world}"},
+                       "dp": {"world": world, "fallback_reason": str(ex), "aborted": True}}, hard_exit=True, rc=4)
+        os._exit(4)
     eng.sync()
     fams_warm = eng.profile_get() if prof else {}
     # dominant family = the one that carries the most algorithmic work per step among the families whose work is known
@@ -845,7 +900,16 @@ def main():
     if plain and not main_streaming:
         # enough steps for a >= 0.3 s timed region
         k_long = int(min(4000, max(a.steps, np.ceil(0.35 / max(elapsed / a.steps, 1e-6)))))
+        # ... with HIP events around EVERY fused family (the headline region keeps only the dominant family's: an event pair costs ~4 us of stream
+        # time; three pairs in a >= 0.3 s region of ~1.4 ms steps are < 1 %): roofline.other_timed_families
+        long_fams_on = prof and dominant.startswith("lstm_fused")
+        if long_fams_on:
+            eng.profile_reset(); eng.set_option("profile_filter", "lstm_fused"); eng.profile(True)
         el, n = timed_region(step, a.warmup + a.steps, k_long)
+        if long_fams_on:
+            eng.profile(False)
+            extras["long_fams"] = (eng.profile_get(), a.warmup + a.steps, k_long)
+            eng.profile_reset(); eng.set_option("profile_filter", dominant)
         extras["long_run"] = region_line(el, n, k_long)
         # every step of every path executed (no identical-prefix plan)
         eng.set_option("prefix_plan", "0")
@@ -917,6 +981,16 @@ def main():
         else:
             allr = [mine]
         dp_info["per_rank_ms_per_step"] = [round(float(x.item()), 4) for x in allr]
+        dp_info["fallback_reason"] = dpx.fallback_reason   # why the engine's own exchange is not in use (None: it is)
+        # ---- the north_star's scaling experiment beside the weak line: 1 M paths strong-scaled, and the same total on rank 0 alone
+        if not a.total_paths and not a.no_strong_1m and a.dims == "A" and a.compute_dtype == 0 and not a.score_only and not a.train_only:
+            try:
+                dp_info["strong_1M"] = strong_1m(a, eng, dpx, opt, run_batch, timed_region, barrier, world, rank, local_rank, stream,
+                                                 dict(T=T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, nT=nT, dt=dt_, de=de_, dr=dr_, H=H, L=L, C=C), Ps)
+            except dp.DpHang:
+                raise
+            except Exception as ex:   # noqa: BLE001  (deterministic failures happen on every rank alike: the weak line is still worth printing)
+                dp_info["strong_1M"] = {"error": f"{type(ex).__name__}: {ex}"}
         # Replicas must hold the same bits after the timed steps: the rows are summed in rank order inside the row update and the dense arena in rank
         # order inside the merge, so parameters AND Adam state are bit-identical by construction.  A 64-bit digest of the flat
         # parameter vector and of both Adam moments from every rank; any difference fails the run (exit code 3 below).
@@ -947,12 +1021,14 @@ def main():
             kernels[name] = {"ms": round(ms, 4), "launches": launches, "from": "warmup"}
         for name, (ms, launches) in fams.items():        # the dominant family: live, inside the timed region
             kernels[name] = {"ms": round(ms, 4), "launches": launches, "from": "timed"}
-        def family_roofline(name, ms, launches):
-            # launches of a family all see the same N within a step; average work per launch over steps
+        def family_roofline(name, ms, launches, first=None, k=None):
+            # launches of a family all see the same N within a step; average work per launch over the region's steps (first, k: the headline region)
+            first = a.warmup if first is None else first
+            k = a.steps if k is None else k
             work = 0.0
-            for i in range(a.steps):
-                N = paths_of[(a.warmup + i) % len(batches)]
-                fw = family_work(name, N, T, D, H, L, C, F, nT, dt_, de_, dr_, G, exec_of[(a.warmup + i) % len(batches)])
+            for i in range(k):
+                N = paths_of[(first + i) % len(batches)]
+                fw = family_work(name, N, T, D, H, L, C, F, nT, dt_, de_, dr_, G, exec_of[(first + i) % len(batches)])
                 if fw is None:
                     return None
                 work += fw[1]
@@ -960,7 +1036,7 @@ def main():
                 return None
             bound = family_work(name, 1, T, D, H, L, C, F, nT, dt_, de_, dr_, G)[0]
             # every launch of a family inside one step sees that step's N; launches per step is constant
-            total_work = work * (launches / a.steps)
+            total_work = work * (launches / k)
             if bound == "mfma":
                 achieved = total_work / (ms * 1e-3) / 1e12
                 peak, unit = (PEAK_TFLOPS_BF16_MFMA if (a.compute_dtype == 1 and "bf16" in name) else PEAK_TFLOPS_F32_MFMA), "TFLOP/s"
@@ -982,6 +1058,11 @@ def main():
                         "traffic": None, "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": launches}
         if len(fams) > 1:   # the other families timed inside the region (the persistent bf16 layer kernel's scoring launch beside its training launch)
             roofline["other_timed_families"] = {n: family_roofline(n, m, l) for n, (m, l) in fams.items() if n != name}
+        elif "long_fams" in extras:
+            # the fused forward launches (and the dominant family once more), timed with their own events inside the long_run region.  The scoring
+            # forward runs on the side stream beside the training forward: its event pair spans its wait for CUs as well (see kernels_note).
+            lf, lfirst, lk = extras["long_fams"]
+            roofline["other_timed_families"] = {n: dict(family_roofline(n, m, l, lfirst, lk) or {}, region="long_run", steps=lk) for n, (m, l) in sorted(lf.items())}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -1117,6 +1198,81 @@ def main():
         emit_last(out, hard_exit=(world > 1 or a.force_dp), rc=3 if diverged else 0)
     elif diverged:
         sys.exit(3)
+
+
+STRONG_TOTAL = 1_000_000   # north_star: ">= 70 % data-parallel scaling efficiency at 8 GPUs on 1M synthetic length-6 paths"
+
+
+def strong_1m(a, eng, dpx, opt, run_batch, timed_region, barrier, world, rank, local_rank, stream, shp, Ps):
+    """The strong-scaling experiment inside a weak-scaling invocation (the driver passes no --total-paths): STRONG_TOTAL paths divided over the
+    ranks and over strong_steps() steps through the same data-parallel step as the headline, and the SAME total on rank 0 alone (a second engine,
+    the plain step, the other ranks waiting at a barrier) -- so that speed-up and efficiency come from one invocation on one set of boxes."""
+    import torch
+    from kprn_amd import _ffi, synth
+    T, F, Vt, Ve, Vr, nT = shp["T"], shp["F"], shp["Vt"], shp["Ve"], shp["Vr"], shp["nT"]
+
+    def make_pool(engine, pps, seed0):
+        pool = []
+        for i, P in enumerate(Ps):
+            idx, labels = synth.make_paths(max(1, pps // P), P, T, F=F, Vt=Vt, Ve=Ve, Vr=Vr, num_types=nT, seed=seed0 + 97 * i)
+            pool.append(engine.batch(idx, labels))
+        return pool
+
+    # (a) all ranks: total / (world * steps) paths per rank and step
+    ks = strong_steps(STRONG_TOTAL, world, a.steps)
+    pps = max(64, STRONG_TOTAL // (world * ks))
+    pool = make_pool(eng, pps, 555 + 7919 * rank)
+    npaths = [b.n_paths for b in pool]
+    cap_before = dpx.capacity
+    dpx.set_capacity(max(max(b.n_uniq for b in pool), cap_before))   # (collective: the larger of the two bounds, the same on every rank)
+
+    def st(i):
+        run_batch(pool[i % len(pool)])
+        return npaths[i % len(pool)]
+    for i in range(2):
+        st(i)
+    el, n = timed_region(st, 2, ks)
+    out = {"total_paths": STRONG_TOTAL, "steps": ks, "paths_per_rank_step": pps, "value": round(n / el, 1), "unit": "paths/s",
+           "ms_per_step": round(1e3 * el / ks, 4), "paths_counted": int(n)}
+    for b in pool:
+        b.free()
+    # (b) rank 0 alone: the same total through the plain step of a second engine (no exchange), enough steps for >= 32 768 paths each
+    k1 = strong_steps(STRONG_TOTAL, 1, a.steps)
+    pps1 = max(64, STRONG_TOTAL // k1)
+    n1 = None
+    barrier()
+    if rank == 0:
+        e1 = _ffi.Engine(Vt, Ve, Vr, shp["dt"], shp["de"], shp["dr"], shp["H"], shp["L"], F=F, num_types=nT, C_=shp["C"], reducer=2, device_id=local_rank,
+                         rank=0, world=1, param_init=0.1, seed=12345, stream=stream)
+        e1.set_option("score_overlap", "0" if a.no_score_overlap else "1")
+        p1 = make_pool(e1, pps1, 555)
+        np1 = [b.n_paths for b in p1]
+
+        def st1(i):
+            b = p1[i % len(p1)]
+            e1.forward_async(b, 1)
+            e1.train_step(b, opt, 1, want_loss=False)
+            return np1[i % len(p1)]
+        for i in range(3):
+            st1(i)
+        e1.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        c1 = sum(st1(3 + i) for i in range(k1))
+        e1.sync(); torch.cuda.synchronize()
+        e1s = time.perf_counter() - t0
+        n1 = {"steps": k1, "paths_per_step": pps1, "value": round(c1 / e1s, 1), "ms_per_step": round(1e3 * e1s / k1, 4), "paths_counted": int(c1),
+              "what": "rank 0 alone: a second engine, the plain step (no exchange), the other ranks waiting"}
+        for b in p1:
+            b.free()
+        e1.close()
+    barrier()
+    if n1 is not None:
+        out["n1"] = n1
+        out["speedup_vs_n1"] = round(out["value"] / n1["value"], 4)
+        out["efficiency"] = round(out["value"] / n1["value"] / world, 4)
+    out["what"] = ("strong scaling measured inside this invocation: value = total paths / max-over-ranks time of `steps` data-parallel steps; n1 = the same "
+                   "total on rank 0 alone; efficiency = value / (n1.value * n_gpus).  Steps are lowered until a rank's step holds >= 32 768 paths")
+    return out
 
 
 def emit_last(out, hard_exit=False, rc=0):

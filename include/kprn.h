@@ -183,6 +183,11 @@ int kprn_batch_distinct_rows(kprn_handle* h, const kprn_batch* b, int32_t* n);
  * the batch's reference step (left padding, movie_data_format.py:250-254) and that the fused kernels therefore run once
  * for the batch instead of once per path -- same results; for work / roofline accounting                                  */
 int kprn_batch_executed_steps(kprn_handle* h, const kprn_batch* b, int64_t* steps);
+/* what the fused BPTT launches' time-split tile hand-over (option "tile_handover") does with this batch: out[0] = pairs of workgroups
+ * between which a tile changes hands, out[1] = steps moved in all, out[2] / out[3] = the longest workgroup's work in HALF steps with whole
+ * tiles only / with the hand-over (a tile's first executed step counts one half: it has no recurrent product).  All zero / equal when the
+ * batch does not run on the fused kernels or the option is off.  Diagnostics: waits for the engine's stream.                          */
+int kprn_batch_handover_stats(kprn_handle* h, const kprn_batch* b, int64_t* out /* [4] */);
 
 /* ---- scoring: model:forward(inputs) (test_from_checkpoint.lua:81-82,109) ------------
  * probs[B]      = Sigmoid(reduce_p(mapper))[:, classId]       (Select(2,classId))
@@ -217,7 +222,9 @@ int kprn_apply_update(kprn_handle* h, const kprn_opt* opt);
  * the optimiser step are queued and complete in stream order BEFORE anything a later call on this handle can observe (parameters, gradients,
  * scores, the next step) -- the caller's idx / labels have been consumed, and the caller prepares its next minibatch while the device finishes
  * this one (MyOptimizer.lua:184-221 returns the same number; it just cannot overlap).  A device error raised by the rest of the step surfaces at
- * the next call.  kprn_set_option(h, "train_step_return", "drain") restores the wait for the whole step; kprn_sync always waits for everything. */
+ * the next call.  kprn_set_option(h, "train_step_return", "drain") restores the wait for the whole step; kprn_sync always waits for everything.
+ * kprn_train_step (host buffers) waits for the loss stage whether or not `loss` is NULL -- that wait is what lets the next call upload its
+ * minibatch beside this step's backward; kprn_train_step_batch with loss == NULL is fully asynchronous.                                      */
 int kprn_train_step(kprn_handle* h, const int32_t* idx, int32_t B, int32_t P, int32_t T, int32_t F,
                     const float* labels, int32_t class_id, const kprn_opt* opt, float* loss);
 int kprn_train_step_batch(kprn_handle* h, const kprn_batch* b, int32_t class_id, const kprn_opt* opt,
@@ -320,6 +327,10 @@ int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t*
  *                     priority: its single-tile workgroups take the CUs the first BPTT launch leaves idle in its tail
  *   "score_rest_in_backward" "0" (default) | "1": with "score_split" f > 0, the fused backward places the deferred part of the scoring pass itself, right behind its
  *                     last BPTT launch (beside the step's serial tail); measured slower than the whole pass first at world 1
+ *   "tile_handover"   "2" (default) | "1" | "0": the fused D = H = 64 BPTT launches let a 64-path tile change workgroups once, between two of its steps, so
+ *                     that the workgroups' step sums differ by less than a step on a left-padded path set (workgroup b paired with b + G / 2; "1": with
+ *                     G - 1 - b; "0": whole tiles only).  Same gradients up to fp32 re-association of the weight-gradient partial sums; see
+ *                     kprn_batch_handover_stats, DESIGN.md section 3.3b
  *   "train_step_return" "loss" (default) | "drain": see kprn_train_step
  *   "inline_upload"   "side" (default): kprn_train_step uploads its minibatch on the upload stream, beside the previous step's backward, whenever the previous
  *                     call waited for its loss (every reader of the slot being refilled is then known to be done); "main": on the engine's stream

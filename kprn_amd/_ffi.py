@@ -208,6 +208,13 @@ class Batch:
         self.engine._ck(self.engine.L.kprn_batch_executed_steps(self.engine.h, self.ptr, C.byref(n)))
         return int(n.value)
 
+    @property
+    def handover_stats(self):
+        """time-split tile hand-over on this batch: (pairs, steps moved, longest workgroup in half steps without, with)"""
+        out = (C.c_int64 * 4)()
+        self.engine._ck(self.engine.L.kprn_batch_handover_stats(self.engine.h, self.ptr, out))
+        return tuple(int(v) for v in out)
+
     def free(self):
         if self.ptr:
             self.engine.L.kprn_batch_destroy(self.engine.h, self.ptr)

@@ -395,10 +395,9 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 template <int LA, int LB, int EPI, int NTW>
 void launch(hipStream_t s, const TArgs& a, int split_k) {
   const size_t lds_bytes = (size_t)4 * TILE_F * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.need()) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_tiled<LA, LB, EPI, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
   }
   const int64_t mgroups = (a.mtiles + 7) / 8;
   dim3 grid((unsigned)(mgroups * a.ntiles * 8), (unsigned)split_k);

@@ -1263,10 +1263,9 @@ static bool table_grad_lds(hipStream_t s, const int32_t* idx, int64_t N, int T, 
                            int V, float* gW) {
   const size_t bytes = (size_t)V * dcols * sizeof(float);
   if (dcols <= 0 || dcols > 128 || bytes > 64 * 1024) return false;
-  static bool attr_set = false;
-  if (bytes > 48 * 1024 && !attr_set) {
+  static PerDeviceOnce attr_set;
+  if (bytes > 48 * 1024 && attr_set.need()) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_table_grad_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_set = true;
   }
   // positions per workgroup: enough that the flush (V * dcols atomics) stays small beside the reads, few enough to fill the chip
   const int64_t total = N * T;

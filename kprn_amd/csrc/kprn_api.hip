@@ -26,6 +26,7 @@ bool transpose_job(kprn_handle* h, kk::TransposeJob* tj);
 void prefix_forward(kprn_handle* h, const kprn_batch* b);
 void mc_prepare(kprn_handle* h);
 void release(kprn_handle* h);
+void handover_stats(kprn_handle* h, const kprn_batch* b, int64_t* out);
 }  // namespace fused
 
 static thread_local std::string g_create_error;
@@ -898,7 +899,8 @@ static void apply_update_impl(kprn_handle* h, const kprn_opt* o) {
 #define API_BEGIN(h)                                   \
   if (!(h)) return KPRN_E_ARG;                         \
   try {                                                \
-    HIP_TRY(hipSetDevice((h)->cfg.device_id));
+    HIP_TRY(hipSetDevice((h)->cfg.device_id));         \
+    if ((h)->ho_fault && *(volatile int*)(h)->ho_fault) throw KprnError{KPRN_E_DEVICE, "a fused kernel's tile hand-over wait timed out: results since then are invalid"};
 #define API_END(h)                                                                        \
   }                                                                                       \
   catch (const KprnError& e) { (h)->err = e.msg; return e.code; }                         \
@@ -1020,6 +1022,7 @@ void kprn_destroy(kprn_handle* h) {
   if (h->ev_part1) { hipEventDestroy(h->ev_part1); h->ev_part1 = nullptr; }
   if (h->loss_mirror) { hipHostFree(h->loss_mirror); h->loss_mirror = nullptr; }
   if (h->probs_mirror) { hipHostFree(h->probs_mirror); h->probs_mirror = nullptr; }
+  if (h->ho_fault) { hipHostFree(h->ho_fault); h->ho_fault = nullptr; }
   if (h->ev_loss) { hipEventDestroy(h->ev_loss); h->ev_loss = nullptr; }
   for (auto e : h->event_pool) hipEventDestroy(e);
   Workspace& w = h->ws;
@@ -1362,6 +1365,18 @@ int kprn_batch_create(kprn_handle* h, const int32_t* idx, const float* labels, i
 // inline_now (the host-buffer entry points kprn_train_step / kprn_forward, which return results and therefore wait for the feed anyway): derive on the
 // CALLING thread and copy on the engine's own stream -- no worker hand-over, no upload thread, no cross-stream events (a 128-pair minibatch is
 // microseconds of host work; the thread hand-overs were most of its feed time)
+// The upload stream, made once -- by whichever feed path needs it first (the inline side upload of kprn_train_step or the worker-built feed; a second
+// creation would drop the first handle with copies still queued on it, outside quiesce() and kprn_destroy's reach).  A queue of its own: HIP
+// multiplexes the streams of one priority onto a few hardware queues, and this stream spends its life waiting on events of the compute streams --
+// sharing a hardware queue with one of them stalls that stream's kernels behind the waits (measured: every kernel of the step 1.2-5x slower).  The
+// high-priority class has its own queues.
+static void ensure_upload_stream(kprn_handle* h) {
+  if (h->upload_stream) return;
+  int lo = 0, hi = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIP_TRY(hipStreamCreateWithPriority(&h->upload_stream, hipStreamNonBlocking, hi));
+}
+
 static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const float* labels, const int64_t* rows, bool inline_now = false) {
   const int32_t B = b->B, P = b->P, T = b->T, F = b->F;
   const int64_t nsteps = (int64_t)B * P * T, N = (int64_t)B * P, n_index = b->n_index;
@@ -1374,14 +1389,7 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
     if (h->feed_threads <= 0) h->feed_threads = 4;
     h->feed_pool = hostfeed::make_pool(std::max(1, h->feed_workers));
     h->upload_pool = hostfeed::make_pool(1);
-    {
-      // a queue of its own: HIP multiplexes the streams of one priority onto a few hardware queues, and this stream spends its
-      // life waiting on events of the compute streams -- sharing a hardware queue with one of them stalls that stream's
-      // kernels behind the waits (measured: every kernel of the step 1.2-5x slower).  The high-priority class has its own queues.
-      int lo = 0, hi = 0;
-      HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      HIP_TRY(hipStreamCreateWithPriority(&h->upload_stream, hipStreamNonBlocking, hi));
-    }
+    ensure_upload_stream(h);
   }
   if (!b->ev_fork) {
     HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -1414,7 +1422,7 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
   if (inline_now) {
     try {
       // where the upload runs: beside the step in flight when nothing can still read this slot (kprn_internal.h: dropin_prev_waited), else in stream order
-      const bool side_copy = h->inline_upload_side && labels != nullptr && h->dropin_prev_waited && h->inline_side_ok;
+      const bool side_copy = h->inline_upload_side && labels != nullptr && h->dropin_prev_waited_now && h->inline_side_ok;
       hipStream_t cs = h->stream;
       kprn_batch::HostResult* r = &b->hres;
       const int32_t* src = idx;
@@ -1425,11 +1433,7 @@ static void feed_host(kprn_handle* h, kprn_batch* b, const int32_t* idx, const f
       if (!r->bad) {
         if (want_idx && !rows) memcpy(hs + l.idx, idx, (size_t)(nsteps * F) * sizeof(int32_t));
         hs[l.cnt] = r->n_uniq;
-        if (side_copy && !h->upload_stream) {   // (its own hardware queue class: see the worker path above)
-          int lo = 0, hi = 0;
-          HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-          HIP_TRY(hipStreamCreateWithPriority(&h->upload_stream, hipStreamNonBlocking, hi));
-        }
+        if (side_copy) ensure_upload_stream(h);
         cs = side_copy ? h->upload_stream : h->stream;
         if (h->score_pending && h->score_stream) HIP_TRY(hipStreamWaitEvent(cs, h->ev_score_done, 0));   // (a pass on the side stream may still read the slot)
         const int64_t w0 = want_idx ? 0 : l.idx_s, w1 = want_index ? l.words : l.key;
@@ -1670,6 +1674,15 @@ int kprn_batch_executed_steps(kprn_handle* h, const kprn_batch* b, int64_t* step
   API_END(h)
 }
 
+int kprn_batch_handover_stats(kprn_handle* h, const kprn_batch* b, int64_t* out) {
+  API_BEGIN(h)
+  KPRN_REQUIRE(b && out, KPRN_E_ARG, "NULL argument");
+  batch_ready(h, b);
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (use_fused(h, b, true) && h->cfg.compute_dtype == 0) fused::handover_stats(h, b, out);
+  API_END(h)
+}
+
 // ---- a side stream that really runs beside the main stream ---------------------------------------------------------------------
 // HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default; assigned round-robin as streams are made),
 // and two streams that land on the same queue execute IN ORDER.  In a process that also holds torch's and RCCL's streams the scoring
@@ -1747,6 +1760,9 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
     fused::mc_prepare(h);         // (likewise: the split weights of the matrix-core forward)
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_fork, 0));
+    // an earlier pass (or its deferred part, which may have run on the rest stream: "score_rest_before_bptt") writes the same S2 / sel2: this pass
+    // starts behind it whichever stream it finished on
+    if (h->score_pending && h->ev_score_done) HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_score_done, 0));
     Workspace& w = h->ws;
     hipStream_t main_stream = h->stream;
     float* S0 = w.S; float* sel0 = w.sel;
@@ -1978,9 +1994,16 @@ int kprn_train_step(kprn_handle* h, const int32_t* idx, int32_t B, int32_t P, in
   // frees nothing; alternating, so that the rows the lazy optimiser still names belong to the OTHER slot) instead of a batch created and
   // destroyed per call (two device allocations, a device-side index build with its synchronisations and three stream drains per step:
   // 1.06 ms per 128-pair step against 0.38 ms for the step itself).
+  // dropin_prev_waited says "the previous call waited for its own step's loss": it holds for exactly one call.  Taken and cleared here, so that a call
+  // that fails anywhere below (an id out of range, a bad argument) leaves it false and the call after it uploads in stream order again.
+  const bool prev_waited = h->dropin_prev_waited;
+  h->dropin_prev_waited = false;
+  h->dropin_prev_waited_now = prev_waited;   // (what the inline feed of THIS call reads)
   int rc = dropin_feed(h, /*score=*/false, idx, labels, B, P, T, F);
+  h->dropin_prev_waited_now = false;
   if (rc != KPRN_OK) return rc;
-  // (the loss is always fetched: waiting for it is what lets the NEXT call's upload run beside this step's backward)
+  // (the loss is always fetched -- the call waits for the loss stage whether or not the caller passed `loss`: that wait is what lets the NEXT call's
+  // upload run beside this step's backward)
   float l = 0.f;
   rc = kprn_train_step_batch(h, h->dropin_slot[h->dropin_last], class_id, opt, &l);
   h->dropin_prev_waited = (rc == KPRN_OK);
@@ -2427,6 +2450,12 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     // its tiling from this option.)
     join_score(h);
     h->small_tiles_on = atoi(value) != 0;
+  } else if (strcmp(key, "tile_handover") == 0) {
+    // fused D = H = 64 backward launches: a tile may change workgroups once between two of its steps -- "2" (default): workgroup b paired with b + G / 2,
+    // "1": with G - 1 - b -- or workgroups run whole tiles only ("0")
+    const int v = atoi(value);
+    KPRN_REQUIRE(v >= 0 && v <= 2, KPRN_E_ARG, "tile_handover must be 0, 1 or 2");
+    h->tile_handover = v;
   } else if (strcmp(key, "persist_layers") == 0) {
     // generic fp32 pipelines: a recurrent layer as ONE persistent launch ("1", default: where layer_f32_persist.hip takes the shape and the batch gives
     // every CU a tile; "2": at any batch size -- tests) or one launch per step ("0")
@@ -2440,7 +2469,7 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
   } else if (strcmp(key, "bf16_t_pad") == 0) {
     bf16p::set_t_pad(atoi(value));   // small-table route: pad (elements) of the row pitch of dA^T / Z^T ("0": rows 2^18-aligned at the bench's size)
   } else if (strcmp(key, "bf16_gemm_regstage") == 0) {
-    // bf16 split-K products on gx::k_gemm16r ("1", default: operands global -> registers -> LDS, four chunks in flight per thread) or gx::k_gemm16x ("0": LDS-DMA, two)
+    // bf16 split-K products on gx::k_gemm16r ("1": opt-in, operands global -> registers -> LDS, four chunks in flight per thread) or gx::k_gemm16x ("0", default: LDS-DMA, two)
     bf16p::set_gemm_regstage(atoi(value) != 0);
   } else if (strcmp(key, "bf16_gemm_touch") == 0) {
     // bf16 products on gx::k_gemm16x: every wave touches (one dword per tile row = one cache line) the chunk this many chunks ahead of its DMA: an L2 prefetch

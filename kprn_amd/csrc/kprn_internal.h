@@ -213,8 +213,10 @@ struct kprn_handle {
   int dropin_next_train = 0, dropin_next_score = 0, dropin_last = 0;
   // The inline feed of kprn_train_step uploads on the upload stream (beside the previous step's backward) when every reader of the slot it refills is known to be
   // done: the slot was last read two calls ago, and the previous call WAITED for its own step's loss, i.e. for a kernel ordered behind that reader (option
-  // "inline_upload" = "side", default; "main": on the engine's stream as in round 4).  A previous call that returned without waiting (loss == NULL) clears the flag.
-  bool dropin_prev_waited = false; int inline_upload_side = 1;
+  // "inline_upload" = "side", default; "main": on the engine's stream as in round 4).  kprn_train_step always waits for its loss stage (whether or not the
+  // caller asked for the loss); the flag is consumed by the NEXT kprn_train_step (dropin_prev_waited_now: valid during that call's feed only) and set again
+  // only by a call that succeeded, so a failed call never lends its predecessor's guarantee to its successor.
+  bool dropin_prev_waited = false, dropin_prev_waited_now = false; int inline_upload_side = 1;
   bool inline_side_ok = true;   // (feed_impl: false when the handle still referred to the slot being refilled -- its rows are copied out in stream order first)
   bool score_pending = false;     // a pass is (possibly) still running on score_stream
   int bf16_bptt_dxe = 8;          // option "bf16_bptt_dxe": the persistent BPTT launch also forms dx for the entity slice (weight ring depth 8 | 16; 0: a separate product)
@@ -224,6 +226,11 @@ struct kprn_handle {
   float* st_ctmp = nullptr; int64_t st_ctmp_cap = 0;   //   ... its [GH][ns + de] product result
   bool bf16_small_tables = true;  // option "bf16_small_tables": configs[3] backward forms the type / relation gradients from G = dA^T [S_r | S_t] (lstm_bf16.hip)
   bool small_tiles_on = true;     // option "small_tiles": batches of <= 8 192 paths run on tiles of one 16-row m-tile (no identical-prefix plan)
+  // option "tile_handover": the fused D = H = 64 BACKWARD launches let a tile change workgroups once between two of its steps, so that the workgroups'
+  // step sums differ by less than a step (lstm_fused_common.h ho_plan).  "2" (default): workgroup b is paired with b + G / 2; "1": with G - 1 - b; "0": whole
+  // tiles only (the A/B reference).  ho_fault: page-locked word a kernel sets when its wait for the other workgroup's state timed out -- every later API
+  // call then fails instead of returning numbers computed from a stale slot
+  int tile_handover = 2; int* ho_fault = nullptr;
   float score_split = 0.f;        // option: fraction of a scoring pass's tiles deferred to kprn_forward_batch_async_rest
   // option "score_rest_in_backward": the deferred part of a split pass is placed by the fused backward itself, right behind its last BPTT launch -- it runs on the side
   // stream beside the step's serial tail (prefix backward, gradient gather-reduce, slab reduce), whose latency-bound launches leave most CUs idle; the update joins it
@@ -474,8 +481,22 @@ float debug_gemm16(hipStream_t s, int64_t M, int N, int64_t K, int split_k, int 
 void set_gemm_touch(int chunks);   // (process-wide) L2 prefetch distance of k_gemm16x (0: off)
 void set_gemm_regstage(bool on);   // (process-wide) the split-K bf16 products on gx::k_gemm16r (register-staged operands, four chunks in flight)
 void set_t_pad(int elements);      // (process-wide) pad of the transposed images' row pitch on the small-table route (HBM channel spread)
-void set_gemm_pingpong(bool on);   // (process-wide) the split-K bf16 products on the two-group 256 x 256 kernel (default) or on k_gemm16x   // ms per launch (kprn_debug_gemm what 5 / 6)
+void set_gemm_pingpong(bool on);   // (process-wide) the split-K bf16 products on the two-group 256 x 256 kernel (opt-in) or on k_gemm16x (default)   // ms per launch (kprn_debug_gemm what 5 / 6)
 }  // namespace bf16p
+
+// ---- once per DEVICE -----------------------------------------------------------------------------------------
+// hipFuncSetAttribute (the raised dynamic-LDS limit of a kernel) applies to the CURRENT device: a `static bool done` guard is per process, and the second
+// GPU of a process (the data-parallel loopback and multichip tests hold several) then launches the kernel without it.  One bit per device ordinal.
+struct PerDeviceOnce {
+  unsigned long long mask = 0;
+  bool need() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return true;
+    const unsigned long long bit = 1ull << (d & 63);
+    const unsigned long long old = __atomic_fetch_or(&mask, bit, __ATOMIC_RELAXED);
+    return !(old & bit);
+  }
+};
 
 // ---- environment switches ---------------------------------------------------------------------------------
 // The shipped library reads a dozen environment variables, each set by a test that names it (README.md has the list).  Every other

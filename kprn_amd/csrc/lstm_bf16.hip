@@ -273,10 +273,9 @@ __global__ __launch_bounds__(Geo<BIG>::NT, BIG ? 1 : 2) void k_gemm16(GArgs a) {
 template <int EPI, int BIG>
 static void launch16(hipStream_t s, GArgs a, int split_k) {
   const size_t lds_bytes = (size_t)4 * Geo<BIG>::TILE * sizeof(bf16);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.need()) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_gemm16<EPI, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
   }
   a.nsplit = split_k;
   dim3 grid((unsigned)(((a.mtiles + 7) / 8) * 8 * a.ntiles));
@@ -1072,21 +1071,20 @@ static bool gemm16x(hipStream_t s, const bf16* A, int64_t lda, const bf16* B, in
   split_k = (int)((K + kchunk - 1) / kchunk);
   a.kchunk = kchunk; a.nsplit = split_k;
   const size_t lds_bytes = p ? (size_t)gx::PNBUF * gx::PBUF_BYTES : (y ? (size_t)gx::YSTAGE * gx::YSTAGE_BYTES : (size_t)gx::NSTAGE * gx::STAGE_BYTES + 2048 /* touch scratch */);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.need()) {
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::PNBUF * gx::PBUF_BYTES)));
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::NSTAGE * gx::STAGE_BYTES + 2048)));
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::NSTAGE * gx::STAGE_BYTES + 2048)));
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16y<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::YSTAGE * gx::YSTAGE_BYTES)));
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16y<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)gx::YSTAGE * gx::YSTAGE_BYTES)));
-    attr_done = true;
   }
   dim3 grid((unsigned)(((a.mtiles + 7) / 8) * 8 * a.ntiles));
   if (split_k > 1) grid = dim3((unsigned)(((split_k + 7) / 8) * 8 * a.mtiles * a.ntiles));
   if (!p && !y && accumulate && split_k > 1 && g_gemm16_regstage) {
-    static bool r_attr = false;
+    static PerDeviceOnce r_attr;
     const size_t lds_r = (size_t)2 * gx::STAGE_BYTES;
-    if (!r_attr) { HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16r<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r)); r_attr = true; }
+    if (r_attr.need()) { HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16r<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r)); }
     hipLaunchKernelGGL((gx::k_gemm16r<true>), grid, dim3(gx::NTHR), lds_r, s, a);
     HIP_TRY(hipGetLastError());
     return true;
@@ -1132,10 +1130,9 @@ static bool gemm16xt(hipStream_t s, const bf16* AT, int64_t ldat, const bf16* B,
   a.AT = AT; a.ldat = ldat; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.Mp = Mp; a.N = N; a.K = K; a.Np = Np; a.Nv = Nv; a.zero = zero16();
   a.mtiles = (Mp + gx::BM - 1) / gx::BM; a.ntiles = (N + gx::BN - 1) / gx::BN;
   const size_t lds_bytes = (size_t)gx::NSTAGE * gx::STAGE_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.need()) {
     HIP_TRY(hipFuncSetAttribute((const void*)gx::k_gemm16xt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
   }
   hipLaunchKernelGGL(gx::k_gemm16xt, dim3((unsigned)(((a.mtiles + 7) / 8) * 8 * a.ntiles)), dim3(gx::NTHR), lds_bytes, s, a);
   HIP_TRY(hipGetLastError());

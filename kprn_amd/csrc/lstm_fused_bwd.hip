@@ -52,6 +52,7 @@ struct BwdArgs {
   // steps is summed per prefix class into PG and finished by k_prefix_bwd
   const int32_t* tile_k;
   float* PG;               // [KCAP+1][PFB] this layer: sum over rows of dA at the tile's first executed step | of dc handed below it
+  HoArgs ho;               // time-split tile hand-over (lstm_fused_common.h ho_plan)
 };
 
 constexpr int PART = 2 * 256 * 64 + 256;  // floats per workgroup partial slab
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int arow = lane & 15, ag = lane >> 4;
   const int T = a.T, L = a.L, ly = a.layer;
+  // (first thing in the kernel: its one round trip is in flight under the weight loads below)
+  const HoPlan ho = ho_plan(a.ho, a.tile_k, a.n_tiles, T);
 
   // ---- AGPR residents: this wave's slice of [W_i2g^T | W_o2g^T] (stage E's B operand) and the dW accumulators
   //      dwi/dwo[q][nt][r] <-> dW row q*64 + 16j + 4ag + r, col 16nt + arow
@@ -140,51 +143,43 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   // every plane of ITS layer through the cache, and what is recent is the dx the top layer wrote last, i.e. of its first tiles.
   // (0.319 -> 0.312 ms per launch.)
   const int64_t n_mine = (a.n_tiles > (int64_t)blockIdx.x) ? (a.n_tiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-  for (int64_t tq = 0; tq < n_mine; ++tq) {
-    const int64_t ti = TOP ? n_mine - 1 - tq : tq;
-    const int64_t tile = (int64_t)blockIdx.x + ti * gridDim.x;
-    const int64_t n0 = tile * MTR;
-    const int k0 = a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tile]) : 0;  // steps below k0 belong to the prefix
-    // Everything below counts steps from the tile's first executed one: tt = t - k0 in [0, Te).  The step index enters the
-    // addresses only through these per-tile bases, so the step bodies see the same (compile-time 0 for the last step)
-    // offsets whether or not the tile sits behind a prefix.
-    const int Te = T - k0;
-    const float* frag_tile = a.save_frag + tile * NMT * frag_mt_stride + (int64_t)k0 * L * 4 * frag_unit + lane * 4;
-    float* dx_tile = a.DX + (((tile * NMT) * T + k0) * 4 + j) * 256 + lane * 4;  // + (mt * T + tt) * 1024
-    const int32_t* idk = ids + k0 * 4;                                           // [(row * T + tt) * 4 + slot]
+  // Time-split hand-over (lstm_fused_common.h ho_plan): the LIGHT workgroup of a pair runs the first ho.d steps (T-1 .. T-d) of the heavy one's
+  // first tile before its own tiles and publishes (dh, dc); the HEAVY one keeps that tile for last and resumes it at step T-d-1.
+  float* const ho_slot = a.ho.state + (int64_t)ho.slot * HO_STATE + threadIdx.x * 4;   // [dh | dc][NMT][256 threads][4]
+  // the pair's tile is the heavy workgroup's first one (ti = 0): last in the top layer's order anyway, moved to the end of the bottom layer's
+  auto own_of = [&](const int64_t it) -> int64_t {
+    const int64_t ti = TOP ? n_mine - 1 - it : ((ho.role == 1) ? (it + 1 < n_mine ? it + 1 : 0) : it);
+    return (int64_t)blockIdx.x + ti * gridDim.x;
+  };
+  for (int64_t it = 0; it < n_mine; ++it) {
+    const int64_t own_tile = own_of(it);
+    const bool late = ho.role == 1 && own_tile == (int64_t)blockIdx.x;    // the late piece of the pair's tile: starts from the stored state
+    const bool early = ho.role == 2 && it == 0;   // the early piece of the pair's tile rides IN FRONT of this workgroup's first own tile:
+    // its ho.d recurrent steps run through the same recurrent loop, and a rare block between two steps stores the state and re-points everything
+    // at the own tile.  (Nothing here skips a block of MFMAs: every way of leaving the tile's step 0 out -- if / else, continue, a loop with an
+    // opaque trip count -- made hipcc shuffle the 128 launch-persistent dW accumulators at every tile's end or hold the step's operand registers
+    // live across it; a second instantiation of the step body in front of the loop was correct but ran as cold code: +10 us per piece.)
+    // Per-piece bases.  Everything below counts steps from the tile's first executed one: tt = t - k0 in [0, Te).  The step index enters the
+    // addresses only through these bases, so the step bodies see the same (compile-time 0 for the last step) offsets whether or not the tile
+    // sits behind a prefix.
+    int64_t tile, n0;
+    int k0, Te;                  // k0: steps below it belong to the prefix
+    const float* frag_tile;
+    float* dx_tile;              // + (mt * T + tt) * 1024
+    const int32_t* idk;          // [(row * T + tt) * 4 + slot]
+    auto retarget = [&](const int64_t tl) {
+      tile = tl;
+      n0 = tl * MTR;
+      k0 = a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tl]) : 0;
+      Te = T - k0;
+      frag_tile = a.save_frag + tl * NMT * frag_mt_stride + (int64_t)k0 * L * 4 * frag_unit + lane * 4;
+      dx_tile = a.DX + (((tl * NMT) * T + k0) * 4 + j) * 256 + lane * 4;
+      idk = ids + k0 * 4;
+    };
+    retarget(early ? ho.tile : own_tile);
     auto frag_ptr = [&](int mt, int t, int l, int w, int plane) -> const float* {
       return frag_tile + mt * frag_mt_stride + ((int64_t)(t * L + l) * 4 + w) * frag_unit + plane * 256;
     };
-    f32x4 dc[NMT], dh[NMT];
-#pragma unroll
-    for (int m = 0; m < NMT; ++m) {
-      dc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dh[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (TOP) {
-        // nn.Linear(H,46) backward restricted to the selected column (OneModel.lua:275, MyOptimizer.lua:126): the recurrent
-        // dh starts at dS[n] W_out[cid][:], and gW_out[cid][:] += dS[n] h_T[n][:] straight from the saved h fragment
-        const f32x4 hf = *(const f32x4*)(frag_tile + m * frag_mt_stride + ((int64_t)((Te - 1) * L + ly) * 4 + j) * frag_unit + 6 * 256);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t n = n0 + m * 16 + ag * 4 + r;
-          const float d = (n < a.N) ? a.dS[n] : 0.f;
-          dh[m][r] = d * wout_c;
-          gwo += d * hf[r];
-          gbo += d;
-        }
-      }
-    }
-    if (BOTTOM) {
-      lds_barrier();  // previous tile's id tile / x tile fully consumed
-      ids_stage<256, MTR>(a.idx, a.N, T, a.F, a.nT, tile, ids);
-      lds_barrier();
-      f32x4 nin[MTR * 16 / 256];
-      gather_load<256, MTR>(a, gsrc, tile, Te - 1, idk, nin, T - 1);
-      gather_store<256, MTR>(in_t, nin);
-      lds_barrier();
-    }
-    TPROBE(1)  // tile prologue
-
     // Stage C operands, single-buffered: each register set is re-requested for the NEXT m-tile as soon as its
     // last consumer has issued (the factors after the VALU block, each B fragment after its 32 MFMAs), so the
     // loads have ~3k cycles of MFMA issue to land in.
@@ -203,9 +198,51 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) bin[nt][r] = in_t[(mt * 16 + ag * 4 + r) * LDA + nt * 16 + arow];
     };
-    load_P(0, Te - 1);
+    const int tt_hi = late ? Te - 1 - ho.d : Te - 1;   // first step this piece runs
+    f32x4 dc[NMT], dh[NMT];
+    auto init_state = [&]() {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) load_B(nt, 0, Te - 1, Te > 1);
+      for (int m = 0; m < NMT; ++m) {
+        dc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dh[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (TOP) {
+          // nn.Linear(H,46) backward restricted to the selected column (OneModel.lua:275, MyOptimizer.lua:126): the recurrent
+          // dh starts at dS[n] W_out[cid][:], and gW_out[cid][:] += dS[n] h_T[n][:] straight from the saved h fragment
+          const f32x4 hf = *(const f32x4*)(frag_tile + m * frag_mt_stride + ((int64_t)((Te - 1) * L + ly) * 4 + j) * frag_unit + 6 * 256);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t n = n0 + m * 16 + ag * 4 + r;
+            const float d = (n < a.N) ? a.dS[n] : 0.f;
+            dh[m][r] = d * wout_c;
+            gwo += d * hf[r];
+            gbo += d;
+          }
+        }
+      }
+    };
+    if (__builtin_expect(late, 0)) {   // (uniform) the other workgroup ran the steps above tt_hi
+      ho_wait(a.ho, ho.slot);
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) { dh[m] = ho_load4(ho_slot + m * 1024); dc[m] = ho_load4(ho_slot + (NMT + m) * 1024); }
+    } else {
+      init_state();
+    }
+    auto tile_prologue = [&](const int tt_first) {
+      if (BOTTOM) {
+        lds_barrier();  // previous tile's id tile / x tile fully consumed
+        ids_stage<256, MTR>(a.idx, a.N, T, a.F, a.nT, tile, ids);
+        lds_barrier();
+        f32x4 nin[MTR * 16 / 256];
+        gather_load<256, MTR>(a, gsrc, tile, tt_first, idk, nin, k0 + tt_first);
+        gather_store<256, MTR>(in_t, nin);
+        lds_barrier();
+      }
+    };
+    tile_prologue(tt_hi);
+    TPROBE(1)  // tile prologue
+    load_P(0, tt_hi);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) load_B(nt, 0, tt_hi, tt_hi > 0);
 
     // the step body is compiled twice (REC: t > 0, there is an h_{t-1} / c_{t-1}): no MFMA sits under a run-time condition
     auto step = [&](auto rec_tag, const int t) {  // t: step counted from the tile's first executed one
@@ -356,8 +393,26 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       lds_barrier();  // dA_t free for reuse, x_{t-1} tile visible
       TPROBE(5)  // end barrier
     };
-    for (int tt = Te - 1; tt > 0; --tt) step(std::true_type{}, tt);
+    int tt_sw = early ? Te - ho.d : -1;   // the early piece's last step
+    for (int tt = tt_hi; tt > 0; --tt) {
+      step(std::true_type{}, tt);
+      if (__builtin_expect(tt == tt_sw, 0)) {   // (uniform, once per launch at most) the pair's tile goes on in its heavy workgroup; this one turns to its own first tile
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) { ho_store4(ho_slot + m * 1024, dh[m]); ho_store4(ho_slot + (NMT + m) * 1024, dc[m]); }
+        // (the flag follows at this tile's end: by then the stores have long been acknowledged, and the pair's heavy workgroup asks for them a
+        // few tiles from now -- publishing here would drain every load in flight first)
+        retarget(own_tile);
+        init_state();
+        tile_prologue(Te - 1);
+        load_P(0, Te - 1);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) load_B(nt, 0, Te - 1, Te > 1);
+        tt = Te;   // (the loop goes on with the own tile's step Te - 1)
+        tt_sw = -1;
+      }
+    }
     step(std::false_type{}, 0);
+    if (__builtin_expect(early, 0)) ho_publish(a.ho, ho.slot);   // (uniform) the state stored in front of this tile's recurrent steps
     if (k0 > 0) {
       // ... and dc_{k0-1} = sum over rows of the dc this step hands down
       float cs = 0.f;
@@ -590,7 +645,8 @@ static void launch_bwd(kprn_handle* h, const BwdArgs& a, int grid) {
   size_t lds_bytes = (size_t)MT * LDD * sizeof(float);
   if (BOTTOM) lds_bytes += (size_t)MT * LDA * sizeof(float) + (MT * MAXT_LDS * 4) * sizeof(int32_t);
   lds_bytes += (size_t)(KCAP + 1) * PFB * sizeof(float);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP, NMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  static PerDeviceOnce attr_done;  // one per template instantiation (the call is host time in front of every launch otherwise)
+  if (attr_done.need()) HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP, NMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL((k_lstm_bwd<BOTTOM, TOP, NMT>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());
 }
@@ -650,6 +706,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     a.n_tiles = n_tiles;
     a.part = s->part + (size_t)l * s->num_cu * PART; a.timing = s->timing;
     a.dbg = kprn_dbg_mask();
+    a.ho = handover_args(h, grid);
     const bool bottom = (l == 0), top = (l == L - 1);
     // type / relation gradients: a passenger job of the entity-gradient launch when the shapes allow (one type slot, slices in
     // 16-column blocks, tables of at most 16 rows), else the general scatter kernel
@@ -720,6 +777,21 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       HIP_TRY(hipMemcpy(tb.data(), s->timing, tb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       double sum[8] = {0};
       for (int g = 0; g < grid; ++g) for (int k = 0; k < 8; ++k) sum[k] += (double)tb[(size_t)g * 8 + k];
+      {   // (per-workgroup totals: the longest, and the mean of the first 21 / of the others -- the heavy and the light workgroups of the bench's tile mix)
+        double tmax = 0, th = 0, tl = 0; int nh = 0, nl = 0, imax = 0;
+        for (int g = 0; g < grid; ++g) {
+          double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)tb[(size_t)g * 8 + k];
+          if (tot > tmax) { tmax = tot; imax = g; }
+          if (g < 21) { th += tot; ++nh; } else { tl += tot; ++nl; }
+        }
+        if (getenv("KPRN_TIMING_DUMP")) {   // (measurement build only) every workgroup's total, in workgroup order
+          fprintf(stderr, "[kprn timing dump] bwd layer %d:", l);
+          for (int g = 0; g < grid; ++g) { double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)tb[(size_t)g * 8 + k]; fprintf(stderr, " %.0f", tot / 1000.0); }
+          fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "[kprn timing] bwd layer %d per-WG total: max %.0f (WG %d) mean of WG 0..20 %.0f, of the others %.0f; tile-prologue of WG 0: %.0f, WG 100: %.0f\n", l, tmax, imax,
+                th / (nh ? nh : 1), tl / (nl ? nl : 1), (double)tb[1], grid > 100 ? (double)tb[100 * 8 + 1] : 0.0);
+      }
       fprintf(stderr, "[kprn timing] bwd layer %d N=%lld grid=%d avg cycles/WG: prologue %.0f tile-prologue %.0f stageC-valu %.0f stageC-mfma %.0f midbar %.0f stageE %.0f endbar %.0f flush %.0f\n",
               l, (long long)N, grid, sum[0] / grid, sum[1] / grid, sum[7] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[6] / grid);
     }
@@ -742,7 +814,9 @@ void params_changed(kprn_handle* h) {
 void release(kprn_handle* h) {
   State* s = (State*)h->fused_state;
   if (!s) return;
-  for (float* p : {s->save_frag, s->WT, s->DX, s->DXe, s->part, s->part_small, s->pfb, s->pfs, s->pfx, s->PG, s->r1, s->mc_bias, s->mc_hseq[0], s->mc_hseq[1]}) if (p) hipFree(p);
+  for (float* p : {s->save_frag, s->WT, s->DX, s->DXe, s->part, s->part_small, s->pfb, s->pfs, s->pfx, s->PG, s->r1, s->mc_bias, s->mc_hseq[0], s->mc_hseq[1],
+                   s->ho_state[0], s->ho_state[1]}) if (p) hipFree(p);
+  for (unsigned* p : {s->ho_flag[0], s->ho_flag[1]}) if (p) hipFree(p);
   if (s->mc_wsp) hipFree(s->mc_wsp);
   if (s->timing) hipFree(s->timing);
   delete s;

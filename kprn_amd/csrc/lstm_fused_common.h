@@ -17,6 +17,15 @@ constexpr int DH = 64;        // D == H == 64 in this variant
 constexpr int MT = 64;        // paths per tile
 constexpr int LDA = DH + 4;   // LDS row stride (floats): 16-byte aligned, spreads ds_read_b128 slots
 
+// time-split tile hand-over (described further down, at ho_plan)
+struct HoArgs {
+  float* state = nullptr;      // [gridDim.x][HO_STATE] hand-over slots, indexed by the HEAVY workgroup of a pair
+  unsigned* flag = nullptr;    // [gridDim.x] epoch of the slot's contents
+  unsigned epoch = 0;          // this launch's serial; 0: no hand-over (every workgroup runs whole tiles)
+  int mode = 1;                // pairing: 1 = b with G - 1 - b, 2 = b with b + G / 2
+  int* fault = nullptr;        // host-visible: set when a wait timed out
+};
+
 struct FwdArgs {
   const int32_t* idx;  // [N][T][F] 1-based
   int64_t N;
@@ -37,6 +46,7 @@ struct FwdArgs {
   float* save_frag;  // training: [(N/16)][T][L][4 waves][NPL][64 lanes][4]   (nullable)
   int64_t n_tiles;
   unsigned long long* timing;  // optional [grid][8] cycle counters (KPRN_TIMING=1)
+  HoArgs ho;         // time-split tile hand-over (below)
 };
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): ~1e-7 absolute error on the gate values, far inside the 1e-4 score bar
@@ -173,6 +183,109 @@ constexpr int NPL = 7;
 #define KPRN_PIN_A8(A, B) \
   asm volatile("" : "+a"((A)[0]), "+a"((A)[1]), "+a"((A)[2]), "+a"((A)[3]), "+a"((B)[0]), "+a"((B)[1]), "+a"((B)[2]), "+a"((B)[3]))
 
+// ---- time-split tile hand-over ----------------------------------------------------------
+// The persistent kernels deal tiles round-robin (tile = blockIdx.x + i gridDim.x) and a tile's time is its executed steps, so with a
+// left-padded path set (tiles of T and T - 2 steps) the workgroups' sums differ by whole steps: 21 of 256 draw 20 tile-steps, the others
+// 18, and the launch lasts 20.  A tile is therefore allowed to change workgroups once, BETWEEN two of its steps: the recurrent state of
+// its 64 rows ((h, c) per layer in the forward, (dh, dc) in the backward) goes through a per-tile slot in global memory.  Workgroup b is
+// paired with workgroup G - 1 - b (tiles are sorted longest first, so loads fall with b: the pairing is heaviest with lightest); when
+// their loads differ by at least one full step, the LAST d steps (in the kernel's own time order) of the heavy one's first tile move:
+//   forward:  heavy runs steps k0 .. T-1-d of the tile FIRST and publishes (h, c); light resumes it at T-d as its LAST piece of work;
+//   backward: light runs steps T-1 .. T-d of the tile FIRST and publishes (dh, dc); heavy resumes it at T-d-1 as its last piece.
+// The piece that publishes runs at the very start of its workgroup, the piece that waits at the very end of the other: the wait is a
+// formality (and bounded: a time-out raises the fault word instead of hanging the queue).  Both sides evaluate the same closed-form
+// rule from tile_k -- no schedule array, nothing for the batch planners to build.  Cost unit: half a step (a tile's first executed step
+// in the forward / last one in the backward has no recurrent half).
+constexpr int HO_STATE = 4 * MT * DH;   // floats per slot: forward h [L][64][64] + c [L][NMT][256][4]; backward dh | dc [NMT][256][4] each
+struct HoPlan { int role; int d; int64_t tile; int slot; };   // role: 0 whole tiles only, 1 heavy, 2 light; tile: the one that changes hands; d: steps moved
+constexpr long long HO_TIMEOUT_TICKS = 200000000ll;   // 2 s of the 100 MHz wall clock
+
+// the pair of workgroup bx among G: mode 1 = G - 1 - bx (heaviest with lightest), 2 = bx +- G / 2 (the heavy one is still the lower index, and the highest
+// indices -- the workgroups the hardware places last when the launch starts under another kernel's tail -- keep their slack); bx itself: unpaired
+__host__ __device__ __forceinline__ int ho_partner(int mode, int G, int bx) {
+  const int half = G >> 1;
+  return (mode == 2) ? (bx < half ? bx + half : (bx - half < half ? bx - half : bx)) : G - 1 - bx;
+}
+// what a pair with these loads (half steps) does; steps: executed steps of the heavy one's first tile; keep: steps of that tile that must stay in front of
+// the moved ones (forward: 2 -- the ids of a workgroup's next tile are staged under a tile's first slot and read under its second; backward: 1)
+__host__ __device__ __forceinline__ HoPlan ho_decide(int bx, int px, int mine, int theirs, int steps, int keep) {
+  HoPlan p{0, 0, -1, 0};
+  const int diff = mine > theirs ? mine - theirs : theirs - mine;
+  if (px == bx || diff < 4) return p;
+  p.role = mine > theirs ? 1 : 2;
+  p.tile = mine > theirs ? bx : px;
+  p.slot = (int)p.tile;
+  // d minimises max(heavy - 2 d, light + 2 d)
+  int d = diff >> 2;
+  if (2 * (d + 1) - diff < -2 * d) ++d;
+  p.d = d < steps - keep ? d : steps - keep;
+  if (p.d < 1) p.role = 0;
+  return p;
+}
+// host form (kprn_batch_handover_stats evaluates the rule for every workgroup): tile_k0(t) = prefix length of tile t
+template <class K0>
+inline HoPlan ho_plan_host(bool on, int mode, int G, int bx, int64_t n_tiles, int T, K0 tile_k0, int* load, int keep = 1) {
+  const int px = ho_partner(mode, G, bx);
+  int mine = 0, theirs = 0;
+  for (int64_t t = bx; t < n_tiles; t += G) mine += 2 * (T - tile_k0(t)) - 1;
+  for (int64_t t = px; t < n_tiles; t += G) theirs += 2 * (T - tile_k0(t)) - 1;
+  if (load) *load = mine;
+  if (!on || (n_tiles + G - 1) / G > 32) return HoPlan{0, 0, -1, 0};
+  const int64_t heavy = mine > theirs ? bx : px;
+  return ho_decide(bx, px, mine, theirs, T - tile_k0(heavy), keep);
+}
+// device form: ONE round trip -- lane i < 32 of every wave reads the prefix length of this workgroup's i-th tile, lane 32 + i of the pair's, and the two sums
+// are wave reductions.  (Read tile after tile it was eight dependent loads in front of every workgroup's first tile: 4 us, 1.5 % of the launch.)
+__device__ __forceinline__ HoPlan ho_plan(const HoArgs& ho, const int32_t* tile_k, int64_t n_tiles, int T, int keep = 1) {
+  const int G = gridDim.x, bx = blockIdx.x;
+  const int px = ho_partner(ho.mode, G, bx);
+  if (!ho.epoch || px == bx || (n_tiles + G - 1) / G > 32) return HoPlan{0, 0, -1, 0};
+  const int lane = threadIdx.x & 63, i = lane & 31;
+  const int64_t t = (int64_t)(lane < 32 ? bx : px) + (int64_t)i * G;
+  const int k = (tile_k && t < n_tiles) ? tile_k[t] : 0;
+  int cost = t < n_tiles ? 2 * (T - k) - 1 : 0;
+#pragma unroll
+  for (int sh = 1; sh < 32; sh <<= 1) cost += __shfl_xor(cost, sh, 64);
+  const int mine = __builtin_amdgcn_readlane(cost, 0), theirs = __builtin_amdgcn_readlane(cost, 32);
+  const int k_mine = __builtin_amdgcn_readlane(k, 0), k_theirs = __builtin_amdgcn_readlane(k, 32);
+  return ho_decide(bx, px, mine, theirs, T - (mine > theirs ? k_mine : k_theirs), keep);
+}
+
+// slot traffic at agent scope (sc1: written through to / read from where the eight XCDs' L2s agree), 16 bytes per call
+__device__ __forceinline__ void ho_store4(float* p, const f32x4& v) {
+  union { f32x4 f; unsigned long long u[2]; } c;
+  c.f = v;
+  __hip_atomic_store((unsigned long long*)p, c.u[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((unsigned long long*)p + 1, c.u[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 ho_load4(const float* p) {
+  union { f32x4 f; unsigned long long u[2]; } c;
+  c.u[0] = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  c.u[1] = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return c.f;
+}
+// ... 4 bytes per call (the forward's cell state: its registers are scalars of the hot loop -- handled as 16-byte tuples here they constrained that loop's
+// allocation: 140 spilled registers)
+__device__ __forceinline__ void ho_store1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ho_load1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every thread's slot stores have been acknowledged -> the flag
+__device__ __forceinline__ void ho_publish(const HoArgs& ho, int slot) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(ho.flag + slot, ho.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ho_wait(const HoArgs& ho, int slot) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(ho.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ho.epoch) {
+    __builtin_amdgcn_s_sleep(16);
+    if (wall_clock64() - t0 > HO_TIMEOUT_TICKS) {
+      if (threadIdx.x == 0) __hip_atomic_store(ho.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+  asm volatile("" ::: "memory");   // the slot's loads stay behind the flag's
+}
+
 // ---- host-side state shared by forward() and backward() ----
 struct State {
   float* save_frag = nullptr;
@@ -196,6 +309,10 @@ struct State {
   int64_t pf_batch = -1;    // batch serial the table was computed for (-1: stale)
 
   float* part = nullptr;    // [L][num_cu][PART]
+  // time-split tile hand-over: slots + flags per launch context (0: the engine's main stream, 1: the scoring stream -- the two run side by side),
+  // one launch serial for all of them, the fault word in page-locked host memory
+  float* ho_state[2] = {nullptr, nullptr}; unsigned* ho_flag[2] = {nullptr, nullptr};
+  unsigned ho_epoch = 0;
   float* part_small = nullptr;  // [8 num_cu][Vt*dt + Vr*dr] small-table partials of the embedding scatter
   int part_small_n = 0;
   unsigned long long* timing = nullptr;  // [num_cu][8] when KPRN_TIMING=1
@@ -217,6 +334,8 @@ bool fwd_supported(const kprn_handle* h, int T);
 // small batches: tiles of ONE 16-row m-tile (four times as many workgroups, a quarter of the latency per tile); no identical-prefix plan
 constexpr int64_t SMALL_TILES_MAX_PATHS = 8192;
 bool small_tiles(const kprn_handle* h, int64_t N, bool has_plan);
+void handover_stats(kprn_handle* h, const kprn_batch* b, int64_t* out /*[4]: pairs, steps moved, longest workgroup in half steps without / with*/);
+HoArgs handover_args(kprn_handle* h, int grid);   // this launch's hand-over context (epoch 0: off)
 void prefix_forward(kprn_handle* h, const kprn_batch* b);
 void forward_mc(kprn_handle* h, const kprn_batch* b, bool save);
 void mc_prepare(kprn_handle* h);

@@ -328,6 +328,16 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
         else if (l + 1 < L) nxt = hbuf(l + 1, par ^ 1) + a_off;
         else nxt = hbuf(0, par) + a_off;
         if (!FIRST) {
+          if (L == 1 && mt == 0) {
+            // One layer: this recurrent half reads rows 0-15 of h_{t-1}, which the four waves wrote behind the previous slot's only barrier (the
+            // interleaved cell of that slot's unit (0, 1)) -- with two layers the upper layer's barrier lies in between.  Nothing else orders the
+            // waves here, and they do drift: in a tile's first slot waves 0-2 run the head of the tile before (46 classes = 3 column tiles) and
+            // wave 3 does not, so wave 3 arrived a whole slot early and read rows the others had not written yet (wrong scores, run to run, in
+            // the second and later tiles of a workgroup: found in round 6, batches of more than 256 tiles).  The fragment the previous slot
+            // prefetched was that same early read.
+            lds_barrier();
+            apre = *(const f32x4*)(hp_buf + a_off);
+          }
           half_unit<SAVE, true, true, true>(hp_buf + mt * 16 * LDA + a_off, wo[l], bias4[l], acc, apre, in_base, pacc, c[pl][pm], pout, sv);
           save_unit(q_tile, q_t, pl, pm);
           if (mt == 0) {
@@ -434,6 +444,52 @@ bool small_tiles(const kprn_handle* h, int64_t N, bool has_plan) {
   return h->small_tiles_on && !has_plan && h->cfg.compute_dtype == 0 && h->cfg.L == 2 && N <= max_paths;
 }
 
+// The hand-over context of the launch about to be queued on h->stream: slots + flags of that stream's own set (the scoring pass runs beside the
+// training forward on its stream; launches of one stream are ordered, so they share a set under distinct epochs), a fresh epoch.  epoch 0 (off) when the
+// option is off, or for a stream that is neither the engine's own nor the scoring stream as a whole-batch launch.
+HoArgs handover_args(kprn_handle* h, int grid) {
+  HoArgs ho;
+  State* s = st(h);
+  if (!h->tile_handover || grid < 2 || grid > s->num_cu) return ho;
+  const int ctx = (h->score_stream && h->stream == h->score_stream) ? 1 : 0;
+  if (!s->ho_state[ctx]) {
+    HIP_TRY(kprn_dev_malloc((void**)&s->ho_state[ctx], (size_t)s->num_cu * HO_STATE * sizeof(float)));
+    HIP_TRY(kprn_dev_malloc((void**)&s->ho_flag[ctx], (size_t)s->num_cu * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(s->ho_flag[ctx], 0, (size_t)s->num_cu * sizeof(unsigned), h->stream));   // (ordered before the first launch that reads them)
+  }
+  if (!h->ho_fault) {
+    HIP_TRY(hipHostMalloc((void**)&h->ho_fault, 64, hipHostMallocDefault));
+    *h->ho_fault = 0;
+  }
+  if (++s->ho_epoch == 0) ++s->ho_epoch;
+  ho.state = s->ho_state[ctx]; ho.flag = s->ho_flag[ctx]; ho.epoch = s->ho_epoch; ho.fault = h->ho_fault; ho.mode = h->tile_handover;
+  return ho;
+}
+
+// what the hand-over rule does with this batch on the fused kernels' grid (diagnostics, tests, bench.py): evaluated on the host from the device's tile_k
+void handover_stats(kprn_handle* h, const kprn_batch* b, int64_t* out) {
+  State* s = st(h);
+  const int64_t N = (int64_t)b->B * b->P;
+  const bool small = small_tiles(h, N, b->tile_k != nullptr);
+  const int64_t n_tiles = small ? (N + 15) / 16 : (N + MT - 1) / MT;
+  const int G = (int)std::min<int64_t>(n_tiles, (int64_t)s->num_cu);
+  std::vector<int32_t> tk((size_t)n_tiles, 0);
+  if (b->tile_k) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(tk.data(), b->tile_k, (size_t)n_tiles * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  out[0] = out[1] = out[2] = out[3] = 0;
+  const bool on = h->tile_handover && G >= 2 && fwd_supported(h, b->T) && h->cfg.compute_dtype == 0;
+  for (int bx = 0; bx < G; ++bx) {
+    int load = 0;
+    const HoPlan p = ho_plan_host(on, h->tile_handover, G, bx, n_tiles, b->T, [&](int64_t tl) -> int { return tk[(size_t)tl]; }, &load);
+    out[2] = std::max<int64_t>(out[2], load);
+    if (p.role == 1) { out[0] += 1; out[1] += p.d; load -= 2 * p.d; }
+    else if (p.role == 2) load += 2 * p.d;
+    out[3] = std::max<int64_t>(out[3], load);
+  }
+}
+
 bool fwd_supported(const kprn_handle* h, int T) {
   const kprn_config& c = h->cfg;
   return (h->D == DH && c.H == DH && c.L >= 1 && c.L <= 2 && (c.dt % 4) == 0 && (c.de % 4) == 0 && (c.dr % 4) == 0 && T >= 2 && T <= MAXT_LDS);
@@ -442,10 +498,9 @@ bool fwd_supported(const kprn_handle* h, int T) {
 template <int L, bool SAVE, int NMT = 4>
 static void launch_fwd(kprn_handle* h, const FwdArgs& a, int grid) {
   const size_t lds_bytes = (size_t)(2 + 2 * L) * MT * LDA * sizeof(float) + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t) + (size_t)(KCAP + 1) * L * PFB * sizeof(float);
-  static bool attr_done = false;  // one per template instantiation
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;  // one per template instantiation
+  if (attr_done.need()) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd<L, SAVE, NMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
   }
   hipLaunchKernelGGL((k_lstm_fwd<L, SAVE, NMT>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());

@@ -560,10 +560,9 @@ __global__ void k_mc_prep(McPrepArgs a) {
 template <int M, bool SAVE>
 static void launch_mc(kprn_handle* h, const McArgs& a, int grid) {
   const size_t lds_bytes = (size_t)4 * McFmt<M>::NP * MT * LDB * 2 + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t) + (size_t)(KCAP + 1) * PFB * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.need()) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd_mc<M, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
   }
   hipLaunchKernelGGL((k_lstm_fwd_mc<M, SAVE>), dim3(grid), dim3(256), lds_bytes, h->stream, a);
   HIP_TRY(hipGetLastError());

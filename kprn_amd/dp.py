@@ -29,6 +29,46 @@ import torch
 import torch.distributed as dist
 
 
+def call_with_watchdog(fn, timeout_s, what):
+    """fn() on a daemon thread, at most timeout_s seconds -> (ok, reason).  A collective bootstrap that never returns (ncclCommInitRank with a rank
+    missing, a wedged transport) must not hang the job: the caller falls back and records `reason`; the stuck thread is left behind (it cannot be
+    cancelled) and dies with the process.  An exception raised by fn is a failure with its message as the reason."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            fn()
+            box["ok"] = True
+        except BaseException as ex:   # noqa: BLE001
+            box["err"] = f"{type(ex).__name__}: {ex}"
+
+    th = threading.Thread(target=run, name=f"kprn-watchdog-{what}", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return False, f"{what} did not return within {timeout_s:g} s"
+    if "err" in box:
+        return False, f"{what} failed: {box['err']}"
+    return True, None
+
+
+def first_reason(mine, group=None):
+    """the first rank's non-empty reason (every rank learns why the job fell back, not only the rank it happened on).  Collective."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return mine
+    allr = [None] * dist.get_world_size(group)
+    dist.all_gather_object(allr, mine, group=group)
+    for r, why in enumerate(allr):
+        if why:
+            return why if why == mine else f"rank {r}: {why}"
+    return None
+
+
+class DpHang(RuntimeError):
+    """the engine's own exchange did not complete on the device within the watchdog's bound"""
+
+
 class _DevArray:
     """minimal __cuda_array_interface__ carrier for a raw device pointer owned by libkprn."""
 
@@ -73,13 +113,20 @@ class GpuAdapter:
         engine.set_option("dp_fused_update", "1" if self.fused_update else "0")
 
     # ---- the exchange issued by the engine itself (kprn_dp_*, include/kprn.h): RCCL on the engine's stream ----
-    def native_setup(self, group, rank, world):
+    def native_setup(self, group, rank, world, timeout_s=None):
         """Bootstraps the engine's own RCCL communicator over the torch process group (which only carries the 128-byte id) -> True, or
-        False when every rank agrees it cannot be had (then the collectives stay with torch.distributed).  Collective."""
+        False when every rank agrees it cannot be had (then the collectives stay with torch.distributed; self.fallback_reason says why).
+        Collective.  ncclCommInitRank runs under a watchdog (KPRN_DP_INIT_TIMEOUT seconds, default 60): a bootstrap that never returns on
+        some rank fails everywhere instead of hanging the job."""
         from . import _ffi
+        self.fallback_reason = None
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("KPRN_DP_INIT_TIMEOUT", "60"))
         if dist.get_backend(group) != "nccl":
+            self.fallback_reason = "process group backend is not nccl"
             return False
         if not (self.dense_in_pack and self.fused_update):
+            self.fallback_reason = "caller asked for the dense all-reduce / the separate merge"
             return False   # kprn_dp_init forces both options on: a caller who asked for the all-reduce / the separate merge keeps the hook path
         path = _ffi.torch_rccl_path()
         idb, ok = bytes(128), 1
@@ -88,24 +135,33 @@ class GpuAdapter:
                 idb = _ffi.dp_unique_id(path)
             elif not _ffi.dp_available(path):
                 ok = 0
-        except Exception:
+        except Exception as ex:   # noqa: BLE001
             ok = 0
+            self.fallback_reason = f"librccl not usable from the engine: {ex}"
         with torch.cuda.stream(self.stream):
             t = torch.tensor([ok], dtype=torch.int32, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
             if int(t.item()) == 0:
+                self.fallback_reason = self.fallback_reason or "librccl not usable from the engine on some rank"
                 return False
             idt = torch.tensor(list(idb), dtype=torch.uint8, device=self.device)
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast(idt, src=src, group=group)
             idb = bytes(idt.cpu().tolist())
-            try:
+
+            def init():
+                if os.environ.get("KPRN_DP_TEST_INIT_HANG") == "1":   # (tests: a bootstrap that never returns)
+                    import time
+                    time.sleep(3600)
                 self.e.dp_init(idb, rank, world, path)   # ncclCommInitRank: every rank is in here
-            except Exception:
+            good, why = call_with_watchdog(init, timeout_s, "kprn_dp_init (ncclCommInitRank)")
+            if not good:
                 ok = 0
+                self.fallback_reason = why
             t = torch.tensor([ok], dtype=torch.int32, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
             if int(t.item()) == 0:
+                self.fallback_reason = first_reason(self.fallback_reason, group) or "kprn_dp_init failed on another rank"
                 if ok:
                     self.e.dp_shutdown()
                 self.e.set_option("dp_dense_in_pack", "1" if self.dense_in_pack else "0")
@@ -181,8 +237,16 @@ class DataParallel:
         # The engine's own exchange (one RCCL all-gather in place on the engine's stream, queued from C between pack and update) when the
         # adapter can set it up -- GPU adapter over the "nccl" backend; KPRN_DP_NATIVE=0 keeps the collectives with torch.distributed
         self.native = False
+        self.fallback_reason = None   # why the engine's own exchange is not in use (None: it is, or it was never asked for)
         if self.collectives and hasattr(adapter, "native_setup") and os.environ.get("KPRN_DP_NATIVE", "1") != "0":
             self.native = bool(adapter.native_setup(group, self.rank, self.world))
+            if not self.native:
+                self.fallback_reason = getattr(adapter, "fallback_reason", None)
+        elif self.collectives and hasattr(adapter, "native_setup"):
+            self.fallback_reason = "KPRN_DP_NATIVE=0"
+        # the FIRST exchange through the engine's communicator is waited for on the host, bounded (KPRN_DP_FIRST_STEP_TIMEOUT seconds, default 60): a
+        # collective that never completes on the device raises DpHang instead of hanging the first synchronisation of the job
+        self._first_native_checked = False
 
     def _ctx(self):
         """torch's current stream := the adapter's stream (GPU adapter), for the duration of the exchange's torch calls"""
@@ -239,6 +303,19 @@ class DataParallel:
         self._ev = []
         return {n: round(v / max(k, 1), 4) for n, v in acc.items()}
 
+    def _bounded_wait(self, timeout_s):
+        """host waits, at most timeout_s, for everything queued on the adapter's stream so far"""
+        import time
+        if not hasattr(self.a, "stream") or not torch.cuda.is_available():
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        t0 = time.perf_counter()
+        while not ev.query():
+            if time.perf_counter() - t0 > timeout_s:
+                raise DpHang(f"rank {self.rank}: the first exchange through the engine's RCCL communicator did not complete within {timeout_s:g} s")
+            time.sleep(0.002)
+
     def train_step(self, batch, opt, class_id=1, global_pairs=None, overlap=None):
         """one data-parallel MyOptimizer:trainBatch; `batch` holds THIS rank's pairs.
         overlap: optional callable that ENQUEUES work which does not depend on this step's update (e.g. a scoring pass
@@ -279,6 +356,9 @@ class DataParallel:
             self._mark()            # (no separate merge)
             a.exchange_finish(opt)  # dense sum + optimiser step with the union of the rows inside the row kernel
             self._mark()
+            if not self._first_native_checked:
+                self._first_native_checked = True
+                self._bounded_wait(float(os.environ.get("KPRN_DP_FIRST_STEP_TIMEOUT", "60")))
             return
         buf = a.pack(cap)  # one packed tensor per rank, same length everywhere
         if self._all is None or self._all.numel() != buf.numel() * self.world or self._all.dtype != buf.dtype:

@@ -74,3 +74,39 @@ def test_replica_digests_ride_on_the_line_and_a_diverged_replica_fails_the_run()
     assert len(lines) == 1
     bad = json.loads(lines[0])
     assert bad["dp"]["replicas_bit_identical"] is False and bad["dp"]["replica_digests"]["per_rank"][0] != bad["dp"]["replica_digests"]["per_rank"][1]
+
+
+def test_a_weak_invocation_also_reports_the_strong_scaling_experiment():
+    """round 6: the driver's scaling command carries no --total-paths.  A data-parallel run therefore ALSO times the north_star's experiment --
+    1 000 000 paths split over ranks and steps, and the same total on rank 0 alone -- and reports it under dp.strong_1M with speed-up and
+    efficiency from this one invocation.  (Partitioning unit = pairs: module/MapReduce.lua:24-47.)"""
+    d = _run(["--gpus", "2", "--steps", "20", "--warmup", "1", "--dry-run"])
+    assert d["scaling"] == "weak" and d["paths_counted"] == 2 * 20 * 65536       # the weak line is what it was
+    s1 = d["dp"]["strong_1M"]
+    assert s1["total_paths"] == 1000000 and s1["steps"] == 15 and s1["paths_per_rank_step"] == 1000000 // (2 * 15)   # >= 32 768 paths per rank and step
+    assert s1["paths_counted"] == 2 * 15 * (1000000 // 30)
+    assert s1["n1"]["steps"] == 20 and s1["n1"]["paths_per_step"] == 50000 and s1["n1"]["paths_counted"] == 1000000
+    assert s1["speedup_vs_n1"] > 0 and abs(s1["efficiency"] - s1["speedup_vs_n1"] / 2) < 1e-5
+    assert d["dp"]["fallback_reason"] is None and d["dp"]["exchange"].startswith("engine")
+    # ... and not with --total-paths (that run IS the strong experiment) or --no-strong-1m
+    assert "strong_1M" not in _run(["--gpus", "2", "--steps", "5", "--warmup", "0", "--dry-run", "--total-paths", "1000000"])["dp"]
+    assert "strong_1M" not in _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--dry-run", "--no-strong-1m"])["dp"]
+
+
+def test_a_communicator_bootstrap_that_never_returns_falls_back_instead_of_hanging():
+    """kprn_amd/dp.py call_with_watchdog around kprn_dp_init: one rank's bootstrap hangs (forced), every rank agrees to fall back to the
+    torch.distributed collectives, the reason is on the line, the run completes."""
+    d = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--no-strong-1m"], env={"KPRN_DP_TEST_INIT_HANG": "1", "KPRN_DP_INIT_TIMEOUT": "1.5"})
+    assert d["n_gpus"] == 2 and d["ranks_reporting"] == 2 and d["dp"]["replicas_bit_identical"] is True
+    assert "fallback" in d["dp"]["exchange"] and "did not return within 1.5 s" in d["dp"]["fallback_reason"]
+
+
+def test_watchdog_reports_exceptions_and_successes():
+    from kprn_amd.dp import call_with_watchdog
+    assert call_with_watchdog(lambda: None, 5, "noop") == (True, None)
+    ok, why = call_with_watchdog(lambda: 1 / 0, 5, "div")
+    assert not ok and "ZeroDivisionError" in why
+    import time
+    t0 = time.perf_counter()
+    ok, why = call_with_watchdog(lambda: time.sleep(30), 0.3, "sleeper")
+    assert not ok and "did not return within 0.3 s" in why and time.perf_counter() - t0 < 5

