@@ -331,6 +331,7 @@ int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t*
  *                     that the workgroups' step sums differ by less than a step on a left-padded path set (workgroup b paired with b + G / 2; "1": with
  *                     G - 1 - b; "0": whole tiles only).  Same gradients up to fp32 re-association of the weight-gradient partial sums; see
  *                     kprn_batch_handover_stats, DESIGN.md section 3.3b
+ *   "adam_merged"     "1" (default) | "0": lazy-exact Adam updates the touched entity rows and the dense arena in one launch (bit-identical to two)
  *   "train_step_return" "loss" (default) | "drain": see kprn_train_step
  *   "inline_upload"   "side" (default): kprn_train_step uploads its minibatch on the upload stream, beside the previous step's backward, whenever the previous
  *                     call waited for its loss (every reader of the slot being refilled is then known to be done); "main": on the engine's stream

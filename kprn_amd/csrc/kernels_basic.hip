@@ -638,21 +638,25 @@ __device__ __forceinline__ void adam_elem(float& x, float& m, float& v, float g,
 // consume != 0: the gradient is zeroed as it is used (zeroGradParameters of the next trainBatch, MyOptimizer.lua:186, done here);
 // [z0,z0+zn0) and [z1,z1+zn1): pad rows of the arena, re-zeroed after the update (zeroPadTokens, MyOptimizer.lua:219);
 // tab_slot: this step's entry of the device step-size table (read by the lazy row replay).
-__global__ void k_adam_dense(float* __restrict__ x, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                             float step, float b1, float b2, float eps, const float* __restrict__ norm2, float clip, float l2, int reg,
-                             int consume, int64_t z0, int zn0, int64_t z1, int zn1, float* __restrict__ tab_slot) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && tab_slot) *tab_slot = step;
-  if (i >= n) return;
-  float gi = g[i];
-  float xi = x[i];
-  if (reg) { gi = gi * clip_factor(norm2, clip); gi = gi + l2 * xi; }
-  float mi = m[i], vi = v[i];
-  adam_elem(xi, mi, vi, gi, step, b1, b2, eps);
-  if ((i >= z0 && i < z0 + zn0) || (i >= z1 && i < z1 + zn1)) xi = 0.f;
-  x[i] = xi; m[i] = mi; v[i] = vi;
-  if (consume) g[i] = 0.f;
+struct AdamDenseJob {   // the dense arena's share of an optimiser step (k_adam_dense, or extra workgroups of the row update's launch)
+  float *x, *g, *m, *v; int64_t n;
+  float step, b1, b2, eps; const float* norm2; float clip, l2; int reg, consume;
+  int64_t z0; int zn0; int64_t z1; int zn1; float* tab_slot;
+};
+__device__ __forceinline__ void adam_dense_block(const AdamDenseJob& a, int64_t block) {
+  const int64_t i = block * blockDim.x + threadIdx.x;
+  if (i == 0 && a.tab_slot) *a.tab_slot = a.step;
+  if (i >= a.n) return;
+  float gi = a.g[i];
+  float xi = a.x[i];
+  if (a.reg) { gi = gi * clip_factor(a.norm2, a.clip); gi = gi + a.l2 * xi; }
+  float mi = a.m[i], vi = a.v[i];
+  adam_elem(xi, mi, vi, gi, a.step, a.b1, a.b2, a.eps);
+  if ((i >= a.z0 && i < a.z0 + a.zn0) || (i >= a.z1 && i < a.z1 + a.zn1)) xi = 0.f;
+  a.x[i] = xi; a.m[i] = mi; a.v[i] = vi;
+  if (a.consume) a.g[i] = 0.f;
 }
+__global__ void k_adam_dense(AdamDenseJob a) { adam_dense_block(a, blockIdx.x); }
 
 __global__ void k_adagrad_dense(float* __restrict__ x, float* __restrict__ g, float* __restrict__ G, int64_t n, float clr,
                                 const float* __restrict__ norm2, float clip, float l2, int reg, int consume, int64_t z0, int zn0, int64_t z1,
@@ -700,11 +704,16 @@ __global__ void k_adam_rows(float* __restrict__ W, float* __restrict__ g, float*
 
 // the same for rows of d = 4 G floats handled by G = 8 / 16 / 32 lanes with 16-byte accesses (d = 32: eight rows per wave instead of one
 // half-empty wave per row; the per-element arithmetic is adam_elem's, so the result stays bit-identical to the dense sweep)
+// dense (nullable in effect: n_dense_blocks = 0): the dense arena's update rides in the same launch as workgroups [rows_blocks, rows_blocks + n_dense_blocks)
+// -- two latency-bound launches of the step's serial tail become one.  The row update then takes THIS step's size from `step_now` (the dense job writes the
+// table entry for later replays; inside one launch nothing orders that store before a row's read of it); step_now < 0: read it from the table.
 template <int G>
 __global__ void k_adam_rows_v(float* __restrict__ W, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                               int32_t* __restrict__ last, const int32_t* __restrict__ rows, const int32_t* __restrict__ count,
-                              int32_t t_now, int apply_step, const float* __restrict__ step_tab, float b1, float b2, float eps, int64_t pad_row) {
+                              int32_t t_now, int apply_step, const float* __restrict__ step_tab, float b1, float b2, float eps, int64_t pad_row,
+                              int rows_blocks, float step_now, AdamDenseJob dense) {
   typedef float f4 __attribute__((ext_vector_type(4)));
+  if ((int)blockIdx.x >= rows_blocks) { adam_dense_block(dense, (int64_t)blockIdx.x - rows_blocks); return; }
   const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const int j = threadIdx.x % G;
   if (slot >= *count) return;
@@ -723,7 +732,7 @@ __global__ void k_adam_rows_v(float* __restrict__ W, float* __restrict__ g, floa
       for (int q = 0; q < 4; ++q) adam_elem(x[q], mm[q], vv[q], 0.f, st, b1, b2, eps);
     }
   if (apply_step) {
-    const float st = step_tab[t_now];
+    const float st = step_now >= 0.f ? step_now : step_tab[t_now];
 #pragma unroll
     for (int q = 0; q < 4; ++q) adam_elem(x[q], mm[q], vv[q], g4[q], st, b1, b2, eps);
     *(f4*)(g + o) = f4{0.f, 0.f, 0.f, 0.f};
@@ -1405,12 +1414,17 @@ void sumsq_rows(hipStream_t s, const float* G, const int32_t* rows, const int32_
   CHECK_LAUNCH();
 }
 
+static AdamDenseJob dense_job(float* x, float* g, float* m, float* v, int64_t n, float step, float b1, float b2, float eps,
+                              const float* norm2, float clip, float l2, int consume, int64_t z0, int zn0, int64_t z1, int zn1, float* tab_slot) {
+  AdamDenseJob a;
+  a.x = x; a.g = g; a.m = m; a.v = v; a.n = n; a.step = step; a.b1 = b1; a.b2 = b2; a.eps = eps; a.norm2 = norm2; a.clip = clip; a.l2 = l2;
+  a.reg = (norm2 != nullptr || l2 != 0.f) ? 1 : 0; a.consume = consume; a.z0 = z0; a.zn0 = zn0; a.z1 = z1; a.zn1 = zn1; a.tab_slot = tab_slot;
+  return a;
+}
 void adam_dense(hipStream_t s, float* x, float* g, float* m, float* v, int64_t n, float step, float b1, float b2, float eps,
                 const float* norm2, float clip, float l2, int consume, int64_t z0, int zn0, int64_t z1, int zn1, float* tab_slot) {
   if (n <= 0) return;
-  int reg = (norm2 != nullptr || l2 != 0.f) ? 1 : 0;
-  hipLaunchKernelGGL(k_adam_dense, dim3(nblocks(n)), dim3(TPB), 0, s, x, g, m, v, n, step, b1, b2, eps, norm2, clip, l2, reg, consume, z0, zn0, z1,
-                     zn1, tab_slot);
+  hipLaunchKernelGGL(k_adam_dense, dim3(nblocks(n)), dim3(TPB), 0, s, dense_job(x, g, m, v, n, step, b1, b2, eps, norm2, clip, l2, consume, z0, zn0, z1, zn1, tab_slot));
   CHECK_LAUNCH();
 }
 
@@ -1426,12 +1440,30 @@ void adam_rows(hipStream_t s, float* W, float* g, float* m, float* v, int32_t* l
                int d, int32_t t_now, int apply_step, const float* step_tab, float b1, float b2, float eps, int64_t pad_row) {
   if (max_rows <= 0) return;
   const bool al = !(((uintptr_t)W | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15);
-  if (al && d == 32) hipLaunchKernelGGL(k_adam_rows_v<8>, dim3(nblocks(max_rows * 8)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, apply_step, step_tab, b1, b2, eps, pad_row);
-  else if (al && d == 64) hipLaunchKernelGGL(k_adam_rows_v<16>, dim3(nblocks(max_rows * 16)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, apply_step, step_tab, b1, b2, eps, pad_row);
-  else if (al && d == 128) hipLaunchKernelGGL(k_adam_rows_v<32>, dim3(nblocks(max_rows * 32)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, apply_step, step_tab, b1, b2, eps, pad_row);
+  AdamDenseJob none;
+  memset(&none, 0, sizeof(none));
+  if (al && d == 32) { const int nb = (int)nblocks(max_rows * 8); hipLaunchKernelGGL(k_adam_rows_v<8>, dim3(nb), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, apply_step, step_tab, b1, b2, eps, pad_row, nb, -1.f, none); }
+  else if (al && d == 64) { const int nb = (int)nblocks(max_rows * 16); hipLaunchKernelGGL(k_adam_rows_v<16>, dim3(nb), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, apply_step, step_tab, b1, b2, eps, pad_row, nb, -1.f, none); }
+  else if (al && d == 128) { const int nb = (int)nblocks(max_rows * 32); hipLaunchKernelGGL(k_adam_rows_v<32>, dim3(nb), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, apply_step, step_tab, b1, b2, eps, pad_row, nb, -1.f, none); }
   else hipLaunchKernelGGL(k_adam_rows, dim3(nblocks(max_rows * 64)), dim3(TPB), 0, s, W, g, m, v, last, rows, count, d, t_now, apply_step, step_tab, b1,
                           b2, eps, pad_row);
   CHECK_LAUNCH();
+}
+
+// the optimiser step of the lazy-exact row update AND of the dense arena as ONE launch (rows of 32 / 64 / 128 floats, 16-byte aligned tables); false: the
+// caller launches the two separately.  Same per-element arithmetic as the separate kernels (adam_elem): bit-identical results.
+bool adam_step_merged(hipStream_t s, float* W, float* g, float* m, float* v, int32_t* last, const int32_t* rows, const int32_t* count, int64_t max_rows, int d,
+                      int32_t t_now, const float* step_tab, int64_t pad_row, float* dx, float* dg, float* dm, float* dv, int64_t dn, float step, float b1,
+                      float b2, float eps, const float* norm2, float clip, float l2, int64_t z0, int zn0, int64_t z1, int zn1, float* tab_slot) {
+  const bool al = !(((uintptr_t)W | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15);
+  if (max_rows <= 0 || dn <= 0 || !al || !(d == 32 || d == 64 || d == 128)) return false;
+  const AdamDenseJob dj = dense_job(dx, dg, dm, dv, dn, step, b1, b2, eps, norm2, clip, l2, /*consume=*/1, z0, zn0, z1, zn1, tab_slot);
+  const int nd = (int)nblocks(dn);
+  if (d == 32) { const int nb = (int)nblocks(max_rows * 8); hipLaunchKernelGGL(k_adam_rows_v<8>, dim3(nb + nd), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, 1, step_tab, b1, b2, eps, pad_row, nb, step, dj); }
+  else if (d == 64) { const int nb = (int)nblocks(max_rows * 16); hipLaunchKernelGGL(k_adam_rows_v<16>, dim3(nb + nd), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, 1, step_tab, b1, b2, eps, pad_row, nb, step, dj); }
+  else { const int nb = (int)nblocks(max_rows * 32); hipLaunchKernelGGL(k_adam_rows_v<32>, dim3(nb + nd), dim3(TPB), 0, s, W, g, m, v, last, rows, count, t_now, 1, step_tab, b1, b2, eps, pad_row, nb, step, dj); }
+  CHECK_LAUNCH();
+  return true;
 }
 
 void adam_flush_all(hipStream_t s, float* W, float* m, float* v, int32_t* last, int64_t V, int d, int32_t t_now, const float* step_tab, float b1,

@@ -837,12 +837,24 @@ static void apply_update_impl(kprn_handle* h, const kprn_opt* o) {
     const double bc1 = 1.0 - pow((double)o->beta1, (double)t), bc2 = 1.0 - pow((double)o->beta2, (double)t);
     const float step = (float)((double)o->lr * sqrt(bc2) / bc1);
     h->step_tab_host[t] = step;  // host mirror (table growth); the device entry is written by the dense kernel
-    {
+    // the row update and the dense arena's update as ONE launch where the shapes allow (two latency-bound launches of the serial tail less; option
+    // "adam_merged" = "0": separately): the same arithmetic per element either way
+    bool merged = false;
+    if (h->adam_merged && !dense_ent && !fuse_union && h->step_rows_ub > 0) {
+      ProfScope ps(h, "adam_step");
+      merged = kk::adam_step_merged(s, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, rows, rcount, h->step_rows_ub, c.de, (int32_t)t, h->step_tab, pad_row,
+                                    h->dense, h->g_dense, h->s1_dense, h->s2_dense, h->n_dense, step, o->beta1, o->beta2, o->eps, norm2, o->grad_clip_norm,
+                                    l2, z0, c.dt, z1, c.dr, h->step_tab + t);
+    }
+    if (!merged) {
       ProfScope ps(h, "adam_dense");
       kk::adam_dense(s, h->dense, h->g_dense, h->s1_dense, h->s2_dense, h->n_dense, step, o->beta1, o->beta2, o->eps, norm2, o->grad_clip_norm, l2,
                      /*consume=*/1, z0, c.dt, z1, c.dr, h->step_tab + t);
     }
-    if (dense_ent) {
+    if (merged) {
+      h->lazy_pending = true;
+      pad_done = h->pad_clean;
+    } else if (dense_ent) {
       ProfScope ps(h, "adam_entity_dense");
       kk::adam_dense(s, h->We, h->g_We, h->s1_We, h->s2_We, h->n_ent, step, o->beta1, o->beta2, o->eps, norm2, o->grad_clip_norm, l2,
                      /*consume=*/0, pad_row * c.de, c.de, 0, 0, nullptr);
@@ -2456,6 +2468,9 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
     const int v = atoi(value);
     KPRN_REQUIRE(v >= 0 && v <= 2, KPRN_E_ARG, "tile_handover must be 0, 1 or 2");
     h->tile_handover = v;
+  } else if (strcmp(key, "adam_merged") == 0) {
+    // lazy-exact Adam: the entity rows' update and the dense arena's update in ONE launch ("1", default) or in two ("0": the A/B reference; bit-identical)
+    h->adam_merged = atoi(value) != 0;
   } else if (strcmp(key, "persist_layers") == 0) {
     // generic fp32 pipelines: a recurrent layer as ONE persistent launch ("1", default: where layer_f32_persist.hip takes the shape and the batch gives
     // every CU a tile; "2": at any batch size -- tests) or one launch per step ("0")

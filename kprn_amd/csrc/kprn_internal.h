@@ -231,6 +231,7 @@ struct kprn_handle {
   // tiles only (the A/B reference).  ho_fault: page-locked word a kernel sets when its wait for the other workgroup's state timed out -- every later API
   // call then fails instead of returning numbers computed from a stale slot
   int tile_handover = 2; int* ho_fault = nullptr;
+  bool adam_merged = true;        // option "adam_merged": the row update and the dense arena's update of an Adam step in one launch
   float score_split = 0.f;        // option: fraction of a scoring pass's tiles deferred to kprn_forward_batch_async_rest
   // option "score_rest_in_backward": the deferred part of a split pass is placed by the fused backward itself, right behind its last BPTT launch -- it runs on the side
   // stream beside the step's serial tail (prefix backward, gradient gather-reduce, slab reduce), whose latency-bound launches leave most CUs idle; the update joins it
@@ -320,6 +321,9 @@ void adagrad_dense(hipStream_t s, float* x, float* g, float* G, int64_t n, float
 // lazy-exact row update of the entity table
 void adam_rows(hipStream_t s, float* W, float* g, float* m, float* v, int32_t* last, const int32_t* rows, const int32_t* count, int64_t max_rows,
                int d, int32_t t_now, int apply_step, const float* step_tab, float b1, float b2, float eps, int64_t pad_row);
+bool adam_step_merged(hipStream_t s, float* W, float* g, float* m, float* v, int32_t* last, const int32_t* rows, const int32_t* count, int64_t max_rows, int d,
+                      int32_t t_now, const float* step_tab, int64_t pad_row, float* dx, float* dg, float* dm, float* dv, int64_t dn, float step, float b1,
+                      float b2, float eps, const float* norm2, float clip, float l2, int64_t z0, int zn0, int64_t z1, int zn1, float* tab_slot);
 void adam_flush_all(hipStream_t s, float* W, float* m, float* v, int32_t* last, int64_t V, int d, int32_t t_now, const float* step_tab, float b1, float b2, float eps, int64_t pad_row);
 void adagrad_rows(hipStream_t s, float* W, float* g, float* G, const int32_t* rows, const int32_t* count, int64_t max_rows, int d, float clr, int64_t pad_row);
 void zero_rows(hipStream_t s, float* W, int64_t row, int d);

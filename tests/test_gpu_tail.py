@@ -1,0 +1,62 @@
+"""-m gpu: the serial tail of a training step: launches merged into one must leave the SAME bits as the launches they replace.
+
+optim.adam sweeps the whole flat vector (MyOptimizer.lua:218); here the touched entity rows (lazy-exact replay) and the dense arena
+are updated by one launch (option "adam_merged", default on) instead of two -- the per-element arithmetic is the same device function, so parameters
+and both moments must be bit-identical to the two-launch form, at the bench's shape and at the reference's minibatch size (config.sh:38)."""
+import numpy as np
+import pytest
+
+from kprn_amd import _ffi, synth
+
+pytestmark = pytest.mark.gpu
+T = 6
+
+
+def _distinct_paths(seed, lo):
+    """one pair, one path, six DISTINCT entity rows (no gradient atomic ever sees two addends: the step's gradients are reproducible bit for bit)"""
+    idx, labels = synth.make_paths(1, 1, T, Ve=2000, seed=seed)
+    idx = idx.copy()
+    idx[0, 0, :, 1] = np.arange(lo, lo + T)
+    return idx, labels
+
+
+@pytest.mark.parametrize("de,H", [(32, 64), (64, 96), (128, 160)])
+def test_merged_adam_launch_is_bit_identical_to_two_launches(de, H):
+    """rows of 32 / 64 / 128 floats (the three vector widths of the row kernel); D = H = 64 runs the fused kernels, the others the generic pipeline"""
+    res = []
+    for merged in ("1", "0"):
+        eng = _ffi.Engine(6, 2000, 9, 16, de, 16, H, 2)
+        eng.set_option("adam_merged", merged)
+        rng = np.random.default_rng(1)
+        eng.set_flat_params((rng.random(eng.n_params) * 0.2 - 0.1).astype(np.float32))
+        opt = _ffi.make_opt(method=1, lr=5e-3)
+        b0, b1 = eng.batch(*_distinct_paths(1, 1)), eng.batch(*_distinct_paths(2, 101))
+        losses = [eng.train_step(b0, opt)]
+        losses += [eng.train_step(b1, opt) for _ in range(9)]     # b0's rows coast for nine steps: the lazy replay runs when they come back
+        eng.profile(True)
+        losses.append(eng.train_step(b0, opt))
+        fam = eng.profile_get()
+        assert ("adam_step" in fam) == (merged == "1") and ("adam_dense" in fam) == (merged == "0"), sorted(fam)
+        res.append((eng.get_flat_params(), eng.get_flat_opt_state(0), eng.get_flat_opt_state(1), losses))
+        eng.close()
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert np.array_equal(a, b)
+    assert res[0][3] == res[1][3]
+
+
+def test_merged_adam_launch_at_the_bench_shape_agrees_to_rounding():
+    """65 536-path batches: hub entities' gradients are summed with atomics in any order (run to run), so parameters are compared to rounding"""
+    batches = [synth.make_paths(8192, 4, T, Ve=50000, seed=70 + k) for k in range(2)]
+    res = []
+    for merged in ("1", "0"):
+        eng = _ffi.Engine(6, 50000, 9, 16, 32, 16, 64, 2)
+        eng.set_option("adam_merged", merged)
+        rng = np.random.default_rng(1)
+        eng.set_flat_params((rng.random(eng.n_params) * 0.2 - 0.1).astype(np.float32))
+        opt = _ffi.make_opt(method=1, lr=1e-3)
+        bs = [eng.batch(i, l) for i, l in batches]
+        for k in range(5):
+            eng.train_step(bs[k % 2], opt)
+        res.append(eng.get_flat_params().astype(np.float64))
+        eng.close()
+    assert float(np.max(np.abs(res[0] - res[1]))) < 2e-6
