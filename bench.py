@@ -55,8 +55,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--paths-per-step", type=int, default=65536, help="paths per rank per step")
-    ap.add_argument("--dims", default="A", choices=["A", "B", "shipped", "C4"],
+    ap.add_argument("--dims", default="A", choices=["A", "B", "shipped", "gru", "C4"],
                     help="A: D=H=64 (16/32/16); B: 64/64/64 -> D=H=192; shipped: run_scripts/config.sh as shipped (rnn, 50/100/50 -> D=200, H=250, L=1); "
+                         "gru: config.sh's sizes with -rnnType gru (OneModel.lua:237-238); "
                          "C4: BASELINE configs[3] -- 20 M entities, 100 relations, d = 128 -> D = H = 384, L = 1, bf16 storage + bf16 MFMA "
                          "(--c4-fp32: the same shape in fp32)")
     ap.add_argument("--c4-fp32", action="store_true")
@@ -107,6 +108,9 @@ def parse():
                     help="every path has T real steps (no left padding -> no identical-prefix skipping) and the batch is a whole number of 256 x 64-path "
                          "tiles: every workgroup of the fused kernels draws the same number of tile-steps.  The dominant kernel's roofline.frac on this "
                          "line is the kernel's own ceiling, free of the 18-vs-20 tile-step quantisation of the 4 / 6-step mix (DESIGN.md section 7-1)")
+    ap.add_argument("--stream-total-paths", type=int, default=0,
+                    help="after the headline region: this many paths in all through the STREAMING feed (every step's batch arrives from page-locked host memory "
+                         "through the slot ring), reported under \"streaming_total\" with its ratio to the resident rate -- BASELINE configs[3] names 50 M paths")
     ap.add_argument("--no-strong-1m", action="store_true",
                     help="data-parallel runs without --total-paths also time the north_star's strong-scaling experiment (1 000 000 paths split over ranks "
                          "and steps, and the same total on rank 0 alone) and report it under \"strong_1M\"; this flag skips it")
@@ -270,7 +274,7 @@ def dims_of(a):
         return 16, 32, 16, 64
     if a.dims == "C4":
         return 128, 128, 128, 384
-    if a.dims == "shipped":
+    if a.dims in ("shipped", "gru"):
         return 50, 100, 50, 250
     return 64, 64, 64, 192
 
@@ -526,7 +530,8 @@ def other_configs():
     runs = [("C5_inference_T3to7", ["--workload", "c5", "--steps", "1000", "--warmup", "10"]),
             ("dimsB_D192_H192_L2", ["--dims", "B", "--steps", "18", "--warmup", "2"]),
             ("shipped_rnn_D200_H250", ["--dims", "shipped", "--steps", "72", "--warmup", "3"]),
-            ("C4_20M_entities_d128_bf16", ["--dims", "C4", "--steps", "75", "--warmup", "3"])]
+            ("gru_D200_H250", ["--dims", "gru", "--steps", "30", "--warmup", "3"]),
+            ("C4_20M_entities_d128_bf16", ["--dims", "C4", "--steps", "75", "--warmup", "3", "--stream-total-paths", "50000000"])]
     out = {}
     for name, flags in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-alt", "--no-extra-regions", "--no-other-configs", "--no-batch-sweep", "--batch-feed", "resident"] + flags
@@ -541,6 +546,8 @@ def other_configs():
                          "mfma_frac_end_to_end_executed": d.get("mfma_frac_end_to_end_executed"),   # (issued MFMA flops only: the small-table identity removes products)
                          "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
                          "wall_s": round(time.perf_counter() - t0, 1), "flags": " ".join(flags)}
+            if d.get("streaming_total"):   # configs[3] at the size the config names: 50 M paths streamed from host memory
+                out[name]["streaming_50M"] = {k: d["streaming_total"].get(k) for k in ("value", "unit", "ms_per_step", "steps", "total_paths", "seconds", "ratio_to_resident")}
             oth = rf.get("other_timed_families")
             if oth:
                 out[name]["roofline"]["other_timed_families"] = {k: {q: v.get(q) for q in ("bound", "frac", "avg_launch_ms")} for k, v in oth.items() if v}
@@ -678,18 +685,19 @@ def main():
     from kprn_amd import _ffi, synth, dp
     dt_, de_, dr_, H = dims_of(a)
     shipped = a.dims == "shipped"
+    gru = a.dims == "gru"
     c4 = a.dims == "C4"
     if c4 and a.compute_dtype == 0 and not a.c4_fp32:
         a.compute_dtype = 1
     if a.entities <= 0:
         a.entities = 20_000_000 if c4 else 2851220
-    D, L, T, C, F, nT = dt_ + de_ + dr_, (1 if (shipped or c4) else a.layers), a.T, 46, 3, 1
-    G = 1 if shipped else 4
+    D, L, T, C, F, nT = dt_ + de_ + dr_, (1 if (shipped or c4 or gru) else a.layers), a.T, 46, 3, 1
+    G = 1 if shipped else (3 if gru else 4)   # rows of recurrent weights per hidden unit (gru: r, z and the candidate)
     Vt, Ve, Vr = 6, a.entities, (100 if c4 else 9)
     stream = torch.cuda.current_stream().cuda_stream
     eng = _ffi.Engine(Vt, Ve, Vr, dt_, de_, dr_, H, L, F=F, num_types=nT, C_=C, reducer=2, device_id=local_rank,
                       rank=rank, world=world, param_init=0.1, seed=12345, stream=stream,
-                      rnn_type=1 if shipped else 0, use_relu=1, rnn_init=1 if shipped else 0, compute_dtype=a.compute_dtype)
+                      rnn_type=1 if shipped else (2 if gru else 0), use_relu=1, rnn_init=1 if shipped else 0, compute_dtype=a.compute_dtype)
     eng.set_option("impl", a.impl)
     eng.set_option("score_overlap", "0" if a.no_score_overlap else "1")
     eng.set_option("feed_build", a.feed_build)
@@ -780,7 +788,7 @@ def main():
     NS = AHEAD + 1
     # slots sized once for the largest bucket (BatcherFileList.lua:53-60 preallocates its GPU tensors the same way)
     slots = ([_ffi.Batch.reserve(eng, max(b.B for b in batches), max(paths_of), T, F) for _ in range(NS)]
-             if a.batch_feed != "resident" else [None] * NS)
+             if (a.batch_feed != "resident" or a.stream_total_paths > 0) else [None] * NS)
     fed_upto = [-1]
     host_t = {"feed": [], "run": []}   # host-side seconds per step spent queueing the feed / the step (KPRN_BENCH_HOST_TIMING=1 prints them)
     def step_streaming(i):
@@ -897,6 +905,17 @@ def main():
                                    what="every step's batch arrives from page-locked host memory: id validation + identical-prefix plan + occurrence "
                                         "index derived per batch (host worker threads, or kernels on a side stream with --feed-build device) and "
                                         "uploaded under the steps in flight")
+    if world == 1 and not a.force_dp and a.stream_total_paths > 0 and not main_streaming:
+        # a path set of the size the config names, streamed: ceil(total / paths per step) steps, every batch fed from host memory under the steps in flight
+        k_t = int(np.ceil(a.stream_total_paths / float(np.mean(paths_of))))
+        for i in range(12):
+            step_streaming(i)
+        eng.sync()
+        el, n = timed_region(step_streaming, 12, k_t)
+        extras["streaming_total"] = dict(region_line(el, n, k_t), total_paths=int(n), seconds=round(el, 3), ratio_to_resident=round((n / el) / value, 4),
+                                         feed_build=a.feed_build, feed_ahead=a.feed_ahead,
+                                         what="the whole path set streamed once: every step's batch arrives from page-locked host memory (validation, plan, "
+                                              "occurrence index derived per batch on host worker threads, one upload per batch under the steps in flight)")
     if plain and not main_streaming:
         # enough steps for a >= 0.3 s timed region
         k_long = int(min(4000, max(a.steps, np.ceil(0.35 / max(elapsed / a.steps, 1e-6)))))
@@ -1132,7 +1151,7 @@ def main():
         # flops (what the reference computes); `..._executed` only the MFMA work the engine really issues.
         saved = 0.0
         gh = G * H
-        generic_tabs = (shipped or a.dims == "B" or a.impl == "generic" or (c4 and a.compute_dtype != 1)) and not a.score_only
+        generic_tabs = (shipped or a.dims == "B" or a.impl == "generic" or (c4 and a.compute_dtype != 1)) and not a.score_only and not gru
         st_on = not any(o.replace(" ", "") in ("small_tables=0", "bf16_small_tables=0") for o in a.set_option)
         if st_on and not a.score_only and (c4 and a.compute_dtype == 1 or generic_tabs) and nT == 1:
             ns = 128 if (c4 and a.compute_dtype == 1) else ((Vr + Vt + 3) // 4) * 4
@@ -1143,6 +1162,9 @@ def main():
         exec_tflops_issued = (exec_flops - saved) * world / elapsed / 1e12
         wl = (f"C2 KKBOX-MI synthetic: T={T}, D=H={H} ({dt_}/{de_}/{dr_}), L={L} FastLSTM, fp32, Ve={Ve}, "
               f"C=46, LSE pool, Adam; scoring pass + train step per batch")
+        if gru:
+            wl = (f"config.sh's sizes with -rnnType gru (OneModel.lua:237-238), synthetic KKBox-shaped paths: T={T}, nn.GRU, D={D} ({dt_}/{de_}/{dr_}), H={H}, L=1, "
+                  f"fp32, Ve={Ve}, C=46, LSE pool, Adam; scoring pass + train step per batch")
         if shipped:
             wl = (f"run_scripts/config.sh as shipped, synthetic KKBox-shaped paths: T={T}, rnn (ReLU, MaskZero, identity init), "
                   f"D={D} ({dt_}/{de_}/{dr_}), H={H}, L=1, fp32, Ve={Ve}, C=46, LSE pool, Adam; scoring pass + train step per batch")
@@ -1180,7 +1202,7 @@ def main():
                                               "`mfma_frac_end_to_end_executed` the issued ones"} if saved > 0 else None),
             "final_loss": round(loss, 6),
             "roofline": roofline, "cpu_baseline": cpu,
-            "streaming": extras.get("streaming"), "long_run": extras.get("long_run"), "batch_sweep": extras.get("batch_sweep"),
+            "streaming": extras.get("streaming"), "streaming_total": extras.get("streaming_total"), "long_run": extras.get("long_run"), "batch_sweep": extras.get("batch_sweep"),
             "dropin_minibatch": extras.get("dropin_minibatch"),
             "other_configs": other,
             "value_no_prefix_plan": (extras.get("no_prefix_plan") or {}).get("value"), "no_prefix_plan": extras.get("no_prefix_plan"),

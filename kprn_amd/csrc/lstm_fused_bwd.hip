@@ -394,13 +394,15 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       TPROBE(5)  // end barrier
     };
     int tt_sw = early ? Te - ho.d : -1;   // the early piece's last step
+    int tt_pub = -1;                       // ... and the step behind which its state is published (below)
     for (int tt = tt_hi; tt > 0; --tt) {
       step(std::true_type{}, tt);
+      if (__builtin_expect(tt == tt_pub, 0)) { ho_publish(a.ho, ho.slot); tt_pub = -1; }
       if (__builtin_expect(tt == tt_sw, 0)) {   // (uniform, once per launch at most) the pair's tile goes on in its heavy workgroup; this one turns to its own first tile
 #pragma unroll
         for (int m = 0; m < NMT; ++m) { ho_store4(ho_slot + m * 1024, dh[m]); ho_store4(ho_slot + (NMT + m) * 1024, dc[m]); }
-        // (the flag follows at this tile's end: by then the stores have long been acknowledged, and the pair's heavy workgroup asks for them a
-        // few tiles from now -- publishing here would drain every load in flight first)
+        // (the flag follows one recurrent step later: by then the stores have been acknowledged -- publishing here would drain every load in
+        // flight first -- and the pair's heavy workgroup, which runs at least one other tile first, asks for them several steps from now)
         retarget(own_tile);
         init_state();
         tile_prologue(Te - 1);
@@ -409,10 +411,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         for (int nt = 0; nt < 4; ++nt) load_B(nt, 0, Te - 1, Te > 1);
         tt = Te;   // (the loop goes on with the own tile's step Te - 1)
         tt_sw = -1;
+        tt_pub = Te - 1;   // (Te >= 2: the own tile has a recurrent step)
       }
     }
     step(std::false_type{}, 0);
-    if (__builtin_expect(early, 0)) ho_publish(a.ho, ho.slot);   // (uniform) the state stored in front of this tile's recurrent steps
     if (k0 > 0) {
       // ... and dc_{k0-1} = sum over rows of the dc this step hands down
       float cs = 0.f;

@@ -208,10 +208,11 @@ __host__ __device__ __forceinline__ int ho_partner(int mode, int G, int bx) {
 }
 // what a pair with these loads (half steps) does; steps: executed steps of the heavy one's first tile; keep: steps of that tile that must stay in front of
 // the moved ones (forward: 2 -- the ids of a workgroup's next tile are staged under a tile's first slot and read under its second; backward: 1)
-__host__ __device__ __forceinline__ HoPlan ho_decide(int bx, int px, int mine, int theirs, int steps, int keep) {
+// heavy_tiles: tiles of the heavy workgroup -- with a single one it has nothing to run while the other workgroup works on the piece it waits for
+__host__ __device__ __forceinline__ HoPlan ho_decide(int bx, int px, int mine, int theirs, int steps, int keep, int64_t heavy_tiles) {
   HoPlan p{0, 0, -1, 0};
   const int diff = mine > theirs ? mine - theirs : theirs - mine;
-  if (px == bx || diff < 4) return p;
+  if (px == bx || diff < 4 || heavy_tiles < 2) return p;
   p.role = mine > theirs ? 1 : 2;
   p.tile = mine > theirs ? bx : px;
   p.slot = (int)p.tile;
@@ -232,7 +233,7 @@ inline HoPlan ho_plan_host(bool on, int mode, int G, int bx, int64_t n_tiles, in
   if (load) *load = mine;
   if (!on || (n_tiles + G - 1) / G > 32) return HoPlan{0, 0, -1, 0};
   const int64_t heavy = mine > theirs ? bx : px;
-  return ho_decide(bx, px, mine, theirs, T - tile_k0(heavy), keep);
+  return ho_decide(bx, px, mine, theirs, T - tile_k0(heavy), keep, (n_tiles - 1 - heavy) / G + 1);
 }
 // device form: ONE round trip -- lane i < 32 of every wave reads the prefix length of this workgroup's i-th tile, lane 32 + i of the pair's, and the two sums
 // are wave reductions.  (Read tile after tile it was eight dependent loads in front of every workgroup's first tile: 4 us, 1.5 % of the launch.)
@@ -248,7 +249,7 @@ __device__ __forceinline__ HoPlan ho_plan(const HoArgs& ho, const int32_t* tile_
   for (int sh = 1; sh < 32; sh <<= 1) cost += __shfl_xor(cost, sh, 64);
   const int mine = __builtin_amdgcn_readlane(cost, 0), theirs = __builtin_amdgcn_readlane(cost, 32);
   const int k_mine = __builtin_amdgcn_readlane(k, 0), k_theirs = __builtin_amdgcn_readlane(k, 32);
-  return ho_decide(bx, px, mine, theirs, T - (mine > theirs ? k_mine : k_theirs), keep);
+  return ho_decide(bx, px, mine, theirs, T - (mine > theirs ? k_mine : k_theirs), keep, (n_tiles - 1 - (mine > theirs ? bx : px)) / G + 1);
 }
 
 // slot traffic at agent scope (sc1: written through to / read from where the eight XCDs' L2s agree), 16 bytes per call
