@@ -7,6 +7,7 @@ FETCH_SIZE tallies 128-B requests at 64 B, so wide coalesced reads are DOUBLED h
 ("fetch_bytes_corrected"); WRITE_SIZE is uncalibrated and reported as-is (x1024).
 """
 import csv
+import re
 import json
 import os
 import sys
@@ -41,8 +42,8 @@ def short(name):
         return ("rnn" if "k_bptt<1" in name else "lstm") + "_layer_bwd"
     if "k_lstm_fwd_mc" in name:
         return "lstm_mc_fwd_train" if "true>" in name else "lstm_mc_fwd"
-    if "k_lstm_fwd" in name:
-        return "lstm_fused_fwd_train" if ", true>" in name.replace(" ", " ") else "lstm_fused_fwd"
+    if "k_lstm_fwd" in name:   # k_lstm_fwd<L, SAVE, NMT>: the training (SAVE) and the scoring launch are separate families
+        return "lstm_fused_fwd_train" if re.search(r"k_lstm_fwd<\d+, (true|\(bool\)1)", name) else "lstm_fused_fwd"
     if "k_lstm_bwd" in name:
         return "lstm_fused_bwd"
     n = name.split("(")[0]
