@@ -672,7 +672,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   }
   if (!s->part) HIP_TRY(kprn_dev_malloc((void**)&s->part, (size_t)2 * s->num_cu * PART * sizeof(float)));  // one slab set per layer
   static const bool want_timing = KPRN_DEV_ENV("KPRN_TIMING") != nullptr;
-  if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
+  if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 12 * sizeof(unsigned long long)));
   if (s->wt_dirty) {  // (normally done already: the transposes ride in the loss-stage launch, transpose_job())
     ProfScope ps(h, "weight_transpose");
     kk::TransposeJob tj;

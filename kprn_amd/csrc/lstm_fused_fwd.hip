@@ -142,33 +142,52 @@ __device__ __forceinline__ void cell_all(const f32x4 (&pacc)[4], float (&pc)[4],
 }
 
 // nn.Linear(H, C) on the tile's h_T (LDS) -> S[n][0..C)
+// Round 6, per-phase cycle counters: this was 10-11 k cycles per tile (4-5 % of the launch) for 64 MFMAs -- a chain of round trips, not arithmetic: the weight
+// fragments and every row's output position (perm[n]) were loaded under conditions (hipcc puts such a load AND its wait inside a branch: DESIGN.md 3.4c), the
+// positions one by one in front of their stores, and each m-tile's 16 MFMAs chained on one accumulator.  Now: every load is unconditional from a clamped address
+// and issued up front (positions first: they are needed last), the four m-tiles' chains are interleaved.
 template <int NMT>
 __device__ __forceinline__ void head_tile(const FwdArgs& a, const float* hbuf, int64_t tile, int j, int lane) {
   const int ntiles = (a.C + 15) >> 4;
   const int arow = lane & 15, ag = lane >> 4;
+  int pr[NMT][4];   // output row of the tile's rows 16 mt + 4 ag + r
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t n = tile * (16 * NMT) + mt * 16 + ag * 4 + r;
+      const int64_t nc = n < a.N ? n : a.N - 1;
+      pr[mt][r] = a.perm ? a.perm[nc] : (int)nc;   // (uniform branch; the load itself is unconditional)
+    }
   for (int nt = j; nt < ntiles; nt += 4) {
     const int col = nt * 16 + arow;
     const bool cv = col < a.C;
-    const float b = cv ? a.bout[col] : 0.f;
+    const int colc = cv ? col : a.C - 1;   // (columns past C compute a copy of the last one and are not stored)
+    const float b = a.bout[colc];
     f32x4 w4[4];
 #pragma unroll
-    for (int S = 0; S < 4; ++S) w4[S] = cv ? *(const f32x4*)(a.Wout + (int64_t)col * DH + S * 16 + ag * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int S = 0; S < 4; ++S) w4[S] = *(const f32x4*)(a.Wout + (int64_t)colc * DH + S * 16 + ag * 4);
+    f32x4 acc[NMT];
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) {
-      f32x4 acc = f32x4{b, b, b, b};
+    for (int mt = 0; mt < NMT; ++mt) acc[mt] = f32x4{b, b, b, b};
 #pragma unroll
-      for (int S = 0; S < 4; ++S) {
-        const f32x4 a4 = *(const f32x4*)(hbuf + (mt * 16 + arow) * LDA + S * 16 + ag * 4);
+    for (int S = 0; S < 4; ++S) {
+      f32x4 a4[NMT];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], w4[S][jj], acc, 0, 0, 0);
-      }
-      if (cv) {
+      for (int mt = 0; mt < NMT; ++mt) a4[mt] = *(const f32x4*)(hbuf + (mt * 16 + arow) * LDA + S * 16 + ag * 4);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][jj], w4[S][jj], acc[mt], 0, 0, 0);
+    }
+    if (cv) {
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t n = tile * (16 * NMT) + mt * 16 + ag * 4 + r;
-          if (n < a.N) a.S[(a.perm ? (int64_t)a.perm[n] : n) * a.C + col] = acc[r];
+          if (n < a.N) a.S[(int64_t)pr[mt][r] * a.C + col] = acc[mt][r];
         }
-      }
     }
   }
 }
@@ -191,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // hidden tile owned by this wave
   const int arow = lane & 15, ag = lane >> 4;
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = (KPRN_PROBES_ON && a.timing) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long tstart = tlast;
 #define FPROBE(slot_)                                              \
@@ -356,8 +375,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) c[L - 1][NMT - 1][r] = cinit[L - 1];
           }
+          if (cross) { FPROBE(8) }   // (measurement build) first slot: prefix lookup + the pending cell of the tile before
           lds_barrier();
+          if (cross) { FPROBE(9) }   // ... barrier
           if (cross && has_prev) head_tile<NMT>(a, hbuf(L - 1, q_par), p_tile, j, lane);
+          if (cross) { FPROBE(10) }  // ... the head of the tile before
           apre = *(const f32x4*)(in_base);
           half_unit<SAVE, false, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], pout, sv);
           if (cls > 0) {  // (uniform)
@@ -430,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   FPROBE(5)  // drain
   if (KPRN_PROBES_ON && a.timing && threadIdx.x == 0) {
     tacc[7] = __builtin_amdgcn_s_memtime() - tstart;
-    for (int k = 0; k < 8; ++k) a.timing[(int64_t)blockIdx.x * 8 + k] = tacc[k];
+    for (int k = 0; k < 12; ++k) a.timing[(int64_t)blockIdx.x * 12 + k] = tacc[k];
   }
 #undef FPROBE
 }
@@ -553,7 +575,7 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin,
   const int cus = (!save && h->reserve_cus > 0 && !ignore_reserve) ? std::max(1, s->num_cu - h->reserve_cus) : s->num_cu;
   const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)cus);
   static const bool want_timing = KPRN_DEV_ENV("KPRN_TIMING") != nullptr;
-  if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 8 * sizeof(unsigned long long)));
+  if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 12 * sizeof(unsigned long long)));
   a.timing = s->timing;
   ProfScope ps(h, save ? "lstm_fused_fwd_train" : "lstm_fused_fwd");
   if (c.L == 1) { if (save) launch_fwd<1, true>(h, a, grid); else launch_fwd<1, false>(h, a, grid); }
@@ -561,12 +583,12 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin,
   else { if (save) launch_fwd<2, true>(h, a, grid); else launch_fwd<2, false>(h, a, grid); }
   if (s->timing) {
     HIP_TRY(hipStreamSynchronize(h->stream));
-    std::vector<unsigned long long> tb((size_t)grid * 8);
+    std::vector<unsigned long long> tb((size_t)grid * 12);
     HIP_TRY(hipMemcpy(tb.data(), s->timing, tb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum[8] = {0};
-    for (int g = 0; g < grid; ++g) for (int k = 0; k < 8; ++k) sum[k] += (double)tb[(size_t)g * 8 + k];
-    fprintf(stderr, "[kprn timing] fwd save=%d N=%lld grid=%d avg cycles/WG: prologue %.0f ids+gather-issue %.0f first-slots %.0f rec-slots %.0f gather-land %.0f drain %.0f total %.0f\n",
-            (int)save, (long long)N, grid, sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[7] / grid);
+    double sum[12] = {0};
+    for (int g = 0; g < grid; ++g) for (int k = 0; k < 12; ++k) sum[k] += (double)tb[(size_t)g * 12 + k];
+    fprintf(stderr, "[kprn timing] fwd save=%d N=%lld grid=%d avg cycles/WG: prologue %.0f ids+gather-issue %.0f first-slots %.0f (of which, before their units: prefix + pending cell %.0f, barrier %.0f, head %.0f) rec-slots %.0f gather-land %.0f drain %.0f total %.0f\n",
+            (int)save, (long long)N, grid, sum[0] / grid, sum[1] / grid, (sum[2] + sum[8] + sum[9] + sum[10]) / grid, sum[8] / grid, sum[9] / grid, sum[10] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[7] / grid);
   }
 }
 
