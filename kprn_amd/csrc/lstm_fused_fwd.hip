@@ -72,13 +72,19 @@ __device__ __forceinline__ void cell_step(CellRegs& x, const f32x4 (&acc)[4], fl
     const float hh = x.o * x.t;
     out_row[R * LDA] = hh;
     if (SAVE) {  // backward-ready factors (lstm_fused_common.h, NPL)
-      sv[0][R] = x.ig * (1.0f - x.i);
-      sv[1][R] = x.i * (1.0f - x.g * x.g);
-      sv[2][R] = x.cp * x.f * (1.0f - x.f);
-      sv[3][R] = hh * (1.0f - x.o);
-      sv[4][R] = x.o * (1.0f - x.t * x.t);
+#ifdef KPRN_EXP_NOFACT
+      sv[0][R] = x.i; sv[1][R] = x.g; sv[2][R] = x.cp; sv[3][R] = x.o; sv[4][R] = x.t; sv[5][R] = x.f; sv[6][R] = hh;
+#else
+      // each factor as ONE fused multiply-add (six VALU instructions per element where the products of (1 - x) took twelve)
+      const float cf = x.cp * x.f;
+      sv[0][R] = __builtin_fmaf(-x.ig, x.i, x.ig);   // i g (1 - i)
+      sv[1][R] = __builtin_fmaf(-x.ig, x.g, x.i);    // i (1 - g^2)
+      sv[2][R] = __builtin_fmaf(-cf, x.f, cf);       // c_{t-1} f (1 - f)
+      sv[3][R] = __builtin_fmaf(-hh, x.o, hh);       // h (1 - o)        (h = o tanh c)
+      sv[4][R] = __builtin_fmaf(-hh, x.t, x.o);      // o (1 - tanh^2 c)
       sv[5][R] = x.f;
       sv[6][R] = hh;
+#endif
     }
   }
 }
@@ -101,9 +107,14 @@ __device__ __forceinline__ void cell_q(const f32x4 (&acc)[4], float (&cst)[4], f
 // requested half way through (a read placed first would wait for the previous group's last MFMA to pick up
 // the register it overwrites).  CELL: one cell_step of the previous unit behind every MFMA; the order is
 // pinned with sched_barrier (the asm MFMAs carry no latency the scheduler could reason about).
-template <bool SAVE, bool CELL, bool BIAS, bool PF, int S>
+// ST (training, a half without a cell): the 7 planes of the unit whose cell ran in the half before leave here, ONE store per 8 MFMAs.  A store holds its wave
+// for the 16 cycles its 1 KiB takes on the CU's 64 B/clk store path, and the four waves -- in step behind a barrier -- used to issue the 7 back to back at the
+// same moment: 4 x 7 x 16 cycles during which every wave stood still for most of the time (round 6, knock-out builds: the stores were 7.4 % of the launch).
+// Spread out, the first one after a barrier still collides and leaves the waves 16 cycles apart; none of the later ones does.
+template <bool SAVE, bool CELL, bool BIAS, bool PF, int S, bool ST = false>
 __device__ __forceinline__ void k_group(const f32x4 a4, f32x4& apre, const float* next_addr, const f32x4 (&w)[4][4], const f32x4 (&bias4)[4],
-                                        f32x4 (&acc)[4], CellRegs& x, const f32x4 (&pacc)[4], float (&pc)[4], float* pout_row, f32x4 (&sv)[NPL]) {
+                                        f32x4 (&acc)[4], CellRegs& x, const f32x4 (&pacc)[4], float (&pc)[4], float* pout_row, f32x4 (&sv)[NPL],
+                                        float* fb = nullptr) {
 #define KPRN_G1(K)                                                                                  \
   {                                                                                                 \
     constexpr int jj = (K) >> 2, q = (K) & 3;                                                       \
@@ -111,6 +122,12 @@ __device__ __forceinline__ void k_group(const f32x4 a4, f32x4& apre, const float
     else KPRN_MFMA(acc[q], a4[jj], w[q][S][jj]);                                                    \
     if (PF && (K) == 7) apre = *(const f32x4*)(next_addr);                                          \
     if (CELL) { cell_step<SAVE, S, (K)>(x, pacc, pc, pout_row, sv); __builtin_amdgcn_sched_barrier(0); } \
+    if (ST && ((K) == 3 || (K) == 11) && 2 * S + ((K) == 11) < NPL) {                               \
+      constexpr int pk = 2 * S + ((K) == 11);                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+      *(f32x4*)(fb + pk * 256) = sv[pk < NPL ? pk : 0];                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+    }                                                                                               \
   }
   KPRN_G1(0) KPRN_G1(1) KPRN_G1(2) KPRN_G1(3) KPRN_G1(4) KPRN_G1(5) KPRN_G1(6) KPRN_G1(7)
   KPRN_G1(8) KPRN_G1(9) KPRN_G1(10) KPRN_G1(11) KPRN_G1(12) KPRN_G1(13) KPRN_G1(14) KPRN_G1(15)
@@ -119,18 +136,20 @@ __device__ __forceinline__ void k_group(const f32x4 a4, f32x4& apre, const float
 
 // Half of a unit's 4-gate GEMM: 4 k-groups over one LDS tile (the recurrent h_{t-1} tile or the step-input
 // tile).  apre always holds the A fragment of the group about to run.
-template <bool SAVE, bool CELL, bool BIAS, bool PF>
+template <bool SAVE, bool CELL, bool BIAS, bool PF, bool ST = false>
 __device__ __forceinline__ void half_unit(const float* abase, const f32x4 (&w)[4][4], const f32x4 (&bias4)[4], f32x4 (&acc)[4], f32x4& apre,
-                                          const float* next_abase, const f32x4 (&pacc)[4], float (&pc)[4], float* pout_row, f32x4 (&sv)[NPL]) {
+                                          const float* next_abase, const f32x4 (&pacc)[4], float (&pc)[4], float* pout_row, f32x4 (&sv)[NPL],
+                                          float* fb = nullptr) {
+  static_assert(!(ST && CELL), "the planes leave in the half behind the one that forms them");
   CellRegs x;
   f32x4 a4 = apre;
-  k_group<SAVE, CELL, BIAS, true, 0>(a4, apre, abase + 16, w, bias4, acc, x, pacc, pc, pout_row, sv);
+  k_group<SAVE, CELL, BIAS, true, 0, ST>(a4, apre, abase + 16, w, bias4, acc, x, pacc, pc, pout_row, sv, fb);
   a4 = apre;
-  k_group<SAVE, CELL, false, true, 1>(a4, apre, abase + 32, w, bias4, acc, x, pacc, pc, pout_row, sv);
+  k_group<SAVE, CELL, false, true, 1, ST>(a4, apre, abase + 32, w, bias4, acc, x, pacc, pc, pout_row, sv, fb);
   a4 = apre;
-  k_group<SAVE, CELL, false, true, 2>(a4, apre, abase + 48, w, bias4, acc, x, pacc, pc, pout_row, sv);
+  k_group<SAVE, CELL, false, true, 2, ST>(a4, apre, abase + 48, w, bias4, acc, x, pacc, pc, pout_row, sv, fb);
   a4 = apre;
-  k_group<SAVE, CELL, false, PF, 3>(a4, apre, next_abase, w, bias4, acc, x, pacc, pc, pout_row, sv);
+  k_group<SAVE, CELL, false, PF, 3, ST>(a4, apre, next_abase, w, bias4, acc, x, pacc, pc, pout_row, sv, fb);
 }
 
 template <bool SAVE>
@@ -288,11 +307,19 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   const int a_off = arow * LDA + ag * 4;                   // this lane's A-fragment offset inside a 16-row block
   const int o_off = (ag * 4) * LDA + j * 16 + arow;        // this lane's cell-output offset inside a 16-row block
 
+  auto save_addr = [&](int64_t p_tile, int p_t, int pl, int pm) -> float* {
+    return a.save_frag + (p_tile * NMT + pm) * frag_mt_stride + ((int64_t)(p_t * L + pl) * 4 + j) * frag_unit + lane * 4;
+  };
   auto save_unit = [&](int64_t p_tile, int p_t, int pl, int pm) {
     if (!SAVE) return;
-    float* fb = a.save_frag + (p_tile * NMT + pm) * frag_mt_stride + ((int64_t)(p_t * L + pl) * 4 + j) * frag_unit + lane * 4;
+    float* fb = save_addr(p_tile, p_t, pl, pm);
 #pragma unroll
+#ifdef KPRN_EXP_NOSTORE
+    for (int k = 0; k < NPL; ++k) asm volatile("" ::"v"(sv[k]));
+    if (a.T == 77) *(f32x4*)(fb) = sv[0];
+#else
     for (int k = 0; k < NPL; ++k) *(f32x4*)(fb + k * 256) = sv[k];
+#endif
   };
   // FIRST: the tile's first executed step.  There is no recurrent half: the tile's common prefix state enters as one
   // extra k-slot per gate (A = 1 in k-slot 0, B = (W_o2g h_prefix)[col] in k-slot 0: adds that vector to every row) and
@@ -358,12 +385,18 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
             apre = *(const f32x4*)(hp_buf + a_off);
           }
           half_unit<SAVE, true, true, true>(hp_buf + mt * 16 * LDA + a_off, wo[l], bias4[l], acc, apre, in_base, pacc, c[pl][pm], pout, sv);
-          save_unit(q_tile, q_t, pl, pm);
           if (mt == 0) {
             lds_barrier();
             apre = *(const f32x4*)(in_base);
           }
+          // (training: the planes of the unit whose cell just ran leave under this half, one store per 8 MFMAs)
+#ifdef KPRN_EXP_BURST
+          save_unit(q_tile, q_t, pl, pm);
           half_unit<SAVE, false, false, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], pout, sv);
+#else
+          half_unit<SAVE, false, false, true, SAVE>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], pout, sv,
+                                                    SAVE ? save_addr(q_tile, q_t, pl, pm) : nullptr);
+#endif
         } else if (mt == 0) {
           if (!cross || has_prev) {
             KPRN_MFMA_DRAIN();  // last MFMAs of the previous unit -> VALU reads
