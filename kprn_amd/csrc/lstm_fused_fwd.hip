@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
         asm volatile("" : "+a"(wi[l][q][S]));
         asm volatile("" : "+a"(wo[l][q][S]));
       }
+  FPROBE(6)  // (measurement build) the weights
   float c[L][NMT][4];
 #pragma unroll
   for (int l = 0; l < L; ++l)
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
     for (int c = L * PFB + threadIdx.x; c < n_cls * L * PFB; c += NT) ((float*)pft)[c] = a.pfb[c];
   }
   lds_barrier();
+  FPROBE(11)  // ... first ids + prefix table
   int k0 = tile_k0(blockIdx.x);  // the tile runs steps k0 .. T-1 (k0 <= T-2)
   gather_load<NT, MTR>(a, gsrc, blockIdx.x, k0, idbuf(0), gv);
   gather_store<NT, MTR>(xbuf(0), gv);
@@ -620,8 +622,8 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin,
     HIP_TRY(hipMemcpy(tb.data(), s->timing, tb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     double sum[12] = {0};
     for (int g = 0; g < grid; ++g) for (int k = 0; k < 12; ++k) sum[k] += (double)tb[(size_t)g * 12 + k];
-    fprintf(stderr, "[kprn timing] fwd save=%d N=%lld grid=%d avg cycles/WG: prologue %.0f ids+gather-issue %.0f first-slots %.0f (of which, before their units: prefix + pending cell %.0f, barrier %.0f, head %.0f) rec-slots %.0f gather-land %.0f drain %.0f total %.0f\n",
-            (int)save, (long long)N, grid, sum[0] / grid, sum[1] / grid, (sum[2] + sum[8] + sum[9] + sum[10]) / grid, sum[8] / grid, sum[9] / grid, sum[10] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[7] / grid);
+    fprintf(stderr, "[kprn timing] fwd save=%d N=%lld grid=%d avg cycles/WG: prologue %.0f (weights %.0f, first ids + prefix table %.0f, first gather %.0f) ids+gather-issue %.0f first-slots %.0f (of which, before their units: prefix + pending cell %.0f, barrier %.0f, head %.0f) rec-slots %.0f gather-land %.0f drain %.0f total %.0f\n",
+            (int)save, (long long)N, grid, (sum[0] + sum[6] + sum[11]) / grid, sum[6] / grid, sum[11] / grid, sum[0] / grid, sum[1] / grid, (sum[2] + sum[8] + sum[9] + sum[10]) / grid, sum[8] / grid, sum[9] / grid, sum[10] / grid, sum[3] / grid, sum[4] / grid, sum[5] / grid, sum[7] / grid);
   }
 }
 
