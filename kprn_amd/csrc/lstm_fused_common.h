@@ -133,6 +133,56 @@ __device__ __forceinline__ void gather_load(const Args& a, const GatherSrc& g, i
   }
 }
 
+// ---- the same through LDS-DMA (round 6: the fused forward) ------------------------------------------------
+// ids_stage loads a tile's ids into registers, converts and writes them to LDS: a load round trip in front of every tile's first slot (2.5 k cycles a
+// tile, per-phase counters) and a division by T per entry.  Here the ids go global -> LDS without passing a register (global_load_lds_dword: lane l's
+// dword lands at dst + 4 l), RAW (1-based: the gather's table base is shifted by one row instead), in three planes [kind][t][row] -- a wave instruction
+// is one step's 64 rows (or four steps' 16), no division -- and nothing waits for them: a wave's pieces have landed when its next counted vmcnt wait has
+// passed (gather_store, or the explicit wait in the prologue), the other waves see them behind the barrier after that.
+template <int MTR = MT> constexpr int IDS_PLANE = MAXT_LDS * MTR;   // ints per plane (3 planes fit the [MT][MAXT_LDS][4] buffer of ids_stage)
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
+template <int NTHREADS, int MTR = MT>
+__device__ __forceinline__ void ids_stage_dma(const int32_t* idx, int64_t N, int T, int F, int nT, int64_t tile, int32_t* ids) {
+  static_assert(NTHREADS == 256 && (MTR == 64 || MTR == 16), "4 waves; a wave instruction covers 64 / MTR steps");
+  constexpr int PER = 64 / MTR;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = lane % MTR;
+  int64_t n = tile * MTR + row;
+  if (n >= N) n = N - 1;
+  const unsigned base = lds_offset_of(ids);
+  for (int tb = wave * PER; tb < T; tb += 4 * PER) {
+    int t = tb + lane / MTR;
+    if (t >= T) t = T - 1;   // (lanes past T fill plane entries nothing reads: MAXT_LDS is a multiple of PER)
+    const int32_t* f = idx + (n * T + t) * F;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int32_t* src = f + (k == 0 ? F - nT - 2 : (k == 1 ? F - 2 : F - 1));
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + (unsigned)(k * IDS_PLANE<MTR> + tb * MTR) * 4u));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+  }
+}
+// (its gather: ids from the planes, the table base one row down)
+template <int NTHREADS, int MTR = MT, class Args>
+__device__ __forceinline__ void gather_load_planes(const Args& a, const GatherSrc& g, int64_t tile, int t, const int32_t* ids, f32x4 (&v)[MTR * 16 / NTHREADS]) {
+  constexpr int PER = MTR * 16 / NTHREADS;
+  const int32_t* p = ids + g.slot * IDS_PLANE<MTR> + t * MTR + (threadIdx.x >> 4);
+  const float* base1 = g.base - g.width;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) v[k] = *(const f32x4*)(base1 + (int64_t)p[k * (NTHREADS >> 4)] * g.width);
+  if (a.nT > 1 && g.slot == 0) {  // several type slots per step: CAddTable over them (FeatureEmbedding.lua:55)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int row = (threadIdx.x >> 4) + k * (NTHREADS >> 4);
+      int64_t n = tile * MTR + row;
+      if (n >= a.N) n = a.N - 1;
+      const int32_t* f = a.idx + (n * a.T + t) * a.F;
+      for (int q = 1; q < a.nT; ++q) v[k] += *(const f32x4*)(base1 + (int64_t)f[a.F - a.nT - 2 + q] * g.width);
+    }
+  }
+}
+
 template <int NTHREADS, int MTR = MT>
 __device__ __forceinline__ void gather_store(float* xbuf, const f32x4 (&v)[MTR * 16 / NTHREADS]) {
   constexpr int PER = MTR * 16 / NTHREADS;

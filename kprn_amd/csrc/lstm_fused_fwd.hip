@@ -284,15 +284,16 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
 
   f32x4 gv[MTR * 16 / NT];
   const GatherSrc gsrc = gather_src(a);
-  ids_stage<NT, MTR>(a.idx, a.N, T, a.F, a.nT, blockIdx.x, idbuf(0));
+  ids_stage_dma<NT, MTR>(a.idx, a.N, T, a.F, a.nT, blockIdx.x, idbuf(0));
   if (a.tile_k) {  // classes 1 .. longest prefix of the batch (class 0 = no prefix: nothing to look up)
     const int n_cls = __builtin_amdgcn_readfirstlane(a.pmeta[0]) + 1;
     for (int c = L * PFB + threadIdx.x; c < n_cls * L * PFB; c += NT) ((float*)pft)[c] = a.pfb[c];
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's id pieces have landed
   lds_barrier();
   FPROBE(11)  // ... first ids + prefix table
   int k0 = tile_k0(blockIdx.x);  // the tile runs steps k0 .. T-1 (k0 <= T-2)
-  gather_load<NT, MTR>(a, gsrc, blockIdx.x, k0, idbuf(0), gv);
+  gather_load_planes<NT, MTR>(a, gsrc, blockIdx.x, k0, idbuf(0), gv);
   gather_store<NT, MTR>(xbuf(0), gv);
 
   // The work of a slot (one step t of one tile) is a chain of units u = (layer l, 16-row m-tile mt).  Unit u:
@@ -454,9 +455,15 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
       tn = k0_n;
     }
     const bool have_next = tile_n < a.n_tiles;
-    // the next tile's ids are staged while this tile's first step computes (visible after >= 1 barrier: a tile has >= 2 steps)
-    if (t == k0 && tile + gridDim.x < a.n_tiles) ids_stage<NT, MTR>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
-    if (have_next) gather_load<NT, MTR>(a, gsrc, tile_n, tn, idbuf(tpar_n), gv);
+    // the next tile's ids are requested (LDS-DMA) while this tile's first step computes.  They are read at the top of the tile's LAST slot: by then every
+    // wave has passed the counted wait of this slot's gather_store (its pieces have landed) and at least one barrier of a later slot -- unless the tile
+    // has only two steps: then the last slot is the next one, and the waves meet here first.
+    if (t == k0 && tile + gridDim.x < a.n_tiles) ids_stage_dma<NT, MTR>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
+    if (have_next && tile_n != tile && t == k0 + 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+    }
+    if (have_next) gather_load_planes<NT, MTR>(a, gsrc, tile_n, tn, idbuf(tpar_n), gv);
     FPROBE(1)  // id staging + gather issue
     // (2) the units of this slot
     if (t == k0) { slot(std::true_type{}, tile, t, par, s > 0, p_tile, p_t, k0); FPROBE(2) }
