@@ -441,6 +441,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   int64_t p_tile = tile;
   int p_t = t;
   int par = 0;
+  const int G = __builtin_amdgcn_readfirstlane((int)gridDim.x);   // (kept in a register: hipcc re-read it from the dispatch packet, with the wait, at every tile boundary)
+  int k0_req = 0;   // the next tile's first step, requested a slot or more ahead of the tile boundary (per lane; made uniform there)
   for (int64_t s = 0;; ++s) {
     par = (int)(s & 1);
     // (1) issue the gather for the NEXT slot (latency hidden under this slot's MFMAs)
@@ -449,16 +451,19 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
     int tpar_n = tpar;
     int k0_n = k0;
     if (tn == T) {
-      tile_n += gridDim.x;
+      tile_n += G;
       tpar_n ^= 1;
-      k0_n = (tile_n < a.n_tiles) ? tile_k0(tile_n) : 0;
+      k0_n = (tile_n < a.n_tiles) ? __builtin_amdgcn_readfirstlane(k0_req) : 0;
       tn = k0_n;
     }
     const bool have_next = tile_n < a.n_tiles;
     // the next tile's ids are requested (LDS-DMA) while this tile's first step computes.  They are read at the top of the tile's LAST slot: by then every
     // wave has passed the counted wait of this slot's gather_store (its pieces have landed) and at least one barrier of a later slot -- unless the tile
     // has only two steps: then the last slot is the next one, and the waves meet here first.
-    if (t == k0 && tile + gridDim.x < a.n_tiles) ids_stage_dma<NT, MTR>(a.idx, a.N, T, a.F, a.nT, tile + gridDim.x, idbuf(tpar ^ 1));
+    if (t == k0 && tile + G < a.n_tiles) {
+      ids_stage_dma<NT, MTR>(a.idx, a.N, T, a.F, a.nT, tile + G, idbuf(tpar ^ 1));
+      k0_req = a.tile_k ? a.tile_k[tile + G] : 0;   // (a load whose wait sits at the tile boundary, not here)
+    }
     if (have_next && tile_n != tile && t == k0 + 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
