@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   unsigned long long tlast = (KPRN_PROBES_ON && a.timing) ? __builtin_amdgcn_s_memtime() : 0ull;
   float* dA_t = lds;                                        // [64][LDD]
   float* in_t = dA_t + MT * LDD;                            // bottom: [64][LDA] x_t
-  int32_t* ids = (int32_t*)(in_t + (BOTTOM ? MT * LDA : 0));  // bottom: [64][T][4] the tile's ids, 0-based (x_t re-gather)
-  float* pg = (float*)(ids + (BOTTOM ? MT * MAXT_LDS * 4 : 0));  // [KCAP+1][PFB] this workgroup's share of PG
+  int32_t* ids = (int32_t*)(in_t + (BOTTOM ? MT * LDA : 0));  // bottom: 2 x the id planes of a tile (x_t re-gather): this tile's, and the next one's on its way (LDS-DMA)
+  constexpr int IDS_BUF = MT * MAXT_LDS * 4;                   // ints per buffer (>= 3 planes: lstm_fused_common.h ids_stage_dma)
+  float* pg = (float*)(ids + (BOTTOM ? 2 * IDS_BUF : 0));      // [KCAP+1][PFB] this workgroup's share of PG
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -151,6 +152,15 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     const int64_t ti = TOP ? n_mine - 1 - it : ((ho.role == 1) ? (it + 1 < n_mine ? it + 1 : 0) : it);
     return (int64_t)blockIdx.x + ti * gridDim.x;
   };
+  // A tile's start used to be a chain of round trips with the matrix pipe idle: its first step (tile_k), its ids -> LDS, its first x rows.  The first two
+  // are now requested while the tile BEFORE runs (round 6): the ids by LDS-DMA into the other id buffer, tile_k into one register.
+  int ipar = 1;        // id buffer of the running tile (flipped at every tile start)
+  int k0_req = 0;      // tile_k of the next tile to start (per lane; made uniform in retarget)
+  auto request_tile = [&](const int64_t tl, const int buf) {
+    if (a.tile_k) k0_req = a.tile_k[tl];
+    if (BOTTOM) ids_stage_dma<256, MTR>(a.idx, a.N, T, a.F, a.nT, tl, ids + buf * IDS_BUF);
+  };
+  if (n_mine > 0) request_tile(ho.role == 2 ? ho.tile : own_of(0), 0);
   for (int64_t it = 0; it < n_mine; ++it) {
     const int64_t own_tile = own_of(it);
     const bool late = ho.role == 1 && own_tile == (int64_t)blockIdx.x;    // the late piece of the pair's tile: starts from the stored state
@@ -166,15 +176,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     int k0, Te;                  // k0: steps below it belong to the prefix
     const float* frag_tile;
     float* dx_tile;              // + (mt * T + tt) * 1024
-    const int32_t* idk;          // [(row * T + tt) * 4 + slot]
-    auto retarget = [&](const int64_t tl) {
+    auto retarget = [&](const int64_t tl) {   // (tl is the tile the last request_tile named)
       tile = tl;
       n0 = tl * MTR;
-      k0 = a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tl]) : 0;
+      k0 = a.tile_k ? __builtin_amdgcn_readfirstlane(k0_req) : 0;
       Te = T - k0;
       frag_tile = a.save_frag + tl * NMT * frag_mt_stride + (int64_t)k0 * L * 4 * frag_unit + lane * 4;
       dx_tile = a.DX + (((tl * NMT) * T + k0) * 4 + j) * 256 + lane * 4;
-      idk = ids + k0 * 4;
     };
     retarget(early ? ho.tile : own_tile);
     auto frag_ptr = [&](int mt, int t, int l, int w, int plane) -> const float* {
@@ -227,18 +235,20 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     } else {
       init_state();
     }
-    auto tile_prologue = [&](const int tt_first) {
+    // next: the tile that starts after this one (-1: none)
+    auto tile_prologue = [&](const int tt_first, const int64_t next) {
+      ipar ^= 1;
       if (BOTTOM) {
-        lds_barrier();  // previous tile's id tile / x tile fully consumed
-        ids_stage<256, MTR>(a.idx, a.N, T, a.F, a.nT, tile, ids);
-        lds_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tile's ids have landed (requested a tile ago)
+        lds_barrier();  // ... everyone's have; the previous tile's x tile is fully consumed
         f32x4 nin[MTR * 16 / 256];
-        gather_load<256, MTR>(a, gsrc, tile, tt_first, idk, nin, k0 + tt_first);
+        gather_load_planes<256, MTR>(a, gsrc, tile, k0 + tt_first, ids + ipar * IDS_BUF, nin);
         gather_store<256, MTR>(in_t, nin);
-        lds_barrier();
       }
+      if (next >= 0) request_tile(next, ipar ^ 1);   // (the other id buffer: last read by the tile before, behind the barrier above)
+      if (BOTTOM) lds_barrier();
     };
-    tile_prologue(tt_hi);
+    tile_prologue(tt_hi, early ? own_tile : (it + 1 < n_mine ? own_of(it + 1) : (int64_t)-1));
     TPROBE(1)  // tile prologue
     load_P(0, tt_hi);
 #pragma unroll
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
       TPROBE(3)  // mid barrier wait
       // bottom layer: x_{t-1} is requested here (latency hides under stage E) and lands after it
       f32x4 nin[MTR * 16 / 256];
-      if (BOTTOM && REC) gather_load<256, MTR>(a, gsrc, tile, t - 1, idk, nin, k0 + t - 1);
+      if (BOTTOM && REC) gather_load_planes<256, MTR>(a, gsrc, tile, k0 + t - 1, ids + ipar * IDS_BUF, nin);
 
       // ---- E. [dx | dh_prev] = dA * [W_i2g | W_o2g]; this wave: columns 16j..16j+15 of each ----------
       f32x4 ax[4], ah[4];
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         // flight first -- and the pair's heavy workgroup, which runs at least one other tile first, asks for them several steps from now)
         retarget(own_tile);
         init_state();
-        tile_prologue(Te - 1);
+        tile_prologue(Te - 1, n_mine > 1 ? own_of(1) : (int64_t)-1);
         load_P(0, Te - 1);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) load_B(nt, 0, Te - 1, Te > 1);
@@ -645,7 +655,7 @@ bool bwd_supported(const kprn_handle* h, int T) { return fwd_supported(h, T); }
 template <bool BOTTOM, bool TOP, int NMT = 4>
 static void launch_bwd(kprn_handle* h, const BwdArgs& a, int grid) {
   size_t lds_bytes = (size_t)MT * LDD * sizeof(float);
-  if (BOTTOM) lds_bytes += (size_t)MT * LDA * sizeof(float) + (MT * MAXT_LDS * 4) * sizeof(int32_t);
+  if (BOTTOM) lds_bytes += (size_t)MT * LDA * sizeof(float) + 2 * (MT * MAXT_LDS * 4) * sizeof(int32_t);
   lds_bytes += (size_t)(KCAP + 1) * PFB * sizeof(float);
   static PerDeviceOnce attr_done;  // one per template instantiation (the call is host time in front of every launch otherwise)
   if (attr_done.need()) HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd<BOTTOM, TOP, NMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
