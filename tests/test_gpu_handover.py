@@ -143,3 +143,23 @@ def test_one_layer_more_tiles_than_workgroups():
     ps0 = eng.forward(eng.batch(idx, labels), 1, want=("path_scores",))["path_scores"]
     assert rel_inf(ps0, ops) < 3e-6
     eng.close()
+
+
+@pytest.mark.parametrize("Tt,real_len,plan", [(2, 2, False), (6, 2, True), (3, 2, True)])
+def test_two_step_tiles_more_tiles_than_workgroups(Tt, real_len, plan):
+    """round 6: a tile's ids reach LDS by DMA, requested in the first slot of the tile BEFORE and read at the top of that tile's last slot (forward;
+    lstm_fused_common.h ids_stage_dma), and by the tile before's start in the bottom BPTT launch.  With two-step tiles the last slot is the very next one:
+    the only case in which the waves must meet once more in between.  T = 2, and longer paths whose common left padding leaves two executed steps
+    (tile_k = T - 2), 300 tiles on 256 workgroups, twice; scores and every gradient against the f64 oracle (model/OneModel.lua:236,268-275)."""
+    eng, o64, theta = mk(handover=2, plan=plan)
+    idx, labels = synth.make_paths(300 * 64 - 3, 1, Tt, Ve=SHAPE["Ve"], seed=41 + Tt, real_len=real_len)
+    ops, _, _ = o64.forward(theta, idx)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    for rep in range(2):
+        b, ps, probs, loss, g = run(eng, idx, labels)
+        assert rel_inf(ps, ops) < 3e-6, rep
+        assert abs(loss - ol) < 1e-5 * max(1.0, abs(ol))
+        for nm, (off, shp) in eng.layout().items():
+            n = int(np.prod(shp))
+            assert rel_inf(g[off:off + n], og[off:off + n]) < 2e-4, (nm, rep)
+    eng.close()
