@@ -163,3 +163,26 @@ def test_two_step_tiles_more_tiles_than_workgroups(Tt, real_len, plan):
             n = int(np.prod(shp))
             assert rel_inf(g[off:off + n], og[off:off + n]) < 2e-4, (nm, rep)
     eng.close()
+
+
+@pytest.mark.parametrize("Tt,F,nT,L", [(16, 3, 1, 2), (7, 6, 2, 2), (5, 4, 2, 1)])
+def test_dma_id_planes_long_paths_and_two_type_slots(Tt, F, nT, L):
+    """the LDS-DMA id staging at its edges: T = MAXT_LDS (the planes are full), two type slots per step (the CAddTable branch of the gather reads the batch's
+    own id tensor beside the planes: net/FeatureEmbedding.lua:55), unused leading feature columns (F = 6), one layer; 290 tiles on 256 workgroups (second tiles
+    take the staged-ahead path), forward and every gradient against the f64 oracle."""
+    shape = dict(SHAPE, L=L)
+    eng = _ffi.Engine(shape["Vt"], shape["Ve"], shape["Vr"], shape["dt"], shape["de"], shape["dr"], shape["H"], L, F=F, num_types=nT)
+    eng.set_option("small_tiles", "0")
+    o64 = Oracle(make_cfg(F=F, numTypes=nT, **shape), np.float64)
+    theta = o64.init_params(5, 0.1).astype(np.float32).astype(np.float64)
+    eng.set_flat_params(theta.astype(np.float32))
+    idx, labels = synth.make_paths(290 * 64 - 9, 1, Tt, F=F, Ve=SHAPE["Ve"], num_types=nT, seed=60 + Tt)
+    b, ps, probs, loss, g = run(eng, idx, labels)
+    ops, _, _ = o64.forward(theta, idx)
+    assert rel_inf(ps, ops) < 3e-6
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 1e-5 * max(1.0, abs(ol))
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], og[off:off + n]) < 2e-4, nm
+    eng.close()
