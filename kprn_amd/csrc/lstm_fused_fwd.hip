@@ -47,6 +47,10 @@ constexpr float N2LOG2E = -2.8853900817779268f;  // tanh(x) = 2 rcp(1 + exp2(-2x
 // behind MFMA K of a 16-MFMA group.  With one wave per SIMD nothing else hides the cell: a VALU op issues in
 // the shadow of the running MFMA only if it does not wait on the op right before it, so each step holds at
 // most one transcendental (16 cycles) and never consumes a value produced in the same step.
+// the training forward's plane stores go through explicitly GLOBAL pointers (the address of a tile's region is rebuilt from two scalar registers in the kernel:
+// as a generic pointer its stores would be flat_store)
+typedef __attribute__((address_space(1))) char gchar;
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
 struct CellRegs { float m0, m1, m2, m3, e0, e1, e2, e3, i, g, f, o, ig, c, cp, t; };
 template <bool SAVE, int R, int K>
 __device__ __forceinline__ void cell_step(CellRegs& x, const f32x4 (&acc)[4], float (&cst)[4], float* out_row, f32x4 (&sv)[NPL]) {
@@ -114,7 +118,7 @@ __device__ __forceinline__ void cell_q(const f32x4 (&acc)[4], float (&cst)[4], f
 template <bool SAVE, bool CELL, bool BIAS, bool PF, int S, bool ST = false>
 __device__ __forceinline__ void k_group(const f32x4 a4, f32x4& apre, const float* next_addr, const f32x4 (&w)[4][4], const f32x4 (&bias4)[4],
                                         f32x4 (&acc)[4], CellRegs& x, const f32x4 (&pacc)[4], float (&pc)[4], float* pout_row, f32x4 (&sv)[NPL],
-                                        float* fb = nullptr) {
+                                        gchar* fb = nullptr) {
 #define KPRN_G1(K)                                                                                  \
   {                                                                                                 \
     constexpr int jj = (K) >> 2, q = (K) & 3;                                                       \
@@ -125,7 +129,7 @@ __device__ __forceinline__ void k_group(const f32x4 a4, f32x4& apre, const float
     if (ST && ((K) == 3 || (K) == 11) && 2 * S + ((K) == 11) < NPL) {                               \
       constexpr int pk = 2 * S + ((K) == 11);                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                            \
-      *(f32x4*)(fb + pk * 256) = sv[pk < NPL ? pk : 0];                                             \
+      *(gf32x4*)(fb + pk * 1024) = sv[pk < NPL ? pk : 0];                                           \
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }                                                                                               \
   }
@@ -139,7 +143,7 @@ __device__ __forceinline__ void k_group(const f32x4 a4, f32x4& apre, const float
 template <bool SAVE, bool CELL, bool BIAS, bool PF, bool ST = false>
 __device__ __forceinline__ void half_unit(const float* abase, const f32x4 (&w)[4][4], const f32x4 (&bias4)[4], f32x4 (&acc)[4], f32x4& apre,
                                           const float* next_abase, const f32x4 (&pacc)[4], float (&pc)[4], float* pout_row, f32x4 (&sv)[NPL],
-                                          float* fb = nullptr) {
+                                          gchar* fb = nullptr) {
   static_assert(!(ST && CELL), "the planes leave in the half behind the one that forms them");
   CellRegs x;
   f32x4 a4 = apre;
@@ -310,18 +314,28 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   const int a_off = arow * LDA + ag * 4;                   // this lane's A-fragment offset inside a 16-row block
   const int o_off = (ag * 4) * LDA + j * 16 + arow;        // this lane's cell-output offset inside a 16-row block
 
-  auto save_addr = [&](int64_t p_tile, int p_t, int pl, int pm) -> float* {
-    return a.save_frag + (p_tile * NMT + pm) * frag_mt_stride + ((int64_t)(p_t * L + pl) * 4 + j) * frag_unit + lane * 4;
+  // A unit's planes sit at (its tile's region) + (an offset that fits 32 bits: m-tile, step, layer, wave, lane).  The region's address is wave-uniform and is
+  // held in scalar registers (readfirstlane: hipcc kept the tile index and the strides in vector registers and formed every unit's address with 64-bit VALU
+  // multiplies -- quarter rate, in a kernel whose VALU time nothing hides); the offset is one scalar term + lane * 16.
+  const uint32_t mt_stride32 = (uint32_t)frag_mt_stride;   // floats; T <= 16, L <= 2: 4 m-tiles of it are < 4 MB
+  auto tile_region = [&](int64_t tl) -> gchar* {
+    const uint64_t v = (uint64_t)(size_t)(a.save_frag + tl * NMT * frag_mt_stride);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (gchar*)(((uint64_t)hi << 32) | lo);
   };
-  auto save_unit = [&](int64_t p_tile, int p_t, int pl, int pm) {
+  auto save_addr = [&](gchar* region, int p_t, int pl, int pm) -> gchar* {
+    const uint32_t u = ((uint32_t)pm * mt_stride32 + (uint32_t)((p_t * L + pl) * 4 + j) * (uint32_t)frag_unit) * 4u;
+    return region + (u + (uint32_t)lane * 16u);
+  };
+  auto save_unit = [&](gchar* region, int p_t, int pl, int pm) {
     if (!SAVE) return;
-    float* fb = save_addr(p_tile, p_t, pl, pm);
+    gchar* fb = save_addr(region, p_t, pl, pm);
 #pragma unroll
 #ifdef KPRN_EXP_NOSTORE
     for (int k = 0; k < NPL; ++k) asm volatile("" ::"v"(sv[k]));
-    if (a.T == 77) *(f32x4*)(fb) = sv[0];
+    if (a.T == 77) *(gf32x4*)(fb) = sv[0];
 #else
-    for (int k = 0; k < NPL; ++k) *(f32x4*)(fb + k * 256) = sv[k];
+    for (int k = 0; k < NPL; ++k) *(gf32x4*)(fb + k * 1024) = sv[k];
 #endif
   };
   // FIRST: the tile's first executed step.  There is no recurrent half: the tile's common prefix state enters as one
@@ -330,6 +344,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   auto slot = [&](auto first_tag, const int64_t tile, const int t, const int par, const bool has_prev, const int64_t p_tile, const int p_t,
                   const int cls) {
     constexpr bool FIRST = decltype(first_tag)::value;
+    gchar* const reg_c = SAVE ? tile_region(tile) : nullptr;      // where this slot's tile, and the tile of the slot before, keep their planes
+    gchar* const reg_p = SAVE ? tile_region(p_tile) : nullptr;
     float cinit[L];
     float rec0[L][4];  // k-slot 0 of the B operand: (W_o2g h_prefix)[gate q, col 16j + arow]
     const float one0 = (ag == 0) ? 1.0f : 0.f;
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
         const int pl = (mt > 0) ? l : ((l > 0) ? l - 1 : L - 1);
         const int pm = (mt > 0) ? mt - 1 : NMT - 1;
         const bool cross = (l == 0 && mt == 0);             // it belongs to the previous slot
-        const int64_t q_tile = cross ? p_tile : tile;
+        gchar* const q_reg = cross ? reg_p : reg_c;
         const int q_t = cross ? p_t : t;
         const int q_par = cross ? (par ^ 1) : par;
         float* pout = hbuf(pl, q_par) + pm * 16 * LDA + o_off;
@@ -394,18 +410,18 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
           }
           // (training: the planes of the unit whose cell just ran leave under this half, one store per 8 MFMAs)
 #ifdef KPRN_EXP_BURST
-          save_unit(q_tile, q_t, pl, pm);
+          save_unit(q_reg, q_t, pl, pm);
           half_unit<SAVE, false, false, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], pout, sv);
 #else
           half_unit<SAVE, false, false, true, SAVE>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], pout, sv,
-                                                    SAVE ? save_addr(q_tile, q_t, pl, pm) : nullptr);
+                                                    SAVE ? save_addr(q_reg, q_t, pl, pm) : nullptr);
 #endif
         } else if (mt == 0) {
           if (!cross || has_prev) {
             KPRN_MFMA_DRAIN();  // last MFMAs of the previous unit -> VALU reads
             KPRN_PIN_V4(pacc);
             cell_all<SAVE>(pacc, c[pl][pm], pout, sv);
-            save_unit(q_tile, q_t, pl, pm);
+            save_unit(q_reg, q_t, pl, pm);
           }
           if (cross) {
 #pragma unroll
@@ -424,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
           }
         } else {
           half_unit<SAVE, true, true, true>(in_base, wi[l], bias4[l], acc, apre, nxt, pacc, c[pl][pm], pout, sv);
-          save_unit(q_tile, q_t, pl, pm);
+          save_unit(q_reg, q_t, pl, pm);
           if (cls > 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) KPRN_MFMA_VV(acc[q], one0, rec0[l][q]);
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
     constexpr int LAST = (L * NMT - 1) & 1;   // accumulator set of a slot's last unit
     KPRN_PIN_V4(accs[LAST]);
     cell_all<SAVE>(accs[LAST], c[L - 1][NMT - 1], hbuf(L - 1, par) + (NMT - 1) * 16 * LDA + o_off, sv);
-    save_unit(p_tile, p_t, L - 1, NMT - 1);
+    save_unit(SAVE ? tile_region(p_tile) : nullptr, p_t, L - 1, NMT - 1);
     lds_barrier();
     head_tile<NMT>(a, hbuf(L - 1, par), p_tile, j, lane);
   }
