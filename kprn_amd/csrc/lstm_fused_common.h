@@ -201,6 +201,18 @@ __device__ __forceinline__ void gather_store(float* xbuf, const f32x4 (&v)[MTR *
 //   dC = dc + dh P5;  dA_i = dC P1;  dA_g = dC P2;  dA_f = dC P3;  dA_o = dh P4;  dc' = dC P6
 // plane 6 = h: the B operand of dW = dA^T [x | h] in exactly the register layout the MFMA wants.
 constexpr int NPL = 7;
+// Explicitly GLOBAL pointers for the training forward's plane stores: a tile's region is wave-uniform, its address is rebuilt from two scalar registers
+// (readfirstlane) and everything below it fits a 32-bit offset -- the stores are then `global_store voffset, data, sbase` and the per-unit 64-bit VALU
+// multiplies by run-time strides are gone (training forward 783 k -> 774 k cycles per workgroup).  A pointer rebuilt from integers without the address space
+// would be a FLAT one (flat_store).  The same form on the BACKWARD's plane loads was measured and taken out again: stage C's MFMA phase went from 299 k to
+// 358 k cycles per workgroup (each load's offset then comes from a v_add right in front of it, inside the dW MFMA stream; profiles/r06 README, call r7o).
+typedef __attribute__((address_space(1))) char gchar;
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
+__device__ __forceinline__ gchar* uniform_global(const void* p) {
+  const uint64_t v = (uint64_t)(size_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (gchar*)(((uint64_t)hi << 32) | lo);
+}
 
 // ---- MFMA issue, hand-placed ---------------------------------------------------------------------------
 // v_mfma_f32_16x16x4_f32 as inline asm with the register FILES chosen here.  Values that only ever feed the

@@ -47,10 +47,6 @@ constexpr float N2LOG2E = -2.8853900817779268f;  // tanh(x) = 2 rcp(1 + exp2(-2x
 // behind MFMA K of a 16-MFMA group.  With one wave per SIMD nothing else hides the cell: a VALU op issues in
 // the shadow of the running MFMA only if it does not wait on the op right before it, so each step holds at
 // most one transcendental (16 cycles) and never consumes a value produced in the same step.
-// the training forward's plane stores go through explicitly GLOBAL pointers (the address of a tile's region is rebuilt from two scalar registers in the kernel:
-// as a generic pointer its stores would be flat_store)
-typedef __attribute__((address_space(1))) char gchar;
-typedef __attribute__((address_space(1))) f32x4 gf32x4;
 struct CellRegs { float m0, m1, m2, m3, e0, e1, e2, e3, i, g, f, o, ig, c, cp, t; };
 template <bool SAVE, int R, int K>
 __device__ __forceinline__ void cell_step(CellRegs& x, const f32x4 (&acc)[4], float (&cst)[4], float* out_row, f32x4 (&sv)[NPL]) {
@@ -318,11 +314,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   // held in scalar registers (readfirstlane: hipcc kept the tile index and the strides in vector registers and formed every unit's address with 64-bit VALU
   // multiplies -- quarter rate, in a kernel whose VALU time nothing hides); the offset is one scalar term + lane * 16.
   const uint32_t mt_stride32 = (uint32_t)frag_mt_stride;   // floats; T <= 16, L <= 2: 4 m-tiles of it are < 4 MB
-  auto tile_region = [&](int64_t tl) -> gchar* {
-    const uint64_t v = (uint64_t)(size_t)(a.save_frag + tl * NMT * frag_mt_stride);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (gchar*)(((uint64_t)hi << 32) | lo);
-  };
+  auto tile_region = [&](int64_t tl) -> gchar* { return uniform_global(a.save_frag + tl * NMT * frag_mt_stride); };
   auto save_addr = [&](gchar* region, int p_t, int pl, int pm) -> gchar* {
     const uint32_t u = ((uint32_t)pm * mt_stride32 + (uint32_t)((p_t * L + pl) * 4 + j) * (uint32_t)frag_unit) * 4u;
     return region + (u + (uint32_t)lane * 16u);
