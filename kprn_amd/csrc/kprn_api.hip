@@ -2471,6 +2471,10 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
   } else if (strcmp(key, "adam_merged") == 0) {
     // lazy-exact Adam: the entity rows' update and the dense arena's update in ONE launch ("1", default) or in two ("0": the A/B reference; bit-identical)
     h->adam_merged = atoi(value) != 0;
+  } else if (strcmp(key, "fused_small_tables") == 0) {
+    // fused D = H = 64 path: the type / relation table gradients are formed inside the bottom layer's BPTT launch (one-hot MFMAs on the dx registers) ("1", default) or by a
+    // passenger job of the entity-gradient launch that re-reads dx ("0": the A/B reference)
+    h->fused_small_tables = atoi(value) != 0;
   } else if (strcmp(key, "persist_layers") == 0) {
     // generic fp32 pipelines: a recurrent layer as ONE persistent launch ("1", default: where layer_f32_persist.hip takes the shape and the batch gives
     // every CU a tile; "2": at any batch size -- tests) or one launch per step ("0")

@@ -53,7 +53,9 @@ struct BwdArgs {
   const int32_t* tile_k;
   float* PG;               // [KCAP+1][PFB] this layer: sum over rows of dA at the tile's first executed step | of dc handed below it
   HoArgs ho;               // time-split tile hand-over (lstm_fused_common.h ho_plan)
+  int small_lds;           // bottom layer: the type / relation table gradients are formed inside this launch (one-hot MFMAs on dx; option "fused_small_tables")
 };
+
 
 constexpr int PART = 2 * 256 * 64 + 256;  // floats per workgroup partial slab
 constexpr int LDD = 4 * DH + 4;  // dA tile row stride
@@ -136,6 +138,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   const float wout_c = TOP ? a.wout_row[j * 16 + arow] : 0.f;
   float gwo = 0.f, gbo = 0.f;  // head gradient partials of this lane: column 16j + arow over its rows / sum of dS over its rows
   for (int c = tid; c < (KCAP + 1) * PFB; c += 256) pg[c] = 0.f;  // (first read: after the barriers of a whole tile)
+  // bottom layer, waves that own a type / relation slice of dx: that table's gradient, [16 rows v][this wave's 16 columns] in the MFMA C layout
+  // (lane (g, col) holds rows v = 4 g + i), two accumulators so that consecutive MFMAs do not chain
+  f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   TPROBE(0)
 
   // A workgroup walks ITS tiles (blockIdx.x + i gridDim.x, the forward's assignment) in the order that finds the most in the 256 MB
@@ -389,7 +394,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         // dx in fragment order: the layer below (or, bottom layer, the small-table gradient job) reloads it the same way,
         // 1 KiB per instruction; in place -- this thread read this very slot as `up` at the start of the step.
         // Rows past N: exact zeros (dA = 0 there).
-        if (!compact) *(f32x4*)(dx_tile + (mt * T + t) * 1024) = ax[mt];
+        // (with the small tables' gradients formed below, nobody reads the type / relation slices of the bottom layer's dx: not stored)
+        if (!compact && !(BOTTOM && a.small_lds && wcls != 1)) *(f32x4*)(dx_tile + (mt * T + t) * 1024) = ax[mt];
       }
       if (compact) {
         // entity columns of the bottom layer: row-major for the gather-reduce over the occurrence index (16 lanes = 64 contiguous bytes)
@@ -398,6 +404,30 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) de_row[(int64_t)(mt * 16 + r) * T * a.de] = ax[mt][r];
+      }
+      if (BOTTOM && a.small_lds && wcls != 1) {   // (wave-uniform)
+        // nn.LookupTable backward of the type / relation tables (net/FeatureEmbedding.lua:112-121, 86): tables of at most 16 rows, so the gradient is a one-hot
+        // product on the dx registers this wave holds anyway (its 16 columns ARE a type / relation slice): grad[v][col] += sum_rows [id(row) == v] dx[row][col]
+        // = D += A B with A = one-hot [16 v x 4 k], B = dx [4 k x 16 col]; MFMA (mt, r) contracts over the rows {16 mt + 4 ag + r}: lane (ag, arow) holds
+        // exactly its B element (ax[mt][r]) and its A element (the id of its own row against v = arow), the ids come from the id planes already in LDS.
+        // 16 MFMAs per step on two of the four waves.  (Round 6: as a passenger job of the entity-gradient launch this re-read both slices of dx and the
+        // ids from HBM -- 25 of that launch's 60 us; as ds_add_f32 into an LDS table it cost the launch 50 us.)  Rows past N carry dx = 0.
+        const int32_t* idp = ids + ipar * IDS_BUF + ((wcls == 0) ? 0 : 2) * IDS_PLANE<MTR> + (k0 + t) * MTR + ag * 4;
+        // (asm MFMAs with the accumulators held in architectural VGPRs, like every other MFMA of this kernel: left to hipcc -- the builtin -- the two
+        // accumulators were parked in AGPRs that belong to the launch-persistent dW tiles and shuffled around every MFMA; the small-tile instantiation came
+        // out numerically wrong)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+          const int4 id4 = *(const int4*)(idp + mt * 16);   // rows 16 mt + 4 ag + r, raw (1-based)
+          const float o0 = (id4.x - 1 == arow) ? 1.f : 0.f, o1 = (id4.y - 1 == arow) ? 1.f : 0.f;
+          const float o2 = (id4.z - 1 == arow) ? 1.f : 0.f, o3 = (id4.w - 1 == arow) ? 1.f : 0.f;
+          KPRN_MFMA_VV(sacc[0], o0, ax[mt][0]);   // (the macro carries the two wait states between the VALU result and the MFMA that reads it)
+          KPRN_MFMA_VV(sacc[1], o1, ax[mt][1]);
+          KPRN_MFMA_VV(sacc[0], o2, ax[mt][2]);
+          KPRN_MFMA_VV(sacc[1], o3, ax[mt][3]);
+        }
+        KPRN_MFMA_DRAIN();   // the accumulators cross the loop back-edge: nothing may copy them before they have landed
+        asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]));
       }
       TPROBE(4)  // stage E (dX MFMAs) + outputs
       lds_barrier();  // dA_t free for reuse, x_{t-1} tile visible
@@ -440,6 +470,16 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     for (int c = PFB + tid; c < (KCAP + 1) * PFB; c += 256) {
       const float v = pg[c];
       if (v != 0.f) unsafeAtomicAdd(a.PG + c, v);
+    }
+  }
+  if (BOTTOM && a.small_lds && wcls != 1) {
+    const f32x4 sg = sacc[0] + sacc[1];
+    const int V = (wcls == 0) ? a.Vt : a.Vr, width = (wcls == 0) ? a.dt : a.dr;
+    float* g = ((wcls == 0) ? a.gWt : a.gWr) + (j * 16 + arow - ((wcls == 0) ? 0 : a.dt + a.de));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = 4 * ag + i;
+      if (v < V && sg[i] != 0.f) unsafeAtomicAdd(g + (int64_t)v * width, sg[i]);
     }
   }
 
@@ -727,6 +767,10 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     // with the index, the entity columns of the bottom layer's dx leave the kernel row-major for the gather-reduce
     s->DXe_on = have_index && !(a.dbg & 1);
     a.DXe = (bottom && s->DXe_on) ? s->DXe : nullptr;
+    // ... or, round 6, formed inside the bottom layer's launch (one-hot MFMAs on the dx registers; option "fused_small_tables")
+    // (64-path tiles only: at small batches the passenger job hides in a launch that is latency-bound anyway, and the 16 extra MFMAs per step do not)
+    const bool small_lds = bottom && small_job && have_index && !(a.dbg & 1) && h->fused_small_tables && !small;
+    a.small_lds = small_lds ? 1 : 0;
     {
       // one event pair around the L back-to-back launches of the family (an event pair costs ~4 us of stream time)
       if (top) { bwd_scope.reset(new ProfScope(h, "lstm_fused_bwd")); bwd_scope->launches = L; }
@@ -756,7 +800,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
       sg.nT = c.num_types; sg.dt = c.dt; sg.de = c.de; sg.dr = c.dr; sg.Vt = c.Vt; sg.Vr = c.Vr; sg.gWt = a.gWt; sg.gWr = a.gWr; sg.nblocks = 4 * s->num_cu;
       { static const int sgb = KPRN_DEV_ENV("KPRN_SG_BLOCKS") ? atoi(KPRN_DEV_ENV("KPRN_SG_BLOCKS")) : 0; if (sgb > 0) sg.nblocks = sgb; }   // (measurement)
       bidx::entity_grad(strm, s->DXe, /*compact entity slice=*/2, b->key_sorted, b->pos_sorted, b->n_index, N, T, DH, c.dt, c.de, c.Ve, a.gWe, &ra,
-                        small_job ? &sg : nullptr);
+                        (small_job && !a.small_lds) ? &sg : nullptr);
       reduced = true;
     }
     const bool small_in_kernel = small_job && have_index;   // (handled above)

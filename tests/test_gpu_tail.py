@@ -60,3 +60,36 @@ def test_merged_adam_launch_at_the_bench_shape_agrees_to_rounding():
         res.append(eng.get_flat_params().astype(np.float64))
         eng.close()
     assert float(np.max(np.abs(res[0] - res[1]))) < 2e-6
+
+
+@pytest.mark.parametrize("pairs,P,small,plan", [(4000, 4, "0", True), (19200, 1, "0", False), (60, 4, "1", True)])
+def test_small_table_gradients_in_the_bptt_launch_equal_the_passenger_job(pairs, P, small, plan):
+    """nn.LookupTable backward of the type / relation tables (net/FeatureEmbedding.lua:86,112-121): summed in LDS tables inside the bottom layer's BPTT launch
+    (option "fused_small_tables", default) or by the entity-gradient launch's passenger job from a second reading of dx -- the same sums in another order.
+    64-path tiles with more tiles than workgroups (hand-over pieces included), and the 16-row tiles of small batches; every other gradient is untouched."""
+    idx, labels = synth.make_paths(pairs, P, T, Ve=30000, seed=11 + P)
+    grads = []
+    for on in ("1", "0"):
+        eng = _ffi.Engine(6, 30000, 9, 16, 32, 16, 64, 2)
+        eng.set_option("small_tiles", small)
+        eng.set_option("prefix_plan", "1" if plan else "0")
+        eng.set_option("fused_small_tables", on)
+        rng = np.random.default_rng(3)
+        eng.set_flat_params((rng.random(eng.n_params) * 0.2 - 0.1).astype(np.float32))
+        b = eng.batch(idx, labels)
+        eng.forward(b, 1, want=("probs",))
+        eng.profile(True)
+        eng.backward(b, 1)
+        fam = eng.profile_get()
+        grads.append((eng.get_flat_grads().astype(np.float64), eng.layout()))
+        eng.close()
+    (g1, lay), (g0, _) = grads
+    for nm, (off, shp) in lay.items():
+        n = int(np.prod(shp))
+        a, c = g1[off:off + n], g0[off:off + n]
+        scale = max(1e-30, float(np.max(np.abs(c))))
+        if "type" in nm.lower() or "rel" in nm.lower():
+            assert float(np.max(np.abs(a - c))) / scale < 2e-5, nm
+            assert float(np.max(np.abs(c))) > 0, nm
+        else:
+            assert float(np.max(np.abs(a - c))) / scale < 2e-6, nm   # (atomics of the entity / weight-slab sums re-associate run to run)
