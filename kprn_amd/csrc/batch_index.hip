@@ -224,6 +224,14 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
   const int key_before = (base > 0) ? kb_ld : -1;
   const int key_after = (base + cnt < nsteps) ? ka_ld : -1;
   const int waves_per_group = D >> 4;  // FRAG: 16-column blocks per (16-row block, t)
+  // Where the runs end, found once and lane-parallel (round 6): lane i compares its key with lane i + 1's, a ballot gives the 64-bit mask the walk below
+  // tests one bit of per position.  (The walk used to find the ends itself -- two readlanes, compares and two branches for every one of the 64 positions
+  // and columns' chunk -- and with six waves a SIMD that instruction stream, not the gather, was most of the launch: rows fetched in sorted order instead of
+  // at random did not change its time, `KPRN_EGRAD_DBG` 64.)
+  const int key_next = __shfl_down(my_key, 1, 64);
+  const bool is_end = (lane < cnt) && (lane == cnt - 1 || key_next != my_key);
+  const unsigned long long endmask = __ballot(is_end);
+  const bool continues = __builtin_amdgcn_readlane(my_key, (cnt - 1) & 63) == key_after;   // the segment's last run goes on in the next segment
   for (int c0 = 0; c0 < de; c0 += 64) {
     const bool act = c0 + lane < de;
     const int ecol = act ? c0 + lane : de - 1;  // column inside the entity slice (idle lanes re-read the last one: loads stay unconditional)
@@ -259,20 +267,16 @@ __global__ __launch_bounds__(256) void k_entity_grad(const float* __restrict__ D
 #pragma unroll
       for (int i2 = 0; i2 < 32; ++i2) {
         const int i = 32 * hf + i2;
-        acc += v[i2];
-        if (i < cnt) {  // wave-uniform
+        acc += v[i2];   // (positions past cnt add to a sum that is never stored: position cnt - 1 is always an end)
+        if (endmask & (1ull << i)) {  // (wave-uniform) the run ends here, or the segment does
           const int k = __builtin_amdgcn_readlane(my_key, i);
-          const bool more = (i < 63) && (i + 1 < cnt);
-          const int knext = more ? __builtin_amdgcn_readlane(my_key, (i + 1) & 63) : key_after;
-          if (!more || knext != k) {  // the run ends, or the segment does
-            const bool whole = opened_here && (knext != k);  // every occurrence of row k was in this segment
-            if (act && k != sentinel) {
-              float* dst = gWe + (int64_t)k * de + ecol;
-              if (whole) *dst = acc; else if (!(dbg & 1)) unsafeAtomicAdd(dst, acc);
-            }
-            acc = 0.f;
-            opened_here = true;
+          const bool whole = opened_here && !(i == cnt - 1 && continues);  // every occurrence of row k was in this segment
+          if (act && k != sentinel) {
+            float* dst = gWe + (int64_t)k * de + ecol;
+            if (whole) *dst = acc; else if (!(dbg & 1)) unsafeAtomicAdd(dst, acc);
           }
+          acc = 0.f;
+          opened_here = true;
         }
       }
     }
