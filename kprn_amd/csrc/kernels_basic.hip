@@ -738,7 +738,10 @@ __global__ void k_adam_rows_v(float* __restrict__ W, float* __restrict__ g, floa
     *(f4*)(g + o) = f4{0.f, 0.f, 0.f, 0.f};
   }
   if (r == pad_row) { x[0] = x[1] = x[2] = x[3] = 0.f; }  // zeroPadTokens after every step the row lived through (MyOptimizer.lua:219)
-  *(f4*)(W + o) = f4{x[0], x[1], x[2], x[3]}; *(f4*)(m + o) = f4{mm[0], mm[1], mm[2], mm[3]}; *(f4*)(v + o) = f4{vv[0], vv[1], vv[2], vv[3]};
+  // a catch-up that finds the row current (touched by the step before: every row of a batch that comes again, most rows of consecutive minibatches) has
+  // changed nothing: its three 16-byte stores per lane are skipped (round 6: they were half of the catch-up launch's traffic)
+  const bool changed = apply_step || (l > 0 && l < upto) || r == pad_row;
+  if (changed) { *(f4*)(W + o) = f4{x[0], x[1], x[2], x[3]}; *(f4*)(m + o) = f4{mm[0], mm[1], mm[2], mm[3]}; *(f4*)(v + o) = f4{vv[0], vv[1], vv[2], vv[3]}; }
   if (j == 0) last[r] = t_now;
 }
 
