@@ -3,6 +3,7 @@
 // /root/reference/release/songPathRnn/).
 #include <string.h>
 #include "kprn_internal.h"
+#include "adam_rows_dev.h"
 
 namespace {
 
@@ -628,12 +629,7 @@ __device__ __forceinline__ float clip_factor(const float* norm2, float clip) {
   return (nrm > clip) ? clip / nrm : 1.f;
 }
 
-__device__ __forceinline__ void adam_elem(float& x, float& m, float& v, float g, float step, float b1, float b2, float eps) {
-  m = m * b1 + (1.f - b1) * g;
-  v = v * b2 + (1.f - b2) * g * g;
-  float denom = sqrtf(v) + eps;
-  x = x - step * (m / denom);
-}
+using kk_dev::adam_elem;   // (adam_rows_dev.h: shared with lstm_fused_prefix.hip's catch-up + prefix launch)
 
 // consume != 0: the gradient is zeroed as it is used (zeroGradParameters of the next trainBatch, MyOptimizer.lua:186, done here);
 // [z0,z0+zn0) and [z1,z1+zn1): pad rows of the arena, re-zeroed after the update (zeroPadTokens, MyOptimizer.lua:219);
@@ -712,37 +708,9 @@ __global__ void k_adam_rows_v(float* __restrict__ W, float* __restrict__ g, floa
                               int32_t* __restrict__ last, const int32_t* __restrict__ rows, const int32_t* __restrict__ count,
                               int32_t t_now, int apply_step, const float* __restrict__ step_tab, float b1, float b2, float eps, int64_t pad_row,
                               int rows_blocks, float step_now, AdamDenseJob dense) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
   if ((int)blockIdx.x >= rows_blocks) { adam_dense_block(dense, (int64_t)blockIdx.x - rows_blocks); return; }
-  const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  const int j = threadIdx.x % G;
-  if (slot >= *count) return;
-  const int64_t r = rows[slot];
-  const int32_t l = last[r];
-  const int32_t upto = apply_step ? t_now - 1 : t_now;  // replay (l, upto] with g = 0
-  const int64_t o = r * (4 * G) + 4 * j;
-  const f4 x4 = *(const f4*)(W + o), m4 = *(const f4*)(m + o), v4 = *(const f4*)(v + o);
-  f4 g4 = f4{0.f, 0.f, 0.f, 0.f};
-  if (apply_step) g4 = *(const f4*)(g + o);
-  float x[4] = {x4[0], x4[1], x4[2], x4[3]}, mm[4] = {m4[0], m4[1], m4[2], m4[3]}, vv[4] = {v4[0], v4[1], v4[2], v4[3]};
-  if (l > 0)
-    for (int32_t k = l + 1; k <= upto; ++k) {
-      const float st = step_tab[k];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) adam_elem(x[q], mm[q], vv[q], 0.f, st, b1, b2, eps);
-    }
-  if (apply_step) {
-    const float st = step_now >= 0.f ? step_now : step_tab[t_now];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) adam_elem(x[q], mm[q], vv[q], g4[q], st, b1, b2, eps);
-    *(f4*)(g + o) = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  if (r == pad_row) { x[0] = x[1] = x[2] = x[3] = 0.f; }  // zeroPadTokens after every step the row lived through (MyOptimizer.lua:219)
-  // a catch-up that finds the row current (touched by the step before: every row of a batch that comes again, most rows of consecutive minibatches) has
-  // changed nothing: its three 16-byte stores per lane are skipped (round 6: they were half of the catch-up launch's traffic)
-  const bool changed = apply_step || (l > 0 && l < upto) || r == pad_row;
-  if (changed) { *(f4*)(W + o) = f4{x[0], x[1], x[2], x[3]}; *(f4*)(m + o) = f4{mm[0], mm[1], mm[2], mm[3]}; *(f4*)(v + o) = f4{vv[0], vv[1], vv[2], vv[3]}; }
-  if (j == 0) last[r] = t_now;
+  const kk_dev::AdamRowsArgs ra{W, g, m, v, last, rows, count, t_now, apply_step, step_tab, b1, b2, eps, pad_row, step_now};
+  kk_dev::adam_rows_lane_block<G>(ra, (int64_t)blockIdx.x);
 }
 
 // Data-parallel exchange, union + update in ONE launch (lazy-exact Adam, no clip / L2).  `all` = the all-gathered packed buffers

@@ -24,6 +24,8 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid);
 void params_changed(kprn_handle* h);
 bool transpose_job(kprn_handle* h, kk::TransposeJob* tj);
 void prefix_forward(kprn_handle* h, const kprn_batch* b);
+bool catch_up_with_prefix(kprn_handle* h, const kprn_batch* b, float* W, float* g, float* m, float* v, int32_t* last, int32_t t_now, const float* step_tab,
+                          float b1, float b2, float eps);
 void mc_prepare(kprn_handle* h);
 void release(kprn_handle* h);
 void handover_stats(kprn_handle* h, const kprn_batch* b, int64_t* out);
@@ -263,13 +265,18 @@ static void ensure_ws_generic(kprn_handle* h, int64_t N, int T) {
 
 // rows of this batch that are behind opt_step are replayed before the forward reads them
 static void flush_lazy(kprn_handle* h);
+static bool use_fused(kprn_handle* h, const kprn_batch* b, bool save_for_backward);
 static void catch_up(kprn_handle* h, const kprn_batch* b) {
   if (h->lazy_pending && !b->has_index) { flush_lazy(h); return; }   // (no row list: bring the whole table up to date instead)
   if (!h->lazy_pending || b->n_uniq == 0) return;
   if (h->caught_serial == b->serial && h->caught_step == h->opt_step) return;  // this batch's rows are already current
   join_score(h);
   ProfScope ps(h, "adam_rows_catchup");
+  // (fused path, a batch with an identical-prefix plan: its prefix table is one more workgroup of this launch -- fused::catch_up_with_prefix)
+  const bool with_prefix = h->cfg.compute_dtype == 0 && use_fused(h, b, false) &&
+                           fused::catch_up_with_prefix(h, b, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, (int32_t)h->opt_step, h->step_tab, h->last_b1, h->last_b2, h->last_eps);
   // count lives at the tail of the list buffer
+  if (!with_prefix)
   kk::adam_rows(h->stream, h->We, h->g_We, h->s1_We, h->s2_We, h->We_last, b->uniq, b->uniq + b->uniq_cap, b->n_uniq, h->cfg.de,
                 (int32_t)h->opt_step, 0, h->step_tab, h->last_b1, h->last_b2, h->last_eps, (int64_t)h->cfg.Ve - 1);
   bf16p::rows_updated(h, b->uniq, b->uniq + b->uniq_cap, b->n_uniq);
@@ -2471,6 +2478,10 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
   } else if (strcmp(key, "adam_merged") == 0) {
     // lazy-exact Adam: the entity rows' update and the dense arena's update in ONE launch ("1", default) or in two ("0": the A/B reference; bit-identical)
     h->adam_merged = atoi(value) != 0;
+  } else if (strcmp(key, "catchup_prefix") == 0) {
+    // fused D = H = 64 path: a batch's lazy-exact row catch-up and its identical-prefix table in one launch ("1", default) or in two ("0": the A/B reference;
+    // bit-identical)
+    h->catchup_prefix = atoi(value) != 0;
   } else if (strcmp(key, "fused_small_tables") == 0) {
     // fused D = H = 64 path: the type / relation table gradients are formed inside the bottom layer's BPTT launch (one-hot MFMAs on the dx registers) ("1", default) or by a
     // passenger job of the entity-gradient launch that re-reads dx ("0": the A/B reference)

@@ -232,6 +232,7 @@ struct kprn_handle {
   // call then fails instead of returning numbers computed from a stale slot
   int tile_handover = 2; int* ho_fault = nullptr;
   bool adam_merged = true;        // option "adam_merged": the row update and the dense arena's update of an Adam step in one launch
+  bool catchup_prefix = true;     // option "catchup_prefix": a batch's row catch-up and its identical-prefix table in one launch (fused path)
   bool fused_small_tables = true; // option "fused_small_tables": the fused path's type / relation table gradients formed inside the bottom BPTT launch (one-hot MFMAs on dx)
   float score_split = 0.f;        // option: fraction of a scoring pass's tiles deferred to kprn_forward_batch_async_rest
   // option "score_rest_in_backward": the deferred part of a split pass is placed by the fused backward itself, right behind its last BPTT launch -- it runs on the side

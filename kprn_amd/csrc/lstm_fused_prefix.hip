@@ -17,6 +17,7 @@
 //                  virtual tile of DX that the batch index points at).
 // Exact up to the order of fp32 additions.  One workgroup each; plain VALU dot products (a few microseconds, 1 row).
 #include "lstm_fused_common.h"
+#include "adam_rows_dev.h"
 
 namespace fused {
 
@@ -70,28 +71,14 @@ __device__ __forceinline__ void rows_land(const f32x4 (&st)[16], float* tile, f3
   }
 }
 
+// Layer by layer (all prefix steps of layer 0, then all of layer 1, the lower layer's h_t kept in LDS): one layer's two weight rows per thread are resident
+// at a time, 128 registers instead of 256 -- the block also rides as a passenger of the row catch-up's launch (k_catchup_prefix), whose other workgroups
+// should keep two to a CU.  Every dot product sees the operands it saw in the step-major order: bit-identical results.
 template <int L>
-__global__ __launch_bounds__(256) void k_prefix_fwd(PrefFwdArgs a) {
-  __shared__ float x[DH], hcur[2][DH], cst[2][DH], gates[4 * DH];
+__device__ __forceinline__ void prefix_fwd_block(const PrefFwdArgs& a) {
+  __shared__ float x[DH], hcur[DH], cst[DH], gates[4 * DH], hhist[KCAP][DH];
   __shared__ __attribute__((aligned(16))) float wtile[128 * LDW];
   const int r = threadIdx.x;
-  f32x4 wi[L][16], wo[L][16];
-  float bias[L];
-  {
-    f32x4 sa[16], sb[16];
-    rows_request(a.Wi[0], sa);
-    rows_request(a.Wo[0], sb);
-#pragma unroll
-    for (int l = 0; l < L; ++l) bias[l] = a.bi[l][r];
-    rows_land(sa, wtile, wi[0]);
-    if (L > 1) rows_request(a.Wi[L - 1], sa);
-    rows_land(sb, wtile, wo[0]);
-    if (L > 1) {
-      rows_request(a.Wo[L - 1], sb);
-      rows_land(sa, wtile, wi[L - 1]);
-      rows_land(sb, wtile, wo[L - 1]);
-    }
-  }
   const int kmax = a.kmax;
   if (r < DH) {
     const int32_t* ids = a.ref;
@@ -105,23 +92,29 @@ __global__ __launch_bounds__(256) void k_prefix_fwd(PrefFwdArgs a) {
     }
     x[r] = v;
     a.pfx[r] = v;
-    hcur[0][r] = 0.f; hcur[1][r] = 0.f;
-    cst[0][r] = 0.f; cst[1][r] = 0.f;
   }
-  __syncthreads();
-  float rec[L];  // (W_o2g h_{t-1})[r] per layer
 #pragma unroll
-  for (int l = 0; l < L; ++l) rec[l] = 0.f;
-  for (int t = 0; t < kmax; ++t) {
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const float* in = (l == 0) ? x : hcur[l - 1];
-      gates[r] = (bias[l] + rec[l]) + row_dot(wi[l], in);
+  for (int l = 0; l < L; ++l) {
+    f32x4 wi[16], wo[16];
+    const float bias = a.bi[l][r];
+    {   // (requested layer by layer: the staging registers of a second layer in flight would be the 128 this order saves)
+      f32x4 sa[16], sb[16];
+      rows_request(a.Wi[l], sa);
+      rows_request(a.Wo[l], sb);
+      rows_land(sa, wtile, wi);
+      rows_land(sb, wtile, wo);
+    }
+    if (r < DH) { hcur[r] = 0.f; cst[r] = 0.f; }
+    __syncthreads();
+    float rec = 0.f;  // (W_o2g h_{t-1})[r]
+    for (int t = 0; t < kmax; ++t) {
+      const float* in = (l == 0) ? x : hhist[t];   // (layer 1 reads layer 0's h_t, written a whole layer ago)
+      gates[r] = (bias + rec) + row_dot(wi, in);
       __syncthreads();
       if (r < DH) {
         // gate order of the packed pre-activations: i, g, f, o (FastLSTM; lstm_fused_fwd.hip cell_step)
         const float gi = fast_sigmoid(gates[r]), gg = fast_tanh(gates[DH + r]), gf = fast_sigmoid(gates[2 * DH + r]), go = fast_sigmoid(gates[3 * DH + r]);
-        const float cp = cst[l][r];
+        const float cp = cst[r];
         const float cn = gf * cp + gi * gg;
         const float tc = fast_tanh(cn);
         const float hh = go * tc;
@@ -133,17 +126,31 @@ __global__ __launch_bounds__(256) void k_prefix_fwd(PrefFwdArgs a) {
         sv[4 * DH] = go * (1.0f - tc * tc);
         sv[5 * DH] = gf;
         sv[6 * DH] = hh;
-        cst[l][r] = cn;
-        hcur[l][r] = hh;
+        cst[r] = cn;
+        hcur[r] = hh;
       }
       __syncthreads();
       // class t+1 starts behind this step: the recurrent half of its first executed step
-      const float rr = row_dot(wo[l], hcur[l]);
-      rec[l] = rr;
+      const float rr = row_dot(wo, hcur);
+      rec = rr;
       a.pfb[((t + 1) * L + l) * PFB + r] = rr;
-      if (r < DH) a.pfb[((t + 1) * L + l) * PFB + 4 * DH + r] = cst[l][r];
+      if (r < DH) { a.pfb[((t + 1) * L + l) * PFB + 4 * DH + r] = cst[r]; if (l + 1 < L) hhist[t][r] = hcur[r]; }
+      __syncthreads();   // (hcur is rewritten by the next step's cell)
     }
   }
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void k_prefix_fwd(PrefFwdArgs a) { prefix_fwd_block<L>(a); }
+
+// The catch-up of a batch's entity rows (lazy-exact Adam, kernels_basic.hip) and this batch's prefix table in ONE launch: both sit in the serial stretch
+// between the optimiser step and the next forward, the table is one workgroup's latency chain (12-16 us) and the catch-up is a chain of dependent loads whose
+// time does not depend on its occupancy (measured with 72 KB of LDS per workgroup: 13.0 against 12.8 us).  Workgroup 0 = the table, the others = the rows.
+// Host side: only when the reference step's entity IS the pad row -- the one row both jobs touch, zero before and after (zeroPadTokens) whichever comes first.
+template <int G, int L>
+__global__ __launch_bounds__(256, 2) void k_catchup_prefix(kk_dev::AdamRowsArgs ra, PrefFwdArgs pa) {
+  if (blockIdx.x == 0) { prefix_fwd_block<L>(pa); return; }
+  kk_dev::adam_rows_lane_block<G>(ra, (int64_t)blockIdx.x - 1);
 }
 
 struct PrefBwdArgs {
@@ -261,15 +268,8 @@ static void ensure_prefix_buffers(State* s, hipStream_t stream) {
   HIP_TRY(hipMemsetAsync(s->pfb, 0, (size_t)(KCAP + 1) * 2 * PFB * sizeof(float), stream));
 }
 
-// prefix table for (current parameters, this batch's reference step); cached until either changes
-void prefix_forward(kprn_handle* h, const kprn_batch* b) {
-  State* s = st(h);
-  ensure_prefix_buffers(s, h->stream);
-  if (s->pf_batch == b->serial) return;
+static void prefix_fwd_args(kprn_handle* h, const kprn_batch* b, State* s, PrefFwdArgs& a) {
   const kprn_config& c = h->cfg;
-  PrefFwdArgs a;
-  if (!b->tile_k || b->h_kmax == 0) { s->pf_batch = b->serial; return; }  // class 0 only: zeros since allocation, never rewritten
-  join_score(h);  // a scoring pass on the side stream may still be reading the table
   a.kmax = b->h_kmax;
   for (int q = 0; q < 16; ++q) a.ref[q] = b->h_ref[q];
   a.F = b->F; a.nT = c.num_types;
@@ -280,6 +280,44 @@ void prefix_forward(kprn_handle* h, const kprn_batch* b) {
     a.Wi[l] = h->dense + h->layer[ll].Wi; a.bi[l] = h->dense + h->layer[ll].bi; a.Wo[l] = h->dense + h->layer[ll].Wo;
   }
   a.pfb = s->pfb; a.pfs = s->pfs; a.pfx = s->pfx;
+}
+
+// the catch-up of b's rows AND b's prefix table as one launch (k_catchup_prefix); false: not applicable, the caller launches the catch-up by itself and
+// prefix_forward follows where it always did.  The caller has joined the scoring stream.
+bool catch_up_with_prefix(kprn_handle* h, const kprn_batch* b, float* W, float* g, float* m, float* v, int32_t* last, int32_t t_now, const float* step_tab,
+                          float b1, float b2, float eps) {
+  State* s = st(h);
+  const kprn_config& c = h->cfg;
+  if (!h->catchup_prefix || !b->tile_k || b->h_kmax == 0 || b->n_uniq <= 0) return false;
+  if (!(c.de == 32 || c.de == 64 || c.de == 128) || (((uintptr_t)W | (uintptr_t)m | (uintptr_t)v) & 15)) return false;
+  if (b->h_ref[b->F - 2] != c.Ve) return false;   // (1-based id of the pad row: the last one)
+  ensure_prefix_buffers(s, h->stream);
+  if (s->pf_batch == b->serial) return false;
+  PrefFwdArgs pa;
+  prefix_fwd_args(h, b, s, pa);
+  kk_dev::AdamRowsArgs ra{W, g, m, v, last, b->uniq, b->uniq + b->uniq_cap, t_now, 0, step_tab, b1, b2, eps, (int64_t)c.Ve - 1, -1.f};
+  const int G = c.de / 4;
+  const unsigned nb = (unsigned)(((int64_t)b->n_uniq * G + 255) / 256) + 1;
+#define KPRN_CP(G_) \
+  { if (c.L == 1) hipLaunchKernelGGL((k_catchup_prefix<G_, 1>), dim3(nb), dim3(256), 0, h->stream, ra, pa); \
+    else hipLaunchKernelGGL((k_catchup_prefix<G_, 2>), dim3(nb), dim3(256), 0, h->stream, ra, pa); }
+  if (G == 8) KPRN_CP(8) else if (G == 16) KPRN_CP(16) else KPRN_CP(32)
+#undef KPRN_CP
+  HIP_TRY(hipGetLastError());
+  s->pf_batch = b->serial;
+  return true;
+}
+
+// prefix table for (current parameters, this batch's reference step); cached until either changes
+void prefix_forward(kprn_handle* h, const kprn_batch* b) {
+  State* s = st(h);
+  ensure_prefix_buffers(s, h->stream);
+  if (s->pf_batch == b->serial) return;
+  const kprn_config& c = h->cfg;
+  PrefFwdArgs a;
+  if (!b->tile_k || b->h_kmax == 0) { s->pf_batch = b->serial; return; }  // class 0 only: zeros since allocation, never rewritten
+  join_score(h);  // a scoring pass on the side stream may still be reading the table
+  prefix_fwd_args(h, b, s, a);
   ProfScope ps(h, "prefix_fwd");
   if (c.L == 1) hipLaunchKernelGGL(k_prefix_fwd<1>, dim3(1), dim3(256), 0, h->stream, a);
   else hipLaunchKernelGGL(k_prefix_fwd<2>, dim3(1), dim3(256), 0, h->stream, a);

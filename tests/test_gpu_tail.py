@@ -93,3 +93,33 @@ def test_small_table_gradients_in_the_bptt_launch_equal_the_passenger_job(pairs,
             assert float(np.max(np.abs(c))) > 0, nm
         else:
             assert float(np.max(np.abs(a - c))) / scale < 2e-6, nm   # (atomics of the entity / weight-slab sums re-associate run to run)
+
+
+def test_catch_up_and_prefix_table_in_one_launch_is_bit_identical_to_two():
+    """the stretch between the optimiser step and the next forward: the lazy-exact catch-up of the next batch's entity rows
+    (optimizer/MyOptimizer.lua:218 as a replay) and that batch's identical-prefix table (model/OneModel.lua:236 on the shared padded steps) as ONE launch
+    (option "catchup_prefix", default) or as two.  Same arithmetic either way: after Adam steps whose gradients are reproducible bit for bit (one path of
+    distinct rows: no atomic sees two addends), the scores of a padded batch that shares rows with them -- rows that coast, rows that replay, the pad row --
+    and the table's own values are equal bit for bit; the one-launch form runs the table's own kernel less often."""
+    big = synth.make_paths(900, 4, T, Ve=2000, seed=301)
+    res = []
+    for merged in ("1", "0"):
+        eng = _ffi.Engine(6, 2000, 9, 16, 32, 16, 64, 2)
+        eng.set_option("small_tiles", "0")
+        eng.set_option("catchup_prefix", merged)
+        rng = np.random.default_rng(2)
+        eng.set_flat_params((rng.random(eng.n_params) * 0.2 - 0.1).astype(np.float32))
+        opt = _ffi.make_opt(method=1, lr=5e-3)
+        b0, b1, bb = eng.batch(*_distinct_paths(1, 1)), eng.batch(*_distinct_paths(2, 101)), eng.batch(*big)
+        scores = []
+        eng.profile(True)
+        for k in range(6):
+            eng.train_step(b0 if k % 3 == 0 else b1, opt)
+            scores.append(eng.forward(bb, 1, want=("path_scores",))["path_scores"].copy())   # catch-up of bb's rows (+ its prefix table: parameters moved)
+        fam = eng.profile_get()
+        res.append((scores, eng.get_flat_params(), fam.get("prefix_fwd", (0.0, 0))[1], fam.get("adam_rows_catchup", (0.0, 0))[1]))
+        eng.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[0][1], res[1][1])
+    assert res[1][2] >= 6 and res[0][2] < res[1][2], (res[0][2:], res[1][2:])
