@@ -24,6 +24,7 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid);
 void params_changed(kprn_handle* h);
 bool transpose_job(kprn_handle* h, kk::TransposeJob* tj);
 void prefix_forward(kprn_handle* h, const kprn_batch* b);
+bool forward_dual(kprn_handle* h, const kprn_batch* bt, const kprn_batch* bs, float* S_score);
 bool catch_up_with_prefix(kprn_handle* h, const kprn_batch* b, float* W, float* g, float* m, float* v, int32_t* last, int32_t t_now, const float* step_tab,
                           float b1, float b2, float eps);
 void mc_prepare(kprn_handle* h);
@@ -455,7 +456,23 @@ static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool
   catch_up(h, b);
   ensure_ws_common(h, N, b->B);
   if (use_fused(h, b, save_for_backward)) {
-    fused::forward(h, b, save_for_backward);
+    bool dual = false;
+    if (save_for_backward && h->score_dual && h->score_rest_batch && h->score_rest_tile0 == 0 && h->ev_score_done) {
+      // a deferred scoring pass ("score_dual") rides in this training forward's launch; its pooling stage follows on this stream, and the event the
+      // pass's readers wait for is recorded here
+      const kprn_batch* sb = h->score_rest_batch;
+      dual = fused::forward_dual(h, b, sb, h->S2);
+      if (dual) {
+        h->score_rest_batch = nullptr;
+        Workspace& w = h->ws;
+        float* S0 = w.S; float* sel0 = w.sel;
+        w.S = h->S2; w.sel = h->sel2;
+        try { pool_stage(h, sb, h->score_rest_cid - 1, false); } catch (...) { w.S = S0; w.sel = sel0; throw; }
+        w.S = S0; w.sel = sel0;
+        HIP_TRY(hipEventRecord(h->ev_score_done, h->stream));
+      }
+    }
+    if (!dual) fused::forward(h, b, save_for_backward);
   } else if (!b->idx_valid) {
     throw KprnError{KPRN_E_ARG, "this label-less batch was fed for the fused kernels (plan only); feed it again after changing impl"};
   } else if (bf16p::supported(h, b)) {
@@ -1777,6 +1794,18 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
     }
     fused::prefix_forward(h, b);  // (main stream; cached for the pass below and for the training forward of the same batch)
     fused::mc_prepare(h);         // (likewise: the split weights of the matrix-core forward)
+    if ((h->score_dual == 1 || (h->score_dual == 2 && fused::small_tiles(h, N, b->tile_k != nullptr))) && h->cfg.compute_dtype == 0 && h->cfg.L == 2 &&
+        !(h->score_split > 0.f)) {
+      // "score_dual": the WHOLE pass waits for the training forward that usually comes next and rides in its launch (forward_impl, fused::forward_dual) --
+      // deferred like the second part of a split pass (tile 0 on): whoever needs its result, its buffers or the parameters it reads first runs it the usual
+      // way (join_score -> launch_score_rest)
+      if (h->score_pending && h->ev_score_done) HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_score_done, 0));   // (an earlier pass wrote the same S2 / sel2)
+      h->score_rest_batch = b; h->score_rest_cid = class_id; h->score_rest_tile0 = 0;
+      h->score_pending = true;
+      h->last_forward_side = true;
+      h->last_B = b->B;
+      return KPRN_OK;
+    }
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_fork, 0));
     // an earlier pass (or its deferred part, which may have run on the rest stream: "score_rest_before_bptt") writes the same S2 / sel2: this pass
@@ -2478,6 +2507,13 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
   } else if (strcmp(key, "adam_merged") == 0) {
     // lazy-exact Adam: the entity rows' update and the dense arena's update in ONE launch ("1", default) or in two ("0": the A/B reference; bit-identical)
     h->adam_merged = atoi(value) != 0;
+  } else if (strcmp(key, "score_dual") == 0) {
+    // with "score_overlap": a scoring pass queued by kprn_forward_batch_async is held back and runs in the launch of the training forward that follows
+    // (one kernel, two branches: no second stream, no fork / join events) -- "1": always, "2" (default): for batches below the 16-row-tile threshold
+    // (8 192 paths: measured break-even; above it the side stream's pass lets the loss stage and the backward start under its tail), "0": never
+    const int v = atoi(value);
+    KPRN_REQUIRE(v >= 0 && v <= 2, KPRN_E_ARG, "score_dual must be 0, 1 or 2");
+    h->score_dual = v;
   } else if (strcmp(key, "catchup_prefix") == 0) {
     // fused D = H = 64 path: a batch's lazy-exact row catch-up and its identical-prefix table in one launch ("1", default) or in two ("0": the A/B reference;
     // bit-identical)

@@ -400,6 +400,7 @@ bool small_tiles(const kprn_handle* h, int64_t N, bool has_plan);
 void handover_stats(kprn_handle* h, const kprn_batch* b, int64_t* out /*[4]: pairs, steps moved, longest workgroup in half steps without / with*/);
 HoArgs handover_args(kprn_handle* h, int grid);   // this launch's hand-over context (epoch 0: off)
 void prefix_forward(kprn_handle* h, const kprn_batch* b);
+bool forward_dual(kprn_handle* h, const kprn_batch* bt, const kprn_batch* bs, float* S_score);
 bool catch_up_with_prefix(kprn_handle* h, const kprn_batch* b, float* W, float* g, float* m, float* v, int32_t* last, int32_t t_now, const float* step_tab,
                           float b1, float b2, float eps);
 void forward_mc(kprn_handle* h, const kprn_batch* b, bool save);

@@ -213,8 +213,9 @@ __device__ __forceinline__ void head_tile(const FwdArgs& a, const float* hbuf, i
 
 // NMT: 16-row m-tiles of a tile -- 4 (64-path tiles), or 1 for small batches (fused::small_tiles: four times as many workgroups, each a quarter
 // of the latency; the unit pipeline below is the same, a slot is then the chain of L units (layer l, m-tile 0))
+// bx / G_: this workgroup's index among, and the number of, the workgroups that walk THIS pass's tiles (k_lstm_fwd: the launch's; k_lstm_fwd_dual: a part of it)
 template <int L, bool SAVE, int NMT>
-__global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
+__device__ __forceinline__ void fwd_body(const FwdArgs& a, const int bx, const int G_) {
   constexpr int NT = 256, MTR = 16 * NMT;
   static_assert(NMT == 4 || (NMT == 1 && L == 2), "the accumulator ping-pong needs an even number of units per slot");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -279,12 +280,12 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
       for (int r = 0; r < 4; ++r) c[l][m][r] = 0.f;
 
   const int T = a.T;
-  if ((int64_t)blockIdx.x >= a.n_tiles) return;
+  if ((int64_t)bx >= a.n_tiles) return;
   auto tile_k0 = [&](int64_t tl) -> int { return a.tile_k ? __builtin_amdgcn_readfirstlane(a.tile_k[tl]) : 0; };
 
   f32x4 gv[MTR * 16 / NT];
   const GatherSrc gsrc = gather_src(a);
-  ids_stage_dma<NT, MTR>(a.idx, a.N, T, a.F, a.nT, blockIdx.x, idbuf(0));
+  ids_stage_dma<NT, MTR>(a.idx, a.N, T, a.F, a.nT, bx, idbuf(0));
   if (a.tile_k) {  // classes 1 .. longest prefix of the batch (class 0 = no prefix: nothing to look up)
     const int n_cls = __builtin_amdgcn_readfirstlane(a.pmeta[0]) + 1;
     for (int c = L * PFB + threadIdx.x; c < n_cls * L * PFB; c += NT) ((float*)pft)[c] = a.pfb[c];
@@ -292,8 +293,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's id pieces have landed
   lds_barrier();
   FPROBE(11)  // ... first ids + prefix table
-  int k0 = tile_k0(blockIdx.x);  // the tile runs steps k0 .. T-1 (k0 <= T-2)
-  gather_load_planes<NT, MTR>(a, gsrc, blockIdx.x, k0, idbuf(0), gv);
+  int k0 = tile_k0(bx);  // the tile runs steps k0 .. T-1 (k0 <= T-2)
+  gather_load_planes<NT, MTR>(a, gsrc, bx, k0, idbuf(0), gv);
   gather_store<NT, MTR>(xbuf(0), gv);
 
   // The work of a slot (one step t of one tile) is a chain of units u = (layer l, 16-row m-tile mt).  Unit u:
@@ -443,13 +444,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   };
 
   FPROBE(0)  // prologue: weights, first ids, first gather
-  int64_t tile = blockIdx.x;
+  int64_t tile = bx;
   int t = k0;
   int tpar = 0;  // parity of the tile's id buffer
   int64_t p_tile = tile;
   int p_t = t;
   int par = 0;
-  const int G = __builtin_amdgcn_readfirstlane((int)gridDim.x);   // (kept in a register: hipcc re-read it from the dispatch packet, with the wait, at every tile boundary)
+  const int G = __builtin_amdgcn_readfirstlane(G_);   // (kept in a register: hipcc re-read gridDim from the dispatch packet, with the wait, at every tile boundary)
   int k0_req = 0;   // the next tile's first step, requested a slot or more ahead of the tile boundary (per lane; made uniform there)
   for (int64_t s = 0;; ++s) {
     par = (int)(s & 1);
@@ -507,9 +508,21 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) {
   FPROBE(5)  // drain
   if (KPRN_PROBES_ON && a.timing && threadIdx.x == 0) {
     tacc[7] = __builtin_amdgcn_s_memtime() - tstart;
-    for (int k = 0; k < 12; ++k) a.timing[(int64_t)blockIdx.x * 12 + k] = tacc[k];
+    for (int k = 0; k < 12; ++k) a.timing[(int64_t)bx * 12 + k] = tacc[k];
   }
 #undef FPROBE
+}
+
+template <int L, bool SAVE, int NMT>
+__global__ __launch_bounds__(256, 1) void k_lstm_fwd(FwdArgs a) { fwd_body<L, SAVE, NMT>(a, (int)blockIdx.x, (int)gridDim.x); }
+
+// The training forward AND a scoring pass in ONE launch (option "score_dual"): workgroups [0, g0) are the training forward's, the rest the pass's -- two
+// branches of one kernel.  The dispatcher places the first g0 on the chip and hands the pass's workgroups the CUs as those retire: what the two streams
+// of "score_overlap" do, without the fork / join events between the streams (6-8 us of idle queue each: profiles/r06/kernel_timelines.txt).
+template <int L, int NMT>
+__global__ __launch_bounds__(256, 1) void k_lstm_fwd_dual(FwdArgs a0, FwdArgs a1, int g0) {
+  if ((int)blockIdx.x < g0) fwd_body<L, true, NMT>(a0, (int)blockIdx.x, g0);
+  else fwd_body<L, false, NMT>(a1, (int)blockIdx.x - g0, (int)gridDim.x - g0);
 }
 
 // ---- host side ----
@@ -586,13 +599,12 @@ static void launch_fwd(kprn_handle* h, const FwdArgs& a, int grid) {
 // tile_begin / tile_end (scoring only, tile_end < 0 = all): the pass restricted to a range of the batch's 64-path tiles -- a scoring pass split
 // in two around a data-parallel step's collective (kprn_set_option "score_split").  The kernel sees a shorter batch: the per-tile arrays are
 // handed over shifted, scores still land at their path's own row of S.
-void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin, int64_t tile_end, bool ignore_reserve) {
+// the arguments of one pass (S: where its scores go); false: nothing to launch (an empty tile range)
+static bool fwd_args(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin, int64_t tile_end, bool ignore_reserve, float* S, FwdArgs& a, int& grid,
+                     bool& small) {
   const kprn_config& c = h->cfg;
-  if (c.compute_dtype != 0) { forward_mc(h, b, save); return; }  // bf16 / f32x6: the matrix-core forward (lstm_fused_fwd_mc.hip)
   State* s = st(h);
   const int64_t N = (int64_t)b->B * b->P;
-  FwdArgs a;
-  prefix_forward(h, b);  // (cached while neither the parameters nor the batch change)
   a.idx = b->idx_s ? b->idx_s : b->idx; a.N = N; a.T = b->T; a.F = b->F; a.nT = c.num_types;
   a.perm = b->perm; a.tile_k = b->tile_k; a.pmeta = b->pmeta; a.pfb = s->pfb;
   a.Wt = h->dense + h->off_Wt; a.We = h->We; a.Wr = h->dense + h->off_Wr;
@@ -602,12 +614,12 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin,
     a.Wi[l] = h->dense + h->layer[ll].Wi; a.bi[l] = h->dense + h->layer[ll].bi; a.Wo[l] = h->dense + h->layer[ll].Wo;
   }
   a.Wout = h->dense + h->off_outW; a.bout = h->dense + h->off_outb; a.C = c.C;
-  a.S = h->ws.S;
-  const bool small = small_tiles(h, N, b->tile_k != nullptr);   // (c.L == 2: the only small-tile instantiation)
+  a.S = S;
+  small = small_tiles(h, N, b->tile_k != nullptr);   // (c.L == 2: the only small-tile instantiation)
   a.n_tiles = small ? (N + 15) / 16 : (N + MT - 1) / MT;
   if (!small && !save && (tile_begin > 0 || tile_end >= 0)) {
     const int64_t t0 = std::min<int64_t>(tile_begin, a.n_tiles), t1 = tile_end < 0 ? a.n_tiles : std::min<int64_t>(tile_end, a.n_tiles);
-    if (t1 <= t0) return;
+    if (t1 <= t0) return false;
     a.idx += t0 * MT * a.T * a.F;
     if (a.perm) a.perm += t0 * MT; else a.S += t0 * MT * (int64_t)c.C;
     if (a.tile_k) a.tile_k += t0;
@@ -628,10 +640,54 @@ void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin,
     a.save_frag = s->save_frag;
   }
   const int cus = (!save && h->reserve_cus > 0 && !ignore_reserve) ? std::max(1, s->num_cu - h->reserve_cus) : s->num_cu;
-  const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)cus);
+  grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)cus);
   static const bool want_timing = KPRN_DEV_ENV("KPRN_TIMING") != nullptr;
   if (want_timing && !s->timing) HIP_TRY(kprn_dev_malloc((void**)&s->timing, (size_t)s->num_cu * 12 * sizeof(unsigned long long)));
   a.timing = s->timing;
+  return true;
+}
+
+// The training forward of `bt` and a whole scoring pass over `bs` (scores to S_score) as one launch (k_lstm_fwd_dual); false: not applicable -- the caller
+// launches them the usual way.  Both passes read ONE identical-prefix table: the two batches must be the same one, or neither may have a plan.
+bool forward_dual(kprn_handle* h, const kprn_batch* bt, const kprn_batch* bs, float* S_score) {
+  const kprn_config& c = h->cfg;
+  State* s = st(h);
+  if (c.compute_dtype != 0 || c.L != 2 || !fwd_supported(h, bt->T) || !fwd_supported(h, bs->T) || s->timing) return false;
+  const bool same = bt->serial == bs->serial;
+  const bool planless = (!bt->tile_k || bt->h_kmax == 0) && (!bs->tile_k || bs->h_kmax == 0);
+  if (!same && !planless) return false;
+  FwdArgs a0, a1;
+  int g0 = 0, g1 = 0;
+  bool small0 = false, small1 = false;
+  prefix_forward(h, bt);
+  if (h->score_rest_batch != bs) return false;   // (a rewrite of the prefix table joins the scoring stream first: the deferred pass has then run the usual way)
+  if (!fwd_args(h, bt, true, 0, -1, false, h->ws.S, a0, g0, small0) || !fwd_args(h, bs, false, 0, -1, true, S_score, a1, g1, small1) || small0 != small1) return false;
+  a0.timing = a1.timing = nullptr;
+  const size_t lds_bytes = (size_t)(2 + 2 * 2) * MT * LDA * sizeof(float) + 2 * MT * MAXT_LDS * 4 * sizeof(int32_t) + (size_t)(KCAP + 1) * 2 * PFB * sizeof(float);
+  ProfScope ps(h, "lstm_fused_fwd_dual");
+  if (small0) {
+    static PerDeviceOnce once;
+    if (once.need()) HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd_dual<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((k_lstm_fwd_dual<2, 1>), dim3(g0 + g1), dim3(256), lds_bytes, h->stream, a0, a1, g0);
+  } else {
+    static PerDeviceOnce once;
+    if (once.need()) HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_fwd_dual<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((k_lstm_fwd_dual<2, 4>), dim3(g0 + g1), dim3(256), lds_bytes, h->stream, a0, a1, g0);
+  }
+  HIP_TRY(hipGetLastError());
+  return true;
+}
+
+void forward(kprn_handle* h, const kprn_batch* b, bool save, int64_t tile_begin, int64_t tile_end, bool ignore_reserve) {
+  const kprn_config& c = h->cfg;
+  if (c.compute_dtype != 0) { forward_mc(h, b, save); return; }  // bf16 / f32x6: the matrix-core forward (lstm_fused_fwd_mc.hip)
+  State* s = st(h);
+  const int64_t N = (int64_t)b->B * b->P;
+  FwdArgs a;
+  int grid = 0;
+  bool small = false;
+  prefix_forward(h, b);  // (cached while neither the parameters nor the batch change)
+  if (!fwd_args(h, b, save, tile_begin, tile_end, ignore_reserve, h->ws.S, a, grid, small)) return;
   ProfScope ps(h, save ? "lstm_fused_fwd_train" : "lstm_fused_fwd");
   if (c.L == 1) { if (save) launch_fwd<1, true>(h, a, grid); else launch_fwd<1, false>(h, a, grid); }
   else if (small) { if (save) launch_fwd<2, true, 1>(h, a, grid); else launch_fwd<2, false, 1>(h, a, grid); }

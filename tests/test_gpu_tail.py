@@ -123,3 +123,49 @@ def test_catch_up_and_prefix_table_in_one_launch_is_bit_identical_to_two():
         assert np.array_equal(a, b)
     assert np.array_equal(res[0][1], res[1][1])
     assert res[1][2] >= 6 and res[0][2] < res[1][2], (res[0][2:], res[1][2:])
+
+
+@pytest.mark.parametrize("pairs,P", [(3000, 4), (60, 4), (20000, 1)])
+def test_scoring_pass_in_the_training_forwards_launch_is_bit_identical(pairs, P):
+    """option "score_dual" (with "score_overlap"): a pass queued by kprn_forward_batch_async waits for the training forward that follows and runs as a second
+    branch of its kernel (eval/test_from_checkpoint.lua:109's forward and MyOptimizer.lua:177-221's, one launch).  64-path tiles, the 16-row tiles of small
+    batches, more tiles than workgroups; the pass's probabilities bit for bit those of the side-stream pass, the training step's loss and parameters equal
+    (the same kernels' arithmetic; entity-gradient atomics re-associate run to run).  A pass nobody trains behind is run the usual way when its result is read."""
+    idx, labels = synth.make_paths(pairs, P, T, Ve=30000, seed=21 + P)
+    res = []
+    for dual in ("1", "0"):
+        eng = _ffi.Engine(6, 30000, 9, 16, 32, 16, 64, 2)
+        eng.set_option("score_overlap", "1")
+        eng.set_option("score_dual", dual)
+        rng = np.random.default_rng(4)
+        eng.set_flat_params((rng.random(eng.n_params) * 0.2 - 0.1).astype(np.float32))
+        opt = _ffi.make_opt(method=1, lr=1e-3)
+        b = eng.batch(idx, labels)
+        probs, losses = [], []
+        eng.profile(True)
+        for k in range(3):
+            eng.forward_async(b, 1)
+            losses.append(eng.train_step(b, opt))
+            probs.append(eng.read_probs(b.B).copy())
+        fam = eng.profile_get()
+        assert ("lstm_fused_fwd_dual" in fam) == (dual == "1"), sorted(fam)
+        eng.forward_async(b, 1)                      # ... and a pass with no training forward behind it
+        probs.append(eng.read_probs(b.B).copy())
+        res.append((probs, losses, eng.get_flat_params().astype(np.float64)))
+        eng.close()
+    # the default ("2"): the one launch below the 16-row-tile threshold only
+    eng = _ffi.Engine(6, 30000, 9, 16, 32, 16, 64, 2)
+    eng.set_option("score_overlap", "1")
+    b = eng.batch(idx, labels)
+    opt = _ffi.make_opt(method=1, lr=1e-3)
+    eng.profile(True)
+    for _ in range(2):   # (a new engine's first step zeroes the pad rows first -- a parameter change: the queued pass runs ahead of it, the usual way)
+        eng.forward_async(b, 1)
+        eng.train_step(b, opt)
+    assert ("lstm_fused_fwd_dual" in eng.profile_get()) == (pairs * P < 8192)
+    eng.close()
+    assert np.array_equal(res[0][0][0], res[1][0][0])          # same parameters, same arithmetic: the first pass bit for bit
+    for a, c in zip(res[0][0][1:], res[1][0][1:]):
+        np.testing.assert_allclose(a, c, rtol=2e-5)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5)
+    assert float(np.max(np.abs(res[0][2] - res[1][2]))) < 2e-6
