@@ -469,7 +469,10 @@ static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool
         w.S = h->S2; w.sel = h->sel2;
         try { pool_stage(h, sb, h->score_rest_cid - 1, false); } catch (...) { w.S = S0; w.sel = sel0; throw; }
         w.S = S0; w.sel = sel0;
-        HIP_TRY(hipEventRecord(h->ev_score_done, h->stream));
+        // the pass is now part of THIS stream's order: nothing is pending on the side stream, and no event is recorded for it here (an event record is
+        // 6 us of idle queue in front of the loss stage at 256 paths) -- kprn_read_probs orders its copy behind this stream when somebody reads
+        h->score_pending = false;
+        h->score_on_main = true;
       }
     }
     if (!dual) fused::forward(h, b, save_for_backward);
@@ -1801,11 +1804,13 @@ int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_
       // way (join_score -> launch_score_rest)
       if (h->score_pending && h->ev_score_done) HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_score_done, 0));   // (an earlier pass wrote the same S2 / sel2)
       h->score_rest_batch = b; h->score_rest_cid = class_id; h->score_rest_tile0 = 0;
+      h->score_on_main = false;
       h->score_pending = true;
       h->last_forward_side = true;
       h->last_B = b->B;
       return KPRN_OK;
     }
+    h->score_on_main = false;
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_fork, 0));
     // an earlier pass (or its deferred part, which may have run on the rest stream: "score_rest_before_bptt") writes the same S2 / sel2: this pass
@@ -1893,6 +1898,10 @@ int kprn_read_probs(kprn_handle* h, float* probs, int32_t B) {
   if (h->last_forward_side) {
     if (h->score_rest_batch) launch_score_rest(h);
     // (the second part of a split pass may have run on the rest stream, and a join may already have cleared score_pending: the pass's event orders this copy)
+    if (h->score_on_main) {   // ("score_dual": the pass ran in a training forward's launch on the main stream)
+      HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+      HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_fork, 0));
+    } else
     if (h->ev_score_done) HIP_TRY(hipStreamWaitEvent(h->score_stream, h->ev_score_done, 0));
     HIP_TRY(hipMemcpyAsync(probs, h->sel2, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->score_stream));
     HIP_TRY(hipStreamSynchronize(h->score_stream));

@@ -247,6 +247,7 @@ struct kprn_handle {
   void (*after_bptt_hook)(kprn_handle*) = nullptr;   // (set by kprn_api.hip: lstm_fused_bwd.hip cannot see launch_score_rest)
   const kprn_batch* score_rest_batch = nullptr; int score_rest_cid = 1; int64_t score_rest_tile0 = 0;   // the deferred part of a split pass
   bool last_forward_side = false; // kprn_read_probs reads the side buffers
+  bool score_on_main = false;     // ... which the last pass filled from the MAIN stream ("score_dual")
   float* S2 = nullptr; float* sel2 = nullptr; int64_t cap_N2 = 0, cap_B2 = 0;
   int reserve_cus = 0;          // CUs the SCORING forward leaves free (a collective's copy kernels run beside it; kprn_set_option)
   int32_t last_B = 0;

@@ -10,7 +10,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # last full steps: find k_adam_rows occurrences (two per step: update, then next step's catch-up)
-idx = [i for i, n in enumerate(names) if "k_lstm_fwd<2, true" in n or "k_lstm_fwdILi2ELb1" in n]
+idx = [i for i, n in enumerate(names) if "k_lstm_fwd<2, true" in n or "k_lstm_fwdILi2ELb1" in n or "k_lstm_fwd_dual" in n]
 if len(idx) < 4: print("few steps", len(idx)); sys.exit(0)
 m = len(idx) // 2                 # (the middle of the trace = the timed region; the last steps of a --force-dp run belong to the region with events around the exchange)
 a, b = idx[m], idx[m + 2]         # two whole steps, from one training forward to the one after next
