@@ -408,7 +408,16 @@ __global__ __launch_bounds__(256) void k_loss_stage(const float* __restrict__ S,
                                                     int B, int P, int C, int H, int cid, int reducer, int K, int literal, float invB,
                                                     float* __restrict__ pooled, float* __restrict__ probs, float* __restrict__ sel,
                                                     float* __restrict__ dS, const int32_t* __restrict__ slot_of, float* __restrict__ gW_row,
-                                                    float* __restrict__ gb_c, float* __restrict__ partial, int n_loss_blocks, kk::TransposeJob tj, float* __restrict__ partial_host) {
+                                                    float* __restrict__ gb_c, float* __restrict__ partial, int n_loss_blocks, kk::TransposeJob tj, float* __restrict__ partial_host,
+                                                    kk::PoolJob pj) {
+  if ((int)blockIdx.x >= n_loss_blocks + 64 * tj.n) {  // (workgroup-uniform) passenger: the pooling stage of a scoring pass (k_pool_sel's arithmetic)
+    const int b = ((int)blockIdx.x - n_loss_blocks - 64 * tj.n) * 256 + (int)threadIdx.x;
+    if (b >= pj.B) return;
+    const float pr = sigmoidf_(reduce_col(pj.S + (int64_t)b * pj.P * C + pj.cid, pj.P, C, reducer, K));
+    pj.sel[b] = pr;
+    if (pj.sel_host) pj.sel_host[b] = pr;
+    return;
+  }
   if ((int)blockIdx.x >= n_loss_blocks) {  // (workgroup-uniform) the passenger job: 256x64 weight transposes
     const int rb = blockIdx.x - n_loss_blocks;
     const int m = rb >> 6, i = (rb & 63) * 256 + threadIdx.x;  // over the 64*256 outputs of matrix m
@@ -990,14 +999,18 @@ void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reduce
 
 void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
                 int literal, float invB, float* pooled, float* probs, float* sel, float* dS, const int32_t* slot_of, float* gW_row, float* gb_c,
-                float* partial, const TransposeJob* tj, float* partial_host) {
+                float* partial, const TransposeJob* tj, float* partial_host, const PoolJob* pj) {
   if (B <= 0) return;
   TransposeJob t;
   memset(&t, 0, sizeof(t));
   if (tj) t = *tj;
+  PoolJob pjob;
+  memset(&pjob, 0, sizeof(pjob));
+  if (pj) pjob = *pj;
   const int nlb = (B + LOSS_PPW - 1) / LOSS_PPW;
-  hipLaunchKernelGGL(k_loss_stage, dim3((unsigned)(nlb + 64 * t.n)), dim3(256), 0, s, S, labels, hT, B, P, C, H, cid, reducer, K, literal, invB,
-                     pooled, probs, sel, dS, slot_of, gW_row, gb_c, partial, nlb, t, partial_host);
+  const int npb = (pjob.B + 255) / 256;
+  hipLaunchKernelGGL(k_loss_stage, dim3((unsigned)(nlb + 64 * t.n + npb)), dim3(256), 0, s, S, labels, hT, B, P, C, H, cid, reducer, K, literal, invB,
+                     pooled, probs, sel, dS, slot_of, gW_row, gb_c, partial, nlb, t, partial_host, pjob);
   CHECK_LAUNCH();
 }
 

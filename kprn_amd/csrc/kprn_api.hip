@@ -464,11 +464,7 @@ static void forward_impl(kprn_handle* h, const kprn_batch* b, int class_id, bool
       dual = fused::forward_dual(h, b, sb, h->S2);
       if (dual) {
         h->score_rest_batch = nullptr;
-        Workspace& w = h->ws;
-        float* S0 = w.S; float* sel0 = w.sel;
-        w.S = h->S2; w.sel = h->sel2;
-        try { pool_stage(h, sb, h->score_rest_cid - 1, false); } catch (...) { w.S = S0; w.sel = sel0; throw; }
-        w.S = S0; w.sel = sel0;
+        h->pool_defer_batch = sb; h->pool_defer_cid = h->score_rest_cid - 1;   // (its pooling stage: more workgroups of the loss stage's launch, backward_impl)
         // the pass is now part of THIS stream's order: nothing is pending on the side stream, and no event is recorded for it here (an event record is
         // 6 us of idle queue in front of the loss stage at 256 paths) -- kprn_read_probs orders its copy behind this stream when somebody reads
         h->score_pending = false;
@@ -802,9 +798,11 @@ static void backward_impl(kprn_handle* h, const kprn_batch* b, int class_id, int
     float* gd = h->g_dense;
     kk::TransposeJob tj;  // fused path: the backward's W^T copies, stale after an update, are rebuilt by passenger workgroups
     const bool have_tj = fusedp && fused::transpose_job(h, &tj);
+    kk::PoolJob pj{h->S2, 0, 0, 0, h->sel2, nullptr};
+    if (h->pool_defer_batch) { pj.B = h->pool_defer_batch->B; pj.P = h->pool_defer_batch->P; pj.cid = h->pool_defer_cid; h->pool_defer_batch = nullptr; }
     kk::loss_stage(h->stream, h->score_buf, b->labels, /*hT=*/nullptr, b->B, b->P, c.C, c.H, cid, c.reducer, c.K, literal,
                    invB, /*pooled=*/nullptr, /*probs=*/nullptr, w.sel, w.dS, fusedp ? b->slot_of : nullptr, gd + h->off_outW + (int64_t)cid * c.H, gd + h->off_outb + cid, h->loss_partial,
-                   have_tj ? &tj : nullptr, h->loss_early_armed ? h->loss_mirror : nullptr);
+                   have_tj ? &tj : nullptr, h->loss_early_armed ? h->loss_mirror : nullptr, pj.B > 0 ? &pj : nullptr);
     h->loss_pending = kk::loss_partials(b->B);
     if (h->loss_early_armed) {   // what kprn_train_step_batch waits for instead of the end of the step
       h->loss_early_n = h->loss_pending;
@@ -1690,6 +1688,7 @@ void kprn_batch_destroy(kprn_handle* h, kprn_batch* b) {
     if (h->upload_stream) hipStreamSynchronize(h->upload_stream);
     if (h->feed_stream) hipStreamSynchronize(h->feed_stream);
     if (h->score_rest_batch == b) { try { launch_score_rest(h); } catch (...) { h->score_rest_batch = nullptr; } }   // (the deferred part of a split pass reads the batch)
+    if (h->pool_defer_batch == b) h->pool_defer_batch = nullptr;   // (a step that failed between its forward and its loss stage)
     if (h->score_stream) hipStreamSynchronize(h->score_stream);
   if (h->rest_stream) hipStreamSynchronize(h->rest_stream);  // a scoring pass on the second stream may still read the batch
     hipStreamSynchronize(h->stream);
@@ -1775,6 +1774,7 @@ extern "C" {
 int kprn_forward_batch_async(kprn_handle* h, const kprn_batch* b, int32_t class_id) {
   API_BEGIN(h)
   if (h->score_rest_batch) launch_score_rest(h);   // (the second part of an earlier split pass that nobody placed: before its buffers are reused)
+  h->pool_defer_batch = nullptr;
   h->last_forward_side = false;
   if (h->score_overlap && b && use_fused(h, b, false)) {
     // the pass goes to the side stream with its own output buffers; everything it reads is final on the main stream first

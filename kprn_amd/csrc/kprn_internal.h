@@ -248,6 +248,7 @@ struct kprn_handle {
   const kprn_batch* score_rest_batch = nullptr; int score_rest_cid = 1; int64_t score_rest_tile0 = 0;   // the deferred part of a split pass
   bool last_forward_side = false; // kprn_read_probs reads the side buffers
   bool score_on_main = false;     // ... which the last pass filled from the MAIN stream ("score_dual")
+  const kprn_batch* pool_defer_batch = nullptr; int pool_defer_cid = 0;   // ... and whose pooling stage rides in the loss stage's launch that follows
   float* S2 = nullptr; float* sel2 = nullptr; int64_t cap_N2 = 0, cap_B2 = 0;
   int reserve_cus = 0;          // CUs the SCORING forward leaves free (a collective's copy kernels run beside it; kprn_set_option)
   int32_t last_B = 0;
@@ -295,10 +296,13 @@ void pool_sigmoid(hipStream_t s, const float* S, int B, int P, int C, int reduce
 // A second, independent job the loss-stage launch can carry in extra workgroups: WT[m] = W[m]^T for up to four [256][64]
 // matrices (the fused backward's transposed LSTM weights, stale after every update).
 struct TransposeJob { const float* W[4]; float* WT[4]; int n; };
+// ... and the pooling stage of a scoring pass that ran in the training forward's launch ("score_dual"): reducer + sigmoid + select of ITS batch, as more
+// workgroups of the loss stage's launch (B = 0: none)
+struct PoolJob { const float* S; int B, P, cid; float* sel; float* sel_host; };
 // (partial_host: optional page-locked mirror of the per-workgroup loss partials)
 void loss_stage(hipStream_t s, const float* S, const float* labels, const float* hT, int B, int P, int C, int H, int cid, int reducer, int K,
                 int literal, float invB, float* pooled, float* probs, float* sel, float* dS, const int32_t* slot_of /*nullable: dS[slot_of[n]]*/,
-                float* gW_row, float* gb_c, float* partial, const TransposeJob* tj = nullptr, float* partial_host = nullptr);
+                float* gW_row, float* gb_c, float* partial, const TransposeJob* tj = nullptr, float* partial_host = nullptr, const PoolJob* pj = nullptr);
 void sum_partials(hipStream_t s, const float* partial, int n, float* out, int accumulate);
 int loss_partials(int B);  // number of per-workgroup loss partials the loss stage writes for B pairs
 void zero_pad3(hipStream_t s, float* a, int na, float* b, int nb, float* c, int nc);
