@@ -70,10 +70,11 @@ def test_register_spills_of_the_persistent_kernels():
     # ... and what is spilled stays out of the step bodies: the blocks that hold a step's MFMAs (the recurrent step of the backward: 416 + 3 x 32 + 512, its
     # last step 2 x 256; the forward's slots: 1024 / 8 x 68) write nothing to scratch and reload at most one register (the early / late hand-over pieces are
     # further instantiations of the same bodies: every copy is checked)
-    for f, pat in (("lstm_fused_bwd.hip", r"k_lstm_bwdIL"), ("lstm_fused_fwd.hip", r"k_lstm_fwdIL")):
+    # (round 6: k_lstm_fwd_dual holds BOTH forward bodies as two branches -- each must stay as clean as the kernel of its own)
+    for f, pat, need in (("lstm_fused_bwd.hip", r"k_lstm_bwdIL", 2), ("lstm_fused_fwd.hip", r"k_lstm_fwdIL", 2), ("lstm_fused_fwd.hip", r"k_lstm_fwd_dualIL", 1)):
         text = chk.compile_isa(os.path.join(CSRC, f))
         seen = 0
-        for km in re.finditer(r"\n(_ZN5fused10" + pat + r"\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S):
+        for km in re.finditer(r"\n(_ZN5fused\d+" + pat + r"\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S):
             if "Li4EEEv" not in km.group(1):
                 continue   # (the 16-row small-batch instantiations have registers to spare)
             blocks = re.split(r"\n\.LBB\d+_\d+:", km.group(2))
@@ -83,7 +84,7 @@ def test_register_spills_of_the_persistent_kernels():
                 assert not re.findall(r"scratch_store", b), km.group(1)
                 assert len(re.findall(r"scratch_load", b)) <= (4 if "bwdILb1E" in km.group(1) else 1), km.group(1)
             seen += 1
-        assert seen >= 2, f
+        assert seen >= need, (f, pat)
 
 
 def test_persistent_bptt_kernel_keeps_its_state_in_registers():
