@@ -332,6 +332,8 @@ int kprn_profile_get(kprn_handle* h, kprn_prof_entry* out, int32_t cap, int32_t*
  *                     G - 1 - b; "0": whole tiles only).  Same gradients up to fp32 re-association of the weight-gradient partial sums; see
  *                     kprn_batch_handover_stats, DESIGN.md section 3.3b
  *   "adam_merged"     "1" (default) | "0": lazy-exact Adam updates the touched entity rows and the dense arena in one launch (bit-identical to two)
+ *   "bwd_pipe"        "1" (default) | "0": fused path, batches of 16-row tiles, two layers: both layers' BPTT in one launch, the bottom layer a step behind
+ *                     the top layer | one launch per layer
  *   "score_dual"      "2" (default) | "1" | "0": with "score_overlap": a pass queued by kprn_forward_batch_async is held back and runs in the launch of the
  *                     training forward that follows (one kernel, no second stream) -- for batches below 8 192 paths | always | never; anything that needs
  *                     the pass earlier runs it the usual way

@@ -2516,6 +2516,10 @@ int kprn_set_option(kprn_handle* h, const char* key, const char* value) {
   } else if (strcmp(key, "adam_merged") == 0) {
     // lazy-exact Adam: the entity rows' update and the dense arena's update in ONE launch ("1", default) or in two ("0": the A/B reference; bit-identical)
     h->adam_merged = atoi(value) != 0;
+  } else if (strcmp(key, "bwd_pipe") == 0) {
+    // fused path, small batches (16-row tiles), two layers: both layers' BPTT as ONE launch with the bottom layer one step behind the top layer ("1", default)
+    // or as two launches ("0": the A/B reference)
+    h->bwd_pipe = atoi(value) != 0;
   } else if (strcmp(key, "score_dual") == 0) {
     // with "score_overlap": a scoring pass queued by kprn_forward_batch_async is held back and runs in the launch of the training forward that follows
     // (one kernel, two branches: no second stream, no fork / join events) -- "1": always, "2" (default): for batches below the 16-row-tile threshold

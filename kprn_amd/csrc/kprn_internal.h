@@ -232,6 +232,7 @@ struct kprn_handle {
   // call then fails instead of returning numbers computed from a stale slot
   int tile_handover = 2; int* ho_fault = nullptr;
   bool adam_merged = true;        // option "adam_merged": the row update and the dense arena's update of an Adam step in one launch
+  bool bwd_pipe = true;           // option "bwd_pipe": small batches, two layers: both layers' BPTT in one launch, the bottom layer a step behind the top layer
   int score_dual = 2;             // option "score_dual": a queued scoring pass rides in the next training forward's launch (fused::forward_dual): 0 never | 1 always | 2 small batches
   bool catchup_prefix = true;     // option "catchup_prefix": a batch's row catch-up and its identical-prefix table in one launch (fused path)
   bool fused_small_tables = true; // option "fused_small_tables": the fused path's type / relation table gradients formed inside the bottom BPTT launch (one-hot MFMAs on dx)

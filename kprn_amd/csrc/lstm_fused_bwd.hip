@@ -54,6 +54,10 @@ struct BwdArgs {
   float* PG;               // [KCAP+1][PFB] this layer: sum over rows of dA at the tile's first executed step | of dc handed below it
   HoArgs ho;               // time-split tile hand-over (lstm_fused_common.h ho_plan)
   int small_lds;           // bottom layer: the type / relation table gradients are formed inside this launch (one-hot MFMAs on dx; option "fused_small_tables")
+  // layer pipeline of small batches (k_lstm_bwd_dual): both layers' workgroups are resident at once, the top layer's publish dx of (tile, step) as soon as it
+  // is stored, the bottom layer's wait for it step by step -- the bottom layer runs ONE step behind the top layer instead of a whole launch behind
+  unsigned* pipe_flag;     // [n_tiles][MAXT_LDS] epoch (ho.epoch) of the dx of (tile, absolute step)
+  int pipe;                // 0: no pipeline; 1: producer (top layer); 2: consumer (bottom layer)
 };
 
 
@@ -83,8 +87,9 @@ struct Pre {
 };
 
 // NMT: 16-row m-tiles of a tile -- 4, or 1 for small batches (fused::small_tiles; no identical-prefix plan there)
+// bx / G_: this workgroup's index among, and the number of, the workgroups of THIS layer's pass (k_lstm_bwd: the launch's; k_lstm_bwd_dual: half of it)
 template <bool BOTTOM, bool TOP, int NMT>
-__global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
+__device__ __forceinline__ void bwd_body(const BwdArgs& a, const int bx, const int G_) {
   constexpr int MTR = 16 * NMT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   const int arow = lane & 15, ag = lane >> 4;
   const int T = a.T, L = a.L, ly = a.layer;
   // (first thing in the kernel: its one round trip is in flight under the weight loads below)
-  const HoPlan ho = ho_plan(a.ho, a.tile_k, a.n_tiles, T);
+  const HoPlan ho = ho_plan(a.ho, a.tile_k, a.n_tiles, T, 1, bx, G_);
 
   // ---- AGPR residents: this wave's slice of [W_i2g^T | W_o2g^T] (stage E's B operand) and the dW accumulators
   //      dwi/dwo[q][nt][r] <-> dW row q*64 + 16j + 4ag + r, col 16nt + arow
@@ -148,14 +153,14 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   // recent ones are the likeliest to still be there.  Bottom layer: first tile first -- by then the top layer's launch has streamed
   // every plane of ITS layer through the cache, and what is recent is the dx the top layer wrote last, i.e. of its first tiles.
   // (0.319 -> 0.312 ms per launch.)
-  const int64_t n_mine = (a.n_tiles > (int64_t)blockIdx.x) ? (a.n_tiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+  const int64_t n_mine = (a.n_tiles > (int64_t)bx) ? (a.n_tiles - 1 - bx) / G_ + 1 : 0;
   // Time-split hand-over (lstm_fused_common.h ho_plan): the LIGHT workgroup of a pair runs the first ho.d steps (T-1 .. T-d) of the heavy one's
   // first tile before its own tiles and publishes (dh, dc); the HEAVY one keeps that tile for last and resumes it at step T-d-1.
   float* const ho_slot = a.ho.state + (int64_t)ho.slot * HO_STATE + threadIdx.x * 4;   // [dh | dc][NMT][256 threads][4]
   // the pair's tile is the heavy workgroup's first one (ti = 0): last in the top layer's order anyway, moved to the end of the bottom layer's
   auto own_of = [&](const int64_t it) -> int64_t {
     const int64_t ti = TOP ? n_mine - 1 - it : ((ho.role == 1) ? (it + 1 < n_mine ? it + 1 : 0) : it);
-    return (int64_t)blockIdx.x + ti * gridDim.x;
+    return (int64_t)bx + ti * G_;
   };
   // A tile's start used to be a chain of round trips with the matrix pipe idle: its first step (tile_k), its ids -> LDS, its first x rows.  The first two
   // are now requested while the tile BEFORE runs (round 6): the ids by LDS-DMA into the other id buffer, tile_k into one register.
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   if (n_mine > 0) request_tile(ho.role == 2 ? ho.tile : own_of(0), 0);
   for (int64_t it = 0; it < n_mine; ++it) {
     const int64_t own_tile = own_of(it);
-    const bool late = ho.role == 1 && own_tile == (int64_t)blockIdx.x;    // the late piece of the pair's tile: starts from the stored state
+    const bool late = ho.role == 1 && own_tile == (int64_t)bx;    // the late piece of the pair's tile: starts from the stored state
     const bool early = ho.role == 2 && it == 0;   // the early piece of the pair's tile rides IN FRONT of this workgroup's first own tile:
     // its ho.d recurrent steps run through the same recurrent loop, and a rare block between two steps stores the state and re-points everything
     // at the own tile.  (Nothing here skips a block of MFMAs: every way of leaving the tile's step 0 out -- if / else, continue, a loop with an
@@ -200,7 +205,21 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
     auto load_P = [&](int mt, int t) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) P[k] = *(const f32x4*)frag_ptr(mt, t, ly, j, k);
-      if (!TOP) up = *(const f32x4*)(dx_tile + (mt * T + t) * 1024);
+      if constexpr (!TOP && NMT == 1) {
+        if (a.pipe == 2) {   // (layer pipeline: the top layer's workgroup of this tile is a step or so ahead, in this very launch)
+          const unsigned* fl = a.pipe_flag + tile * MAXT_LDS + (k0 + t);
+          const long long t0 = wall_clock64();
+          while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.ho.epoch) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > HO_TIMEOUT_TICKS) {
+              if (threadIdx.x == 0) __hip_atomic_store(a.ho.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              break;
+            }
+          }
+          asm volatile("" ::: "memory");
+          up = ho_load4(dx_tile + (mt * T + t) * 1024);
+        } else up = *(const f32x4*)(dx_tile + (mt * T + t) * 1024);
+      } else if (!TOP) up = *(const f32x4*)(dx_tile + (mt * T + t) * 1024);
     };
     auto load_B = [&](int nt, int mt, int t, bool has_hp) {
       if (!BOTTOM) bin[nt] = *(const f32x4*)frag_ptr(mt, t, ly - 1, nt, 6);
@@ -395,6 +414,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         // 1 KiB per instruction; in place -- this thread read this very slot as `up` at the start of the step.
         // Rows past N: exact zeros (dA = 0 there).
         // (with the small tables' gradients formed below, nobody reads the type / relation slices of the bottom layer's dx: not stored)
+        if constexpr (TOP && !BOTTOM && NMT == 1) {
+          if (a.pipe == 1) ho_store4(dx_tile + (mt * T + t) * 1024, ax[mt]);   // (read by another CU of this launch: agent scope)
+          else *(f32x4*)(dx_tile + (mt * T + t) * 1024) = ax[mt];
+        } else
         if (!compact && !(BOTTOM && a.small_lds && wcls != 1)) *(f32x4*)(dx_tile + (mt * T + t) * 1024) = ax[mt];
       }
       if (compact) {
@@ -430,7 +453,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
         asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]));
       }
       TPROBE(4)  // stage E (dX MFMAs) + outputs
+      if constexpr (TOP && !BOTTOM && NMT == 1) {
+        if (a.pipe == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's dx stores have been acknowledged (everything older has long landed)
+      }
       lds_barrier();  // dA_t free for reuse, x_{t-1} tile visible
+      if constexpr (TOP && !BOTTOM && NMT == 1) {
+        if (a.pipe == 1 && tid == 0) __hip_atomic_store(a.pipe_flag + tile * MAXT_LDS + (k0 + t), a.ho.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       TPROBE(5)  // end barrier
     };
     int tt_sw = early ? Te - ho.d : -1;   // the early piece's last step
@@ -490,7 +519,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) KPRN_PIN_A8(dwi[q], dwo[q]);
   {
-    float* pw = a.part + (int64_t)blockIdx.x * PART;
+    float* pw = a.part + (int64_t)bx * PART;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -520,8 +549,20 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) {
   }
   TPROBE(6)  // flush
   if (KPRN_PROBES_ON && a.timing && tid == 0) {
-    for (int k = 0; k < 8; ++k) a.timing[(int64_t)blockIdx.x * 8 + k] = tacc[k];
+    for (int k = 0; k < 8; ++k) a.timing[(int64_t)bx * 8 + k] = tacc[k];
   }
+}
+
+template <bool BOTTOM, bool TOP, int NMT>
+__global__ __launch_bounds__(256, 1) void k_lstm_bwd(BwdArgs a) { bwd_body<BOTTOM, TOP, NMT>(a, (int)blockIdx.x, (int)gridDim.x); }
+
+// Two layers, small batches: BOTH layers' BPTT in one launch, workgroups [0, g) the top layer's, [g, 2 g) the bottom layer's, all resident at once (the host
+// launches this only when 2 g <= the CUs: a bottom-layer workgroup that waits must never keep a top-layer one off the chip).  The bottom layer runs one step
+// behind the top layer (BwdArgs.pipe): a 16-row tile's BPTT is a latency chain per layer, and the two chains overlap instead of following each other.
+template <int NMT>
+__global__ __launch_bounds__(256, 1) void k_lstm_bwd_dual(BwdArgs top, BwdArgs bottom, int g) {
+  if ((int)blockIdx.x < g) bwd_body<false, true, NMT>(top, (int)blockIdx.x, g);
+  else bwd_body<true, false, NMT>(bottom, (int)blockIdx.x - g, g);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -743,8 +784,10 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
   bool have_r1 = false, reduced = false;
   std::unique_ptr<ProfScope> bwd_scope;
   bidx::SlabReduce ra;
+  BwdArgs pipe_top;
   for (int l = L - 1; l >= 0; --l) {
     BwdArgs a;
+    a.pipe = 0; a.pipe_flag = nullptr;
     a.idx = b->idx_s ? b->idx_s : b->idx; a.N = N; a.T = T; a.F = b->F; a.nT = c.num_types;
     a.tile_k = b->tile_k; a.PG = s->PG + (size_t)l * (KCAP + 1) * PFB;
     a.Wt = h->dense + h->off_Wt; a.We = h->We; a.Wr = h->dense + h->off_Wr;
@@ -774,6 +817,24 @@ void backward(kprn_handle* h, const kprn_batch* b, int cid) {
     {
       // one event pair around the L back-to-back launches of the family (an event pair costs ~4 us of stream time)
       if (top) { bwd_scope.reset(new ProfScope(h, "lstm_fused_bwd")); bwd_scope->launches = L; }
+      // small batches, two layers, both layers' workgroups fit the chip at once: ONE launch, the bottom layer a step behind the top layer (k_lstm_bwd_dual)
+      const bool pipe = small && L == 2 && 2 * grid <= s->num_cu && h->bwd_pipe && !s->timing && a.ho.fault != nullptr;
+      if (pipe && top) {
+        if (!s->pipe_flag) {
+          HIP_TRY(kprn_dev_malloc((void**)&s->pipe_flag, (size_t)s->num_cu * MAXT_LDS * sizeof(unsigned)));
+          HIP_TRY(hipMemsetAsync(s->pipe_flag, 0, (size_t)s->num_cu * MAXT_LDS * sizeof(unsigned), strm));
+        }
+        a.pipe = 1; a.pipe_flag = s->pipe_flag;
+        pipe_top = a;   // (launched with the bottom layer's, below)
+        bwd_scope->launches = 1;
+      } else if (pipe && bottom) {
+        a.pipe = 2; a.pipe_flag = s->pipe_flag; a.ho = pipe_top.ho;   // (one epoch for the pair)
+        size_t lds_bytes = (size_t)MT * LDD * sizeof(float) + (size_t)MT * LDA * sizeof(float) + 2 * (MT * MAXT_LDS * 4) * sizeof(int32_t) + (size_t)(KCAP + 1) * PFB * sizeof(float);
+        static PerDeviceOnce once;
+        if (once.need()) HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_bwd_dual<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((k_lstm_bwd_dual<1>), dim3(2 * grid), dim3(256), lds_bytes, h->stream, pipe_top, a, grid);
+        HIP_TRY(hipGetLastError());
+      } else
       if (small) { if (bottom) launch_bwd<true, false, 1>(h, a, grid); else launch_bwd<false, true, 1>(h, a, grid); }   // (L == 2)
       else if (bottom && top) launch_bwd<true, true>(h, a, grid);
       else if (bottom) launch_bwd<true, false>(h, a, grid);
@@ -872,7 +933,7 @@ void release(kprn_handle* h) {
   if (!s) return;
   for (float* p : {s->save_frag, s->WT, s->DX, s->DXe, s->part, s->part_small, s->pfb, s->pfs, s->pfx, s->PG, s->r1, s->mc_bias, s->mc_hseq[0], s->mc_hseq[1],
                    s->ho_state[0], s->ho_state[1]}) if (p) hipFree(p);
-  for (unsigned* p : {s->ho_flag[0], s->ho_flag[1]}) if (p) hipFree(p);
+  for (unsigned* p : {s->ho_flag[0], s->ho_flag[1], s->pipe_flag}) if (p) hipFree(p);
   if (s->mc_wsp) hipFree(s->mc_wsp);
   if (s->timing) hipFree(s->timing);
   delete s;

@@ -299,8 +299,7 @@ inline HoPlan ho_plan_host(bool on, int mode, int G, int bx, int64_t n_tiles, in
 }
 // device form: ONE round trip -- lane i < 32 of every wave reads the prefix length of this workgroup's i-th tile, lane 32 + i of the pair's, and the two sums
 // are wave reductions.  (Read tile after tile it was eight dependent loads in front of every workgroup's first tile: 4 us, 1.5 % of the launch.)
-__device__ __forceinline__ HoPlan ho_plan(const HoArgs& ho, const int32_t* tile_k, int64_t n_tiles, int T, int keep = 1) {
-  const int G = gridDim.x, bx = blockIdx.x;
+__device__ __forceinline__ HoPlan ho_plan(const HoArgs& ho, const int32_t* tile_k, int64_t n_tiles, int T, int keep, const int bx, const int G) {
   const int px = ho_partner(ho.mode, G, bx);
   if (!ho.epoch || px == bx || (n_tiles + G - 1) / G > 32) return HoPlan{0, 0, -1, 0};
   const int lane = threadIdx.x & 63, i = lane & 31;
@@ -352,6 +351,7 @@ __device__ __forceinline__ void ho_wait(const HoArgs& ho, int slot) {
 // ---- host-side state shared by forward() and backward() ----
 struct State {
   float* save_frag = nullptr;
+  unsigned* pipe_flag = nullptr;   // layer pipeline of the small-batch BPTT launch: [num_cu][MAXT_LDS] epochs
   int64_t cap_N = 0;
   int cap_T = 0;
   int num_cu = 0;

@@ -1,5 +1,5 @@
 """Repeat-run stress of the round-6 paths whose failures would be races, not arithmetic: LDS-DMA id staging one tile ahead (forward and bottom BPTT launch),
-the time-split tile hand-over, the small tables' gradients inside the bottom launch, the scoring pass inside the training forward's launch.  Every repeat is
+the time-split tile hand-over, the small tables' gradients inside the bottom launch, the scoring pass inside the training forward's launch, both layers' BPTT in one launch (the bottom layer's workgroups waiting on the top layer's flags).  Every repeat is
 compared with the f64 oracle (gradients) or with the first repeat (scores: bit for bit).  REPS=40 python scripts/gpu_stress_r6.py"""
 import os
 import sys

@@ -169,3 +169,34 @@ def test_scoring_pass_in_the_training_forwards_launch_is_bit_identical(pairs, P)
         np.testing.assert_allclose(a, c, rtol=2e-5)
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5)
     assert float(np.max(np.abs(res[0][2] - res[1][2]))) < 2e-6
+
+
+@pytest.mark.parametrize("pairs,P", [(60, 4), (500, 4), (8, 2)])
+def test_both_layers_bptt_in_one_launch_equals_one_launch_per_layer(pairs, P):
+    """option "bwd_pipe" (default): at batches of 16-row tiles whose two layers' workgroups fit the chip together, BPTT through both FastLSTM layers
+    (model/OneModel.lua:236,268-274 backward) is ONE launch -- the bottom layer's workgroup of a tile waits, step by step, for the dx the top layer's
+    workgroup of the same tile has just published -- instead of one launch per layer.  The same arithmetic in the same order per tile: every gradient
+    equal to what the atomics of the embedding backward re-associate, and the pipeline really is one launch."""
+    idx, labels = synth.make_paths(pairs, P, T, Ve=30000, seed=33 + pairs)
+    res = []
+    for pipe in ("1", "0"):
+        eng = _ffi.Engine(6, 30000, 9, 16, 32, 16, 64, 2)
+        eng.set_option("small_tiles", "1")
+        eng.set_option("bwd_pipe", pipe)
+        rng = np.random.default_rng(5)
+        eng.set_flat_params((rng.random(eng.n_params) * 0.2 - 0.1).astype(np.float32))
+        b = eng.batch(idx, labels)
+        eng.forward(b, 1, want=("probs",))
+        eng.profile(True)
+        losses = [eng.backward(b, 1) for _ in range(3)]          # (three times: the epoch of the flags moves on)
+        fam = eng.profile_get()
+        res.append((eng.get_flat_grads().astype(np.float64), eng.layout(), losses, fam["lstm_fused_bwd"]))
+        eng.close()
+    (g1, lay, l1, f1), (g0, _, l0, f0) = res
+    assert l1 == l0
+    for nm, (off, shp) in lay.items():
+        n = int(np.prod(shp))
+        a, c = g1[off:off + n], g0[off:off + n]
+        assert float(np.max(np.abs(a - c))) <= 2e-6 * max(1e-30, float(np.max(np.abs(c)))), nm
+    if pairs * P > 16:     # (one tile: a single workgroup per layer, launched the usual way)
+        assert f1[1] < f0[1], (f1, f0)   # launches recorded for the family: 3 x 1 against 3 x 2
