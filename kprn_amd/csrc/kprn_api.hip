@@ -309,6 +309,13 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b, bool save) {
       float* hs = w.Hs + (int64_t)l * T * N * H;
       const float* Wo = h->dense + h->layer[l].Wo;
       const float* Uc = h->dense + h->layer[l].Uc;
+      if (!bf && h->persist_layers && lp32::supported(2, N, Din, H, h->persist_layers == 2)) {
+        // all T steps of the layer -- both dependent products of a step -- in ONE persistent launch (layer_f32_persist.hip, CELL 2)
+        ProfScope ps(h, "gru_layer_fwd");
+        lp32::forward_layer(s, 2, in, N, T, Din, H, h->dense + h->layer[l].Wi, Wo, h->dense + h->layer[l].bi, nullptr, hs, nullptr, act, nullptr, 0, save,
+                            /*write_all_h=*/l < L - 1, h->dense + h->layer[l].Wc, Uc, h->dense + h->layer[l].bc);
+        continue;
+      }
       {
         ProfScope ps(h, "gemm_i2g_fwd");
         gemm::run(s, in, Din, 1, h->dense + h->layer[l].Wi, 1, Din, act, 4 * H, (int64_t)T * N, 2 * H, Din, false, h->dense + h->layer[l].bi, 1, bf);

@@ -555,11 +555,13 @@ void build(const Shape& g, const int32_t* idx, int kcap, int nth, bool want_inde
 
 // ---- one recurrent layer, all T steps, as ONE persistent fp32 launch (layer_f32_persist.hip): the wide shapes of the generic pipeline -------------
 namespace lp32 {
-bool supported(int cell /*0 FastLSTM, 1 rnn*/, int64_t N, int Din, int H, bool force /*any N (tests)*/);
+bool supported(int cell /*0 FastLSTM, 1 rnn, 2 gru*/, int64_t N, int Din, int H, bool force /*any N (tests)*/);
 // in [T][N][Din]; hs [T][N][H] (every step when save or write_all_h, else the last one); save: cs + gate values [T][N][4H] (FastLSTM) / pre-activations
 // [T][N][H] (rnn) in the generic backward's layouts; mask [T][N] (rnn: MaskZero)
 void forward_layer(hipStream_t s, int cell, const float* in, int64_t N, int T, int Din, int H, const float* Wi, const float* Wo, const float* bi, const float* bo,
-                   float* hs, float* cs, float* act, const float* mask, int relu, bool save, bool write_all_h);
+                   float* hs, float* cs, float* act, const float* mask, int relu, bool save, bool write_all_h, const float* Wc = nullptr /*gru: c_i2h.weight*/,
+                   const float* Uc = nullptr /*gru: c_h2h.weight*/, const float* bc = nullptr /*gru: c_i2h.bias*/);
+// (gru: Wi / bi / Wo are i2g.weight [2H][Din] / i2g.bias / o2g.weight [2H][H]; act [T][N][4H] = [r | z | n | r * h'] when save)
 // BPTT through the layer (cell backward of all T steps + dh_{t-1} = dA_t W_o2g) as one persistent launch; dA [T][N][GH] out (GH = 4H FastLSTM, H rnn)
 bool bptt_supported(int cell, int64_t N, int H, bool force);
 size_t bptt_scratch_floats(int H, int GH);

@@ -37,6 +37,7 @@ struct LArgs {
   const float* in; int64_t N; int T; int Din; int H;
   const float* Wi; const float* Wo; const float* bi; const float* bo;
   float* hs; float* cs; float* act; const float* mask;
+  const float* Wc; const float* Uc; const float* bc;   // gru: the candidate's maps (c_i2h weight / bias, c_h2h)
   int relu, write_all_h;
   int64_t tiles;
   int KX, KH, PITCH, R;
@@ -73,8 +74,15 @@ __device__ __forceinline__ void store4(float* __restrict__ p, const f32x4 v, int
 }
 
 // CELL 0: FastLSTM (gate rows i, g, f, o of W: row q H + u), NCH chunks of 64 hidden units.  CELL 1: rnn, one chunk of 256 units (NCH = 1).
+// CELL 2: nn.GRU (OneModel.lua:237-238), NCH chunks of 64 units in the FastLSTM lane layout.  A step has two DEPENDENT products -- [r; z] = sigmoid(i2g x + o2g h'),
+// then n = tanh(c_i2h x + c_h2h (r * h')) -- so it runs as (NCH + 1) / 2 passes over [x_t | h_{t-1}] whose four n-tiles are the r and z rows of TWO chunks,
+// the cell's first half (r, z, r * h' -- h' is still in this lane's registers from the step before), a barrier pair around r * h' taking h_{t-1}'s place in
+// the LDS tile, and ONE pass whose four n-tiles are the candidate rows of the four chunks over [x_t | r * h']: every MFMA of the step does wanted work at H > 192,
+// the weight stream and its ring are the other cells'.  Saves in the per-step pipeline's record: act [T][N][4H] = [r | z | n | r * h'], h [T][N][H].
 template <int CELL, int NCH, bool SAVE>
 __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
+  constexpr int NPR = (NCH + 1) / 2;                        // gru: passes over the [r; z] rows
+  constexpr int NPASS = (CELL == 2) ? NPR + 1 : NCH;        // products (accumulator fills) per step
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   float* const At = (float*)smem;                                  // [64][PITCH]: x_t | h_{t-1} (pad columns zero)
   const int tid = threadIdx.x, lane = tid & 63, arow = lane & 15, ag = lane >> 4;
@@ -92,9 +100,15 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
 
   // ---- weight rows of this lane's four n-tiles
   auto wrow = [&](int q, int c) -> int {
-    int u = (CELL == 0) ? 64 * c + 16 * w + arow : 256 * c + 64 * w + 16 * q + arow;
+    int u;
+    if (CELL == 0) u = 64 * c + 16 * w + arow;
+    else if (CELL == 1) u = 256 * c + 64 * w + 16 * q + arow;
+    else if (c < NPR) u = 64 * std::min(2 * c + (q >> 1), NCH - 1) + 16 * w + arow;   // gru: n-tiles r, z of chunk 2 c, r, z of chunk 2 c + 1
+    else u = 64 * q + 16 * w + arow;                                                   // gru: candidate rows of chunk q
     if (u >= H) u = H - 1;   // (units past H: any valid row, the result is dropped)
-    return (CELL == 0) ? q * H + u : u;
+    if (CELL == 0) return q * H + u;
+    if (CELL == 2 && c < NPR) return (q & 1) * H + u;
+    return u;
   };
   // ---- the DMA stream: groups in the order they are consumed.  Cursor of the NEXT group to request: (tile, step, chunk, segment, group).
   int l_tile = t_beg, l_t = 0, l_c = 0, l_seg = 0, l_g = 0;
@@ -102,6 +116,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
   const float* wp[4];         // this lane's source of the next group, per n-tile
   auto l_setup = [&]() {
     const float* base = l_seg ? a.Wo : a.Wi;
+    if (CELL == 2 && l_c == NPR) base = l_seg ? a.Uc : a.Wc;
     const int ld = l_seg ? H : Din;
 #pragma unroll
     for (int q = 0; q < 4; ++q) wp[q] = base + (int64_t)wrow(q, l_c) * ld + 4 * ag;
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
       if (l_seg == 0 && l_t > 0) l_seg = 1;
       else {
         l_seg = 0;
-        if (++l_c == NCH) { l_c = 0; if (++l_t == T) { l_t = 0; ++l_tile; } }
+        if (++l_c == NPASS) { l_c = 0; if (++l_t == T) { l_t = 0; ++l_tile; } }
       }
       l_setup();
     }
@@ -195,7 +210,14 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int64_t row0 = (int64_t)tile * ROWS;
     f32x4 cst[CELL == 0 ? NCH : 1][4];   // FastLSTM: c_t of this lane's quads
-    f32x4 hn[CELL == 0 ? NCH : 4][4];    // h_t of the step (written to LDS behind the step's last MFMA)
+    f32x4 hn[CELL == 1 ? 4 : NCH][4];    // h_t of the step (written to LDS behind the step's last MFMA)
+    f32x4 zst[CELL == 2 ? NCH : 1][4], rh[CELL == 2 ? NCH : 1][4];   // gru: z_t and r_t * h_{t-1} between the two halves of the cell
+    if constexpr (CELL == 2) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hn[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int c = 0; c < (CELL == 0 ? NCH : 1); ++c)
 #pragma unroll
@@ -204,7 +226,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
     x_store();
     bar();
     for (int t = 0; t < T; ++t) {
-      if (t + 1 < T) x_request(row0, t + 1);
+      if (CELL != 2 && t + 1 < T) x_request(row0, t + 1);   // (gru: behind the cell's first half, when r * h' has left its registers)
       float mk[4];
       if (CELL == 1) {
 #pragma unroll
@@ -220,7 +242,24 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
       read_b(0, c_slot);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
+      for (int c = 0; c < NPASS; ++c) {
+        if constexpr (CELL == 2) {
+          if (c == NPR) {
+            if (t > 0) {
+              bar();   // every wave has read h_{t-1} for the last time: r * h' takes its place (the candidate's recurrent operand)
+#pragma unroll
+              for (int ch = 0; ch < NCH; ++ch) {
+                const int u0 = 64 * ch + 16 * w + 4 * ag;
+                if (u0 < KH) {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) *(f32x4*)(At + (16 * i + arow) * PITCH + KX + u0) = rh[ch][i];
+                }
+              }
+              bar();
+            }
+            if (t + 1 < T) x_request(row0, t + 1);
+          }
+        }
         zero_acc();
         for (int seg = 0; seg < nseg; ++seg) {
           const int ng = seg ? ngh : ngx, k0 = seg ? KX : 0;
@@ -228,7 +267,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
             // group n = c_n (set 0), then n + 1 (set 1); the group behind the pair: the next pair of this segment, the other segment, the next chunk --
             // or nothing (the step's last pair: the LDS tile is about to be rewritten)
             const bool last_pair = (g + 2 == ng) && (seg + 1 == nseg);
-            const bool step_end = last_pair && (c + 1 == NCH);
+            const bool step_end = last_pair && (c + 1 == NPASS);
             // Each half: the 64 MFMAs of one group in four quarters; behind the first the DMA request of the group R ahead (into the slot this
             // group's fragments were read from: those reads fed the MFMAs just issued), behind the second the wait for the next group's weights
             // and its B fragments, behind the third its A fragments.
@@ -301,6 +340,61 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
               if (a.write_all_h || t == T - 1) store4(a.hs + o, hh, nv);
             }
           }
+        } else if constexpr (CELL == 2) {
+          if (c < NPR) {   // first half: r, z of chunks 2 c, 2 c + 1;  r * h' (h' = this lane's h_{t-1}: zero at t = 0)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+              const int ch = 2 * c + cc;
+              if (ch < NCH) {
+                const int u0 = 64 * ch + 16 * w + 4 * ag, nv = H - u0;
+                f32x4 br, bz;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { br[r] = (r < nv) ? a.bi[u0 + r] : 0.f; bz[r] = (r < nv) ? a.bi[H + u0 + r] : 0.f; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const int64_t row = row0 + 16 * i + arow;
+                  f32x4 rg, zg, rhv;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    rg[r] = sigm(acc[i][2 * cc][r] + br[r]);
+                    zg[r] = sigm(acc[i][2 * cc + 1][r] + bz[r]);
+                    rhv[r] = (r < nv) ? rg[r] * hn[ch][i][r] : 0.f;   // units past H: zero columns of the candidate's operand
+                  }
+                  zst[ch][i] = zg;
+                  rh[ch][i] = rhv;
+                  if (SAVE && row < a.N && nv > 0) {
+                    float* gdst = a.act + ((int64_t)t * a.N + row) * (4 * (int64_t)H) + u0;
+                    store4(gdst, rg, nv); store4(gdst + H, zg, nv); store4(gdst + 3 * H, rhv, nv);
+                  }
+                }
+              }
+            }
+          } else {   // second half: n = tanh(.), h = (1 - z) n + z h'
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+              const int u0 = 64 * ch + 16 * w + 4 * ag, nv = H - u0;
+              f32x4 bn;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) bn[r] = (r < nv) ? a.bc[u0 + r] : 0.f;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int64_t row = row0 + 16 * i + arow;
+                f32x4 ng, hh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  ng[r] = tanh_fast(acc[i][ch][r] + bn[r]);
+                  const float z = zst[ch][i][r];
+                  hh[r] = (r < nv) ? (1.f - z) * ng[r] + z * hn[ch][i][r] : 0.f;
+                }
+                hn[ch][i] = hh;
+                if (row < a.N && nv > 0) {
+                  const int64_t o = ((int64_t)t * a.N + row) * H + u0;
+                  if (SAVE) store4(a.act + ((int64_t)t * a.N + row) * (4 * (int64_t)H) + 2 * H + u0, ng, nv);
+                  if (a.write_all_h || t == T - 1) store4(a.hs + o, hh, nv);
+                }
+              }
+            }
+          }
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -333,7 +427,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
       bar();
       if (t + 1 < T) {
         x_store();
-        if constexpr (CELL == 0) {
+        if constexpr (CELL != 1) {
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
             const int u0 = 64 * c + 16 * w + 4 * ag;
@@ -672,17 +766,18 @@ static size_t lds_need(int Din, int H, int R) {
 // tiles to give every CU one
 // (a tile per CU at least, unless forced: below ~16 k paths the per-step launches put more workgroups on the chip than N / 64 persistent ones)
 bool supported(int cell, int64_t N, int Din, int H, bool force) {
-  if (cell != 0 && cell != 1) return false;
+  if (cell < 0 || cell > 2) return false;
   if ((Din & 3) || Din < 16 || Din > 16 * XPMAX || H < 16 || H > 256) return false;
   if (N < (force ? (int64_t)1 : (int64_t)ROWS * num_cus()) || (N + ROWS - 1) / ROWS >= ((int64_t)1 << 31)) return false;
   return lds_need(Din, H, 2) <= (size_t)160 * 1024;
 }
 
 void forward_layer(hipStream_t s, int cell, const float* in, int64_t N, int T, int Din, int H, const float* Wi, const float* Wo, const float* bi, const float* bo,
-                   float* hs, float* cs, float* act, const float* mask, int relu, bool save, bool write_all_h) {
+                   float* hs, float* cs, float* act, const float* mask, int relu, bool save, bool write_all_h, const float* Wc, const float* Uc, const float* bc) {
   LArgs a;
   memset(&a, 0, sizeof(a));
   a.in = in; a.N = N; a.T = T; a.Din = Din; a.H = H; a.Wi = Wi; a.Wo = Wo; a.bi = bi; a.bo = bo; a.hs = hs; a.cs = cs; a.act = act; a.mask = mask;
+  a.Wc = Wc; a.Uc = Uc; a.bc = bc;
   a.relu = relu; a.write_all_h = (write_all_h || save) ? 1 : 0;
   a.tiles = (N + ROWS - 1) / ROWS;
   a.KX = (Din + 31) & ~31; a.KH = (H + 31) & ~31; a.PITCH = a.KX + a.KH + 4;
@@ -692,7 +787,13 @@ void forward_layer(hipStream_t s, int cell, const float* in, int64_t N, int T, i
   typedef void (*Kern)(LArgs);
   Kern k = nullptr;
   if (cell == 1) k = save ? (Kern)k_layer<1, 1, true> : (Kern)k_layer<1, 1, false>;
-  else {
+  else if (cell == 2) {
+    const int nch = (H + 63) / 64;
+    if (nch == 1) k = save ? (Kern)k_layer<2, 1, true> : (Kern)k_layer<2, 1, false>;
+    else if (nch == 2) k = save ? (Kern)k_layer<2, 2, true> : (Kern)k_layer<2, 2, false>;
+    else if (nch == 3) k = save ? (Kern)k_layer<2, 3, true> : (Kern)k_layer<2, 3, false>;
+    else k = save ? (Kern)k_layer<2, 4, true> : (Kern)k_layer<2, 4, false>;
+  } else {
     const int nch = (H + 63) / 64;
     if (nch == 1) k = save ? (Kern)k_layer<0, 1, true> : (Kern)k_layer<0, 1, false>;
     else if (nch == 2) k = save ? (Kern)k_layer<0, 2, true> : (Kern)k_layer<0, 2, false>;

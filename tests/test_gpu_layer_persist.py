@@ -75,6 +75,54 @@ def test_persistent_layer_against_the_f64_oracle(kind, dims, L, pairs, P, T):
     eng.close()
 
 
+GRU_CASES = [((50, 100, 50, 250), 1, 150, 2, 6),    # bench.py --dims gru: K padded 200 -> 224, four chunks (the last one 58 units), two [r; z] passes + the candidate pass
+             ((64, 64, 64, 192), 2, 129, 1, 4),     # three chunks: the second [r; z] pass has one chunk only; both layers through the launch; a ragged last tile
+             ((16, 32, 16, 80), 1, 100, 2, 3),      # H = 80: second chunk a quarter full
+             ((16, 32, 16, 64), 2, 300, 3, 6),      # one chunk: half of every pass's n-tiles idle; 900 paths = 14 tiles + 4 rows
+             ((64, 64, 64, 192), 1, 40, 1, 1)]      # T = 1: no recurrent half, no r * h' hand-over
+
+
+@pytest.mark.parametrize("dims,L,pairs,P,T", GRU_CASES)
+def test_persistent_gru_layer_against_the_f64_oracle(dims, L, pairs, P, T):
+    """nn.GRU (OneModel.lua:237-238) through k_layer<2, NCH, SAVE>: both dependent products of a step inside the launch (r * h' takes h_{t-1}'s place in the
+    LDS tile between them).  Scores, every class probability, and -- through the saves it writes in the per-step pipeline's record [r | z | n | r * h'] and the
+    unchanged GRU backward -- every gradient, against the float64 oracle and against the per-step launches (measured: 5e-7 / 1.6e-6 / 1.2e-6)."""
+    dt, de, dr, H = dims
+    eng = _ffi.Engine(6, 800, 9, dt, de, dr, H, L, rnn_type=2, param_init=0.07)
+    eng.set_option("impl", "generic")
+    eng.set_option("persist_layers", "2")
+    o64 = Oracle(make_cfg(Vt=6, Ve=800, Vr=9, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=2), np.float64)
+    theta = o64.init_params(5, 0.07).astype(np.float32).astype(np.float64)
+    eng.set_flat_params(theta.astype(np.float32))
+    idx, labels = synth.make_paths(pairs, P, T, Ve=800, seed=pairs + T)
+    b = eng.batch(idx, labels)
+    eng.profile(True)
+    out = eng.forward(b, 1, want=("probs", "all_probs", "path_scores"))
+    fam = eng.profile_get()
+    assert "gru_layer_fwd" in fam and "gru_cell_fwd" not in fam and "gemm_o2g_fwd" not in fam and "gemm_i2g_fwd" not in fam, sorted(fam)
+    ps, _, probs = o64.forward(theta, idx)
+    assert rel_inf(out["path_scores"], ps) < 2e-5, rel_inf(out["path_scores"], ps)
+    np.testing.assert_allclose(out["all_probs"], probs, rtol=1e-4)
+    loss = eng.backward(b, 1)
+    fam = eng.profile_get()
+    assert "gru_cell_fwd" not in fam and "gemm_o2g_fwd" not in fam, sorted(fam)   # (the training forward is the launch too)
+    ol, og, _ = o64.forward_backward(theta, idx, labels)
+    assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
+    g = eng.get_flat_grads()
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], og[off:off + n]) < 2e-4, (nm, rel_inf(g[off:off + n], og[off:off + n]))
+    eng.set_option("persist_layers", "0")
+    out0 = eng.forward(b, 1, want=("probs", "path_scores"))
+    assert rel_inf(out["path_scores"], out0["path_scores"].astype(np.float64)) < 2e-6
+    eng.backward(b, 1)
+    g0 = eng.get_flat_grads().astype(np.float64)
+    for nm, (off, shp) in eng.layout().items():
+        n = int(np.prod(shp))
+        assert rel_inf(g[off:off + n], g0[off:off + n]) < 2e-5, (nm, rel_inf(g[off:off + n], g0[off:off + n]))
+    eng.close()
+
+
 @pytest.mark.parametrize("kind,dims,L", [("lstm", (64, 64, 64, 192), 2), ("rnn", (50, 100, 50, 250), 1)])
 def test_adam_steps_through_the_persistent_layers(kind, dims, L):
     """Three Adam steps: the loss follows the float64 oracle (measured 1e-7), the parameters equal those of the per-step launches to fp32 reordering
