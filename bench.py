@@ -304,13 +304,13 @@ def family_work(name, N, T, D, H, L, C, F, nT, dt, de, dr, G=4, NT=None):
             din = D if l == 0 else H
             fl += N * 2 * g * (T * din + (T - 1) * H)
         return "mfma", fl / (L * T)
-    if name in ("lstm_layer_fwd", "rnn_layer_fwd"):   # one launch per layer, all T steps (layer_f32_persist.hip); no recurrent half at t = 0
+    if name in ("lstm_layer_fwd", "rnn_layer_fwd", "gru_layer_fwd"):   # one launch per layer, all T steps (layer_f32_persist.hip); no recurrent half at t = 0
         fl = 0
         for l in range(L):
             din = D if l == 0 else H
             fl += N * 2 * g * (T * din + (T - 1) * H)
         return "mfma", fl / L
-    if name in ("lstm_layer_bwd", "rnn_layer_bwd"):   # BPTT of one layer in one launch: the recurrent products dh_{t-1} = dA_t W_o2g of steps T-1 .. 1
+    if name in ("lstm_layer_bwd", "rnn_layer_bwd", "gru_layer_bwd"):   # BPTT of one layer in one launch: the recurrent products dh_{t-1} = dA_t W_o2g of steps T-1 .. 1 (gru: d(r h') = d pre_n c_h2h and [d pre_r | d pre_z] o2g: g = 3H)
         return "mfma", N * 2 * g * (T - 1) * H
     if name in ("lstm_fused_fwd", "lstm_fused_fwd_train"):
         fl = 0

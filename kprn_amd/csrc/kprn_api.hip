@@ -620,8 +620,13 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       const float* Wc = h->dense + h->layer[l].Wc;
       const float* Uc = h->dense + h->layer[l].Uc;
       const bool has_up = (l < L - 1);
-      if (has_up) HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
-      for (int t = T - 1; t >= 0; --t) {
+      const bool bptt2 = !bf && h->persist_layers && lp32::bptt_supported(2, N, H, h->persist_layers == 2);
+      if (bptt2) {
+        // the cell backward of all T steps and both recurrent products of a step (d(r h') = d pre_n c_h2h; dh' += [d pre_r | d pre_z] o2g) in ONE launch
+        ProfScope ps(h, "gru_layer_bwd");
+        lp32::bptt_layer(s, 2, act, nullptr, hs, nullptr, has_up ? w.dIn : w.dH, has_up, Wo, lp_wot_buffer(h, H, 3 * H), w.dA, N, T, H, 0, Uc);
+      } else if (has_up) HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
+      for (int t = T - 1; t >= 0 && !bptt2; --t) {
         float* dA_t = w.dA + (int64_t)t * N * 4 * H;
         const float* a_t = act + (int64_t)t * N * 4 * H;
         const float* hp = t > 0 ? hs + (int64_t)(t - 1) * N * H : nullptr;

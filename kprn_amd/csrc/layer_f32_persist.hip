@@ -21,10 +21,20 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "kprn_internal.h"
 
 namespace lp32 {
+
+// compile-time loop: the body sees its index as a constant
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 f32x4u __attribute__((aligned(4)));
@@ -472,9 +482,9 @@ struct BPArgs {
   const float* hs;       // rnn: h [T][N][H] (the activation's derivative is formed from it)
   const float* mask;     // rnn: [T][N]
   const float* dHup;     // UP: [T][N][H] gradient from the layer above;  else [N][H]: the head's gradient, applied at t = T-1
-  const float* WoT;      // [Hp rows][GH] W_o2g^T (row = output unit; zero rows / slack behind H)
+  const float* WoT;      // [Hp rows][WG] W_o2g^T (row = output unit; zero rows / slack behind H);  gru: [c_h2h^T | o2g^T] (WG = 3H: k = candidate unit, r row, z row)
   float* dA;             // [T][N][GH]
-  int64_t N; int T, H, GH, relu;
+  int64_t N; int T, H, GH, WG, relu;
   int64_t tiles;
 };
 
@@ -482,6 +492,9 @@ constexpr int BP_LD = 260;      // floats per row of the dA chunk tile
 constexpr int BP_R = 3;         // DMA ring depth (groups)
 
 template <int N_> __device__ __forceinline__ void vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000); }
 // DMA with a scalar base: address = sbase + voff (32-bit, unsigned)
 __device__ __forceinline__ void dma16s(const float* sbase, unsigned voff, unsigned lds_dst) {
   unsigned keep;
@@ -490,17 +503,25 @@ __device__ __forceinline__ void dma16s(const float* sbase, unsigned voff, unsign
 }
 
 // CELL 0: FastLSTM, NCH chunks (of 64 units) = n-tiles per wave;  CELL 1: rnn, one chunk of 256 units, 4 n-tiles per wave.  UP: a layer above exists.
+// CELL 2: nn.GRU (OneModel.lua:237-238) in the rnn's lane layout (n-tile q of wave w = units 64 w + 16 q ..).  A step's backward has two DEPENDENT products:
+//   d pre_n = dh (1 - z)(1 - n^2) -> d(r h') = d pre_n c_h2h -> d pre_r = d(r h') h' r (1 - r) -> dh' = dh z + d(r h') r + [d pre_r | d pre_z] o2g,
+// walked as THREE K chunks over one [c_h2h^T | o2g^T] stream: chunk 0 (k = candidate units) forms d(r h') in the accumulators, the cell's second part
+// turns it into d pre_r and restarts them, chunks 1 (r rows) and 2 (z rows) accumulate the rest of dh'.  The saves a part needs are requested one product
+// ahead of it where the registers allow (r under chunk 0; the gradient from above of step t - 1 under chunk 1, added to dh behind it); z, n, h' are fetched at
+// the head of the step.
 template <int CELL, int NCH, bool UP>
 __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
   constexpr int NT = (CELL == 0) ? NCH : 4;          // n-tiles (groups of 16 output units) per wave
-  constexpr int KCH = (CELL == 0) ? NCH : 1;         // K chunks per step
-  constexpr int NPF = (CELL == 0) ? 28 : 32;         // 16-byte save requests per lane and chunk
+  constexpr int KCH = (CELL == 0) ? NCH : (CELL == 2 ? 3 : 1);   // K chunks per step
+  constexpr int NPF = (CELL == 0) ? 28 : 32;         // 16-byte save requests per lane and chunk (gru: 16 / 16 or none / none behind the cell's three parts)
   constexpr int GBB = NT * 1024;                     // bytes of one wave's weight group
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   float* const Dt = (float*)smem;                    // dA chunk tile [64][BP_LD]
   const int tid = threadIdx.x, lane = tid & 63, arow = lane & 15, ag = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, GH = a.GH, T = a.T;
+  const int WG = a.WG;                                            // floats per row of the transposed weights
+  const int NG = (CELL == 2) ? (((H + 31) >> 5) << 1) : 16;       // groups of 16 k per chunk (gru: the chunk is H wide, in whole pairs of groups)
   char* const ring = smem + (size_t)ROWS * BP_LD * 4 + (size_t)w * BP_R * GBB;
   const unsigned ring_lds = lds_off(ring);
   const int t_beg = __builtin_amdgcn_readfirstlane((int)(a.tiles * (int64_t)blockIdx.x / (int64_t)gridDim.x));
@@ -513,21 +534,21 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
   for (int cc = 0; cc < NT; ++cc) {
     int uo = (CELL == 0) ? 64 * cc + 16 * w + arow : 64 * w + 16 * cc + arow;
     if (uo >= H) uo = H - 1;
-    voff[cc] = (unsigned)(((int64_t)uo * GH + 4 * ag) * 4);
+    voff[cc] = (unsigned)(((int64_t)uo * WG + 4 * ag) * 4);
   }
   // cursor of the next group to request: (tile, step, chunk, group); steps T-1 .. 1 have a product, step 0 has none
   int l_tile = (T > 1) ? t_beg : t_end, l_t = T - 1, l_c = 0, l_g = 0, l_n = 0, l_slot = 0;
   auto l_issue = [&]() {
     if (l_tile >= t_end) return;
     // k of the group inside the row: FastLSTM gate (g >> 2), units 64 c + 16 (g & 3) ..;  rnn: units 16 g ..
-    const int koff = (CELL == 0) ? (l_g >> 2) * H + 64 * l_c + 16 * (l_g & 3) : 16 * l_g;
+    const int koff = (CELL == 0) ? (l_g >> 2) * H + 64 * l_c + 16 * (l_g & 3) : (CELL == 2 ? __builtin_amdgcn_readfirstlane(l_c * H + 16 * l_g) : 16 * l_g);
     const float* sb = a.WoT + koff;
     const unsigned dst = ring_lds + (unsigned)l_slot * GBB;
     l_slot = (l_slot + 1 == BP_R) ? 0 : l_slot + 1;
 #pragma unroll
     for (int cc = 0; cc < NT; ++cc) dma16s(sb, voff[cc], (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + cc * 1024)));
     ++l_n;
-    if (++l_g == 16) {
+    if (++l_g == NG) {
       l_g = 0;
       if (++l_c == KCH) { l_c = 0; if (--l_t == 0) { l_t = T - 1; ++l_tile; } }
     }
@@ -536,9 +557,13 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
   int c_n = 0, c_slot = 0;
   auto slot_of = [&](int ahead) -> int { int sl = c_slot + ahead; return sl >= BP_R ? sl - BP_R : sl; };
   // group n has landed; pf: the NPF save requests of this chunk were issued behind it (it is one of the first BP_R groups of the chunk's product)
-  auto wait_w = [&](int n, bool pf) {
+  auto wait_w = [&](int n, int pf /* save requests issued behind the group: 0, NPF (gru: 0 or 16) */) {
     const int younger = l_n - 1 - n;
-    if (pf) {
+    if (CELL == 2 && pf == 16) {
+      if (younger >= 2) vmwait<2 * NT + 16>();
+      else if (younger == 1) vmwait<NT + 16>();
+      else vmwait<16>();
+    } else if (pf) {
       if (younger >= 2) vmwait<2 * NT + NPF>();
       else if (younger == 1) vmwait<NT + NPF>();
       else vmwait<NPF>();
@@ -575,6 +600,46 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
   // ---- saves of one chunk's cell backward (requested a chunk ahead)
   struct Sv { f32x4 g[CELL == 0 ? 4 : 1][4]; f32x4 c[4], cp[4]; f32x4 up[CELL == 0 ? 1 : 4][4]; f32x4 hq[CELL == 0 ? 1 : 4][4]; };
   Sv sv;
+  // gru: the record's r, z, n planes (act [T][N][4H] = [r | z | n | r h']), h' = h_{t-1} (sv.hq), the gradient from above (sv.up); which: 1 r, 2 z + n, 4 up, 8 h'
+  f32x4 gr[CELL == 2 ? 4 : 1][4], gz[CELL == 2 ? 4 : 1][4], gn[CELL == 2 ? 4 : 1][4];
+  // Buffer loads: descriptor + plane offset in scalar registers, ONE 32-bit lane offset per (n-tile, m-tile).  (With ordinary pointers the 64 requests in front of a
+  // tile's first step hold 64 address pairs beside their 64 quads: 1.0-1.3 KB of scratch per lane.)
+  unsigned rl4[4], u4[4];   // this lane's rows of the tile (clamped to the batch) x 4 bytes; first unit of its quads (a quad straddling H re-reads the last full one) x 4 bytes
+  auto tile_lanes = [&](int64_t row0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t rl = 16 * i + arow;
+      if (row0 + rl >= a.N) rl = a.N - 1 - row0;
+      rl4[i] = (unsigned)rl * 4u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int u = 64 * w + 16 * q + 4 * ag;
+      if (u + 4 > H) u = (H >= 4) ? H - 4 : 0;
+      u4[q] = (unsigned)u * 4u;
+    }
+  };
+  auto ldq = [&](rsrc_t r, unsigned voff, unsigned soff) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0)); };
+  auto request_gru = [&](int64_t row0, int t, int which) {
+    asm volatile("" ::: "memory");
+    const rsrc_t ra = make_rsrc(a.act + ((int64_t)t * a.N + row0) * GH);
+    const rsrc_t rh = make_rsrc(a.hs + ((int64_t)(t > 0 ? t - 1 : 0) * a.N + row0) * H);   // (t = 0: any valid rows, the cell takes h' = 0)
+    const rsrc_t ru = make_rsrc(a.dHup + (UP ? ((int64_t)t * a.N + row0) * H : row0 * H));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned va = rl4[i] * (unsigned)GH + u4[q], vh = rl4[i] * (unsigned)H + u4[q];
+        if (which & 1) gr[q][i] = ldq(ra, va, 0u);
+        if (which & 2) { gz[q][i] = ldq(ra, va, (unsigned)H * 4u); gn[q][i] = ldq(ra, va, (unsigned)H * 8u); }
+        if (which & 8) sv.hq[q][i] = ldq(rh, vh, 0u);
+        if (which & 4) sv.up[q][i] = ldq(ru, vh, 0u);
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  f32x4 dzk[CELL == 2 ? 4 : 1][4];   // gru: d pre_z between the cell's first and third part
   auto request = [&](int64_t row0, int t, int c) {   // unconditional loads from clamped addresses: exactly NPF requests per lane
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -615,7 +680,23 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
     for (int c = 0; c < (CELL == 0 ? NCH : 1); ++c)
 #pragma unroll
       for (int i = 0; i < 4; ++i) dc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    request(row0, T - 1, 0);
+    if constexpr (CELL == 2) {
+      // the gradient that enters at the last step becomes dh right away (the cell's first part never looks at sv.up: one plane less alive across the products)
+      tile_lanes(row0);
+      request_gru(row0, T - 1, 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int u0 = 64 * w + 16 * q + 4 * ag, nv = H - u0;
+        const int sh = (u0 + 4 > H && H >= 4) ? u0 + 4 - H : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rs = (r + sh < 4) ? r + sh : 3;
+            dh[i][q][r] = (r < nv && row0 + 16 * i + arow < a.N) ? sv.up[q][i][rs] : 0.f;
+          }
+      }
+    } else request(row0, T - 1, 0);
     for (int t = T - 1; t >= 0; --t) {
       const float upw = (UP || t == T - 1) ? 1.f : 0.f;   // the head's gradient enters at the last step only
       float mk[4];
@@ -626,10 +707,125 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
           mk[i] = (r < a.N) ? a.mask[(int64_t)t * a.N + r] : 0.f;
         }
       }
+      // ---- gru: one part of the cell backward (c = 0, 1, 2: see the kernel's header), dA quads -> global + LDS tile
+      auto gru_part = [&](auto c_) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_)::value;
 #pragma unroll
-      for (int c = 0; c < KCH; ++c) {
+            for (int q = 0; q < 4; ++q) {
+              const int u0 = 64 * w + 16 * q + 4 * ag, nv = H - u0;
+              const int sh = (u0 + 4 > H && H >= 4) ? u0 + 4 - H : 0;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int64_t row = row0 + 16 * i + arow;
+                f32x4 d;
+                int col;   // column block of the record this part's quad belongs to
+                if (c == 0) {          // d pre_n -> tile; d pre_z kept; dh <- the direct path dh z
+                  col = 2 * H;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const int rs = (r + sh < 4) ? r + sh : 3;
+                    const float z = gz[q][i][rs], nn = gn[q][i][rs];
+                    const float hp = t > 0 ? sv.hq[q][i][rs] : 0.f;
+                    const float dhv = dh[i][q][r];   // (the gradient from above is in it: added at the tile's start / behind chunk 1's product of the step before)
+                    const bool ok = r < nv && row < a.N;
+                    d[r] = ok ? dhv * (1.f - z) * (1.f - nn * nn) : 0.f;
+                    dzk[q][i][r] = ok ? dhv * (hp - nn) * z * (1.f - z) : 0.f;
+                    dh[i][q][r] = ok ? dhv * z : 0.f;
+                  }
+                } else if (c == 1) {   // the accumulators hold d(r h'): d pre_r -> tile; dh += d(r h') r; the accumulators start again
+                  col = 0;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const int rs = (r + sh < 4) ? r + sh : 3;
+                    const float rr = gr[q][i][rs], hp = sv.hq[q][i][rs], drh = acc[i][q][r];
+                    const bool ok = r < nv && row < a.N;
+                    d[r] = ok ? drh * hp * rr * (1.f - rr) : 0.f;
+                    dh[i][q][r] += ok ? drh * rr : 0.f;
+                  }
+                  acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {               // d pre_z -> tile; the gradient from above of step t - 1 (requested under chunk 1's product) joins dh
+                  col = H;
+                  d = dzk[q][i];
+                  if (UP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                      const int rs = (r + sh < 4) ? r + sh : 3;
+                      dh[i][q][r] += (r < nv && row < a.N) ? sv.up[q][i][rs] : 0.f;
+                    }
+                  }
+                }
+                *(f32x4*)(Dt + (16 * i + arow) * BP_LD + 64 * w + 16 * q + 4 * ag) = d;
+                if (row < a.N && nv > 0) {
+                  float* gdst = a.dA + ((int64_t)t * a.N + row) * GH + u0;
+                  store4(gdst + col, d, nv);
+                  if (t == 0) { store4(gdst + H, dzk[q][i], nv); store4(gdst, f32x4{0.f, 0.f, 0.f, 0.f}, nv); }
+                }
+              }
+            }
+      };
+      // ---- gru: the product of one chunk on the tile the part just wrote (npf: save requests issued behind the groups in flight)
+      auto gru_product = [&](int npf) __attribute__((always_inline)) {
+        bar();
+        wait_w(c_n, npf);
+        read_a(0, 0);
+        read_b(0, c_slot);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < NG; g += 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(0, 0);
+          l_issue();
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(0, 1);
+          wait_w(c_n + 1, g + 1 < BP_R ? npf : 0);
+          read_b(1, slot_of(1));
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(0, 2);
+          read_a(1, g + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(0, 3);
+          mfma_q(1, 0);
+          l_issue();
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(1, 1);
+          if (g + 2 < NG) {
+            wait_w(c_n + 2, g + 2 < BP_R ? npf : 0);
+            read_b(0, slot_of(2));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(1, 2);
+          if (g + 2 < NG) read_a(0, g + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_q(1, 3);
+          c_n += 2;
+          c_slot = slot_of(2);
+        }
+        bar();   // every wave is done with the tile: the next part may overwrite it
+      };
+      if constexpr (CELL == 2) {
+        // step 0: h' = 0 -- no d(r h'), no d pre_r; the first part writes the step's whole dA
+        // Which plane is requested where is a register budget (512 per lane: dh, the accumulators, the fragment sets and d pre_z take 256) and an allocator matter: planes
+        // requested under chunk 2's product are alive across the step loop's back edge, and every such schedule came out with ~1 KB of scratch per lane, reloaded inside
+        // the MFMA loops.  Measured at bench.py's --dims gru batch (65 536 paths, H 250, L 1): every part fetching its own planes (three exposed round trips a step)
+        // 3.32 ms; r and the gradient from above under chunks 0 / 1, z, n, h' exposed at the head of the step (this) 1.74 ms = 0.45 of the fp32 peak on the three
+        // products; anything under chunk 2 (z, n, h' or z, n) 3.25 ms.  The per-step launches this replaces: 2.65 ms.
+        request_gru(row0, t, 10);                          // z, n, h'
+        gru_part(std::integral_constant<int, 0>{});
+        if (t > 0) {
+          request_gru(row0, t, 1);                         // r, under chunk 0's product
+          gru_product(16);
+          gru_part(std::integral_constant<int, 1>{});
+          if (UP) request_gru(row0, t - 1, 4);             // the gradient from above of step t - 1, under chunk 1's product
+          gru_product(UP ? 16 : 0);
+          gru_part(std::integral_constant<int, 2>{});
+          gru_product(0);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < (CELL == 2 ? 0 : KCH); ++c) {
         // ---- cell backward of chunk c: dA quads -> global + LDS tile
-        if constexpr (CELL == 0) {
+        if constexpr (CELL == 2) {
+          // (gru: its own step body above)
+        } else if constexpr (CELL == 0) {
           const int u0 = 64 * c + 16 * w + 4 * ag, nv = H - u0;
           const int sh = (u0 + 4 > H && H >= 4) ? u0 + 4 - H : 0;   // the quad was read `sh` units early (see request): its valid elements sit at r + sh
 #pragma unroll
@@ -682,24 +878,27 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
           }
         }
         // ---- the saves of the chunk behind this one (this tile's next chunk / step); the next tile requests its own first chunk
-        const bool more = !(c + 1 == KCH && t == 0);
-        if (more) {
-          if (c + 1 < KCH) request(row0, t, c + 1); else request(row0, t - 1, 0);
+        const bool more = (CELL == 2) ? true : !(c + 1 == KCH && t == 0);
+        if constexpr (CELL != 2) {
+          if (more) {
+            if (c + 1 < KCH) request(row0, t, c + 1); else request(row0, t - 1, 0);
+          }
         }
+        const int npf = (CELL == 2) ? (c == 0 ? 16 : (c == 1 ? (UP ? 16 : 0) : 48)) : (more ? NPF : 0);   // requests issued behind the product's first groups
         if (t == 0) continue;   // (uniform) step 0: no dh_{-1} to form
         bar();
         // ---- product of the chunk: 16 groups in 8 pairs; fragments of group n + 1 are read under the MFMAs of group n
-        wait_w(c_n, more);
+        wait_w(c_n, npf);
         read_a(0, 0);
         read_b(0, c_slot);
         __builtin_amdgcn_sched_barrier(0);
-        for (int g = 0; g < 16; g += 2) {
+        for (int g = 0; g < NG; g += 2) {
           __builtin_amdgcn_sched_barrier(0);
           mfma_q(0, 0);
           l_issue();
           __builtin_amdgcn_sched_barrier(0);
           mfma_q(0, 1);
-          wait_w(c_n + 1, more && g + 1 < BP_R);
+          wait_w(c_n + 1, g + 1 < BP_R ? npf : 0);
           read_b(1, slot_of(1));
           __builtin_amdgcn_sched_barrier(0);
           mfma_q(0, 2);
@@ -710,13 +909,13 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
           l_issue();
           __builtin_amdgcn_sched_barrier(0);
           mfma_q(1, 1);
-          if (g + 2 < 16) {
-            wait_w(c_n + 2, more && g + 2 < BP_R);
+          if (g + 2 < NG) {
+            wait_w(c_n + 2, g + 2 < BP_R ? npf : 0);
             read_b(0, slot_of(2));
           }
           __builtin_amdgcn_sched_barrier(0);
           mfma_q(1, 2);
-          if (g + 2 < 16) read_a(0, g + 2);
+          if (g + 2 < NG) read_a(0, g + 2);
           __builtin_amdgcn_sched_barrier(0);
           mfma_q(1, 3);
           c_n += 2;
@@ -728,14 +927,17 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int cc = 0; cc < NT; ++cc) { dh[i][cc] = acc[i][cc]; acc[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int cc = 0; cc < NT; ++cc) {
+          if (CELL == 2) dh[i][cc] += acc[i][cc]; else dh[i][cc] = acc[i][cc];   // (gru: on top of dh z + d(r h') r)
+          acc[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// W [R][C] -> WT [C][R] (64 x 64 tiles through LDS)
-__global__ __launch_bounds__(256) void k_transpose_f32(const float* __restrict__ W, float* __restrict__ WT, int R, int C) {
+// W [R][C] -> WT [C][ldo >= R] (64 x 64 tiles through LDS)
+__global__ __launch_bounds__(256) void k_transpose_f32(const float* __restrict__ W, float* __restrict__ WT, int R, int C, int ldo) {
   __shared__ float t[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
@@ -745,7 +947,7 @@ __global__ __launch_bounds__(256) void k_transpose_f32(const float* __restrict__
   __syncthreads();
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int c = e >> 6, r = e & 63;
-    if (c0 + c < C && r0 + r < R) WT[(int64_t)(c0 + c) * R + r0 + r] = t[r][c];
+    if (c0 + c < C && r0 + r < R) WT[(int64_t)(c0 + c) * ldo + r0 + r] = t[r][c];
   }
 }
 
@@ -807,7 +1009,7 @@ void forward_layer(hipStream_t s, int cell, const float* in, int64_t N, int T, i
 
 // ---- BPTT host side
 bool bptt_supported(int cell, int64_t N, int H, bool force) {
-  if (cell != 0 && cell != 1) return false;
+  if (cell < 0 || cell > 2) return false;
   if (H < 16 || H > 256) return false;
   if (N < (force ? (int64_t)1 : (int64_t)ROWS * num_cus()) || (N + ROWS - 1) / ROWS >= ((int64_t)1 << 31)) return false;
   return true;
@@ -817,13 +1019,19 @@ size_t bptt_scratch_floats(int H, int GH) { return (size_t)(H + 8) * GH + 1024; 
 // act / cs / hs / mask: the forward's saves (generic layouts); dHup: the gradient from above ([T][N][H] when up, else the head's [N][H], applied at
 // t = T-1); Wo [GH][H]; wot: scratch of bptt_scratch_floats(); dA out [T][N][GH]
 void bptt_layer(hipStream_t s, int cell, const float* act, const float* cs, const float* hs, const float* mask, const float* dHup, bool up, const float* Wo,
-                float* wot, float* dA, int64_t N, int T, int H, int relu) {
-  const int GH = cell == 0 ? 4 * H : H;
-  HIP_TRY(hipMemsetAsync(wot, 0, bptt_scratch_floats(H, GH) * sizeof(float), s));
-  hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)((H + 63) / 64), (unsigned)((GH + 63) / 64)), dim3(256), 0, s, Wo, wot, GH, H);
+                float* wot, float* dA, int64_t N, int T, int H, int relu, const float* Uc) {
+  const int GH = cell == 1 ? H : 4 * H;                        // floats per row of dA (gru: the record's four blocks, the last one unused)
+  const int WG = cell == 2 ? 3 * H : GH;                       // floats per row of the transposed weights
+  HIP_TRY(hipMemsetAsync(wot, 0, bptt_scratch_floats(H, WG) * sizeof(float), s));
+  if (cell == 2) {   // [c_h2h^T | o2g^T]: row = output unit, k = candidate unit | r row | z row
+    hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)((H + 63) / 64), (unsigned)((H + 63) / 64)), dim3(256), 0, s, Uc, wot, H, H, WG);
+    hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)((H + 63) / 64), (unsigned)((2 * H + 63) / 64)), dim3(256), 0, s, Wo, wot + H, 2 * H, H, WG);
+  } else {
+    hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)((H + 63) / 64), (unsigned)((GH + 63) / 64)), dim3(256), 0, s, Wo, wot, GH, H, GH);
+  }
   BPArgs a;
   memset(&a, 0, sizeof(a));
-  a.act = act; a.cs = cs; a.hs = hs; a.mask = mask; a.dHup = dHup; a.WoT = wot; a.dA = dA; a.N = N; a.T = T; a.H = H; a.GH = GH; a.relu = relu;
+  a.act = act; a.cs = cs; a.hs = hs; a.mask = mask; a.dHup = dHup; a.WoT = wot; a.dA = dA; a.N = N; a.T = T; a.H = H; a.GH = GH; a.WG = WG; a.relu = relu;
   a.tiles = (N + ROWS - 1) / ROWS;
   const int nch = cell == 0 ? (H + 63) / 64 : 1;
   const int nt = cell == 0 ? nch : 4;
@@ -833,6 +1041,7 @@ void bptt_layer(hipStream_t s, int cell, const float* act, const float* cs, cons
   Kern k = nullptr;
 #define KPRN_BK(C_, N_) (up ? (Kern)k_bptt<C_, N_, true> : (Kern)k_bptt<C_, N_, false>)
   if (cell == 1) k = KPRN_BK(1, 1);
+  else if (cell == 2) k = KPRN_BK(2, 1);
   else if (nch == 1) k = KPRN_BK(0, 1);
   else if (nch == 2) k = KPRN_BK(0, 2);
   else if (nch == 3) k = KPRN_BK(0, 3);

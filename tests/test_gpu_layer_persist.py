@@ -85,8 +85,8 @@ GRU_CASES = [((50, 100, 50, 250), 1, 150, 2, 6),    # bench.py --dims gru: K pad
 @pytest.mark.parametrize("dims,L,pairs,P,T", GRU_CASES)
 def test_persistent_gru_layer_against_the_f64_oracle(dims, L, pairs, P, T):
     """nn.GRU (OneModel.lua:237-238) through k_layer<2, NCH, SAVE>: both dependent products of a step inside the launch (r * h' takes h_{t-1}'s place in the
-    LDS tile between them).  Scores, every class probability, and -- through the saves it writes in the per-step pipeline's record [r | z | n | r * h'] and the
-    unchanged GRU backward -- every gradient, against the float64 oracle and against the per-step launches (measured: 5e-7 / 1.6e-6 / 1.2e-6)."""
+    LDS tile between them), and its BPTT through k_bptt<2, 1, UP> (three K chunks a step over one [c_h2h^T | o2g^T] stream).  Scores, every class probability
+    and every gradient against the float64 oracle and against the per-step launches (measured: 5e-7 / 1.6e-6 / 1.2e-6)."""
     dt, de, dr, H = dims
     eng = _ffi.Engine(6, 800, 9, dt, de, dr, H, L, rnn_type=2, param_init=0.07)
     eng.set_option("impl", "generic")
@@ -106,6 +106,8 @@ def test_persistent_gru_layer_against_the_f64_oracle(dims, L, pairs, P, T):
     loss = eng.backward(b, 1)
     fam = eng.profile_get()
     assert "gru_cell_fwd" not in fam and "gemm_o2g_fwd" not in fam, sorted(fam)   # (the training forward is the launch too)
+    # ... and so is BPTT through the layer (k_bptt<2, 1, UP>: the cell backward of all T steps and both recurrent products of a step)
+    assert "gru_layer_bwd" in fam and "gru_cell_bwd" not in fam and "gemm_o2g_bwd_dh" not in fam, sorted(fam)
     ol, og, _ = o64.forward_backward(theta, idx, labels)
     assert abs(loss - ol) < 1e-5 * max(1, abs(ol))
     g = eng.get_flat_grads()
@@ -174,14 +176,14 @@ def test_a_tile_per_cu_takes_the_launch_by_default(kind, dims, L, pairs, P):
     eng.close()
 
 
-@pytest.mark.parametrize("kind,dims,L", [("lstm", (64, 64, 64, 192), 2), ("rnn", (50, 100, 50, 250), 1)])
+@pytest.mark.parametrize("kind,dims,L", [("lstm", (64, 64, 64, 192), 2), ("rnn", (50, 100, 50, 250), 1), ("gru", (50, 100, 50, 250), 1), ("gru", (32, 64, 32, 128), 2)])
 def test_full_batch_agrees_with_the_step_launches(kind, dims, L):
     """bench.py's own batch (65 536 paths: four tiles per workgroup on every CU, the DMA rings and the counted waits under full load -- the timing regime
     the small cases cannot reach): probabilities and every gradient of the persistent launches against the per-step launches on the same engine.  The
     counted `vmcnt` waits assume that loads retire in issue order whether they land in registers or (LDS-DMA) in LDS; a weight group used before it
     landed would show here as errors of order 1e-2."""
     dt, de, dr, H = dims
-    rt = 1 if kind == "rnn" else 0
+    rt = {"lstm": 0, "rnn": 1, "gru": 2}[kind]
     eng = _ffi.Engine(6, 200000, 9, dt, de, dr, H, L, rnn_type=rt, use_relu=1, param_init=0.06)
     eng.set_option("impl", "generic")
     idx, labels = synth.make_paths(16384, 4, 6, Ve=200000, seed=19)
@@ -194,7 +196,7 @@ def test_full_batch_agrees_with_the_step_launches(kind, dims, L):
         p = eng.forward(b, 1, want=("probs",))["probs"].astype(np.float64)
         eng.backward(b, 1)
         fam = eng.profile_get()
-        assert (("lstm_layer_bwd" in fam or "rnn_layer_bwd" in fam) and ("lstm_layer_fwd" in fam or "rnn_layer_fwd" in fam)) == (mode == "1"), sorted(fam)
+        assert (any(k + "_layer_bwd" in fam for k in ("lstm", "rnn", "gru")) and any(k + "_layer_fwd" in fam for k in ("lstm", "rnn", "gru"))) == (mode == "1"), sorted(fam)
         g = eng.get_flat_grads().astype(np.float64)
         if mode in res:   # a second pass through the persistent launches: the same answer again (to the atomics' reordering in the dW products)
             assert np.max(np.abs(p - res[mode][0])) < 1e-7
