@@ -975,6 +975,15 @@ void gru_bwd2(hipStream_t s, const float* a, const float* hp, float* dA, const f
   CHECK_LAUNCH();
 }
 
+__global__ void k_add_into(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+void add_into(hipStream_t s, float* dst, const float* src, int64_t n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_add_into, dim3(nblocks(n)), dim3(TPB), 0, s, dst, src, n);
+}
+
 void add_bias_rows(hipStream_t s, float* Y, const float* b, int64_t rows, int cols) {
   if (rows <= 0) return;
   hipLaunchKernelGGL(k_add_bias, dim3(nblocks(rows * cols)), dim3(TPB), 0, s, Y, b, rows * cols, cols);

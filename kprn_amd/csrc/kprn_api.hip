@@ -654,10 +654,24 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
         gemm::run(s, w.dA + (int64_t)N * 4 * H + 2 * H, 1, 4 * H, act + (int64_t)N * 4 * H + 3 * H, 4 * H, 1, gd + h->layer[l].Uc, H, H, H,
                   (int64_t)(T - 1) * N, true, nullptr, split, bf);
       }
+      // The input maps of the gates and of the candidate are two arrays (i2g.weight [2H][Din], c_i2h.weight [H][Din]) but ONE operand of the record's first 3H columns:
+      // one dW product into a zeroed [3H][Din] image (added to the two gradients behind it) and one dx product on a packed copy -- the [H][Din] halves alone fall below
+      // the tiled kernel's 256 rows, and the second dx product was a read-modify-write pass over dIn.
+      const int64_t cat = (int64_t)3 * H * Din;
+      if (2 * cat > h->st_ctmp_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        dfree(h->st_ctmp);
+        h->st_ctmp = dalloc<float>(2 * cat);
+        h->st_ctmp_cap = 2 * cat;
+      }
+      float* wcat = h->st_ctmp;
+      float* gcat = h->st_ctmp + cat;
       {
         ProfScope ps(h, "gemm_i2g_bwd_dw");
-        gemm::run(s, w.dA, 1, 4 * H, in, Din, 1, gd + h->layer[l].Wi, Din, 2 * H, Din, (int64_t)T * N, true, nullptr, split, bf);
-        gemm::run(s, w.dA + 2 * H, 1, 4 * H, in, Din, 1, gd + h->layer[l].Wc, Din, H, Din, (int64_t)T * N, true, nullptr, split, bf);
+        HIP_TRY(hipMemsetAsync(gcat, 0, (size_t)cat * sizeof(float), s));
+        gemm::run(s, w.dA, 1, 4 * H, in, Din, 1, gcat, Din, 3 * H, Din, (int64_t)T * N, true, nullptr, split, bf);
+        kk::add_into(s, gd + h->layer[l].Wi, gcat, (int64_t)2 * H * Din);
+        kk::add_into(s, gd + h->layer[l].Wc, gcat + (int64_t)2 * H * Din, (int64_t)H * Din);
       }
       {
         ProfScope ps(h, "bias_colsum");
@@ -666,8 +680,9 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       }
       {
         ProfScope ps(h, "gemm_i2g_bwd_dx");
-        gemm::run(s, w.dA, 4 * H, 1, Wi, Din, 1, w.dIn, Din, (int64_t)T * N, Din, 2 * H, false, nullptr, 1, bf);
-        gemm::run(s, w.dA + 2 * H, 4 * H, 1, Wc, Din, 1, w.dIn, Din, (int64_t)T * N, Din, H, true, nullptr, 1, bf);
+        HIP_TRY(hipMemcpyAsync(wcat, Wi, (size_t)2 * H * Din * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(wcat + (int64_t)2 * H * Din, Wc, (size_t)H * Din * sizeof(float), hipMemcpyDeviceToDevice, s));
+        gemm::run(s, w.dA, 4 * H, 1, wcat, Din, 1, w.dIn, Din, (int64_t)T * N, Din, 3 * H, false, nullptr, 1, bf);
       }
     }
   } else if (c.rnn_type == 1) {

@@ -288,6 +288,7 @@ void rnn_cell_fwd(hipStream_t s, float* pre, const float* bh, const float* mask,
 void rnn_cell_bwd(hipStream_t s, const float* pre, const float* hcur, const float* mask, const float* dH_up, const float* dH, float* dA, int64_t N,
                   int H, int relu);
 void add_bias_rows(hipStream_t s, float* Y, const float* b, int64_t rows, int cols);
+void add_into(hipStream_t s, float* dst, const float* src, int64_t n);   // dst[i] += src[i]
 void col_sum_add(hipStream_t s, const float* A, int64_t rows, int cols, float* out, int64_t ld = 0, float* out2 = nullptr);  // ld: row stride of A (0 = cols); out2: also += there
 void gru_gates_fwd(hipStream_t s, float* a, const float* hp, int64_t N, int H);
 void gru_out_fwd(hipStream_t s, float* a, const float* hp, float* h, int64_t N, int H);
