@@ -350,11 +350,11 @@ __global__ __launch_bounds__(256) void gemm_kernel_big(const float* __restrict__
 namespace gemm {
 
 void run(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C,
-         int64_t ldc, int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k, bool bf16) {
+         int64_t ldc, int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k, bool bf16, bool untiled) {
   if (M <= 0 || N <= 0) return;
   if (split_k < 1) split_k = 1;
   static const bool no_tiled = getenv("KPRN_NO_TILED_GEMM") != nullptr;  // (measurement: the round-1 kernels)
-  if (!bf16 && !no_tiled && run_tiled(s, A, sAm, sAk, B, sBk, sBn, C, ldc, M, N, K, accumulate, bias, split_k)) return;
+  if (!bf16 && !no_tiled && !untiled && run_tiled(s, A, sAm, sAk, B, sBk, sBn, C, ldc, M, N, K, accumulate, bias, split_k)) return;
   int64_t kchunk = (K + split_k - 1) / split_k;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
   if (kchunk <= 0) kchunk = BK;

@@ -649,7 +649,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       }
       if (T > 1) {
         ProfScope ps(h, "gemm_o2g_bwd_dw");
-        gemm::run(s, w.dA + (int64_t)N * 4 * H, 1, 4 * H, hs, H, 1, gd + h->layer[l].Wo, H, 2 * H, H, (int64_t)(T - 1) * N, true, nullptr, split, bf);
+        gemm::run(s, w.dA + (int64_t)N * 4 * H, 1, 4 * H, hs, H, 1, gd + h->layer[l].Wo, H, 2 * H, H, (int64_t)(T - 1) * N, true, nullptr, split, bf, /*untiled=*/true);
         // c_h2h += d pre_n[1..T-1]^T (r*h')[1..T-1]
         gemm::run(s, w.dA + (int64_t)N * 4 * H + 2 * H, 1, 4 * H, act + (int64_t)N * 4 * H + 3 * H, 4 * H, 1, gd + h->layer[l].Uc, H, H, H,
                   (int64_t)(T - 1) * N, true, nullptr, split, bf);
@@ -669,7 +669,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       {
         ProfScope ps(h, "gemm_i2g_bwd_dw");
         HIP_TRY(hipMemsetAsync(gcat, 0, (size_t)cat * sizeof(float), s));
-        gemm::run(s, w.dA, 1, 4 * H, in, Din, 1, gcat, Din, 3 * H, Din, (int64_t)T * N, true, nullptr, split, bf);
+        gemm::run(s, w.dA, 1, 4 * H, in, Din, 1, gcat, Din, 3 * H, Din, (int64_t)T * N, true, nullptr, split, bf, /*untiled=*/true);
         kk::add_into(s, gd + h->layer[l].Wi, gcat, (int64_t)2 * H * Din);
         kk::add_into(s, gd + h->layer[l].Wc, gcat + (int64_t)2 * H * Din, (int64_t)H * Din);
       }

@@ -575,7 +575,8 @@ namespace gemm {
 // element (m,k) of A at A[m*sAm + k*sAk]; (k,n) of B at B[k*sBk + n*sBn]; C row-major ldc.
 // accumulate: C += (atomic when split_k > 1); else C = A*B (+ bias[n]).
 void run(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C, int64_t ldc,
-         int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k, bool bf16 = false);
+         int64_t M, int N, int64_t K, bool accumulate, const float* bias, int split_k, bool bf16 = false, bool untiled = false);
+// (untiled: keep the product off gemm_tiled.hip -- the GRU's split-K dW products, M = 2H / 3H = 500 / 750 rows: 1.53 against 2.06 ms, profiles/r06/bench_r_gru_*)
 // gemm_tiled.hip: 128 x 128 x 32 LDS-tiled kernel (16-byte loads, XCD-aware tile order); false: shape / layout not covered
 bool run_tiled(hipStream_t s, const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C, int64_t ldc, int64_t M, int N,
                int64_t K, bool accumulate, const float* bias, int split_k);

@@ -120,33 +120,46 @@ def test_wide_fp32_layer_kernels_keep_state_in_registers_and_their_weight_ring_c
     SIMD, 512 entries) and the weights arrive through an LDS-DMA ring with COUNTED vmcnt waits.  Pinned here, per instantiation <CELL, NCH, flag>: nothing is spilled
     (the H = 256 BPTT, NCH = 4, parks a few dozen registers: bounded), no scratch traffic between the MFMAs, the ring is still LDS-DMA, and most of its waits are
     counted ones -- a build in which hipcc sinks the waits to vmcnt(0) (the first builds did) would pass every parity test and lose the overlap.
-    (These kernels leave early for workgroups without a tile, so their bodies end at .Lfunc_end, not at the first s_endpgm.)"""
+    (These kernels leave early for workgroups without a tile, so their bodies end at .Lfunc_end, not at the first s_endpgm.)
+    Round 6, CELL 2 (nn.GRU): the forward instantiations spill nothing; the BPTT launch parks 25 (99 with a layer above) registers, all of it in the cell's three parts --
+    a schedule that kept save planes alive across the step loop spilled ~260 and reloaded them between the MFMAs.  Their forward's waits between the
+    first and the last MFMA of a step include hipcc's own for the cell's bias quads and the x rows (most of them vmcnt(0)): only the counted ring waits are pinned there."""
     text = chk.compile_isa(os.path.join(CSRC, "layer_f32_persist.hip"))
     res = {k: v for k, v in chk.kernel_resources(text).items() if "lp32" in k and ("k_layer" in k or "k_bptt" in k)}
-    assert len(res) == 20, sorted(res)
+    assert len(res) == 30, sorted(res)
     seen = 0
     for km in re.finditer(r"\n(_ZN4lp32\d+k_(layer|bptt)\w+):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", text, re.S):
         name, kind = km.group(1), km.group(2)
         nch4 = "ELi4EL" in name
+        gru = "ILi2E" in name
         v = res[name]
         assert v["vgpr_count"] <= 512, (name, v)
-        if kind == "bptt" and nch4:
+        if kind == "bptt" and gru:
+            assert v["vgpr_spill_count"] <= (110 if name.endswith("Lb1EEEvNS_6BPArgsE") else 32), (name, v)     # 98 / 25
+        elif kind == "bptt" and nch4:
             assert v["vgpr_spill_count"] <= 64, (name, v)     # 27 / 51
         else:
             assert v["vgpr_spill_count"] == 0, (name, v)
         ins = [l.split(";")[0].strip() for l in km.group(3).split("\n")]
         ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
         mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
-        assert len(mf) >= 128, (name, len(mf))
+        assert len(mf) >= (96 if gru else 128), (name, len(mf))
         inside = ins[mf[0]:mf[-1]]
         scratch = [l for l in inside if l.startswith("scratch_")]
-        assert len(scratch) <= (16 if (kind == "bptt" and nch4) else 0), (name, len(scratch))
+        if kind == "bptt" and gru:   # (42 / 3: between a step's products, in the cell's parts)
+            assert len(scratch) <= (48 if name.endswith("Lb1EEEvNS_6BPArgsE") else 6), (name, len(scratch))
+        else:
+            assert len(scratch) <= (16 if (kind == "bptt" and nch4) else 0), (name, len(scratch))
         assert [l for l in inside if l.startswith("global_load_lds")], name       # the weight ring
         waits = [l for l in inside if l.startswith("s_waitcnt") and "vmcnt" in l]
         drained = [l for l in waits if "vmcnt(0)" in l]
-        assert waits and len(drained) <= (0.45 if kind == "layer" else 0.32) * len(waits), (name, len(drained), len(waits))
+        if gru:
+            counted = [l for l in waits if "vmcnt(0)" not in l]
+            assert len(counted) >= 8, (name, len(counted), len(waits))      # the ring's own waits (vmcnt(8) / (4), with the save requests' allowance in the BPTT)
+        else:
+            assert waits and len(drained) <= (0.45 if kind == "layer" else 0.32) * len(waits), (name, len(drained), len(waits))
         seen += 1
-    assert seen == 20
+    assert seen == 30
 
 
 def test_operand_loads_are_not_a_chain_of_round_trips():
