@@ -42,6 +42,7 @@ typedef f32x4 f32x4u __attribute__((aligned(4)));
 constexpr int ROWS = 64, NTHR = 256;
 constexpr int XPMAX = 16;   // 16-byte pieces of a tile row one thread prefetches (Din <= 256)
 constexpr int GB = 4096;    // bytes of one wave's weight group in the DMA ring: 4 n-tiles x 64 lanes x 16 B
+constexpr int BS_FLOATS = 4 * 256;   // the forward's bias planes in LDS
 
 struct LArgs {
   const float* in; int64_t N; int T; int Din; int H;
@@ -106,6 +107,19 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
   const int t_end = __builtin_amdgcn_readfirstlane((int)(a.tiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x));
   if (t_beg >= t_end) return;
   for (int i = tid; i < ROWS * PITCH; i += NTHR) At[i] = 0.f;
+  // The cell's bias quads, staged once per launch: Bs[plane][256] (FastLSTM: gates i, g, f, o; rnn: b_i2h + b_h2h; gru: r, z, candidate), zero past H.  (Read from
+  // global memory inside the cell, every chunk's cell began with an exposed round trip: hipcc's vmcnt(0) in front of the first use.)
+  float* const Bs = (float*)(smem + (size_t)ROWS * PITCH * 4 + (size_t)4 * R * GB);
+  for (int i = tid; i < BS_FLOATS; i += NTHR) {
+    const int q = i >> 8, u = i & 255;
+    float v = 0.f;
+    if (u < H) {
+      if (CELL == 0) v = a.bi[q * H + u];
+      else if (CELL == 1) v = (q == 0) ? a.bi[u] + a.bo[u] : 0.f;
+      else v = (q < 2) ? a.bi[q * H + u] : (q == 2 ? a.bc[u] : 0.f);
+    }
+    Bs[i] = v;
+  }
   bar();
 
   // ---- weight rows of this lane's four n-tiles
@@ -321,9 +335,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
           const int u0 = 64 * c + 16 * w + 4 * ag, nv = H - u0;
           f32x4 bq[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bq[q][r] = (r < nv) ? a.bi[q * H + u0 + r] : 0.f;
+          for (int q = 0; q < 4; ++q) bq[q] = *(const f32x4*)(Bs + q * 256 + u0);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int64_t row = row0 + 16 * i + arow;
@@ -357,9 +369,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
               const int ch = 2 * c + cc;
               if (ch < NCH) {
                 const int u0 = 64 * ch + 16 * w + 4 * ag, nv = H - u0;
-                f32x4 br, bz;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { br[r] = (r < nv) ? a.bi[u0 + r] : 0.f; bz[r] = (r < nv) ? a.bi[H + u0 + r] : 0.f; }
+                const f32x4 br = *(const f32x4*)(Bs + u0), bz = *(const f32x4*)(Bs + 256 + u0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                   const int64_t row = row0 + 16 * i + arow;
@@ -383,9 +393,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
               const int u0 = 64 * ch + 16 * w + 4 * ag, nv = H - u0;
-              f32x4 bn;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) bn[r] = (r < nv) ? a.bc[u0 + r] : 0.f;
+              const f32x4 bn = *(const f32x4*)(Bs + 512 + u0);
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 const int64_t row = row0 + 16 * i + arow;
@@ -409,9 +417,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int u0 = 256 * c + 64 * w + 16 * q + 4 * ag, nv = H - u0;
-            f32x4 bv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (r < nv) ? a.bi[u0 + r] + a.bo[u0 + r] : 0.f;
+            const f32x4 bv = *(const f32x4*)(Bs + u0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int64_t row = row0 + 16 * i + arow;
@@ -962,7 +968,7 @@ static int num_cus() {
 }
 static size_t lds_need(int Din, int H, int R) {
   const int KX = (Din + 31) & ~31, KH = (H + 31) & ~31;
-  return (size_t)ROWS * (KX + KH + 4) * 4 + (size_t)4 * R * GB;
+  return (size_t)ROWS * (KX + KH + 4) * 4 + (size_t)4 * R * GB + (size_t)BS_FLOATS * 4;
 }
 // shapes the launch takes: fp32, Din a multiple of 4 up to 256, H up to 256 (FastLSTM: up to 4 chunks of 64 units; rnn: one chunk of 256), enough
 // tiles to give every CU one
