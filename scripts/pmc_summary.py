@@ -36,10 +36,10 @@ def short(name):
     if "k_lstm16_persist" in name:   # persistent bf16 layer kernel: <KX, KH, SAVE, ...>
         return "lstm_persist_bf16_train" if "24, 24, true" in name.replace("(bool)1", "true") else "lstm_persist_bf16_score"
     if "lp32::k_layer<" in name:      # one wide fp32 layer, all T steps (layer_f32_persist.hip): <CELL, NCH, SAVE>
-        cell = "rnn" if "k_layer<1" in name else "lstm"
+        cell = "rnn" if "k_layer<1" in name else ("gru" if "k_layer<2" in name else "lstm")
         return cell + ("_layer_fwd_train" if "true>" in name.replace("(bool)1", "true") else "_layer_fwd")
     if "lp32::k_bptt<" in name:
-        return ("rnn" if "k_bptt<1" in name else "lstm") + "_layer_bwd"
+        return ("rnn" if "k_bptt<1" in name else ("gru" if "k_bptt<2" in name else "lstm")) + "_layer_bwd"
     if "k_lstm_fwd_mc" in name:
         return "lstm_mc_fwd_train" if "true>" in name else "lstm_mc_fwd"
     if "k_lstm_fwd" in name:   # k_lstm_fwd<L, SAVE, NMT>: the training (SAVE) and the scoring launch are separate families
