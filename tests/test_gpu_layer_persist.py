@@ -19,13 +19,13 @@ def rel_inf(a, b):
 
 def _mk(kind, dims, L, Vr=9, use_relu=1, init=0.07, seed=5):
     dt, de, dr, H = dims
-    rt = 1 if kind == "rnn" else 0
+    rt = {"lstm": 0, "rnn": 1, "gru": 2}[kind]
     eng = _ffi.Engine(6, 800, Vr, dt, de, dr, H, L, rnn_type=rt, use_relu=use_relu, param_init=init)
     eng.set_option("impl", "generic")
     eng.set_option("persist_layers", "2")
     o64 = Oracle(make_cfg(Vt=6, Ve=800, Vr=Vr, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=rt, use_relu=use_relu), np.float64)
     theta = o64.init_params(seed, init).astype(np.float32).astype(np.float64)
-    if rt:
+    if rt == 1:
         o64.zero_pad(theta)   # zero pad embeddings -> MaskZero masks the pad steps
     eng.set_flat_params(theta.astype(np.float32))
     return eng, o64, theta
@@ -125,7 +125,7 @@ def test_persistent_gru_layer_against_the_f64_oracle(dims, L, pairs, P, T):
     eng.close()
 
 
-@pytest.mark.parametrize("kind,dims,L", [("lstm", (64, 64, 64, 192), 2), ("rnn", (50, 100, 50, 250), 1)])
+@pytest.mark.parametrize("kind,dims,L", [("lstm", (64, 64, 64, 192), 2), ("rnn", (50, 100, 50, 250), 1), ("gru", (50, 100, 50, 250), 1), ("gru", (32, 64, 32, 128), 2)])
 def test_adam_steps_through_the_persistent_layers(kind, dims, L):
     """Three Adam steps: the loss follows the float64 oracle (measured 1e-7), the parameters equal those of the per-step launches to fp32 reordering
     (measured 4e-7: scripts/gpu_probe_layer_persist.py), and both sit on the oracle's walk.  Against the oracle a max bar would be vacuous: Adam's first
@@ -153,12 +153,12 @@ def test_adam_steps_through_the_persistent_layers(kind, dims, L):
     ref.close()
 
 
-@pytest.mark.parametrize("kind,dims,L,pairs,P", [("lstm", (64, 64, 64, 192), 2, 4400, 4), ("rnn", (50, 100, 50, 250), 1, 5700, 3)])
+@pytest.mark.parametrize("kind,dims,L,pairs,P", [("lstm", (64, 64, 64, 192), 2, 4400, 4), ("rnn", (50, 100, 50, 250), 1, 5700, 3), ("gru", (50, 100, 50, 250), 1, 5700, 3)])
 def test_a_tile_per_cu_takes_the_launch_by_default(kind, dims, L, pairs, P):
     """>= 16 384 paths (a 64-path tile for every CU): the default configuration uses the persistent launch; a second pass is bit-identical; scores of a
     sample of pairs against the float64 oracle"""
     dt, de, dr, H = dims
-    rt = 1 if kind == "rnn" else 0
+    rt = {"lstm": 0, "rnn": 1, "gru": 2}[kind]
     eng = _ffi.Engine(6, 5000, 9, dt, de, dr, H, L, rnn_type=rt, use_relu=1, param_init=0.06)
     eng.set_option("impl", "generic")
     o64 = Oracle(make_cfg(Vt=6, Ve=5000, Vr=9, dt=dt, de=de, dr=dr, H=H, L=L, rnn_type=rt, use_relu=1), np.float64)
@@ -167,7 +167,7 @@ def test_a_tile_per_cu_takes_the_launch_by_default(kind, dims, L, pairs, P):
     b = eng.batch(idx, labels)
     eng.profile(True)
     out = eng.forward(b, 1, want=("probs",))
-    assert ("rnn_layer_fwd" if rt else "lstm_layer_fwd") in eng.profile_get()
+    assert kind + "_layer_fwd" in eng.profile_get()
     again = eng.forward(b, 1, want=("probs",))
     assert np.array_equal(out["probs"], again["probs"])
     sel = np.arange(0, pairs, 37)
