@@ -361,7 +361,7 @@ static void forward_generic(kprn_handle* h, const kprn_batch* b, bool save) {
         // all T steps of the layer in ONE persistent launch: h never leaves the CU, weights stream L2 -> LDS by DMA (layer_f32_persist.hip)
         ProfScope ps(h, "rnn_layer_fwd");
         lp32::forward_layer(s, 1, in, N, T, Din, H, h->dense + h->layer[l].Wi, h->dense + h->layer[l].Wo, h->dense + h->layer[l].bi, h->dense + h->layer[l].bo, hs,
-                            nullptr, pre, mask, c.use_relu == 1 ? 1 : 0, save, /*write_all_h=*/true);
+                            nullptr, pre, mask, c.use_relu == 1 ? 1 : 0, save, /*write_all_h=*/l < L - 1);   // (a scoring pass needs the top layer's last step only; the training forward writes every step: forward_layer)
         continue;
       }
       if (stepk) {
