@@ -482,6 +482,15 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
 //     arithmetic is scalar); the saves of the NEXT chunk are requested right behind a chunk's cell backward, so they land under its product.  Those
 //     requests sit between DMA groups in the in-order return stream: the hand-written waits for the first three groups of a product allow for them
 //     (vmcnt(groups + NPF)) instead of draining them.
+// measurement builds (scripts/build_variants.py, KPRN_VARIANT_DEFS=-DKPRN_BPTT_DBG=<mask>): 1 no dA stores to global memory, 2 no save requests, 4 no products.  Results are
+// wrong by construction; the shipped library has the mask at 0.
+#ifndef KPRN_BPTT_DBG
+#define KPRN_BPTT_DBG 0
+#endif
+__device__ __forceinline__ void store4d(float* __restrict__ p, const f32x4 v, int nv) {
+  if (KPRN_BPTT_DBG & 1) { asm volatile("" :: "v"(v), "v"(p)); return; }
+  store4(p, v, nv);
+}
 struct BPArgs {
   const float* act;      // FastLSTM: gate values [T][N][4H];  rnn: unused
   const float* cs;       // FastLSTM: c [T][N][H]
@@ -627,6 +636,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
   };
   auto ldq = [&](rsrc_t r, unsigned voff, unsigned soff) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0)); };
   auto request_gru = [&](int64_t row0, int t, int which) {
+    if (KPRN_BPTT_DBG & 2) return;
     asm volatile("" ::: "memory");
     const rsrc_t ra = make_rsrc(a.act + ((int64_t)t * a.N + row0) * GH);
     const rsrc_t rh = make_rsrc(a.hs + ((int64_t)(t > 0 ? t - 1 : 0) * a.N + row0) * H);   // (t = 0: any valid rows, the cell takes h' = 0)
@@ -647,6 +657,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
   };
   f32x4 dzk[CELL == 2 ? 4 : 1][4];   // gru: d pre_z between the cell's first and third part
   auto request = [&](int64_t row0, int t, int c) {   // unconditional loads from clamped addresses: exactly NPF requests per lane
+    if (KPRN_BPTT_DBG & 2) return;
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -763,14 +774,15 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
                 *(f32x4*)(Dt + (16 * i + arow) * BP_LD + 64 * w + 16 * q + 4 * ag) = d;
                 if (row < a.N && nv > 0) {
                   float* gdst = a.dA + ((int64_t)t * a.N + row) * GH + u0;
-                  store4(gdst + col, d, nv);
-                  if (t == 0) { store4(gdst + H, dzk[q][i], nv); store4(gdst, f32x4{0.f, 0.f, 0.f, 0.f}, nv); }
+                  store4d(gdst + col, d, nv);
+                  if (t == 0) { store4d(gdst + H, dzk[q][i], nv); store4d(gdst, f32x4{0.f, 0.f, 0.f, 0.f}, nv); }
                 }
               }
             }
       };
       // ---- gru: the product of one chunk on the tile the part just wrote (npf: save requests issued behind the groups in flight)
       auto gru_product = [&](int npf) __attribute__((always_inline)) {
+        if (KPRN_BPTT_DBG & 4) return;
         bar();
         wait_w(c_n, npf);
         read_a(0, 0);
@@ -818,10 +830,10 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
         gru_part(std::integral_constant<int, 0>{});
         if (t > 0) {
           request_gru(row0, t, 1);                         // r, under chunk 0's product
-          gru_product(16);
+          gru_product((KPRN_BPTT_DBG & 2) ? 0 : 16);
           gru_part(std::integral_constant<int, 1>{});
           if (UP) request_gru(row0, t - 1, 4);             // the gradient from above of step t - 1, under chunk 1's product
-          gru_product(UP ? 16 : 0);
+          gru_product(((KPRN_BPTT_DBG & 2) || !UP) ? 0 : 16);
           gru_part(std::integral_constant<int, 2>{});
           gru_product(0);
         }
@@ -829,6 +841,8 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
 #pragma unroll
       for (int c = 0; c < (CELL == 2 ? 0 : KCH); ++c) {
         // ---- cell backward of chunk c: dA quads -> global + LDS tile
+        // (Taking every requested plane over in front of the first dA store -- so that hipcc's counted waits for the later quads do not turn into waits for the part's own
+        //  stores -- was measured: dims B 1.386 -> 1.349 ms, shipped rnn 0.624 -> 0.652 (the take-over's vmcnt(0) also drains the weight groups in flight): not kept.)
         if constexpr (CELL == 2) {
           // (gru: its own step body above)
         } else if constexpr (CELL == 0) {
@@ -858,7 +872,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
             *(f32x4*)(lrow) = di; *(f32x4*)(lrow + 64) = dg; *(f32x4*)(lrow + 128) = df; *(f32x4*)(lrow + 192) = dO;
             if (row < a.N && nv > 0) {
               float* gdst = a.dA + ((int64_t)t * a.N + row) * GH + u0;
-              store4(gdst, di, nv); store4(gdst + H, dg, nv); store4(gdst + 2 * H, df, nv); store4(gdst + 3 * H, dO, nv);
+              store4d(gdst, di, nv); store4d(gdst + H, dg, nv); store4d(gdst + 2 * H, df, nv); store4d(gdst + 3 * H, dO, nv);
             }
           }
         } else {
@@ -879,7 +893,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
                 d[r] = (r < nv && mk[i] != 0.f) ? dhv * der : 0.f;
               }
               *(f32x4*)(Dt + (16 * i + arow) * BP_LD + 64 * w + 16 * q + 4 * ag) = d;
-              if (row < a.N && nv > 0) store4(a.dA + ((int64_t)t * a.N + row) * GH + u0, d, nv);
+              if (row < a.N && nv > 0) store4d(a.dA + ((int64_t)t * a.N + row) * GH + u0, d, nv);
             }
           }
         }
@@ -890,8 +904,9 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
             if (c + 1 < KCH) request(row0, t, c + 1); else request(row0, t - 1, 0);
           }
         }
-        const int npf = (CELL == 2) ? (c == 0 ? 16 : (c == 1 ? (UP ? 16 : 0) : 48)) : (more ? NPF : 0);   // requests issued behind the product's first groups
+        const int npf = (KPRN_BPTT_DBG & 2) ? 0 : ((CELL == 2) ? 0 : (more ? NPF : 0));   // requests issued behind the product's first groups
         if (t == 0) continue;   // (uniform) step 0: no dh_{-1} to form
+        if (KPRN_BPTT_DBG & 4) continue;
         bar();
         // ---- product of the chunk: 16 groups in 8 pairs; fragments of group n + 1 are read under the MFMAs of group n
         wait_w(c_n, npf);
