@@ -482,7 +482,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
 //     arithmetic is scalar); the saves of the NEXT chunk are requested right behind a chunk's cell backward, so they land under its product.  Those
 //     requests sit between DMA groups in the in-order return stream: the hand-written waits for the first three groups of a product allow for them
 //     (vmcnt(groups + NPF)) instead of draining them.
-// measurement builds (scripts/build_variants.py, KPRN_VARIANT_DEFS=-DKPRN_BPTT_DBG=<mask>): 1 no dA stores to global memory, 2 no save requests, 4 no products.  Results are
+// measurement builds (scripts/build_variants.py, KPRN_VARIANT_DEFS=-DKPRN_BPTT_DBG=<mask>): 1 no dA stores to global memory, 2 no save requests, 4 no products, (rnn only) 8 no LDS tile writes, 16 no quad shift / masks.  Results are
 // wrong by construction; the shipped library has the mask at 0.
 #ifndef KPRN_BPTT_DBG
 #define KPRN_BPTT_DBG 0
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       int u = 64 * w + 16 * q + 4 * ag;
-      if (u + 4 > H) u = (H >= 4) ? H - 4 : 0;
+      if (u >= H) u = 0;
       u4[q] = (unsigned)u * 4u;
     }
   };
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
       if (row >= a.N) row = a.N - 1;
       if constexpr (CELL == 0) {
         int u = 64 * c + 16 * w + 4 * ag;
-        if (u + 4 > H) u = (H >= 4) ? H - 4 : 0;   // (a quad straddling H re-reads the last full quad: its lanes are masked in the cell)
+        if (u >= H) u = 0;   // (units past H: any valid quad, masked in the cell.  A quad STRADDLING H is read where it lies -- up to 12 bytes past its row, i.e. the next row's first values or, behind a plane's last row, the 64 bytes of slack every device allocation carries (kprn_api.hip dalloc) -- and its lanes past H are masked by SELECTS: shifting it back inside the row cost every element of every plane a runtime component select, 14 % of the shipped rnn's launch: profiles/r06/probe_bptt_knockouts.txt)
         const float* ar = a.act + ((int64_t)t * a.N + row) * GH + u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) sv.g[q][i] = *(const f32x4u*)(ar + q * H);
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           int u = 64 * w + 16 * q + 4 * ag;
-          if (u + 4 > H) u = (H >= 4) ? H - 4 : 0;
+          if (u >= H) u = 0;
           sv.hq[q][i] = *(const f32x4u*)(a.hs + ((int64_t)t * a.N + row) * H + u);
           sv.up[q][i] = *(const f32x4u*)(a.dHup + (UP ? ((int64_t)t * a.N + row) * H : row * H) + u);
         }
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int u0 = 64 * w + 16 * q + 4 * ag, nv = H - u0;
-        const int sh = (u0 + 4 > H && H >= 4) ? u0 + 4 - H : 0;
+        constexpr int sh = 0;   // (quads are read where they lie: see request)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int u0 = 64 * w + 16 * q + 4 * ag, nv = H - u0;
-              const int sh = (u0 + 4 > H && H >= 4) ? u0 + 4 - H : 0;
+              constexpr int sh = 0;   // (quads are read where they lie: see request)
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 const int64_t row = row0 + 16 * i + arow;
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
           // (gru: its own step body above)
         } else if constexpr (CELL == 0) {
           const int u0 = 64 * c + 16 * w + 4 * ag, nv = H - u0;
-          const int sh = (u0 + 4 > H && H >= 4) ? u0 + 4 - H : 0;   // the quad was read `sh` units early (see request): its valid elements sit at r + sh
+          constexpr int sh = 0;   // (quads are read where they lie: see request)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int64_t row = row0 + 16 * i + arow;
@@ -879,20 +879,20 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int u0 = 64 * w + 16 * q + 4 * ag, nv = H - u0;
-            const int sh = (u0 + 4 > H && H >= 4) ? u0 + 4 - H : 0;
+            constexpr int sh = 0;   // (quads are read where they lie: see request)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int64_t row = row0 + 16 * i + arow;
               f32x4 d;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const int rs = (r + sh < 4) ? r + sh : 3;
+                const int rs = (KPRN_BPTT_DBG & 16) ? r : ((r + sh < 4) ? r + sh : 3);   // (16: measurement -- no quad shift, no masks)
                 const float hv = sv.hq[q][i][rs];
                 const float der = a.relu ? (hv > 0.f ? 1.f : 0.f) : (1.f - hv * hv);
                 const float dhv = dh[i][q][r] + upw * sv.up[q][i][rs];
-                d[r] = (r < nv && mk[i] != 0.f) ? dhv * der : 0.f;
+                d[r] = (KPRN_BPTT_DBG & 16) ? dhv * der : ((r < nv && mk[i] != 0.f) ? dhv * der : 0.f);
               }
-              *(f32x4*)(Dt + (16 * i + arow) * BP_LD + 64 * w + 16 * q + 4 * ag) = d;
+              if (!(KPRN_BPTT_DBG & 8)) *(f32x4*)(Dt + (16 * i + arow) * BP_LD + 64 * w + 16 * q + 4 * ag) = d;   // (8: measurement -- no LDS tile writes)
               if (row < a.N && nv > 0) store4d(a.dA + ((int64_t)t * a.N + row) * GH + u0, d, nv);
             }
           }
