@@ -841,8 +841,26 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
 #pragma unroll
       for (int c = 0; c < (CELL == 2 ? 0 : KCH); ++c) {
         // ---- cell backward of chunk c: dA quads -> global + LDS tile
-        // (Taking every requested plane over in front of the first dA store -- so that hipcc's counted waits for the later quads do not turn into waits for the part's own
-        //  stores -- was measured: dims B 1.386 -> 1.349 ms, shipped rnn 0.624 -> 0.652 (the take-over's vmcnt(0) also drains the weight groups in flight): not kept.)
+        // Every requested plane is taken over HERE, in front of the first dA store (KPRN_BPTT_TAKEOVER: cell mask, 0 = off for A/B builds): hipcc waits for a loaded register at
+        // its first use with a COUNT, and with the part's own stores in the same in-order counter the later quads' waits turned into waits for the stores' acknowledgements.
+        // One call, alternating (profiles/r06/bench_x_*): shipped rnn 0.628 -> 0.618 ms, dims B 1.351 -> 1.330.
+#ifndef KPRN_BPTT_TAKEOVER
+#define KPRN_BPTT_TAKEOVER 3
+#endif
+        if constexpr (CELL != 2) {
+          if ((KPRN_BPTT_TAKEOVER >> CELL) & 1) {
+            if constexpr (CELL == 0) {
+              asm volatile("" :: "v"(sv.g[0][0]), "v"(sv.g[0][1]), "v"(sv.g[0][2]), "v"(sv.g[0][3]), "v"(sv.g[1][0]), "v"(sv.g[1][1]), "v"(sv.g[1][2]), "v"(sv.g[1][3]));
+              asm volatile("" :: "v"(sv.g[2][0]), "v"(sv.g[2][1]), "v"(sv.g[2][2]), "v"(sv.g[2][3]), "v"(sv.g[3][0]), "v"(sv.g[3][1]), "v"(sv.g[3][2]), "v"(sv.g[3][3]));
+              asm volatile("" :: "v"(sv.c[0]), "v"(sv.c[1]), "v"(sv.c[2]), "v"(sv.c[3]), "v"(sv.cp[0]), "v"(sv.cp[1]), "v"(sv.cp[2]), "v"(sv.cp[3]));
+              asm volatile("" :: "v"(sv.up[0][0]), "v"(sv.up[0][1]), "v"(sv.up[0][2]), "v"(sv.up[0][3]));
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                asm volatile("" :: "v"(sv.hq[q][0]), "v"(sv.hq[q][1]), "v"(sv.hq[q][2]), "v"(sv.hq[q][3]), "v"(sv.up[q][0]), "v"(sv.up[q][1]), "v"(sv.up[q][2]), "v"(sv.up[q][3]));
+            }
+          }
+        }
         if constexpr (CELL == 2) {
           // (gru: its own step body above)
         } else if constexpr (CELL == 0) {
