@@ -233,6 +233,9 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
 
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int64_t row0 = (int64_t)tile * ROWS;
+    // (wave-uniform) every row of the tile exists: with a whole 16-unit block below H as well, a quad's stores need no lane predicate and no partial form -- the
+    // exec-mask bookkeeping of `if (row < N && nv > 0) store4(.., nv)` around every store was a tenth of the cell's instructions
+    const bool tfull = row0 + ROWS <= a.N;
     f32x4 cst[CELL == 0 ? NCH : 1][4];   // FastLSTM: c_t of this lane's quads
     f32x4 hn[CELL == 1 ? 4 : NCH][4];    // h_t of the step (written to LDS behind the step's last MFMA)
     f32x4 zst[CELL == 2 ? NCH : 1][4], rh[CELL == 2 ? NCH : 1][4];   // gru: z_t and r_t * h_{t-1} between the two halves of the cell
@@ -352,15 +355,17 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
             }
             cst[c][i] = cc;
             hn[c][i] = hh;
-            if (row < a.N && nv > 0) {
+            auto put = [&](auto nvc) __attribute__((always_inline)) {
               const int64_t o = ((int64_t)t * a.N + row) * H + u0;
               if (SAVE) {
-                store4(a.cs + o, cc, nv);
+                store4(a.cs + o, cc, nvc);
                 float* gdst = a.act + ((int64_t)t * a.N + row) * (4 * (int64_t)H) + u0;
-                store4(gdst, ig, nv); store4(gdst + H, gg, nv); store4(gdst + 2 * H, fg, nv); store4(gdst + 3 * H, og, nv);
+                store4(gdst, ig, nvc); store4(gdst + H, gg, nvc); store4(gdst + 2 * H, fg, nvc); store4(gdst + 3 * H, og, nvc);
               }
-              if (a.write_all_h || t == T - 1) store4(a.hs + o, hh, nv);
-            }
+              if (a.write_all_h || t == T - 1) store4(a.hs + o, hh, nvc);
+            };
+            if (tfull && 64 * c + 16 * w + 16 <= H) put(std::integral_constant<int, 4>{});
+            else if (row < a.N && nv > 0) put(nv);
           }
         } else if constexpr (CELL == 2) {
           if (c < NPR) {   // first half: r, z of chunks 2 c, 2 c + 1;  r * h' (h' = this lane's h_{t-1}: zero at t = 0)
@@ -382,9 +387,13 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
                   }
                   zst[ch][i] = zg;
                   rh[ch][i] = rhv;
-                  if (SAVE && row < a.N && nv > 0) {
-                    float* gdst = a.act + ((int64_t)t * a.N + row) * (4 * (int64_t)H) + u0;
-                    store4(gdst, rg, nv); store4(gdst + H, zg, nv); store4(gdst + 3 * H, rhv, nv);
+                  if (SAVE) {
+                    auto put = [&](auto nvc) __attribute__((always_inline)) {
+                      float* gdst = a.act + ((int64_t)t * a.N + row) * (4 * (int64_t)H) + u0;
+                      store4(gdst, rg, nvc); store4(gdst + H, zg, nvc); store4(gdst + 3 * H, rhv, nvc);
+                    };
+                    if (tfull && 64 * ch + 16 * w + 16 <= H) put(std::integral_constant<int, 4>{});
+                    else if (row < a.N && nv > 0) put(nv);
                   }
                 }
               }
@@ -405,11 +414,13 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
                   hh[r] = (r < nv) ? (1.f - z) * ng[r] + z * hn[ch][i][r] : 0.f;
                 }
                 hn[ch][i] = hh;
-                if (row < a.N && nv > 0) {
+                auto put = [&](auto nvc) __attribute__((always_inline)) {
                   const int64_t o = ((int64_t)t * a.N + row) * H + u0;
-                  if (SAVE) store4(a.act + ((int64_t)t * a.N + row) * (4 * (int64_t)H) + 2 * H + u0, ng, nv);
-                  if (a.write_all_h || t == T - 1) store4(a.hs + o, hh, nv);
-                }
+                  if (SAVE) store4(a.act + ((int64_t)t * a.N + row) * (4 * (int64_t)H) + 2 * H + u0, ng, nvc);
+                  if (a.write_all_h || t == T - 1) store4(a.hs + o, hh, nvc);
+                };
+                if (tfull && 64 * ch + 16 * w + 16 <= H) put(std::integral_constant<int, 4>{});
+                else if (row < a.N && nv > 0) put(nv);
               }
             }
           }
@@ -430,11 +441,13 @@ __global__ __launch_bounds__(NTHR, 1) void k_layer(LArgs a) {
                 v[r] = (live && r < nv) ? x : 0.f;
               }
               hn[q][i] = v;
-              if (row < a.N && nv > 0) {
+              auto put = [&](auto nvc) __attribute__((always_inline)) {
                 const int64_t o = ((int64_t)t * a.N + row) * H + u0;
-                if (SAVE) store4(a.act + o, pre, nv);
-                if (a.write_all_h || t == T - 1) store4(a.hs + o, v, nv);
-              }
+                if (SAVE) store4(a.act + o, pre, nvc);
+                if (a.write_all_h || t == T - 1) store4(a.hs + o, v, nvc);
+              };
+              if (tfull && 256 * c + 64 * w + 16 * q + 16 <= H) put(std::integral_constant<int, 4>{});
+              else if (row < a.N && nv > 0) put(nv);
             }
           }
         }
@@ -688,6 +701,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
 
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int64_t row0 = (int64_t)tile * ROWS;
+    const bool tfull = row0 + ROWS <= a.N;   // (wave-uniform) every row of the tile exists: see the forward
     f32x4 dh[4][NT], dc[CELL == 0 ? NCH : 1][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -772,7 +786,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
                   }
                 }
                 *(f32x4*)(Dt + (16 * i + arow) * BP_LD + 64 * w + 16 * q + 4 * ag) = d;
-                if (row < a.N && nv > 0) {
+                if (row < a.N && nv > 0) {   // (the uniform whole-block form of the other cells measured 1 % slower here: profiles/r06/bench_y_*)
                   float* gdst = a.dA + ((int64_t)t * a.N + row) * GH + u0;
                   store4d(gdst + col, d, nv);
                   if (t == 0) { store4d(gdst + H, dzk[q][i], nv); store4d(gdst, f32x4{0.f, 0.f, 0.f, 0.f}, nv); }
@@ -888,10 +902,12 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
             }
             float* lrow = Dt + (16 * i + arow) * BP_LD + 16 * w + 4 * ag;
             *(f32x4*)(lrow) = di; *(f32x4*)(lrow + 64) = dg; *(f32x4*)(lrow + 128) = df; *(f32x4*)(lrow + 192) = dO;
-            if (row < a.N && nv > 0) {
+            auto put = [&](auto nvc) __attribute__((always_inline)) {
               float* gdst = a.dA + ((int64_t)t * a.N + row) * GH + u0;
-              store4d(gdst, di, nv); store4d(gdst + H, dg, nv); store4d(gdst + 2 * H, df, nv); store4d(gdst + 3 * H, dO, nv);
-            }
+              store4d(gdst, di, nvc); store4d(gdst + H, dg, nvc); store4d(gdst + 2 * H, df, nvc); store4d(gdst + 3 * H, dO, nvc);
+            };
+            if (tfull && 64 * c + 16 * w + 16 <= H) put(std::integral_constant<int, 4>{});
+            else if (row < a.N && nv > 0) put(nv);
           }
         } else {
 #pragma unroll
@@ -911,7 +927,8 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
                 d[r] = (KPRN_BPTT_DBG & 16) ? dhv * der : ((r < nv && mk[i] != 0.f) ? dhv * der : 0.f);
               }
               if (!(KPRN_BPTT_DBG & 8)) *(f32x4*)(Dt + (16 * i + arow) * BP_LD + 64 * w + 16 * q + 4 * ag) = d;   // (8: measurement -- no LDS tile writes)
-              if (row < a.N && nv > 0) store4d(a.dA + ((int64_t)t * a.N + row) * GH + u0, d, nv);
+              if (tfull && 64 * w + 16 * q + 16 <= H) store4d(a.dA + ((int64_t)t * a.N + row) * GH + u0, d, 4);
+              else if (row < a.N && nv > 0) store4d(a.dA + ((int64_t)t * a.N + row) * GH + u0, d, nv);
             }
           }
         }
