@@ -700,7 +700,8 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       if (bptt1) {
         // the cell backward of all T steps + the recurrent gradient in ONE persistent launch (layer_f32_persist.hip k_bptt): dh never leaves the CU
         ProfScope ps(h, "rnn_layer_bwd");
-        lp32::bptt_layer(s, 1, nullptr, nullptr, hs, mask, has_up ? w.dIn : w.dH, has_up, Wo, lp_wot_buffer(h, H, H), w.dA, N, T, H, relu);
+        lp32::bptt_layer(s, 1, nullptr, nullptr, hs, mask, has_up ? w.dIn : w.dH, has_up, Wo, lp_wot_buffer(h, H, H), w.dA, N, T, H, relu, nullptr, gd + h->layer[l].bi,
+                         gd + h->layer[l].bo);
       } else if (has_up) HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
       for (int t = T - 1; t >= 0 && !bptt1; --t) {
         float* dA_t = w.dA + (int64_t)t * N * H;
@@ -718,7 +719,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
         ProfScope ps(h, "gemm_o2g_bwd_dw");
         gemm::run(s, w.dA + (int64_t)N * H, 1, H, hs, H, 1, gd + h->layer[l].Wo, H, H, H, (int64_t)(T - 1) * N, true, nullptr, split, bf);
       }
-      {
+      if (!(bptt1 && lp32::bptt_sums_bias(1, H))) {   // (the persistent BPTT launch forms the sums itself)
         ProfScope ps(h, "bias_colsum");  // i2h.bias and h2h.bias see the same gradient (both are added to every pre-activation)
         kk::col_sum_add(s, w.dA, (int64_t)T * N, H, gd + h->layer[l].bi, 0, gd + h->layer[l].bo);   // (one pass over dA for both)
       }
@@ -749,7 +750,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
     if (bptt0) {
       // the cell backward of all T steps + the recurrent gradient in ONE persistent launch (layer_f32_persist.hip k_bptt): dh / dc never leave the CU
       ProfScope ps(h, "lstm_layer_bwd");
-      lp32::bptt_layer(s, 0, act, cs, nullptr, nullptr, has_up ? w.dIn : w.dH, has_up, Wo, lp_wot_buffer(h, H, 4 * H), w.dA, N, T, H, 0);
+      lp32::bptt_layer(s, 0, act, cs, nullptr, nullptr, has_up ? w.dIn : w.dH, has_up, Wo, lp_wot_buffer(h, H, 4 * H), w.dA, N, T, H, 0, nullptr, gd + h->layer[l].bi);
     } else if (has_up) {
       HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
       HIP_TRY(hipMemsetAsync(w.dC, 0, (size_t)N * H * sizeof(float), s));
@@ -771,7 +772,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       // gWo[4H,H] += dA[1..T-1]^T * h[0..T-2]
       gemm::run(s, w.dA + (int64_t)N * 4 * H, 1, 4 * H, hs, H, 1, gd + h->layer[l].Wo, H, 4 * H, H, (int64_t)(T - 1) * N, true, nullptr, split, bf);
     }
-    {
+    if (!(bptt0 && lp32::bptt_sums_bias(0, H))) {   // (the persistent BPTT launch forms the sums itself, up to two chunks)
       ProfScope ps(h, "bias_colsum");
       kk::col_sum_add(s, w.dA, (int64_t)T * N, 4 * H, gd + h->layer[l].bi);
     }

@@ -567,7 +567,9 @@ void forward_layer(hipStream_t s, int cell, const float* in, int64_t N, int T, i
 bool bptt_supported(int cell, int64_t N, int H, bool force);
 size_t bptt_scratch_floats(int H, int GH);
 void bptt_layer(hipStream_t s, int cell, const float* act, const float* cs, const float* hs, const float* mask, const float* dHup, bool up, const float* Wo,
-                float* wot, float* dA, int64_t N, int T, int H, int relu, const float* Uc = nullptr /*gru: c_h2h.weight; Wo = o2g.weight [2H][H], wot of bptt_scratch_floats(H, 3H)*/);
+                float* wot, float* dA, int64_t N, int T, int H, int relu, const float* Uc = nullptr /*gru: c_h2h.weight; Wo = o2g.weight [2H][H], wot of bptt_scratch_floats(H, 3H)*/,
+                float* dbias = nullptr, float* dbias2 = nullptr /*bptt_sums_bias(): the layer's bias gradient(s) += the column sums of dA, formed inside the launch*/);
+bool bptt_sums_bias(int cell, int H);
 }  // namespace lp32
 
 // ---- GEMM (gemm_f32.hip): C[M,N] (+)= A(M,K) * B(K,N), arbitrary strides, fp32 MFMA -----------

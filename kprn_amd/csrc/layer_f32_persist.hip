@@ -512,6 +512,7 @@ struct BPArgs {
   const float* dHup;     // UP: [T][N][H] gradient from the layer above;  else [N][H]: the head's gradient, applied at t = T-1
   const float* WoT;      // [Hp rows][WG] W_o2g^T (row = output unit; zero rows / slack behind H);  gru: [c_h2h^T | o2g^T] (WG = 3H: k = candidate unit, r row, z row)
   float* dA;             // [T][N][GH]
+  float* dbias; float* dbias2;   // FastLSTM (up to 2 chunks) / rnn: the bias gradient (column sums of dA) is formed HERE, += per workgroup (nullptr: not wanted); rnn: both biases
   int64_t N; int T, H, GH, WG, relu;
   int64_t tiles;
 };
@@ -699,6 +700,12 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // column sums of this workgroup's dA quads (the bias gradient): per lane, reduced over the 16 lanes of a unit quad and added to the gradient once, at the end --
+  // the separate sweep over dA (kernels_basic.hip k_colsum) re-read 1.2 GB per layer at dims B
+  constexpr bool BSUM = (CELL == 1) || (CELL == 0 && NCH <= 2);   // (three chunks: 48 more registers spilled 500 bytes per lane)
+  f32x4 bsum[BSUM ? (CELL == 0 ? 4 * NCH : 4) : 1];
+#pragma unroll
+  for (int j = 0; j < (BSUM ? (CELL == 0 ? 4 * NCH : 4) : 1); ++j) bsum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int64_t row0 = (int64_t)tile * ROWS;
     const bool tfull = row0 + ROWS <= a.N;   // (wave-uniform) every row of the tile exists: see the forward
@@ -901,6 +908,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
               dO[r] = ok ? dov * og * (1.f - og) : 0.f;
               dc[c][i][r] = ok ? dcv * fg : 0.f;
             }
+            if constexpr (BSUM) { bsum[4 * c] += di; bsum[4 * c + 1] += dg; bsum[4 * c + 2] += df; bsum[4 * c + 3] += dO; }
             float* lrow = Dt + (16 * i + arow) * BP_LD + 16 * w + 4 * ag;
             *(f32x4*)(lrow) = di; *(f32x4*)(lrow + 64) = dg; *(f32x4*)(lrow + 128) = df; *(f32x4*)(lrow + 192) = dO;
             auto put = [&](auto nvc) __attribute__((always_inline)) {
@@ -927,6 +935,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
                 const float dhv = dh[i][q][r] + upw * sv.up[q][i][rs];
                 d[r] = (KPRN_BPTT_DBG & 16) ? dhv * der : ((r < nv && mk[i] != 0.f) ? dhv * der : 0.f);
               }
+              if constexpr (BSUM) bsum[q] += d;
               if (!(KPRN_BPTT_DBG & 8)) *(f32x4*)(Dt + (16 * i + arow) * BP_LD + 64 * w + 16 * q + 4 * ag) = d;   // (8: measurement -- no LDS tile writes)
               if (tfull && 64 * w + 16 * q + 16 <= H) store4d(a.dA + ((int64_t)t * a.N + row) * GH + u0, d, 4);
               else if (row < a.N && nv > 0) store4d(a.dA + ((int64_t)t * a.N + row) * GH + u0, d, nv);
@@ -988,6 +997,28 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
           if (CELL == 2) dh[i][cc] += acc[i][cc]; else dh[i][cc] = acc[i][cc];   // (gru: on top of dh z + d(r h') r)
           acc[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    }
+  }
+  if constexpr (BSUM) {
+    if (a.dbias) {
+#pragma unroll
+      for (int j = 0; j < (CELL == 0 ? 4 * NCH : 4); ++j) {
+        f32x4 v = bsum[j];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], m, 64);   // over the 16 paths (arow) of the quad's lanes
+        const int u0 = (CELL == 0) ? 64 * (j >> 2) + 16 * w + 4 * ag : 64 * w + 16 * j + 4 * ag;
+        const int col = (CELL == 0) ? (j & 3) * H + u0 : u0;
+        if (arow == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (u0 + r < H) {
+              atomicAdd(a.dbias + col + r, v[r]);
+              if (CELL == 1 && a.dbias2) atomicAdd(a.dbias2 + col + r, v[r]);
+            }
+        }
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1071,12 +1102,13 @@ bool bptt_supported(int cell, int64_t N, int H, bool force) {
   if (N < (force ? (int64_t)1 : (int64_t)ROWS * num_cus()) || (N + ROWS - 1) / ROWS >= ((int64_t)1 << 31)) return false;
   return true;
 }
+bool bptt_sums_bias(int cell, int H) { return cell == 1 || (cell == 0 && (H + 63) / 64 <= 2); }   // (FastLSTM from three chunks up and the GRU launch have no registers left for the sums)
 size_t bptt_scratch_floats(int H, int GH) { return (size_t)(H + 8) * GH + 1024; }   // W_o2g^T + zero slack behind its last row
 
 // act / cs / hs / mask: the forward's saves (generic layouts); dHup: the gradient from above ([T][N][H] when up, else the head's [N][H], applied at
 // t = T-1); Wo [GH][H]; wot: scratch of bptt_scratch_floats(); dA out [T][N][GH]
 void bptt_layer(hipStream_t s, int cell, const float* act, const float* cs, const float* hs, const float* mask, const float* dHup, bool up, const float* Wo,
-                float* wot, float* dA, int64_t N, int T, int H, int relu, const float* Uc) {
+                float* wot, float* dA, int64_t N, int T, int H, int relu, const float* Uc, float* dbias, float* dbias2) {
   const int GH = cell == 1 ? H : 4 * H;                        // floats per row of dA (gru: the record's four blocks, the last one unused)
   const int WG = cell == 2 ? 3 * H : GH;                       // floats per row of the transposed weights
   HIP_TRY(hipMemsetAsync(wot, 0, bptt_scratch_floats(H, WG) * sizeof(float), s));
@@ -1089,6 +1121,7 @@ void bptt_layer(hipStream_t s, int cell, const float* act, const float* cs, cons
   BPArgs a;
   memset(&a, 0, sizeof(a));
   a.act = act; a.cs = cs; a.hs = hs; a.mask = mask; a.dHup = dHup; a.WoT = wot; a.dA = dA; a.N = N; a.T = T; a.H = H; a.GH = GH; a.WG = WG; a.relu = relu;
+  a.dbias = bptt_sums_bias(cell, H) ? dbias : nullptr; a.dbias2 = dbias2;
   a.tiles = (N + ROWS - 1) / ROWS;
   const int nch = cell == 0 ? (H + 63) / 64 : 1;
   const int nt = cell == 0 ? nch : 4;
