@@ -772,7 +772,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       // gWo[4H,H] += dA[1..T-1]^T * h[0..T-2]
       gemm::run(s, w.dA + (int64_t)N * 4 * H, 1, 4 * H, hs, H, 1, gd + h->layer[l].Wo, H, 4 * H, H, (int64_t)(T - 1) * N, true, nullptr, split, bf);
     }
-    if (!(bptt0 && lp32::bptt_sums_bias(0, H))) {   // (the persistent BPTT launch forms the sums itself, up to two chunks)
+    if (!(bptt0 && lp32::bptt_sums_bias(0, H))) {   // (the persistent BPTT launch forms the sums itself)
       ProfScope ps(h, "bias_colsum");
       kk::col_sum_add(s, w.dA, (int64_t)T * N, 4 * H, gd + h->layer[l].bi);
     }

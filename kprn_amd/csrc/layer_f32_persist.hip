@@ -703,6 +703,16 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
   // column sums of this workgroup's dA quads (the bias gradient): per lane, reduced over the 16 lanes of a unit quad and added to the gradient once, at the end --
   // the separate sweep over dA (kernels_basic.hip k_colsum) re-read 1.2 GB per layer at dims B
   constexpr bool BSUM = (CELL == 1) || (CELL == 0 && NCH <= 2);   // (three chunks: 48 more registers spilled 500 bytes per lane)
+  // FastLSTM from three chunks up: the same sums, kept in LDS.  A part's quads are summed over its four m-tiles in registers and over the 16 lanes of a unit quad by
+  // shuffles; lane arow = 0 then adds them to ITS slots of Bs[gate][256] -- every slot has one owner for the whole launch: no atomics, no barrier -- and flushes them at the end.
+  constexpr bool BSUM_LDS = (CELL == 0 && NCH >= 3);
+  float* const Bs = (float*)(smem + (size_t)ROWS * BP_LD * 4 + (size_t)4 * BP_R * GBB);
+  if (BSUM_LDS && a.dbias && arow == 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(f32x4*)(Bs + g * 256 + 64 * c + 16 * w + 4 * ag) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   f32x4 bsum[BSUM ? (CELL == 0 ? 4 * NCH : 4) : 1];
 #pragma unroll
   for (int j = 0; j < (BSUM ? (CELL == 0 ? 4 * NCH : 4) : 1); ++j) bsum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -888,6 +898,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
         } else if constexpr (CELL == 0) {
           const int u0 = 64 * c + 16 * w + 4 * ag, nv = H - u0;
           constexpr int sh = 0;   // (quads are read where they lie: see request)
+          f32x4 ps[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // (BSUM_LDS: this part's sums over its m-tiles)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int64_t row = row0 + 16 * i + arow;
@@ -909,6 +920,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
               dc[c][i][r] = ok ? dcv * fg : 0.f;
             }
             if constexpr (BSUM) { bsum[4 * c] += di; bsum[4 * c + 1] += dg; bsum[4 * c + 2] += df; bsum[4 * c + 3] += dO; }
+            if constexpr (BSUM_LDS) { ps[0] += di; ps[1] += dg; ps[2] += df; ps[3] += dO; }
             float* lrow = Dt + (16 * i + arow) * BP_LD + 16 * w + 4 * ag;
             *(f32x4*)(lrow) = di; *(f32x4*)(lrow + 64) = dg; *(f32x4*)(lrow + 128) = df; *(f32x4*)(lrow + 192) = dO;
             auto put = [&](auto nvc) __attribute__((always_inline)) {
@@ -917,6 +929,18 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
             };
             if (tfull && 64 * c + 16 * w + 16 <= H) put(std::integral_constant<int, 4>{});
             else if (row < a.N && nv > 0) put(nv);
+          }
+          if constexpr (BSUM_LDS) {
+            if (a.dbias) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) ps[g][r] += __shfl_xor(ps[g][r], m, 64);
+                if (arow == 0) *(f32x4*)(Bs + g * 256 + u0) += ps[g];
+              }
+            }
           }
         } else {
 #pragma unroll
@@ -996,6 +1020,20 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
         for (int cc = 0; cc < NT; ++cc) {
           if (CELL == 2) dh[i][cc] += acc[i][cc]; else dh[i][cc] = acc[i][cc];   // (gru: on top of dh z + d(r h') r)
           acc[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  }
+  if constexpr (BSUM_LDS) {
+    if (a.dbias && arow == 0) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int u0 = 64 * c + 16 * w + 4 * ag;
+          const f32x4 v = *(const f32x4*)(Bs + g * 256 + u0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (u0 + r < H) atomicAdd(a.dbias + g * H + u0 + r, v[r]);
         }
     }
   }
@@ -1102,7 +1140,7 @@ bool bptt_supported(int cell, int64_t N, int H, bool force) {
   if (N < (force ? (int64_t)1 : (int64_t)ROWS * num_cus()) || (N + ROWS - 1) / ROWS >= ((int64_t)1 << 31)) return false;
   return true;
 }
-bool bptt_sums_bias(int cell, int H) { return cell == 1 || (cell == 0 && (H + 63) / 64 <= 2); }   // (FastLSTM from three chunks up and the GRU launch have no registers left for the sums)
+bool bptt_sums_bias(int cell, int H) { return cell == 0 || cell == 1; }   // (in registers; FastLSTM from three chunks up: in LDS slots; the GRU launch sweeps dA)
 size_t bptt_scratch_floats(int H, int GH) { return (size_t)(H + 8) * GH + 1024; }   // W_o2g^T + zero slack behind its last row
 
 // act / cs / hs / mask: the forward's saves (generic layouts); dHup: the gradient from above ([T][N][H] when up, else the head's [N][H], applied at
@@ -1125,7 +1163,7 @@ void bptt_layer(hipStream_t s, int cell, const float* act, const float* cs, cons
   a.tiles = (N + ROWS - 1) / ROWS;
   const int nch = cell == 0 ? (H + 63) / 64 : 1;
   const int nt = cell == 0 ? nch : 4;
-  const size_t lds = (size_t)ROWS * BP_LD * 4 + (size_t)4 * BP_R * nt * 1024;
+  const size_t lds = (size_t)ROWS * BP_LD * 4 + (size_t)4 * BP_R * nt * 1024 + 4096;   // dA chunk tile, the four waves' weight rings, the bias sums' slots
   const int grid = (int)std::min<int64_t>(a.tiles, num_cus());
   typedef void (*Kern)(BPArgs);
   Kern k = nullptr;
