@@ -624,7 +624,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
       if (bptt2) {
         // the cell backward of all T steps and both recurrent products of a step (d(r h') = d pre_n c_h2h; dh' += [d pre_r | d pre_z] o2g) in ONE launch
         ProfScope ps(h, "gru_layer_bwd");
-        lp32::bptt_layer(s, 2, act, nullptr, hs, nullptr, has_up ? w.dIn : w.dH, has_up, Wo, lp_wot_buffer(h, H, 3 * H), w.dA, N, T, H, 0, Uc);
+        lp32::bptt_layer(s, 2, act, nullptr, hs, nullptr, has_up ? w.dIn : w.dH, has_up, Wo, lp_wot_buffer(h, H, 3 * H), w.dA, N, T, H, 0, Uc, gd + h->layer[l].bi, gd + h->layer[l].bc);
       } else if (has_up) HIP_TRY(hipMemsetAsync(w.dH, 0, (size_t)N * H * sizeof(float), s));
       for (int t = T - 1; t >= 0 && !bptt2; --t) {
         float* dA_t = w.dA + (int64_t)t * N * 4 * H;
@@ -673,7 +673,7 @@ static void backward_generic(kprn_handle* h, const kprn_batch* b, int cid) {
         kk::add_into(s, gd + h->layer[l].Wi, gcat, (int64_t)2 * H * Din);
         kk::add_into(s, gd + h->layer[l].Wc, gcat + (int64_t)2 * H * Din, (int64_t)H * Din);
       }
-      {
+      if (!bptt2) {   // (the persistent BPTT launch forms the sums itself)
         ProfScope ps(h, "bias_colsum");
         kk::col_sum_add(s, w.dA, (int64_t)T * N, 2 * H, gd + h->layer[l].bi, 4 * H);
         kk::col_sum_add(s, w.dA + 2 * H, (int64_t)T * N, H, gd + h->layer[l].bc, 4 * H);

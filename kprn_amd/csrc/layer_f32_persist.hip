@@ -706,12 +706,19 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
   // FastLSTM from three chunks up: the same sums, kept in LDS.  A part's quads are summed over its four m-tiles in registers and over the 16 lanes of a unit quad by
   // shuffles; lane arow = 0 then adds them to ITS slots of Bs[gate][256] -- every slot has one owner for the whole launch: no atomics, no barrier -- and flushes them at the end.
   constexpr bool BSUM_LDS = (CELL == 0 && NCH >= 3);
+  constexpr bool BSUM_GRU = (CELL == 2);   // gru: slots Bs[0 r | 1 z | 2 n][256] (d pre_r, d pre_z -> i2g.bias; d pre_n -> c_i2h.bias = dbias2)
   float* const Bs = (float*)(smem + (size_t)ROWS * BP_LD * 4 + (size_t)4 * BP_R * GBB);
   if (BSUM_LDS && a.dbias && arow == 0) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int g = 0; g < 4; ++g) *(f32x4*)(Bs + g * 256 + 64 * c + 16 * w + 4 * ag) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (BSUM_GRU && a.dbias && arow == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) *(f32x4*)(Bs + g * 256 + 64 * w + 16 * q + 4 * ag) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   f32x4 bsum[BSUM ? (CELL == 0 ? 4 * NCH : 4) : 1];
 #pragma unroll
@@ -763,6 +770,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
             for (int q = 0; q < 4; ++q) {
               const int u0 = 64 * w + 16 * q + 4 * ag, nv = H - u0;
               constexpr int sh = 0;   // (quads are read where they lie: see request)
+              f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f}, psz = f32x4{0.f, 0.f, 0.f, 0.f};   // the quad's column sums over its m-tiles (step 0: d pre_z leaves with the first part)
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 const int64_t row = row0 + 16 * i + arow;
@@ -803,11 +811,23 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
                     }
                   }
                 }
+                ps += d;
+                if (c == 0 && t == 0) psz += dzk[q][i];
                 *(f32x4*)(Dt + (16 * i + arow) * BP_LD + 64 * w + 16 * q + 4 * ag) = d;
                 if (row < a.N && nv > 0) {   // (the uniform whole-block form of the other cells measured 1 % slower here: profiles/r06/bench_y_*)
                   float* gdst = a.dA + ((int64_t)t * a.N + row) * GH + u0;
                   store4d(gdst + col, d, nv);
                   if (t == 0) { store4d(gdst + H, dzk[q][i], nv); store4d(gdst, f32x4{0.f, 0.f, 0.f, 0.f}, nv); }
+                }
+              }
+              if (a.dbias) {   // (uniform) the bias gradient's share of this quad: over its 16 lanes, into the owner lane's LDS slots (see BSUM_LDS)
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) { ps[r] += __shfl_xor(ps[r], m, 64); if (c == 0 && t == 0) psz[r] += __shfl_xor(psz[r], m, 64); }
+                if (arow == 0) {
+                  *(f32x4*)(Bs + (c == 0 ? 2 : (c == 1 ? 0 : 1)) * 256 + u0) += ps;
+                  if (c == 0 && t == 0) *(f32x4*)(Bs + 256 + u0) += psz;
                 }
               }
             }
@@ -1037,6 +1057,20 @@ __global__ __launch_bounds__(NTHR, 1) void k_bptt(BPArgs a) {
         }
     }
   }
+  if constexpr (BSUM_GRU) {
+    if (a.dbias && arow == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const int u0 = 64 * w + 16 * q + 4 * ag;
+          const f32x4 v = *(const f32x4*)(Bs + g * 256 + u0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (u0 + r < H) atomicAdd((g < 2 ? a.dbias + g * H : a.dbias2) + u0 + r, v[r]);
+        }
+    }
+  }
   if constexpr (BSUM) {
     if (a.dbias) {
 #pragma unroll
@@ -1140,7 +1174,7 @@ bool bptt_supported(int cell, int64_t N, int H, bool force) {
   if (N < (force ? (int64_t)1 : (int64_t)ROWS * num_cus()) || (N + ROWS - 1) / ROWS >= ((int64_t)1 << 31)) return false;
   return true;
 }
-bool bptt_sums_bias(int cell, int H) { return cell == 0 || cell == 1; }   // (in registers; FastLSTM from three chunks up: in LDS slots; the GRU launch sweeps dA)
+bool bptt_sums_bias(int cell, int H) { return cell >= 0 && cell <= 2; }   // (in registers; FastLSTM from three chunks up and the GRU launch: in LDS slots)
 size_t bptt_scratch_floats(int H, int GH) { return (size_t)(H + 8) * GH + 1024; }   // W_o2g^T + zero slack behind its last row
 
 // act / cs / hs / mask: the forward's saves (generic layouts); dHup: the gradient from above ([T][N][H] when up, else the head's [N][H], applied at
